@@ -1,0 +1,201 @@
+/*
+ * rectipy_hip.h -- C ABI of the MI355X (gfx950) integration + BPTT engine.
+ *
+ * This is the drop-in boundary for ONE hot path of RectiPy: the per-step
+ * explicit-Euler recurrence of a dense recurrent population and its adjoint.
+ * Every pointer that is not marked [host] is a DEVICE pointer into HBM owned by
+ * the caller (the Python facade allocates them as torch tensors and passes
+ * `tensor.data_ptr()`); the kernels borrow them.  `stream` is a hipStream_t
+ * passed as void* (0 = default stream).  No torch types appear here.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   rp_forward        <- RateNet.forward            rectipy/nodes.py:166-170
+ *                        SpikeResetNet.forward      rectipy/nodes.py:382-392
+ *                        Spike.forward              rectipy/nodes.py:474-476
+ *                        the generated vector field neuron_model_templates/
+ *                          rate_neurons/leaky_integrator.yaml:10,22,33
+ *                          spiking_neurons/qif.yaml:11-12
+ *                        the time loop + sampling   rectipy/network.py:588-599
+ *                        the input edge             rectipy/edges.py:48-49
+ *   rp_refresh_source <- (state re-initialisation)  rectipy/nodes.py:198-211,398-401
+ *   rp_rate_backward  <- torch.autograd over the unrolled loop,
+ *                        Network._bptt_step         rectipy/network.py:1123-1130
+ *   rp_outer_accum    <- the per-step outer-product accumulation autograd does
+ *                        for `weights @ r`          (same call site)
+ *
+ * All functions return RP_OK (0) or a negative RP_ERR_* code;
+ * rp_last_error() returns a thread-local description of the last failure.
+ * The Python facade maps RP_ERR_ARG -> ValueError, RP_ERR_SHAPE -> RuntimeError
+ * (as torch raises on size mismatch, rectipy_tests/test_nodes.py:148-151).
+ *
+ * Arithmetic: fp32 storage and fp32 arithmetic, one rounding per operation,
+ * no fast-math, no contraction.  The row dot product has a FIXED summation
+ * tree that does not depend on grid size or on how rows are sharded over GPUs
+ * (see DESIGN.md "Summation order"), mirrored by oracle/rnn_oracle.c.
+ */
+#ifndef RECTIPY_HIP_H
+#define RECTIPY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RP_ABI_VERSION 1
+
+#define RP_OK 0
+#define RP_ERR_ARG (-1)      /* null pointer, bad enum, bad flag combination  */
+#define RP_ERR_SHAPE (-2)    /* inconsistent sizes / leading dimensions       */
+#define RP_ERR_ARCH (-3)     /* no gfx950 device visible                      */
+#define RP_ERR_HIP (-4)      /* HIP runtime error (text in rp_last_error)     */
+
+/* neuron models (closed table replacing the PyRates code generator for this path) */
+#define RP_MODEL_LI_TANH 0    /* leaky_integrator.yaml: li_op + tanh_op      */
+#define RP_MODEL_LI_SIGMOID 1 /* leaky_integrator.yaml: li_op + sigmoid_op   */
+#define RP_MODEL_QIF 2        /* qif.yaml: qif_op, threshold + reset         */
+
+#define RP_MAX_PARAMS 8
+#define RP_MAX_STATE 4
+
+/* parameter slots p[] (each a per-neuron vector of length `rows`) */
+#define RP_P_TAU 0
+#define RP_P_K 1
+#define RP_P_ETA 2
+#define RP_P_RMAX 3  /* LI_SIGMOID */
+#define RP_P_SLOPE 4 /* LI_SIGMOID: s */
+#define RP_P_V0 5    /* LI_SIGMOID */
+#define RP_P_TAU_S 3 /* QIF */
+
+/* state slots y[] (per-neuron vectors of length `rows`) */
+#define RP_Y_V 0
+
+/* input modes */
+#define RP_X_NONE 0  /* I_ext = 0                                             */
+#define RP_X_FULL 1  /* I_ext[i] = x[t*ldx + i]            (x is T x rows)    */
+#define RP_X_BCAST 2 /* I_ext[i] = x[t*ldx]                (x is T x 1)       */
+#define RP_X_PROJ 3  /* I_ext[i] = sum_j w_in[i*ldwin+j]*x[t*ldx+j], j<m      */
+
+/* which variable is the node output ("out" of var_map, nodes.py:67-68) */
+#define RP_OUT_STATE0 0 /* y[0]: v                                            */
+#define RP_OUT_SOURCE 1 /* the presynaptic source: r=act(v) (LI) or s (QIF)   */
+
+/*
+ * A recurrent population (one "diff_eq" node, rectipy/network.py:213-306).
+ * Rows of W are target neurons, columns are source neurons
+ * (documentation/interfaces/model_definition.py:57).  With row sharding a rank
+ * owns rows [row0, row0+rows) of the n x n matrix; per-neuron vectors are LOCAL
+ * (length rows), the two source buffers are GLOBAL (length n).
+ */
+typedef struct rp_net {
+    int32_t model;            /* RP_MODEL_*                                   */
+    int32_t n;                /* global neuron count = columns of W           */
+    int32_t rows;             /* local rows (== n when not sharded)           */
+    int32_t row0;             /* global index of local row 0                  */
+    int64_t ldw;              /* leading dimension of W in elements (>= n)    */
+    const float* W;           /* [rows x ldw] row-major                       */
+    const float* p[RP_MAX_PARAMS]; /* per-neuron parameter vectors [rows]     */
+    float* y[RP_MAX_STATE];   /* per-neuron state vectors [rows] (in/out)     */
+    float* src[2];            /* [n] presynaptic source, ping-pong (in/out)   */
+    int32_t cur;              /* [host, in/out] index of the current src      */
+    float dt;                 /* Euler step                                   */
+    float theta;              /* QIF spike threshold (nodes.py:338)           */
+    float v_reset;            /* QIF reset value     (nodes.py:338)           */
+} rp_net;
+
+/*
+ * One call = `steps` Euler steps (the body of the loop at network.py:588-599).
+ * Absolute step index of step t is step0 + t; it drives cutoff / sampling
+ * exactly as the reference does (record iff step >= cutoff and
+ * step % sampling_steps == 0, storing the mean of the buffered outputs).
+ */
+typedef struct rp_run {
+    int32_t steps;
+    int64_t step0;            /* absolute index of the first step             */
+    int32_t x_mode;           /* RP_X_*                                       */
+    int32_t m;                /* RP_X_PROJ: input dimension                   */
+    const float* x;           /* inputs, row t at x + t*ldx                   */
+    int64_t ldx;
+    const float* w_in;        /* RP_X_PROJ: [rows x ldwin]                    */
+    int64_t ldwin;
+    int32_t out_var;          /* RP_OUT_*                                     */
+    int32_t cutoff;
+    int32_t sampling_steps;   /* >= 1                                         */
+    int32_t max_samples;      /* rows available in samples / rec[]            */
+    float* traj;              /* optional [steps x ldtraj]: pre-update output */
+    int64_t ldtraj;
+    float* save_state[RP_MAX_STATE]; /* optional [steps x ldsave]: pre-update y[j] */
+    float* save_src;          /* optional [steps x ldsave]: pre-update source (local rows) */
+    float* save_acc;          /* optional [steps x ldsave]: (W @ src)_i       */
+    int64_t ldsave;
+    float* acc;               /* [rows] running sum of buffered outputs (in/out); required if samples */
+    int32_t acc_count;        /* [host, in/out] buffered outputs in acc       */
+    int32_t sample_idx;       /* [host, in/out] next sample row               */
+    float* samples;           /* optional [max_samples x ldsamples]           */
+    int64_t ldsamples;
+    float* rec[RP_MAX_STATE]; /* optional [max_samples x ldsamples]: recorded state at sample steps
+                                 (LI: post-update, network.py:147-148; QIF: pre-update, nodes.py:387-392) */
+    int32_t* spike_events;    /* optional QIF: (step, global index) int32 pairs */
+    int32_t spike_capacity;   /* number of pairs that fit                     */
+    int32_t* spike_count;     /* device counter (keeps counting past capacity) */
+} rp_run;
+
+/* Arguments of the adjoint sweep over a stored window (LI models). */
+typedef struct rp_bwd {
+    int32_t steps;            /* window length T                              */
+    const float* traj_v;      /* [T x ld] pre-update v_t (save_state[0])      */
+    const float* traj_r;      /* [T x ld] pre-update r_t (save_src)           */
+    const float* traj_acc;    /* optional [T x ld] (W r_t)_i, needed for grad_k */
+    int64_t ld;
+    int32_t grad_var;         /* RP_OUT_*: variable grad_out refers to        */
+    const float* grad_out;    /* [T x ldg] dL/d out_t                         */
+    int64_t ldg;
+    float* lam;               /* [n] adjoint state lambda (in: lambda_T, out: lambda_0 = dL/dy0) */
+    float* u_traj;            /* [T x ld] out: u_{t+1} = k * lambda_{t+1} rows (row t), feeds rp_outer_accum */
+    float* partials;          /* workspace [rp_bwd_partial_rows(n) x n]       */
+    float* grad_tau;          /* optional [n] accumulated (+=)                */
+    float* grad_k;            /* optional [n] accumulated (+=)                */
+    float* grad_eta;          /* optional [n] accumulated (+=)                */
+    float* grad_x;            /* optional [T x ldgx] dL/dI_ext,t              */
+    int64_t ldgx;
+} rp_bwd;
+
+int rp_abi_version(void);
+const char* rp_last_error(void);
+
+/* sizeof the three argument structs as compiled (lets a binding verify its layout) */
+int rp_sizeof_net(void);
+int rp_sizeof_run(void);
+int rp_sizeof_bwd(void);
+
+/* RP_OK iff HIP device `device` exists and is gfx950. */
+int rp_device_check(int device);
+
+/* src[cur][row0+i] = act(y[0][i]) for LI models (no-op for QIF, whose source is a state). */
+int rp_refresh_source(const rp_net* net, void* stream);
+
+/* `run->steps` fused Euler steps; asynchronous on `stream`. */
+int rp_forward(rp_net* net, rp_run* run, void* stream);
+
+/* Rows of the partial-sum workspace needed by rp_rate_backward for n neurons. */
+int32_t rp_bwd_partial_rows(int32_t n);
+
+/* Adjoint sweep t = T-1..0 over a stored window (unsharded LI models). */
+int rp_rate_backward(const rp_net* net, const rp_bwd* bwd, void* stream);
+
+/* C[n x n] (ldc) += alpha * A^T B with A = [T x n] (lda), B = [T x n] (ldb): MFMA f32 GEMM. */
+int rp_outer_accum(int32_t n, int32_t T, float alpha, const float* A, int64_t lda, const float* B,
+                   int64_t ldb, float* C, int64_t ldc, void* stream);
+
+/* Benchmark-only: override the streaming configuration of the tanh step kernel
+   (rows per wave, unroll depth, non-temporal W loads, grid cap); rows_per_wave = 0 restores
+   the built-in choice.  Results are bit-identical for every configuration. */
+int rp_set_tuning(int rows_per_wave, int unroll, int nontemporal, int max_blocks);
+
+/* Bandwidth probe used by bench.py: sums `bytes` of HBM with the same load shape as the step kernel. */
+int rp_stream_probe(const float* buf, int64_t n_floats, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECTIPY_HIP_H */

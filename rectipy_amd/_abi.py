@@ -1,0 +1,147 @@
+"""ctypes mirror of ``include/rectipy_hip.h`` (structs and constants only, no library loading).
+
+Field order and types must match the header exactly; ``tests/test_abi.py`` checks the
+struct sizes against the values the compiled library reports.
+"""
+import ctypes as C
+
+RP_ABI_VERSION = 1
+
+RP_OK = 0
+RP_ERR_ARG = -1
+RP_ERR_SHAPE = -2
+RP_ERR_ARCH = -3
+RP_ERR_HIP = -4
+
+RP_MODEL_LI_TANH = 0
+RP_MODEL_LI_SIGMOID = 1
+RP_MODEL_QIF = 2
+
+RP_MAX_PARAMS = 8
+RP_MAX_STATE = 4
+
+RP_P_TAU, RP_P_K, RP_P_ETA = 0, 1, 2
+RP_P_RMAX, RP_P_SLOPE, RP_P_V0 = 3, 4, 5
+RP_P_TAU_S = 3
+RP_Y_V = 0
+
+RP_X_NONE, RP_X_FULL, RP_X_BCAST, RP_X_PROJ = 0, 1, 2, 3
+RP_OUT_STATE0, RP_OUT_SOURCE = 0, 1
+
+fp = C.c_void_p  # device (HIP library) or host (oracle) float*/int32* pointers travel as integers
+
+
+class RpNet(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32),
+        ("n", C.c_int32),
+        ("rows", C.c_int32),
+        ("row0", C.c_int32),
+        ("ldw", C.c_int64),
+        ("W", fp),
+        ("p", fp * RP_MAX_PARAMS),
+        ("y", fp * RP_MAX_STATE),
+        ("src", fp * 2),
+        ("cur", C.c_int32),
+        ("dt", C.c_float),
+        ("theta", C.c_float),
+        ("v_reset", C.c_float),
+    ]
+
+
+class RpRun(C.Structure):
+    _fields_ = [
+        ("steps", C.c_int32),
+        ("step0", C.c_int64),
+        ("x_mode", C.c_int32),
+        ("m", C.c_int32),
+        ("x", fp),
+        ("ldx", C.c_int64),
+        ("w_in", fp),
+        ("ldwin", C.c_int64),
+        ("out_var", C.c_int32),
+        ("cutoff", C.c_int32),
+        ("sampling_steps", C.c_int32),
+        ("max_samples", C.c_int32),
+        ("traj", fp),
+        ("ldtraj", C.c_int64),
+        ("save_state", fp * RP_MAX_STATE),
+        ("save_src", fp),
+        ("save_acc", fp),
+        ("ldsave", C.c_int64),
+        ("acc", fp),
+        ("acc_count", C.c_int32),
+        ("sample_idx", C.c_int32),
+        ("samples", fp),
+        ("ldsamples", C.c_int64),
+        ("rec", fp * RP_MAX_STATE),
+        ("spike_events", fp),
+        ("spike_capacity", C.c_int32),
+        ("spike_count", fp),
+    ]
+
+
+class RpBwd(C.Structure):
+    _fields_ = [
+        ("steps", C.c_int32),
+        ("traj_v", fp),
+        ("traj_r", fp),
+        ("traj_acc", fp),
+        ("ld", C.c_int64),
+        ("grad_var", C.c_int32),
+        ("grad_out", fp),
+        ("ldg", C.c_int64),
+        ("lam", fp),
+        ("u_traj", fp),
+        ("partials", fp),
+        ("grad_tau", fp),
+        ("grad_k", fp),
+        ("grad_eta", fp),
+        ("grad_x", fp),
+        ("ldgx", C.c_int64),
+    ]
+
+
+def declare(lib, prefix):
+    """Attach argtypes/restypes for the entry points `<prefix>_*` that `lib` exports."""
+    P = C.POINTER
+
+    def sig(name, restype, argtypes):
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = restype
+            fn.argtypes = argtypes
+        return fn
+
+    if prefix == "rp":
+        sig("rp_abi_version", C.c_int, [])
+        sig("rp_last_error", C.c_char_p, [])
+        sig("rp_device_check", C.c_int, [C.c_int])
+        sig("rp_sizeof_net", C.c_int, [])
+        sig("rp_sizeof_run", C.c_int, [])
+        sig("rp_sizeof_bwd", C.c_int, [])
+        sig("rp_refresh_source", C.c_int, [P(RpNet), C.c_void_p])
+        sig("rp_forward", C.c_int, [P(RpNet), P(RpRun), C.c_void_p])
+        sig("rp_bwd_partial_rows", C.c_int32, [C.c_int32])
+        sig("rp_rate_backward", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
+        sig("rp_outer_accum", C.c_int,
+            [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
+        sig("rp_stream_probe", C.c_int, [fp, C.c_int64, fp, C.c_void_p])
+        sig("rp_set_tuning", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int])
+    else:
+        sig("oracle_refresh_source", C.c_int, [P(RpNet)])
+        sig("oracle_forward", C.c_int, [P(RpNet), P(RpRun)])
+        sig("oracle_rate_backward", C.c_int, [P(RpNet), P(RpBwd)])
+        sig("oracle_outer_accum", C.c_int,
+            [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64])
+        sig("oracle_expf", C.c_float, [C.c_float])
+        sig("oracle_tanhf", C.c_float, [C.c_float])
+        sig("oracle_row_dot", C.c_float, [fp, fp, C.c_int, C.c_int])
+    return lib
+
+
+EXPORTS = [
+    "rp_abi_version", "rp_last_error", "rp_device_check", "rp_sizeof_net", "rp_sizeof_run", "rp_sizeof_bwd",
+    "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_outer_accum",
+    "rp_stream_probe", "rp_set_tuning",
+]

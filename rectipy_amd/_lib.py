@@ -1,0 +1,57 @@
+"""Loader for the gfx950 C-ABI library.  There is NO fallback: if the library is missing
+or was built against a different ABI, importing compute paths fails loudly."""
+import ctypes as C
+import os
+
+from . import _abi
+
+_LIB = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "_C", "librectipy_hip.so")
+
+
+def load():
+    """Load (once) and return the ctypes handle of librectipy_hip.so."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise HipLibraryError(
+            f"{path} not found. Build it with `python -m rectipy_amd.build` (needs hipcc, no GPU). "
+            "rectipy_amd has no CPU fallback for the integration path.")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:
+        raise HipLibraryError(f"cannot load {path}: {e}") from e
+    missing = [s for s in _abi.EXPORTS if not hasattr(lib, s)]
+    if missing:
+        raise HipLibraryError(f"{path} does not export {missing}; rebuild with `python -m rectipy_amd.build --force`")
+    _abi.declare(lib, "rp")
+    if lib.rp_abi_version() != _abi.RP_ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: library {lib.rp_abi_version()}, python {_abi.RP_ABI_VERSION}")
+    for name, struct in (("rp_sizeof_net", _abi.RpNet), ("rp_sizeof_run", _abi.RpRun), ("rp_sizeof_bwd", _abi.RpBwd)):
+        if getattr(lib, name)() != C.sizeof(struct):
+            raise HipLibraryError(f"{name}() = {getattr(lib, name)()} but ctypes mirror is {C.sizeof(struct)} bytes")
+    _LIB = lib
+    return lib
+
+
+def check(rc):
+    """Map a C status code to the exception the reference would raise at this seam."""
+    if rc == _abi.RP_OK:
+        return
+    msg = load().rp_last_error().decode("utf-8", "replace")
+    if rc == _abi.RP_ERR_ARG:
+        raise ValueError(msg)
+    if rc == _abi.RP_ERR_SHAPE:
+        raise RuntimeError(msg)  # torch raises RuntimeError on size mismatch (rectipy_tests/test_nodes.py:148-151)
+    if rc == _abi.RP_ERR_ARCH:
+        raise HipLibraryError(msg)
+    raise RuntimeError(f"HIP failure: {msg}")

@@ -1,0 +1,245 @@
+// rnn_backward.hip -- hand-written adjoint (BPTT) sweep of the rate-neuron recurrence.
+//
+// Replaces torch.autograd over the unrolled loop of Network._bptt / _bptt_step
+// (reference rectipy/network.py:1028-1040, 1123-1130) for the leaky-integrator models.
+// With y_{t+1} = y_t + dt f(y_t), out_t = v_t or r_t = act(v_t), G_t = dL/d out_t:
+//
+//   u_{t+1} = k * lambda_{t+1}
+//   z       = W^T u_{t+1}                                (4 n^2 bytes of W, HBM-bound)
+//   lambda_t = lambda_{t+1} + dt (-lambda_{t+1}/tau + act'(v_t) * z) + G_t [* act'(v_t)]
+//   grad_eta += dt lambda_{t+1};  grad_k += dt lambda_{t+1} (W r_t);
+//   grad_tau += dt lambda_{t+1} v_t / tau^2;  grad_x_t = dt lambda_{t+1}
+//   grad_W  += dt u_{t+1} r_t^T   -> deferred to ONE MFMA GEMM per window (outer_gemm.hip)
+//
+// W is stored row-major and is NOT copied or transposed: the transposed product is a
+// column-strip accumulation.  A wave owns one 256-column strip (16 bytes per lane,
+// 1 KiB contiguous per row) and a chunk of RC consecutive rows, streams them with
+// non-temporal loads, scales each by the wave-uniform u_i and keeps 4 column sums per
+// lane -- no cross-lane reduction at all.  The Q = ceil(n/RC) chunk partials per
+// column are then added in chunk order by the element-wise finalize kernel, which
+// also applies the adjoint update and prepares u for the next (earlier) step.  The
+// summation order is a function of n only (mirrored in oracle/rnn_oracle.c).
+
+#include "rp_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxChunks = 32;
+
+__host__ __device__ inline int chunk_rows(int n) {  // RC(n): rows per chunk, multiple of 8
+    int rc = (n + kMaxChunks - 1) / kMaxChunks;
+    rc = (rc + 7) & ~7;
+    return rc < 8 ? 8 : rc;
+}
+
+struct BwdParams {
+    const float* W;
+    int64_t ldw;
+    int n;
+    int model;
+    const float* p[RP_MAX_PARAMS];
+    float dt;
+    int rc, q;  // rows per chunk, number of chunks
+    const float* u;  // [n] u_{t+1}
+    float* partials;  // [q x n]
+    // finalize
+    int t;
+    const float* v_t;
+    const float* r_t;
+    int grad_var;
+    const float* g_t;
+    float* lam;
+    // prep for step t-1 (null u_next => last step)
+    float* u_next;
+    const float* v_prev;
+    const float* acc_prev;
+    float* grad_tau;
+    float* grad_k;
+    float* grad_eta;
+    float* gx_prev;
+};
+
+// partials[q][j] = sum_{i in chunk q, ascending} W[i][j] * u[i]
+template <bool VEC4, int U>
+__global__ __launch_bounds__(kThreads) void wt_partial_kernel(const BwdParams P) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    constexpr int CW = VEC4 ? 256 : 64;  // columns per strip
+    const int strips = (P.n + CW - 1) / CW;
+    const int items = strips * P.q;
+    for (int item = blockIdx.x * (kThreads / 64) + wave; item < items; item += gridDim.x * (kThreads / 64)) {
+        const int strip = item % strips;
+        const int chunk = item / strips;
+        const int i0 = chunk * P.rc;
+        const int i1 = min(i0 + P.rc, P.n);
+        const float* __restrict__ u = P.u;
+        if constexpr (VEC4) {
+            const int col = strip * 256 + 4 * lane;
+            if (col < P.n) {
+                rp_f4 a = {0.f, 0.f, 0.f, 0.f};
+                const float* wp = P.W + (int64_t)i0 * P.ldw + col;
+                int i = i0;
+                for (; i + U <= i1; i += U) {
+                    rp_f4 w[U];
+                    float uu[U];
+#pragma unroll
+                    for (int k = 0; k < U; ++k) w[k] = rp_ld4_stream(wp + (int64_t)k * P.ldw);
+#pragma unroll
+                    for (int k = 0; k < U; ++k) uu[k] = u[i + k];
+#pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        a.x = fmaf(w[k].x, uu[k], a.x);
+                        a.y = fmaf(w[k].y, uu[k], a.y);
+                        a.z = fmaf(w[k].z, uu[k], a.z);
+                        a.w = fmaf(w[k].w, uu[k], a.w);
+                    }
+                    wp += (int64_t)U * P.ldw;
+                }
+                for (; i < i1; ++i) {
+                    rp_f4 w = rp_ld4_stream(wp);
+                    float uu = u[i];
+                    a.x = fmaf(w.x, uu, a.x);
+                    a.y = fmaf(w.y, uu, a.y);
+                    a.z = fmaf(w.z, uu, a.z);
+                    a.w = fmaf(w.w, uu, a.w);
+                    wp += P.ldw;
+                }
+                *reinterpret_cast<rp_f4*>(P.partials + (int64_t)chunk * P.n + col) = a;
+            }
+        } else {
+            const int col = strip * 64 + lane;
+            if (col < P.n) {
+                float a = 0.f;
+                for (int i = i0; i < i1; ++i) a = fmaf(P.W[(int64_t)i * P.ldw + col], u[i], a);
+                P.partials[(int64_t)chunk * P.n + col] = a;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float act_deriv(const BwdParams& P, int j, float r) {
+    if (P.model == RP_MODEL_LI_TANH) return 1.0f - r * r;
+    // d/dv [r_max / (1 + exp(s (v0 - v)))] = s r (1 - r / r_max)
+    return P.p[RP_P_SLOPE][j] * r * (1.0f - r / P.p[RP_P_RMAX][j]);
+}
+
+// u_next = k * lam and the per-neuron parameter gradients that pair lambda_{t+1} with step t
+__device__ __forceinline__ void prep_step(const BwdParams& P, int j, float lam) {
+    P.u_next[j] = P.p[RP_P_K][j] * lam;
+    const float dl = P.dt * lam;
+    if (P.grad_eta) P.grad_eta[j] += dl;
+    if (P.grad_k) P.grad_k[j] += dl * P.acc_prev[j];
+    if (P.grad_tau) {
+        const float tau = P.p[RP_P_TAU][j];
+        P.grad_tau[j] += dl * (P.v_prev[j] / (tau * tau));
+    }
+    if (P.gx_prev) P.gx_prev[j] = dl;
+}
+
+__global__ void prep_kernel(const BwdParams P) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < P.n) prep_step(P, j, P.lam[j]);
+}
+
+__global__ void finalize_kernel(const BwdParams P) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n) return;
+    float z = 0.f;
+    for (int c = 0; c < P.q; ++c) z = z + P.partials[(int64_t)c * P.n + j];
+    const float lam = P.lam[j];
+    const float d = act_deriv(P, j, P.r_t[j]);
+    const float g = P.g_t ? P.g_t[j] : 0.f;
+    const float gv = (P.grad_var == RP_OUT_STATE0) ? g : g * d;
+    const float lam_new = (lam + P.dt * (-lam / P.p[RP_P_TAU][j] + d * z)) + gv;
+    P.lam[j] = lam_new;
+    if (P.u_next) prep_step(P, j, lam_new);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t rp_bwd_partial_rows(int32_t n) {
+    if (n <= 0) return 0;
+    int rc = chunk_rows(n);
+    return (n + rc - 1) / rc;
+}
+
+int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
+    if (!net || !b) RP_FAIL(RP_ERR_ARG, "net/bwd is null");
+    if (net->model != RP_MODEL_LI_TANH && net->model != RP_MODEL_LI_SIGMOID)
+        RP_FAIL(RP_ERR_ARG, "rp_rate_backward supports the leaky-integrator models only (model=%d)", net->model);
+    if (net->rows != net->n || net->row0 != 0)
+        RP_FAIL(RP_ERR_ARG, "rp_rate_backward needs the unsharded matrix (rows=%d n=%d)", net->rows, net->n);
+    if (net->n <= 0 || net->ldw < net->n) RP_FAIL(RP_ERR_SHAPE, "bad n/ldw");
+    if (b->steps < 0) RP_FAIL(RP_ERR_ARG, "steps < 0");
+    if (!net->W || !b->traj_v || !b->traj_r || !b->lam || !b->u_traj || !b->partials)
+        RP_FAIL(RP_ERR_ARG, "W, traj_v, traj_r, lam, u_traj, partials must be non-null");
+    if (!net->p[RP_P_TAU] || !net->p[RP_P_K]) RP_FAIL(RP_ERR_ARG, "tau/k null");
+    if (net->model == RP_MODEL_LI_SIGMOID && (!net->p[RP_P_RMAX] || !net->p[RP_P_SLOPE]))
+        RP_FAIL(RP_ERR_ARG, "sigmoid parameters null");
+    if (b->ld < net->n) RP_FAIL(RP_ERR_SHAPE, "ld < n");
+    if (b->grad_out && b->ldg < net->n) RP_FAIL(RP_ERR_SHAPE, "ldg < n");
+    if (b->grad_x && b->ldgx < net->n) RP_FAIL(RP_ERR_SHAPE, "ldgx < n");
+    if (b->grad_k && !b->traj_acc) RP_FAIL(RP_ERR_ARG, "grad_k needs traj_acc");
+    if (b->grad_var != RP_OUT_STATE0 && b->grad_var != RP_OUT_SOURCE) RP_FAIL(RP_ERR_ARG, "bad grad_var");
+    const bool vec4 = (net->n % 4 == 0) && (net->ldw % 4 == 0);
+    if (vec4 && ((reinterpret_cast<uintptr_t>(net->W) & 15u) || (reinterpret_cast<uintptr_t>(b->partials) & 15u)))
+        RP_FAIL(RP_ERR_ARG, "W and partials must be 16-byte aligned");
+    if (b->steps == 0) return RP_OK;
+
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int n = net->n;
+    const int T = b->steps;
+    BwdParams P = {};
+    P.W = net->W;
+    P.ldw = net->ldw;
+    P.n = n;
+    P.model = net->model;
+    for (int q = 0; q < RP_MAX_PARAMS; ++q) P.p[q] = net->p[q];
+    P.dt = net->dt;
+    P.rc = chunk_rows(n);
+    P.q = (n + P.rc - 1) / P.rc;
+    P.partials = b->partials;
+    P.grad_var = b->grad_var;
+    P.lam = b->lam;
+    P.grad_tau = b->grad_tau;
+    P.grad_k = b->grad_k;
+    P.grad_eta = b->grad_eta;
+
+    const int eblocks = (n + 255) / 256;
+    const int strips = vec4 ? (n + 255) / 256 : (n + 63) / 64;
+    int mblocks = (strips * P.q + 3) / 4;
+    if (mblocks > 4096) mblocks = 4096;
+
+    auto set_prep = [&](int tp) {  // prepare u_{tp+1} (row tp of u_traj) and the grads paired with step tp
+        P.u_next = b->u_traj + (int64_t)tp * b->ld;
+        P.v_prev = b->traj_v + (int64_t)tp * b->ld;
+        P.acc_prev = b->traj_acc ? b->traj_acc + (int64_t)tp * b->ld : nullptr;
+        P.gx_prev = b->grad_x ? b->grad_x + (int64_t)tp * b->ldgx : nullptr;
+    };
+
+    set_prep(T - 1);
+    hipLaunchKernelGGL(prep_kernel, dim3(eblocks), dim3(256), 0, st, P);
+    for (int t = T - 1; t >= 0; --t) {
+        P.t = t;
+        P.u = b->u_traj + (int64_t)t * b->ld;
+        if (vec4)
+            hipLaunchKernelGGL((wt_partial_kernel<true, 8>), dim3(mblocks), dim3(kThreads), 0, st, P);
+        else
+            hipLaunchKernelGGL((wt_partial_kernel<false, 1>), dim3(mblocks), dim3(kThreads), 0, st, P);
+        P.v_t = b->traj_v + (int64_t)t * b->ld;
+        P.r_t = b->traj_r + (int64_t)t * b->ld;
+        P.g_t = b->grad_out ? b->grad_out + (int64_t)t * b->ldg : nullptr;
+        if (t > 0)
+            set_prep(t - 1);
+        else
+            P.u_next = nullptr;
+        hipLaunchKernelGGL(finalize_kernel, dim3(eblocks), dim3(256), 0, st, P);
+    }
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,538 @@
+// rnn_forward.hip -- fused Euler step of a dense recurrent population on gfx950.
+//
+// One launch = one integration step of
+//   LI   (leaky_integrator.yaml:10,22,33)  v' = -v/tau + k*(W r) + I_ext + eta, r = act(v)
+//   QIF  (qif.yaml:11-12, nodes.py:382-392) v' = (v^2+eta+I_ext)/tau + k*(W s), s' = -s/tau_s + spike/dt
+// i.e. what RateNet.forward / SpikeResetNet.forward + the PyRates-generated field
+// do with ~10 ATen ops.  The step is HBM-bound (4*n^2 bytes of W, 2*n^2 flop), so
+// the kernel is a streaming mat-vec with the element-wise field, Euler update,
+// nonlinearity / spike+reset, output sampling and trajectory stores fused into
+// the epilogue of the row that produced the dot product.
+//
+// Mapping: one 64-lane wave owns R consecutive rows.  Lane l streams columns
+// 256*m + 4*l .. +3 of each row with one 16-byte non-temporal load per row per
+// m (1 KiB per wave-instruction, fully coalesced), multiplies by the matching
+// 16 bytes of the source vector (L2-resident, shared by the R rows), and keeps
+// 4 partial sums per row.  The wave then reduces with a fixed butterfly.  The
+// summation tree per row is therefore independent of grid size, R, unrolling
+// and row sharding; oracle/rnn_oracle.c mirrors it bit for bit.
+
+#include "rp_common.h"
+
+thread_local char rp_err_buf[512] = "";
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kThreads = kWavesPerBlock * RP_WAVE;
+
+constexpr int FLAG_BUFFER = 1;  // step >= cutoff: output joins the sampling buffer
+constexpr int FLAG_SAMPLE = 2;  // record mean of the buffer at this step
+
+struct StepParams {
+    const float* W;
+    int64_t ldw;
+    int n, rows, row0;
+    const float* p[RP_MAX_PARAMS];
+    float* y[RP_MAX_STATE];
+    const float* src_cur;
+    float* src_next;
+    float dt, inv_dt, theta, v_reset;
+    int x_mode, m;
+    const float* x_t;  // row t of the input
+    const float* w_in;
+    int64_t ldwin;
+    int out_var;
+    float* traj_t;
+    float* save_state_t[RP_MAX_STATE];
+    float* save_src_t;
+    float* save_acc_t;
+    float* acc;
+    int flags;
+    float count;
+    float* sample_row;
+    float* rec_row[RP_MAX_STATE];
+    int* spike_events;
+    int spike_capacity;
+    int* spike_count;
+    int t_abs;
+};
+
+// ---- row dot products -------------------------------------------------------
+
+// 16-byte path: requires n % 4 == 0, ldw % 4 == 0, 16-byte aligned W and src.
+template <bool NT>
+__device__ __forceinline__ rp_f4 ld_w(const float* p) {
+    if constexpr (NT)
+        return rp_ld4_stream(p);
+    else
+        return rp_ld4(p);
+}
+
+template <int R, int U, bool NT>
+__device__ __forceinline__ void dot_rows_v4(const StepParams& P, int row_base, int lane,
+                                            float (&sum)[R]) {
+    const float* wrow[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        int rr = row_base + j;
+        rr = rr < P.rows ? rr : P.rows - 1;  // clamp: tail rows re-read a valid row, result discarded
+        wrow[j] = P.W + (int64_t)rr * P.ldw + 4 * lane;
+    }
+    const float* sp = P.src_cur + 4 * lane;
+    rp_f4 a[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) a[j] = rp_f4{0.f, 0.f, 0.f, 0.f};
+
+    const int M = P.n >> 8;  // full 256-column chunks
+    int m = 0;
+    for (; m + U <= M; m += U) {
+        rp_f4 rv[U];
+        rp_f4 w[U][R];
+#pragma unroll
+        for (int u = 0; u < U; ++u) rv[u] = rp_ld4(sp + (int64_t)(m + u) * 256);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < R; ++j) w[u][j] = ld_w<NT>(wrow[j] + (int64_t)(m + u) * 256);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                a[j].x = fmaf(w[u][j].x, rv[u].x, a[j].x);
+                a[j].y = fmaf(w[u][j].y, rv[u].y, a[j].y);
+                a[j].z = fmaf(w[u][j].z, rv[u].z, a[j].z);
+                a[j].w = fmaf(w[u][j].w, rv[u].w, a[j].w);
+            }
+    }
+    for (; m < M; ++m) {
+        rp_f4 rv = rp_ld4(sp + (int64_t)m * 256);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            rp_f4 w = ld_w<NT>(wrow[j] + (int64_t)m * 256);
+            a[j].x = fmaf(w.x, rv.x, a[j].x);
+            a[j].y = fmaf(w.y, rv.y, a[j].y);
+            a[j].z = fmaf(w.z, rv.z, a[j].z);
+            a[j].w = fmaf(w.w, rv.w, a[j].w);
+        }
+    }
+    if ((M << 8) + 4 * lane < P.n) {  // partial last chunk (n % 4 == 0, so all 4 columns are valid)
+        rp_f4 rv = rp_ld4(sp + (int64_t)M * 256);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            rp_f4 w = ld_w<NT>(wrow[j] + (int64_t)M * 256);
+            a[j].x = fmaf(w.x, rv.x, a[j].x);
+            a[j].y = fmaf(w.y, rv.y, a[j].y);
+            a[j].z = fmaf(w.z, rv.z, a[j].z);
+            a[j].w = fmaf(w.w, rv.w, a[j].w);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) sum[j] = rp_wave_allreduce(rp_lane_sum4(a[j]));
+}
+
+// 4-byte path for sizes / alignments the 16-byte path cannot take (small test networks).
+template <int R>
+__device__ __forceinline__ void dot_rows_s1(const StepParams& P, int row_base, int lane,
+                                            float (&sum)[R]) {
+    float a[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) a[j] = 0.f;
+    for (int col = lane; col < P.n; col += RP_WAVE) {
+        float rv = P.src_cur[col];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            int rr = row_base + j;
+            rr = rr < P.rows ? rr : P.rows - 1;
+            a[j] = fmaf(P.W[(int64_t)rr * P.ldw + col], rv, a[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) sum[j] = rp_wave_allreduce(a[j]);
+}
+
+// ---- per-neuron epilogues -----------------------------------------------------
+
+__device__ __forceinline__ float input_current(const StepParams& P, int i) {
+    switch (P.x_mode) {
+        case RP_X_FULL: return P.x_t[i];
+        case RP_X_BCAST: return P.x_t[0];
+        case RP_X_PROJ: {  // the input edge `weights @ x` (edges.py:48-49), sequential in j
+            float s = 0.f;
+            const float* wr = P.w_in + (int64_t)i * P.ldwin;
+            for (int j = 0; j < P.m; ++j) s = fmaf(wr[j], P.x_t[j], s);
+            return s;
+        }
+        default: return 0.f;
+    }
+}
+
+// running-buffer mean of the node output (network.py:590-597)
+__device__ __forceinline__ void sample_output(const StepParams& P, int i, float out) {
+    if (P.traj_t) P.traj_t[i] = out;
+    if (P.flags & FLAG_BUFFER) {
+        float a = P.acc[i] + out;
+        if (P.flags & FLAG_SAMPLE) {
+            if (P.sample_row) P.sample_row[i] = a / P.count;
+            a = 0.f;
+        }
+        P.acc[i] = a;
+    }
+}
+
+template <int MODEL>
+__device__ __forceinline__ float activation(const StepParams& P, int i, float v) {
+    if constexpr (MODEL == RP_MODEL_LI_TANH) {
+        return rp_tanhf(v);
+    } else {  // r = r_max / (1 + exp(s*(v0 - v)))   leaky_integrator.yaml:22
+        float e = rp_expf(P.p[RP_P_SLOPE][i] * (P.p[RP_P_V0][i] - v));
+        return P.p[RP_P_RMAX][i] / (1.0f + e);
+    }
+}
+
+template <int MODEL>
+__device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum) {
+    const int gi = P.row0 + i;
+    const float I = input_current(P, i);
+    if constexpr (MODEL == RP_MODEL_QIF) {
+        // SpikeResetNet.forward, nodes.py:382-392; field qif.yaml:11-12
+        const float v = P.y[RP_Y_V][i];
+        const float s = P.src_cur[gi];
+        const float spike = (v - P.theta >= 0.0f) ? 1.0f : 0.0f;  // heaviside(v-theta, 1): equality spikes
+        const float dv = ((v * v + P.p[RP_P_ETA][i]) + I) / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * wsum;
+        const float ds = -s / P.p[RP_P_TAU_S][i] + spike * P.inv_dt;
+        float v_new = v + P.dt * dv;
+        const float s_new = s + P.dt * ds;
+        v_new = v_new * (1.0f - spike) + spike * P.v_reset;
+        P.y[RP_Y_V][i] = v_new;
+        P.src_next[gi] = s_new;
+        if (P.save_state_t[0]) P.save_state_t[0][i] = v;
+        if (P.save_src_t) P.save_src_t[i] = s;
+        if (P.save_acc_t) P.save_acc_t[i] = wsum;
+        sample_output(P, i, P.out_var == RP_OUT_STATE0 ? v : s);
+        if (P.flags & FLAG_SAMPLE) {  // pre-update state (nodes.py:387-392: .y is never advanced)
+            if (P.rec_row[0]) P.rec_row[0][i] = v;
+            if (P.rec_row[1]) P.rec_row[1][i] = s;
+        }
+        if (spike != 0.0f && P.spike_count) {
+            int slot = atomicAdd(P.spike_count, 1);
+            if (slot < P.spike_capacity) {
+                P.spike_events[2 * slot] = P.t_abs;
+                P.spike_events[2 * slot + 1] = gi;
+            }
+        }
+    } else {
+        // RateNet.forward, nodes.py:166-170; field leaky_integrator.yaml:10
+        const float v = P.y[RP_Y_V][i];
+        const float dv = ((-v / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * wsum) + I) + P.p[RP_P_ETA][i];
+        const float v_new = v + P.dt * dv;
+        const float r_new = activation<MODEL>(P, i, v_new);
+        P.y[RP_Y_V][i] = v_new;
+        P.src_next[gi] = r_new;
+        if (P.save_state_t[0]) P.save_state_t[0][i] = v;
+        if (P.save_src_t) P.save_src_t[i] = P.src_cur[gi];
+        if (P.save_acc_t) P.save_acc_t[i] = wsum;
+        sample_output(P, i, P.out_var == RP_OUT_STATE0 ? v : P.src_cur[gi]);
+        if ((P.flags & FLAG_SAMPLE) && P.rec_row[0]) P.rec_row[0][i] = v_new;  // post-update (network.py:147-148)
+    }
+}
+
+template <int MODEL, int R, int U, bool VEC4, bool NT>
+__global__ __launch_bounds__(kThreads) void step_kernel(const StepParams P) {
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int groups = (P.rows + R - 1) / R;
+    for (int g = blockIdx.x * kWavesPerBlock + wave; g < groups; g += gridDim.x * kWavesPerBlock) {
+        const int row_base = g * R;
+        float sum[R];
+        if constexpr (VEC4)
+            dot_rows_v4<R, U, NT>(P, row_base, lane, sum);
+        else
+            dot_rows_s1<R>(P, row_base, lane, sum);
+        float mine = 0.f;
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (lane == j) mine = sum[j];
+        if (lane < R && row_base + lane < P.rows) epilogue<MODEL>(P, row_base + lane, mine);
+    }
+}
+
+template <int MODEL>
+__global__ void refresh_kernel(const StepParams P) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.rows) P.src_next[P.row0 + i] = activation<MODEL>(P, i, P.y[RP_Y_V][i]);
+}
+
+__global__ void stream_probe_kernel(const float* __restrict__ buf, int64_t n4, float* out) {
+    rp_f4 a = {0.f, 0.f, 0.f, 0.f};
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        rp_f4 v = rp_ld4_stream(buf + 4 * i);
+        a += v;
+    }
+    float s = rp_wave_allreduce(rp_lane_sum4(a));
+    if ((threadIdx.x & 63) == 0 && s == 12345.678f) out[0] = s;  // keep the loads live
+}
+
+// ---- host side ----------------------------------------------------------------
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int n_params_required(int model, int* idx, int cap) {
+    int c = 0;
+    idx[c++] = RP_P_TAU;
+    idx[c++] = RP_P_K;
+    idx[c++] = RP_P_ETA;
+    if (model == RP_MODEL_LI_SIGMOID) {
+        idx[c++] = RP_P_RMAX;
+        idx[c++] = RP_P_SLOPE;
+        idx[c++] = RP_P_V0;
+    } else if (model == RP_MODEL_QIF) {
+        idx[c++] = RP_P_TAU_S;
+    }
+    (void)cap;
+    return c;
+}
+
+int validate_net(const rp_net* net) {
+    if (!net) RP_FAIL(RP_ERR_ARG, "net is null");
+    if (net->model < RP_MODEL_LI_TANH || net->model > RP_MODEL_QIF)
+        RP_FAIL(RP_ERR_ARG, "unknown model id %d", net->model);
+    if (net->n <= 0 || net->rows <= 0 || net->row0 < 0 || (int64_t)net->row0 + net->rows > net->n)
+        RP_FAIL(RP_ERR_SHAPE, "bad shard: n=%d rows=%d row0=%d", net->n, net->rows, net->row0);
+    if (net->ldw < net->n) RP_FAIL(RP_ERR_SHAPE, "ldw=%lld < n=%d", (long long)net->ldw, net->n);
+    if (!net->W || !net->y[RP_Y_V] || !net->src[0] || !net->src[1])
+        RP_FAIL(RP_ERR_ARG, "W, y[0], src[0], src[1] must be non-null");
+    if (net->src[0] == net->src[1]) RP_FAIL(RP_ERR_ARG, "src[0] and src[1] must be distinct buffers");
+    if (net->cur != 0 && net->cur != 1) RP_FAIL(RP_ERR_ARG, "cur must be 0 or 1");
+    int idx[RP_MAX_PARAMS];
+    int c = n_params_required(net->model, idx, RP_MAX_PARAMS);
+    for (int q = 0; q < c; ++q)
+        if (!net->p[idx[q]]) RP_FAIL(RP_ERR_ARG, "parameter slot %d is null for model %d", idx[q], net->model);
+    if (!(net->dt > 0.f)) RP_FAIL(RP_ERR_ARG, "dt must be > 0");
+    return RP_OK;
+}
+
+bool use_vec4(const rp_net* net) { return (net->n % 4 == 0) && (net->ldw % 4 == 0); }
+
+void fill_static(StepParams& P, const rp_net* net) {
+    P.W = net->W;
+    P.ldw = net->ldw;
+    P.n = net->n;
+    P.rows = net->rows;
+    P.row0 = net->row0;
+    for (int q = 0; q < RP_MAX_PARAMS; ++q) P.p[q] = net->p[q];
+    for (int q = 0; q < RP_MAX_STATE; ++q) P.y[q] = net->y[q];
+    P.dt = net->dt;
+    P.inv_dt = 1.0f / net->dt;
+    P.theta = net->theta;
+    P.v_reset = net->v_reset;
+}
+
+// Tuning override (rp_set_tuning): 0 = use the built-in choice.
+int g_tune_R = 0, g_tune_U = 0, g_tune_nt = -1, g_tune_blocks = 0;
+
+template <int MODEL, int R, int U, bool VEC4, bool NT>
+void launch_cfg(const StepParams& P, hipStream_t st, int max_blocks) {
+    int groups = (P.rows + R - 1) / R;
+    int blocks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL((step_kernel<MODEL, R, U, VEC4, NT>), dim3(blocks), dim3(kThreads), 0, st, P);
+}
+
+// rows per wave / unroll: large networks stream 4 rows x 2 chunks per wave; small ones
+// use fewer rows per wave so that more waves share the (latency-bound) work.
+template <int MODEL, bool VEC4>
+void launch_step(const StepParams& P, hipStream_t st) {
+    const int rows = P.rows;
+    if constexpr (VEC4 && MODEL == RP_MODEL_LI_TANH) {
+        if (g_tune_R > 0) {  // benchmark-only sweep of the streaming configuration
+            const int key = g_tune_R * 100 + g_tune_U * 10 + (g_tune_nt != 0 ? 1 : 0);
+            const int mb = g_tune_blocks;
+            switch (key) {
+#define RP_CFG(R_, U_)                                                                  \
+    case R_ * 100 + U_ * 10 + 1: launch_cfg<MODEL, R_, U_, true, true>(P, st, mb); return; \
+    case R_ * 100 + U_ * 10 + 0: launch_cfg<MODEL, R_, U_, true, false>(P, st, mb); return;
+                RP_CFG(1, 2) RP_CFG(1, 4) RP_CFG(1, 8)
+                RP_CFG(2, 1) RP_CFG(2, 2) RP_CFG(2, 4)
+                RP_CFG(4, 1) RP_CFG(4, 2) RP_CFG(4, 4)
+                RP_CFG(8, 1) RP_CFG(8, 2)
+#undef RP_CFG
+                default: break;
+            }
+        }
+    }
+    if (rows >= 8192)
+        launch_cfg<MODEL, 4, 2, VEC4, true>(P, st, 2048);
+    else if (rows >= 1024)
+        launch_cfg<MODEL, 2, 2, VEC4, true>(P, st, 0);
+    else
+        launch_cfg<MODEL, 1, 2, VEC4, true>(P, st, 0);
+}
+
+template <bool VEC4>
+void launch_step_model(int model, const StepParams& P, hipStream_t st) {
+    switch (model) {
+        case RP_MODEL_LI_TANH: launch_step<RP_MODEL_LI_TANH, VEC4>(P, st); break;
+        case RP_MODEL_LI_SIGMOID: launch_step<RP_MODEL_LI_SIGMOID, VEC4>(P, st); break;
+        default: launch_step<RP_MODEL_QIF, VEC4>(P, st); break;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rp_abi_version(void) { return RP_ABI_VERSION; }
+
+const char* rp_last_error(void) { return rp_err_buf; }
+
+int rp_sizeof_net(void) { return (int)sizeof(rp_net); }
+int rp_sizeof_run(void) { return (int)sizeof(rp_run); }
+int rp_sizeof_bwd(void) { return (int)sizeof(rp_bwd); }
+
+int rp_device_check(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) RP_FAIL(RP_ERR_ARCH, "no HIP device visible (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= count) RP_FAIL(RP_ERR_ARG, "device %d out of range [0,%d)", device, count);
+    hipDeviceProp_t prop;
+    RP_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        RP_FAIL(RP_ERR_ARCH, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    return RP_OK;
+}
+
+int rp_refresh_source(const rp_net* net, void* stream) {
+    int rc = validate_net(net);
+    if (rc != RP_OK) return rc;
+    if (net->model == RP_MODEL_QIF) return RP_OK;
+    StepParams P = {};
+    fill_static(P, net);
+    P.src_next = net->src[net->cur];
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int blocks = (net->rows + 255) / 256;
+    if (net->model == RP_MODEL_LI_TANH)
+        hipLaunchKernelGGL(refresh_kernel<RP_MODEL_LI_TANH>, dim3(blocks), dim3(256), 0, st, P);
+    else
+        hipLaunchKernelGGL(refresh_kernel<RP_MODEL_LI_SIGMOID>, dim3(blocks), dim3(256), 0, st, P);
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
+int rp_forward(rp_net* net, rp_run* run, void* stream) {
+    int rc = validate_net(net);
+    if (rc != RP_OK) return rc;
+    if (!run) RP_FAIL(RP_ERR_ARG, "run is null");
+    if (run->steps < 0) RP_FAIL(RP_ERR_ARG, "steps < 0");
+    if (run->sampling_steps < 1) RP_FAIL(RP_ERR_ARG, "sampling_steps must be >= 1");
+    if (run->cutoff < 0 || run->step0 < 0) RP_FAIL(RP_ERR_ARG, "cutoff/step0 must be >= 0");
+    if (run->out_var != RP_OUT_STATE0 && run->out_var != RP_OUT_SOURCE)
+        RP_FAIL(RP_ERR_ARG, "bad out_var %d", run->out_var);
+    switch (run->x_mode) {
+        case RP_X_NONE: break;
+        case RP_X_FULL:
+            if (!run->x || run->ldx < net->rows) RP_FAIL(RP_ERR_SHAPE, "RP_X_FULL needs x with ldx >= rows");
+            break;
+        case RP_X_BCAST:
+            if (!run->x || run->ldx < 1) RP_FAIL(RP_ERR_SHAPE, "RP_X_BCAST needs x with ldx >= 1");
+            break;
+        case RP_X_PROJ:
+            if (!run->x || !run->w_in || run->m < 1 || run->ldx < run->m || run->ldwin < run->m)
+                RP_FAIL(RP_ERR_SHAPE, "RP_X_PROJ needs x (ldx >= m), w_in (ldwin >= m), m >= 1");
+            break;
+        default: RP_FAIL(RP_ERR_ARG, "bad x_mode %d", run->x_mode);
+    }
+    if (run->traj && run->ldtraj < net->rows) RP_FAIL(RP_ERR_SHAPE, "ldtraj < rows");
+    bool any_save = run->save_src || run->save_acc;
+    for (int q = 0; q < RP_MAX_STATE; ++q) any_save = any_save || run->save_state[q];
+    if (any_save && run->ldsave < net->rows) RP_FAIL(RP_ERR_SHAPE, "ldsave < rows");
+    bool any_rec = false;
+    for (int q = 0; q < RP_MAX_STATE; ++q) any_rec = any_rec || run->rec[q];
+    if ((run->samples || any_rec)) {
+        if (run->ldsamples < net->rows) RP_FAIL(RP_ERR_SHAPE, "ldsamples < rows");
+        if (!run->acc) RP_FAIL(RP_ERR_ARG, "acc buffer required when sampling");
+    }
+    if (run->spike_count && (!run->spike_events || run->spike_capacity < 0))
+        RP_FAIL(RP_ERR_ARG, "spike_count given without spike_events");
+    const bool vec4 = use_vec4(net);
+    if (vec4 && (!aligned16(net->W) || !aligned16(net->src[0]) || !aligned16(net->src[1])))
+        RP_FAIL(RP_ERR_ARG, "W and src buffers must be 16-byte aligned when n and ldw are multiples of 4");
+
+    // count the samples this call produces before touching anything
+    {
+        int64_t produced = 0;
+        for (int64_t t = run->step0; t < run->step0 + run->steps; ++t)
+            if (t >= run->cutoff && t % run->sampling_steps == 0) ++produced;
+        if ((run->samples || any_rec) && run->sample_idx + produced > run->max_samples)
+            RP_FAIL(RP_ERR_SHAPE, "sample buffers hold %d rows, call needs %lld", run->max_samples,
+                    (long long)(run->sample_idx + produced));
+    }
+
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    StepParams P = {};
+    fill_static(P, net);
+    P.x_mode = run->x_mode;
+    P.m = run->m;
+    P.w_in = run->w_in;
+    P.ldwin = run->ldwin;
+    P.out_var = run->out_var;
+    P.acc = run->acc;
+    P.spike_events = run->spike_events;
+    P.spike_capacity = run->spike_capacity;
+    P.spike_count = run->spike_count;
+
+    for (int t = 0; t < run->steps; ++t) {
+        const int64_t t_abs = run->step0 + t;
+        P.src_cur = net->src[net->cur];
+        P.src_next = net->src[net->cur ^ 1];
+        P.x_t = run->x ? run->x + (int64_t)t * run->ldx : nullptr;
+        P.traj_t = run->traj ? run->traj + (int64_t)t * run->ldtraj : nullptr;
+        for (int q = 0; q < RP_MAX_STATE; ++q)
+            P.save_state_t[q] = run->save_state[q] ? run->save_state[q] + (int64_t)t * run->ldsave : nullptr;
+        P.save_src_t = run->save_src ? run->save_src + (int64_t)t * run->ldsave : nullptr;
+        P.save_acc_t = run->save_acc ? run->save_acc + (int64_t)t * run->ldsave : nullptr;
+        P.t_abs = (int)t_abs;
+        P.flags = 0;
+        P.sample_row = nullptr;
+        for (int q = 0; q < RP_MAX_STATE; ++q) P.rec_row[q] = nullptr;
+        if (run->acc && t_abs >= run->cutoff) {
+            P.flags |= FLAG_BUFFER;
+            run->acc_count += 1;
+            if (t_abs % run->sampling_steps == 0) {
+                P.flags |= FLAG_SAMPLE;
+                P.count = (float)run->acc_count;
+                const int64_t off = (int64_t)run->sample_idx * run->ldsamples;
+                P.sample_row = run->samples ? run->samples + off : nullptr;
+                for (int q = 0; q < RP_MAX_STATE; ++q) P.rec_row[q] = run->rec[q] ? run->rec[q] + off : nullptr;
+                run->sample_idx += 1;
+                run->acc_count = 0;
+            }
+        }
+        if (vec4)
+            launch_step_model<true>(net->model, P, st);
+        else
+            launch_step_model<false>(net->model, P, st);
+        net->cur ^= 1;
+    }
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
+int rp_set_tuning(int rows_per_wave, int unroll, int nontemporal, int max_blocks) {
+    g_tune_R = rows_per_wave;
+    g_tune_U = unroll;
+    g_tune_nt = nontemporal;
+    g_tune_blocks = max_blocks;
+    return RP_OK;
+}
+
+int rp_stream_probe(const float* buf, int64_t n_floats, float* out, void* stream) {
+    if (!buf || !out || n_floats < 4 || !aligned16(buf)) RP_FAIL(RP_ERR_ARG, "bad probe arguments");
+    hipLaunchKernelGGL(stream_probe_kernel, dim3(2048), dim3(256), 0, static_cast<hipStream_t>(stream), buf,
+                       n_floats / 4, out);
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,324 @@
+"""Host-side driver of the C-ABI: owns the HBM-resident tensors of one recurrent population
+and turns window-level requests (``steps`` Euler steps, sampling, trajectory capture, adjoint
+sweep) into single calls of ``librectipy_hip.so``.
+
+PyTorch is plumbing here (device memory, streams).  All arithmetic of the hot path happens in
+the HIP kernels behind ``include/rectipy_hip.h``.
+
+``backend`` is a test seam: the product always uses :class:`HipBackend` (and refuses CPU
+tensors); tests inject an oracle-backed object with the same four methods to exercise the
+host logic (sampling bookkeeping, sharding) without a GPU.
+"""
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import RpBwd, RpNet, RpRun
+
+MODEL_IDS = {"li_tanh": _abi.RP_MODEL_LI_TANH, "li_sigmoid": _abi.RP_MODEL_LI_SIGMOID, "qif": _abi.RP_MODEL_QIF}
+
+# parameter name -> slot, per model (names follow the YAML templates of the reference)
+PARAM_SLOTS = {
+    "li_tanh": {"tau": _abi.RP_P_TAU, "k": _abi.RP_P_K, "eta": _abi.RP_P_ETA},
+    "li_sigmoid": {"tau": _abi.RP_P_TAU, "k": _abi.RP_P_K, "eta": _abi.RP_P_ETA,
+                   "r_max": _abi.RP_P_RMAX, "s": _abi.RP_P_SLOPE, "v0": _abi.RP_P_V0},
+    "qif": {"tau": _abi.RP_P_TAU, "k": _abi.RP_P_K, "eta": _abi.RP_P_ETA, "tau_s": _abi.RP_P_TAU_S},
+}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class HipBackend:
+    """Calls into librectipy_hip.so on the current HIP stream of the tensors' device."""
+    name = "hip"
+
+    def __init__(self):
+        from . import _lib
+        self._lib_mod = _lib
+        self.lib = _lib.load()
+
+    def check_device(self, device: torch.device):
+        if device.type != "cuda":
+            raise self._lib_mod.HipLibraryError(
+                f"rectipy_amd integrates on MI355X only; got device '{device}'. There is no CPU fallback.")
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        self._lib_mod.check(self.lib.rp_device_check(idx))
+
+    @staticmethod
+    def _stream(device):
+        return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def refresh_source(self, net: RpNet, device):
+        with torch.cuda.device(device):
+            self._lib_mod.check(self.lib.rp_refresh_source(C.byref(net), self._stream(device)))
+
+    def forward(self, net: RpNet, run: RpRun, device):
+        with torch.cuda.device(device):
+            self._lib_mod.check(self.lib.rp_forward(C.byref(net), C.byref(run), self._stream(device)))
+
+    def rate_backward(self, net: RpNet, bwd: RpBwd, device):
+        with torch.cuda.device(device):
+            self._lib_mod.check(self.lib.rp_rate_backward(C.byref(net), C.byref(bwd), self._stream(device)))
+
+    def outer_accum(self, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
+        with torch.cuda.device(device):
+            self._lib_mod.check(self.lib.rp_outer_accum(n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
+
+    def partial_rows(self, n):
+        return int(self.lib.rp_bwd_partial_rows(n))
+
+
+_DEFAULT_BACKEND = None
+
+
+def default_backend():
+    global _DEFAULT_BACKEND
+    if _DEFAULT_BACKEND is None:
+        _DEFAULT_BACKEND = HipBackend()
+    return _DEFAULT_BACKEND
+
+
+class Population:
+    """fp32 state of one recurrent population, resident on one device.
+
+    Parameters mirror what ``RateNet.from_pyrates`` receives (reference rectipy/nodes.py:112-164):
+    a weight matrix (rows = targets), per-neuron parameter vectors, the initial state and ``dt``.
+    With row sharding (``row0``/``n`` given) ``weights`` holds rows ``[row0, row0+rows)`` of the
+    global ``n x n`` matrix and per-neuron vectors are local.
+    """
+
+    def __init__(self, model: str, weights, params: Dict[str, object], dt: float, device,
+                 v0=None, s0=None, theta: float = 100.0, v_reset: float = -100.0,
+                 n: Optional[int] = None, row0: int = 0, backend=None):
+        if model not in MODEL_IDS:
+            raise ValueError(f"unknown model '{model}'; available: {sorted(MODEL_IDS)}")
+        self.model = model
+        self.device = torch.device(device)
+        self.backend = backend if backend is not None else default_backend()
+        self.backend.check_device(self.device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+
+        W = torch.as_tensor(weights) if not isinstance(weights, torch.Tensor) else weights
+        if W.dim() != 2:
+            raise ValueError("weights must be a 2-D matrix")
+        W = W.detach().to(**f32).contiguous()
+        self.rows = int(W.shape[0])
+        self.n = int(W.shape[1]) if n is None else int(n)
+        if W.shape[1] != self.n:
+            raise RuntimeError(f"weights has {W.shape[1]} columns, expected n={self.n}")
+        if n is None and W.shape[0] != W.shape[1]:
+            raise RuntimeError(f"recurrent weights must be square, got {tuple(W.shape)}")
+        self.row0 = int(row0)
+        if self.row0 < 0 or self.row0 + self.rows > self.n:
+            raise RuntimeError(f"shard rows [{self.row0}, {self.row0 + self.rows}) outside [0, {self.n})")
+        self.W = W
+        self.dt = float(dt)
+        self.theta = float(theta)
+        self.v_reset = float(v_reset)
+
+        self.params: Dict[str, torch.Tensor] = {}
+        for name in PARAM_SLOTS[model]:
+            if name not in params:
+                raise KeyError(f"parameter '{name}' missing for model '{model}'")
+            self.params[name] = self._vec(params[name])
+
+        self.v = self._vec(0.0 if v0 is None else v0)
+        self.src = [torch.zeros(self.n, **f32), torch.zeros(self.n, **f32)]
+        self.cur = 0
+        if model == "qif":
+            self.set_source_local(self._vec(0.0 if s0 is None else s0))
+        else:
+            self.refresh()
+        self.acc = torch.zeros(self.rows, **f32)
+        self.acc_count = 0
+        self._spike_count = None
+
+    # -- helpers -------------------------------------------------------------------------
+    def _vec(self, val) -> torch.Tensor:
+        if isinstance(val, torch.Tensor):
+            t = val.detach().to(dtype=torch.float32, device=self.device).reshape(-1)
+        else:
+            t = torch.as_tensor(np.asarray(val, dtype=np.float32), device=self.device).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(self.rows)
+        if t.numel() != self.rows:
+            raise RuntimeError(f"per-neuron vector has {t.numel()} entries, population has {self.rows}")
+        return t.contiguous().clone()
+
+    def _net(self) -> RpNet:
+        net = RpNet()
+        net.model = MODEL_IDS[self.model]
+        net.n, net.rows, net.row0 = self.n, self.rows, self.row0
+        net.ldw = self.W.stride(0)
+        net.W = self.W.data_ptr()
+        for name, slot in PARAM_SLOTS[self.model].items():
+            net.p[slot] = self.params[name].data_ptr()
+        net.y[_abi.RP_Y_V] = self.v.data_ptr()
+        net.src[0] = self.src[0].data_ptr()
+        net.src[1] = self.src[1].data_ptr()
+        net.cur = self.cur
+        net.dt = self.dt
+        net.theta = self.theta
+        net.v_reset = self.v_reset
+        return net
+
+    # -- state ---------------------------------------------------------------------------
+    @property
+    def source(self) -> torch.Tensor:
+        """Current presynaptic source vector (global length n): r = act(v) or s."""
+        return self.src[self.cur]
+
+    @property
+    def source_local(self) -> torch.Tensor:
+        return self.src[self.cur][self.row0:self.row0 + self.rows]
+
+    def set_source_local(self, val: torch.Tensor):
+        self.src[self.cur][self.row0:self.row0 + self.rows] = val
+
+    def refresh(self):
+        """Recompute the derived source r = act(v) after v was changed from the host."""
+        if self.model != "qif":
+            self.backend.refresh_source(self._net(), self.device)
+
+    def set_weights(self, W: torch.Tensor):
+        W = W.detach().to(dtype=torch.float32, device=self.device)
+        if tuple(W.shape) != (self.rows, self.n):
+            raise RuntimeError(f"weights shape {tuple(W.shape)} != {(self.rows, self.n)}")
+        self.W = W.contiguous()
+
+    def reset_sampling(self):
+        self.acc.zero_()
+        self.acc_count = 0
+
+    # -- forward -------------------------------------------------------------------------
+    def forward(self, steps: int, x: Optional[torch.Tensor] = None, w_in: Optional[torch.Tensor] = None,
+                out_var: int = _abi.RP_OUT_STATE0, step0: int = 0, cutoff: int = 0, sampling_steps: int = 1,
+                samples: Optional[torch.Tensor] = None, sample_idx: int = 0, rec: Optional[dict] = None,
+                traj: Optional[torch.Tensor] = None, save_v: Optional[torch.Tensor] = None,
+                save_src: Optional[torch.Tensor] = None, save_acc: Optional[torch.Tensor] = None,
+                spike_events: Optional[torch.Tensor] = None, spike_count: Optional[torch.Tensor] = None) -> int:
+        """Integrate ``steps`` Euler steps in one library call.  Returns the next sample index.
+
+        x: None | [steps, rows] | [steps, 1] | [steps, m] together with ``w_in`` [rows, m].
+        """
+        run = RpRun()
+        run.steps = int(steps)
+        run.step0 = int(step0)
+        keep = []  # keep converted tensors alive until the call returned
+        if x is None:
+            run.x_mode = _abi.RP_X_NONE
+        else:
+            if x.dim() != 2 or x.shape[0] < steps:
+                raise RuntimeError(f"inputs must be [steps, m] with at least {steps} rows, got {tuple(x.shape)}")
+            x = x.detach().to(dtype=torch.float32, device=self.device)
+            if x.stride(1) != 1:
+                x = x.contiguous()
+            keep.append(x)
+            run.x = x.data_ptr()
+            run.ldx = x.stride(0) if x.shape[0] > 1 else x.shape[1]
+            if w_in is not None:
+                w_in = w_in.detach().to(dtype=torch.float32, device=self.device).contiguous()
+                if tuple(w_in.shape) != (self.rows, x.shape[1]):
+                    raise RuntimeError(f"input weights {tuple(w_in.shape)} do not map {x.shape[1]} inputs to {self.rows} neurons")
+                keep.append(w_in)
+                run.x_mode, run.m = _abi.RP_X_PROJ, x.shape[1]
+                run.w_in, run.ldwin = w_in.data_ptr(), w_in.stride(0)
+            elif x.shape[1] == self.rows:
+                run.x_mode = _abi.RP_X_FULL
+            elif x.shape[1] == 1:
+                run.x_mode = _abi.RP_X_BCAST
+            else:
+                raise RuntimeError(f"input of width {x.shape[1]} does not match the {self.rows} neurons of the population")
+        run.out_var = out_var
+        run.cutoff = int(cutoff)
+        run.sampling_steps = int(sampling_steps)
+
+        def rowbuf(t, name, min_rows):
+            if t is None:
+                return None, 0
+            if t.dtype != torch.float32 or t.device != self.device or t.dim() != 2 or t.stride(1) != 1 \
+                    or t.shape[1] < self.rows or t.shape[0] < min_rows:
+                raise RuntimeError(f"{name} must be a float32 [>= {min_rows}, >= {self.rows}] row-major tensor on {self.device}")
+            return t.data_ptr(), t.stride(0)
+
+        run.traj, run.ldtraj = rowbuf(traj, "traj", steps)
+        ld_save = 0
+        for t, field in ((save_v, None), (save_src, "save_src"), (save_acc, "save_acc")):
+            p, ld = rowbuf(t, "save buffer", steps)
+            if p is not None:
+                if ld_save and ld != ld_save:
+                    raise RuntimeError("all save buffers must share one leading dimension")
+                ld_save = ld
+                if field is None:
+                    run.save_state[0] = p
+                else:
+                    setattr(run, field, p)
+        run.ldsave = ld_save
+
+        sampling = samples is not None or bool(rec)
+        if sampling:
+            run.acc = self.acc.data_ptr()
+            run.acc_count = self.acc_count
+            run.sample_idx = int(sample_idx)
+            ld_s, max_rows = 0, None
+            bufs = [("samples", samples)] + [(f"rec[{k}]", v) for k, v in (rec or {}).items()]
+            for name, t in bufs:
+                if t is None:
+                    continue
+                p, ld = rowbuf(t, name, 0)
+                if ld_s and ld != ld_s:
+                    raise RuntimeError("sample/record buffers must share one leading dimension")
+                ld_s = ld
+                max_rows = t.shape[0] if max_rows is None else min(max_rows, t.shape[0])
+            run.samples = _ptr(samples)
+            for k, t in (rec or {}).items():
+                run.rec[int(k)] = _ptr(t)
+            run.ldsamples = ld_s
+            run.max_samples = max_rows or 0
+        if spike_count is not None:
+            run.spike_events = spike_events.data_ptr()
+            run.spike_capacity = spike_events.shape[0]
+            run.spike_count = spike_count.data_ptr()
+
+        net = self._net()
+        self.backend.forward(net, run, self.device)
+        self.cur = net.cur
+        if sampling:
+            self.acc_count = run.acc_count
+        del keep
+        return int(run.sample_idx)
+
+    # -- adjoint -------------------------------------------------------------------------
+    def backward(self, traj_v, traj_r, grad_out, grad_var, lam, u_traj, traj_acc=None,
+                 grad_tau=None, grad_k=None, grad_eta=None, grad_x=None):
+        """Adjoint sweep over a stored window (see rp_rate_backward)."""
+        T = int(traj_v.shape[0])
+        b = RpBwd()
+        b.steps = T
+        b.traj_v, b.traj_r, b.traj_acc = traj_v.data_ptr(), traj_r.data_ptr(), _ptr(traj_acc)
+        b.ld = traj_v.stride(0) if T > 1 else max(traj_v.shape[1], self.n)
+        b.grad_var = grad_var
+        b.grad_out = _ptr(grad_out)
+        b.ldg = 0 if grad_out is None else (grad_out.stride(0) if T > 1 else grad_out.shape[1])
+        b.lam = lam.data_ptr()
+        b.u_traj = u_traj.data_ptr()
+        q = self.backend.partial_rows(self.n)
+        partials = torch.empty(q, self.n, dtype=torch.float32, device=self.device)
+        b.partials = partials.data_ptr()
+        b.grad_tau, b.grad_k, b.grad_eta = _ptr(grad_tau), _ptr(grad_k), _ptr(grad_eta)
+        b.grad_x = _ptr(grad_x)
+        b.ldgx = 0 if grad_x is None else (grad_x.stride(0) if T > 1 else grad_x.shape[1])
+        self.backend.rate_backward(self._net(), b, self.device)
+        return partials  # returned so the caller keeps it alive until the stream has consumed it
+
+    def outer_accum(self, alpha: float, A: torch.Tensor, B: torch.Tensor, Cmat: torch.Tensor):
+        """Cmat += alpha * A^T @ B on the matrix cores (A, B: [T, n])."""
+        T = int(A.shape[0])
+        self.backend.outer_accum(self.n, T, float(alpha), A.data_ptr(), A.stride(0) if T > 1 else A.shape[1],
+                                 B.data_ptr(), B.stride(0) if T > 1 else B.shape[1], Cmat.data_ptr(),
+                                 Cmat.stride(0), self.device)
