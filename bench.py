@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Headline benchmark: integration steps/s of an N-neuron dense tanh rate RNN on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--neurons 32768]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): N = 32768 neurons,
+W = 1.5 * randn(N, N) / sqrt(N) (generated on device in 1024-row blocks seeded by block index, so
+every sharding sees the same matrix), tau = 10, k = 1, eta = 0, v(0) = 0, dt = 1e-2, a broadcast
+sinusoidal input, sampling_steps = 100.  A "step" is one explicit-Euler step of the whole network
+(= one launch of the fused step kernel).  Inputs are resident in HBM when the timed region starts.
+
+With --gpus N > 1 the SAME network is row-sharded over N ranks (strong scaling): each rank steps its
+rows, then the ranks all-gather the new source vector over RCCL/xGMI, every step.
+
+The JSON line carries `roofline` (algorithmic bytes per launch / measured launch duration, against
+the 8 TB/s HBM peak) and, at N = 1, `cpu_baseline` (a torch-eager port of the reference's CPU loop,
+timed on this box's host cores for a bounded number of steps) plus `extra` with the fwd+bwd window.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def gen_rows(n, row0, rows, device, g=1.5, block=1024):
+    """Rows [row0, row0+rows) of the synthetic coupling matrix; identical for every sharding."""
+    W = torch.empty(rows, n, dtype=torch.float32, device=device)
+    gen = torch.Generator(device=device)
+    r = row0
+    while r < row0 + rows:
+        b0 = (r // block) * block
+        gen.manual_seed(1000 + b0 // block)
+        blk = torch.randn(min(block, n - b0), n, dtype=torch.float32, device=device, generator=gen)
+        lo, hi = r - b0, min(b0 + block, row0 + rows) - b0
+        W[r - row0:r - row0 + (hi - lo)] = blk[lo:hi]
+        r = b0 + hi
+    W.mul_(g / n ** 0.5)
+    return W
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--neurons", type=int, default=32768)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from rectipy_amd import _abi
+    from rectipy_amd.engine import Population
+
+    N, K, Wm = args.neurons, args.steps, args.warmup
+    dt = 1e-2
+    T_total = Wm + K
+    tt = torch.arange(T_total, device=dev, dtype=torch.float32) * dt
+    x = torch.sin(2 * torch.pi * 0.2 * tt).reshape(-1, 1).contiguous()
+    sampling = 100
+    n_samples = T_total // sampling + 2
+    params = dict(tau=10.0, k=1.0, eta=0.0)
+
+    if world == 1:
+        row0, rows = 0, N
+        pop = Population("li_tanh", gen_rows(N, 0, N, dev), params, dt, dev)
+        samples = torch.zeros(n_samples, N, device=dev)
+
+        def run(steps, step0, idx):
+            return pop.forward(steps, x=x[step0:step0 + steps], step0=step0, sampling_steps=sampling,
+                               samples=samples, sample_idx=idx)
+    else:
+        from rectipy_amd.sharded import ShardedPopulation, shard_bounds
+        row0, rows = shard_bounds(N, world, rank)
+        sp = ShardedPopulation("li_tanh", gen_rows(N, row0, rows, dev), params, dt, dev, n=N)
+        pop = sp.pop
+        samples = torch.zeros(n_samples, rows, device=dev)
+
+        def run(steps, step0, idx):
+            return sp.forward(steps, x=x[step0:step0 + steps], step0=step0, sampling_steps=sampling,
+                              samples=samples, sample_idx=idx)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    idx = run(Wm, 0, 0)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    idx = run(K, Wm, idx)
+    e1.record()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kernel_ms = e0.elapsed_time(e1) / K  # events on the launch stream: average step-kernel duration (+ gaps)
+    if world > 1:
+        tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+    finite = bool(torch.isfinite(pop.v).all().item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    steps_per_s = K / wall
+    # algorithmic bytes per launch: W once + per-neuron vectors (v r/w, tau, k, eta, r r/w) + input
+    algo_bytes = 4.0 * rows * N + 4.0 * (7 * rows + 1)
+    achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_step_kernel_traffic.json")
+    if world == 1 and N == 32768 and os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+    out = {
+        "metric": "integration steps/sec (fwd), N-neuron dense tanh rate RNN",
+        "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": wall / K * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"tanh rate RNN N={N} dense W fp32, forward-only Euler, dt=1e-2, sampling_steps=100, "
+                               f"broadcast sinusoid input (BASELINE.json configs[1])",
+                   "neurons": N, "rows_per_gpu": rows, "parallelism": f"row-shard x{world} + all-gather(r) per step"
+                   if world > 1 else "single GPU"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "kernel": "step_kernel<LI_TANH,R=4,U=2,vec4,nt>", "algorithmic_bytes_per_launch": algo_bytes,
+                     "avg_launch_ms": kernel_ms},
+        "state_finite": finite,
+    }
+
+    if world == 1 and not args.no_extra:
+        out["extra"] = fwd_bwd_extra(pop, x, N, dev)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(pop, x, dt, N)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def fwd_bwd_extra(pop, x, N, dev):
+    """BASELINE.json configs[2]: BPTT over a 1000-step window (forward with trajectory capture, adjoint
+    sweep, MFMA dW GEMM), MSE on a k=3 readout.  Timed with events on the launch stream."""
+    from rectipy_amd import _abi
+    T = 1000
+    f32 = dict(dtype=torch.float32, device=dev)
+    tv, tr, ut = (torch.empty(T, N, **f32) for _ in range(3))
+    gen = torch.Generator(device=dev).manual_seed(2)
+    W_out = torch.randn(3, N, generator=gen, **f32) / N ** 0.5
+    target = torch.randn(T, 3, generator=gen, **f32) * 0.1
+    gW = torch.zeros(N, N, **f32)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def window(Tw):
+        v_, r_, u_ = tv[:Tw], tr[:Tw], ut[:Tw]
+        ev[0].record()
+        pop.forward(Tw, x=x[:Tw], save_v=v_, save_src=r_)
+        ev[1].record()
+        preds = v_ @ W_out.T
+        g_out = (2.0 / preds.numel()) * (preds - target[:Tw]) @ W_out  # dL/dv_t for the MSE readout
+        lam = torch.zeros(N, **f32)
+        keep = pop.backward(v_, r_, g_out, _abi.RP_OUT_STATE0, lam, u_)
+        ev[2].record()
+        pop.outer_accum(pop.dt, u_, r_, gW)
+        ev[3].record()
+        torch.cuda.synchronize()
+        del keep
+
+    window(50)  # warm-up on a short window
+    window(T)
+    fwd, bwd, gemm = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
+    total = fwd + bwd + gemm
+    bytes_step = 4.0 * N * N
+    return {
+        "workload": "BPTT window T=1000, N=32768, MSE readout k=3 (BASELINE.json configs[2])",
+        "fwd_bwd_steps_per_s": T / (total * 1e-3),
+        "fwd_ms_per_step": fwd / T, "bwd_ms_per_step": bwd / T, "dw_gemm_ms_per_window": gemm,
+        "bwd_roofline": {"bound": "hbm", "achieved": bytes_step / (bwd / T * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": bytes_step / (bwd / T * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+        "dw_gemm_roofline": {"bound": "mfma", "achieved": 2.0 * N * N * T / (gemm * 1e-3) / 1e12, "peak": 157.3,
+                             "unit": "TFLOP/s", "frac": 2.0 * N * N * T / (gemm * 1e-3) / 1e12 / 157.3},
+        "grad_finite": bool(torch.isfinite(gW).all().item()),
+    }
+
+
+def cpu_baseline(pop, x, dt, N):
+    """Torch-eager port of the reference's per-step CPU loop on this box's host cores: 3 warm-up + 30 timed
+    steps of the same network (per-step cost is stationary; ~60 ms/step on 8 cores)."""
+    from oracle.torch_eager import time_eager
+    W = pop.W.cpu()
+    tau, k, eta = (pop.params[n].cpu() for n in ("tau", "k", "eta"))
+    v = pop.v.cpu()
+    xs = x[:64].cpu().expand(64, N).contiguous()
+    warm, timed = 3, 30
+    sps = time_eager(W, tau, k, eta, v, xs, dt, warm, timed)
+    return {"value": sps, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{warm} warm-up + {timed} timed Euler steps of the same N={N} network, torch {torch.__version__} "
+                      f"CPU eager loop (oracle/torch_eager.py), fp32, no_grad"}
+
+
+if __name__ == "__main__":
+    main()

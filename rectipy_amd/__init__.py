@@ -1,0 +1,13 @@
+"""rectipy_amd -- MI355X-native engine for RectiPy's time-stepped integration + BPTT path.
+
+Same front-end names as the reference (``rectipy/__init__.py:34``): ``Network``, ``Observer``;
+the arithmetic runs in hand-written gfx950 kernels behind the C ABI of ``include/rectipy_hip.h``.
+"""
+__version__ = "0.1.0"
+
+from .network import Network
+from .observer import Observer
+from .nodes import InstantNode, RateNet, SpikeResetNet
+from .edges import Linear
+
+__all__ = ["Network", "Observer", "RateNet", "SpikeResetNet", "InstantNode", "Linear"]

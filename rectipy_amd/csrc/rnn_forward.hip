@@ -233,7 +233,10 @@ __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum)
         if (P.save_src_t) P.save_src_t[i] = P.src_cur[gi];
         if (P.save_acc_t) P.save_acc_t[i] = wsum;
         sample_output(P, i, P.out_var == RP_OUT_STATE0 ? v : P.src_cur[gi]);
-        if ((P.flags & FLAG_SAMPLE) && P.rec_row[0]) P.rec_row[0][i] = v_new;  // post-update (network.py:147-148)
+        if (P.flags & FLAG_SAMPLE) {  // post-update values (network.py:147-148)
+            if (P.rec_row[0]) P.rec_row[0][i] = v_new;
+            if (P.rec_row[1]) P.rec_row[1][i] = r_new;
+        }
     }
 }
 

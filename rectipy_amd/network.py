@@ -1,0 +1,622 @@
+"""``Network``: the user-facing graph of nodes and edges with ``run`` / ``fit_bptt`` / ``test``,
+API-compatible with the reference's ``rectipy.Network`` (rectipy/network.py:16-1193) for the
+integration + BPTT path.
+
+What is different underneath: the reference walks the graph in Python once per Euler step
+(network.py:588-599, 962-981).  Here a chain ``[input nodes/edges] -> one diff-eq population ->
+[readout edges/nodes]`` is executed as ONE fused window on the GPU: the population's T steps are a
+single C-ABI call (rectipy_amd.engine), the input projection is folded into the step kernel, and
+the readout is applied to the sampled trajectory afterwards.  Topologies that do not match fall
+back to a per-step walk in which every diff-eq node still steps through the HIP kernels.
+"""
+from time import perf_counter
+from typing import Callable, Iterator, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from networkx import DiGraph, topological_sort
+
+from .edges import Linear
+from .nodes import InstantNode, RateNet, SpikeResetNet
+from .observer import Observer
+from .utility import add_op_name, retrieve_from_dict
+
+_OPTIMIZERS = {"sgd": torch.optim.SGD, "adam": torch.optim.Adam, "adamw": torch.optim.AdamW,
+               "adagrad": torch.optim.Adagrad, "adadelta": torch.optim.Adadelta, "adamax": torch.optim.Adamax,
+               "rmsprop": torch.optim.RMSprop, "rprop": torch.optim.Rprop}
+_LOSSES = {"mse": torch.nn.MSELoss, "l1": torch.nn.L1Loss, "nll": torch.nn.NLLLoss, "ce": torch.nn.CrossEntropyLoss,
+           "kld": torch.nn.KLDivLoss, "hinge": torch.nn.HingeEmbeddingLoss}
+
+_WINDOW_BYTES = 2 << 30  # cap for [T, N] staging buffers of one fused call
+
+
+class Network:
+    """Graph of diff-eq populations, activation nodes and linear edges (reference network.py:16-44)."""
+
+    def __init__(self, dt: float, device: str = "cuda:0", dtype: torch.dtype = torch.float32, backend=None):
+        self.graph = DiGraph()
+        self.device = device
+        self.dtype = dtype
+        self.dt = dt
+        self._backend = backend  # test seam, see rectipy_amd.engine
+        self._var_map = {}
+        self._in_node = None
+        self._out_node = None
+        self._order: List[str] = []
+        self._train_edge = ()
+
+    # ---- container protocol -------------------------------------------------------------
+    def __getitem__(self, item):
+        if isinstance(item, tuple):
+            return self.graph[item[0]][item[1]]
+        return self.graph.nodes[item]
+
+    def __iter__(self):
+        for n in self.graph.nodes:
+            yield self[n]
+
+    def __len__(self):
+        return len(self.graph.nodes)
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    @property
+    def n_out(self) -> int:
+        return self[self._out_node]["n_out"] if self._out_node is not None else 0
+
+    @property
+    def n_in(self) -> int:
+        return self[self._in_node]["n_in"] if self._in_node is not None else 0
+
+    @property
+    def nodes(self):
+        return self.graph.nodes
+
+    @property
+    def state(self) -> dict:
+        """State vectors of all diff-eq nodes (live tensors, as the reference: network.py:88-98)."""
+        return {n: self.get_node(n).y for n in self.nodes if hasattr(self.get_node(n), "y")}
+
+    def get_node(self, node: str):
+        return self[node]["node"]
+
+    def get_edge(self, source: str, target: str) -> Linear:
+        return self[source, target]["edge"]
+
+    def get_var(self, node: str, var: str):
+        try:
+            return self.get_node(node)[self._relabel_var(var)]
+        except KeyError:
+            return self[node][var]
+
+    def set_var(self, node: str, var: str, val):
+        try:
+            n = self.get_node(node)
+            try:
+                n.set_param(self._relabel_var(var), val)
+            except KeyError:
+                with torch.no_grad():
+                    n[self._relabel_var(var)][:] = torch.as_tensor(val)
+                if hasattr(n, "_pop"):
+                    n._pop.refresh()
+        except KeyError:
+            raise KeyError(f"Variable {var} was not found on node {node}.")
+
+    # ---- construction ---------------------------------------------------------------------
+    def add_node(self, label: str, node, node_type: str, op: str = None, **node_attrs) -> None:
+        """Add any object that follows the node protocol (reference network.py:178-211)."""
+        if op:
+            for p in getattr(node, "parameter_names", []):
+                add_op_name(op, p, self._var_map)
+            for v in getattr(node, "variable_names", []):
+                add_op_name(op, v, self._var_map)
+        self.graph.add_node(label, node=node, node_type=node_type, n_out=node.n_out, n_in=node.n_in, eval=True,
+                            out=None, **node_attrs)
+
+    def add_diffeq_node(self, label: str, node: str, input_var: str, output_var: str, weights: np.ndarray = None,
+                        source_var: str = None, target_var: str = None, spike_var: Union[str, list] = None,
+                        reset_var: Union[str, list] = None, reset: bool = True, op: str = None,
+                        train_params: list = None, **kwargs) -> RateNet:
+        """Add a population defined by a built-in template (signature of reference network.py:213-216).
+
+        ``op`` shorthand: bare variable names get ``<op>/`` prefixed, as the reference does
+        (network.py:262-285)."""
+        names = {"svar": source_var, "tvar": target_var, "in_ext": input_var, "out": output_var, "spike": spike_var,
+                 "reset": reset_var}
+        record_vars = kwargs.pop("record_vars", None)
+        self._var_map = {}
+        if op is not None:
+            for key, var in list(names.items()):
+                names[key] = [add_op_name(op, v, self._var_map) for v in var] if isinstance(var, list) \
+                    else add_op_name(op, var, self._var_map)
+            if record_vars:
+                record_vars = [add_op_name(op, v, self._var_map) for v in record_vars]
+            if train_params:
+                train_params = [add_op_name(op, p, self._var_map) for p in train_params]
+            if "node_vars" in kwargs:
+                kwargs["node_vars"] = {(k if "/" in k else f"all/{op}/{k}"): v for k, v in kwargs["node_vars"].items()}
+        if record_vars:
+            kwargs["var_mapping"] = {v: v for v in record_vars}
+        kwargs.setdefault("device", self.device)
+        kwargs.setdefault("dt", self.dt)
+        if self._backend is not None:
+            kwargs.setdefault("backend", self._backend)
+        common = dict(weights=weights, source_var=names["svar"], target_var=names["tvar"], train_params=train_params)
+        if spike_var is None:
+            new = RateNet.from_pyrates(node, names["in_ext"], names["out"], **common, **kwargs)
+        elif reset_var is None:
+            raise ValueError("To define a reservoir with a spiking neural network layer, please provide the "
+                             "name of the variable that should be reset after a spike occurred (`reset_var`).")
+        elif not reset:
+            raise NotImplementedError("reset=False (in-equation reset, the reference's SpikeNet) is not supported; "
+                                      "the reference's own implementation of it is broken (nodes.py:323-330)")
+        else:
+            new = SpikeResetNet.from_pyrates(node, names["in_ext"], names["out"], spike_var=names["spike"],
+                                             reset_var=names["reset"], **common, **kwargs)
+        self.add_node(label, node=new, node_type="diff_eq", op=op)
+        return new
+
+    def add_func_node(self, label: str, n: int, activation_function: str, **kwargs) -> InstantNode:
+        kwargs.pop("node_type", None)
+        node = InstantNode(n, activation_function, **kwargs)
+        self.add_node(label, node=node, node_type="func_instant")
+        return node
+
+    def add_edge(self, source: str, target: str, weights=None, train: Optional[str] = None,
+                 edge_attrs: dict = None, **kwargs) -> Linear:
+        """Linear projection source -> target (reference network.py:340-401); `train` in {None, 'gd'}."""
+        for unsupported in ("mask", "delays", "filter_weights"):
+            if unsupported in kwargs:
+                raise NotImplementedError(f"edge option '{unsupported}' (Linear{unsupported.title()} edges) is out of scope")
+        kwargs.update(n_in=self[source]["n_out"], n_out=self[target]["n_in"], weights=weights, dtype=self.dtype)
+        if train is None:
+            edge = Linear(**kwargs, detach=True)
+        elif train == "gd":
+            edge = Linear(**kwargs, detach=False)
+        elif train == "rls":
+            raise NotImplementedError("recursive-least-squares edges are out of scope of the BPTT path")
+        else:
+            raise ValueError("Invalid option for keyword argument `train`. Valid options: None, 'gd'.")
+        edge_device = self.device if self._backend is None else "cpu"
+        self.graph.add_edge(source, target, edge=edge.to(edge_device), trainable=train is not None, n_in=edge.n_in,
+                            n_out=edge.n_out, **(edge_attrs or {}))
+        return edge
+
+    def pop_node(self, node: str):
+        data = self.get_node(node)
+        self.graph.remove_node(node)
+        return data
+
+    def pop_edge(self, source: str, target: str) -> Linear:
+        edge = self.get_edge(source, target)
+        self.graph.remove_edge(source, target)
+        return edge
+
+    def clear(self):
+        for node in list(self.nodes):
+            self.pop_node(node)
+
+    def compile(self):
+        """Find the unique input / output node and an evaluation order (reference network.py:439-460)."""
+        in_nodes = [n for n in self.graph.nodes if self.graph.in_degree(n) == 0]
+        if len(in_nodes) != 1:
+            raise ValueError(f"Unable to identify the input node of the Network. Nodes that have no input edges: "
+                             f"{in_nodes}. Make sure that exactly one such node exists in the network.")
+        out_nodes = [n for n in self.graph.nodes if self.graph.out_degree(n) == 0]
+        if len(out_nodes) != 1:
+            raise ValueError(f"Unable to identify the output node of the Network. Nodes that have no outgoing edges: "
+                             f"{out_nodes}. Make sure that exactly one such node exists in the network.")
+        self._in_node, self._out_node = in_nodes[0], out_nodes[0]
+        self._order = list(topological_sort(self.graph))
+
+    # ---- per-step evaluation (drop-in for user loops) ----------------------------------------
+    def forward(self, x) -> torch.Tensor:
+        """One step through the whole graph (reference network.py:462-478)."""
+        if not self._order:
+            self.compile()
+        for n in self._order:
+            preds = list(self.graph.predecessors(n))
+            if preds:
+                inp = None
+                for p in preds:
+                    contrib = self.get_edge(p, n).forward(self[p]["out"])
+                    inp = contrib if inp is None else inp + contrib
+            else:
+                inp = x
+            self[n]["out"] = self.get_node(n).forward(inp)
+        return self[self._out_node]["out"]
+
+    def parameters(self, recurse: bool = True) -> Iterator:
+        for n in self.graph.nodes:
+            for p in self.get_node(n).parameters(recurse=recurse):
+                yield p
+        for s, t in self.graph.edges:
+            for p in self.get_edge(s, t).parameters():
+                yield p
+
+    def detach(self, requires_grad: bool = True, detach_params: bool = False) -> None:
+        for n in self.nodes:
+            node = self.get_node(n)
+            if hasattr(node, "y"):
+                node.detach(requires_grad=requires_grad, detach_params=detach_params)
+
+    def reset(self, state: dict = None):
+        for n in self.nodes:
+            node = self.get_node(n)
+            if hasattr(node, "y"):
+                if state and n in state:
+                    node.reset(y=state[n])
+                else:
+                    node.reset()
+
+    # ---- fused-window planning ------------------------------------------------------------------
+    def _chain_plan(self):
+        """(pre, rnn_label, post) when the graph is a simple chain around ONE diff-eq node whose other
+        members are element-wise activation nodes and plain Linear edges; else None."""
+        order = self._order
+        if any(self.graph.in_degree(n) > 1 or self.graph.out_degree(n) > 1 for n in order):
+            return None
+        diffeq = [n for n in order if self[n]["node_type"] == "diff_eq"]
+        if len(diffeq) != 1 or not isinstance(self.get_node(diffeq[0]), RateNet):
+            return None
+        for n in order:
+            node = self.get_node(n)
+            if n != diffeq[0] and not (isinstance(node, InstantNode) and node.name in InstantNode.elementwise):
+                return None
+        for s, t in self.graph.edges:
+            if type(self.get_edge(s, t)) is not Linear:
+                return None
+        i = order.index(diffeq[0])
+        return order[:i], diffeq[0], order[i + 1:]
+
+    def _apply_chain(self, labels: List[str], X: Optional[torch.Tensor], entry: Optional[str], exit_to: Optional[str]):
+        """Apply activation nodes + the edges between them to a whole [T, m] batch.  `entry` is the node
+        feeding labels[0] (None: X is the external input); `exit_to` the node after labels[-1]."""
+        prev = entry
+        for lab in labels:
+            if prev is not None:
+                X = self.get_edge(prev, lab).forward(X)
+            X = self.get_node(lab).forward(X)
+            prev = lab
+        if exit_to is not None and prev is not None:
+            X = self.get_edge(prev, exit_to).forward(X)
+        return X
+
+    def _to_input(self, inputs) -> torch.Tensor:
+        dev = self.device if self._backend is None else "cpu"
+        if isinstance(inputs, np.ndarray):
+            inputs = torch.tensor(inputs, device=dev, dtype=torch.float32)
+        inputs = inputs.to(device=dev, dtype=torch.float32)
+        if inputs.dim() == 1:
+            inputs = inputs.reshape(-1, 1)
+        return inputs
+
+    @staticmethod
+    def _sample_steps(steps: int, cutoff: int, sampling_steps: int, start: int = 0) -> List[int]:
+        return [t for t in range(start, start + steps) if t >= cutoff and t % sampling_steps == 0]
+
+    # ---- simulation ---------------------------------------------------------------------------
+    def run(self, inputs: Union[np.ndarray, torch.Tensor], sampling_steps: int = 1, cutoff: int = 0,
+            verbose: bool = True, enable_grad: bool = True, **kwargs) -> Observer:
+        """Integrate the input-driven network (signature and recording semantics of reference
+        network.py:542-601): steps below `cutoff` are computed but not buffered; a sample is taken when
+        ``step >= cutoff and step % sampling_steps == 0`` and stores the MEAN of the outputs buffered
+        since the previous sample; recorded state variables are the values right after that step."""
+        inputs = self._to_input(inputs)
+        steps = inputs.shape[0]
+        truncate_steps = kwargs.pop("truncate_steps", steps)
+        self.compile()
+        if "obs" in kwargs:
+            obs = kwargs.pop("obs")
+        else:
+            obs = Observer(dt=self.dt, record_loss=kwargs.pop("record_loss", False), **kwargs)
+        rec_vars = list(obs.recorded_state_variables)
+        plan = self._chain_plan()
+        if plan is not None and all(v[0] == plan[1] for v in rec_vars):
+            rnn = self.get_node(plan[1])
+            slots = self._record_slots(rnn, rec_vars)
+            if slots is not None:
+                with (torch.enable_grad() if enable_grad else torch.no_grad()):
+                    self._run_fused(plan, inputs, sampling_steps, cutoff, truncate_steps, obs, slots, verbose)
+                return obs
+        self._run_stepwise(inputs, sampling_steps, cutoff, truncate_steps, obs, rec_vars, enable_grad, verbose)
+        return obs
+
+    def _record_slots(self, rnn: RateNet, rec_vars) -> Optional[List[int]]:
+        """Kernel record slot of each requested variable of the population (0: first state variable,
+        1: source r / s), or None if one of them is not recordable in-kernel."""
+        slots = []
+        state_names = [s for s, _ in rnn._template.state]
+        for _, var in rec_vars:
+            name = self._relabel_var(var)
+            if name == state_names[0]:
+                slots.append(0)
+            elif name == rnn._template.source_var:
+                slots.append(1)
+            else:
+                return None
+        return slots
+
+    def _wants_grad(self, plan, inputs) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        if inputs.requires_grad or any(p.requires_grad for p in self.parameters()):
+            return True
+        return self.get_node(plan[1])._wants_grad(None)
+
+    def _run_fused(self, plan, inputs, sampling_steps, cutoff, truncate_steps, obs: Observer, slots, verbose):
+        pre, label, post = plan
+        rnn: RateNet = self.get_node(label)
+        pop = rnn._pop
+        N, dev, T = pop.rows, pop.device, inputs.shape[0]
+        sample_at = self._sample_steps(T, cutoff, sampling_steps)
+        S = len(sample_at)
+        exit_to = post[0] if post else None
+        linear_post = all(self.get_node(n).name == "identity" for n in post)
+        grad = self._wants_grad(plan, inputs) and not isinstance(rnn, SpikeResetNet)
+
+        if grad:
+            # autograd path: the population's window is one autograd node, everything around it is torch
+            outs, recs = [], [[] for _ in slots]
+            for a in range(0, T, truncate_steps):
+                b = min(a + truncate_steps, T)
+                X = self._apply_chain(pre, inputs[a:b], None, label) if pre else inputs[a:b]
+                traj = rnn._grad_window(b - a, self._fit_width(X, N))
+                outs.append(self._apply_chain(post, traj, label, None) if post else traj)
+                if slots:
+                    tv, tr = rnn._last_window
+                    for j, slot in enumerate(slots):  # post-update values: row t+1, last row = current state
+                        src = tv if slot == 0 else tr
+                        last = pop.v if slot == 0 else pop.source_local
+                        recs[j].append(torch.cat((src[1:], last.detach().reshape(1, -1))))
+                if truncate_steps < T and b - a == truncate_steps:
+                    self.detach()
+            per_step = torch.cat(outs)
+            rows, start = [], cutoff
+            for t in sample_at:  # mean over the steps buffered since the previous sample (network.py:595)
+                rows.append(per_step[start:t + 1].mean(dim=0))
+                start = t + 1
+            outputs = torch.stack(rows) if rows else per_step[:0]
+            rec_out = [torch.cat(r)[sample_at] for r in recs]
+            obs.record_block(sample_at, outputs, 0.0, rec_out)
+            return
+
+        # no-grad path: sampling happens inside the step kernel
+        w_in, X, x_chunked = None, None, False
+        if pre:
+            if len(pre) == 1 and self.get_node(pre[0]).name == "identity" and inputs.shape[1] <= 64:
+                w_in, X = self.get_edge(pre[0], label).weights, inputs  # projection folded into the kernel
+            else:
+                x_chunked = True
+        else:
+            X = self._fit_width(inputs, N)
+        pop.reset_sampling()
+        f32 = dict(dtype=torch.float32, device=dev)
+        rec_bufs = {slot: torch.empty(S, N, **f32) for slot in set(slots)}
+        chunk = max(1, min(T, _WINDOW_BYTES // (4 * N)))
+        if linear_post:
+            samples = torch.empty(S, N, **f32)
+            idx = 0
+            for a in range(0, T, chunk):
+                b = min(a + chunk, T)
+                Xc = self._fit_width(self._apply_chain(pre, inputs[a:b], None, label), N) if x_chunked else \
+                    (None if X is None else X[a:b])
+                idx = rnn.run_window(b - a, x=Xc, w_in=w_in, step0=a, cutoff=cutoff, sampling_steps=sampling_steps,
+                                     samples=samples, rec=rec_bufs, sample_idx=idx)
+                if verbose:
+                    print(f"Progress: {b}/{T} integration steps finished.")
+            outputs = self._apply_chain(post, samples, label, None) if post else samples
+        else:
+            # a non-linear readout does not commute with the buffer mean: read out every step, then average
+            rows, pending, start, idx = [], [], cutoff, 0
+            for a in range(0, T, chunk):
+                b = min(a + chunk, T)
+                Xc = self._fit_width(self._apply_chain(pre, inputs[a:b], None, label), N) if x_chunked else \
+                    (None if X is None else X[a:b])
+                traj = torch.empty(b - a, N, **f32)
+                idx = rnn.run_window(b - a, x=Xc, w_in=w_in, step0=a, cutoff=cutoff, sampling_steps=sampling_steps,
+                                     traj=traj, rec=rec_bufs, sample_idx=idx)
+                pending.append(self._apply_chain(post, traj, label, None))
+            per_step = torch.cat(pending)
+            for t in sample_at:
+                rows.append(per_step[start:t + 1].mean(dim=0))
+                start = t + 1
+            outputs = torch.stack(rows) if rows else per_step[:0]
+        obs.record_block(sample_at, outputs, 0.0, [rec_bufs[s] for s in slots])
+
+    @staticmethod
+    def _fit_width(X: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
+        if X is not None and X.shape[1] not in (1, n):
+            raise RuntimeError(f"The size of the input ({X.shape[1]}) must match the number of neurons ({n}) or be 1")
+        return X
+
+    def _run_stepwise(self, inputs, sampling_steps, cutoff, truncate_steps, obs, rec_vars, enable_grad, verbose):
+        """Generic topologies: the reference's loop (network.py:586-599), one graph walk per step."""
+        steps = inputs.shape[0]
+        buffer = []
+        with (torch.enable_grad() if enable_grad else torch.no_grad()):
+            for step in range(steps):
+                output = self.forward(inputs[step, :])
+                if step >= cutoff:
+                    buffer.append(output)
+                    if step % sampling_steps == 0:
+                        if verbose:
+                            print(f"Progress: {step}/{steps} integration steps finished.")
+                        obs.record(step, torch.mean(torch.stack(buffer, dim=0), dim=0), 0.0,
+                                   [self.get_var(v[0], v[1]) for v in rec_vars])
+                        buffer = []
+                if truncate_steps < steps and step % truncate_steps == truncate_steps - 1:
+                    self.detach()
+
+    # ---- training -------------------------------------------------------------------------------
+    def fit_bptt(self, inputs: Union[np.ndarray, list], targets: Union[np.ndarray, list], optimizer: str = "sgd",
+                 optimizer_kwargs: dict = None, loss: str = "mse", loss_kwargs: dict = None, lr: float = 1e-3,
+                 sampling_steps: int = 1, update_steps: int = 100, verbose: bool = True, **kwargs) -> Observer:
+        """Backpropagation through time (signature of reference network.py:603-707).
+
+        array inputs: windows of `update_steps` steps -- forward window, loss on the window's predictions,
+        ``zero_grad / backward / step``, detach (network.py:1028-1040).  list inputs: one update per epoch
+        on the sampled outputs of ``run`` and a state reset afterwards (network.py:983-1014)."""
+        self.compile()
+        loss_fn = self._get_loss_function(loss, loss_kwargs)
+        opt = self._get_optimizer(optimizer, lr, self.parameters(), optimizer_kwargs)
+        step_kwargs = retrieve_from_dict(["closure"], kwargs)
+        error_kwargs = retrieve_from_dict(["retain_graph"], kwargs)
+        obs = Observer(dt=self.dt, **retrieve_from_dict(["record_output", "record_loss", "record_vars"], kwargs))
+        t0 = perf_counter()
+        if isinstance(inputs, list):
+            if len(inputs) != len(targets):
+                raise ValueError("Wrong dimensions of input and target output. Please make sure that `inputs` and "
+                                 "`targets` agree in the first dimension (epochs).")
+            obs = self._bptt_epochs(inputs, targets, loss_fn, opt, obs, error_kwargs, step_kwargs, sampling_steps,
+                                    verbose, **kwargs)
+        else:
+            inp = self._to_input(inputs)
+            tgt = torch.as_tensor(targets).to(device=inp.device, dtype=torch.float32)
+            if inp.shape[0] != tgt.shape[0]:
+                raise ValueError("Wrong dimensions of input and target output. Please make sure that `inputs` and "
+                                 "`targets` agree in the first dimension.")
+            obs = self._bptt(inp, tgt, loss_fn, opt, obs, error_kwargs, step_kwargs, sampling_steps, update_steps,
+                             verbose)
+        print(f"Finished optimization after {perf_counter() - t0} s.")
+        return obs
+
+    @staticmethod
+    def _bptt_step(predictions, targets, optimizer, loss, error_kwargs, step_kwargs) -> float:
+        error = loss(predictions, targets)
+        optimizer.zero_grad()
+        error.backward(**error_kwargs)
+        optimizer.step(**step_kwargs)
+        return error.item()
+
+    def _bptt(self, inp, target, loss, optimizer, obs: Observer, error_kwargs, step_kwargs, sampling_steps,
+              optim_steps, verbose) -> Observer:
+        plan = self._chain_plan()
+        rec_vars = list(obs.recorded_state_variables)
+        steps = inp.shape[0]
+        if plan is None or rec_vars or isinstance(self.get_node(plan[1]), SpikeResetNet):
+            return self._bptt_stepwise(inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps,
+                                       optim_steps, verbose)
+        pre, label, post = plan
+        rnn: RateNet = self.get_node(label)
+        N = rnn._pop.rows
+        error = 0.0
+        for a in range(0, steps, optim_steps):
+            b = min(a + optim_steps, steps)
+            with torch.enable_grad():
+                X = self._apply_chain(pre, inp[a:b], None, label) if pre else inp[a:b]
+                traj = rnn._grad_window(b - a, self._fit_width(X, N)) if self._wants_grad(plan, X) else \
+                    self._nograd_traj(rnn, b - a, self._fit_width(X, N))
+                preds = self._apply_chain(post, traj, label, None) if post else traj
+                prev_error = error
+                if b - a == optim_steps:  # only complete windows trigger an update (network.py:1035)
+                    error = self._bptt_step(preds, target[a:b], optimizer, loss, error_kwargs, step_kwargs)
+                    self.detach()
+            sample_at = [t for t in range(a, b) if t % sampling_steps == 0]
+            if sample_at:
+                # the loss recorded at a step is that of the last COMPLETED window at that step (network.py:1043-1046)
+                losses = [error if (t == b - 1 and b - a == optim_steps) else prev_error for t in sample_at]
+                obs.record_block(sample_at, preds.detach()[[t - a for t in sample_at]], losses, [])
+                if verbose:
+                    print(f"Progress: {sample_at[-1]}/{steps} training steps finished. Current loss: {error}.")
+        return obs
+
+    @staticmethod
+    def _nograd_traj(rnn: RateNet, steps: int, X):
+        traj = torch.empty(steps, rnn._pop.rows, dtype=torch.float32, device=rnn._pop.device)
+        rnn.run_window(steps, x=X, traj=traj)
+        return traj
+
+    def _bptt_stepwise(self, inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps,
+                       optim_steps, verbose) -> Observer:
+        rec_vars = list(obs.recorded_state_variables)
+        steps, error, predictions, old_step = inp.shape[0], 0.0, [], 0
+        for step in range(steps):
+            pred = self.forward(inp[step, :])
+            predictions.append(pred)
+            if step % optim_steps == optim_steps - 1:
+                error = self._bptt_step(torch.stack(predictions), target[old_step:step + 1], optimizer, loss,
+                                        error_kwargs, step_kwargs)
+                self.detach()
+                old_step = step + 1
+                predictions.clear()
+            if step % sampling_steps == 0:
+                if verbose:
+                    print(f"Progress: {step}/{steps} training steps finished. Current loss: {error}.")
+                obs.record(step, pred.detach(), error, [self.get_var(v[0], v[1]) for v in rec_vars])
+        return obs
+
+    def _bptt_epochs(self, inp: list, target: list, loss, optimizer, obs, error_kwargs, step_kwargs,
+                     sampling_steps: int = 1, verbose: bool = False, **kwargs) -> Observer:
+        y0 = {k: v.detach().clone() for k, v in self.state.items()}
+        epoch_losses = []
+        for epoch in range(len(inp)):
+            obs = self.run(inp[epoch], verbose=False, sampling_steps=sampling_steps, enable_grad=True, **kwargs)
+            tgt = torch.as_tensor(target[epoch]).to(device=obs.stacked("out").device, dtype=torch.float32)
+            epoch_loss = self._bptt_step(obs.stacked("out"), tgt, optimizer, loss, error_kwargs, step_kwargs)
+            epoch_losses.append(epoch_loss)
+            self.reset(y0)
+            if verbose:
+                print(f"Progress: {epoch + 1}/{len(inp)} training epochs finished.\nEpoch loss: {epoch_loss}.\n")
+        obs.save("epoch_loss", epoch_losses)
+        obs.save("epochs", np.arange(len(inp)))
+        return obs
+
+    def test(self, inputs: np.ndarray, targets: np.ndarray, loss: str = "mse", loss_kwargs: dict = None,
+             sampling_steps: int = 100, verbose: bool = True, **kwargs) -> tuple:
+        """Run with frozen parameters and evaluate the loss (reference network.py:898-944)."""
+        loss_fn = self._get_loss_function(loss, loss_kwargs)
+        obs = self.run(inputs=inputs, sampling_steps=sampling_steps, verbose=verbose, enable_grad=False, **kwargs)
+        output = obs.stacked("out")
+        tgt = torch.as_tensor(targets).to(device=output.device, dtype=output.dtype)
+        return obs, loss_fn(output, tgt).item()
+
+    def fit_ridge(self, inputs: np.ndarray, targets: np.ndarray, sampling_steps: int = 100, alpha: float = 1e-4,
+                  verbose: bool = True, add_readout_node: bool = True, **kwargs) -> Observer:
+        """Ridge-regression readout on the collected states (reference network.py:709-784)."""
+        if np.shape(inputs)[0] != np.shape(targets)[0]:
+            raise ValueError("Wrong dimensions of input and target output. Please make sure that `inputs` and "
+                             "`targets` agree in the first dimension.")
+        self.compile()
+        t0 = perf_counter()
+        obs = self.run(inputs=inputs, sampling_steps=sampling_steps, verbose=verbose, enable_grad=False, **kwargs)
+        print(f"Finished network state collection after {perf_counter() - t0} s.")
+        t0 = perf_counter()
+        X = obs.stacked("out")
+        Y = torch.as_tensor(targets).to(device=X.device, dtype=X.dtype)
+        if Y.shape[0] != X.shape[0]:
+            Y = Y[obs["steps"]]
+        eye = torch.eye(X.shape[1], device=X.device, dtype=X.dtype)
+        w_out = torch.linalg.solve(X.T @ X + alpha * eye, X.T @ Y)
+        y = X @ w_out
+        print(f"Finished fitting of read-out weights after {perf_counter() - t0} s.")
+        if add_readout_node:
+            out_node = self._out_node
+            self.add_func_node("readout", n=w_out.shape[1], activation_function="identity")
+            self.add_edge(out_node, target="readout", weights=w_out.T)
+        obs.save("y", y)
+        obs.save("w_out", w_out)
+        return obs
+
+    def fit_rls(self, *args, **kwargs):
+        raise NotImplementedError("recursive-least-squares training is out of scope of the integration + BPTT path")
+
+    def fit_eprop(self, *args, **kwargs):
+        raise NotImplementedError("Method is currently not implemented")  # as in the reference (network.py:896)
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def _relabel_var(self, var: str) -> str:
+        return self._var_map.get(var, var)
+
+    @staticmethod
+    def _get_optimizer(optimizer: str, lr: float, model_params: Iterator, optimizer_kwargs: dict = None):
+        if optimizer not in _OPTIMIZERS:
+            raise ValueError(f"Invalid optimizer choice '{optimizer}'. Valid options: {sorted(_OPTIMIZERS)}.")
+        return _OPTIMIZERS[optimizer](model_params, lr=lr, **(optimizer_kwargs or {}))
+
+    @staticmethod
+    def _get_loss_function(loss: str, loss_kwargs: dict = None) -> Callable:
+        if loss not in _LOSSES:
+            raise ValueError(f"Invalid loss function choice '{loss}'. Valid options: {sorted(_LOSSES)}.")
+        return _LOSSES[loss](**(loss_kwargs or {}))

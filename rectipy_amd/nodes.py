@@ -1,0 +1,522 @@
+"""Node classes of the MI355X engine, mirroring the node protocol of the reference
+(rectipy/nodes.py): ``forward(x)``, ``y``, ``n_in``, ``n_out``, ``parameters()``,
+``detach()``, ``reset()``, ``set_param()``, ``__getitem__``, ``parameter_names``,
+``variable_names``.
+
+``RateNet`` / ``SpikeResetNet`` here do not wrap a Python vector-field callable: they own a
+:class:`rectipy_amd.engine.Population` whose Euler step, nonlinearity, spike/reset and
+adjoint run in hand-written gfx950 kernels.  A whole window of T steps is one library call
+(``run_window``); ``forward(x)`` is the T = 1 case kept for drop-in per-step loops.
+State and arithmetic are float32 (the reference defaults the node state to float64,
+rectipy/nodes.py:59,120 -- documented difference).
+"""
+import warnings
+from typing import Iterator, List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import _abi
+from .engine import PARAM_SLOTS, Population
+from .templates import Template, resolve
+
+_warned_f64 = False
+
+
+def _warn_f64(dtype):
+    global _warned_f64
+    if dtype is torch.float64 and not _warned_f64:
+        warnings.warn("rectipy_amd integrates in float32 on the GPU; a float64 node state was requested "
+                      "(the reference's default) and is held as float32.", stacklevel=3)
+        _warned_f64 = True
+
+
+class InstantNode:
+    """Memory-less activation node (reference rectipy/nodes.py:14-51)."""
+
+    _funcs = {
+        "tanh": lambda kw: torch.nn.Tanh(),
+        "sigmoid": lambda kw: torch.nn.Sigmoid(),
+        "identity": lambda kw: torch.nn.Identity(),
+        "softmax": lambda kw: torch.nn.Softmax(dim=kw.get("dim", 0)),
+        "softmin": lambda kw: torch.nn.Softmin(dim=kw.get("dim", 0)),
+        "log_softmax": lambda kw: torch.nn.LogSoftmax(dim=kw.get("dim", 0)),
+    }
+    elementwise = ("tanh", "sigmoid", "identity")
+
+    def __init__(self, n: int, func: str, **kwargs):
+        if func not in self._funcs:
+            raise ValueError(f"Invalid keyword argument `func`: {func} is not a valid option "
+                             f"(choose from {sorted(self._funcs)}).")
+        self.n_in = n
+        self.n_out = n
+        self.name = func
+        self.func = self._funcs[func](kwargs)
+
+    def __getitem__(self, item):
+        return None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.func(x)
+
+    def parameters(self, **kwargs):
+        return self.func.parameters(**kwargs)
+
+
+class _RateWindow(torch.autograd.Function):
+    """T Euler steps of a leaky-integrator population as ONE autograd node.
+
+    forward  = rp_forward with the pre-update v_t, r_t (and W r_t) rows captured,
+    backward = rp_rate_backward (adjoint sweep) + rp_outer_accum (MFMA dW GEMM).
+    Replaces autograd over the Python-unrolled loop (reference rectipy/network.py:1028-1040).
+    """
+
+    @staticmethod
+    def forward(ctx, node, steps, x, v_in, W, tau, k, eta):
+        pop: Population = node._pop
+        N, dev = pop.rows, pop.device
+        need_acc = k.requires_grad
+        traj_v = torch.empty(steps, N, dtype=torch.float32, device=dev)
+        traj_r = torch.empty(steps, N, dtype=torch.float32, device=dev)
+        traj_acc = torch.empty(steps, N, dtype=torch.float32, device=dev) if need_acc else None
+        pop.forward(steps, x=x, save_v=traj_v, save_src=traj_r, save_acc=traj_acc)
+        ctx.node = node
+        ctx.steps = steps
+        ctx.x_width = None if x is None else x.shape[1]
+        ctx.saved = (traj_v, traj_r, traj_acc)
+        node._last_window = (traj_v, traj_r)
+        out = traj_r if node._out_code == _abi.RP_OUT_SOURCE else traj_v
+        return out.clone(), pop.v.clone()
+
+    @staticmethod
+    def backward(ctx, g_traj, g_vend):
+        node = ctx.node
+        pop: Population = node._pop
+        N, dev, T = pop.rows, pop.device, ctx.steps
+        traj_v, traj_r, traj_acc = ctx.saved
+        f32 = dict(dtype=torch.float32, device=dev)
+        lam = torch.zeros(N, **f32) if g_vend is None else g_vend.detach().to(**f32).clone().contiguous()
+        g_out = None if g_traj is None else g_traj.detach().to(**f32).contiguous()
+        need = ctx.needs_input_grad  # (node, steps, x, v_in, W, tau, k, eta)
+        u_traj = torch.empty(T, N, **f32)
+        g_tau = torch.zeros(N, **f32) if need[5] else None
+        g_k = torch.zeros(N, **f32) if need[6] else None
+        g_eta = torch.zeros(N, **f32) if need[7] else None
+        g_x = torch.empty(T, N, **f32) if need[2] else None
+        keep = pop.backward(traj_v, traj_r, g_out, node._out_code, lam, u_traj, traj_acc=traj_acc,
+                            grad_tau=g_tau, grad_k=g_k, grad_eta=g_eta, grad_x=g_x)
+        g_W = None
+        if need[4]:
+            g_W = torch.zeros(N, N, **f32)
+            pop.outer_accum(pop.dt, u_traj, traj_r, g_W)
+        if g_x is not None and ctx.x_width == 1:
+            g_x = g_x.sum(dim=1, keepdim=True)
+        del keep
+        return None, None, g_x, (lam if need[3] else None), g_W, g_tau, g_k, g_eta
+
+
+class RateNet:
+    """Rate-neuron population integrated on the GPU (reference ``RateNet``, rectipy/nodes.py:54-290)."""
+
+    state_vars = ["y"]
+    _spiking = False
+
+    # ---- construction ----------------------------------------------------------------
+    def __init__(self, template: Template, weights, node_vars: dict, input_var: str, output_var: str,
+                 dt: float = 1e-3, dtype: torch.dtype = torch.float64, train_params: list = None,
+                 device: str = "cuda:0", backend=None, **kwargs):
+        _warn_f64(dtype)
+        self._template = template
+        self.dt = dt
+        self.device = device
+        state_names = [s for s, _ in template.state]
+
+        # initial state and parameters: YAML defaults overridden by node_vars ("all/<op>/<var>": value)
+        values = dict(template.params)
+        values.update(dict(template.state))
+        for key, val in (node_vars or {}).items():
+            parts = key.split("/")
+            if len(parts) == 3 and parts[0] != "all":
+                raise NotImplementedError(f"node_vars key '{key}': only 'all/<op>/<var>' (optionally with per-neuron "
+                                          "vectors as values) is supported")
+            name = "/".join(parts[-2:])
+            if name not in values:
+                raise KeyError(f"Variable {name} was not found on template '{template.name}'.")
+            values[name] = val
+        if weights is None:
+            raise ValueError("the dense-recurrence engine needs the `weights` matrix of the population")
+        eng_params = {template.engine_names[p]: values[p] for p, _ in template.params}
+        kw = {}
+        if self._spiking:
+            kw = dict(v0=values[state_names[0]], s0=values[state_names[1]],
+                      theta=kwargs.pop("spike_threshold", 1e2), v_reset=kwargs.pop("spike_reset", -1e2))
+        else:
+            kw = dict(v0=values[state_names[0]])
+        self._pop = Population(template.model, weights, eng_params, dt, device, backend=backend, **kw)
+        N = self._pop.rows
+        self.n_in = N
+        self.n_out = N
+
+        # name maps (the reference builds them from PyRates' key lists, nodes.py:150-159)
+        self._param_map = {"weights": "weights"}
+        for p, _ in template.params:
+            self._param_map[p] = template.engine_names[p]
+        for key, var in (kwargs.pop("param_mapping", None) or {}).items():
+            if var in self._param_map:
+                self._param_map[key] = self._param_map[var]
+        self._var_map = {name: (i * N, (i + 1) * N) for i, name in enumerate(state_names)}
+        if input_var != template.input_var:
+            if input_var in self._param_map or input_var in self._var_map or input_var == template.target_var:
+                raise NotImplementedError(f"input_var='{input_var}': the kernels add extrinsic input to "
+                                          f"'{template.input_var}' only")
+            raise KeyError(f"Variable {input_var} was not found on template '{template.name}'.")
+        if output_var in self._var_map:
+            self._out_code = _abi.RP_OUT_STATE0 if output_var == state_names[0] else _abi.RP_OUT_SOURCE
+        elif output_var in template.derived:
+            self._out_code = _abi.RP_OUT_SOURCE
+        else:
+            raise KeyError(f"Variable {output_var} was not found on template '{template.name}'.")
+        self._out_name = output_var
+        self._var_map["out"] = self._var_map.get(output_var, (0, N))
+        for key, var in (kwargs.pop("var_mapping", None) or {}).items():
+            if var in self._var_map:
+                self._var_map[key] = self._var_map[var]
+            elif var not in template.derived:
+                raise KeyError(f"Variable {var} was not found on template '{template.name}'.")
+
+        # trainable parameters
+        self._train_names: List[str] = []
+        for p in (train_params or []):
+            if p not in self._param_map:
+                raise KeyError(f"Parameter {p} was not found on the node.")
+            self._train_names.append(self._param_map[p])
+        self._check_trainable()
+        for name in self._train_names:
+            self._tensor(name).requires_grad_(True)
+        self._y_grad: Optional[torch.Tensor] = None  # autograd handle of the state (same values as pop.v)
+        self._y_requires_grad = len(self._train_names) >= 1  # nodes.py:89-90
+
+    def _check_trainable(self):
+        ok = {"weights", "tau", "k", "eta"}
+        bad = [n for n in self._train_names if n not in ok]
+        if bad:
+            raise NotImplementedError(f"no adjoint kernel for parameters {bad}; trainable: {sorted(ok)}")
+
+    @classmethod
+    def from_pyrates(cls, node, input_var: str, output_var: str, weights: np.ndarray = None,
+                     source_var: str = None, target_var: str = None, train_params: list = None, **kwargs):
+        """Build a population from a template path -- the signature of the reference's
+        ``RateNet.from_pyrates`` (rectipy/nodes.py:112-164).  ``node`` must name one of the built-in
+        templates (:mod:`rectipy_amd.templates`); PyRates itself is not used."""
+        template = resolve(node)
+        dt = kwargs.pop("dt", 1e-3)
+        dtype = kwargs.pop("dtype", torch.float64)
+        device = kwargs.pop("device", "cuda:0")
+        for ignored in ("clear", "verbose", "file_name", "float_precision"):
+            kwargs.pop(ignored, None)
+        for unsupported in ("edge_attr", "edge_template"):
+            if kwargs.pop(unsupported, None) is not None:
+                raise NotImplementedError(f"'{unsupported}' (edge operators on recurrent connections) is not supported")
+        if weights is None:
+            n = kwargs.pop("N", None)
+            if n is None:
+                raise ValueError("either `weights` or `N` must be given")
+            weights = np.zeros((n, n), dtype=np.float32)
+        else:
+            kwargs.pop("N", None)
+            if source_var is None or target_var is None:
+                raise ValueError("If synaptic weights are passed (`weights`), please provide the names of the source "
+                                 "and target variable that should be connected via `weights`.")
+            known = {s for s, _ in template.state} | set(template.derived) | {p for p, _ in template.params} | \
+                {template.input_var, template.target_var}
+            for v in (source_var, target_var):
+                if v not in known:
+                    raise KeyError(f"Variable {v} was not found on template '{template.name}'.")
+            if source_var != template.source_var or target_var != template.target_var:
+                raise NotImplementedError(
+                    f"recurrent coupling {source_var} -> {target_var} has no kernel; the '{template.name}' kernel "
+                    f"couples {template.source_var} -> {template.target_var}")
+        node_vars = kwargs.pop("node_vars", None)
+        return cls(template, weights, node_vars, input_var, output_var, dt=dt, dtype=dtype,
+                   train_params=train_params, device=device, **kwargs)
+
+    # ---- name access -------------------------------------------------------------------
+    def _tensor(self, engine_name: str) -> torch.Tensor:
+        return self._pop.W if engine_name == "weights" else self._pop.params[engine_name]
+
+    def __getitem__(self, item):
+        if item in self._param_map:
+            return self._tensor(self._param_map[item])
+        if item in self._template.derived:
+            return self._pop.source_local
+        lo, hi = self._var_map[item]  # KeyError for unknown names, as the reference (test_nodes.py:78-79)
+        return self.y[lo:hi]
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    @property
+    def parameter_names(self) -> list:
+        return list(self._param_map.keys())
+
+    @property
+    def variable_names(self) -> list:
+        return list(self._var_map.keys())
+
+    @property
+    def train_params(self) -> list:
+        return [self._tensor(n) for n in self._train_names]
+
+    def parameters(self, recurse: bool = True) -> Iterator:
+        for p in self.train_params:
+            yield p
+
+    def set_param(self, param: str, val: Union[torch.Tensor, float]):
+        if param not in self._param_map:
+            raise KeyError(f"Parameter {param} was not found on the node.")
+        name = self._param_map[param]
+        old = self._tensor(name)
+        with torch.no_grad():
+            if name == "weights":
+                new = torch.as_tensor(val, dtype=torch.float32, device=old.device)
+                if tuple(new.shape) != tuple(old.shape):
+                    raise RuntimeError(f"weights shape {tuple(new.shape)} != {tuple(old.shape)}")
+                old.copy_(new)
+            else:
+                old.copy_(self._pop._vec(val))
+
+    # ---- state --------------------------------------------------------------------------
+    @property
+    def y(self) -> torch.Tensor:
+        """State vector.  Live view of the device state (the reference also hands out the live tensor,
+        network.py:96); carries the autograd history of the current window when one is being recorded."""
+        if self._y_grad is None and self._y_requires_grad:
+            self._y_grad = self._pop.v.detach().clone().requires_grad_(True)
+        return self._pop.v if self._y_grad is None else self._y_grad
+
+    def detach(self, requires_grad: bool = False, detach_params: bool = False):
+        """Cut the autograd history of the state (reference nodes.py:176-196)."""
+        self._y_grad = None
+        self._y_requires_grad = requires_grad
+        if detach_params:
+            for name in self._train_names:
+                self._tensor(name).requires_grad_(requires_grad)
+
+    def reset(self, y: Union[np.ndarray, torch.Tensor] = None, idx: np.ndarray = None):
+        """Set the state (cloned, reference nodes.py:198-211); ``idx`` resets a subset."""
+        pop = self._pop
+        with torch.no_grad():
+            if y is None:
+                new = torch.zeros_like(pop.v)
+            else:
+                new = torch.as_tensor(y).detach().to(dtype=torch.float32, device=pop.device).reshape(-1).clone()
+            if idx is None:
+                if new.numel() != pop.v.numel():
+                    raise RuntimeError(f"state has {pop.v.numel()} entries, got {new.numel()}")
+                pop.v.copy_(new)
+            else:
+                index = torch.as_tensor(np.asarray(idx), dtype=torch.long, device=pop.device)
+                if index.numel() != new.numel() or (index.numel() and int(index.max()) >= pop.v.numel()):
+                    raise RuntimeError("index/value size mismatch in reset")
+                pop.v[index] = new
+        self._y_grad = None
+        pop.refresh()
+        pop.reset_sampling()
+
+    # ---- integration --------------------------------------------------------------------
+    def _as_input(self, x, steps=None) -> Optional[torch.Tensor]:
+        if x is None:
+            return None
+        if not isinstance(x, torch.Tensor):
+            if isinstance(x, np.ndarray):
+                raise RuntimeError("node inputs must be torch tensors (the reference raises here as well)")
+            x = torch.tensor([float(x)], dtype=torch.float32)
+        x = x.to(device=self._pop.device, dtype=torch.float32)
+        if steps is None:  # single step: 0-d or 1-d
+            x = x.reshape(1, -1)
+        if x.dim() != 2:
+            raise RuntimeError(f"inputs must be [steps, m], got {tuple(x.shape)}")
+        if x.shape[1] not in (1, self._pop.rows):
+            raise RuntimeError(f"The size of the input ({x.shape[1]}) must match the number of neurons "
+                               f"({self._pop.rows}) or be 1")
+        return x
+
+    def _wants_grad(self, x) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        if any(self._tensor(n).requires_grad for n in self._train_names):
+            return True
+        if x is not None and x.requires_grad:
+            return True
+        return self._y_grad is not None and self._y_grad.requires_grad
+
+    def _grad_window(self, steps: int, x: Optional[torch.Tensor]) -> torch.Tensor:
+        """`steps` Euler steps recorded as one autograd node; returns the [steps, N] output trajectory."""
+        pop = self._pop
+        v_in = self._y_grad
+        if v_in is None:
+            v_in = pop.v.detach().clone().requires_grad_(self._y_requires_grad)
+        traj, v_end = _RateWindow.apply(self, steps, x, v_in, pop.W, pop.params["tau"], pop.params["k"],
+                                        pop.params["eta"])
+        self._y_grad = v_end
+        return traj
+
+    def forward(self, x) -> torch.Tensor:
+        """One Euler step; returns the PRE-update output slice (reference nodes.py:166-170)."""
+        x2 = self._as_input(x)
+        if self._wants_grad(x2):
+            return self._grad_window(1, x2)[0]
+        out = torch.empty(1, self._pop.rows, dtype=torch.float32, device=self._pop.device)
+        self._pop.forward(1, x=x2, traj=out, out_var=self._out_code)
+        self._y_grad = None
+        return out[0]
+
+    def run_window(self, steps: int, x: Optional[torch.Tensor] = None, w_in: Optional[torch.Tensor] = None,
+                   **kw):
+        """Fused multi-step integration without autograd (see Population.forward for kwargs)."""
+        self._y_grad = None
+        return self._pop.forward(steps, x=x, w_in=w_in, out_var=self._out_code, **kw)
+
+
+class SpikeResetNet(RateNet):
+    """Spiking population with threshold + reset (reference ``SpikeResetNet``, rectipy/nodes.py:333-401).
+
+    The state vector is cat(v, s).  As in the reference, ``y`` / ``__getitem__`` expose the state
+    BEFORE the most recent step (nodes.py:387-392 never advances ``self.y``), while the current state
+    lives in the population (``v``, ``s``).
+    """
+
+    state_vars = ["_y_start", "_y_spike", "_y_stop"]
+    _spiking = True
+
+    def __init__(self, template: Template, weights, node_vars, input_var, output_var, spike_var: str = None,
+                 reset_var: str = None, **kwargs):
+        if not template.spike_var:
+            raise ValueError(f"template '{template.name}' is not a spiking model")
+        def same(name, full):  # accept '<op>/<var>' and the bare variable name
+            return name == full or name == full.split("/")[-1]
+
+        if spike_var is not None and not same(spike_var, template.spike_var):
+            raise KeyError(f"Variable {spike_var} was not found on template '{template.name}' as a spike input.")
+        if reset_var is not None and not same(reset_var, template.reset_var):
+            raise NotImplementedError(f"reset_var='{reset_var}': the kernel resets '{template.reset_var}'")
+        kwargs.pop("spike_center", None)  # Spike.center is 1.0 in every use of the reference (x == 0 spikes)
+        self._spike_slope = kwargs.pop("spike_slope", None)
+        super().__init__(template, weights, node_vars, input_var, output_var, **kwargs)
+        N = self._pop.rows
+        self._var_map["reset_var"] = self._var_map[template.reset_var]
+        self._param_map["spike_var"] = "spike"
+        self._y_prev = None  # pre-update state of the last step
+        self.spike_events: Optional[torch.Tensor] = None
+        self._spike_count: Optional[torch.Tensor] = None
+        if self._train_names:
+            raise NotImplementedError("surrogate-gradient BPTT through spiking populations has no gfx950 kernel yet")
+
+    @classmethod
+    def from_pyrates(cls, node, input_var: str, output_var: str, weights: np.ndarray = None,
+                     source_var: str = None, target_var: str = None, spike_var: str = "spike",
+                     reset_var: str = "v", train_params: list = None, **kwargs):
+        if isinstance(spike_var, list):
+            raise NotImplementedError("multiple spike/reset variable pairs (MultiSpikeResetNet) are out of scope")
+        kwargs["spike_var"] = spike_var
+        kwargs["reset_var"] = reset_var
+        return super().from_pyrates(node, input_var, output_var, weights=weights, source_var=source_var,
+                                    target_var=target_var, train_params=train_params, **kwargs)
+
+    def _check_trainable(self):
+        pass
+
+    def _tensor(self, engine_name: str) -> torch.Tensor:
+        if engine_name == "spike":
+            raise KeyError("the spike input is internal to the fused kernel")
+        return super()._tensor(engine_name)
+
+    @property
+    def y(self) -> torch.Tensor:
+        if self._y_prev is not None:
+            return self._y_prev
+        return torch.cat((self._pop.v, self._pop.source_local))
+
+    @property
+    def current_state(self) -> torch.Tensor:
+        """cat(v, s) after the last step (what the reference keeps in _y_start/_y_spike/_y_stop)."""
+        return torch.cat((self._pop.v, self._pop.source_local))
+
+    def enable_spike_recording(self, capacity: int):
+        """Allocate a device buffer for (step, neuron) spike events."""
+        dev = self._pop.device
+        self.spike_events = torch.zeros(capacity, 2, dtype=torch.int32, device=dev)
+        self._spike_count = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def spikes(self) -> np.ndarray:
+        """Recorded events sorted by (step, neuron); raises if the buffer overflowed."""
+        if self._spike_count is None:
+            raise RuntimeError("call enable_spike_recording() first")
+        count = int(self._spike_count.item())
+        if count > self.spike_events.shape[0]:
+            raise RuntimeError(f"spike buffer overflow: {count} events, capacity {self.spike_events.shape[0]}")
+        ev = self.spike_events[:count].cpu().numpy()
+        return ev[np.lexsort((ev[:, 1], ev[:, 0]))]
+
+    def detach(self, requires_grad: bool = False, detach_params: bool = False):
+        pass
+
+    def reset(self, y=None, idx=None):
+        pop = self._pop
+        N = pop.rows
+        with torch.no_grad():
+            cur = torch.cat((pop.v, pop.source_local)) if self._y_prev is None else self._y_prev.clone()
+            if y is None:
+                new = torch.zeros(2 * N, dtype=torch.float32, device=pop.device)
+            else:
+                new = torch.as_tensor(y).detach().to(dtype=torch.float32, device=pop.device).reshape(-1).clone()
+            if idx is None:
+                if new.numel() != 2 * N:
+                    raise RuntimeError(f"state has {2 * N} entries, got {new.numel()}")
+                cur = new
+            else:
+                index = torch.as_tensor(np.asarray(idx), dtype=torch.long, device=pop.device)
+                cur[index] = new
+            pop.v.copy_(cur[:N])
+            pop.set_source_local(cur[N:])
+        self._y_prev = None
+        pop.reset_sampling()
+
+    def _wants_grad(self, x) -> bool:
+        return False
+
+    def forward(self, x) -> torch.Tensor:
+        x2 = self._as_input(x)
+        pop = self._pop
+        N = pop.rows
+        out = torch.empty(1, N, dtype=torch.float32, device=pop.device)
+        sv = torch.empty(1, N, dtype=torch.float32, device=pop.device)
+        ss = torch.empty(1, N, dtype=torch.float32, device=pop.device)
+        pop.forward(1, x=x2, traj=out, save_v=sv, save_src=ss, out_var=self._out_code,
+                    spike_events=self.spike_events, spike_count=self._spike_count)
+        self._y_prev = torch.cat((sv[0], ss[0]))
+        return out[0]
+
+    def run_window(self, steps: int, x=None, w_in=None, **kw):
+        """Fused window; the last step is issued separately so that ``y`` can expose its pre-update state."""
+        pop = self._pop
+        N = pop.rows
+        kw.setdefault("spike_events", self.spike_events)
+        kw.setdefault("spike_count", self._spike_count)
+        step0 = kw.pop("step0", 0)
+        idx = kw.pop("sample_idx", 0)
+
+        def rows(t, a, b):
+            return None if t is None else t[a:b]
+
+        traj = kw.pop("traj", None)
+        if steps > 1:
+            idx = pop.forward(steps - 1, x=rows(x, 0, steps - 1), w_in=w_in, out_var=self._out_code, step0=step0,
+                              sample_idx=idx, traj=rows(traj, 0, steps - 1), **kw)
+        sv = torch.empty(1, N, dtype=torch.float32, device=pop.device)
+        ss = torch.empty(1, N, dtype=torch.float32, device=pop.device)
+        idx = pop.forward(1, x=rows(x, steps - 1, steps), w_in=w_in, out_var=self._out_code,
+                          step0=step0 + steps - 1, sample_idx=idx, traj=rows(traj, steps - 1, steps),
+                          save_v=sv, save_src=ss, **kw)
+        self._y_prev = torch.cat((sv[0], ss[0]))
+        return idx

@@ -1,0 +1,90 @@
+"""Closed table of neuron-model templates for the HIP integration path.
+
+The reference hands a YAML template to the third-party PyRates code generator
+(rectipy/nodes.py:232-262), which returns a torch function for N vectorised neurons.
+PyRates is not a dependency of this engine: the hot path runs a fixed set of vector
+fields compiled into the gfx950 kernels, and this table maps the reference's template
+paths and ``<operator>/<variable>`` names onto them.  Equations, variable names and
+default values are those of the reference's YAML files:
+
+  neuron_model_templates/rate_neurons/leaky_integrator.yaml:8-36  (li_op, sigmoid_op, tanh_op)
+  neuron_model_templates/spiking_neurons/qif.yaml:8-22            (qif_op)
+
+Anything else (lif, ik, qif_sfa, user YAML, PyRates template objects) raises -- there is
+no silent fallback to a generic interpreter.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+
+@dataclass(frozen=True)
+class Template:
+    name: str                       # e.g. "tanh"
+    model: str                      # engine model id (rectipy_amd.engine.MODEL_IDS)
+    state: Tuple[Tuple[str, float], ...]     # state variables in state-vector order, with defaults
+    params: Tuple[Tuple[str, float], ...]    # per-neuron constants with YAML defaults
+    input_var: str                  # extrinsic input the kernels add (I_ext)
+    target_var: str                 # variable the recurrent weights project to
+    source_var: str                 # variable the recurrent weights read
+    derived: Tuple[str, ...] = ()   # non-state outputs computed from the state (r = act(v))
+    spike_var: str = ""             # spiking models: input that receives spike/dt
+    reset_var: str = ""             # spiking models: state variable that is reset
+    engine_names: Dict[str, str] = field(default_factory=dict)  # "<op>/<var>" -> engine parameter name
+
+
+_LI_PARAMS = (("li_op/tau", 10.0), ("li_op/k", 1.0), ("li_op/eta", 0.0))
+
+_FILES: Dict[str, Dict[str, Template]] = {
+    "leaky_integrator": {
+        "tanh": Template(
+            name="tanh", model="li_tanh", state=(("li_op/v", 0.0),), params=_LI_PARAMS,
+            input_var="li_op/I_ext", target_var="li_op/r_in", source_var="tanh_op/r", derived=("tanh_op/r",),
+            engine_names={"li_op/tau": "tau", "li_op/k": "k", "li_op/eta": "eta"}),
+        "sigmoid": Template(
+            name="sigmoid", model="li_sigmoid", state=(("li_op/v", 0.0),),
+            params=_LI_PARAMS + (("sigmoid_op/r_max", 1.0), ("sigmoid_op/s", 1.0), ("sigmoid_op/v0", 0.0)),
+            input_var="li_op/I_ext", target_var="li_op/r_in", source_var="sigmoid_op/r", derived=("sigmoid_op/r",),
+            engine_names={"li_op/tau": "tau", "li_op/k": "k", "li_op/eta": "eta", "sigmoid_op/r_max": "r_max",
+                          "sigmoid_op/s": "s", "sigmoid_op/v0": "v0"}),
+    },
+    "qif": {
+        "qif": Template(
+            name="qif", model="qif", state=(("qif_op/v", -2.0), ("qif_op/s", 0.0)),
+            params=(("qif_op/tau", 1.0), ("qif_op/k", 1.0), ("qif_op/tau_s", 1.0), ("qif_op/eta", -5.0)),
+            input_var="qif_op/I_ext", target_var="qif_op/s_in", source_var="qif_op/s",
+            spike_var="qif_op/spike", reset_var="qif_op/v",
+            engine_names={"qif_op/tau": "tau", "qif_op/k": "k", "qif_op/tau_s": "tau_s", "qif_op/eta": "eta"}),
+    },
+}
+
+# templates that exist in the reference's YAML files but have no kernel here yet
+_KNOWN_UNSUPPORTED = {"qif": ("qif_sfa",), "lif": ("lif",), "ik": ("ik", "ik_theta", "ik_nodim", "ik_eta")}
+
+
+def resolve(path) -> Template:
+    """Map a template path such as
+    ``neuron_model_templates.rate_neurons.leaky_integrator.tanh`` to a :class:`Template`.
+
+    Error behaviour follows what the reference surfaces from PyRates
+    (rectipy_tests/test_network.py:94-101): unknown file -> FileNotFoundError, unknown
+    template inside a known file -> AttributeError.
+    """
+    if not isinstance(path, str):
+        raise NotImplementedError(
+            "rectipy_amd accepts template paths of its built-in models only; PyRates NodeTemplate/"
+            "CircuitTemplate objects need the PyRates code generator, which this engine does not use.")
+    parts = path.replace("/", ".").split(".")
+    if len(parts) < 2:
+        raise FileNotFoundError(f"'{path}' is not of the form <package>.<file>.<template>")
+    fname, tname = parts[-2], parts[-1]
+    if fname in _FILES and tname in _FILES[fname]:
+        return _FILES[fname][tname]
+    if fname in _KNOWN_UNSUPPORTED and tname in _KNOWN_UNSUPPORTED[fname]:
+        raise NotImplementedError(f"template '{fname}.{tname}' has no gfx950 kernel yet (see DESIGN.md, 'next')")
+    if fname in _FILES or fname in _KNOWN_UNSUPPORTED:
+        raise AttributeError(f"template file '{fname}' has no template named '{tname}'")
+    raise FileNotFoundError(f"no built-in template file '{fname}' (from '{path}')")
+
+
+def available() -> List[str]:
+    return [f"{f}.{t}" for f, d in _FILES.items() for t in d]

@@ -1,0 +1,75 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/rectipy_hip.h declares and
+agrees with the ctypes mirror on struct layouts.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from rectipy_amd import _abi, _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rectipy_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 12
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/rectipy_hip.h but not exported"
+    assert sorted(_abi.EXPORTS) == syms, "python EXPORTS list is out of sync with the header"
+
+
+def test_struct_layouts_and_version(lib):
+    assert lib.rp_abi_version() == _abi.RP_ABI_VERSION
+    assert lib.rp_sizeof_net() == C.sizeof(_abi.RpNet)
+    assert lib.rp_sizeof_run() == C.sizeof(_abi.RpRun)
+    assert lib.rp_sizeof_bwd() == C.sizeof(_abi.RpBwd)
+
+
+def test_argument_validation_without_gpu(lib):
+    """Bad arguments are rejected before any HIP call, with the documented status codes."""
+    net = _abi.RpNet()
+    run = _abi.RpRun()
+    assert lib.rp_forward(C.byref(net), C.byref(run), None) == _abi.RP_ERR_SHAPE  # n = 0
+    net.model = 99
+    assert lib.rp_forward(C.byref(net), C.byref(run), None) == _abi.RP_ERR_ARG
+    assert b"model" in lib.rp_last_error()
+    assert lib.rp_outer_accum(0, 1, 1.0, None, 0, None, 0, None, 0, None) == _abi.RP_ERR_ARG
+    assert lib.rp_bwd_partial_rows(32768) == 32 and lib.rp_bwd_partial_rows(10) == 2
+    with pytest.raises(ValueError):
+        _lib.check(_abi.RP_ERR_ARG)
+    with pytest.raises(RuntimeError):
+        _lib.check(_abi.RP_ERR_SHAPE)
+
+
+def test_product_refuses_cpu_tensors():
+    """No CPU fallback: the HIP backend refuses to integrate on a CPU device."""
+    import numpy as np
+    from rectipy_amd import Network
+    net = Network(dt=1e-2, device="cpu")
+    with pytest.raises(_lib.HipLibraryError):
+        net.add_diffeq_node("rnn", "neuron_model_templates.rate_neurons.leaky_integrator.tanh",
+                            input_var="li_op/I_ext", output_var="li_op/v", weights=np.eye(4), source_var="tanh_op/r",
+                            target_var="li_op/r_in")
+
+
+def test_no_oracle_import_in_product():
+    pkg = os.path.join(ROOT, "rectipy_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports the oracle"
+                assert "rnn_oracle" not in text or f in ("rnn_forward.hip", "rnn_backward.hip", "outer_gemm.hip"), f

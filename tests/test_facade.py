@@ -1,0 +1,260 @@
+"""Host-side API parity with the reference's own tests (rectipy_tests/test_nodes.py, test_network.py),
+run with the CPU oracle doing the arithmetic so that no GPU is needed.  What those tests assert about
+construction, naming, errors, reset/detach and simulation bookkeeping is asserted here."""
+import numpy as np
+import pytest
+import torch
+
+from rectipy_amd import Network, Observer, RateNet, SpikeResetNet
+from rectipy_amd.edges import Linear
+
+TANH = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
+QIF = "neuron_model_templates.spiking_neurons.qif.qif"
+IN, OUT, SRC, TGT = "li_op/I_ext", "tanh_op/r", "tanh_op/r", "li_op/r_in"
+
+
+@pytest.fixture
+def where(oracle_backend):
+    return dict(device="cpu", backend=oracle_backend)
+
+
+def test_node_construction_variants(where):
+    """mirrors test_2_1_ratenet_init / test_3_1_diffeq_nodes"""
+    n = 10
+    W = np.random.default_rng(0).standard_normal((n, n))
+    rnn2 = RateNet.from_pyrates(TANH, weights=W, source_var=SRC, target_var=TGT, input_var=IN, output_var=OUT,
+                                clear=True, verbose=False, dtype=torch.float32, **where)
+    rnn3 = SpikeResetNet.from_pyrates(QIF, weights=W, source_var="qif_op/s", target_var="qif_op/s_in",
+                                      input_var="qif_op/I_ext", output_var="qif_op/s", reset_var="qif_op/v",
+                                      spike_var="qif_op/spike", spike_threshold=1e3, spike_reset=-1e3, clear=True,
+                                      verbose=False, dtype=torch.float32, **where)
+    rnn4 = RateNet.from_pyrates(TANH, weights=W, source_var=SRC, target_var=TGT, input_var=IN, output_var=OUT,
+                                train_params=["weights"], dtype=torch.float32, **where)
+    assert len(rnn2.y) == n and len(rnn3.y) == 2 * n
+    assert len(list(rnn4.parameters())) - len(list(rnn2.parameters())) == 1
+    assert rnn4["li_op/v"].shape[0] == n
+    assert rnn3.y.dtype == torch.float32
+    assert rnn4.y.requires_grad and not rnn2.y.requires_grad
+    with pytest.raises(KeyError):
+        _ = rnn2["li_op/u"]
+    with pytest.raises(FileNotFoundError):
+        RateNet.from_pyrates("neuron_model_templates.rate_neurons.freaky_integrator.tanh", weights=W, source_var=SRC,
+                             target_var=TGT, input_var=IN, output_var=OUT, **where)
+    with pytest.raises(AttributeError):
+        RateNet.from_pyrates("neuron_model_templates.rate_neurons.leaky_integrator.tan", weights=W, source_var=SRC,
+                             target_var=TGT, input_var=IN, output_var=OUT, **where)
+    with pytest.raises(KeyError):
+        RateNet.from_pyrates(TANH, weights=W, source_var="x", target_var=TGT, input_var=IN, output_var=OUT, **where)
+    with pytest.raises(NotImplementedError):
+        RateNet.from_pyrates("neuron_model_templates.spiking_neurons.lif.lif", weights=W, source_var="s",
+                             target_var="s_in", input_var="I_ext", output_var="s", **where)
+
+    nets = [Network(1e-2, **where) for _ in range(4)]
+    nets[0].add_diffeq_node("n1", node=TANH, input_var=IN, output_var=OUT, weights=W, source_var=SRC, target_var=TGT)
+    nets[1].add_diffeq_node("n1", TANH, weights=W, input_var="I_ext", output_var=OUT, source_var=SRC,
+                            target_var="r_in", op="li_op")
+    nets[2].add_diffeq_node("n1", TANH, weights=W, input_var=IN, output_var=OUT, source_var=SRC, target_var=TGT,
+                            train_params=["weights"])
+    nets[3].add_diffeq_node("n1", QIF, weights=W, input_var="I_ext", output_var="s", source_var="s",
+                            target_var="s_in", op="qif_op", spike_var="spike", reset_var="v", dtype=torch.float32)
+    assert isinstance(nets[0].get_node("n1"), RateNet) and isinstance(nets[3].get_node("n1"), SpikeResetNet)
+    assert isinstance(nets[0]["n1"]["node"], RateNet)
+    assert len(nets[1]._var_map) - len(nets[0]._var_map) > 0
+    assert len(nets[0].get_node("n1").train_params) == 0 and len(nets[2].get_node("n1").train_params) == 1
+    assert nets[1].get_var("n1", var="v").shape[0] == n
+    net5 = Network(1e-2, **where)
+    net5.add_node("n1", rnn2, node_type="diff_eq")
+    assert net5.get_node("n1") is rnn2
+
+
+def test_forward_reset_and_shape_errors(where):
+    """mirrors test_2_3_forward / test_2_4_reset"""
+    n = 10
+    rng = np.random.default_rng(1)
+    W, y0 = rng.standard_normal((n, n)), rng.standard_normal(n)
+    rnn = RateNet.from_pyrates(TANH, weights=W, source_var=SRC, target_var=TGT, input_var=IN, output_var="li_op/v",
+                               node_vars={"all/li_op/v": y0, "all/li_op/tau": 1.0}, dtype=torch.float32, **where)
+    x = torch.randn(n)
+    r1 = rnn.forward(x)
+    assert r1.shape[0] == n and np.allclose(r1.numpy(), y0, atol=1e-6)  # pre-update output
+    r2 = rnn.forward(x)
+    rnn.reset(y0)
+    r3 = rnn.forward(x)
+    rnn.reset(y0[0:3], idx=np.arange(0, 3))
+    r5 = rnn.forward(x)
+    rnn.reset(y0 + 1.0)
+    r4 = rnn.forward(x)
+    for a, b in ((r1, r2), (r1, r4), (r1, r5)):
+        assert np.mean(np.abs(a.numpy() - b.numpy())) > 0
+    assert torch.equal(r1, r3)
+    assert torch.equal(r1[0:3], r5[0:3]) and np.allclose(r2[3:].numpy(), r5[3:].numpy(), atol=1e-6)
+    with pytest.raises(RuntimeError):
+        rnn.forward(torch.randn(n + 1))
+    with pytest.raises(RuntimeError):
+        rnn.forward(np.random.randn(n))
+    with pytest.raises(RuntimeError):
+        rnn.reset(np.random.randn(n + 1))
+    with pytest.raises(RuntimeError):
+        rnn.reset(y0, idx=np.arange(0, n + 1))
+    # scalar / length-1 inputs broadcast (documentation/interfaces/torch_integration.py:118-120)
+    rnn.reset(y0)
+    a = rnn.forward(0.3)
+    rnn.reset(y0)
+    b = rnn.forward(torch.tensor([0.3]))
+    assert torch.equal(a, b)
+    # set_param / get item
+    rnn.set_param("li_op/tau", 5.0)
+    assert float(rnn["li_op/tau"][0]) == 5.0
+    with pytest.raises(KeyError):
+        rnn.set_param("li_op/nope", 1.0)
+
+
+def test_detach_flags(where):
+    """mirrors test_2_2_detach"""
+    W = np.random.default_rng(2).standard_normal((10, 10))
+    rnn1 = RateNet.from_pyrates(TANH, weights=W, source_var=SRC, target_var=TGT, input_var=IN, output_var=OUT,
+                                train_params=["weights"], dtype=torch.float32, **where)
+    rnn2 = RateNet.from_pyrates(TANH, weights=W, source_var=SRC, target_var=TGT, input_var=IN, output_var=OUT,
+                                train_params=["weights"], dtype=torch.float32, **where)
+    rnn2.detach(detach_params=True, requires_grad=False)
+    assert rnn1.y.requires_grad and not rnn2.y.requires_grad
+    assert rnn1["weights"].requires_grad and not rnn2["weights"].requires_grad
+
+
+def test_edges_and_parameters(where):
+    """mirrors test_edges.py Linear checks and test_3_3 / test_3_5 parameter counts"""
+    lin = Linear(4, 3, weights=np.ones((4, 3)))
+    assert tuple(lin.weights.shape) == (3, 4) and not lin.weights.requires_grad
+    lin2 = Linear(4, 3, detach=False)
+    assert lin2.weights.requires_grad and len(list(lin2.parameters())) == 1
+    ref = torch.nn.Linear(4, 3, bias=False)
+    lin3 = Linear(4, 3, weights=ref.weight.detach(), dtype=torch.float32)
+    xin = torch.randn(4)
+    assert torch.allclose(lin3(xin), ref(xin), atol=1e-6)
+    with pytest.raises(ValueError):
+        Linear(4, 3, weights=np.ones((5, 3)))
+    with pytest.raises(RuntimeError):
+        lin3(torch.randn(5))
+
+    n = 10
+    W = np.random.default_rng(3).standard_normal((n, n))
+    net = Network(1e-2, **where)
+    net.add_diffeq_node("rnn", TANH, weights=W, input_var=IN, output_var=OUT, source_var=SRC, target_var=TGT,
+                        train_params=["weights"], dtype=torch.float32)
+    net.add_func_node("inp", 3, "tanh")
+    net.add_func_node("out", 2, "softmax")
+    net.add_edge("inp", "rnn", train="gd")
+    net.add_edge("rnn", "out", weights=np.random.randn(2, n))
+    assert len(list(net.parameters())) == 2
+    assert net.get_edge("rnn", "out").weights.shape == (2, n)
+    with pytest.raises(ValueError):
+        net.add_edge("rnn", "out", train="bogus")
+    with pytest.raises(ValueError):
+        net.add_func_node("bad", 3, "relu6")
+    net.compile()
+    assert net.n_in == 3 and net.n_out == 2
+    out = net.forward(torch.randn(3))
+    assert out.shape == (2,) and abs(float(out.sum()) - 1.0) < 1e-5
+    net.pop_edge("rnn", "out")
+    net.pop_node("out")
+    assert len(net) == 2
+
+
+def test_compile_errors(where):
+    """mirrors test_3_4: zero or two output nodes raise ValueError"""
+    n = 6
+    W = np.zeros((n, n))
+    net = Network(1e-2, **where)
+    net.add_diffeq_node("rnn", TANH, weights=W, input_var=IN, output_var=OUT, source_var=SRC, target_var=TGT)
+    net.add_func_node("o1", 2, "identity")
+    net.add_func_node("o2", 2, "identity")
+    net.add_edge("rnn", "o1")
+    net.add_edge("rnn", "o2")
+    with pytest.raises(ValueError):
+        net.compile()
+    net.pop_node("o2")
+    net.compile()
+    net.add_edge("o1", "rnn", weights=np.zeros((n, 2)))  # a cycle: no node without input edges
+    with pytest.raises(ValueError):
+        net.compile()
+
+
+def test_run_matches_manual_forward_loop(where):
+    """mirrors test_3_6_simulation: run(sampling_steps=2) == manual forward loop with buffer-mean; recorded
+    variables == get_var right after each forward"""
+    n, steps, dt = 10, 100, 1e-2
+    rng = np.random.default_rng(4)
+    W = rng.standard_normal((n, n))
+    x = torch.tensor(rng.standard_normal((steps, n)), dtype=torch.float32)
+    nets = []
+    for _ in range(3):
+        net = Network(dt=dt, **where)
+        net.add_diffeq_node("rnn", TANH, weights=W, input_var=IN, output_var=OUT, source_var=SRC, target_var=TGT,
+                            dtype=torch.float32, record_vars=["li_op/v"])
+        nets.append(net)
+    res1 = nets[0].run(inputs=x, sampling_steps=2, verbose=False)
+    res2 = nets[1].run(inputs=x, record_output=False, record_vars=[("rnn", "li_op/v", False)], verbose=False)
+    nets[2].compile()
+    res3, res4, buffer = [], [], []
+    for step in range(steps):
+        out = nets[2].forward(x[step, :])
+        buffer.append(out.detach().numpy())
+        if step % 2 == 0:
+            res3.append(np.mean(buffer, axis=0))
+            buffer = []
+        res4.append(nets[2].get_var("rnn", var="li_op/v").detach().numpy().copy())
+    assert np.abs(res1.to_dataframe("out").values - np.asarray(res3)).max() < 1e-6
+    assert np.abs(res2.to_dataframe(("rnn", "li_op/v")).values - np.asarray(res4)).max() < 1e-6
+    assert "out" not in res2.recorded_variables
+
+
+def test_readout_training_recovers_weights(where):
+    """mirrors test_3_7_optimization (bptt and ridge legs): a trained readout recovers W_out"""
+    dt, n, n_out, steps = 1e-2, 10, 3, 100
+    rng = np.random.default_rng(5)
+    W, W_out, x = rng.standard_normal((n, n)), rng.standard_normal((n_out, n)), rng.standard_normal((steps, n))
+    net = Network(dt, **where)
+    net.add_diffeq_node("rnn", TANH, input_var=IN, output_var=OUT, weights=W, source_var=SRC, target_var=TGT,
+                        dtype=torch.float32)
+    net.add_func_node("output", n_out, "identity")
+    net.add_edge("rnn", "output", weights=W_out, train=None)
+    y0 = {k: v.clone() for k, v in net.state.items()}
+    target = net.run(x, sampling_steps=1, enable_grad=False, verbose=False).to_numpy("out")
+    net.pop_edge("rnn", "output")
+    net.add_edge("rnn", "output", weights=rng.standard_normal((n_out, n)), train="gd")
+    net.reset(y0)
+    epochs = 300
+    obs = net.fit_bptt([x] * epochs, [target] * epochs, sampling_steps=1, verbose=False, lr=0.1, optimizer="adam")
+    fitted = net.get_edge("rnn", "output").weights.detach().numpy()
+    assert np.mean((W_out - fitted) ** 2) < 0.5
+    assert len(obs["epoch_loss"]) == epochs and obs["epoch_loss"][-1] < obs["epoch_loss"][0]
+    net.reset(y0)
+    net.pop_node("output")
+    obs_r = net.fit_ridge(x, target, sampling_steps=1, add_readout_node=False, verbose=False, alpha=1e-6)
+    assert np.mean((W_out - obs_r["w_out"].numpy().T) ** 2) < 0.5
+    # Network.test: frozen run + loss against targets (network.py:898-944)
+    net.reset(y0)
+    rates = net.run(x, sampling_steps=1, enable_grad=False, verbose=False).to_numpy("out")
+    net.reset(y0)
+    obs_t, loss = net.test(x, rates, sampling_steps=1, verbose=False)
+    assert loss == 0.0 and len(obs_t["out"]) == steps
+    net.reset(y0)
+    _, loss_off = net.test(x, rates + 1.0, sampling_steps=1, verbose=False)
+    assert loss_off == pytest.approx(1.0, rel=1e-5)
+
+
+def test_observer_api():
+    obs = Observer(dt=0.1, record_vars=[("a", "v", False), ("a", "w", True)])
+    for s in range(3):
+        obs.record(s, torch.ones(2) * s, 0.5, [torch.arange(4.0), torch.arange(4.0)])
+    obs.record_block([3, 4], torch.ones(2, 2) * 7, [0.1, 0.2], [torch.zeros(2, 4), torch.ones(2, 4)])
+    assert obs["steps"] == [0, 1, 2, 3, 4] and len(obs["out"]) == 5
+    assert obs.to_numpy("out").shape == (5, 2) and obs.to_numpy(("a", "v")).shape == (5, 4)
+    assert obs.to_numpy(("a", "w")).shape == (5,) and obs.to_numpy("loss")[-1] == pytest.approx(0.2)
+    assert obs.stacked("out").shape == (5, 2)
+    df = obs.to_dataframe("out")
+    assert df.shape == (5, 2) and df.index[-1] == pytest.approx(0.4)
+    obs.save("extra", [torch.zeros(1)])
+    assert obs["extra"][0].shape == (1,) and obs.recorded_state_variables == [("a", "v"), ("a", "w")]
+    with pytest.raises(KeyError):
+        _ = obs["missing"]

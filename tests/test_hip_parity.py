@@ -127,3 +127,134 @@ def test_sharded_rows_match_unsharded(hip_device):
                       out_var=_abi.RP_OUT_SOURCE)
         r_full = torch.cat([s.source_local for s in shards])  # the "all-gather"
     assert_same(traj_full, traj, "sharded trajectory")
+
+
+@pytest.mark.parametrize("N,T", [(48, 20), (256, 16), (1000, 12), (1028, 9)])
+@pytest.mark.parametrize("model,grad_var", [("li_tanh", _abi.RP_OUT_STATE0), ("li_tanh", _abi.RP_OUT_SOURCE),
+                                            ("li_sigmoid", _abi.RP_OUT_SOURCE)])
+def test_rate_backward_bit_exact(oracle_backend, hip_device, N, T, model, grad_var):
+    """Adjoint sweep (column-strip W^T u, finalize, parameter gradients): HIP == oracle, bit for bit."""
+    W, params, v0 = make_li(N, seed=N + 7, model=model)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(T, N, generator=gen) * 0.5
+    g_out = torch.randn(T, N, generator=gen) * 0.1
+    lam_T = torch.randn(N, generator=gen) * 0.01
+    res = []
+    for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+        pop = Population(model, W, params, 1e-2, dev, v0=v0, backend=backend)
+        tv, tr, ta, ut, gx = (torch.zeros(T, N, device=dev) for _ in range(5))
+        pop.forward(T, x=x.to(dev), save_v=tv, save_src=tr, save_acc=ta)
+        lam = lam_T.clone().to(dev)
+        gt, gk, ge = (torch.zeros(N, device=dev) for _ in range(3))
+        keep = pop.backward(tv, tr, g_out.to(dev), grad_var, lam, ut, traj_acc=ta, grad_tau=gt, grad_k=gk,
+                            grad_eta=ge, grad_x=gx)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        res.append((lam, ut, gt, gk, ge, gx))
+        del keep
+    for a, b, name in zip(res[0], res[1], ("lambda_0", "u_traj", "grad_tau", "grad_k", "grad_eta", "grad_x")):
+        assert_same(a, b, f"{model} N={N} {name}")
+    assert float(res[0][0].abs().max()) > 0
+
+
+@pytest.mark.parametrize("N,T", [(48, 7), (128, 16), (200, 100), (260, 33)])
+def test_outer_accum_bit_exact(oracle_backend, hip_device, N, T):
+    """MFMA f32 dW GEMM == t-ordered fmaf chain of the oracle, bit for bit (incl. ragged tiles)."""
+    gen = torch.Generator().manual_seed(N + T)
+    A = torch.randn(T, N, generator=gen)
+    B = torch.randn(T, N, generator=gen)
+    C0 = torch.randn(N, N, generator=gen)
+    # asymmetric operands: a swapped row/col map in the C write-back cannot pass
+    A[:, 0] += 3.0
+    res = []
+    for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+        pop = Population("li_tanh", torch.zeros(N, N), dict(tau=1.0, k=1.0, eta=0.0), 1e-2, dev, backend=backend)
+        Cm = C0.clone().to(dev)
+        pop.outer_accum(0.37, A.to(dev), B.to(dev), Cm)
+        res.append(Cm)
+    assert_same(res[0], res[1], f"outer_accum N={N} T={T}")
+    ref = C0.double() + 0.37 * (A.double().T @ B.double())
+    assert (res[1].cpu().double() - ref).abs().max() < 1e-4
+
+
+def test_full_size_properties(hip_device):
+    """BASELINE size (N = 32768): properties that do not need the oracle to run at that size.
+    (1) sampled rows of the fused step agree with a float64 dot product;  (2) the transposed product of the
+    adjoint kernel agrees with float64 W^T u (so forward and backward read the same matrix consistently);
+    (3) row-sharding the same step over 4 shards is bit-identical."""
+    N = 32768
+    dev = hip_device
+    gen = torch.Generator(device=dev).manual_seed(0)
+    W = torch.randn(N, N, device=dev, generator=gen) * (1.5 / N ** 0.5)
+    v0 = torch.randn(N, device=dev, generator=gen)
+    tau = torch.rand(N, device=dev, generator=gen) * 5 + 5
+    k = torch.rand(N, device=dev, generator=gen) + 0.5
+    params = dict(tau=tau, k=k, eta=0.0)
+    pop = Population("li_tanh", W, params, 1e-2, dev, v0=v0)
+    r0 = pop.source.clone()
+    acc = torch.zeros(1, N, device=dev)
+    tv = torch.zeros(1, N, device=dev)
+    tr = torch.zeros(1, N, device=dev)
+    pop.forward(1, save_acc=acc, save_v=tv, save_src=tr)
+    assert torch.equal(tr[0], r0) and torch.equal(tv[0], v0)
+    rows = torch.randint(0, N, (64,), generator=torch.Generator().manual_seed(1)).to(dev)
+    ref = W[rows].double() @ r0.double()
+    assert (acc[0, rows].double() - ref).abs().max() < 2e-5
+    v_ref = v0.double() + 1e-2 * (-v0.double() / tau.double() + k.double() * (W.double() @ r0.double()))
+    assert (pop.v.double() - v_ref).abs().max() < 2e-5
+    # (2) adjoint of the same step
+    lam_T = torch.randn(N, device=dev, generator=gen)
+    lam = lam_T.clone()
+    ut = torch.zeros(1, N, device=dev)
+    keep = pop.backward(tv, tr, None, _abi.RP_OUT_STATE0, lam, ut)
+    u = (k * lam_T).double()
+    z = W.double().T @ u
+    lam_ref = lam_T.double() + 1e-2 * (-lam_T.double() / tau.double() + (1 - r0.double() ** 2) * z)
+    assert (lam.double() - lam_ref).abs().max() < 5e-5
+    del keep, z, v_ref
+    # (3) sharding invariance at full size
+    P = 4
+    shard_rows = N // P
+    v1 = pop.v.clone()
+    for p in range(P):
+        sl = slice(p * shard_rows, (p + 1) * shard_rows)
+        sh = Population("li_tanh", W[sl], dict(tau=tau[sl], k=k[sl], eta=0.0), 1e-2, dev, v0=v0[sl], n=N,
+                        row0=p * shard_rows)
+        sh.source.copy_(r0)
+        sh.forward(1)
+        assert torch.equal(sh.v, v1[sl])
+
+
+def test_qif_full_size_uncoupled_neurons_match_scalar_model(hip_device):
+    """N = 65536 QIF population with W = 0 in effect (k = 0): every neuron is an independent scalar QIF unit, so
+    a handful of neurons can be re-simulated in float32 numpy with the reference's update order and must match
+    exactly, spike steps included."""
+    N, T = 65536, 2000
+    dev = hip_device
+    W = torch.zeros(N, N, device=dev)
+    eta = torch.linspace(-6.0, 4.0, N, device=dev)
+    pop = Population("qif", W, dict(tau=1.0, k=0.0, eta=eta, tau_s=1.0), 1e-3, dev, v0=-2.0, s0=0.0, theta=100.0,
+                     v_reset=-100.0)
+    ev = torch.zeros(4_000_000, 2, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    x = torch.full((T, 1), 15.0, device=dev)
+    pop.forward(T, x=x, spike_events=ev, spike_count=cnt)
+    c = int(cnt.item())
+    assert 0 < c <= ev.shape[0]
+    events = ev[:c].cpu().numpy()
+    f = np.float32
+    dt, inv_dt = f(1e-3), f(1.0) / f(1e-3)
+    for i in (0, 1234, 40000, 65535):
+        v, s, e, spikes = f(-2.0), f(0.0), eta[i].cpu().numpy().astype(np.float32), []
+        for t in range(T):
+            sp = f(1.0) if v - f(100.0) >= 0 else f(0.0)
+            dv = f(f(f(v * v) + e) + f(15.0)) / f(1.0) + f(0.0)
+            ds = f(-s / f(1.0)) + f(sp * inv_dt)
+            v_new = f(v + f(dt * dv))
+            s = f(s + f(dt * ds))
+            v = f(f(v_new * f(1.0 - sp)) + f(sp * f(-100.0)))
+            if sp:
+                spikes.append(t)
+        got = sorted(events[events[:, 1] == i][:, 0].tolist())
+        assert got == spikes, f"neuron {i}: spike steps differ"
+        assert float(pop.v[i]) == float(v) and float(pop.source[i]) == float(s)

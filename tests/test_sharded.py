@@ -1,0 +1,82 @@
+"""Row-sharded integration, world_size 2, gloo on CPU (oracle arithmetic): the sharded trajectory equals the
+single-process one bit for bit, because the per-row summation tree does not depend on the sharding."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+N, T, WORLD = 256, 30, 2
+
+
+def _data():
+    g = torch.Generator().manual_seed(0)
+    W = torch.randn(N, N, generator=g) * 1.5 / N ** 0.5
+    params = dict(tau=torch.rand(N, generator=g) * 5 + 5, k=torch.rand(N, generator=g) + 0.5,
+                  eta=torch.randn(N, generator=g) * 0.1)
+    v0 = torch.randn(N, generator=g)
+    x = torch.randn(T, N, generator=g) * 0.5
+    return W, params, v0, x
+
+
+def _worker(rank, port, model, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from oracle.backend import OracleBackend
+        from rectipy_amd import _abi
+        from rectipy_amd.sharded import ShardedPopulation, shard_bounds
+        W, params, v0, x = _data()
+        row0, rows = shard_bounds(N, WORLD, rank)
+        sl = slice(row0, row0 + rows)
+        kw = {}
+        if model == "qif":
+            params = dict(tau=1.0, k=1.0, eta=-5.0 + params["eta"][sl], tau_s=1.0)
+            W = W.abs() * 2
+            kw = dict(s0_local=torch.zeros(rows), theta=5.0, v_reset=-5.0)
+            x = x + 15.0
+        else:
+            params = {k: v[sl] for k, v in params.items()}
+        sp = ShardedPopulation("li_tanh" if model == "li" else "qif", W[sl], params, 1e-2, "cpu", n=N,
+                               v0_local=v0[sl], backend=OracleBackend(), **kw)
+        traj = torch.zeros(T, rows)
+        samples = torch.zeros(T, rows)
+        n_s = sp.forward(T, x=x[:, sl], traj=traj, out_var=_abi.RP_OUT_SOURCE, cutoff=3, sampling_steps=4,
+                         samples=samples)
+        np.savez(os.path.join(out_dir, f"{model}_{rank}.npz"), traj=traj.numpy(), samples=samples[:n_s].numpy(),
+                 v=sp.pop.v.numpy(), src=sp.pop.source.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model", ["li", "qif"])
+def test_two_rank_shards_reproduce_single_process(tmp_path, oracle_backend, model):
+    from rectipy_amd import _abi
+    from rectipy_amd.engine import Population
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(port, model, str(tmp_path)), nprocs=WORLD, join=True)
+
+    W, params, v0, x = _data()
+    kw = {}
+    if model == "qif":
+        params = dict(tau=1.0, k=1.0, eta=-5.0 + params["eta"], tau_s=1.0)
+        W = W.abs() * 2
+        kw = dict(s0=torch.zeros(N), theta=5.0, v_reset=-5.0)
+        x = x + 15.0
+    full = Population("li_tanh" if model == "li" else "qif", W, params, 1e-2, "cpu", v0=v0, backend=oracle_backend, **kw)
+    traj = torch.zeros(T, N)
+    samples = torch.zeros(T, N)
+    n_s = full.forward(T, x=x, traj=traj, out_var=_abi.RP_OUT_SOURCE, cutoff=3, sampling_steps=4, samples=samples)
+    parts = [np.load(tmp_path / f"{model}_{r}.npz") for r in range(WORLD)]
+    assert np.array_equal(np.concatenate([p["traj"] for p in parts], axis=1), traj.numpy())
+    assert np.array_equal(np.concatenate([p["samples"] for p in parts], axis=1), samples[:n_s].numpy())
+    assert np.array_equal(np.concatenate([p["v"] for p in parts]), full.v.numpy())
+    for p in parts:  # every rank holds the full, identical source vector after the last all-gather
+        assert np.array_equal(p["src"], full.source.numpy())
+    if model == "qif":
+        assert np.abs(np.diff(traj.numpy(), axis=0)).max() > 0.5, "no spikes in the sharded QIF test"
