@@ -76,7 +76,7 @@ def main():
     N, K, Wm = args.neurons, args.steps, args.warmup
     dt = 1e-2
     T_total = Wm + K
-    tt = torch.arange(T_total, device=dev, dtype=torch.float32) * dt
+    tt = torch.arange(max(T_total, 1000), device=dev, dtype=torch.float32) * dt
     x = torch.sin(2 * torch.pi * 0.2 * tt).reshape(-1, 1).contiguous()
     sampling = 100
     n_samples = T_total // sampling + 2
