@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--neurons", type=int, default=32768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use the sharded (RCCL) path even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -66,8 +67,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
 
     from rectipy_amd import _abi
@@ -82,7 +86,7 @@ def main():
     n_samples = T_total // sampling + 2
     params = dict(tau=10.0, k=1.0, eta=0.0)
 
-    if world == 1:
+    if not use_dist:
         row0, rows = 0, N
         pop = Population("li_tanh", gen_rows(N, 0, N, dev), params, dt, dev)
         samples = torch.zeros(n_samples, N, device=dev)
@@ -102,7 +106,7 @@ def main():
                               samples=samples, sample_idx=idx)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     idx = run(Wm, 0, 0)
@@ -119,15 +123,14 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     kernel_ms = e0.elapsed_time(e1) / K  # events on the launch stream: average step-kernel duration (+ gaps)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax.item())
     finite = bool(torch.isfinite(pop.v).all().item())
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     steps_per_s = K / wall
@@ -154,12 +157,13 @@ def main():
         "state_finite": finite,
     }
 
-    if world == 1 and not args.no_extra:
-        out["extra"] = fwd_bwd_extra(pop, x, N, dev)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pop, x, dt, N)
+    if world == 1 and not args.no_extra:
+        out["extra"] = fwd_bwd_extra(pop, x, N, dev)
+        out["extra"].update(facade_fit_bptt(pop, x, N, dev))  # last: it trains (modifies) the shared weight matrix
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -206,6 +210,30 @@ def fwd_bwd_extra(pop, x, N, dev):
                              "unit": "TFLOP/s", "frac": 2.0 * N * N * T / (gemm * 1e-3) / 1e12 / 157.3},
         "grad_finite": bool(torch.isfinite(gW).all().item()),
     }
+
+
+def facade_fit_bptt(pop, x, N, dev):
+    """The same config through the reference-compatible front end: Network.fit_bptt with trainable recurrent
+    weights and a gd-trained k=3 readout, SGD, two 1000-step windows (wall clock, includes torch's loss,
+    autograd bookkeeping and optimizer step over the 4.3 GB weight matrix)."""
+    from rectipy_amd import Network
+    T, win = 2000, 1000
+    gen = torch.Generator(device=dev).manual_seed(3)
+    net = Network(dt=pop.dt, device=str(dev))
+    net.add_diffeq_node("rnn", "neuron_model_templates.rate_neurons.leaky_integrator.tanh", input_var="li_op/I_ext",
+                        output_var="li_op/v", weights=pop.W, source_var="tanh_op/r", target_var="li_op/r_in",
+                        train_params=["weights"], dtype=torch.float32)
+    net.add_func_node("out", 3, "identity")
+    net.add_edge("rnn", "out", weights=torch.randn(3, N, generator=gen, device=dev) / N ** 0.5, train="gd")
+    inp = x[:T].clone()
+    tgt = torch.randn(T, 3, generator=gen, device=dev) * 0.1
+    net.fit_bptt(inp[:100], tgt[:100], optimizer="sgd", lr=1e-4, update_steps=100, sampling_steps=100, verbose=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    obs = net.fit_bptt(inp, tgt, optimizer="sgd", lr=1e-4, update_steps=win, sampling_steps=100, verbose=False)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    return {"facade_fit_bptt_steps_per_s": T / wall, "facade_fit_bptt_loss": [float(v) for v in obs["loss"][-2:]]}
 
 
 def cpu_baseline(pop, x, dt, N):

@@ -258,3 +258,40 @@ def test_qif_full_size_uncoupled_neurons_match_scalar_model(hip_device):
         got = sorted(events[events[:, 1] == i][:, 0].tolist())
         assert got == spikes, f"neuron {i}: spike steps differ"
         assert float(pop.v[i]) == float(v) and float(pop.source[i]) == float(s)
+
+
+def test_qif_full_size_dense_step_properties(hip_device):
+    """BASELINE config 4 size (N = 65536, dense coupling): one step from a random state.  Sampled neurons are
+    recomputed from a float64 dot product; spiking neurons are exactly those with v >= theta, are reset to
+    v_reset, and their s jumps by exactly 1 relative to a non-spiking twin."""
+    N, dev = 65536, hip_device
+    gen = torch.Generator(device=dev).manual_seed(4)
+    W = torch.rand(N, N, device=dev, generator=gen) * (20.0 / N)
+    v0 = torch.rand(N, device=dev, generator=gen) * 220.0 - 110.0  # some above theta = 100
+    v0[7] = 100.0  # equality spikes
+    s0 = torch.rand(N, device=dev, generator=gen)
+    eta = torch.randn(N, device=dev, generator=gen) - 5.0
+    pop = Population("qif", W, dict(tau=1.0, k=1.0, eta=eta, tau_s=1.0), 1e-3, dev, v0=v0, s0=s0, theta=100.0,
+                     v_reset=-100.0)
+    ev = torch.zeros(N, 2, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    acc = torch.zeros(1, N, device=dev)
+    pop.forward(1, x=torch.full((1, 1), 15.0, device=dev), save_acc=acc, spike_events=ev, spike_count=cnt, step0=5)
+    spiking = v0 >= 100.0
+    c = int(cnt.item())
+    assert c == int(spiking.sum()) and bool(spiking[7])
+    events = ev[:c].cpu().numpy()
+    assert (events[:, 0] == 5).all()
+    assert sorted(events[:, 1].tolist()) == torch.nonzero(spiking).flatten().cpu().tolist()
+    rows = torch.randint(0, N, (64,), generator=torch.Generator().manual_seed(1)).to(dev)
+    ref_acc = W[rows].double() @ s0.double()
+    assert (acc[0, rows].double() - ref_acc).abs().max() < 2e-5
+    v_new, s_new = pop.v, pop.source
+    assert bool((v_new[spiking] == -100.0).all())
+    quiet = ~spiking
+    v_ref = v0.double() + 1e-3 * ((v0.double() ** 2 + eta.double() + 15.0) + W[rows].double().sum() * 0)
+    dv = (v0[rows].double() ** 2 + eta[rows].double() + 15.0) + ref_acc
+    ok = quiet[rows]
+    assert ((v_new[rows].double() - (v0[rows].double() + 1e-3 * dv))[ok]).abs().max() < 2e-4
+    s_ref = s0.double() * (1 - 1e-3) + spiking.double()
+    assert (s_new.double() - s_ref).abs().max() < 1e-5
