@@ -18,7 +18,8 @@
  *                        the time loop + sampling   rectipy/network.py:588-599
  *                        the input edge             rectipy/edges.py:48-49
  *   rp_refresh_source <- (state re-initialisation)  rectipy/nodes.py:198-211,398-401
- *   rp_rate_backward  <- torch.autograd over the unrolled loop,
+ *   rp_rate_backward, rp_qif_backward
+ *                     <- torch.autograd over the unrolled loop (incl. Spike.backward, nodes.py:479-481),
  *                        Network._bptt_step         rectipy/network.py:1123-1130
  *   rp_outer_accum    <- the per-step outer-product accumulation autograd does
  *                        for `weights @ r`          (same call site)
@@ -158,6 +159,13 @@ typedef struct rp_bwd {
     float* grad_eta;          /* optional [n] accumulated (+=)                */
     float* grad_x;            /* optional [T x ldgx] dL/dI_ext,t              */
     int64_t ldgx;
+    /* spiking (QIF) sweep only; ignored by rp_rate_backward */
+    float* lam2;              /* [n] adjoint of s (in: at T, out: at 0); traj_r then holds s_t */
+    float* grad_tau_s;        /* optional [n] accumulated (+=)                */
+    float slope;              /* surrogate slope: d spike / d x = 1 / (1 + slope |x|)^2, x = v - theta (nodes.py:479-481) */
+    int32_t x_mode;           /* RP_X_NONE / RP_X_FULL / RP_X_BCAST: the input of the forward window (needed for grad_tau) */
+    const float* x;
+    int64_t ldx;
 } rp_bwd;
 
 int rp_abi_version(void);
@@ -182,6 +190,10 @@ int32_t rp_bwd_partial_rows(int32_t n);
 
 /* Adjoint sweep t = T-1..0 over a stored window (unsharded LI models). */
 int rp_rate_backward(const rp_net* net, const rp_bwd* bwd, void* stream);
+
+/* Surrogate-gradient adjoint sweep of the spiking (QIF) step: gradient flows through the Heaviside via
+   Spike.backward (nodes.py:479-481) but not through the reset mask (nodes.py:384). */
+int rp_qif_backward(const rp_net* net, const rp_bwd* bwd, void* stream);
 
 /* C[n x n] (ldc) += alpha * A^T B with A = [T x n] (lda), B = [T x n] (ldb): MFMA f32 GEMM. */
 int rp_outer_accum(int32_t n, int32_t T, float alpha, const float* A, int64_t lda, const float* B,

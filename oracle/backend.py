@@ -60,6 +60,9 @@ class OracleBackend:
     def rate_backward(self, net, bwd, device):
         assert self.lib.oracle_rate_backward(C.byref(net), C.byref(bwd)) == 0
 
+    def qif_backward(self, net, bwd, device):
+        assert self.lib.oracle_qif_backward(C.byref(net), C.byref(bwd)) == 0
+
     def outer_accum(self, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
         assert self.lib.oracle_outer_accum(n, T, alpha, A, lda, B, ldb, Cmat, ldc) == 0
 

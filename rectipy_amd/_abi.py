@@ -99,6 +99,12 @@ class RpBwd(C.Structure):
         ("grad_eta", fp),
         ("grad_x", fp),
         ("ldgx", C.c_int64),
+        ("lam2", fp),
+        ("grad_tau_s", fp),
+        ("slope", C.c_float),
+        ("x_mode", C.c_int32),
+        ("x", fp),
+        ("ldx", C.c_int64),
     ]
 
 
@@ -124,6 +130,7 @@ def declare(lib, prefix):
         sig("rp_forward", C.c_int, [P(RpNet), P(RpRun), C.c_void_p])
         sig("rp_bwd_partial_rows", C.c_int32, [C.c_int32])
         sig("rp_rate_backward", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
+        sig("rp_qif_backward", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
         sig("rp_outer_accum", C.c_int,
             [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
         sig("rp_stream_probe", C.c_int, [fp, C.c_int64, fp, C.c_void_p])
@@ -132,6 +139,7 @@ def declare(lib, prefix):
         sig("oracle_refresh_source", C.c_int, [P(RpNet)])
         sig("oracle_forward", C.c_int, [P(RpNet), P(RpRun)])
         sig("oracle_rate_backward", C.c_int, [P(RpNet), P(RpBwd)])
+        sig("oracle_qif_backward", C.c_int, [P(RpNet), P(RpBwd)])
         sig("oracle_outer_accum", C.c_int,
             [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64])
         sig("oracle_expf", C.c_float, [C.c_float])
@@ -142,6 +150,6 @@ def declare(lib, prefix):
 
 EXPORTS = [
     "rp_abi_version", "rp_last_error", "rp_device_check", "rp_sizeof_net", "rp_sizeof_run", "rp_sizeof_bwd",
-    "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_outer_accum",
+    "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum",
     "rp_stream_probe", "rp_set_tuning",
 ]

@@ -58,6 +58,14 @@ struct BwdParams {
     float* grad_k;
     float* grad_eta;
     float* gx_prev;
+    // spiking (QIF) sweep
+    float* lam_s;
+    float* grad_tau_s;
+    float slope, theta;
+    int x_mode;
+    const float* x_prev;   // input row of step t-1 (prep) ...
+    const float* s_prev;   // ... and its s_{t-1}
+    const float* s_t;
 };
 
 // partials[q][j] = sum_{i in chunk q, ascending} W[i][j] * u[i]
@@ -156,6 +164,69 @@ __global__ void finalize_kernel(const BwdParams P) {
     if (P.u_next) prep_step(P, j, lam_new);
 }
 
+// ---- spiking (QIF) sweep ---------------------------------------------------------------------------
+// forward step (nodes.py:382-392, qif.yaml:11-12):  sp = H(v - theta), reset = sp.detach(),
+//   v' = (v + dt ((v^2 + eta + I)/tau + k (W s))) (1 - reset) + reset v_reset,   s' = s + dt (-s/tau_s + sp/dt)
+// adjoint with lv = dL/dv_{t+1}, ls = dL/ds_{t+1}:
+//   a = lv (1 - reset_t);  u = k a;  z = W^T u
+//   lv_t = (a + dt (a (2 v_t / tau))) + ls sg(v_t - theta) + [G_t if out = v]
+//   ls_t = (ls + dt (-ls / tau_s + z)) + [G_t if out = s]
+// with the surrogate sg(x) = 1 / (1 + slope |x|)^2 (Spike.backward, nodes.py:479-481).
+
+__device__ __forceinline__ float qif_input(const BwdParams& P, const float* row, int j) {
+    if (P.x_mode == RP_X_FULL) return row[j];
+    if (P.x_mode == RP_X_BCAST) return row[0];
+    return 0.f;
+}
+
+__device__ __forceinline__ void qif_prep_step(const BwdParams& P, int j, float lv, float ls) {
+    const float v = P.v_prev[j];
+    const float reset = (v - P.theta >= 0.0f) ? 1.0f : 0.0f;
+    const float a = lv * (1.0f - reset);
+    P.u_next[j] = P.p[RP_P_K][j] * a;
+    const float tau = P.p[RP_P_TAU][j];
+    const float da = P.dt * a;
+    if (P.grad_eta) P.grad_eta[j] += da / tau;
+    if (P.grad_k) P.grad_k[j] += da * P.acc_prev[j];
+    if (P.grad_tau) {
+        const float num = (v * v + P.p[RP_P_ETA][j]) + qif_input(P, P.x_prev, j);
+        P.grad_tau[j] += -(da * (num / (tau * tau)));
+    }
+    if (P.grad_tau_s) {
+        const float ts = P.p[RP_P_TAU_S][j];
+        P.grad_tau_s[j] += (P.dt * ls) * (P.s_prev[j] / (ts * ts));
+    }
+    if (P.gx_prev) P.gx_prev[j] = da / tau;
+}
+
+__global__ void qif_prep_kernel(const BwdParams P) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < P.n) qif_prep_step(P, j, P.lam[j], P.lam_s[j]);
+}
+
+__global__ void qif_finalize_kernel(const BwdParams P) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n) return;
+    float z = 0.f;
+    for (int c = 0; c < P.q; ++c) z = z + P.partials[(int64_t)c * P.n + j];
+    const float lv = P.lam[j];
+    const float ls = P.lam_s[j];
+    const float v = P.v_t[j];
+    const float x = v - P.theta;
+    const float reset = (x >= 0.0f) ? 1.0f : 0.0f;
+    const float a = lv * (1.0f - reset);
+    const float den = 1.0f + P.slope * fabsf(x);
+    const float sg = 1.0f / (den * den);
+    const float g = P.g_t ? P.g_t[j] : 0.f;
+    const float gv = (P.grad_var == RP_OUT_STATE0) ? g : 0.f;
+    const float gs = (P.grad_var == RP_OUT_STATE0) ? 0.f : g;
+    const float lv_new = ((a + P.dt * (a * ((2.0f * v) / P.p[RP_P_TAU][j]))) + ls * sg) + gv;
+    const float ls_new = (ls + P.dt * (-ls / P.p[RP_P_TAU_S][j] + z)) + gs;
+    P.lam[j] = lv_new;
+    P.lam_s[j] = ls_new;
+    if (P.u_next) qif_prep_step(P, j, lv_new, ls_new);
+}
+
 }  // namespace
 
 extern "C" {
@@ -237,6 +308,90 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
         else
             P.u_next = nullptr;
         hipLaunchKernelGGL(finalize_kernel, dim3(eblocks), dim3(256), 0, st, P);
+    }
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
+int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
+    if (!net || !b) RP_FAIL(RP_ERR_ARG, "net/bwd is null");
+    if (net->model != RP_MODEL_QIF) RP_FAIL(RP_ERR_ARG, "rp_qif_backward needs the QIF model (model=%d)", net->model);
+    if (net->rows != net->n || net->row0 != 0)
+        RP_FAIL(RP_ERR_ARG, "rp_qif_backward needs the unsharded matrix (rows=%d n=%d)", net->rows, net->n);
+    if (net->n <= 0 || net->ldw < net->n) RP_FAIL(RP_ERR_SHAPE, "bad n/ldw");
+    if (b->steps < 0) RP_FAIL(RP_ERR_ARG, "steps < 0");
+    if (!net->W || !b->traj_v || !b->traj_r || !b->lam || !b->lam2 || !b->u_traj || !b->partials)
+        RP_FAIL(RP_ERR_ARG, "W, traj_v, traj_r (s_t), lam, lam2, u_traj, partials must be non-null");
+    if (!net->p[RP_P_TAU] || !net->p[RP_P_K] || !net->p[RP_P_ETA] || !net->p[RP_P_TAU_S])
+        RP_FAIL(RP_ERR_ARG, "tau/k/eta/tau_s null");
+    if (b->ld < net->n) RP_FAIL(RP_ERR_SHAPE, "ld < n");
+    if (b->grad_out && b->ldg < net->n) RP_FAIL(RP_ERR_SHAPE, "ldg < n");
+    if (b->grad_x && b->ldgx < net->n) RP_FAIL(RP_ERR_SHAPE, "ldgx < n");
+    if (b->grad_k && !b->traj_acc) RP_FAIL(RP_ERR_ARG, "grad_k needs traj_acc");
+    if (b->grad_var != RP_OUT_STATE0 && b->grad_var != RP_OUT_SOURCE) RP_FAIL(RP_ERR_ARG, "bad grad_var");
+    if (b->x_mode != RP_X_NONE && b->x_mode != RP_X_FULL && b->x_mode != RP_X_BCAST)
+        RP_FAIL(RP_ERR_ARG, "x_mode must be NONE, FULL or BCAST");
+    if (b->x_mode != RP_X_NONE && (!b->x || b->ldx < (b->x_mode == RP_X_FULL ? net->n : 1)))
+        RP_FAIL(RP_ERR_SHAPE, "x/ldx inconsistent with x_mode");
+    const bool vec4 = (net->n % 4 == 0) && (net->ldw % 4 == 0);
+    if (vec4 && ((reinterpret_cast<uintptr_t>(net->W) & 15u) || (reinterpret_cast<uintptr_t>(b->partials) & 15u)))
+        RP_FAIL(RP_ERR_ARG, "W and partials must be 16-byte aligned");
+    if (b->steps == 0) return RP_OK;
+
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int n = net->n;
+    const int T = b->steps;
+    BwdParams P = {};
+    P.W = net->W;
+    P.ldw = net->ldw;
+    P.n = n;
+    P.model = net->model;
+    for (int q = 0; q < RP_MAX_PARAMS; ++q) P.p[q] = net->p[q];
+    P.dt = net->dt;
+    P.rc = chunk_rows(n);
+    P.q = (n + P.rc - 1) / P.rc;
+    P.partials = b->partials;
+    P.grad_var = b->grad_var;
+    P.lam = b->lam;
+    P.lam_s = b->lam2;
+    P.grad_tau = b->grad_tau;
+    P.grad_k = b->grad_k;
+    P.grad_eta = b->grad_eta;
+    P.grad_tau_s = b->grad_tau_s;
+    P.slope = b->slope;
+    P.theta = net->theta;
+    P.x_mode = b->x_mode;
+
+    const int eblocks = (n + 255) / 256;
+    const int strips = vec4 ? (n + 255) / 256 : (n + 63) / 64;
+    int mblocks = (strips * P.q + 3) / 4;
+    if (mblocks > 4096) mblocks = 4096;
+
+    auto set_prep = [&](int tp) {
+        P.u_next = b->u_traj + (int64_t)tp * b->ld;
+        P.v_prev = b->traj_v + (int64_t)tp * b->ld;
+        P.s_prev = b->traj_r + (int64_t)tp * b->ld;
+        P.acc_prev = b->traj_acc ? b->traj_acc + (int64_t)tp * b->ld : nullptr;
+        P.gx_prev = b->grad_x ? b->grad_x + (int64_t)tp * b->ldgx : nullptr;
+        P.x_prev = b->x ? b->x + (int64_t)tp * b->ldx : nullptr;
+    };
+
+    set_prep(T - 1);
+    hipLaunchKernelGGL(qif_prep_kernel, dim3(eblocks), dim3(256), 0, st, P);
+    for (int t = T - 1; t >= 0; --t) {
+        P.t = t;
+        P.u = b->u_traj + (int64_t)t * b->ld;
+        if (vec4)
+            hipLaunchKernelGGL((wt_partial_kernel<true, 8>), dim3(mblocks), dim3(kThreads), 0, st, P);
+        else
+            hipLaunchKernelGGL((wt_partial_kernel<false, 1>), dim3(mblocks), dim3(kThreads), 0, st, P);
+        P.v_t = b->traj_v + (int64_t)t * b->ld;
+        P.g_t = b->grad_out ? b->grad_out + (int64_t)t * b->ldg : nullptr;
+        if (t > 0)
+            set_prep(t - 1);
+        else
+            P.u_next = nullptr;
+        hipLaunchKernelGGL(qif_finalize_kernel, dim3(eblocks), dim3(256), 0, st, P);
     }
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;

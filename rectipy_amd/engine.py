@@ -65,6 +65,10 @@ class HipBackend:
         with torch.cuda.device(device):
             self._lib_mod.check(self.lib.rp_rate_backward(C.byref(net), C.byref(bwd), self._stream(device)))
 
+    def qif_backward(self, net: RpNet, bwd: RpBwd, device):
+        with torch.cuda.device(device):
+            self._lib_mod.check(self.lib.rp_qif_backward(C.byref(net), C.byref(bwd), self._stream(device)))
+
     def outer_accum(self, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
         with torch.cuda.device(device):
             self._lib_mod.check(self.lib.rp_outer_accum(n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
@@ -295,8 +299,10 @@ class Population:
 
     # -- adjoint -------------------------------------------------------------------------
     def backward(self, traj_v, traj_r, grad_out, grad_var, lam, u_traj, traj_acc=None,
-                 grad_tau=None, grad_k=None, grad_eta=None, grad_x=None):
-        """Adjoint sweep over a stored window (see rp_rate_backward)."""
+                 grad_tau=None, grad_k=None, grad_eta=None, grad_x=None, lam_s=None, grad_tau_s=None,
+                 slope: float = 0.5, x: Optional[torch.Tensor] = None):
+        """Adjoint sweep over a stored window (rp_rate_backward; rp_qif_backward for the spiking model, which
+        additionally takes the adjoint of s, the surrogate slope and the window's input for grad_tau)."""
         T = int(traj_v.shape[0])
         b = RpBwd()
         b.steps = T
@@ -313,8 +319,22 @@ class Population:
         b.grad_tau, b.grad_k, b.grad_eta = _ptr(grad_tau), _ptr(grad_k), _ptr(grad_eta)
         b.grad_x = _ptr(grad_x)
         b.ldgx = 0 if grad_x is None else (grad_x.stride(0) if T > 1 else grad_x.shape[1])
-        self.backend.rate_backward(self._net(), b, self.device)
-        return partials  # returned so the caller keeps it alive until the stream has consumed it
+        if self.model != "qif":
+            self.backend.rate_backward(self._net(), b, self.device)
+            return partials  # returned so the caller keeps it alive until the stream has consumed it
+        b.lam2 = lam_s.data_ptr()
+        b.grad_tau_s = _ptr(grad_tau_s)
+        b.slope = float(slope)
+        if x is None:
+            b.x_mode = _abi.RP_X_NONE
+        else:
+            x = x.detach().to(dtype=torch.float32, device=self.device).contiguous()
+            if x.shape[1] not in (1, self.n) or x.shape[0] < T:
+                raise RuntimeError(f"window input must be [{T}, 1] or [{T}, {self.n}], got {tuple(x.shape)}")
+            b.x_mode = _abi.RP_X_FULL if x.shape[1] == self.n and self.n != 1 else _abi.RP_X_BCAST
+            b.x, b.ldx = x.data_ptr(), x.shape[1]
+        self.backend.qif_backward(self._net(), b, self.device)
+        return partials, x
 
     def outer_accum(self, alpha: float, A: torch.Tensor, B: torch.Tensor, Cmat: torch.Tensor):
         """Cmat += alpha * A^T @ B on the matrix cores (A, B: [T, n])."""

@@ -354,7 +354,8 @@ class Network:
         S = len(sample_at)
         exit_to = post[0] if post else None
         linear_post = all(self.get_node(n).name == "identity" for n in post)
-        grad = self._wants_grad(plan, inputs) and not isinstance(rnn, SpikeResetNet)
+        grad = self._wants_grad(plan, inputs)
+        spiking = isinstance(rnn, SpikeResetNet)
 
         if grad:
             # autograd path: the population's window is one autograd node, everything around it is torch
@@ -366,10 +367,13 @@ class Network:
                 outs.append(self._apply_chain(post, traj, label, None) if post else traj)
                 if slots:
                     tv, tr = rnn._last_window
-                    for j, slot in enumerate(slots):  # post-update values: row t+1, last row = current state
+                    for j, slot in enumerate(slots):
                         src = tv if slot == 0 else tr
-                        last = pop.v if slot == 0 else pop.source_local
-                        recs[j].append(torch.cat((src[1:], last.detach().reshape(1, -1))))
+                        if spiking:  # SpikeResetNet exposes the pre-update state (nodes.py:387-392)
+                            recs[j].append(src)
+                        else:  # post-update values: row t+1, last row = current state
+                            last = pop.v if slot == 0 else pop.source_local
+                            recs[j].append(torch.cat((src[1:], last.detach().reshape(1, -1))))
                 if truncate_steps < T and b - a == truncate_steps:
                     self.detach()
             per_step = torch.cat(outs)
@@ -495,7 +499,7 @@ class Network:
         plan = self._chain_plan()
         rec_vars = list(obs.recorded_state_variables)
         steps = inp.shape[0]
-        if plan is None or rec_vars or isinstance(self.get_node(plan[1]), SpikeResetNet):
+        if plan is None or rec_vars:
             return self._bptt_stepwise(inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps,
                                        optim_steps, verbose)
         pre, label, post = plan

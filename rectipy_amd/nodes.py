@@ -115,6 +115,62 @@ class _RateWindow(torch.autograd.Function):
         return None, None, g_x, (lam if need[3] else None), g_W, g_tau, g_k, g_eta
 
 
+class _QifWindow(torch.autograd.Function):
+    """T steps of a spiking (QIF) population as ONE autograd node: forward = rp_forward with v_t, s_t captured,
+    backward = rp_qif_backward (surrogate-gradient adjoint, Spike.backward of reference nodes.py:479-481; no
+    gradient through the reset mask, nodes.py:384) + rp_outer_accum for dW."""
+
+    @staticmethod
+    def forward(ctx, node, steps, x, y_in, W, tau, k, eta, tau_s):
+        pop: Population = node._pop
+        N, dev = pop.rows, pop.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        traj_v = torch.empty(steps, N, **f32)
+        traj_s = torch.empty(steps, N, **f32)
+        traj_acc = torch.empty(steps, N, **f32) if k.requires_grad else None
+        pop.forward(steps, x=x, save_v=traj_v, save_src=traj_s, save_acc=traj_acc,
+                    spike_events=node.spike_events, spike_count=node._spike_count)
+        ctx.node, ctx.steps = node, steps
+        ctx.x = None if x is None else x.detach()
+        ctx.saved = (traj_v, traj_s, traj_acc)
+        node._last_window = (traj_v, traj_s)
+        out = traj_s if node._out_code == _abi.RP_OUT_SOURCE else traj_v
+        return out.clone(), torch.cat((pop.v, pop.source_local))
+
+    @staticmethod
+    def backward(ctx, g_traj, g_yend):
+        node = ctx.node
+        pop: Population = node._pop
+        N, dev, T = pop.rows, pop.device, ctx.steps
+        traj_v, traj_s, traj_acc = ctx.saved
+        f32 = dict(dtype=torch.float32, device=dev)
+        if g_yend is None:
+            lam_v, lam_s = torch.zeros(N, **f32), torch.zeros(N, **f32)
+        else:
+            g = g_yend.detach().to(**f32)
+            lam_v, lam_s = g[:N].clone().contiguous(), g[N:].clone().contiguous()
+        g_out = None if g_traj is None else g_traj.detach().to(**f32).contiguous()
+        need = ctx.needs_input_grad  # (node, steps, x, y_in, W, tau, k, eta, tau_s)
+        u_traj = torch.empty(T, N, **f32)
+        g_tau = torch.zeros(N, **f32) if need[5] else None
+        g_k = torch.zeros(N, **f32) if need[6] else None
+        g_eta = torch.zeros(N, **f32) if need[7] else None
+        g_ts = torch.zeros(N, **f32) if need[8] else None
+        g_x = torch.empty(T, N, **f32) if need[2] else None
+        keep = pop.backward(traj_v, traj_s, g_out, node._out_code, lam_v, u_traj, traj_acc=traj_acc, grad_tau=g_tau,
+                            grad_k=g_k, grad_eta=g_eta, grad_x=g_x, lam_s=lam_s, grad_tau_s=g_ts,
+                            slope=node._spike_slope, x=ctx.x)
+        g_W = None
+        if need[4]:
+            g_W = torch.zeros(N, N, **f32)
+            pop.outer_accum(pop.dt, u_traj, traj_s, g_W)
+        if g_x is not None and ctx.x is not None and ctx.x.shape[1] == 1:
+            g_x = g_x.sum(dim=1, keepdim=True)
+        del keep
+        g_y = torch.cat((lam_v, lam_s)) if need[3] else None
+        return None, None, g_x, g_y, g_W, g_tau, g_k, g_eta, g_ts
+
+
 class RateNet:
     """Rate-neuron population integrated on the GPU (reference ``RateNet``, rectipy/nodes.py:54-290)."""
 
@@ -409,8 +465,9 @@ class SpikeResetNet(RateNet):
         self._y_prev = None  # pre-update state of the last step
         self.spike_events: Optional[torch.Tensor] = None
         self._spike_count: Optional[torch.Tensor] = None
-        if self._train_names:
-            raise NotImplementedError("surrogate-gradient BPTT through spiking populations has no gfx950 kernel yet")
+        # surrogate slope of Spike.backward; the reference's default is 100 / |theta - v_reset| (nodes.py:346)
+        if self._spike_slope is None:
+            self._spike_slope = 100.0 / abs(self._pop.theta - self._pop.v_reset)
 
     @classmethod
     def from_pyrates(cls, node, input_var: str, output_var: str, weights: np.ndarray = None,
@@ -424,7 +481,10 @@ class SpikeResetNet(RateNet):
                                     target_var=target_var, train_params=train_params, **kwargs)
 
     def _check_trainable(self):
-        pass
+        ok = {"weights", "tau", "k", "eta", "tau_s"}
+        bad = [n for n in self._train_names if n not in ok]
+        if bad:
+            raise NotImplementedError(f"no adjoint kernel for parameters {bad}; trainable: {sorted(ok)}")
 
     def _tensor(self, engine_name: str) -> torch.Tensor:
         if engine_name == "spike":
@@ -458,9 +518,6 @@ class SpikeResetNet(RateNet):
         ev = self.spike_events[:count].cpu().numpy()
         return ev[np.lexsort((ev[:, 1], ev[:, 0]))]
 
-    def detach(self, requires_grad: bool = False, detach_params: bool = False):
-        pass
-
     def reset(self, y=None, idx=None):
         pop = self._pop
         N = pop.rows
@@ -482,11 +539,24 @@ class SpikeResetNet(RateNet):
         self._y_prev = None
         pop.reset_sampling()
 
-    def _wants_grad(self, x) -> bool:
-        return False
+    def _grad_window(self, steps: int, x: Optional[torch.Tensor]) -> torch.Tensor:
+        """`steps` spiking steps recorded as one autograd node (surrogate-gradient BPTT)."""
+        pop = self._pop
+        y_in = self._y_grad
+        if y_in is None:
+            y_in = torch.cat((pop.v, pop.source_local)).detach().requires_grad_(self._y_requires_grad)
+        traj, y_end = _QifWindow.apply(self, steps, x, y_in, pop.W, pop.params["tau"], pop.params["k"],
+                                       pop.params["eta"], pop.params["tau_s"])
+        self._y_grad = y_end
+        tv, ts = self._last_window
+        self._y_prev = torch.cat((tv[-1], ts[-1]))
+        return traj
 
     def forward(self, x) -> torch.Tensor:
         x2 = self._as_input(x)
+        if self._wants_grad(x2):
+            return self._grad_window(1, x2)[0]
+        self._y_grad = None
         pop = self._pop
         N = pop.rows
         out = torch.empty(1, N, dtype=torch.float32, device=pop.device)
@@ -499,6 +569,7 @@ class SpikeResetNet(RateNet):
 
     def run_window(self, steps: int, x=None, w_in=None, **kw):
         """Fused window; the last step is issued separately so that ``y`` can expose its pre-update state."""
+        self._y_grad = None
         pop = self._pop
         N = pop.rows
         kw.setdefault("spike_events", self.spike_events)
