@@ -80,7 +80,7 @@ def main():
     N, K, Wm = args.neurons, args.steps, args.warmup
     dt = 1e-2
     T_total = Wm + K
-    tt = torch.arange(max(T_total, 1000), device=dev, dtype=torch.float32) * dt
+    tt = torch.arange(max(T_total, 2000), device=dev, dtype=torch.float32) * dt
     x = torch.sin(2 * torch.pi * 0.2 * tt).reshape(-1, 1).contiguous()
     sampling = 100
     n_samples = T_total // sampling + 2
@@ -216,6 +216,7 @@ def facade_fit_bptt(pop, x, N, dev):
     """The same config through the reference-compatible front end: Network.fit_bptt with trainable recurrent
     weights and a gd-trained k=3 readout, SGD, two 1000-step windows (wall clock, includes torch's loss,
     autograd bookkeeping and optimizer step over the 4.3 GB weight matrix)."""
+    import contextlib
     from rectipy_amd import Network
     T, win = 2000, 1000
     gen = torch.Generator(device=dev).manual_seed(3)
@@ -227,11 +228,12 @@ def facade_fit_bptt(pop, x, N, dev):
     net.add_edge("rnn", "out", weights=torch.randn(3, N, generator=gen, device=dev) / N ** 0.5, train="gd")
     inp = x[:T].clone()
     tgt = torch.randn(T, 3, generator=gen, device=dev) * 0.1
-    net.fit_bptt(inp[:100], tgt[:100], optimizer="sgd", lr=1e-4, update_steps=100, sampling_steps=100, verbose=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    obs = net.fit_bptt(inp, tgt, optimizer="sgd", lr=1e-4, update_steps=win, sampling_steps=100, verbose=False)
-    torch.cuda.synchronize()
+    with contextlib.redirect_stdout(sys.stderr):  # fit_bptt prints its elapsed time, as the reference does
+        net.fit_bptt(inp[:100], tgt[:100], optimizer="sgd", lr=1e-4, update_steps=100, sampling_steps=100, verbose=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        obs = net.fit_bptt(inp, tgt, optimizer="sgd", lr=1e-4, update_steps=win, sampling_steps=100, verbose=False)
+        torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     return {"facade_fit_bptt_steps_per_s": T / wall, "facade_fit_bptt_loss": [float(v) for v in obs["loss"][-2:]]}
 

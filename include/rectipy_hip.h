@@ -204,6 +204,10 @@ int rp_outer_accum(int32_t n, int32_t T, float alpha, const float* A, int64_t ld
    the built-in choice.  Results are bit-identical for every configuration. */
 int rp_set_tuning(int rows_per_wave, int unroll, int nontemporal, int max_blocks);
 
+/* Benchmark-only: rows in flight per wave (unroll) and 1-KiB column groups per lane of the adjoint's column-strip
+   kernel; 0, 0 restores the built-in choice.  Results are bit-identical for every configuration. */
+int rp_set_bwd_tuning(int unroll, int strip_groups);
+
 /* Bandwidth probe used by bench.py: sums `bytes` of HBM with the same load shape as the step kernel. */
 int rp_stream_probe(const float* buf, int64_t n_floats, float* out, void* stream);
 

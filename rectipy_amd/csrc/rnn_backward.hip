@@ -69,11 +69,12 @@ struct BwdParams {
 };
 
 // partials[q][j] = sum_{i in chunk q, ascending} W[i][j] * u[i]
-template <bool VEC4, int U>
+// SW = 16-byte column groups per lane: a wave covers a strip of 256*SW columns (SW KiB contiguous per row).
+template <bool VEC4, int U, int SW>
 __global__ __launch_bounds__(kThreads) void wt_partial_kernel(const BwdParams P) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    constexpr int CW = VEC4 ? 256 : 64;  // columns per strip
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row indices and u[i] go scalar
+    constexpr int CW = VEC4 ? 256 * SW : 64;  // columns per strip
     const int strips = (P.n + CW - 1) / CW;
     const int items = strips * P.q;
     for (int item = blockIdx.x * (kThreads / 64) + wave; item < items; item += gridDim.x * (kThreads / 64)) {
@@ -83,37 +84,56 @@ __global__ __launch_bounds__(kThreads) void wt_partial_kernel(const BwdParams P)
         const int i1 = min(i0 + P.rc, P.n);
         const float* __restrict__ u = P.u;
         if constexpr (VEC4) {
-            const int col = strip * 256 + 4 * lane;
-            if (col < P.n) {
-                rp_f4 a = {0.f, 0.f, 0.f, 0.f};
-                const float* wp = P.W + (int64_t)i0 * P.ldw + col;
+            const int col = strip * CW + 4 * lane;
+            bool ok[SW];
+            rp_f4 a[SW];
+#pragma unroll
+            for (int g = 0; g < SW; ++g) {
+                ok[g] = col + 256 * g < P.n;
+                a[g] = rp_f4{0.f, 0.f, 0.f, 0.f};
+            }
+            // out-of-range column groups re-read the first group's address; their sums are discarded
+            const float* wp = P.W + (int64_t)i0 * P.ldw + col;
+            int goff[SW];
+#pragma unroll
+            for (int g = 0; g < SW; ++g) goff[g] = ok[g] ? 256 * g : 0;
+            if (ok[0]) {
                 int i = i0;
                 for (; i + U <= i1; i += U) {
-                    rp_f4 w[U];
+                    rp_f4 w[U][SW];
                     float uu[U];
 #pragma unroll
-                    for (int k = 0; k < U; ++k) w[k] = rp_ld4_stream(wp + (int64_t)k * P.ldw);
+                    for (int k = 0; k < U; ++k)
+#pragma unroll
+                        for (int g = 0; g < SW; ++g) w[k][g] = rp_ld4_stream(wp + (int64_t)k * P.ldw + goff[g]);
 #pragma unroll
                     for (int k = 0; k < U; ++k) uu[k] = u[i + k];
 #pragma unroll
-                    for (int k = 0; k < U; ++k) {
-                        a.x = fmaf(w[k].x, uu[k], a.x);
-                        a.y = fmaf(w[k].y, uu[k], a.y);
-                        a.z = fmaf(w[k].z, uu[k], a.z);
-                        a.w = fmaf(w[k].w, uu[k], a.w);
-                    }
+                    for (int k = 0; k < U; ++k)
+#pragma unroll
+                        for (int g = 0; g < SW; ++g) {
+                            a[g].x = fmaf(w[k][g].x, uu[k], a[g].x);
+                            a[g].y = fmaf(w[k][g].y, uu[k], a[g].y);
+                            a[g].z = fmaf(w[k][g].z, uu[k], a[g].z);
+                            a[g].w = fmaf(w[k][g].w, uu[k], a[g].w);
+                        }
                     wp += (int64_t)U * P.ldw;
                 }
                 for (; i < i1; ++i) {
-                    rp_f4 w = rp_ld4_stream(wp);
                     float uu = u[i];
-                    a.x = fmaf(w.x, uu, a.x);
-                    a.y = fmaf(w.y, uu, a.y);
-                    a.z = fmaf(w.z, uu, a.z);
-                    a.w = fmaf(w.w, uu, a.w);
+#pragma unroll
+                    for (int g = 0; g < SW; ++g) {
+                        rp_f4 w = rp_ld4_stream(wp + goff[g]);
+                        a[g].x = fmaf(w.x, uu, a[g].x);
+                        a[g].y = fmaf(w.y, uu, a[g].y);
+                        a[g].z = fmaf(w.z, uu, a[g].z);
+                        a[g].w = fmaf(w.w, uu, a[g].w);
+                    }
                     wp += P.ldw;
                 }
-                *reinterpret_cast<rp_f4*>(P.partials + (int64_t)chunk * P.n + col) = a;
+#pragma unroll
+                for (int g = 0; g < SW; ++g)
+                    if (ok[g]) *reinterpret_cast<rp_f4*>(P.partials + (int64_t)chunk * P.n + col + 256 * g) = a[g];
             }
         } else {
             const int col = strip * 64 + lane;
@@ -124,6 +144,32 @@ __global__ __launch_bounds__(kThreads) void wt_partial_kernel(const BwdParams P)
             }
         }
     }
+}
+
+// benchmark-only override of (U, SW); 0 = built-in choice (rp_set_bwd_tuning)
+int g_bwd_U = 0, g_bwd_SW = 0;
+
+void launch_wt_partial(const BwdParams& P, bool vec4, hipStream_t st) {
+    if (!vec4) {
+        const int strips = (P.n + 63) / 64;
+        int blocks = (strips * P.q + 3) / 4;
+        hipLaunchKernelGGL((wt_partial_kernel<false, 1, 1>), dim3(blocks > 4096 ? 4096 : blocks), dim3(kThreads), 0, st, P);
+        return;
+    }
+    // measured at n = 32768 (scripts/tune_backward.py): 2-KiB strips with 6 rows in flight stream at 6.84 TB/s,
+    // 1-KiB strips with 8 rows at 6.27 TB/s; small n keeps the narrow strips for more waves.
+    const int U = g_bwd_U ? g_bwd_U : (P.n >= 8192 ? 6 : 8), SW = g_bwd_SW ? g_bwd_SW : (P.n >= 8192 ? 2 : 1);
+    const int strips = (P.n + 256 * SW - 1) / (256 * SW);
+    int blocks = (strips * P.q + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+#define RP_BW(U_, SW_)                                                                                         \
+    if (U == U_ && SW == SW_) {                                                                                \
+        hipLaunchKernelGGL((wt_partial_kernel<true, U_, SW_>), dim3(blocks), dim3(kThreads), 0, st, P);        \
+        return;                                                                                                \
+    }
+    RP_BW(8, 1) RP_BW(16, 1) RP_BW(4, 1) RP_BW(4, 2) RP_BW(8, 2) RP_BW(2, 2) RP_BW(6, 2) RP_BW(32, 1) RP_BW(12, 1) RP_BW(3, 2) RP_BW(5, 2)
+#undef RP_BW
+    hipLaunchKernelGGL((wt_partial_kernel<true, 8, 1>), dim3(blocks), dim3(kThreads), 0, st, P);
 }
 
 __device__ __forceinline__ float act_deriv(const BwdParams& P, int j, float r) {
@@ -296,10 +342,7 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     for (int t = T - 1; t >= 0; --t) {
         P.t = t;
         P.u = b->u_traj + (int64_t)t * b->ld;
-        if (vec4)
-            hipLaunchKernelGGL((wt_partial_kernel<true, 8>), dim3(mblocks), dim3(kThreads), 0, st, P);
-        else
-            hipLaunchKernelGGL((wt_partial_kernel<false, 1>), dim3(mblocks), dim3(kThreads), 0, st, P);
+        launch_wt_partial(P, vec4, st);
         P.v_t = b->traj_v + (int64_t)t * b->ld;
         P.r_t = b->traj_r + (int64_t)t * b->ld;
         P.g_t = b->grad_out ? b->grad_out + (int64_t)t * b->ldg : nullptr;
@@ -310,6 +353,12 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
         hipLaunchKernelGGL(finalize_kernel, dim3(eblocks), dim3(256), 0, st, P);
     }
     RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
+int rp_set_bwd_tuning(int unroll, int strip_groups) {
+    g_bwd_U = unroll;
+    g_bwd_SW = strip_groups;
     return RP_OK;
 }
 
@@ -381,10 +430,7 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     for (int t = T - 1; t >= 0; --t) {
         P.t = t;
         P.u = b->u_traj + (int64_t)t * b->ld;
-        if (vec4)
-            hipLaunchKernelGGL((wt_partial_kernel<true, 8>), dim3(mblocks), dim3(kThreads), 0, st, P);
-        else
-            hipLaunchKernelGGL((wt_partial_kernel<false, 1>), dim3(mblocks), dim3(kThreads), 0, st, P);
+        launch_wt_partial(P, vec4, st);
         P.v_t = b->traj_v + (int64_t)t * b->ld;
         P.g_t = b->grad_out ? b->grad_out + (int64_t)t * b->ldg : nullptr;
         if (t > 0)

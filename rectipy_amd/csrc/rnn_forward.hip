@@ -29,6 +29,11 @@ constexpr int kThreads = kWavesPerBlock * RP_WAVE;
 constexpr int FLAG_BUFFER = 1;  // step >= cutoff: output joins the sampling buffer
 constexpr int FLAG_SAMPLE = 2;  // record mean of the buffer at this step
 
+// Start chunk of the 8-row group g = (global row) >> 3 on the 16-byte path: m0 = (kStagger * g) mod M.
+// Without it all waves march through addresses that are equal modulo the row stride (a power of two at the
+// benchmark sizes) in lock step; rotating the start is worth +3 % of HBM bandwidth.  Part of the summation spec.
+constexpr unsigned kStagger = 3;
+
 struct StepParams {
     const float* W;
     int64_t ldw;
@@ -85,37 +90,42 @@ __device__ __forceinline__ void dot_rows_v4(const StepParams& P, int row_base, i
     for (int j = 0; j < R; ++j) a[j] = rp_f4{0.f, 0.f, 0.f, 0.f};
 
     const int M = P.n >> 8;  // full 256-column chunks
-    int m = 0;
-    for (; m + U <= M; m += U) {
-        rp_f4 rv[U];
-        rp_f4 w[U][R];
+    auto sweep = [&](int mA, int mB) {  // chunks [mA, mB) in ascending order
+        int m = mA;
+        for (; m + U <= mB; m += U) {
+            rp_f4 rv[U];
+            rp_f4 w[U][R];
 #pragma unroll
-        for (int u = 0; u < U; ++u) rv[u] = rp_ld4(sp + (int64_t)(m + u) * 256);
+            for (int u = 0; u < U; ++u) rv[u] = rp_ld4(sp + (int64_t)(m + u) * 256);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int j = 0; j < R; ++j) w[u][j] = ld_w<NT>(wrow[j] + (int64_t)(m + u) * 256);
+                for (int j = 0; j < R; ++j) w[u][j] = ld_w<NT>(wrow[j] + (int64_t)(m + u) * 256);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    a[j].x = fmaf(w[u][j].x, rv[u].x, a[j].x);
+                    a[j].y = fmaf(w[u][j].y, rv[u].y, a[j].y);
+                    a[j].z = fmaf(w[u][j].z, rv[u].z, a[j].z);
+                    a[j].w = fmaf(w[u][j].w, rv[u].w, a[j].w);
+                }
+        }
+        for (; m < mB; ++m) {
+            rp_f4 rv = rp_ld4(sp + (int64_t)m * 256);
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                a[j].x = fmaf(w[u][j].x, rv[u].x, a[j].x);
-                a[j].y = fmaf(w[u][j].y, rv[u].y, a[j].y);
-                a[j].z = fmaf(w[u][j].z, rv[u].z, a[j].z);
-                a[j].w = fmaf(w[u][j].w, rv[u].w, a[j].w);
+                rp_f4 w = ld_w<NT>(wrow[j] + (int64_t)m * 256);
+                a[j].x = fmaf(w.x, rv.x, a[j].x);
+                a[j].y = fmaf(w.y, rv.y, a[j].y);
+                a[j].z = fmaf(w.z, rv.z, a[j].z);
+                a[j].w = fmaf(w.w, rv.w, a[j].w);
             }
-    }
-    for (; m < M; ++m) {
-        rp_f4 rv = rp_ld4(sp + (int64_t)m * 256);
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            rp_f4 w = ld_w<NT>(wrow[j] + (int64_t)m * 256);
-            a[j].x = fmaf(w.x, rv.x, a[j].x);
-            a[j].y = fmaf(w.y, rv.y, a[j].y);
-            a[j].z = fmaf(w.z, rv.z, a[j].z);
-            a[j].w = fmaf(w.w, rv.w, a[j].w);
         }
-    }
+    };
+    const int m0 = M > 0 ? (int)(((unsigned)((P.row0 + row_base) >> 3) * kStagger) % (unsigned)M) : 0;
+    sweep(m0, M);
+    sweep(0, m0);
     if ((M << 8) + 4 * lane < P.n) {  // partial last chunk (n % 4 == 0, so all 4 columns are valid)
         rp_f4 rv = rp_ld4(sp + (int64_t)M * 256);
 #pragma unroll
@@ -304,6 +314,7 @@ int validate_net(const rp_net* net) {
     if (net->n <= 0 || net->rows <= 0 || net->row0 < 0 || (int64_t)net->row0 + net->rows > net->n)
         RP_FAIL(RP_ERR_SHAPE, "bad shard: n=%d rows=%d row0=%d", net->n, net->rows, net->row0);
     if (net->ldw < net->n) RP_FAIL(RP_ERR_SHAPE, "ldw=%lld < n=%d", (long long)net->ldw, net->n);
+    if (net->row0 % 8 != 0) RP_FAIL(RP_ERR_ARG, "row0=%d must be a multiple of 8 (rows are processed in aligned groups)", net->row0);
     if (!net->W || !net->y[RP_Y_V] || !net->src[0] || !net->src[1])
         RP_FAIL(RP_ERR_ARG, "W, y[0], src[0], src[1] must be non-null");
     if (net->src[0] == net->src[1]) RP_FAIL(RP_ERR_ARG, "src[0] and src[1] must be distinct buffers");

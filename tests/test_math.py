@@ -38,6 +38,6 @@ def test_row_dot_tree(oracle_backend):
     for n, vec4 in ((10, 0), (64, 1), (250, 0), (1024, 1), (1000, 1), (4100, 1)):
         w = rng.standard_normal(n).astype(np.float32)
         r = rng.standard_normal(n).astype(np.float32)
-        got = lib.oracle_row_dot(w.ctypes.data, r.ctypes.data, n, vec4)
+        got = lib.oracle_row_dot(w.ctypes.data, r.ctypes.data, n, vec4, 8 * n + 5)
         ref = float(np.dot(w.astype(np.float64), r.astype(np.float64)))
         assert abs(got - ref) <= 1e-5 * np.sqrt(n)
