@@ -87,13 +87,19 @@ def main():
     params = dict(tau=10.0, k=1.0, eta=0.0)
 
     if not use_dist:
+        # single GPU: through the reference-compatible front end (Network.add_diffeq_node / Network.run)
+        from rectipy_amd import Network
         row0, rows = 0, N
-        pop = Population("li_tanh", gen_rows(N, 0, N, dev), params, dt, dev)
-        samples = torch.zeros(n_samples, N, device=dev)
+        net = Network(dt=dt, device=str(dev))
+        net.add_diffeq_node("rnn", "neuron_model_templates.rate_neurons.leaky_integrator.tanh",
+                            input_var="li_op/I_ext", output_var="li_op/v", weights=gen_rows(N, 0, N, dev),
+                            source_var="tanh_op/r", target_var="li_op/r_in", dtype=torch.float32,
+                            node_vars={"all/li_op/tau": 10.0, "all/li_op/k": 1.0, "all/li_op/eta": 0.0})
+        pop = net.get_node("rnn")._pop
 
         def run(steps, step0, idx):
-            return pop.forward(steps, x=x[step0:step0 + steps], step0=step0, sampling_steps=sampling,
-                               samples=samples, sample_idx=idx)
+            obs = net.run(x[step0:step0 + steps], sampling_steps=sampling, verbose=False, enable_grad=False)
+            return len(obs["steps"])
     else:
         from rectipy_amd.sharded import ShardedPopulation, shard_bounds
         row0, rows = shard_bounds(N, world, rank)
@@ -149,7 +155,7 @@ def main():
         "config": {"workload": f"tanh rate RNN N={N} dense W fp32, forward-only Euler, dt=1e-2, sampling_steps=100, "
                                f"broadcast sinusoid input (BASELINE.json configs[1])",
                    "neurons": N, "rows_per_gpu": rows, "parallelism": f"row-shard x{world} + all-gather(r) per step"
-                   if world > 1 else "single GPU"},
+                   if world > 1 else "single GPU, driven through rectipy_amd.Network.run"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": "step_kernel<LI_TANH,R=4,U=2,vec4,nt>", "algorithmic_bytes_per_launch": algo_bytes,
