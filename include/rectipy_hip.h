@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 1
+#define RP_ABI_VERSION 2
 
 #define RP_OK 0
 #define RP_ERR_ARG (-1)      /* null pointer, bad enum, bad flag combination  */
@@ -55,8 +55,12 @@ extern "C" {
 #define RP_MODEL_LI_TANH 0    /* leaky_integrator.yaml: li_op + tanh_op      */
 #define RP_MODEL_LI_SIGMOID 1 /* leaky_integrator.yaml: li_op + sigmoid_op   */
 #define RP_MODEL_QIF 2        /* qif.yaml: qif_op, threshold + reset         */
+#define RP_MODEL_QIF_SFA 3    /* qif.yaml: qif_sfa_op (spike-frequency adaptation x) */
+#define RP_MODEL_LIF 4        /* lif.yaml: lif_op                            */
+#define RP_MODEL_IK 5         /* ik.yaml: ik_op (Izhikevich, recovery variable u) */
+#define RP_MODEL_COUNT 6
 
-#define RP_MAX_PARAMS 8
+#define RP_MAX_PARAMS 12
 #define RP_MAX_STATE 4
 
 /* parameter slots p[] (each a per-neuron vector of length `rows`) */
@@ -66,10 +70,31 @@ extern "C" {
 #define RP_P_RMAX 3  /* LI_SIGMOID */
 #define RP_P_SLOPE 4 /* LI_SIGMOID: s */
 #define RP_P_V0 5    /* LI_SIGMOID */
-#define RP_P_TAU_S 3 /* QIF */
+#define RP_P_TAU_S 3 /* QIF, QIF_SFA, LIF, IK */
+#define RP_P_ALPHA 4 /* QIF_SFA */
+#define RP_P_TAU_X 5 /* QIF_SFA */
+/* IK (ik.yaml:8-31): slot 0 holds C, slot 1 k, slot 2 eta, slot 3 tau_s */
+#define RP_P_IK_C 0
+#define RP_P_V_R 4
+#define RP_P_V_THETA 5
+#define RP_P_G 6
+#define RP_P_E_R 7
+#define RP_P_B 8
+#define RP_P_TAU_U 9
+#define RP_P_KAPPA 10
 
 /* state slots y[] (per-neuron vectors of length `rows`) */
 #define RP_Y_V 0
+#define RP_Y_AUX 1 /* QIF_SFA: adaptation x; IK: recovery u */
+
+/* record slots rec[] */
+#define RP_REC_V 0
+#define RP_REC_SOURCE 1
+#define RP_REC_AUX 2
+
+/* which equation the extrinsic input enters (rp_run.x_target) */
+#define RP_XT_MEMBRANE 0 /* I_ext of the v equation (every model)            */
+#define RP_XT_SYNAPSE 1  /* s_ext of the s equation (LIF, lif.yaml:16)       */
 
 /* input modes */
 #define RP_X_NONE 0  /* I_ext = 0                                             */
@@ -120,6 +145,7 @@ typedef struct rp_run {
     const float* w_in;        /* RP_X_PROJ: [rows x ldwin]                    */
     int64_t ldwin;
     int32_t out_var;          /* RP_OUT_*                                     */
+    int32_t x_target;         /* RP_XT_*                                      */
     int32_t cutoff;
     int32_t sampling_steps;   /* >= 1                                         */
     int32_t max_samples;      /* rows available in samples / rec[]            */
@@ -134,8 +160,8 @@ typedef struct rp_run {
     int32_t sample_idx;       /* [host, in/out] next sample row               */
     float* samples;           /* optional [max_samples x ldsamples]           */
     int64_t ldsamples;
-    float* rec[RP_MAX_STATE]; /* optional [max_samples x ldsamples]: recorded state at sample steps
-                                 (LI: post-update, network.py:147-148; QIF: pre-update, nodes.py:387-392) */
+    float* rec[RP_MAX_STATE]; /* optional [max_samples x ldsamples], slots RP_REC_*: recorded state at sample steps
+                                 (LI: post-update, network.py:147-148; spiking: pre-update, nodes.py:387-392) */
     int32_t* spike_events;    /* optional QIF: (step, global index) int32 pairs */
     int32_t spike_capacity;   /* number of pairs that fit                     */
     int32_t* spike_count;     /* device counter (keeps counting past capacity) */

@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 1
+RP_ABI_VERSION = 2
 
 RP_OK = 0
 RP_ERR_ARG = -1
@@ -16,14 +16,21 @@ RP_ERR_HIP = -4
 RP_MODEL_LI_TANH = 0
 RP_MODEL_LI_SIGMOID = 1
 RP_MODEL_QIF = 2
+RP_MODEL_QIF_SFA = 3
+RP_MODEL_LIF = 4
+RP_MODEL_IK = 5
 
-RP_MAX_PARAMS = 8
+RP_MAX_PARAMS = 12
 RP_MAX_STATE = 4
 
 RP_P_TAU, RP_P_K, RP_P_ETA = 0, 1, 2
 RP_P_RMAX, RP_P_SLOPE, RP_P_V0 = 3, 4, 5
 RP_P_TAU_S = 3
-RP_Y_V = 0
+RP_P_ALPHA, RP_P_TAU_X = 4, 5
+RP_P_IK_C, RP_P_V_R, RP_P_V_THETA, RP_P_G, RP_P_E_R, RP_P_B, RP_P_TAU_U, RP_P_KAPPA = 0, 4, 5, 6, 7, 8, 9, 10
+RP_Y_V, RP_Y_AUX = 0, 1
+RP_REC_V, RP_REC_SOURCE, RP_REC_AUX = 0, 1, 2
+RP_XT_MEMBRANE, RP_XT_SYNAPSE = 0, 1
 
 RP_X_NONE, RP_X_FULL, RP_X_BCAST, RP_X_PROJ = 0, 1, 2, 3
 RP_OUT_STATE0, RP_OUT_SOURCE = 0, 1
@@ -60,6 +67,7 @@ class RpRun(C.Structure):
         ("w_in", fp),
         ("ldwin", C.c_int64),
         ("out_var", C.c_int32),
+        ("x_target", C.c_int32),
         ("cutoff", C.c_int32),
         ("sampling_steps", C.c_int32),
         ("max_samples", C.c_int32),

@@ -47,7 +47,7 @@ struct StepParams {
     const float* x_t;  // row t of the input
     const float* w_in;
     int64_t ldwin;
-    int out_var;
+    int out_var, x_target;
     float* traj_t;
     float* save_state_t[RP_MAX_STATE];
     float* save_src_t;
@@ -204,25 +204,54 @@ template <int MODEL>
 __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum) {
     const int gi = P.row0 + i;
     const float I = input_current(P, i);
-    if constexpr (MODEL == RP_MODEL_QIF) {
-        // SpikeResetNet.forward, nodes.py:382-392; field qif.yaml:11-12
+    if constexpr (MODEL >= RP_MODEL_QIF) {
+        // SpikeResetNet.forward (nodes.py:382-392) with the field of the spiking template:
+        //   QIF      qif.yaml:11-12     v' = (v^2 + eta + I)/tau + k s_in;          s' = -s/tau_s + spike
+        //   QIF_SFA  qif.yaml:25-35     eta -> eta - x;                             x' = -x/tau_x + alpha spike
+        //   LIF      lif.yaml:10-16     v' = -v/tau + k s_in + I + eta;             s' = -s/tau_s + spike + s_ext
+        //   IK       ik.yaml:8-12       v' = (k(v-v_r)(v-v_theta) - u + I + eta + g s_in (E_r - v))/C
+        //                               u' = (b(v-v_r) - u)/tau_u + kappa spike;    s' = -s/tau_s + spike
         const float v = P.y[RP_Y_V][i];
         const float s = P.src_cur[gi];
         const float spike = (v - P.theta >= 0.0f) ? 1.0f : 0.0f;  // heaviside(v-theta, 1): equality spikes
-        const float dv = ((v * v + P.p[RP_P_ETA][i]) + I) / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * wsum;
-        const float ds = -s / P.p[RP_P_TAU_S][i] + spike * P.inv_dt;
+        const float spike_in = spike * P.inv_dt;                   // nodes.py:385
+        float dv, aux = 0.f, aux_new = 0.f;
+        float ds = -s / P.p[RP_P_TAU_S][i] + spike_in;
+        if constexpr (MODEL == RP_MODEL_QIF) {
+            dv = ((v * v + P.p[RP_P_ETA][i]) + I) / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * wsum;
+        } else if constexpr (MODEL == RP_MODEL_QIF_SFA) {
+            aux = P.y[RP_Y_AUX][i];
+            dv = ((v * v + (P.p[RP_P_ETA][i] - aux)) + I) / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * wsum;
+            aux_new = aux + P.dt * (-aux / P.p[RP_P_TAU_X][i] + P.p[RP_P_ALPHA][i] * spike_in);
+        } else if constexpr (MODEL == RP_MODEL_LIF) {
+            const float Iv = P.x_target == RP_XT_MEMBRANE ? I : 0.f;
+            const float Is = P.x_target == RP_XT_SYNAPSE ? I : 0.f;
+            dv = ((-v / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * wsum) + Iv) + P.p[RP_P_ETA][i];
+            ds = ds + Is;
+        } else {  // IK
+            aux = P.y[RP_Y_AUX][i];
+            const float dvr = v - P.p[RP_P_V_R][i];
+            dv = (((((P.p[RP_P_K][i] * dvr) * (v - P.p[RP_P_V_THETA][i]) - aux) + I) + P.p[RP_P_ETA][i]) +
+                  (P.p[RP_P_G][i] * wsum) * (P.p[RP_P_E_R][i] - v)) / P.p[RP_P_IK_C][i];
+            aux_new = aux + P.dt * ((P.p[RP_P_B][i] * dvr - aux) / P.p[RP_P_TAU_U][i] + P.p[RP_P_KAPPA][i] * spike_in);
+        }
         float v_new = v + P.dt * dv;
         const float s_new = s + P.dt * ds;
         v_new = v_new * (1.0f - spike) + spike * P.v_reset;
         P.y[RP_Y_V][i] = v_new;
         P.src_next[gi] = s_new;
+        if constexpr (MODEL == RP_MODEL_QIF_SFA || MODEL == RP_MODEL_IK) {
+            P.y[RP_Y_AUX][i] = aux_new;
+            if (P.save_state_t[RP_Y_AUX]) P.save_state_t[RP_Y_AUX][i] = aux;
+        }
         if (P.save_state_t[0]) P.save_state_t[0][i] = v;
         if (P.save_src_t) P.save_src_t[i] = s;
         if (P.save_acc_t) P.save_acc_t[i] = wsum;
         sample_output(P, i, P.out_var == RP_OUT_STATE0 ? v : s);
         if (P.flags & FLAG_SAMPLE) {  // pre-update state (nodes.py:387-392: .y is never advanced)
-            if (P.rec_row[0]) P.rec_row[0][i] = v;
-            if (P.rec_row[1]) P.rec_row[1][i] = s;
+            if (P.rec_row[RP_REC_V]) P.rec_row[RP_REC_V][i] = v;
+            if (P.rec_row[RP_REC_SOURCE]) P.rec_row[RP_REC_SOURCE][i] = s;
+            if (P.rec_row[RP_REC_AUX]) P.rec_row[RP_REC_AUX][i] = aux;
         }
         if (spike != 0.0f && P.spike_count) {
             int slot = atomicAdd(P.spike_count, 1);
@@ -300,8 +329,15 @@ int n_params_required(int model, int* idx, int cap) {
         idx[c++] = RP_P_RMAX;
         idx[c++] = RP_P_SLOPE;
         idx[c++] = RP_P_V0;
-    } else if (model == RP_MODEL_QIF) {
+    } else if (model == RP_MODEL_QIF || model == RP_MODEL_LIF) {
         idx[c++] = RP_P_TAU_S;
+    } else if (model == RP_MODEL_QIF_SFA) {
+        idx[c++] = RP_P_TAU_S;
+        idx[c++] = RP_P_ALPHA;
+        idx[c++] = RP_P_TAU_X;
+    } else if (model == RP_MODEL_IK) {
+        const int ik[] = {RP_P_TAU_S, RP_P_V_R, RP_P_V_THETA, RP_P_G, RP_P_E_R, RP_P_B, RP_P_TAU_U, RP_P_KAPPA};
+        for (int q : ik) idx[c++] = q;
     }
     (void)cap;
     return c;
@@ -309,8 +345,10 @@ int n_params_required(int model, int* idx, int cap) {
 
 int validate_net(const rp_net* net) {
     if (!net) RP_FAIL(RP_ERR_ARG, "net is null");
-    if (net->model < RP_MODEL_LI_TANH || net->model > RP_MODEL_QIF)
+    if (net->model < RP_MODEL_LI_TANH || net->model >= RP_MODEL_COUNT)
         RP_FAIL(RP_ERR_ARG, "unknown model id %d", net->model);
+    if ((net->model == RP_MODEL_QIF_SFA || net->model == RP_MODEL_IK) && !net->y[RP_Y_AUX])
+        RP_FAIL(RP_ERR_ARG, "model %d needs the second state vector y[1]", net->model);
     if (net->n <= 0 || net->rows <= 0 || net->row0 < 0 || (int64_t)net->row0 + net->rows > net->n)
         RP_FAIL(RP_ERR_SHAPE, "bad shard: n=%d rows=%d row0=%d", net->n, net->rows, net->row0);
     if (net->ldw < net->n) RP_FAIL(RP_ERR_SHAPE, "ldw=%lld < n=%d", (long long)net->ldw, net->n);
@@ -389,7 +427,10 @@ void launch_step_model(int model, const StepParams& P, hipStream_t st) {
     switch (model) {
         case RP_MODEL_LI_TANH: launch_step<RP_MODEL_LI_TANH, VEC4>(P, st); break;
         case RP_MODEL_LI_SIGMOID: launch_step<RP_MODEL_LI_SIGMOID, VEC4>(P, st); break;
-        default: launch_step<RP_MODEL_QIF, VEC4>(P, st); break;
+        case RP_MODEL_QIF: launch_step<RP_MODEL_QIF, VEC4>(P, st); break;
+        case RP_MODEL_QIF_SFA: launch_step<RP_MODEL_QIF_SFA, VEC4>(P, st); break;
+        case RP_MODEL_LIF: launch_step<RP_MODEL_LIF, VEC4>(P, st); break;
+        default: launch_step<RP_MODEL_IK, VEC4>(P, st); break;
     }
 }
 
@@ -420,7 +461,7 @@ int rp_device_check(int device) {
 int rp_refresh_source(const rp_net* net, void* stream) {
     int rc = validate_net(net);
     if (rc != RP_OK) return rc;
-    if (net->model == RP_MODEL_QIF) return RP_OK;
+    if (net->model >= RP_MODEL_QIF) return RP_OK;
     StepParams P = {};
     fill_static(P, net);
     P.src_next = net->src[net->cur];
@@ -443,6 +484,8 @@ int rp_forward(rp_net* net, rp_run* run, void* stream) {
     if (run->cutoff < 0 || run->step0 < 0) RP_FAIL(RP_ERR_ARG, "cutoff/step0 must be >= 0");
     if (run->out_var != RP_OUT_STATE0 && run->out_var != RP_OUT_SOURCE)
         RP_FAIL(RP_ERR_ARG, "bad out_var %d", run->out_var);
+    if (run->x_target != RP_XT_MEMBRANE && !(run->x_target == RP_XT_SYNAPSE && net->model == RP_MODEL_LIF))
+        RP_FAIL(RP_ERR_ARG, "x_target %d is not available for model %d", run->x_target, net->model);
     switch (run->x_mode) {
         case RP_X_NONE: break;
         case RP_X_FULL:
@@ -491,6 +534,7 @@ int rp_forward(rp_net* net, rp_run* run, void* stream) {
     P.w_in = run->w_in;
     P.ldwin = run->ldwin;
     P.out_var = run->out_var;
+    P.x_target = run->x_target;
     P.acc = run->acc;
     P.spike_events = run->spike_events;
     P.spike_capacity = run->spike_capacity;

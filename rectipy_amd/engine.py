@@ -18,7 +18,10 @@ import torch
 from . import _abi
 from ._abi import RpBwd, RpNet, RpRun
 
-MODEL_IDS = {"li_tanh": _abi.RP_MODEL_LI_TANH, "li_sigmoid": _abi.RP_MODEL_LI_SIGMOID, "qif": _abi.RP_MODEL_QIF}
+MODEL_IDS = {"li_tanh": _abi.RP_MODEL_LI_TANH, "li_sigmoid": _abi.RP_MODEL_LI_SIGMOID, "qif": _abi.RP_MODEL_QIF,
+             "qif_sfa": _abi.RP_MODEL_QIF_SFA, "lif": _abi.RP_MODEL_LIF, "ik": _abi.RP_MODEL_IK}
+SPIKING = ("qif", "qif_sfa", "lif", "ik")   # source vector is the state variable s, threshold + reset on v
+HAS_AUX = ("qif_sfa", "ik")                 # second per-neuron state: adaptation x / recovery u
 
 # parameter name -> slot, per model (names follow the YAML templates of the reference)
 PARAM_SLOTS = {
@@ -26,6 +29,12 @@ PARAM_SLOTS = {
     "li_sigmoid": {"tau": _abi.RP_P_TAU, "k": _abi.RP_P_K, "eta": _abi.RP_P_ETA,
                    "r_max": _abi.RP_P_RMAX, "s": _abi.RP_P_SLOPE, "v0": _abi.RP_P_V0},
     "qif": {"tau": _abi.RP_P_TAU, "k": _abi.RP_P_K, "eta": _abi.RP_P_ETA, "tau_s": _abi.RP_P_TAU_S},
+    "qif_sfa": {"tau": _abi.RP_P_TAU, "k": _abi.RP_P_K, "eta": _abi.RP_P_ETA, "tau_s": _abi.RP_P_TAU_S,
+                "alpha": _abi.RP_P_ALPHA, "tau_x": _abi.RP_P_TAU_X},
+    "lif": {"tau": _abi.RP_P_TAU, "k": _abi.RP_P_K, "eta": _abi.RP_P_ETA, "tau_s": _abi.RP_P_TAU_S},
+    "ik": {"C": _abi.RP_P_IK_C, "k": _abi.RP_P_K, "eta": _abi.RP_P_ETA, "tau_s": _abi.RP_P_TAU_S,
+           "v_r": _abi.RP_P_V_R, "v_theta": _abi.RP_P_V_THETA, "g": _abi.RP_P_G, "E_r": _abi.RP_P_E_R,
+           "b": _abi.RP_P_B, "tau_u": _abi.RP_P_TAU_U, "kappa": _abi.RP_P_KAPPA},
 }
 
 
@@ -98,7 +107,7 @@ class Population:
 
     def __init__(self, model: str, weights, params: Dict[str, object], dt: float, device,
                  v0=None, s0=None, theta: float = 100.0, v_reset: float = -100.0,
-                 n: Optional[int] = None, row0: int = 0, backend=None):
+                 n: Optional[int] = None, row0: int = 0, backend=None, aux0=None):
         if model not in MODEL_IDS:
             raise ValueError(f"unknown model '{model}'; available: {sorted(MODEL_IDS)}")
         self.model = model
@@ -132,9 +141,11 @@ class Population:
             self.params[name] = self._vec(params[name])
 
         self.v = self._vec(0.0 if v0 is None else v0)
+        self.aux = self._vec(0.0 if aux0 is None else aux0) if model in HAS_AUX else None
+        self.spiking = model in SPIKING
         self.src = [torch.zeros(self.n, **f32), torch.zeros(self.n, **f32)]
         self.cur = 0
-        if model == "qif":
+        if self.spiking:
             self.set_source_local(self._vec(0.0 if s0 is None else s0))
         else:
             self.refresh()
@@ -163,6 +174,8 @@ class Population:
         for name, slot in PARAM_SLOTS[self.model].items():
             net.p[slot] = self.params[name].data_ptr()
         net.y[_abi.RP_Y_V] = self.v.data_ptr()
+        if self.aux is not None:
+            net.y[_abi.RP_Y_AUX] = self.aux.data_ptr()
         net.src[0] = self.src[0].data_ptr()
         net.src[1] = self.src[1].data_ptr()
         net.cur = self.cur
@@ -186,7 +199,7 @@ class Population:
 
     def refresh(self):
         """Recompute the derived source r = act(v) after v was changed from the host."""
-        if self.model != "qif":
+        if not self.spiking:
             self.backend.refresh_source(self._net(), self.device)
 
     def set_weights(self, W: torch.Tensor):
@@ -205,7 +218,8 @@ class Population:
                 samples: Optional[torch.Tensor] = None, sample_idx: int = 0, rec: Optional[dict] = None,
                 traj: Optional[torch.Tensor] = None, save_v: Optional[torch.Tensor] = None,
                 save_src: Optional[torch.Tensor] = None, save_acc: Optional[torch.Tensor] = None,
-                spike_events: Optional[torch.Tensor] = None, spike_count: Optional[torch.Tensor] = None) -> int:
+                spike_events: Optional[torch.Tensor] = None, spike_count: Optional[torch.Tensor] = None,
+                x_target: int = _abi.RP_XT_MEMBRANE, save_aux: Optional[torch.Tensor] = None) -> int:
         """Integrate ``steps`` Euler steps in one library call.  Returns the next sample index.
 
         x: None | [steps, rows] | [steps, 1] | [steps, m] together with ``w_in`` [rows, m].
@@ -239,6 +253,7 @@ class Population:
             else:
                 raise RuntimeError(f"input of width {x.shape[1]} does not match the {self.rows} neurons of the population")
         run.out_var = out_var
+        run.x_target = int(x_target)
         run.cutoff = int(cutoff)
         run.sampling_steps = int(sampling_steps)
 
@@ -252,14 +267,14 @@ class Population:
 
         run.traj, run.ldtraj = rowbuf(traj, "traj", steps)
         ld_save = 0
-        for t, field in ((save_v, None), (save_src, "save_src"), (save_acc, "save_acc")):
+        for t, field in ((save_v, 0), (save_aux, 1), (save_src, "save_src"), (save_acc, "save_acc")):
             p, ld = rowbuf(t, "save buffer", steps)
             if p is not None:
                 if ld_save and ld != ld_save:
                     raise RuntimeError("all save buffers must share one leading dimension")
                 ld_save = ld
-                if field is None:
-                    run.save_state[0] = p
+                if isinstance(field, int):
+                    run.save_state[field] = p
                 else:
                     setattr(run, field, p)
         run.ldsave = ld_save
@@ -319,9 +334,11 @@ class Population:
         b.grad_tau, b.grad_k, b.grad_eta = _ptr(grad_tau), _ptr(grad_k), _ptr(grad_eta)
         b.grad_x = _ptr(grad_x)
         b.ldgx = 0 if grad_x is None else (grad_x.stride(0) if T > 1 else grad_x.shape[1])
-        if self.model != "qif":
+        if not self.spiking:
             self.backend.rate_backward(self._net(), b, self.device)
             return partials  # returned so the caller keeps it alive until the stream has consumed it
+        if self.model != "qif":
+            raise NotImplementedError(f"no adjoint kernel for the '{self.model}' model yet")
         b.lam2 = lam_s.data_ptr()
         b.grad_tau_s = _ptr(grad_tau_s)
         b.slope = float(slope)

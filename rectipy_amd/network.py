@@ -330,10 +330,13 @@ class Network:
         state_names = [s for s, _ in rnn._template.state]
         for _, var in rec_vars:
             name = self._relabel_var(var)
-            if name == state_names[0]:
+            first = rnn._template.reset_var if rnn._template.spike_var else state_names[0]
+            if name == first:
                 slots.append(0)
             elif name == rnn._template.source_var:
                 slots.append(1)
+            elif name == getattr(rnn, "_aux_name", None):
+                slots.append(2)
             else:
                 return None
         return slots

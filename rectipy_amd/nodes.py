@@ -203,9 +203,15 @@ class RateNet:
             raise ValueError("the dense-recurrence engine needs the `weights` matrix of the population")
         eng_params = {template.engine_names[p]: values[p] for p, _ in template.params}
         kw = {}
+        # which state variable lives where in the engine: v (reset / first state), s (the source), aux (x or u)
+        self._aux_name = None
         if self._spiking:
-            kw = dict(v0=values[state_names[0]], s0=values[state_names[1]],
+            aux = [s for s in state_names if s not in (template.reset_var, template.source_var)]
+            self._aux_name = aux[0] if aux else None
+            kw = dict(v0=values[template.reset_var], s0=values[template.source_var],
                       theta=kwargs.pop("spike_threshold", 1e2), v_reset=kwargs.pop("spike_reset", -1e2))
+            if self._aux_name:
+                kw["aux0"] = values[self._aux_name]
         else:
             kw = dict(v0=values[state_names[0]])
         self._pop = Population(template.model, weights, eng_params, dt, device, backend=backend, **kw)
@@ -221,13 +227,19 @@ class RateNet:
             if var in self._param_map:
                 self._param_map[key] = self._param_map[var]
         self._var_map = {name: (i * N, (i + 1) * N) for i, name in enumerate(state_names)}
-        if input_var != template.input_var:
+        self._x_target = _abi.RP_XT_MEMBRANE
+        if template.alt_input_var and input_var == template.alt_input_var:
+            self._x_target = _abi.RP_XT_SYNAPSE  # lif.yaml:16: s_ext enters the synaptic equation
+        elif input_var != template.input_var:
             if input_var in self._param_map or input_var in self._var_map or input_var == template.target_var:
                 raise NotImplementedError(f"input_var='{input_var}': the kernels add extrinsic input to "
                                           f"'{template.input_var}' only")
             raise KeyError(f"Variable {input_var} was not found on template '{template.name}'.")
         if output_var in self._var_map:
-            self._out_code = _abi.RP_OUT_STATE0 if output_var == state_names[0] else _abi.RP_OUT_SOURCE
+            if output_var == self._aux_name:
+                raise NotImplementedError(f"output_var='{output_var}': the kernels emit v or the synaptic variable")
+            first = template.reset_var if self._spiking else state_names[0]
+            self._out_code = _abi.RP_OUT_STATE0 if output_var == first else _abi.RP_OUT_SOURCE
         elif output_var in template.derived:
             self._out_code = _abi.RP_OUT_SOURCE
         else:
@@ -481,26 +493,40 @@ class SpikeResetNet(RateNet):
                                     target_var=target_var, train_params=train_params, **kwargs)
 
     def _check_trainable(self):
-        ok = {"weights", "tau", "k", "eta", "tau_s"}
+        ok = {"weights", "tau", "k", "eta", "tau_s"} if self._template.model == "qif" else set()
         bad = [n for n in self._train_names if n not in ok]
         if bad:
-            raise NotImplementedError(f"no adjoint kernel for parameters {bad}; trainable: {sorted(ok)}")
+            raise NotImplementedError(f"no adjoint kernel for parameters {bad} of template '{self._template.name}'; "
+                                      f"trainable: {sorted(ok)}")
 
     def _tensor(self, engine_name: str) -> torch.Tensor:
         if engine_name == "spike":
             raise KeyError("the spike input is internal to the fused kernel")
         return super()._tensor(engine_name)
 
+    def _pack(self, v, s, aux=None) -> torch.Tensor:
+        """cat of the engine's (v, s, aux) vectors in the template's state-vector order."""
+        parts = {self._template.reset_var: v, self._template.source_var: s}
+        if self._aux_name:
+            parts[self._aux_name] = aux
+        return torch.cat([parts[name] for name, _ in self._template.state])
+
+    def _state_bufs(self, rows: int = 1):
+        """Scratch rows that receive the pre-update (v, s, aux) of a step."""
+        pop = self._pop
+        mk = lambda: torch.empty(rows, pop.rows, dtype=torch.float32, device=pop.device)
+        return mk(), mk(), (mk() if self._aux_name else None)
+
     @property
     def y(self) -> torch.Tensor:
         if self._y_prev is not None:
             return self._y_prev
-        return torch.cat((self._pop.v, self._pop.source_local))
+        return self.current_state
 
     @property
     def current_state(self) -> torch.Tensor:
-        """cat(v, s) after the last step (what the reference keeps in _y_start/_y_spike/_y_stop)."""
-        return torch.cat((self._pop.v, self._pop.source_local))
+        """State after the last step (what the reference keeps in _y_start/_y_spike/_y_stop), in template order."""
+        return self._pack(self._pop.v, self._pop.source_local, self._pop.aux)
 
     def enable_spike_recording(self, capacity: int):
         """Allocate a device buffer for (step, neuron) spike events."""
@@ -521,27 +547,37 @@ class SpikeResetNet(RateNet):
     def reset(self, y=None, idx=None):
         pop = self._pop
         N = pop.rows
+        total = len(self._template.state) * N
         with torch.no_grad():
-            cur = torch.cat((pop.v, pop.source_local)) if self._y_prev is None else self._y_prev.clone()
+            cur = self.y.clone()
             if y is None:
-                new = torch.zeros(2 * N, dtype=torch.float32, device=pop.device)
+                new = torch.zeros(total, dtype=torch.float32, device=pop.device)
             else:
                 new = torch.as_tensor(y).detach().to(dtype=torch.float32, device=pop.device).reshape(-1).clone()
             if idx is None:
-                if new.numel() != 2 * N:
-                    raise RuntimeError(f"state has {2 * N} entries, got {new.numel()}")
+                if new.numel() != total:
+                    raise RuntimeError(f"state has {total} entries, got {new.numel()}")
                 cur = new
             else:
                 index = torch.as_tensor(np.asarray(idx), dtype=torch.long, device=pop.device)
                 cur[index] = new
-            pop.v.copy_(cur[:N])
-            pop.set_source_local(cur[N:])
+            for name in (n for n, _ in self._template.state):
+                lo, hi = self._var_map[name]
+                if name == self._template.reset_var:
+                    pop.v.copy_(cur[lo:hi])
+                elif name == self._template.source_var:
+                    pop.set_source_local(cur[lo:hi])
+                else:
+                    pop.aux.copy_(cur[lo:hi])
         self._y_prev = None
+        self._y_grad = None
         pop.reset_sampling()
 
     def _grad_window(self, steps: int, x: Optional[torch.Tensor]) -> torch.Tensor:
         """`steps` spiking steps recorded as one autograd node (surrogate-gradient BPTT)."""
         pop = self._pop
+        if pop.model != "qif":
+            raise NotImplementedError(f"surrogate-gradient BPTT is implemented for the qif template only, not '{pop.model}'")
         y_in = self._y_grad
         if y_in is None:
             y_in = torch.cat((pop.v, pop.source_local)).detach().requires_grad_(self._y_requires_grad)
@@ -560,11 +596,10 @@ class SpikeResetNet(RateNet):
         pop = self._pop
         N = pop.rows
         out = torch.empty(1, N, dtype=torch.float32, device=pop.device)
-        sv = torch.empty(1, N, dtype=torch.float32, device=pop.device)
-        ss = torch.empty(1, N, dtype=torch.float32, device=pop.device)
-        pop.forward(1, x=x2, traj=out, save_v=sv, save_src=ss, out_var=self._out_code,
-                    spike_events=self.spike_events, spike_count=self._spike_count)
-        self._y_prev = torch.cat((sv[0], ss[0]))
+        sv, ss, sa = self._state_bufs()
+        pop.forward(1, x=x2, traj=out, save_v=sv, save_src=ss, save_aux=sa, out_var=self._out_code,
+                    x_target=self._x_target, spike_events=self.spike_events, spike_count=self._spike_count)
+        self._y_prev = self._pack(sv[0], ss[0], None if sa is None else sa[0])
         return out[0]
 
     def run_window(self, steps: int, x=None, w_in=None, **kw):
@@ -574,6 +609,7 @@ class SpikeResetNet(RateNet):
         N = pop.rows
         kw.setdefault("spike_events", self.spike_events)
         kw.setdefault("spike_count", self._spike_count)
+        kw.setdefault("x_target", self._x_target)
         step0 = kw.pop("step0", 0)
         idx = kw.pop("sample_idx", 0)
 
@@ -584,10 +620,9 @@ class SpikeResetNet(RateNet):
         if steps > 1:
             idx = pop.forward(steps - 1, x=rows(x, 0, steps - 1), w_in=w_in, out_var=self._out_code, step0=step0,
                               sample_idx=idx, traj=rows(traj, 0, steps - 1), **kw)
-        sv = torch.empty(1, N, dtype=torch.float32, device=pop.device)
-        ss = torch.empty(1, N, dtype=torch.float32, device=pop.device)
+        sv, ss, sa = self._state_bufs()
         idx = pop.forward(1, x=rows(x, steps - 1, steps), w_in=w_in, out_var=self._out_code,
                           step0=step0 + steps - 1, sample_idx=idx, traj=rows(traj, steps - 1, steps),
-                          save_v=sv, save_src=ss, **kw)
-        self._y_prev = torch.cat((sv[0], ss[0]))
+                          save_v=sv, save_src=ss, save_aux=sa, **kw)
+        self._y_prev = self._pack(sv[0], ss[0], None if sa is None else sa[0])
         return idx

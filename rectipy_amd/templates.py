@@ -8,9 +8,11 @@ paths and ``<operator>/<variable>`` names onto them.  Equations, variable names 
 default values are those of the reference's YAML files:
 
   neuron_model_templates/rate_neurons/leaky_integrator.yaml:8-36  (li_op, sigmoid_op, tanh_op)
-  neuron_model_templates/spiking_neurons/qif.yaml:8-22            (qif_op)
+  neuron_model_templates/spiking_neurons/qif.yaml:8-35            (qif_op, qif_sfa_op)
+  neuron_model_templates/spiking_neurons/lif.yaml:10-23           (lif_op)
+  neuron_model_templates/spiking_neurons/ik.yaml:8-31             (ik_op)
 
-Anything else (lif, ik, qif_sfa, user YAML, PyRates template objects) raises -- there is
+Anything else (the mean-field IK variants, user YAML, PyRates template objects) raises -- there is
 no silent fallback to a generic interpreter.
 """
 from dataclasses import dataclass, field
@@ -29,6 +31,7 @@ class Template:
     derived: Tuple[str, ...] = ()   # non-state outputs computed from the state (r = act(v))
     spike_var: str = ""             # spiking models: input that receives spike/dt
     reset_var: str = ""             # spiking models: state variable that is reset
+    alt_input_var: str = ""         # LIF: extrinsic input into the synaptic equation (s_ext)
     engine_names: Dict[str, str] = field(default_factory=dict)  # "<op>/<var>" -> engine parameter name
 
 
@@ -57,8 +60,36 @@ _FILES: Dict[str, Dict[str, Template]] = {
     },
 }
 
+_FILES["qif"]["qif_sfa"] = Template(
+    # qif.yaml:25-35: qif_op with eta -> eta - x and x' = -x/tau_x + alpha*spike; state order v, s, x
+    name="qif_sfa", model="qif_sfa", state=(("qif_sfa_op/v", -2.0), ("qif_sfa_op/s", 0.0), ("qif_sfa_op/x", 0.0)),
+    params=(("qif_sfa_op/tau", 1.0), ("qif_sfa_op/k", 1.0), ("qif_sfa_op/tau_s", 1.0), ("qif_sfa_op/eta", -5.0),
+            ("qif_sfa_op/alpha", 1.0), ("qif_sfa_op/tau_x", 10.0)),
+    input_var="qif_sfa_op/I_ext", target_var="qif_sfa_op/s_in", source_var="qif_sfa_op/s",
+    spike_var="qif_sfa_op/spike", reset_var="qif_sfa_op/v",
+    engine_names={"qif_sfa_op/tau": "tau", "qif_sfa_op/k": "k", "qif_sfa_op/tau_s": "tau_s", "qif_sfa_op/eta": "eta",
+                  "qif_sfa_op/alpha": "alpha", "qif_sfa_op/tau_x": "tau_x"})
+_FILES["lif"] = {"lif": Template(
+    # lif.yaml:10-23 (li_op with k*r_in -> k*s_in, plus s' = -s/tau_s + spike + s_ext); state order v, s
+    name="lif", model="lif", state=(("lif_op/v", 0.0), ("lif_op/s", 0.0)),
+    params=(("lif_op/tau", 10.0), ("lif_op/k", 1.0), ("lif_op/eta", 0.0), ("lif_op/tau_s", 0.5)),
+    input_var="lif_op/I_ext", target_var="lif_op/s_in", source_var="lif_op/s", spike_var="lif_op/spike",
+    reset_var="lif_op/v", alt_input_var="lif_op/s_ext",
+    engine_names={"lif_op/tau": "tau", "lif_op/k": "k", "lif_op/eta": "eta", "lif_op/tau_s": "tau_s"})}
+_FILES["ik"] = {"ik": Template(
+    # ik.yaml:8-31; state order v, u, s
+    name="ik", model="ik", state=(("ik_op/v", -60.0), ("ik_op/u", 0.0), ("ik_op/s", 0.0)),
+    params=(("ik_op/C", 100.0), ("ik_op/k", 0.7), ("ik_op/v_r", -60.0), ("ik_op/v_theta", -40.0), ("ik_op/eta", 0.0),
+            ("ik_op/g", 1.0), ("ik_op/E_r", 0.0), ("ik_op/b", -2.0), ("ik_op/tau_u", 33.33), ("ik_op/kappa", 10.0),
+            ("ik_op/tau_s", 6.0)),
+    input_var="ik_op/I_ext", target_var="ik_op/s_in", source_var="ik_op/s", spike_var="ik_op/spike",
+    reset_var="ik_op/v",
+    engine_names={"ik_op/C": "C", "ik_op/k": "k", "ik_op/v_r": "v_r", "ik_op/v_theta": "v_theta", "ik_op/eta": "eta",
+                  "ik_op/g": "g", "ik_op/E_r": "E_r", "ik_op/b": "b", "ik_op/tau_u": "tau_u", "ik_op/kappa": "kappa",
+                  "ik_op/tau_s": "tau_s"})}
+
 # templates that exist in the reference's YAML files but have no kernel here yet
-_KNOWN_UNSUPPORTED = {"qif": ("qif_sfa",), "lif": ("lif",), "ik": ("ik", "ik_theta", "ik_nodim", "ik_eta")}
+_KNOWN_UNSUPPORTED = {"ik": ("iku", "ik_biexp"), "qif": ("qif_reset",)}
 
 
 def resolve(path) -> Template:
