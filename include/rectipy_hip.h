@@ -23,6 +23,7 @@
  *                        Network._bptt_step         rectipy/network.py:1123-1130
  *   rp_outer_accum    <- the per-step outer-product accumulation autograd does
  *                        for `weights @ r`          (same call site)
+ *   rp_rls_sweep      <- RLS.update                 rectipy/edges.py:227-234
  *
  * All functions return RP_OK (0) or a negative RP_ERR_* code;
  * rp_last_error() returns a thread-local description of the last failure.
@@ -224,6 +225,28 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* bwd, void* stream);
 /* C[n x n] (ldc) += alpha * A^T B with A = [T x n] (lda), B = [T x n] (ldb): MFMA f32 GEMM. */
 int rp_outer_accum(int32_t n, int32_t T, float alpha, const float* A, int64_t lda, const float* B,
                    int64_t ldb, float* C, int64_t ldc, void* stream);
+
+/*
+ * Recursive-least-squares training of a readout edge (reference RLS.update, rectipy/edges.py:227-234, driven by
+ * Network._rls, rectipy/network.py:1093-1121).  P is the n_in x n_in state-error correlation matrix.
+ */
+typedef struct rp_rls {
+    int32_t n_in, n_out;
+    int64_t ldp, ldw;
+    float* P;        /* [n_in x ldp] in/out                                                   */
+    float* W;        /* [n_out x ldw] readout weights in/out                                   */
+    float beta_inv;  /* 1 / forgetting rate (edges.py:220)                                     */
+    float* z;        /* scratch [n_in], 16-byte aligned                                        */
+    float* zn;       /* scratch [n_in], 16-byte aligned                                        */
+    float* scratch;  /* scratch [4 + n_out]                                                    */
+} rp_rls;
+
+/* `steps` consecutive rows of X [steps x ldx] (edge inputs) and Y [steps x ldy] (targets); an update happens at
+   rows 0, stride, 2*stride, ...  pred[t] = W x_t with the weights in force at step t (before the update at an update
+   step); loss[t] = squared error of the most recent update.  The rank-1 update of P is fused with the mat-vec of
+   the next update step (8 n_in^2 bytes of HBM traffic per update). */
+int rp_rls_sweep(const rp_rls* rls, int32_t steps, int32_t stride, const float* X, int64_t ldx, const float* Y,
+                 int64_t ldy, float* pred, int64_t ldpred, float* loss, void* stream);
 
 /* Benchmark-only: override the streaming configuration of the tanh step kernel
    (rows per wave, unroll depth, non-temporal W loads, grid cap); rows_per_wave = 0 restores

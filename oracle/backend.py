@@ -22,7 +22,7 @@ _LIB = None
 def build(force=False):
     src = os.path.join(HERE, "rnn_oracle.c")
     inc = os.path.join(os.path.dirname(HERE), "include")
-    deps = [src, os.path.join(HERE, "Makefile")] + [os.path.join(inc, f) for f in os.listdir(inc)]
+    deps = [src, os.path.join(HERE, "rls_oracle.c"), os.path.join(HERE, "Makefile")] + [os.path.join(inc, f) for f in os.listdir(inc)]
     stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps)
     if stale:
         if force and os.path.exists(LIB_PATH):
@@ -65,6 +65,9 @@ class OracleBackend:
 
     def outer_accum(self, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
         assert self.lib.oracle_outer_accum(n, T, alpha, A, lda, B, ldb, Cmat, ldc) == 0
+
+    def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
+        assert self.lib.oracle_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss) == 0
 
     def partial_rows(self, n):
         rc = max(8, ((n + 31) // 32 + 7) & ~7)

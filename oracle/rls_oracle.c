@@ -1,0 +1,105 @@
+/*
+ * rls_oracle.c -- CPU oracle of the recursive-least-squares readout update (TEST INFRASTRUCTURE ONLY).
+ *
+ * Restates RLS.update (reference rectipy/edges.py:227-234) as driven by Network._rls
+ * (rectipy/network.py:1093-1121):
+ *     z = beta^-1 P x;  k = 1/(1 + x.z);  W += outer(k (y - W x), z);  P -= k z z^T;  loss = |y - W x|^2
+ * with the summation trees of rectipy_amd/csrc/rls.hip so that the HIP result can be compared bit for bit.
+ * Pinned against golden vectors from the reference in tests/test_rls.py (G14).
+ */
+#include <math.h>
+#include <string.h>
+
+#include "rectipy_hip.h"
+
+static float butterfly64(float* s) {
+    float t[64];
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; ++l) t[l] = s[l] + s[l ^ off];
+        memcpy(s, t, sizeof t);
+    }
+    return s[0];
+}
+
+/* 1024 strided partial sums combined by a halving tree (rls_scalars_kernel) */
+static float block_dot(const float* a, const float* b, int n) {
+    static float red[1024];
+#pragma omp threadprivate(red)
+    for (int t = 0; t < 1024; ++t) red[t] = 0.0f;
+    for (int j = 0; j < n; ++j) red[j & 1023] = fmaf(a[j], b[j], red[j & 1023]);
+    for (int off = 512; off >= 1; off >>= 1)
+        for (int t = 0; t < off; ++t) red[t] = red[t] + red[t + off];
+    return red[0];
+}
+
+static float wave_dot(const float* a, const float* b, int n) { /* rls_predict_kernel */
+    float s[64];
+    for (int l = 0; l < 64; ++l) s[l] = 0.0f;
+    for (int j = 0; j < n; ++j) s[j & 63] = fmaf(a[j], b[j], s[j & 63]);
+    return butterfly64(s);
+}
+
+/* fused pass: optional rank-1 update of row i, then its dot with x_next */
+static float pass_row(float* p, int n, int vec4, int update, float kz, const float* z, const float* x_next) {
+    float s[64];
+    if (update)
+        for (int j = 0; j < n; ++j) p[j] = p[j] - kz * z[j];
+    if (!x_next) return 0.0f;
+    if (vec4) {
+        float a[256];
+        for (int q = 0; q < 256; ++q) a[q] = 0.0f;
+        for (int j = 0; j < n; ++j) a[j & 255] = fmaf(p[j], x_next[j], a[j & 255]);
+        for (int l = 0; l < 64; ++l) s[l] = (a[4 * l] + a[4 * l + 1]) + (a[4 * l + 2] + a[4 * l + 3]);
+    } else {
+        for (int l = 0; l < 64; ++l) s[l] = 0.0f;
+        for (int j = 0; j < n; ++j) s[j & 63] = fmaf(p[j], x_next[j], s[j & 63]);
+    }
+    return butterfly64(s);
+}
+
+int oracle_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, const float* X, int64_t ldx, const float* Y,
+                     int64_t ldy, float* pred, int64_t ldpred, float* loss) {
+    const int n = r->n_in, m = r->n_out;
+    if (steps == 0) return RP_OK;
+    const int vec4 = (n % 4 == 0) && (r->ldp % 4 == 0) && (ldx % 4 == 0);
+    float* za = r->z;
+    float* zb = r->zn;
+    float* err = r->scratch + 4;
+    for (int i = 0; i < n; ++i) za[i] = r->beta_inv * pass_row(r->P + (int64_t)i * r->ldp, n, vec4, 0, 0.0f, 0, X);
+    for (int t = 0; t < steps; t += stride) {
+        const float* x = X + (int64_t)t * ldx;
+        const float* y = Y + (int64_t)t * ldy;
+        const float k = 1.0f / (1.0f + block_dot(x, za, n));
+        float l = 0.0f;
+        for (int o = 0; o < m; ++o) {
+            const float yhat = block_dot(r->W + (int64_t)o * r->ldw, x, n);
+            const float e = y[o] - yhat;
+            l = fmaf(e, e, l);
+            err[o] = e;
+            if (pred) pred[(int64_t)t * ldpred + o] = yhat;
+        }
+        const int seg = t + stride <= steps ? stride : steps - t;
+        if (loss)
+            for (int q = 0; q < seg; ++q) loss[t + q] = l;
+        for (int o = 0; o < m; ++o)
+            for (int j = 0; j < n; ++j) {
+                float* w = r->W + (int64_t)o * r->ldw + j;
+                *w = *w + (k * err[o]) * za[j];
+            }
+        const int next = t + stride;
+        const float* x_next = next < steps ? X + (int64_t)next * ldx : 0;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < n; ++i) {
+            const float v = pass_row(r->P + (int64_t)i * r->ldp, n, vec4, 1, k * za[i], za, x_next);
+            if (x_next) zb[i] = r->beta_inv * v;
+        }
+        if (pred)
+            for (int q = 1; q < seg; ++q)
+                for (int o = 0; o < m; ++o)
+                    pred[(int64_t)(t + q) * ldpred + o] = wave_dot(r->W + (int64_t)o * r->ldw, X + (int64_t)(t + q) * ldx, n);
+        float* tmp = za;
+        za = zb;
+        zb = tmp;
+    }
+    return RP_OK;
+}

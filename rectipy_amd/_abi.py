@@ -116,6 +116,21 @@ class RpBwd(C.Structure):
     ]
 
 
+class RpRls(C.Structure):
+    _fields_ = [
+        ("n_in", C.c_int32),
+        ("n_out", C.c_int32),
+        ("ldp", C.c_int64),
+        ("ldw", C.c_int64),
+        ("P", fp),
+        ("W", fp),
+        ("beta_inv", C.c_float),
+        ("z", fp),
+        ("zn", fp),
+        ("scratch", fp),
+    ]
+
+
 def declare(lib, prefix):
     """Attach argtypes/restypes for the entry points `<prefix>_*` that `lib` exports."""
     P = C.POINTER
@@ -141,6 +156,8 @@ def declare(lib, prefix):
         sig("rp_qif_backward", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
         sig("rp_outer_accum", C.c_int,
             [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
+        sig("rp_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp,
+                                      C.c_void_p])
         sig("rp_stream_probe", C.c_int, [fp, C.c_int64, fp, C.c_void_p])
         sig("rp_set_tuning", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int])
         sig("rp_set_bwd_tuning", C.c_int, [C.c_int, C.c_int])
@@ -151,6 +168,7 @@ def declare(lib, prefix):
         sig("oracle_qif_backward", C.c_int, [P(RpNet), P(RpBwd)])
         sig("oracle_outer_accum", C.c_int,
             [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64])
+        sig("oracle_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp])
         sig("oracle_expf", C.c_float, [C.c_float])
         sig("oracle_tanhf", C.c_float, [C.c_float])
         sig("oracle_row_dot", C.c_float, [fp, fp, C.c_int, C.c_int, C.c_int])
@@ -160,5 +178,5 @@ def declare(lib, prefix):
 EXPORTS = [
     "rp_abi_version", "rp_last_error", "rp_device_check", "rp_sizeof_net", "rp_sizeof_run", "rp_sizeof_bwd",
     "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum",
-    "rp_stream_probe", "rp_set_tuning", "rp_set_bwd_tuning",
+    "rp_rls_sweep", "rp_stream_probe", "rp_set_tuning", "rp_set_bwd_tuning",
 ]

@@ -1,0 +1,263 @@
+// rls.hip -- recursive-least-squares readout training on gfx950.
+//
+// Replaces RLS.update (reference rectipy/edges.py:227-234) driven step by step from
+// Network._rls (rectipy/network.py:1093-1121):
+//     z = beta^-1 P x;  k = 1 / (1 + x.z);  W += outer(k (y - W x), z);  P -= k z z^T;  loss = |y - y_hat|^2
+// (the reference's weight expression `y - k x (W + y z^T)^T` equals k (y - W x) algebraically).
+//
+// The state-error correlation matrix P is n_in x n_in (4.3 GB at n_in = 32768): like the recurrent step this is
+// an HBM-bound streaming problem.  The reference reads P once for z and reads + writes it once for the rank-1
+// update: 12 n^2 bytes per update.  Because the readout does not feed back into the population, the inputs
+// x_t of a whole window are known up front, so the rank-1 update of step t is FUSED with the mat-vec of step
+// t+1: one pass reads P, applies P -= k z z^T, writes it back and accumulates z' = beta^-1 P_new x_{t+1}
+// -- 8 n^2 bytes per update, the minimum for a read-modify-write of P.
+//
+// Row mapping and summation order as in the step kernel (one wave per R rows, lane l owns columns 256 m + 4 l
+// .. +3, m ascending from 0, lane sum (a0+a1)+(a2+a3), fixed butterfly), mirrored by oracle/rls_oracle.c.
+
+#include "rp_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct RlsParams {
+    float* P;
+    int64_t ldp;
+    int n_in, n_out;
+    float* W;
+    int64_t ldw;
+    float beta_inv;
+    float* z;          // current z
+    float* zn;         // next z (output of the fused pass)
+    float* scal;       // [0] = k, [1] = loss
+    const float* x;    // x of the current update step
+    const float* y;    // target of the current update step
+    const float* x_next;
+    float* pred;       // prediction row of the current update step (pre-update weights)
+    float* err;        // [n_out] workspace
+    float* loss_out;   // loss of this update, replicated for the steps it stays valid for
+    int loss_count;
+};
+
+// One block: d = x.z (fixed tree), k = 1/(1+d), y_hat = W x, err = y - y_hat, loss = err.err
+__global__ __launch_bounds__(1024) void rls_scalars_kernel(const RlsParams P) {
+    __shared__ float red[1024];
+    const int tid = threadIdx.x;
+    float a = 0.f;
+    for (int j = tid; j < P.n_in; j += 1024) a = fmaf(P.x[j], P.z[j], a);
+    red[tid] = a;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if (tid < off) red[tid] = red[tid] + red[tid + off];
+        __syncthreads();
+    }
+    const float k = 1.0f / (1.0f + red[0]);
+    __syncthreads();
+    float loss = 0.f;
+    for (int o = 0; o < P.n_out; ++o) {  // outputs are few: one block-wide dot each, same tree
+        float b = 0.f;
+        const float* w = P.W + (int64_t)o * P.ldw;
+        for (int j = tid; j < P.n_in; j += 1024) b = fmaf(w[j], P.x[j], b);
+        red[tid] = b;
+        __syncthreads();
+        for (int off = 512; off >= 1; off >>= 1) {
+            if (tid < off) red[tid] = red[tid] + red[tid + off];
+            __syncthreads();
+        }
+        const float yhat = red[0];
+        __syncthreads();
+        const float e = P.y[o] - yhat;
+        loss = fmaf(e, e, loss);
+        if (tid == 0) {
+            P.err[o] = e;
+            if (P.pred) P.pred[o] = yhat;
+        }
+    }
+    if (tid == 0) {
+        P.scal[0] = k;
+        P.scal[1] = loss;
+    }
+    if (P.loss_out && tid < P.loss_count) P.loss_out[tid] = loss;
+}
+
+// W[o][j] += (k * err[o]) * z[j]
+__global__ void rls_weights_kernel(const RlsParams P) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n_in) return;
+    const float k = P.scal[0];
+    const float zj = P.z[j];
+    for (int o = 0; o < P.n_out; ++o) {
+        float* w = P.W + (int64_t)o * P.ldw + j;
+        *w = *w + (k * P.err[o]) * zj;
+    }
+}
+
+// pred[t][o] = W[o] . X[t]  for `count` rows (one wave per (t, o) pair, butterfly reduce)
+__global__ void rls_predict_kernel(const float* W, int64_t ldw, int n_in, int n_out, const float* X, int64_t ldx,
+                                   float* pred, int64_t ldpred, int count) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (item >= count * n_out) return;
+    const int t = item / n_out, o = item % n_out;
+    const float* w = W + (int64_t)o * ldw;
+    const float* x = X + (int64_t)t * ldx;
+    float a = 0.f;
+    for (int j = lane; j < n_in; j += 64) a = fmaf(w[j], x[j], a);
+    a = rp_wave_allreduce(a);
+    if (lane == 0) pred[(int64_t)t * ldpred + o] = a;
+}
+
+// Fused pass over P: (UPDATE) P[i][:] -= (k z_i) z[:], then zn_i = beta_inv * (P_new[i][:] . x_next)
+template <int R, bool VEC4, bool UPDATE>
+__global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int groups = (P.n_in + R - 1) / R;
+    const float k = UPDATE ? P.scal[0] : 0.f;
+    for (int g = blockIdx.x * (kThreads / 64) + wave; g < groups; g += gridDim.x * (kThreads / 64)) {
+        const int row_base = g * R;
+        float* prow[R];
+        float kz[R];
+        float sum[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            int rr = row_base + j;
+            rr = rr < P.n_in ? rr : P.n_in - 1;
+            prow[j] = P.P + (int64_t)rr * P.ldp;
+            kz[j] = UPDATE ? k * P.z[rr] : 0.f;
+        }
+        const bool dot = P.x_next != nullptr;
+        if constexpr (VEC4) {
+            rp_f4 a[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) a[j] = rp_f4{0.f, 0.f, 0.f, 0.f};
+            for (int col = 4 * lane; col < P.n_in; col += 256) {
+                rp_f4 zv = UPDATE ? rp_ld4(P.z + col) : rp_f4{0.f, 0.f, 0.f, 0.f};
+                rp_f4 xv = dot ? rp_ld4(P.x_next + col) : rp_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    rp_f4 p = rp_ld4_stream(prow[j] + col);
+                    if constexpr (UPDATE) {
+                        p.x = p.x - kz[j] * zv.x;
+                        p.y = p.y - kz[j] * zv.y;
+                        p.z = p.z - kz[j] * zv.z;
+                        p.w = p.w - kz[j] * zv.w;
+                        if (row_base + j < P.n_in) __builtin_nontemporal_store(p, reinterpret_cast<rp_f4*>(prow[j] + col));
+                    }
+                    a[j].x = fmaf(p.x, xv.x, a[j].x);
+                    a[j].y = fmaf(p.y, xv.y, a[j].y);
+                    a[j].z = fmaf(p.z, xv.z, a[j].z);
+                    a[j].w = fmaf(p.w, xv.w, a[j].w);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < R; ++j) sum[j] = rp_wave_allreduce(rp_lane_sum4(a[j]));
+        } else {
+            float a[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) a[j] = 0.f;
+            for (int col = lane; col < P.n_in; col += 64) {
+                const float zv = UPDATE ? P.z[col] : 0.f;
+                const float xv = dot ? P.x_next[col] : 0.f;
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    float p = prow[j][col];
+                    if constexpr (UPDATE) {
+                        p = p - kz[j] * zv;
+                        if (row_base + j < P.n_in) prow[j][col] = p;
+                    }
+                    a[j] = fmaf(p, xv, a[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < R; ++j) sum[j] = rp_wave_allreduce(a[j]);
+        }
+        if (dot) {
+            float mine = 0.f;
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+                if (lane == j) mine = sum[j];
+            if (lane < R && row_base + lane < P.n_in) P.zn[row_base + lane] = P.beta_inv * mine;
+        }
+    }
+}
+
+template <bool UPDATE>
+void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
+    constexpr int R = 2;
+    int groups = (P.n_in + R - 1) / R;
+    int blocks = (groups + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (vec4)
+        hipLaunchKernelGGL((rls_pass_kernel<R, true, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
+    else
+        hipLaunchKernelGGL((rls_pass_kernel<R, false, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
+}
+
+}  // namespace
+
+extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, const float* X, int64_t ldx,
+                            const float* Y, int64_t ldy, float* pred, int64_t ldpred, float* loss, void* stream) {
+    if (!r) RP_FAIL(RP_ERR_ARG, "rls is null");
+    if (r->n_in <= 0 || r->n_out <= 0) RP_FAIL(RP_ERR_SHAPE, "n_in/n_out must be > 0");
+    if (!r->P || !r->W || !r->z || !r->zn || !r->scratch) RP_FAIL(RP_ERR_ARG, "P, W, z, zn, scratch must be non-null");
+    if (r->ldp < r->n_in || r->ldw < r->n_in) RP_FAIL(RP_ERR_SHAPE, "ldp/ldw < n_in");
+    if (steps < 0 || stride < 1 || stride > 1024) RP_FAIL(RP_ERR_ARG, "steps >= 0 and 1 <= stride <= 1024 required");
+    if (steps == 0) return RP_OK;
+    if (!X || !Y || ldx < r->n_in || ldy < r->n_out) RP_FAIL(RP_ERR_SHAPE, "X/Y rows too short");
+    if (pred && ldpred < r->n_out) RP_FAIL(RP_ERR_SHAPE, "ldpred < n_out");
+    const bool vec4 = (r->n_in % 4 == 0) && (r->ldp % 4 == 0) && (ldx % 4 == 0) &&
+                      !(reinterpret_cast<uintptr_t>(r->P) & 15u) && !(reinterpret_cast<uintptr_t>(X) & 15u) &&
+                      !(reinterpret_cast<uintptr_t>(r->z) & 15u) && !(reinterpret_cast<uintptr_t>(r->zn) & 15u);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+
+    RlsParams P = {};
+    P.P = r->P;
+    P.ldp = r->ldp;
+    P.n_in = r->n_in;
+    P.n_out = r->n_out;
+    P.W = r->W;
+    P.ldw = r->ldw;
+    P.beta_inv = r->beta_inv;
+    P.scal = r->scratch;
+    P.err = r->scratch + 4;
+    float* za = r->z;
+    float* zb = r->zn;
+
+    // z_0 = beta^-1 P x_0 (no update)
+    P.z = za;
+    P.zn = za;
+    P.x_next = X;
+    launch_pass<false>(P, vec4, st);
+
+    const int eblocks = (r->n_in + 255) / 256;
+    for (int t = 0; t < steps; t += stride) {
+        P.z = za;
+        P.zn = zb;
+        P.x = X + (int64_t)t * ldx;
+        P.y = Y + (int64_t)t * ldy;
+        P.pred = pred ? pred + (int64_t)t * ldpred : nullptr;
+        P.loss_out = loss ? loss + t : nullptr;  // the loss of this update holds until the next one
+        P.loss_count = t + stride <= steps ? stride : steps - t;
+        hipLaunchKernelGGL(rls_scalars_kernel, dim3(1), dim3(1024), 0, st, P);
+        hipLaunchKernelGGL(rls_weights_kernel, dim3(eblocks), dim3(256), 0, st, P);
+        const int next = t + stride;
+        P.x_next = next < steps ? X + (int64_t)next * ldx : nullptr;
+        launch_pass<true>(P, vec4, st);
+        if (pred && stride > 1) {  // steps between updates are predicted with the updated weights
+            const int count = (next <= steps ? stride : steps - t) - 1;
+            if (count > 0) {
+                const int items = count * r->n_out;
+                hipLaunchKernelGGL(rls_predict_kernel, dim3((items + 3) / 4), dim3(256), 0, st, r->W, r->ldw, r->n_in,
+                                   r->n_out, X + (int64_t)(t + 1) * ldx, ldx, pred + (int64_t)(t + 1) * ldpred, ldpred,
+                                   count);
+            }
+        }
+        float* tmp = za;
+        za = zb;
+        zb = tmp;
+    }
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}

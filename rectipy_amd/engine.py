@@ -82,6 +82,11 @@ class HipBackend:
         with torch.cuda.device(device):
             self._lib_mod.check(self.lib.rp_outer_accum(n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
 
+    def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
+        with torch.cuda.device(device):
+            self._lib_mod.check(self.lib.rp_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss,
+                                                      self._stream(device)))
+
     def partial_rows(self, n):
         return int(self.lib.rp_bwd_partial_rows(n))
 

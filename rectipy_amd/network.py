@@ -175,9 +175,12 @@ class Network:
         elif train == "gd":
             edge = Linear(**kwargs, detach=False)
         elif train == "rls":
-            raise NotImplementedError("recursive-least-squares edges are out of scope of the BPTT path")
+            from .rls import RLS
+            kwargs.pop("delta", None)  # accepted and ignored by the reference's examples (documentation/rls_example.py:36)
+            edge = RLS(**kwargs, backend=self._backend)
+            self._train_edge = (source, target)
         else:
-            raise ValueError("Invalid option for keyword argument `train`. Valid options: None, 'gd'.")
+            raise ValueError("Invalid option for keyword argument `train`. Valid options: None, 'gd', 'rls'.")
         edge_device = self.device if self._backend is None else "cpu"
         self.graph.add_edge(source, target, edge=edge.to(edge_device), trainable=train is not None, n_in=edge.n_in,
                             n_out=edge.n_out, **(edge_attrs or {}))
@@ -265,7 +268,7 @@ class Network:
             if n != diffeq[0] and not (isinstance(node, InstantNode) and node.name in InstantNode.elementwise):
                 return None
         for s, t in self.graph.edges:
-            if type(self.get_edge(s, t)) is not Linear:
+            if not isinstance(self.get_edge(s, t), Linear):  # Linear and its RLS subclass: forward is weights @ x
                 return None
         i = order.index(diffeq[0])
         return order[:i], diffeq[0], order[i + 1:]
@@ -606,8 +609,86 @@ class Network:
         obs.save("w_out", w_out)
         return obs
 
-    def fit_rls(self, *args, **kwargs):
-        raise NotImplementedError("recursive-least-squares training is out of scope of the integration + BPTT path")
+    def fit_rls(self, inputs: Union[list, np.ndarray], targets: Union[list, np.ndarray], update_steps: int = 1,
+                sampling_steps: int = 100, verbose: bool = True, **kwargs) -> Observer:
+        """Recursive-least-squares training of the edge added with ``train="rls"`` (signature of reference
+        network.py:786-856).  array inputs: one pass, an update every `update_steps` steps (network.py:1105-1113);
+        list inputs: one pass per epoch with a state reset in between (network.py:1062-1081)."""
+        self.compile()
+        if not self._train_edge or not self.graph.has_edge(*self._train_edge):
+            raise ValueError("fit_rls needs an edge added with train='rls'")
+        obs = Observer(dt=self.dt, **retrieve_from_dict(["record_output", "record_loss", "record_vars"], kwargs))
+        t0 = perf_counter()
+        if isinstance(inputs, list):
+            if len(inputs) != len(targets):
+                raise ValueError("Wrong dimensions of input and target output. Please make sure that `inputs` and "
+                                 "`targets` agree in the first dimension (epochs).")
+            y0 = {k: v.detach().clone() for k, v in self.state.items()}
+            epoch_losses = []
+            for epoch in range(len(inputs)):
+                inp = self._to_input(inputs[epoch])
+                tgt = torch.as_tensor(targets[epoch]).to(device=inp.device, dtype=torch.float32)
+                _, loss = self._rls_pass(inp, tgt, update_steps, [])
+                epoch_losses.append(float(loss[-1]) if loss.numel() else 0.0)
+                self.reset(y0)
+                if verbose:
+                    print(f"Progress: {epoch + 1}/{len(inputs)} training epochs finished.\nEpoch loss: {epoch_losses[-1]}.\n")
+            obs.save("epoch_loss", epoch_losses)
+            obs.save("epochs", np.arange(len(inputs)))
+        else:
+            if np.shape(inputs)[0] != np.shape(targets)[0]:
+                raise ValueError("Wrong dimensions of input and target output. Please make sure that `inputs` and "
+                                 "`targets` agree in the first dimension.")
+            inp = self._to_input(inputs)
+            tgt = torch.as_tensor(targets).to(device=inp.device, dtype=torch.float32)
+            rec_vars = list(obs.recorded_state_variables)
+            pred, loss = self._rls_pass(inp, tgt, update_steps, rec_vars, obs=obs, sampling_steps=sampling_steps,
+                                        verbose=verbose)
+            if pred is not None:  # fused pass: record the sampled steps in one block
+                sample_at = [t for t in range(inp.shape[0]) if t % sampling_steps == 0]
+                obs.record_block(sample_at, pred[sample_at], [float(v) for v in loss[sample_at].cpu()], [])
+        print(f"Finished optimization after {perf_counter() - t0} s.")
+        return obs
+
+    def _rls_pass(self, inp, tgt, optim_steps, rec_vars, obs=None, sampling_steps=1, verbose=False):
+        """One pass over `inp`.  Fused when the graph is a chain ... -> population -> ... -(RLS)-> output node with an
+        identity output: the population integrates the whole window first (the readout does not feed back), then the
+        RLS sweep runs over the stored edge inputs.  Returns (pred [T, k], loss [T]); (None, loss) after a stepwise pass."""
+        from .rls import RLS
+        src, dst = self._train_edge
+        edge: RLS = self.get_edge(src, dst)
+        order = self._order
+        simple = all(self.graph.in_degree(n) <= 1 and self.graph.out_degree(n) <= 1 for n in order)
+        diffeq = [n for n in order if self[n]["node_type"] == "diff_eq"]
+        fused = (simple and len(diffeq) == 1 and isinstance(self.get_node(diffeq[0]), RateNet) and not rec_vars
+                 and dst == self._out_node and getattr(self.get_node(dst), "name", None) == "identity"
+                 and order.index(src) >= order.index(diffeq[0])
+                 and all(isinstance(self.get_node(n), InstantNode) and self.get_node(n).name in InstantNode.elementwise
+                         for n in order if n != diffeq[0])
+                 and all(type(self.get_edge(s, t)) is Linear or (s, t) == (src, dst) for s, t in self.graph.edges))
+        if fused:
+            label = diffeq[0]
+            rnn: RateNet = self.get_node(label)
+            i = order.index(label)
+            pre, mid = order[:i], order[i + 1:order.index(src) + 1]
+            with torch.no_grad():
+                X = self._apply_chain(pre, inp, None, label) if pre else inp
+                traj = self._nograd_traj(rnn, inp.shape[0], self._fit_width(X, rnn._pop.rows))
+                Xe = self._apply_chain(mid, traj, label, None) if mid else traj
+                return edge.sweep(Xe, tgt, optim_steps)
+        steps, loss, losses = inp.shape[0], 0.0, []
+        with torch.no_grad():
+            for step in range(steps):
+                pred = self.forward(inp[step, :])
+                if step % optim_steps == 0:
+                    edge.update(self[src]["out"], tgt[step, :], self[dst]["out"])
+                    loss = edge.loss
+                losses.append(float(loss))
+                if obs is not None and step % sampling_steps == 0:
+                    if verbose:
+                        print(f"Progress: {step}/{steps} training steps finished. Current loss: {loss}.")
+                    obs.record(step, pred, loss, [self.get_var(v[0], v[1]) for v in rec_vars])
+        return None, torch.tensor(losses)
 
     def fit_eprop(self, *args, **kwargs):
         raise NotImplementedError("Method is currently not implemented")  # as in the reference (network.py:896)

@@ -1,0 +1,90 @@
+"""Recursive-least-squares readout edge (reference ``RLS``, rectipy/edges.py:177-234) on the GPU.
+
+``update(x, y, y_hat)`` keeps the reference's per-step signature; ``sweep(X, Y, stride)`` trains over a whole
+window of stored edge inputs in one library call (``rp_rls_sweep``), fusing the rank-1 update of the
+state-error correlation matrix ``P`` with the mat-vec of the next update step.
+"""
+from typing import Optional, Union
+
+import numpy as np
+import torch
+
+from . import _abi
+from .edges import Linear
+
+
+class RLS(Linear):
+
+    _tensors = ["weights", "P"]
+
+    def __init__(self, n_in: int, n_out: int, weights: Union[np.ndarray, torch.Tensor] = None,
+                 dtype: torch.dtype = torch.float32, beta: float = 1.0, alpha: float = 1.0, backend=None, **kwargs):
+        if beta > 1 or beta < 0:
+            raise ValueError("Parameter beta should be a positive scalar between 0 and 1.")
+        if alpha < 0:
+            raise ValueError("Parameter alpha should be a positive scalar.")
+        if weights is None:
+            weights = torch.zeros((n_out, n_in), dtype=torch.float32)
+        super().__init__(n_in, n_out, weights=weights, dtype=torch.float32, detach=True)
+        self.train_params = []
+        self.beta = beta ** (-1)  # the reference stores the inverse forgetting rate (edges.py:220)
+        self.P = alpha * torch.eye(n_in, dtype=torch.float32)
+        self.loss = 0.0
+        self._backend = backend
+        self._scratch = None
+
+    def to(self, device: str, **kwargs):
+        self.weights = self.weights.detach().to(device).contiguous()
+        self.P = self.P.to(device).contiguous()
+        self._scratch = None
+        return self
+
+    def _ensure(self):
+        if self._backend is None:
+            from .engine import default_backend
+            self._backend = default_backend()
+        self._backend.check_device(self.weights.device)
+        if self._scratch is None:
+            dev = self.weights.device
+            self._scratch = (torch.zeros(self.n_in, dtype=torch.float32, device=dev),
+                             torch.zeros(self.n_in, dtype=torch.float32, device=dev),
+                             torch.zeros(4 + self.n_out, dtype=torch.float32, device=dev))
+
+    def sweep(self, X: torch.Tensor, Y: torch.Tensor, stride: int = 1):
+        """Train over T consecutive steps: X [T, n_in] edge inputs, Y [T, n_out] targets, an update every `stride`
+        steps (at 0, stride, ...).  Returns (pred [T, n_out], loss [T]) as the reference's loop would record them:
+        the prediction of a step uses the weights in force before that step's update."""
+        self._ensure()
+        dev = self.weights.device
+        T = int(X.shape[0])
+        if T > 0 and (X.dim() != 2 or X.shape[1] != self.n_in):
+            raise RuntimeError(f"edge input must be [T, {self.n_in}], got {tuple(X.shape)}")
+        if Y.shape[0] != T or (T > 0 and Y.shape[1] != self.n_out):
+            raise RuntimeError(f"targets must be [{T}, {self.n_out}], got {tuple(Y.shape)}")
+        X = X.detach().to(dtype=torch.float32, device=dev).contiguous()
+        Y = Y.detach().to(dtype=torch.float32, device=dev).contiguous()
+        pred = torch.empty(T, self.n_out, dtype=torch.float32, device=dev)
+        loss = torch.zeros(T, dtype=torch.float32, device=dev)
+        if T == 0:
+            return pred, loss
+        z, zn, scratch = self._scratch
+        r = _abi.RpRls()
+        r.n_in, r.n_out = self.n_in, self.n_out
+        r.ldp, r.ldw = self.P.stride(0), self.weights.stride(0)
+        r.P, r.W = self.P.data_ptr(), self.weights.data_ptr()
+        r.beta_inv = float(self.beta)
+        r.z, r.zn, r.scratch = z.data_ptr(), zn.data_ptr(), scratch.data_ptr()
+        self._backend.rls_sweep(r, T, int(stride), X.data_ptr(), X.stride(0) if T > 1 else self.n_in, Y.data_ptr(),
+                                Y.stride(0) if T > 1 else self.n_out, pred.data_ptr(), self.n_out, loss.data_ptr(), dev)
+        self.loss = loss[-1]
+        return pred, loss
+
+    def update(self, x: torch.Tensor, y: torch.Tensor, y_hat: Optional[torch.Tensor] = None) -> None:
+        """One RLS step (signature of reference edges.py:227).  The weight update never depends on `y_hat`
+        (edges.py:232); it only defines the recorded loss, so it is honoured when given."""
+        _, loss = self.sweep(x.reshape(1, -1), torch.as_tensor(y).reshape(1, -1), 1)
+        if y_hat is not None:
+            err = torch.as_tensor(y).to(y_hat.device, torch.float32).reshape(-1) - y_hat.detach().reshape(-1)
+            self.loss = torch.inner(err, err)
+        else:
+            self.loss = loss[0]

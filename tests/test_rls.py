@@ -1,0 +1,102 @@
+"""Recursive-least-squares readout training: front end + kernels against the reference's fit_rls (golden G14) and
+HIP vs oracle bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rectipy_amd import Network
+from rectipy_amd.rls import RLS
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TANH = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
+TARGETS = [pytest.param("oracle", id="oracle"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture
+def target(request, oracle_backend):
+    if request.param == "oracle":
+        return dict(device="cpu", backend=oracle_backend)
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    return dict(device="cuda:0", backend=None)
+
+
+def build(g, target):
+    net = Network(float(g["dt"]), **target)
+    net.add_diffeq_node("rnn", TANH, weights=g["W"], source_var="tanh_op/r", target_var="li_op/r_in",
+                        input_var="li_op/I_ext", output_var="li_op/v", dtype=torch.float32,
+                        node_vars={"all/li_op/tau": g["tau"], "all/li_op/k": g["k"], "all/li_op/eta": g["eta"],
+                                   "all/li_op/v": g["y0"]})
+    net.add_func_node("out", g["W0"].shape[0], "identity")
+    edge = net.add_edge("rnn", "out", weights=g["W0"].copy(), train="rls", beta=float(g["beta"]), alpha=float(g["alpha"]))
+    return net, edge
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("stride", [1, 4])
+def test_g14_fit_rls_matches_reference(target, stride):
+    g = dict(np.load(os.path.join(GOLD, "g14_rls.npz")))
+    net, edge = build(g, target)
+    assert isinstance(edge, RLS) and abs(edge.beta - 1 / 0.95) < 1e-12
+    obs = net.fit_rls(g["x"], g["target"], update_steps=stride, sampling_steps=1, verbose=False)
+    key = f"s{stride}_f64"
+    scale = np.abs(g["W_after_" + key]).max()
+    assert np.abs(edge.weights.cpu().numpy() - g["W_after_" + key]).max() < 2e-4 * max(1.0, scale)
+    assert np.abs(edge.P.cpu().numpy() - g["P_after_" + key]).max() < 2e-4 * np.abs(g["P_after_" + key]).max()
+    assert np.abs(obs.to_numpy("out") - g["pred_" + key]).max() < 2e-4
+    ref_loss = g["loss_" + key]
+    assert np.abs(obs.to_numpy("loss") - ref_loss).max() < 2e-4 * max(1.0, ref_loss.max())
+    assert np.abs(net.state["rnn"].cpu().numpy() - g["state_" + key]).max() < 2e-5
+    # per-step API (drop-in loops calling edge.update) agrees with the fused sweep
+    net2, edge2 = build(g, target)
+    net2.compile()
+    x = torch.tensor(g["x"], dtype=torch.float32, device=target["device"])
+    y = torch.tensor(g["target"], dtype=torch.float32, device=target["device"])
+    for t in range(x.shape[0]):
+        net2.forward(x[t])
+        if t % stride == 0:
+            edge2.update(net2["rnn"]["out"], y[t], net2["out"]["out"])
+    assert np.abs(edge2.weights.cpu().numpy() - edge.weights.cpu().numpy()).max() < 1e-5
+    assert np.abs(edge2.P.cpu().numpy() - edge.P.cpu().numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_fit_rls_epochs_recovers_readout(target):
+    """mirrors the rls leg of rectipy_tests/test_network.py::test_3_7_optimization"""
+    rng = np.random.default_rng(7)
+    n, k, steps = 10, 3, 100
+    W, W_out, x = rng.standard_normal((n, n)), rng.standard_normal((k, n)), rng.standard_normal((steps, n))
+    net = Network(1e-2, **target)
+    net.add_diffeq_node("rnn", TANH, weights=W, source_var="tanh_op/r", target_var="li_op/r_in",
+                        input_var="li_op/I_ext", output_var="tanh_op/r", dtype=torch.float32)
+    net.add_func_node("output", k, "identity")
+    net.add_edge("rnn", "output", weights=W_out)
+    y0 = {kk: v.clone() for kk, v in net.state.items()}
+    tgt = net.run(x, sampling_steps=1, enable_grad=False, verbose=False).to_numpy("out")
+    net.pop_edge("rnn", "output")
+    net.add_edge("rnn", "output", train="rls", beta=0.99, alpha=1.0)
+    net.reset(y0)
+    obs = net.fit_rls([x] * 40, [tgt] * 40, update_steps=1, verbose=False)
+    fitted = net.get_edge("rnn", "output").weights.cpu().numpy()
+    assert np.mean((W_out - fitted) ** 2) < 0.5 and len(obs["epoch_loss"]) == 40
+    with pytest.raises(ValueError):
+        net.add_edge("rnn", "output", train="rls", beta=1.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_in,n_out,T,stride", [(40, 3, 30, 1), (256, 2, 25, 3), (1000, 4, 12, 1), (1030, 1, 9, 2)])
+def test_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride):
+    gen = torch.Generator().manual_seed(n_in + T)
+    X = torch.randn(T, n_in, generator=gen)
+    Y = torch.randn(T, n_out, generator=gen)
+    W0 = torch.randn(n_out, n_in, generator=gen) * 0.1
+    res = []
+    for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+        edge = RLS(n_in, n_out, weights=W0.clone(), beta=0.97, alpha=1.5, backend=backend).to(dev)
+        pred, loss = edge.sweep(X.to(dev), Y.to(dev), stride)
+        res.append([t.cpu().numpy() for t in (pred, loss, edge.weights, edge.P)])
+    for a, b, name in zip(res[0], res[1], ("pred", "loss", "weights", "P")):
+        same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
+        assert same.all(), f"{name}: {np.count_nonzero(~same)} of {a.size} differ, max abs {np.abs(a - b).max()}"
