@@ -119,5 +119,7 @@ def test_argument_errors(oracle_backend):
         net.fit_bptt(np.zeros((4, 6)), np.zeros((4, 6)), optimizer="nope", verbose=False)
     with pytest.raises(ValueError):
         net.fit_bptt(np.zeros((4, 6)), np.zeros((4, 6)), loss="nope", verbose=False)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):  # no edge was added with train="rls"
         net.fit_rls(np.zeros((4, 6)), np.zeros((4, 6)))
+    with pytest.raises(NotImplementedError):
+        net.fit_eprop(np.zeros((4, 6)), np.zeros((4, 6)))
