@@ -132,24 +132,45 @@ __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
             rp_f4 a[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) a[j] = rp_f4{0.f, 0.f, 0.f, 0.f};
-            for (int col = 4 * lane; col < P.n_in; col += 256) {
-                rp_f4 zv = UPDATE ? rp_ld4(P.z + col) : rp_f4{0.f, 0.f, 0.f, 0.f};
-                rp_f4 xv = dot ? rp_ld4(P.x_next + col) : rp_f4{0.f, 0.f, 0.f, 0.f};
+            constexpr int U = 4;  // column chunks in flight per row: U * R 16-byte loads per lane
+            const rp_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            auto body = [&](int col, rp_f4 (&p)[R], rp_f4 zv, rp_f4 xv) {
 #pragma unroll
                 for (int j = 0; j < R; ++j) {
-                    rp_f4 p = rp_ld4_stream(prow[j] + col);
                     if constexpr (UPDATE) {
-                        p.x = p.x - kz[j] * zv.x;
-                        p.y = p.y - kz[j] * zv.y;
-                        p.z = p.z - kz[j] * zv.z;
-                        p.w = p.w - kz[j] * zv.w;
-                        if (row_base + j < P.n_in) __builtin_nontemporal_store(p, reinterpret_cast<rp_f4*>(prow[j] + col));
+                        p[j].x = p[j].x - kz[j] * zv.x;
+                        p[j].y = p[j].y - kz[j] * zv.y;
+                        p[j].z = p[j].z - kz[j] * zv.z;
+                        p[j].w = p[j].w - kz[j] * zv.w;
+                        if (row_base + j < P.n_in)
+                            __builtin_nontemporal_store(p[j], reinterpret_cast<rp_f4*>(prow[j] + col));
                     }
-                    a[j].x = fmaf(p.x, xv.x, a[j].x);
-                    a[j].y = fmaf(p.y, xv.y, a[j].y);
-                    a[j].z = fmaf(p.z, xv.z, a[j].z);
-                    a[j].w = fmaf(p.w, xv.w, a[j].w);
+                    a[j].x = fmaf(p[j].x, xv.x, a[j].x);
+                    a[j].y = fmaf(p[j].y, xv.y, a[j].y);
+                    a[j].z = fmaf(p[j].z, xv.z, a[j].z);
+                    a[j].w = fmaf(p[j].w, xv.w, a[j].w);
                 }
+            };
+            int col = 4 * lane;
+            for (; col + 256 * (U - 1) < P.n_in; col += 256 * U) {
+                rp_f4 p[U][R], zv[U], xv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    zv[u] = UPDATE ? rp_ld4(P.z + col + 256 * u) : zero4;
+                    xv[u] = dot ? rp_ld4(P.x_next + col + 256 * u) : zero4;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) p[u][j] = rp_ld4_stream(prow[j] + col + 256 * u);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) body(col + 256 * u, p[u], zv[u], xv[u]);
+            }
+            for (; col < P.n_in; col += 256) {
+                rp_f4 p[R];
+                const rp_f4 zv = UPDATE ? rp_ld4(P.z + col) : zero4;
+                const rp_f4 xv = dot ? rp_ld4(P.x_next + col) : zero4;
+#pragma unroll
+                for (int j = 0; j < R; ++j) p[j] = rp_ld4_stream(prow[j] + col);
+                body(col, p, zv, xv);
             }
 #pragma unroll
             for (int j = 0; j < R; ++j) sum[j] = rp_wave_allreduce(rp_lane_sum4(a[j]));

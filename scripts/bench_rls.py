@@ -1,0 +1,25 @@
+"""RLS sweep at large n_in: achieved HBM bandwidth of the fused rank-1 update + next mat-vec pass (8 n^2 B/update)."""
+import json
+import sys
+
+import torch
+
+from rectipy_amd.rls import RLS
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+T, k = 20, 3
+dev = torch.device("cuda:0")
+edge = RLS(n, k, beta=0.99, alpha=1.0).to(dev)
+X = torch.randn(T, n, device=dev) * 0.1
+Y = torch.randn(T, k, device=dev)
+edge.sweep(X[:3], Y[:3], 1)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+edge.sweep(X, Y, 1)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / (T + 1)  # T fused passes + the initial mat-vec
+print(json.dumps({"workload": f"RLS sweep n_in={n}, n_out={k}, {T} updates", "ms_per_update": ms,
+                  "achieved_GBps": 8.0 * n * n / (ms * 1e-3) / 1e9, "frac_of_8TBps": 8.0 * n * n / (ms * 1e-3) / 1e9 / 8000,
+                  "finite": bool(torch.isfinite(edge.P).all().item())}))
