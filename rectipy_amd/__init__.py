@@ -9,5 +9,6 @@ from .network import Network
 from .observer import Observer
 from .nodes import InstantNode, RateNet, SpikeResetNet
 from .edges import Linear
+from .feedback import FeedbackNetwork
 
-__all__ = ["Network", "Observer", "RateNet", "SpikeResetNet", "InstantNode", "Linear"]
+__all__ = ["Network", "FeedbackNetwork", "Observer", "RateNet", "SpikeResetNet", "InstantNode", "Linear"]

@@ -166,14 +166,20 @@ class Network:
     def add_edge(self, source: str, target: str, weights=None, train: Optional[str] = None,
                  edge_attrs: dict = None, **kwargs) -> Linear:
         """Linear projection source -> target (reference network.py:340-401); `train` in {None, 'gd'}."""
-        for unsupported in ("mask", "delays", "filter_weights"):
-            if unsupported in kwargs:
-                raise NotImplementedError(f"edge option '{unsupported}' (Linear{unsupported.title()} edges) is out of scope")
+        from .edge_variants import LinearFilter, LinearMasked, LinearMemory, LinearMemoryFilter
+        if "mask" in kwargs:  # same selection rule as the reference (network.py:372-380)
+            LinEdge = LinearMasked
+        elif "delays" in kwargs:
+            LinEdge = LinearMemoryFilter if "filter_weights" in kwargs else LinearMemory
+        elif "filter_weights" in kwargs:
+            LinEdge = LinearFilter
+        else:
+            LinEdge = Linear
         kwargs.update(n_in=self[source]["n_out"], n_out=self[target]["n_in"], weights=weights, dtype=self.dtype)
         if train is None:
-            edge = Linear(**kwargs, detach=True)
+            edge = LinEdge(**kwargs, detach=True)
         elif train == "gd":
-            edge = Linear(**kwargs, detach=False)
+            edge = LinEdge(**kwargs, detach=False)
         elif train == "rls":
             from .rls import RLS
             kwargs.pop("delta", None)  # accepted and ignored by the reference's examples (documentation/rls_example.py:36)
@@ -268,7 +274,8 @@ class Network:
             if n != diffeq[0] and not (isinstance(node, InstantNode) and node.name in InstantNode.elementwise):
                 return None
         for s, t in self.graph.edges:
-            if not isinstance(self.get_edge(s, t), Linear):  # Linear and its RLS subclass: forward is weights @ x
+            from .rls import RLS
+            if type(self.get_edge(s, t)) not in (Linear, RLS):  # stateful / masked variants are stepped one by one
                 return None
         i = order.index(diffeq[0])
         return order[:i], diffeq[0], order[i + 1:]
