@@ -99,10 +99,45 @@ class Observer:
             parts.append(c if isinstance(c, torch.Tensor) else torch.stack([torch.as_tensor(v) for v in c]))
         return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
 
-    def plot(self, *args, **kwargs):
-        raise NotImplementedError("plotting is outside the scope of rectipy_amd; use to_numpy()/to_dataframe()")
+    # ---- thin matplotlib conveniences (same call signatures as reference observer.py:130-198) ------------
+    @staticmethod
+    def _axis_label(v) -> str:
+        return f"Node: {v[0]}, variable: {v[-1]}" if isinstance(v, tuple) else str(v)
 
-    matshow = plot
+    @staticmethod
+    def _axes(ax, kwargs):
+        if ax is None:
+            import matplotlib.pyplot as plt
+            figsize = kwargs.pop("figsize", None)
+            _, ax = plt.subplots(**({"figsize": figsize} if figsize else {}))
+        return ax
+
+    def _series(self, item) -> np.ndarray:
+        val = self[item]
+        if isinstance(val, (list, tuple)):
+            return np.asarray([v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v for v in val])
+        return np.asarray(val)
+
+    def plot(self, y, x=None, ax=None, **kwargs):
+        """Line plot of recording `y` against time (or against recording / stored item `x`)."""
+        ax = self._axes(ax, kwargs)
+        ys = self._series(y)
+        xs = np.asarray(self["steps"]) * self._dt if x is None else self._series(x)
+        ax.plot(xs[:len(ys)] if len(xs) >= len(ys) else np.arange(len(ys)), ys, **kwargs)
+        ax.set_xlabel("time" if x is None else self._axis_label(x))
+        ax.set_ylabel(self._axis_label(y))
+        return ax
+
+    def matshow(self, v, ax=None, **kwargs):
+        """Colour plot (neurons x time) of recording `v`."""
+        import matplotlib.pyplot as plt
+        ax = self._axes(ax, kwargs)
+        shrink = kwargs.pop("shrink", 0.6)
+        im = ax.imshow(self._series(v).T, **kwargs)
+        plt.colorbar(im, ax=ax, shrink=shrink)
+        ax.set_xlabel("time")
+        ax.set_ylabel(self._axis_label(v))
+        return ax
 
     # ---- internals ------------------------------------------------------------------------
     def _append(self, key, items):
