@@ -51,7 +51,7 @@ class LinearMasked(_Stateful):
 
 class LinearMemory(_Stateful):
     """Delay buffer in front of the projection (reference edges.py:68-94)."""
-    _extra = ("buffer", "delays")
+    _extra = ("buffer", "delays", "_cols", "_src")
 
     def __init__(self, n_in: int, n_out: int, delays: Union[np.ndarray, torch.Tensor], weights=None,
                  dtype: torch.dtype = torch.float32, detach: bool = True, **kwargs):
@@ -60,6 +60,11 @@ class LinearMemory(_Stateful):
             raise ValueError("The number of delays must match the number of node inputs.")
         self.delays = delays
         self.buffer = torch.zeros((n_in, int(delays.max()) + 1), dtype=dtype)
+        # `buffer[:, delays] = x` with repeated delays keeps the LAST matching input on the CPU and is undefined on a
+        # GPU; resolve the duplicates once so that both behave like the CPU path of the reference
+        cols = torch.unique(delays)
+        self._cols = cols
+        self._src = torch.stack([torch.nonzero(delays == c).max() for c in cols])
         super().__init__(n_in, n_out, weights=weights, dtype=dtype, detach=detach)
 
     def _shift(self):
@@ -69,7 +74,7 @@ class LinearMemory(_Stateful):
         if x.dim() != 1:
             raise RuntimeError("delay edges are evaluated one step at a time")
         self.buffer = self._shift()
-        self.buffer[:, self.delays] = x  # the reference's indexing (edges.py:93)
+        self.buffer[:, self._cols] = x[self._src]  # == buffer[:, delays] = x, the reference's indexing (edges.py:93)
         return self.weights @ self.buffer[:, 0]
 
 
@@ -92,7 +97,7 @@ class LinearFilter(_Stateful):
 
 class LinearMemoryFilter(LinearMemory):
     """Delay buffer whose content is filtered every step (reference edges.py:123-147)."""
-    _extra = ("buffer", "delays", "filter")
+    _extra = ("buffer", "delays", "_cols", "_src", "filter")
 
     def __init__(self, n_in: int, n_out: int, delays, filter_weights, weights=None,
                  dtype: torch.dtype = torch.float32, detach: bool = True, **kwargs):

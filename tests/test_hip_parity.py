@@ -295,3 +295,30 @@ def test_qif_full_size_dense_step_properties(hip_device):
     assert ((v_new[rows].double() - (v0[rows].double() + 1e-3 * dv))[ok]).abs().max() < 2e-4
     s_ref = s0.double() * (1 - 1e-3) + spiking.double()
     assert (s_new.double() - s_ref).abs().max() < 1e-5
+
+
+def test_run_to_run_determinism(hip_device):
+    """No atomics on the numerical path and a fixed summation tree: two runs of the same window are bit-identical
+    (forward trajectory, adjoint state, weight gradient), and so is a different launch configuration."""
+    from rectipy_amd import _lib
+    N, T = 4096, 300
+    W, params, v0 = make_li(N, seed=5)
+    x = torch.randn(T, 1, generator=torch.Generator().manual_seed(6)).to(hip_device)
+    g_out = (torch.randn(T, N, generator=torch.Generator().manual_seed(7)) * 0.01).to(hip_device)
+    runs = []
+    for tune in ((0, 0), (0, 0), (2, 4)):
+        _lib.load().rp_set_tuning(tune[0], tune[1], 1, 0)
+        pop = Population("li_tanh", W, params, 1e-2, hip_device, v0=v0)
+        tv, tr, ut = (torch.zeros(T, N, device=hip_device) for _ in range(3))
+        pop.forward(T, x=x, save_v=tv, save_src=tr)
+        lam = torch.zeros(N, device=hip_device)
+        keep = pop.backward(tv, tr, g_out, _abi.RP_OUT_STATE0, lam, ut)
+        gW = torch.zeros(N, N, device=hip_device)
+        pop.outer_accum(pop.dt, ut, tr, gW)
+        torch.cuda.synchronize()
+        runs.append((tv.clone(), lam.clone(), gW))
+        del keep
+    _lib.load().rp_set_tuning(0, 0, 1, 0)
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert torch.equal(a, b)
