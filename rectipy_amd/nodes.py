@@ -214,6 +214,9 @@ class RateNet:
                 kw["aux0"] = values[self._aux_name]
         else:
             kw = dict(v0=values[state_names[0]])
+        shard = kwargs.pop("shard", None)  # (row0, n): this node holds rows [row0, row0+rows) of an n x n matrix
+        if shard is not None:
+            kw.update(row0=int(shard[0]), n=int(shard[1]))
         self._pop = Population(template.model, weights, eng_params, dt, device, backend=backend, **kw)
         N = self._pop.rows
         self.n_in = N

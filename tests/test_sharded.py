@@ -80,3 +80,64 @@ def test_two_rank_shards_reproduce_single_process(tmp_path, oracle_backend, mode
         assert np.array_equal(p["src"], full.source.numpy())
     if model == "qif":
         assert np.abs(np.diff(traj.numpy(), axis=0)).max() > 0.5, "no spikes in the sharded QIF test"
+
+
+def _net_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from oracle.backend import OracleBackend
+        from rectipy_amd.sharded import ShardedNetwork
+        W, params, v0, x, W_in, W_out, u = _net_data()
+        net = ShardedNetwork(1e-2, device="cpu", backend=OracleBackend())
+        net.add_func_node("inp", 3, "identity")
+        net.add_diffeq_node("rnn", TANH, weights=W.numpy(), source_var="tanh_op/r", target_var="li_op/r_in",
+                            input_var="li_op/I_ext", output_var="tanh_op/r", dtype=torch.float32,
+                            node_vars={"all/li_op/tau": params["tau"].numpy(), "all/li_op/k": params["k"].numpy(),
+                                       "all/li_op/eta": params["eta"].numpy(), "all/li_op/v": v0.numpy()})
+        net.add_func_node("out", 2, "tanh")
+        net.add_edge("inp", "rnn", weights=W_in.numpy())
+        net.add_edge("rnn", "out", weights=W_out.numpy())
+        obs = net.run(u.numpy(), sampling_steps=3, cutoff=2, verbose=False, enable_grad=False,
+                      record_vars=[("rnn", "li_op/v", False)])
+        np.savez(os.path.join(out_dir, f"net_{rank}.npz"), out=obs.to_numpy("out"), v=obs.to_numpy(("rnn", "li_op/v")),
+                 state=net.state["rnn"].numpy(), steps=np.asarray(obs["steps"]))
+    finally:
+        dist.destroy_process_group()
+
+
+TANH = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
+
+
+def _net_data():
+    W, params, v0, x = _data()
+    g = torch.Generator().manual_seed(3)
+    return W, params, v0, x, torch.randn(N, 3, generator=g), torch.randn(2, N, generator=g) / N ** 0.5, \
+        torch.randn(T, 3, generator=g)
+
+
+def test_sharded_network_front_end(tmp_path, oracle_backend):
+    """ShardedNetwork.run (inp -> rnn -> tanh read-out) on 2 gloo ranks == Network.run in one process."""
+    from rectipy_amd import Network
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_net_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    W, params, v0, x, W_in, W_out, u = _net_data()
+    net = Network(1e-2, device="cpu", backend=oracle_backend)
+    net.add_func_node("inp", 3, "identity")
+    net.add_diffeq_node("rnn", TANH, weights=W.numpy(), source_var="tanh_op/r", target_var="li_op/r_in",
+                        input_var="li_op/I_ext", output_var="tanh_op/r", dtype=torch.float32,
+                        node_vars={"all/li_op/tau": params["tau"].numpy(), "all/li_op/k": params["k"].numpy(),
+                                   "all/li_op/eta": params["eta"].numpy(), "all/li_op/v": v0.numpy()})
+    net.add_func_node("out", 2, "tanh")
+    net.add_edge("inp", "rnn", weights=W_in.numpy())
+    net.add_edge("rnn", "out", weights=W_out.numpy())
+    obs = net.run(u.numpy(), sampling_steps=3, cutoff=2, verbose=False, enable_grad=False,
+                  record_vars=[("rnn", "li_op/v", False)])
+    parts = [np.load(tmp_path / f"net_{r}.npz") for r in range(WORLD)]
+    for p in parts:
+        assert list(p["steps"]) == list(obs["steps"])
+        assert np.abs(p["out"] - obs.to_numpy("out")).max() < 1e-6      # read-out: partial sums all-reduced
+    assert np.array_equal(np.concatenate([p["v"] for p in parts], axis=1), obs.to_numpy(("rnn", "li_op/v")))
+    assert np.array_equal(np.concatenate([p["state"] for p in parts]), net.state["rnn"].numpy())
