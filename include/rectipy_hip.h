@@ -257,6 +257,9 @@ int rp_set_tuning(int rows_per_wave, int unroll, int nontemporal, int max_blocks
    kernel; 0, 0 restores the built-in choice.  Results are bit-identical for every configuration. */
 int rp_set_bwd_tuning(int unroll, int strip_groups);
 
+/* Benchmark-only: rows per wave, column chunks in flight and store policy (-1 = default) of the RLS pass. */
+int rp_set_rls_tuning(int rows_per_wave, int unroll, int nontemporal_store);
+
 /* Bandwidth probe used by bench.py: sums `bytes` of HBM with the same load shape as the step kernel. */
 int rp_stream_probe(const float* buf, int64_t n_floats, float* out, void* stream);
 

@@ -161,6 +161,7 @@ def declare(lib, prefix):
         sig("rp_stream_probe", C.c_int, [fp, C.c_int64, fp, C.c_void_p])
         sig("rp_set_tuning", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int])
         sig("rp_set_bwd_tuning", C.c_int, [C.c_int, C.c_int])
+        sig("rp_set_rls_tuning", C.c_int, [C.c_int, C.c_int, C.c_int])
     else:
         sig("oracle_refresh_source", C.c_int, [P(RpNet)])
         sig("oracle_forward", C.c_int, [P(RpNet), P(RpRun)])
@@ -178,5 +179,5 @@ def declare(lib, prefix):
 EXPORTS = [
     "rp_abi_version", "rp_last_error", "rp_device_check", "rp_sizeof_net", "rp_sizeof_run", "rp_sizeof_bwd",
     "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum",
-    "rp_rls_sweep", "rp_stream_probe", "rp_set_tuning", "rp_set_bwd_tuning",
+    "rp_rls_sweep", "rp_stream_probe", "rp_set_tuning", "rp_set_bwd_tuning", "rp_set_rls_tuning",
 ]

@@ -109,7 +109,7 @@ __global__ void rls_predict_kernel(const float* W, int64_t ldw, int n_in, int n_
 }
 
 // Fused pass over P: (UPDATE) P[i][:] -= (k z_i) z[:], then zn_i = beta_inv * (P_new[i][:] . x_next)
-template <int R, bool VEC4, bool UPDATE>
+template <int R, int U, bool NTS, bool VEC4, bool UPDATE>
 __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
             rp_f4 a[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) a[j] = rp_f4{0.f, 0.f, 0.f, 0.f};
-            constexpr int U = 4;  // column chunks in flight per row: U * R 16-byte loads per lane
+            // U column chunks in flight per row: U * R 16-byte loads per lane
             const rp_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
             auto body = [&](int col, rp_f4 (&p)[R], rp_f4 zv, rp_f4 xv) {
 #pragma unroll
@@ -142,8 +142,12 @@ __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
                         p[j].y = p[j].y - kz[j] * zv.y;
                         p[j].z = p[j].z - kz[j] * zv.z;
                         p[j].w = p[j].w - kz[j] * zv.w;
-                        if (row_base + j < P.n_in)
-                            __builtin_nontemporal_store(p[j], reinterpret_cast<rp_f4*>(prow[j] + col));
+                        if (row_base + j < P.n_in) {
+                            if constexpr (NTS)
+                                __builtin_nontemporal_store(p[j], reinterpret_cast<rp_f4*>(prow[j] + col));
+                            else
+                                *reinterpret_cast<rp_f4*>(prow[j] + col) = p[j];
+                        }
                     }
                     a[j].x = fmaf(p[j].x, xv.x, a[j].x);
                     a[j].y = fmaf(p[j].y, xv.y, a[j].y);
@@ -204,19 +208,44 @@ __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
     }
 }
 
-template <bool UPDATE>
-void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
-    constexpr int R = 2;
+int g_rls_R = 0, g_rls_U = 0, g_rls_nts = -1;  // benchmark-only override (rp_set_rls_tuning)
+
+template <int R, int U, bool NTS, bool UPDATE>
+void launch_cfg(const RlsParams& P, bool vec4, hipStream_t st) {
     int groups = (P.n_in + R - 1) / R;
     int blocks = (groups + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     if (vec4)
-        hipLaunchKernelGGL((rls_pass_kernel<R, true, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
+        hipLaunchKernelGGL((rls_pass_kernel<R, U, NTS, true, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
     else
-        hipLaunchKernelGGL((rls_pass_kernel<R, false, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
+        hipLaunchKernelGGL((rls_pass_kernel<R, 1, NTS, false, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
+}
+
+template <bool UPDATE>
+void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
+    const int R = g_rls_R ? g_rls_R : 2, U = g_rls_U ? g_rls_U : 4;
+    const bool nts = g_rls_nts < 0 ? true : g_rls_nts != 0;
+#define RP_RLS(R_, U_)                                            \
+    if (R == R_ && U == U_) {                                     \
+        if (nts)                                                  \
+            launch_cfg<R_, U_, true, UPDATE>(P, vec4, st);        \
+        else                                                      \
+            launch_cfg<R_, U_, false, UPDATE>(P, vec4, st);       \
+        return;                                                   \
+    }
+    RP_RLS(2, 4) RP_RLS(1, 4) RP_RLS(1, 8) RP_RLS(2, 2) RP_RLS(4, 2) RP_RLS(4, 1) RP_RLS(2, 8)
+#undef RP_RLS
+    launch_cfg<2, 4, true, UPDATE>(P, vec4, st);
 }
 
 }  // namespace
+
+extern "C" int rp_set_rls_tuning(int rows_per_wave, int unroll, int nontemporal_store) {
+    g_rls_R = rows_per_wave;
+    g_rls_U = unroll;
+    g_rls_nts = nontemporal_store;
+    return RP_OK;
+}
 
 extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, const float* X, int64_t ldx,
                             const float* Y, int64_t ldy, float* pred, int64_t ldpred, float* loss, void* stream) {

@@ -12,6 +12,21 @@ dev = torch.device("cuda:0")
 edge = RLS(n, k, beta=0.99, alpha=1.0).to(dev)
 X = torch.randn(T, n, device=dev) * 0.1
 Y = torch.randn(T, k, device=dev)
+from rectipy_amd import _lib
+lib = _lib.load()
+if len(sys.argv) > 2:
+    for R, U, nts in ((2, 4, 1), (2, 4, 0), (1, 4, 1), (1, 8, 1), (1, 8, 0), (2, 2, 1), (4, 2, 1), (4, 1, 1), (2, 8, 1), (2, 8, 0)):
+        lib.rp_set_rls_tuning(R, U, nts)
+        edge.sweep(X[:3], Y[:3], 1)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        edge.sweep(X, Y, 1)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / (T + 1)
+        print(json.dumps(dict(R=R, U=U, nts=nts, ms=ms, GBps=8.0 * n * n / (ms * 1e-3) / 1e9)), flush=True)
+    lib.rp_set_rls_tuning(0, 0, -1)
 edge.sweep(X[:3], Y[:3], 1)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
