@@ -193,6 +193,11 @@ typedef struct rp_bwd {
     int32_t x_mode;           /* RP_X_NONE / RP_X_FULL / RP_X_BCAST: the input of the forward window (needed for grad_tau) */
     const float* x;
     int64_t ldx;
+    int32_t x_target;         /* RP_XT_*: which equation the window's input entered (LIF)                     */
+    const float* traj_aux;    /* [T x ld] pre-update second state (x of QIF_SFA, u of IK) = save_state[1]     */
+    float* lam3;              /* [n] adjoint of the second state (in: at T, out: at 0)                        */
+    float* grad_p[RP_MAX_PARAMS]; /* optional per-neuron parameter gradients by slot RP_P_* (+=); the named
+                                     fields above take precedence for tau / k / eta / tau_s                   */
 } rp_bwd;
 
 int rp_abi_version(void);
@@ -218,8 +223,8 @@ int32_t rp_bwd_partial_rows(int32_t n);
 /* Adjoint sweep t = T-1..0 over a stored window (unsharded LI models). */
 int rp_rate_backward(const rp_net* net, const rp_bwd* bwd, void* stream);
 
-/* Surrogate-gradient adjoint sweep of the spiking (QIF) step: gradient flows through the Heaviside via
-   Spike.backward (nodes.py:479-481) but not through the reset mask (nodes.py:384). */
+/* Surrogate-gradient adjoint sweep of a spiking step (QIF, QIF_SFA, LIF, IK): gradient flows through the Heaviside
+   via Spike.backward (nodes.py:479-481) but not through the reset mask (nodes.py:384). */
 int rp_qif_backward(const rp_net* net, const rp_bwd* bwd, void* stream);
 
 /* C[n x n] (ldc) += alpha * A^T B with A = [T x n] (lda), B = [T x n] (ldb): MFMA f32 GEMM. */

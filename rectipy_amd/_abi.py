@@ -113,6 +113,10 @@ class RpBwd(C.Structure):
         ("x_mode", C.c_int32),
         ("x", fp),
         ("ldx", C.c_int64),
+        ("x_target", C.c_int32),
+        ("traj_aux", fp),
+        ("lam3", fp),
+        ("grad_p", fp * RP_MAX_PARAMS),
     ]
 
 

@@ -66,6 +66,11 @@ struct BwdParams {
     const float* x_prev;   // input row of step t-1 (prep) ...
     const float* s_prev;   // ... and its s_{t-1}
     const float* s_t;
+    float* lam_x;          // adjoint of the second state (QIF_SFA x, IK u)
+    const float* aux_prev;
+    const float* acc_t;
+    float inv_dt;
+    int x_target;
 };
 
 // partials[q][j] = sum_{i in chunk q, ascending} W[i][j] * u[i]
@@ -210,53 +215,99 @@ __global__ void finalize_kernel(const BwdParams P) {
     if (P.u_next) prep_step(P, j, lam_new);
 }
 
-// ---- spiking (QIF) sweep ---------------------------------------------------------------------------
-// forward step (nodes.py:382-392, qif.yaml:11-12):  sp = H(v - theta), reset = sp.detach(),
-//   v' = (v + dt ((v^2 + eta + I)/tau + k (W s))) (1 - reset) + reset v_reset,   s' = s + dt (-s/tau_s + sp/dt)
-// adjoint with lv = dL/dv_{t+1}, ls = dL/ds_{t+1}:
-//   a = lv (1 - reset_t);  u = k a;  z = W^T u
-//   lv_t = (a + dt (a (2 v_t / tau))) + ls sg(v_t - theta) + [G_t if out = v]
-//   ls_t = (ls + dt (-ls / tau_s + z)) + [G_t if out = s]
-// with the surrogate sg(x) = 1 / (1 + slope |x|)^2 (Spike.backward, nodes.py:479-481).
+// ---- spiking sweep (QIF, QIF_SFA, LIF, IK) -------------------------------------------------------------
+// forward step (nodes.py:382-392):  sp = H(v - theta), reset = sp.detach(), spike_in = sp/dt,
+//   v' = (v + dt dv)(1 - reset) + reset v_reset,  s' = s + dt (-s/tau_s + spike_in [+ s_ext]),  aux' = aux + dt daux
+// adjoint with lv, ls, lx = dL/d(v, s, aux)_{t+1}, a = lv (1 - reset_t), sg = 1/(1 + slope |v_t - theta|)^2
+// (Spike.backward, nodes.py:479-481), z = W^T u:
+//   QIF      u = k a            lv' = a + dt a (2v/tau)            + ls sg
+//   LIF      u = k a            lv' = a + dt (-a/tau)              + ls sg
+//   QIF_SFA  u = k a            lv' = a + dt a (2v/tau)            + (ls + alpha lx) sg     lx' = lx + dt (-lx/tau_x - a/tau)
+//   IK       u = a g (E_r-v)/C  lv' = a + dt (a dfdv + lx b/tau_u) + (ls + kappa lx) sg     lx' = lx + dt (-lx/tau_u - a/C)
+//            dfdv = (k ((v-v_r) + (v-v_theta)) - g (W s)) / C
+//   all      ls' = ls + dt (-ls/tau_s + z)            (+ G_t on the output variable)
 
-__device__ __forceinline__ float qif_input(const BwdParams& P, const float* row, int j) {
+struct SpkGrad {  // per-neuron parameter gradient targets, resolved on the host
+    float* p[RP_MAX_PARAMS];
+};
+
+__device__ __forceinline__ float spk_input(const BwdParams& P, const float* row, int j) {
     if (P.x_mode == RP_X_FULL) return row[j];
     if (P.x_mode == RP_X_BCAST) return row[0];
     return 0.f;
 }
 
-__device__ __forceinline__ void qif_prep_step(const BwdParams& P, int j, float lv, float ls) {
+__device__ __forceinline__ void spk_prep_step(const BwdParams& P, const SpkGrad& G, int j, float lv, float ls, float lx) {
     const float v = P.v_prev[j];
-    const float reset = (v - P.theta >= 0.0f) ? 1.0f : 0.0f;
-    const float a = lv * (1.0f - reset);
-    P.u_next[j] = P.p[RP_P_K][j] * a;
-    const float tau = P.p[RP_P_TAU][j];
+    const float sp = (v - P.theta >= 0.0f) ? 1.0f : 0.0f;
+    const float a = lv * (1.0f - sp);
     const float da = P.dt * a;
-    if (P.grad_eta) P.grad_eta[j] += da / tau;
-    if (P.grad_k) P.grad_k[j] += da * P.acc_prev[j];
-    if (P.grad_tau) {
-        const float num = (v * v + P.p[RP_P_ETA][j]) + qif_input(P, P.x_prev, j);
-        P.grad_tau[j] += -(da * (num / (tau * tau)));
+    const float I = spk_input(P, P.x_prev, j);
+    const float Im = P.x_target == RP_XT_MEMBRANE ? I : 0.f;
+    const float spike_in = sp * P.inv_dt;
+    float gx = 0.f;
+    if (P.model == RP_MODEL_IK) {
+        const float C = P.p[RP_P_IK_C][j], vr = P.p[RP_P_V_R][j], vt = P.p[RP_P_V_THETA][j];
+        const float g = P.p[RP_P_G][j], Er = P.p[RP_P_E_R][j], b = P.p[RP_P_B][j], tu = P.p[RP_P_TAU_U][j];
+        const float acc = P.acc_prev[j], uu = P.aux_prev[j];
+        const float dvr = v - vr, dvt = v - vt;
+        P.u_next[j] = a * ((g * (Er - v)) / C);
+        const float dlx = P.dt * lx;
+        if (G.p[RP_P_ETA]) G.p[RP_P_ETA][j] += da / C;
+        if (G.p[RP_P_K]) G.p[RP_P_K][j] += da * ((dvr * dvt) / C);
+        if (G.p[RP_P_G]) G.p[RP_P_G][j] += da * ((acc * (Er - v)) / C);
+        if (G.p[RP_P_IK_C]) {
+            const float num = ((((P.p[RP_P_K][j] * dvr) * dvt - uu) + Im) + P.p[RP_P_ETA][j]) + (g * acc) * (Er - v);
+            G.p[RP_P_IK_C][j] += -(da * (num / (C * C)));
+        }
+        if (G.p[RP_P_B]) G.p[RP_P_B][j] += dlx * (dvr / tu);
+        if (G.p[RP_P_TAU_U]) G.p[RP_P_TAU_U][j] += -(dlx * ((b * dvr - uu) / (tu * tu)));
+        if (G.p[RP_P_KAPPA]) G.p[RP_P_KAPPA][j] += dlx * spike_in;
+        gx = da / C;
+    } else {
+        const float tau = P.p[RP_P_TAU][j];
+        P.u_next[j] = P.p[RP_P_K][j] * a;
+        if (G.p[RP_P_K]) G.p[RP_P_K][j] += da * P.acc_prev[j];
+        if (P.model == RP_MODEL_LIF) {
+            if (G.p[RP_P_ETA]) G.p[RP_P_ETA][j] += da;
+            if (G.p[RP_P_TAU]) G.p[RP_P_TAU][j] += da * (v / (tau * tau));
+            gx = P.x_target == RP_XT_MEMBRANE ? da : P.dt * ls;
+        } else {  // QIF, QIF_SFA
+            if (G.p[RP_P_ETA]) G.p[RP_P_ETA][j] += da / tau;
+            if (G.p[RP_P_TAU]) {
+                const float eta_eff = P.model == RP_MODEL_QIF_SFA ? P.p[RP_P_ETA][j] - P.aux_prev[j] : P.p[RP_P_ETA][j];
+                const float num = (v * v + eta_eff) + Im;
+                G.p[RP_P_TAU][j] += -(da * (num / (tau * tau)));
+            }
+            gx = da / tau;
+            if (P.model == RP_MODEL_QIF_SFA) {
+                const float dlx = P.dt * lx;
+                const float tx = P.p[RP_P_TAU_X][j];
+                if (G.p[RP_P_ALPHA]) G.p[RP_P_ALPHA][j] += dlx * spike_in;
+                if (G.p[RP_P_TAU_X]) G.p[RP_P_TAU_X][j] += dlx * (P.aux_prev[j] / (tx * tx));
+            }
+        }
     }
-    if (P.grad_tau_s) {
+    if (G.p[RP_P_TAU_S]) {
         const float ts = P.p[RP_P_TAU_S][j];
-        P.grad_tau_s[j] += (P.dt * ls) * (P.s_prev[j] / (ts * ts));
+        G.p[RP_P_TAU_S][j] += (P.dt * ls) * (P.s_prev[j] / (ts * ts));
     }
-    if (P.gx_prev) P.gx_prev[j] = da / tau;
+    if (P.gx_prev) P.gx_prev[j] = gx;
 }
 
-__global__ void qif_prep_kernel(const BwdParams P) {
+__global__ void spk_prep_kernel(const BwdParams P, const SpkGrad G) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < P.n) qif_prep_step(P, j, P.lam[j], P.lam_s[j]);
+    if (j < P.n) spk_prep_step(P, G, j, P.lam[j], P.lam_s[j], P.lam_x ? P.lam_x[j] : 0.f);
 }
 
-__global__ void qif_finalize_kernel(const BwdParams P) {
+__global__ void spk_finalize_kernel(const BwdParams P, const SpkGrad G) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.n) return;
     float z = 0.f;
     for (int c = 0; c < P.q; ++c) z = z + P.partials[(int64_t)c * P.n + j];
     const float lv = P.lam[j];
     const float ls = P.lam_s[j];
+    const float lx = P.lam_x ? P.lam_x[j] : 0.f;
     const float v = P.v_t[j];
     const float x = v - P.theta;
     const float reset = (x >= 0.0f) ? 1.0f : 0.0f;
@@ -266,11 +317,27 @@ __global__ void qif_finalize_kernel(const BwdParams P) {
     const float g = P.g_t ? P.g_t[j] : 0.f;
     const float gv = (P.grad_var == RP_OUT_STATE0) ? g : 0.f;
     const float gs = (P.grad_var == RP_OUT_STATE0) ? 0.f : g;
-    const float lv_new = ((a + P.dt * (a * ((2.0f * v) / P.p[RP_P_TAU][j]))) + ls * sg) + gv;
+    float lv_new, lx_new = 0.f;
+    if (P.model == RP_MODEL_QIF) {
+        lv_new = ((a + P.dt * (a * ((2.0f * v) / P.p[RP_P_TAU][j]))) + ls * sg) + gv;
+    } else if (P.model == RP_MODEL_LIF) {
+        lv_new = ((a + P.dt * (-a / P.p[RP_P_TAU][j])) + ls * sg) + gv;
+    } else if (P.model == RP_MODEL_QIF_SFA) {
+        const float tau = P.p[RP_P_TAU][j];
+        lv_new = ((a + P.dt * (a * ((2.0f * v) / tau))) + (ls + P.p[RP_P_ALPHA][j] * lx) * sg) + gv;
+        lx_new = lx + P.dt * (-lx / P.p[RP_P_TAU_X][j] - a / tau);
+    } else {  // IK
+        const float C = P.p[RP_P_IK_C][j], tu = P.p[RP_P_TAU_U][j];
+        const float dfdv = (P.p[RP_P_K][j] * ((v - P.p[RP_P_V_R][j]) + (v - P.p[RP_P_V_THETA][j])) -
+                            P.p[RP_P_G][j] * P.acc_t[j]) / C;
+        lv_new = ((a + P.dt * (a * dfdv + lx * (P.p[RP_P_B][j] / tu))) + (ls + P.p[RP_P_KAPPA][j] * lx) * sg) + gv;
+        lx_new = lx + P.dt * (-lx / tu - a / C);
+    }
     const float ls_new = (ls + P.dt * (-ls / P.p[RP_P_TAU_S][j] + z)) + gs;
     P.lam[j] = lv_new;
     P.lam_s[j] = ls_new;
-    if (P.u_next) qif_prep_step(P, j, lv_new, ls_new);
+    if (P.lam_x) P.lam_x[j] = lx_new;
+    if (P.u_next) spk_prep_step(P, G, j, lv_new, ls_new, lx_new);
 }
 
 }  // namespace
@@ -364,24 +431,50 @@ int rp_set_bwd_tuning(int unroll, int strip_groups) {
 
 int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     if (!net || !b) RP_FAIL(RP_ERR_ARG, "net/bwd is null");
-    if (net->model != RP_MODEL_QIF) RP_FAIL(RP_ERR_ARG, "rp_qif_backward needs the QIF model (model=%d)", net->model);
+    const int model = net->model;
+    if (model != RP_MODEL_QIF && model != RP_MODEL_QIF_SFA && model != RP_MODEL_LIF && model != RP_MODEL_IK)
+        RP_FAIL(RP_ERR_ARG, "rp_qif_backward needs a spiking model (model=%d)", model);
+    const bool has_aux = model == RP_MODEL_QIF_SFA || model == RP_MODEL_IK;
     if (net->rows != net->n || net->row0 != 0)
         RP_FAIL(RP_ERR_ARG, "rp_qif_backward needs the unsharded matrix (rows=%d n=%d)", net->rows, net->n);
     if (net->n <= 0 || net->ldw < net->n) RP_FAIL(RP_ERR_SHAPE, "bad n/ldw");
     if (b->steps < 0) RP_FAIL(RP_ERR_ARG, "steps < 0");
     if (!net->W || !b->traj_v || !b->traj_r || !b->lam || !b->lam2 || !b->u_traj || !b->partials)
         RP_FAIL(RP_ERR_ARG, "W, traj_v, traj_r (s_t), lam, lam2, u_traj, partials must be non-null");
-    if (!net->p[RP_P_TAU] || !net->p[RP_P_K] || !net->p[RP_P_ETA] || !net->p[RP_P_TAU_S])
-        RP_FAIL(RP_ERR_ARG, "tau/k/eta/tau_s null");
+    if (has_aux && (!b->traj_aux || !b->lam3)) RP_FAIL(RP_ERR_ARG, "model %d needs traj_aux and lam3", model);
+    if (model == RP_MODEL_IK && !b->traj_acc) RP_FAIL(RP_ERR_ARG, "the IK adjoint needs traj_acc (W s_t)");
     if (b->ld < net->n) RP_FAIL(RP_ERR_SHAPE, "ld < n");
     if (b->grad_out && b->ldg < net->n) RP_FAIL(RP_ERR_SHAPE, "ldg < n");
     if (b->grad_x && b->ldgx < net->n) RP_FAIL(RP_ERR_SHAPE, "ldgx < n");
-    if (b->grad_k && !b->traj_acc) RP_FAIL(RP_ERR_ARG, "grad_k needs traj_acc");
     if (b->grad_var != RP_OUT_STATE0 && b->grad_var != RP_OUT_SOURCE) RP_FAIL(RP_ERR_ARG, "bad grad_var");
     if (b->x_mode != RP_X_NONE && b->x_mode != RP_X_FULL && b->x_mode != RP_X_BCAST)
         RP_FAIL(RP_ERR_ARG, "x_mode must be NONE, FULL or BCAST");
     if (b->x_mode != RP_X_NONE && (!b->x || b->ldx < (b->x_mode == RP_X_FULL ? net->n : 1)))
         RP_FAIL(RP_ERR_SHAPE, "x/ldx inconsistent with x_mode");
+    if (b->x_target != RP_XT_MEMBRANE && !(b->x_target == RP_XT_SYNAPSE && model == RP_MODEL_LIF))
+        RP_FAIL(RP_ERR_ARG, "x_target %d is not available for model %d", b->x_target, model);
+
+    // parameter-gradient targets by slot; the named fields of rp_bwd cover the common four
+    SpkGrad G = {};
+    for (int q = 0; q < RP_MAX_PARAMS; ++q) G.p[q] = b->grad_p[q];
+    if (model != RP_MODEL_IK && b->grad_tau) G.p[RP_P_TAU] = b->grad_tau;
+    if (b->grad_k) G.p[RP_P_K] = b->grad_k;
+    if (b->grad_eta) G.p[RP_P_ETA] = b->grad_eta;
+    if (b->grad_tau_s) G.p[RP_P_TAU_S] = b->grad_tau_s;
+    {
+        bool ok[RP_MAX_PARAMS] = {};
+        ok[RP_P_K] = ok[RP_P_ETA] = ok[RP_P_TAU_S] = true;
+        if (model == RP_MODEL_IK) {
+            ok[RP_P_IK_C] = ok[RP_P_G] = ok[RP_P_B] = ok[RP_P_TAU_U] = ok[RP_P_KAPPA] = true;
+        } else {
+            ok[RP_P_TAU] = true;
+            if (model == RP_MODEL_QIF_SFA) ok[RP_P_ALPHA] = ok[RP_P_TAU_X] = true;
+        }
+        for (int q = 0; q < RP_MAX_PARAMS; ++q)
+            if (G.p[q] && !ok[q]) RP_FAIL(RP_ERR_ARG, "no gradient kernel for parameter slot %d of model %d", q, model);
+    }
+    if (G.p[RP_P_K] && !b->traj_acc) RP_FAIL(RP_ERR_ARG, "grad_k needs traj_acc");
+    if (model == RP_MODEL_IK && G.p[RP_P_G] && !b->traj_acc) RP_FAIL(RP_ERR_ARG, "grad_g needs traj_acc");
     const bool vec4 = (net->n % 4 == 0) && (net->ldw % 4 == 0);
     if (vec4 && ((reinterpret_cast<uintptr_t>(net->W) & 15u) || (reinterpret_cast<uintptr_t>(b->partials) & 15u)))
         RP_FAIL(RP_ERR_ARG, "W and partials must be 16-byte aligned");
@@ -394,50 +487,48 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     P.W = net->W;
     P.ldw = net->ldw;
     P.n = n;
-    P.model = net->model;
+    P.model = model;
     for (int q = 0; q < RP_MAX_PARAMS; ++q) P.p[q] = net->p[q];
     P.dt = net->dt;
+    P.inv_dt = 1.0f / net->dt;
     P.rc = chunk_rows(n);
     P.q = (n + P.rc - 1) / P.rc;
     P.partials = b->partials;
     P.grad_var = b->grad_var;
     P.lam = b->lam;
     P.lam_s = b->lam2;
-    P.grad_tau = b->grad_tau;
-    P.grad_k = b->grad_k;
-    P.grad_eta = b->grad_eta;
-    P.grad_tau_s = b->grad_tau_s;
+    P.lam_x = has_aux ? b->lam3 : nullptr;
     P.slope = b->slope;
     P.theta = net->theta;
     P.x_mode = b->x_mode;
+    P.x_target = b->x_target;
 
     const int eblocks = (n + 255) / 256;
-    const int strips = vec4 ? (n + 255) / 256 : (n + 63) / 64;
-    int mblocks = (strips * P.q + 3) / 4;
-    if (mblocks > 4096) mblocks = 4096;
 
     auto set_prep = [&](int tp) {
         P.u_next = b->u_traj + (int64_t)tp * b->ld;
         P.v_prev = b->traj_v + (int64_t)tp * b->ld;
         P.s_prev = b->traj_r + (int64_t)tp * b->ld;
+        P.aux_prev = b->traj_aux ? b->traj_aux + (int64_t)tp * b->ld : nullptr;
         P.acc_prev = b->traj_acc ? b->traj_acc + (int64_t)tp * b->ld : nullptr;
         P.gx_prev = b->grad_x ? b->grad_x + (int64_t)tp * b->ldgx : nullptr;
         P.x_prev = b->x ? b->x + (int64_t)tp * b->ldx : nullptr;
     };
 
     set_prep(T - 1);
-    hipLaunchKernelGGL(qif_prep_kernel, dim3(eblocks), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(spk_prep_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
     for (int t = T - 1; t >= 0; --t) {
         P.t = t;
         P.u = b->u_traj + (int64_t)t * b->ld;
         launch_wt_partial(P, vec4, st);
         P.v_t = b->traj_v + (int64_t)t * b->ld;
+        P.acc_t = b->traj_acc ? b->traj_acc + (int64_t)t * b->ld : nullptr;
         P.g_t = b->grad_out ? b->grad_out + (int64_t)t * b->ldg : nullptr;
         if (t > 0)
             set_prep(t - 1);
         else
             P.u_next = nullptr;
-        hipLaunchKernelGGL(qif_finalize_kernel, dim3(eblocks), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(spk_finalize_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
     }
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;

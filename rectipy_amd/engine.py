@@ -320,7 +320,8 @@ class Population:
     # -- adjoint -------------------------------------------------------------------------
     def backward(self, traj_v, traj_r, grad_out, grad_var, lam, u_traj, traj_acc=None,
                  grad_tau=None, grad_k=None, grad_eta=None, grad_x=None, lam_s=None, grad_tau_s=None,
-                 slope: float = 0.5, x: Optional[torch.Tensor] = None):
+                 slope: float = 0.5, x: Optional[torch.Tensor] = None, x_target: int = _abi.RP_XT_MEMBRANE,
+                 traj_aux=None, lam_x=None, grad_params: Optional[Dict[str, torch.Tensor]] = None):
         """Adjoint sweep over a stored window (rp_rate_backward; rp_qif_backward for the spiking model, which
         additionally takes the adjoint of s, the surrogate slope and the window's input for grad_tau)."""
         T = int(traj_v.shape[0])
@@ -342,11 +343,13 @@ class Population:
         if not self.spiking:
             self.backend.rate_backward(self._net(), b, self.device)
             return partials  # returned so the caller keeps it alive until the stream has consumed it
-        if self.model != "qif":
-            raise NotImplementedError(f"no adjoint kernel for the '{self.model}' model yet")
         b.lam2 = lam_s.data_ptr()
         b.grad_tau_s = _ptr(grad_tau_s)
         b.slope = float(slope)
+        b.x_target = int(x_target)
+        b.traj_aux, b.lam3 = _ptr(traj_aux), _ptr(lam_x)
+        for name, t in (grad_params or {}).items():  # gradients of model-specific parameters, by engine name
+            b.grad_p[PARAM_SLOTS[self.model][name]] = t.data_ptr()
         if x is None:
             b.x_mode = _abi.RP_X_NONE
         else:

@@ -379,9 +379,9 @@ class Network:
                 traj = rnn._grad_window(b - a, self._fit_width(X, N))
                 outs.append(self._apply_chain(post, traj, label, None) if post else traj)
                 if slots:
-                    tv, tr = rnn._last_window
+                    tv, tr, ta = (tuple(rnn._last_window) + (None,))[:3]
                     for j, slot in enumerate(slots):
-                        src = tv if slot == 0 else tr
+                        src = (tv, tr, ta)[slot]
                         if spiking:  # SpikeResetNet exposes the pre-update state (nodes.py:387-392)
                             recs[j].append(src)
                         else:  # post-update values: row t+1, last row = current state

@@ -115,62 +115,6 @@ class _RateWindow(torch.autograd.Function):
         return None, None, g_x, (lam if need[3] else None), g_W, g_tau, g_k, g_eta
 
 
-class _QifWindow(torch.autograd.Function):
-    """T steps of a spiking (QIF) population as ONE autograd node: forward = rp_forward with v_t, s_t captured,
-    backward = rp_qif_backward (surrogate-gradient adjoint, Spike.backward of reference nodes.py:479-481; no
-    gradient through the reset mask, nodes.py:384) + rp_outer_accum for dW."""
-
-    @staticmethod
-    def forward(ctx, node, steps, x, y_in, W, tau, k, eta, tau_s):
-        pop: Population = node._pop
-        N, dev = pop.rows, pop.device
-        f32 = dict(dtype=torch.float32, device=dev)
-        traj_v = torch.empty(steps, N, **f32)
-        traj_s = torch.empty(steps, N, **f32)
-        traj_acc = torch.empty(steps, N, **f32) if k.requires_grad else None
-        pop.forward(steps, x=x, save_v=traj_v, save_src=traj_s, save_acc=traj_acc,
-                    spike_events=node.spike_events, spike_count=node._spike_count)
-        ctx.node, ctx.steps = node, steps
-        ctx.x = None if x is None else x.detach()
-        ctx.saved = (traj_v, traj_s, traj_acc)
-        node._last_window = (traj_v, traj_s)
-        out = traj_s if node._out_code == _abi.RP_OUT_SOURCE else traj_v
-        return out.clone(), torch.cat((pop.v, pop.source_local))
-
-    @staticmethod
-    def backward(ctx, g_traj, g_yend):
-        node = ctx.node
-        pop: Population = node._pop
-        N, dev, T = pop.rows, pop.device, ctx.steps
-        traj_v, traj_s, traj_acc = ctx.saved
-        f32 = dict(dtype=torch.float32, device=dev)
-        if g_yend is None:
-            lam_v, lam_s = torch.zeros(N, **f32), torch.zeros(N, **f32)
-        else:
-            g = g_yend.detach().to(**f32)
-            lam_v, lam_s = g[:N].clone().contiguous(), g[N:].clone().contiguous()
-        g_out = None if g_traj is None else g_traj.detach().to(**f32).contiguous()
-        need = ctx.needs_input_grad  # (node, steps, x, y_in, W, tau, k, eta, tau_s)
-        u_traj = torch.empty(T, N, **f32)
-        g_tau = torch.zeros(N, **f32) if need[5] else None
-        g_k = torch.zeros(N, **f32) if need[6] else None
-        g_eta = torch.zeros(N, **f32) if need[7] else None
-        g_ts = torch.zeros(N, **f32) if need[8] else None
-        g_x = torch.empty(T, N, **f32) if need[2] else None
-        keep = pop.backward(traj_v, traj_s, g_out, node._out_code, lam_v, u_traj, traj_acc=traj_acc, grad_tau=g_tau,
-                            grad_k=g_k, grad_eta=g_eta, grad_x=g_x, lam_s=lam_s, grad_tau_s=g_ts,
-                            slope=node._spike_slope, x=ctx.x)
-        g_W = None
-        if need[4]:
-            g_W = torch.zeros(N, N, **f32)
-            pop.outer_accum(pop.dt, u_traj, traj_s, g_W)
-        if g_x is not None and ctx.x is not None and ctx.x.shape[1] == 1:
-            g_x = g_x.sum(dim=1, keepdim=True)
-        del keep
-        g_y = torch.cat((lam_v, lam_s)) if need[3] else None
-        return None, None, g_x, g_y, g_W, g_tau, g_k, g_eta, g_ts
-
-
 class RateNet:
     """Rate-neuron population integrated on the GPU (reference ``RateNet``, rectipy/nodes.py:54-290)."""
 
@@ -496,7 +440,8 @@ class SpikeResetNet(RateNet):
                                     target_var=target_var, train_params=train_params, **kwargs)
 
     def _check_trainable(self):
-        ok = {"weights", "tau", "k", "eta", "tau_s"} if self._template.model == "qif" else set()
+        from .spiking_autograd import TRAINABLE
+        ok = {"weights"} | set(TRAINABLE[self._template.model])
         bad = [n for n in self._train_names if n not in ok]
         if bad:
             raise NotImplementedError(f"no adjoint kernel for parameters {bad} of template '{self._template.name}'; "
@@ -578,17 +523,16 @@ class SpikeResetNet(RateNet):
 
     def _grad_window(self, steps: int, x: Optional[torch.Tensor]) -> torch.Tensor:
         """`steps` spiking steps recorded as one autograd node (surrogate-gradient BPTT)."""
+        from .spiking_autograd import TRAINABLE, SpikeWindow
         pop = self._pop
-        if pop.model != "qif":
-            raise NotImplementedError(f"surrogate-gradient BPTT is implemented for the qif template only, not '{pop.model}'")
         y_in = self._y_grad
         if y_in is None:
-            y_in = torch.cat((pop.v, pop.source_local)).detach().requires_grad_(self._y_requires_grad)
-        traj, y_end = _QifWindow.apply(self, steps, x, y_in, pop.W, pop.params["tau"], pop.params["k"],
-                                       pop.params["eta"], pop.params["tau_s"])
+            y_in = self.current_state.detach().requires_grad_(self._y_requires_grad)
+        params = [pop.params[n] for n in TRAINABLE[pop.model]]
+        traj, y_end = SpikeWindow.apply(self, steps, x, y_in, pop.W, *params)
         self._y_grad = y_end
-        tv, ts = self._last_window
-        self._y_prev = torch.cat((tv[-1], ts[-1]))
+        tv, ts, ta = self._last_window
+        self._y_prev = self._pack(tv[-1], ts[-1], None if ta is None else ta[-1])
         return traj
 
     def forward(self, x) -> torch.Tensor:
