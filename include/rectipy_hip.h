@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 2
+#define RP_ABI_VERSION 3
 
 #define RP_OK 0
 #define RP_ERR_ARG (-1)      /* null pointer, bad enum, bad flag combination  */
@@ -59,7 +59,9 @@ extern "C" {
 #define RP_MODEL_QIF_SFA 3    /* qif.yaml: qif_sfa_op (spike-frequency adaptation x) */
 #define RP_MODEL_LIF 4        /* lif.yaml: lif_op                            */
 #define RP_MODEL_IK 5         /* ik.yaml: ik_op (Izhikevich, recovery variable u) */
-#define RP_MODEL_COUNT 6
+#define RP_MODEL_IKU 6        /* ik.yaml: iku_op (recovery driven by the population means of v and spike)   */
+#define RP_MODEL_IK_BIEXP 7   /* ik.yaml: ik_biexp_op (iku + bi-exponential synapse, extra state x)          */
+#define RP_MODEL_COUNT 8
 
 #define RP_MAX_PARAMS 12
 #define RP_MAX_STATE 4
@@ -83,15 +85,18 @@ extern "C" {
 #define RP_P_B 8
 #define RP_P_TAU_U 9
 #define RP_P_KAPPA 10
+#define RP_P_TAU_R 11 /* IK_BIEXP: rise time; its decay time tau_d uses slot RP_P_TAU_S */
 
 /* state slots y[] (per-neuron vectors of length `rows`) */
 #define RP_Y_V 0
-#define RP_Y_AUX 1 /* QIF_SFA: adaptation x; IK: recovery u */
+#define RP_Y_AUX 1 /* QIF_SFA: adaptation x; IK family: recovery u */
+#define RP_Y_AUX2 2 /* IK_BIEXP: synaptic rise variable x */
 
 /* record slots rec[] */
 #define RP_REC_V 0
 #define RP_REC_SOURCE 1
 #define RP_REC_AUX 2
+#define RP_REC_AUX2 3
 
 /* which equation the extrinsic input enters (rp_run.x_target) */
 #define RP_XT_MEMBRANE 0 /* I_ext of the v equation (every model)            */
@@ -128,6 +133,7 @@ typedef struct rp_net {
     float dt;                 /* Euler step                                   */
     float theta;              /* QIF spike threshold (nodes.py:338)           */
     float v_reset;            /* QIF reset value     (nodes.py:338)           */
+    float* scratch;           /* device scratch [>= 4 floats]; required by IKU / IK_BIEXP (population means) */
 } rp_net;
 
 /*

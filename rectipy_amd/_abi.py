@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 2
+RP_ABI_VERSION = 3
 
 RP_OK = 0
 RP_ERR_ARG = -1
@@ -19,6 +19,8 @@ RP_MODEL_QIF = 2
 RP_MODEL_QIF_SFA = 3
 RP_MODEL_LIF = 4
 RP_MODEL_IK = 5
+RP_MODEL_IKU = 6
+RP_MODEL_IK_BIEXP = 7
 
 RP_MAX_PARAMS = 12
 RP_MAX_STATE = 4
@@ -28,8 +30,9 @@ RP_P_RMAX, RP_P_SLOPE, RP_P_V0 = 3, 4, 5
 RP_P_TAU_S = 3
 RP_P_ALPHA, RP_P_TAU_X = 4, 5
 RP_P_IK_C, RP_P_V_R, RP_P_V_THETA, RP_P_G, RP_P_E_R, RP_P_B, RP_P_TAU_U, RP_P_KAPPA = 0, 4, 5, 6, 7, 8, 9, 10
-RP_Y_V, RP_Y_AUX = 0, 1
-RP_REC_V, RP_REC_SOURCE, RP_REC_AUX = 0, 1, 2
+RP_P_TAU_R = 11
+RP_Y_V, RP_Y_AUX, RP_Y_AUX2 = 0, 1, 2
+RP_REC_V, RP_REC_SOURCE, RP_REC_AUX, RP_REC_AUX2 = 0, 1, 2, 3
 RP_XT_MEMBRANE, RP_XT_SYNAPSE = 0, 1
 
 RP_X_NONE, RP_X_FULL, RP_X_BCAST, RP_X_PROJ = 0, 1, 2, 3
@@ -53,6 +56,7 @@ class RpNet(C.Structure):
         ("dt", C.c_float),
         ("theta", C.c_float),
         ("v_reset", C.c_float),
+        ("scratch", fp),
     ]
 
 

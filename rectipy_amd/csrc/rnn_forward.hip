@@ -43,6 +43,7 @@ struct StepParams {
     const float* src_cur;
     float* src_next;
     float dt, inv_dt, theta, v_reset;
+    float* scratch;
     int x_mode, m;
     const float* x_t;  // row t of the input
     const float* w_in;
@@ -215,7 +216,7 @@ __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum)
         const float s = P.src_cur[gi];
         const float spike = (v - P.theta >= 0.0f) ? 1.0f : 0.0f;  // heaviside(v-theta, 1): equality spikes
         const float spike_in = spike * P.inv_dt;                   // nodes.py:385
-        float dv, aux = 0.f, aux_new = 0.f;
+        float dv, aux = 0.f, aux_new = 0.f, aux2 = 0.f, aux2_new = 0.f;
         float ds = -s / P.p[RP_P_TAU_S][i] + spike_in;
         if constexpr (MODEL == RP_MODEL_QIF) {
             dv = ((v * v + P.p[RP_P_ETA][i]) + I) / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * wsum;
@@ -228,21 +229,36 @@ __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum)
             const float Is = P.x_target == RP_XT_SYNAPSE ? I : 0.f;
             dv = ((-v / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * wsum) + Iv) + P.p[RP_P_ETA][i];
             ds = ds + Is;
-        } else {  // IK
+        } else {  // IK family (ik.yaml:8-68)
             aux = P.y[RP_Y_AUX][i];
             const float dvr = v - P.p[RP_P_V_R][i];
             dv = (((((P.p[RP_P_K][i] * dvr) * (v - P.p[RP_P_V_THETA][i]) - aux) + I) + P.p[RP_P_ETA][i]) +
                   (P.p[RP_P_G][i] * wsum) * (P.p[RP_P_E_R][i] - v)) / P.p[RP_P_IK_C][i];
-            aux_new = aux + P.dt * ((P.p[RP_P_B][i] * dvr - aux) / P.p[RP_P_TAU_U][i] + P.p[RP_P_KAPPA][i] * spike_in);
+            if constexpr (MODEL == RP_MODEL_IK) {
+                aux_new = aux + P.dt * ((P.p[RP_P_B][i] * dvr - aux) / P.p[RP_P_TAU_U][i] + P.p[RP_P_KAPPA][i] * spike_in);
+            } else {  // iku_op / ik_biexp_op: recovery driven by the population means (ik.yaml:34-46)
+                const float mean_v = P.scratch[0], mean_spike = P.scratch[1];
+                aux_new = aux + P.dt * ((P.p[RP_P_B][i] * (mean_v - P.p[RP_P_V_R][i]) - aux) / P.p[RP_P_TAU_U][i] +
+                                        P.p[RP_P_KAPPA][i] * mean_spike);
+                if constexpr (MODEL == RP_MODEL_IK_BIEXP) {  // s' = -s/tau_d + x ; x' = -x/tau_r + spike
+                    aux2 = P.y[RP_Y_AUX2][i];
+                    ds = -s / P.p[RP_P_TAU_S][i] + aux2;
+                    aux2_new = aux2 + P.dt * (-aux2 / P.p[RP_P_TAU_R][i] + spike_in);
+                }
+            }
         }
         float v_new = v + P.dt * dv;
         const float s_new = s + P.dt * ds;
         v_new = v_new * (1.0f - spike) + spike * P.v_reset;
         P.y[RP_Y_V][i] = v_new;
         P.src_next[gi] = s_new;
-        if constexpr (MODEL == RP_MODEL_QIF_SFA || MODEL == RP_MODEL_IK) {
+        if constexpr (MODEL == RP_MODEL_QIF_SFA || MODEL >= RP_MODEL_IK) {
             P.y[RP_Y_AUX][i] = aux_new;
             if (P.save_state_t[RP_Y_AUX]) P.save_state_t[RP_Y_AUX][i] = aux;
+        }
+        if constexpr (MODEL == RP_MODEL_IK_BIEXP) {
+            P.y[RP_Y_AUX2][i] = aux2_new;
+            if (P.save_state_t[RP_Y_AUX2]) P.save_state_t[RP_Y_AUX2][i] = aux2;
         }
         if (P.save_state_t[0]) P.save_state_t[0][i] = v;
         if (P.save_src_t) P.save_src_t[i] = s;
@@ -252,6 +268,7 @@ __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum)
             if (P.rec_row[RP_REC_V]) P.rec_row[RP_REC_V][i] = v;
             if (P.rec_row[RP_REC_SOURCE]) P.rec_row[RP_REC_SOURCE][i] = s;
             if (P.rec_row[RP_REC_AUX]) P.rec_row[RP_REC_AUX][i] = aux;
+            if (P.rec_row[RP_REC_AUX2]) P.rec_row[RP_REC_AUX2][i] = aux2;
         }
         if (spike != 0.0f && P.spike_count) {
             int slot = atomicAdd(P.spike_count, 1);
@@ -299,6 +316,34 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepParams P) {
     }
 }
 
+// Population means of the pre-update v and of the spike input (iku_op / ik_biexp_op, ik.yaml:34-46): one block,
+// 1024 strided partial sums combined by a halving tree (mirrored by the oracle).
+__global__ __launch_bounds__(1024) void mean_kernel(const StepParams P) {
+    __shared__ float red_v[1024];
+    __shared__ float red_s[1024];
+    const int tid = threadIdx.x;
+    float av = 0.f, as = 0.f;
+    for (int j = tid; j < P.rows; j += 1024) {
+        const float v = P.y[RP_Y_V][j];
+        av = av + v;
+        as = as + ((v - P.theta >= 0.0f) ? 1.0f : 0.0f) * P.inv_dt;
+    }
+    red_v[tid] = av;
+    red_s[tid] = as;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if (tid < off) {
+            red_v[tid] = red_v[tid] + red_v[tid + off];
+            red_s[tid] = red_s[tid] + red_s[tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        P.scratch[0] = red_v[0] / (float)P.rows;
+        P.scratch[1] = red_s[0] / (float)P.rows;
+    }
+}
+
 template <int MODEL>
 __global__ void refresh_kernel(const StepParams P) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,9 +380,10 @@ int n_params_required(int model, int* idx, int cap) {
         idx[c++] = RP_P_TAU_S;
         idx[c++] = RP_P_ALPHA;
         idx[c++] = RP_P_TAU_X;
-    } else if (model == RP_MODEL_IK) {
+    } else if (model >= RP_MODEL_IK) {
         const int ik[] = {RP_P_TAU_S, RP_P_V_R, RP_P_V_THETA, RP_P_G, RP_P_E_R, RP_P_B, RP_P_TAU_U, RP_P_KAPPA};
         for (int q : ik) idx[c++] = q;
+        if (model == RP_MODEL_IK_BIEXP) idx[c++] = RP_P_TAU_R;
     }
     (void)cap;
     return c;
@@ -347,8 +393,15 @@ int validate_net(const rp_net* net) {
     if (!net) RP_FAIL(RP_ERR_ARG, "net is null");
     if (net->model < RP_MODEL_LI_TANH || net->model >= RP_MODEL_COUNT)
         RP_FAIL(RP_ERR_ARG, "unknown model id %d", net->model);
-    if ((net->model == RP_MODEL_QIF_SFA || net->model == RP_MODEL_IK) && !net->y[RP_Y_AUX])
+    if ((net->model == RP_MODEL_QIF_SFA || net->model >= RP_MODEL_IK) && !net->y[RP_Y_AUX])
         RP_FAIL(RP_ERR_ARG, "model %d needs the second state vector y[1]", net->model);
+    if (net->model == RP_MODEL_IK_BIEXP && !net->y[RP_Y_AUX2])
+        RP_FAIL(RP_ERR_ARG, "model %d needs the third state vector y[2]", net->model);
+    if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP) {
+        if (!net->scratch) RP_FAIL(RP_ERR_ARG, "model %d needs rp_net.scratch", net->model);
+        if (net->rows != net->n)
+            RP_FAIL(RP_ERR_ARG, "population means are not available on a row shard (model %d)", net->model);
+    }
     if (net->n <= 0 || net->rows <= 0 || net->row0 < 0 || (int64_t)net->row0 + net->rows > net->n)
         RP_FAIL(RP_ERR_SHAPE, "bad shard: n=%d rows=%d row0=%d", net->n, net->rows, net->row0);
     if (net->ldw < net->n) RP_FAIL(RP_ERR_SHAPE, "ldw=%lld < n=%d", (long long)net->ldw, net->n);
@@ -379,6 +432,7 @@ void fill_static(StepParams& P, const rp_net* net) {
     P.inv_dt = 1.0f / net->dt;
     P.theta = net->theta;
     P.v_reset = net->v_reset;
+    P.scratch = net->scratch;
 }
 
 // Tuning override (rp_set_tuning): 0 = use the built-in choice.
@@ -430,7 +484,9 @@ void launch_step_model(int model, const StepParams& P, hipStream_t st) {
         case RP_MODEL_QIF: launch_step<RP_MODEL_QIF, VEC4>(P, st); break;
         case RP_MODEL_QIF_SFA: launch_step<RP_MODEL_QIF_SFA, VEC4>(P, st); break;
         case RP_MODEL_LIF: launch_step<RP_MODEL_LIF, VEC4>(P, st); break;
-        default: launch_step<RP_MODEL_IK, VEC4>(P, st); break;
+        case RP_MODEL_IK: launch_step<RP_MODEL_IK, VEC4>(P, st); break;
+        case RP_MODEL_IKU: launch_step<RP_MODEL_IKU, VEC4>(P, st); break;
+        default: launch_step<RP_MODEL_IK_BIEXP, VEC4>(P, st); break;
     }
 }
 
@@ -567,6 +623,8 @@ int rp_forward(rp_net* net, rp_run* run, void* stream) {
                 run->acc_count = 0;
             }
         }
+        if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP)
+            hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, st, P);
         if (vec4)
             launch_step_model<true>(net->model, P, st);
         else

@@ -19,9 +19,12 @@ from . import _abi
 from ._abi import RpBwd, RpNet, RpRun
 
 MODEL_IDS = {"li_tanh": _abi.RP_MODEL_LI_TANH, "li_sigmoid": _abi.RP_MODEL_LI_SIGMOID, "qif": _abi.RP_MODEL_QIF,
-             "qif_sfa": _abi.RP_MODEL_QIF_SFA, "lif": _abi.RP_MODEL_LIF, "ik": _abi.RP_MODEL_IK}
-SPIKING = ("qif", "qif_sfa", "lif", "ik")   # source vector is the state variable s, threshold + reset on v
-HAS_AUX = ("qif_sfa", "ik")                 # second per-neuron state: adaptation x / recovery u
+             "qif_sfa": _abi.RP_MODEL_QIF_SFA, "lif": _abi.RP_MODEL_LIF, "ik": _abi.RP_MODEL_IK,
+             "iku": _abi.RP_MODEL_IKU, "ik_biexp": _abi.RP_MODEL_IK_BIEXP}
+SPIKING = ("qif", "qif_sfa", "lif", "ik", "iku", "ik_biexp")  # source = state variable s, threshold + reset on v
+HAS_AUX = ("qif_sfa", "ik", "iku", "ik_biexp")                # second per-neuron state: adaptation x / recovery u
+HAS_AUX2 = ("ik_biexp",)                                      # third state: synaptic rise variable x
+NEEDS_MEANS = ("iku", "ik_biexp")                             # population means of v and spike (not shardable)
 
 # parameter name -> slot, per model (names follow the YAML templates of the reference)
 PARAM_SLOTS = {
@@ -36,6 +39,9 @@ PARAM_SLOTS = {
            "v_r": _abi.RP_P_V_R, "v_theta": _abi.RP_P_V_THETA, "g": _abi.RP_P_G, "E_r": _abi.RP_P_E_R,
            "b": _abi.RP_P_B, "tau_u": _abi.RP_P_TAU_U, "kappa": _abi.RP_P_KAPPA},
 }
+PARAM_SLOTS["iku"] = dict(PARAM_SLOTS["ik"])
+PARAM_SLOTS["ik_biexp"] = {**{k: v for k, v in PARAM_SLOTS["ik"].items() if k != "tau_s"},
+                           "tau_d": _abi.RP_P_TAU_S, "tau_r": _abi.RP_P_TAU_R}
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -112,7 +118,7 @@ class Population:
 
     def __init__(self, model: str, weights, params: Dict[str, object], dt: float, device,
                  v0=None, s0=None, theta: float = 100.0, v_reset: float = -100.0,
-                 n: Optional[int] = None, row0: int = 0, backend=None, aux0=None):
+                 n: Optional[int] = None, row0: int = 0, backend=None, aux0=None, aux2_0=None):
         if model not in MODEL_IDS:
             raise ValueError(f"unknown model '{model}'; available: {sorted(MODEL_IDS)}")
         self.model = model
@@ -147,6 +153,8 @@ class Population:
 
         self.v = self._vec(0.0 if v0 is None else v0)
         self.aux = self._vec(0.0 if aux0 is None else aux0) if model in HAS_AUX else None
+        self.aux2 = self._vec(0.0 if aux2_0 is None else aux2_0) if model in HAS_AUX2 else None
+        self._scratch = torch.zeros(4, **f32) if model in NEEDS_MEANS else None
         self.spiking = model in SPIKING
         self.src = [torch.zeros(self.n, **f32), torch.zeros(self.n, **f32)]
         self.cur = 0
@@ -181,6 +189,10 @@ class Population:
         net.y[_abi.RP_Y_V] = self.v.data_ptr()
         if self.aux is not None:
             net.y[_abi.RP_Y_AUX] = self.aux.data_ptr()
+        if self.aux2 is not None:
+            net.y[_abi.RP_Y_AUX2] = self.aux2.data_ptr()
+        if self._scratch is not None:
+            net.scratch = self._scratch.data_ptr()
         net.src[0] = self.src[0].data_ptr()
         net.src[1] = self.src[1].data_ptr()
         net.cur = self.cur
@@ -224,7 +236,8 @@ class Population:
                 traj: Optional[torch.Tensor] = None, save_v: Optional[torch.Tensor] = None,
                 save_src: Optional[torch.Tensor] = None, save_acc: Optional[torch.Tensor] = None,
                 spike_events: Optional[torch.Tensor] = None, spike_count: Optional[torch.Tensor] = None,
-                x_target: int = _abi.RP_XT_MEMBRANE, save_aux: Optional[torch.Tensor] = None) -> int:
+                x_target: int = _abi.RP_XT_MEMBRANE, save_aux: Optional[torch.Tensor] = None,
+                save_aux2: Optional[torch.Tensor] = None) -> int:
         """Integrate ``steps`` Euler steps in one library call.  Returns the next sample index.
 
         x: None | [steps, rows] | [steps, 1] | [steps, m] together with ``w_in`` [rows, m].
@@ -272,7 +285,7 @@ class Population:
 
         run.traj, run.ldtraj = rowbuf(traj, "traj", steps)
         ld_save = 0
-        for t, field in ((save_v, 0), (save_aux, 1), (save_src, "save_src"), (save_acc, "save_acc")):
+        for t, field in ((save_v, 0), (save_aux, 1), (save_aux2, 2), (save_src, "save_src"), (save_acc, "save_acc")):
             p, ld = rowbuf(t, "save buffer", steps)
             if p is not None:
                 if ld_save and ld != ld_save:
@@ -343,6 +356,8 @@ class Population:
         if not self.spiking:
             self.backend.rate_backward(self._net(), b, self.device)
             return partials  # returned so the caller keeps it alive until the stream has consumed it
+        if self.model in NEEDS_MEANS:
+            raise NotImplementedError(f"no adjoint kernel for the '{self.model}' model (population-mean coupling)")
         b.lam2 = lam_s.data_ptr()
         b.grad_tau_s = _ptr(grad_tau_s)
         b.slope = float(slope)

@@ -347,6 +347,8 @@ class Network:
                 slots.append(1)
             elif name == getattr(rnn, "_aux_name", None):
                 slots.append(2)
+            elif name == getattr(rnn, "_aux2_name", None):
+                slots.append(3)
             else:
                 return None
         return slots

@@ -148,14 +148,17 @@ class RateNet:
         eng_params = {template.engine_names[p]: values[p] for p, _ in template.params}
         kw = {}
         # which state variable lives where in the engine: v (reset / first state), s (the source), aux (x or u)
-        self._aux_name = None
+        self._aux_name = self._aux2_name = None
         if self._spiking:
             aux = [s for s in state_names if s not in (template.reset_var, template.source_var)]
             self._aux_name = aux[0] if aux else None
+            self._aux2_name = aux[1] if len(aux) > 1 else None
             kw = dict(v0=values[template.reset_var], s0=values[template.source_var],
                       theta=kwargs.pop("spike_threshold", 1e2), v_reset=kwargs.pop("spike_reset", -1e2))
             if self._aux_name:
                 kw["aux0"] = values[self._aux_name]
+            if self._aux2_name:
+                kw["aux2_0"] = values[self._aux2_name]
         else:
             kw = dict(v0=values[state_names[0]])
         shard = kwargs.pop("shard", None)  # (row0, n): this node holds rows [row0, row0+rows) of an n x n matrix
@@ -183,7 +186,7 @@ class RateNet:
                                           f"'{template.input_var}' only")
             raise KeyError(f"Variable {input_var} was not found on template '{template.name}'.")
         if output_var in self._var_map:
-            if output_var == self._aux_name:
+            if output_var in (self._aux_name, self._aux2_name):
                 raise NotImplementedError(f"output_var='{output_var}': the kernels emit v or the synaptic variable")
             first = template.reset_var if self._spiking else state_names[0]
             self._out_code = _abi.RP_OUT_STATE0 if output_var == first else _abi.RP_OUT_SOURCE
@@ -441,7 +444,8 @@ class SpikeResetNet(RateNet):
 
     def _check_trainable(self):
         from .spiking_autograd import TRAINABLE
-        ok = {"weights"} | set(TRAINABLE[self._template.model])
+        model = self._template.model
+        ok = ({"weights"} | set(TRAINABLE[model])) if model in TRAINABLE else set()
         bad = [n for n in self._train_names if n not in ok]
         if bad:
             raise NotImplementedError(f"no adjoint kernel for parameters {bad} of template '{self._template.name}'; "
@@ -452,18 +456,20 @@ class SpikeResetNet(RateNet):
             raise KeyError("the spike input is internal to the fused kernel")
         return super()._tensor(engine_name)
 
-    def _pack(self, v, s, aux=None) -> torch.Tensor:
-        """cat of the engine's (v, s, aux) vectors in the template's state-vector order."""
+    def _pack(self, v, s, aux=None, aux2=None) -> torch.Tensor:
+        """cat of the engine's (v, s, aux, aux2) vectors in the template's state-vector order."""
         parts = {self._template.reset_var: v, self._template.source_var: s}
         if self._aux_name:
             parts[self._aux_name] = aux
+        if self._aux2_name:
+            parts[self._aux2_name] = aux2
         return torch.cat([parts[name] for name, _ in self._template.state])
 
     def _state_bufs(self, rows: int = 1):
-        """Scratch rows that receive the pre-update (v, s, aux) of a step."""
+        """Scratch rows that receive the pre-update (v, s, aux, aux2) of a step."""
         pop = self._pop
         mk = lambda: torch.empty(rows, pop.rows, dtype=torch.float32, device=pop.device)
-        return mk(), mk(), (mk() if self._aux_name else None)
+        return mk(), mk(), (mk() if self._aux_name else None), (mk() if self._aux2_name else None)
 
     @property
     def y(self) -> torch.Tensor:
@@ -474,7 +480,7 @@ class SpikeResetNet(RateNet):
     @property
     def current_state(self) -> torch.Tensor:
         """State after the last step (what the reference keeps in _y_start/_y_spike/_y_stop), in template order."""
-        return self._pack(self._pop.v, self._pop.source_local, self._pop.aux)
+        return self._pack(self._pop.v, self._pop.source_local, self._pop.aux, self._pop.aux2)
 
     def enable_spike_recording(self, capacity: int):
         """Allocate a device buffer for (step, neuron) spike events."""
@@ -515,8 +521,10 @@ class SpikeResetNet(RateNet):
                     pop.v.copy_(cur[lo:hi])
                 elif name == self._template.source_var:
                     pop.set_source_local(cur[lo:hi])
-                else:
+                elif name == self._aux_name:
                     pop.aux.copy_(cur[lo:hi])
+                else:
+                    pop.aux2.copy_(cur[lo:hi])
         self._y_prev = None
         self._y_grad = None
         pop.reset_sampling()
@@ -525,6 +533,8 @@ class SpikeResetNet(RateNet):
         """`steps` spiking steps recorded as one autograd node (surrogate-gradient BPTT)."""
         from .spiking_autograd import TRAINABLE, SpikeWindow
         pop = self._pop
+        if pop.model not in TRAINABLE:
+            raise NotImplementedError(f"no adjoint kernel for the '{pop.model}' template")
         y_in = self._y_grad
         if y_in is None:
             y_in = self.current_state.detach().requires_grad_(self._y_requires_grad)
@@ -543,10 +553,10 @@ class SpikeResetNet(RateNet):
         pop = self._pop
         N = pop.rows
         out = torch.empty(1, N, dtype=torch.float32, device=pop.device)
-        sv, ss, sa = self._state_bufs()
-        pop.forward(1, x=x2, traj=out, save_v=sv, save_src=ss, save_aux=sa, out_var=self._out_code,
+        sv, ss, sa, sb = self._state_bufs()
+        pop.forward(1, x=x2, traj=out, save_v=sv, save_src=ss, save_aux=sa, save_aux2=sb, out_var=self._out_code,
                     x_target=self._x_target, spike_events=self.spike_events, spike_count=self._spike_count)
-        self._y_prev = self._pack(sv[0], ss[0], None if sa is None else sa[0])
+        self._y_prev = self._pack(sv[0], ss[0], None if sa is None else sa[0], None if sb is None else sb[0])
         return out[0]
 
     def run_window(self, steps: int, x=None, w_in=None, **kw):
@@ -567,9 +577,9 @@ class SpikeResetNet(RateNet):
         if steps > 1:
             idx = pop.forward(steps - 1, x=rows(x, 0, steps - 1), w_in=w_in, out_var=self._out_code, step0=step0,
                               sample_idx=idx, traj=rows(traj, 0, steps - 1), **kw)
-        sv, ss, sa = self._state_bufs()
+        sv, ss, sa, sb = self._state_bufs()
         idx = pop.forward(1, x=rows(x, steps - 1, steps), w_in=w_in, out_var=self._out_code,
                           step0=step0 + steps - 1, sample_idx=idx, traj=rows(traj, steps - 1, steps),
-                          save_v=sv, save_src=ss, save_aux=sa, **kw)
-        self._y_prev = self._pack(sv[0], ss[0], None if sa is None else sa[0])
+                          save_v=sv, save_src=ss, save_aux=sa, save_aux2=sb, **kw)
+        self._y_prev = self._pack(sv[0], ss[0], None if sa is None else sa[0], None if sb is None else sb[0])
         return idx

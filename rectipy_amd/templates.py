@@ -10,9 +10,9 @@ default values are those of the reference's YAML files:
   neuron_model_templates/rate_neurons/leaky_integrator.yaml:8-36  (li_op, sigmoid_op, tanh_op)
   neuron_model_templates/spiking_neurons/qif.yaml:8-35            (qif_op, qif_sfa_op)
   neuron_model_templates/spiking_neurons/lif.yaml:10-23           (lif_op)
-  neuron_model_templates/spiking_neurons/ik.yaml:8-31             (ik_op)
+  neuron_model_templates/spiking_neurons/ik.yaml:8-68             (ik_op, iku_op, ik_biexp_op)
 
-Anything else (the mean-field IK variants, user YAML, PyRates template objects) raises -- there is
+Anything else (user YAML, PyRates template objects) raises -- there is
 no silent fallback to a generic interpreter.
 """
 from dataclasses import dataclass, field
@@ -88,8 +88,27 @@ _FILES["ik"] = {"ik": Template(
                   "ik_op/g": "g", "ik_op/E_r": "E_r", "ik_op/b": "b", "ik_op/tau_u": "tau_u", "ik_op/kappa": "kappa",
                   "ik_op/tau_s": "tau_s"})}
 
-# templates that exist in the reference's YAML files but have no kernel here yet
-_KNOWN_UNSUPPORTED = {"ik": ("iku", "ik_biexp"), "qif": ("qif_reset",)}
+_IK_PARAMS = (("C", 100.0), ("k", 0.7), ("v_r", -60.0), ("v_theta", -40.0), ("eta", 0.0), ("g", 1.0), ("E_r", 0.0),
+              ("b", -2.0), ("tau_u", 33.33), ("kappa", 10.0))
+_FILES["ik"]["iku"] = Template(
+    # ik.yaml:34-40: ik_op with b*(mean(v)-v_r) and kappa*mean(spike) in the recovery equation; state order v, u, s
+    name="iku", model="iku", state=(("iku_op/v", -60.0), ("iku_op/u", 0.0), ("iku_op/s", 0.0)),
+    params=tuple((f"iku_op/{q}", d) for q, d in _IK_PARAMS) + (("iku_op/tau_s", 6.0),),
+    input_var="iku_op/I_ext", target_var="iku_op/s_in", source_var="iku_op/s", spike_var="iku_op/spike",
+    reset_var="iku_op/v",
+    engine_names={**{f"iku_op/{q}": q for q, _ in _IK_PARAMS}, "iku_op/tau_s": "tau_s"})
+_FILES["ik"]["ik_biexp"] = Template(
+    # ik.yaml:42-68: global recovery variable + bi-exponential synapse; state order v, u, s, x
+    name="ik_biexp", model="ik_biexp",
+    state=(("ik_biexp_op/v", -60.0), ("ik_biexp_op/u", 0.0), ("ik_biexp_op/s", 0.0), ("ik_biexp_op/x", 0.0)),
+    params=tuple((f"ik_biexp_op/{q}", d) for q, d in _IK_PARAMS) + (("ik_biexp_op/tau_r", 2.0), ("ik_biexp_op/tau_d", 6.0)),
+    input_var="ik_biexp_op/I_ext", target_var="ik_biexp_op/s_in", source_var="ik_biexp_op/s",
+    spike_var="ik_biexp_op/spike", reset_var="ik_biexp_op/v",
+    engine_names={**{f"ik_biexp_op/{q}": q for q, _ in _IK_PARAMS}, "ik_biexp_op/tau_r": "tau_r",
+                  "ik_biexp_op/tau_d": "tau_d"})
+
+# operator templates of the reference's YAML files that no node template uses
+_KNOWN_UNSUPPORTED = {"qif": ("qif_reset",)}
 
 
 def resolve(path) -> Template:

@@ -46,7 +46,7 @@ def test_node_construction_variants(where):
     with pytest.raises(KeyError):
         RateNet.from_pyrates(TANH, weights=W, source_var="x", target_var=TGT, input_var=IN, output_var=OUT, **where)
     with pytest.raises(NotImplementedError):
-        RateNet.from_pyrates("neuron_model_templates.spiking_neurons.ik.iku", weights=W, source_var="s",
+        RateNet.from_pyrates("neuron_model_templates.spiking_neurons.qif.qif_reset", weights=W, source_var="s",
                              target_var="s_in", input_var="I_ext", output_var="s", **where)
 
     nets = [Network(1e-2, **where) for _ in range(4)]

@@ -135,3 +135,57 @@ def test_new_spiking_models_hip_vs_oracle_bit_exact(oracle_backend, hip_device, 
     for a, b in zip(res[0][2:], res[1][2:]):
         if a is not None:
             assert ((a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))).all()
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("name,op,states,extra", [
+    ("g18_iku", "iku_op", ("v", "u", "s"), ("tau_s",)),
+    ("g19_ik_biexp", "ik_biexp_op", ("v", "u", "s", "x"), ("tau_r", "tau_d")),
+])
+def test_g18_g19_ik_population_mean_variants(target, name, op, states, extra):
+    """iku / ik_biexp: the recovery variable is driven by mean(v) and mean(spike) over the population
+    (ik.yaml:34-68) -- a per-step reduction kernel in front of the step kernel."""
+    g = gold(name)
+    n, T = g["W"].shape[0], int(g["T"])
+    names = ("C", "k", "v_r", "v_theta", "eta", "g", "E_r", "b", "tau_u", "kappa") + extra
+    node_vars = {f"all/{op}/{q}": g[q] for q in names}
+    for i, st in enumerate(states):
+        node_vars[f"all/{op}/{st}"] = g["y0"][i * n:(i + 1) * n]
+    node = SpikeResetNet.from_pyrates(
+        BASE + "ik." + op[:-3], input_var=f"{op}/I_ext", output_var=f"{op}/s", weights=g["W"], source_var=f"{op}/s",
+        target_var=f"{op}/s_in", spike_var=f"{op}/spike", reset_var=f"{op}/v", dt=float(g["dt"]), dtype=torch.float32,
+        node_vars=node_vars, spike_threshold=float(g["theta"]), spike_reset=float(g["v_reset"]), **target)
+    x = torch.full((T, 1), float(g["x_const"]), device=target["device"])
+    check(node, g, T, x, n_state=len(states), tol_s=2e-3)
+    with pytest.raises(NotImplementedError):
+        SpikeResetNet.from_pyrates(
+            BASE + "ik." + op[:-3], input_var=f"{op}/I_ext", output_var=f"{op}/s", weights=g["W"], source_var=f"{op}/s",
+            target_var=f"{op}/s_in", spike_var=f"{op}/spike", reset_var=f"{op}/v", dtype=torch.float32,
+            train_params=["weights"], **target)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["iku", "ik_biexp"])
+def test_mean_coupled_models_hip_vs_oracle_bit_exact(oracle_backend, hip_device, model):
+    N, T = 1500, 300
+    gen = torch.Generator().manual_seed(23)
+    W = torch.rand(N, N, generator=gen) * 10.0 / N
+    params = dict(C=100.0, k=0.7, v_r=-60.0, v_theta=-40.0, eta=torch.randn(N, generator=gen) * 5, g=1.0, E_r=0.0,
+                  b=-2.0, tau_u=33.33, kappa=10.0)
+    params.update(dict(tau_s=6.0) if model == "iku" else dict(tau_r=2.0, tau_d=6.0))
+    kw = dict(v0=torch.rand(N, generator=gen) * 90 - 60, s0=0.0, aux0=0.0, theta=40.0, v_reset=-55.0)
+    x = torch.full((T, 1), 120.0)
+    res = []
+    for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+        pop = Population(model, W, params, 1e-1, dev, backend=backend, **kw)
+        ev = torch.zeros(N * T, 2, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        traj = torch.zeros(T, N, device=dev)
+        sa = torch.zeros(T, N, device=dev)
+        pop.forward(T, x=x.to(dev), traj=traj, out_var=_abi.RP_OUT_SOURCE, save_aux=sa, spike_events=ev, spike_count=cnt)
+        c = int(cnt.item())
+        e = ev[:c].cpu().numpy()
+        res.append((c, e[np.lexsort((e[:, 1], e[:, 0]))], traj.cpu().numpy(), sa.cpu().numpy(), pop.v.cpu().numpy()))
+    assert res[0][0] == res[1][0] and res[0][0] > N // 4 and (res[0][1] == res[1][1]).all()
+    for a, b in zip(res[0][2:], res[1][2:]):
+        assert ((a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))).all()
