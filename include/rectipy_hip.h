@@ -229,6 +229,18 @@ int32_t rp_bwd_partial_rows(int32_t n);
 /* Adjoint sweep t = T-1..0 over a stored window (unsharded LI models). */
 int rp_rate_backward(const rp_net* net, const rp_bwd* bwd, void* stream);
 
+/*
+ * Row-sharded adjoint of the leaky-integrator models, one step at a time (W^T(k*lambda) from row shards
+ * gives full-length partial sums -> reduce-scatter).  Per-neuron vectors of rp_bwd are LOCAL (length net->rows);
+ * partials needs rp_bwd_shard_partial_rows(n, rows) x n floats.  Sequence:
+ *   rp_bwd_prepare;  for t = T-1 .. 0:  rp_bwd_partial(t, z_full[n]) -> caller reduce-scatters z_full over the ranks
+ *   -> rp_bwd_apply(t, z_local[rows]).
+ */
+int32_t rp_bwd_shard_partial_rows(int32_t n, int32_t rows);
+int rp_bwd_prepare(const rp_net* net, const rp_bwd* bwd, void* stream);
+int rp_bwd_partial(const rp_net* net, const rp_bwd* bwd, int32_t t, float* z_full, void* stream);
+int rp_bwd_apply(const rp_net* net, const rp_bwd* bwd, int32_t t, const float* z_local, void* stream);
+
 /* Surrogate-gradient adjoint sweep of a spiking step (QIF, QIF_SFA, LIF, IK): gradient flows through the Heaviside
    via Spike.backward (nodes.py:479-481) but not through the reset mask (nodes.py:384). */
 int rp_qif_backward(const rp_net* net, const rp_bwd* bwd, void* stream);
@@ -236,6 +248,9 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* bwd, void* stream);
 /* C[n x n] (ldc) += alpha * A^T B with A = [T x n] (lda), B = [T x n] (ldb): MFMA f32 GEMM. */
 int rp_outer_accum(int32_t n, int32_t T, float alpha, const float* A, int64_t lda, const float* B,
                    int64_t ldb, float* C, int64_t ldc, void* stream);
+/* Rectangular form for a row shard: C[m x n] += alpha * A^T B with A = [T x m], B = [T x n]. */
+int rp_outer_accum_rect(int32_t m, int32_t n, int32_t T, float alpha, const float* A, int64_t lda, const float* B,
+                        int64_t ldb, float* C, int64_t ldc, void* stream);
 
 /*
  * Recursive-least-squares training of a readout edge (reference RLS.update, rectipy/edges.py:227-234, driven by

@@ -66,6 +66,22 @@ class OracleBackend:
     def outer_accum(self, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
         assert self.lib.oracle_outer_accum(n, T, alpha, A, lda, B, ldb, Cmat, ldc) == 0
 
+    def outer_accum_rect(self, m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
+        assert self.lib.oracle_outer_accum_rect(m, n, T, alpha, A, lda, B, ldb, Cmat, ldc) == 0
+
+    def bwd_prepare(self, net, bwd, device):
+        assert self.lib.oracle_bwd_prepare(C.byref(net), C.byref(bwd)) == 0
+
+    def bwd_partial(self, net, bwd, t, z_full, device):
+        assert self.lib.oracle_bwd_partial(C.byref(net), C.byref(bwd), t, z_full) == 0
+
+    def bwd_apply(self, net, bwd, t, z_local, device):
+        assert self.lib.oracle_bwd_apply(C.byref(net), C.byref(bwd), t, z_local) == 0
+
+    def shard_partial_rows(self, n, rows):
+        rc = max(8, ((n + 31) // 32 + 7) & ~7)
+        return (rows + rc - 1) // rc
+
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
         assert self.lib.oracle_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss) == 0
 

@@ -164,6 +164,12 @@ def declare(lib, prefix):
         sig("rp_qif_backward", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
         sig("rp_outer_accum", C.c_int,
             [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
+        sig("rp_outer_accum_rect", C.c_int,
+            [C.c_int32, C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
+        sig("rp_bwd_shard_partial_rows", C.c_int32, [C.c_int32, C.c_int32])
+        sig("rp_bwd_prepare", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
+        sig("rp_bwd_partial", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp, C.c_void_p])
+        sig("rp_bwd_apply", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp, C.c_void_p])
         sig("rp_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp,
                                       C.c_void_p])
         sig("rp_stream_probe", C.c_int, [fp, C.c_int64, fp, C.c_void_p])
@@ -177,6 +183,11 @@ def declare(lib, prefix):
         sig("oracle_qif_backward", C.c_int, [P(RpNet), P(RpBwd)])
         sig("oracle_outer_accum", C.c_int,
             [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64])
+        sig("oracle_outer_accum_rect", C.c_int,
+            [C.c_int32, C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64])
+        sig("oracle_bwd_prepare", C.c_int, [P(RpNet), P(RpBwd)])
+        sig("oracle_bwd_partial", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp])
+        sig("oracle_bwd_apply", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp])
         sig("oracle_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp])
         sig("oracle_expf", C.c_float, [C.c_float])
         sig("oracle_tanhf", C.c_float, [C.c_float])
@@ -186,6 +197,7 @@ def declare(lib, prefix):
 
 EXPORTS = [
     "rp_abi_version", "rp_last_error", "rp_device_check", "rp_sizeof_net", "rp_sizeof_run", "rp_sizeof_bwd",
-    "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum",
+    "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum", "rp_outer_accum_rect",
+    "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial", "rp_bwd_apply",
     "rp_rls_sweep", "rp_stream_probe", "rp_set_tuning", "rp_set_bwd_tuning", "rp_set_rls_tuning",
 ]

@@ -56,8 +56,9 @@ __device__ __forceinline__ void store_slice(float* S, int tid, const rp_f4 (&reg
 }
 
 template <bool VEC4>
-__global__ __launch_bounds__(kThreads) void outer_accum_kernel(int n, int T, float alpha, const float* __restrict__ A,
-                                                               int64_t lda, const float* __restrict__ B, int64_t ldb,
+__global__ __launch_bounds__(kThreads) void outer_accum_kernel(int m, int n, int T, float alpha,
+                                                               const float* __restrict__ A, int64_t lda,
+                                                               const float* __restrict__ B, int64_t ldb,
                                                                float* __restrict__ C, int64_t ldc) {
     __shared__ __attribute__((aligned(16))) float As[BK * BM];
     __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(kThreads) void outer_accum_kernel(int n, int T, flo
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     rp_f4 ra[2], rb[2];
-    load_slice<VEC4>(A, lda, n, T, 0, i0, tid, ra);
+    load_slice<VEC4>(A, lda, m, T, 0, i0, tid, ra);
     load_slice<VEC4>(B, ldb, n, T, 0, j0, tid, rb);
 
     const int lk = lane >> 5;   // k offset of this lane inside an MFMA (0/1)
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void outer_accum_kernel(int n, int T, flo
         store_slice(Bs, tid, rb);
         __syncthreads();
         if (t0 + BK < T) {  // prefetch the next slice into registers behind the MFMAs
-            load_slice<VEC4>(A, lda, n, T, t0 + BK, i0, tid, ra);
+            load_slice<VEC4>(A, lda, m, T, t0 + BK, i0, tid, ra);
             load_slice<VEC4>(B, ldb, n, T, t0 + BK, j0, tid, rb);
         }
 #pragma unroll
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void outer_accum_kernel(int n, int T, flo
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < n && col < n) {
+                if (row < m && col < n) {
                     float* cp = C + (int64_t)row * ldc + col;
                     *cp = *cp + alpha * acc[mi][ni][r];
                 }
@@ -125,22 +126,27 @@ __global__ __launch_bounds__(kThreads) void outer_accum_kernel(int n, int T, flo
 
 }  // namespace
 
-extern "C" int rp_outer_accum(int32_t n, int32_t T, float alpha, const float* A, int64_t lda, const float* B,
-                              int64_t ldb, float* C, int64_t ldc, void* stream) {
+extern "C" int rp_outer_accum_rect(int32_t m, int32_t n, int32_t T, float alpha, const float* A, int64_t lda,
+                                   const float* B, int64_t ldb, float* C, int64_t ldc, void* stream) {
     if (!A || !B || !C) RP_FAIL(RP_ERR_ARG, "A, B, C must be non-null");
-    if (n <= 0 || T < 0) RP_FAIL(RP_ERR_ARG, "n must be > 0 and T >= 0");
-    if (lda < n || ldb < n || ldc < n) RP_FAIL(RP_ERR_SHAPE, "leading dimensions must be >= n");
+    if (m <= 0 || n <= 0 || T < 0) RP_FAIL(RP_ERR_ARG, "m, n must be > 0 and T >= 0");
+    if (lda < m || ldb < n || ldc < n) RP_FAIL(RP_ERR_SHAPE, "leading dimensions too small");
     if (T == 0) return RP_OK;
-    const int tiles = (n + BM - 1) / BM;
-    const bool vec4 = (n % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
+    const int tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
+    const bool vec4 = (m % 4 == 0) && (n % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                       !(reinterpret_cast<uintptr_t>(A) & 15u) && !(reinterpret_cast<uintptr_t>(B) & 15u);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (vec4)
-        hipLaunchKernelGGL(outer_accum_kernel<true>, dim3(tiles * tiles), dim3(kThreads), 0, st, n, T, alpha, A, lda,
-                           B, ldb, C, ldc);
+        hipLaunchKernelGGL(outer_accum_kernel<true>, dim3(tiles_m * tiles_n), dim3(kThreads), 0, st, m, n, T, alpha, A,
+                           lda, B, ldb, C, ldc);
     else
-        hipLaunchKernelGGL(outer_accum_kernel<false>, dim3(tiles * tiles), dim3(kThreads), 0, st, n, T, alpha, A, lda,
-                           B, ldb, C, ldc);
+        hipLaunchKernelGGL(outer_accum_kernel<false>, dim3(tiles_m * tiles_n), dim3(kThreads), 0, st, m, n, T, alpha, A,
+                           lda, B, ldb, C, ldc);
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;
+}
+
+extern "C" int rp_outer_accum(int32_t n, int32_t T, float alpha, const float* A, int64_t lda, const float* B,
+                              int64_t ldb, float* C, int64_t ldc, void* stream) {
+    return rp_outer_accum_rect(n, n, T, alpha, A, lda, B, ldb, C, ldc, stream);
 }

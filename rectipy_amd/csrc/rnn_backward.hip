@@ -36,7 +36,9 @@ __host__ __device__ inline int chunk_rows(int n) {  // RC(n): rows per chunk, mu
 struct BwdParams {
     const float* W;
     int64_t ldw;
-    int n;
+    int n;     // columns of W (global neuron count)
+    int rows;  // rows of W held here (== n unless row-sharded)
+    const float* z_direct;  // sharded: this rank's slice of W^T u after the reduce-scatter (else chunk partials are summed)
     int model;
     const float* p[RP_MAX_PARAMS];
     float dt;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(kThreads) void wt_partial_kernel(const BwdParams P)
         const int strip = item % strips;
         const int chunk = item / strips;
         const int i0 = chunk * P.rc;
-        const int i1 = min(i0 + P.rc, P.n);
+        const int i1 = min(i0 + P.rc, P.rows);
         const float* __restrict__ u = P.u;
         if constexpr (VEC4) {
             const int col = strip * CW + 4 * lane;
@@ -198,14 +200,27 @@ __device__ __forceinline__ void prep_step(const BwdParams& P, int j, float lam) 
 
 __global__ void prep_kernel(const BwdParams P) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < P.n) prep_step(P, j, P.lam[j]);
+    if (j < P.rows) prep_step(P, j, P.lam[j]);
+}
+
+// z_full[c] = sum of the chunk partials of column c, in chunk order (sharded sweep: input of the reduce-scatter)
+__global__ void chunk_sum_kernel(const BwdParams P, float* z_full) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.n) return;
+    float z = 0.f;
+    for (int q = 0; q < P.q; ++q) z = z + P.partials[(int64_t)q * P.n + c];
+    z_full[c] = z;
 }
 
 __global__ void finalize_kernel(const BwdParams P) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.n) return;
+    if (j >= P.rows) return;
     float z = 0.f;
-    for (int c = 0; c < P.q; ++c) z = z + P.partials[(int64_t)c * P.n + j];
+    if (P.z_direct) {
+        z = P.z_direct[j];
+    } else {
+        for (int c = 0; c < P.q; ++c) z = z + P.partials[(int64_t)c * P.n + j];
+    }
     const float lam = P.lam[j];
     const float d = act_deriv(P, j, P.r_t[j]);
     const float g = P.g_t ? P.g_t[j] : 0.f;
@@ -380,6 +395,7 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     P.W = net->W;
     P.ldw = net->ldw;
     P.n = n;
+    P.rows = n;
     P.model = net->model;
     for (int q = 0; q < RP_MAX_PARAMS; ++q) P.p[q] = net->p[q];
     P.dt = net->dt;
@@ -419,6 +435,104 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
             P.u_next = nullptr;
         hipLaunchKernelGGL(finalize_kernel, dim3(eblocks), dim3(256), 0, st, P);
     }
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
+// ---- row-sharded sweep, one step at a time -------------------------------------------------------------------
+// Rank p holds rows [row0, row0+rows) of W.  Its strip kernel yields a FULL-length partial W_p^T u_p; the caller
+// reduce-scatters those over the ranks (RCCL) and hands back the rank's slice, then the element-wise update runs on
+// the local neurons.  All per-neuron vectors of rp_bwd are local (length rows).
+
+static int sharded_params(const rp_net* net, const rp_bwd* b, BwdParams& P, bool& vec4) {
+    if (!net || !b) RP_FAIL(RP_ERR_ARG, "net/bwd is null");
+    if (net->model != RP_MODEL_LI_TANH && net->model != RP_MODEL_LI_SIGMOID)
+        RP_FAIL(RP_ERR_ARG, "the sharded adjoint supports the leaky-integrator models only (model=%d)", net->model);
+    if (net->n <= 0 || net->rows <= 0 || net->row0 < 0 || (int64_t)net->row0 + net->rows > net->n || net->ldw < net->n)
+        RP_FAIL(RP_ERR_SHAPE, "bad shard: n=%d rows=%d row0=%d", net->n, net->rows, net->row0);
+    if (b->steps <= 0) RP_FAIL(RP_ERR_ARG, "steps must be > 0");
+    if (!net->W || !b->traj_v || !b->traj_r || !b->lam || !b->u_traj || !b->partials)
+        RP_FAIL(RP_ERR_ARG, "W, traj_v, traj_r, lam, u_traj, partials must be non-null");
+    if (b->ld < net->rows) RP_FAIL(RP_ERR_SHAPE, "ld < rows");
+    if (b->grad_out && b->ldg < net->rows) RP_FAIL(RP_ERR_SHAPE, "ldg < rows");
+    if (b->grad_x && b->ldgx < net->rows) RP_FAIL(RP_ERR_SHAPE, "ldgx < rows");
+    if (b->grad_k && !b->traj_acc) RP_FAIL(RP_ERR_ARG, "grad_k needs traj_acc");
+    vec4 = (net->n % 4 == 0) && (net->ldw % 4 == 0);
+    if (vec4 && ((reinterpret_cast<uintptr_t>(net->W) & 15u) || (reinterpret_cast<uintptr_t>(b->partials) & 15u)))
+        RP_FAIL(RP_ERR_ARG, "W and partials must be 16-byte aligned");
+    P = BwdParams{};
+    P.W = net->W;
+    P.ldw = net->ldw;
+    P.n = net->n;
+    P.rows = net->rows;
+    P.model = net->model;
+    for (int q = 0; q < RP_MAX_PARAMS; ++q) P.p[q] = net->p[q];
+    P.dt = net->dt;
+    P.rc = chunk_rows(net->n);
+    P.q = (net->rows + P.rc - 1) / P.rc;
+    P.partials = b->partials;
+    P.grad_var = b->grad_var;
+    P.lam = b->lam;
+    P.grad_tau = b->grad_tau;
+    P.grad_k = b->grad_k;
+    P.grad_eta = b->grad_eta;
+    return RP_OK;
+}
+
+static void sharded_set_prep(const rp_bwd* b, BwdParams& P, int tp) {
+    P.u_next = b->u_traj + (int64_t)tp * b->ld;
+    P.v_prev = b->traj_v + (int64_t)tp * b->ld;
+    P.acc_prev = b->traj_acc ? b->traj_acc + (int64_t)tp * b->ld : nullptr;
+    P.gx_prev = b->grad_x ? b->grad_x + (int64_t)tp * b->ldgx : nullptr;
+}
+
+int32_t rp_bwd_shard_partial_rows(int32_t n, int32_t rows) {
+    if (n <= 0 || rows <= 0) return 0;
+    const int rc = chunk_rows(n);
+    return (rows + rc - 1) / rc;
+}
+
+int rp_bwd_prepare(const rp_net* net, const rp_bwd* b, void* stream) {
+    BwdParams P;
+    bool vec4;
+    int rc = sharded_params(net, b, P, vec4);
+    if (rc != RP_OK) return rc;
+    sharded_set_prep(b, P, b->steps - 1);
+    hipLaunchKernelGGL(prep_kernel, dim3((P.rows + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), P);
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
+int rp_bwd_partial(const rp_net* net, const rp_bwd* b, int32_t t, float* z_full, void* stream) {
+    BwdParams P;
+    bool vec4;
+    int rc = sharded_params(net, b, P, vec4);
+    if (rc != RP_OK) return rc;
+    if (t < 0 || t >= b->steps || !z_full) RP_FAIL(RP_ERR_ARG, "bad step index or null z_full");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    P.u = b->u_traj + (int64_t)t * b->ld;
+    launch_wt_partial(P, vec4, st);
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3((P.n + 255) / 256), dim3(256), 0, st, P, z_full);
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
+int rp_bwd_apply(const rp_net* net, const rp_bwd* b, int32_t t, const float* z_local, void* stream) {
+    BwdParams P;
+    bool vec4;
+    int rc = sharded_params(net, b, P, vec4);
+    if (rc != RP_OK) return rc;
+    if (t < 0 || t >= b->steps || !z_local) RP_FAIL(RP_ERR_ARG, "bad step index or null z_local");
+    P.t = t;
+    P.z_direct = z_local;
+    P.v_t = b->traj_v + (int64_t)t * b->ld;
+    P.r_t = b->traj_r + (int64_t)t * b->ld;
+    P.g_t = b->grad_out ? b->grad_out + (int64_t)t * b->ldg : nullptr;
+    if (t > 0)
+        sharded_set_prep(b, P, t - 1);
+    else
+        P.u_next = nullptr;
+    hipLaunchKernelGGL(finalize_kernel, dim3((P.rows + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), P);
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;
 }
@@ -487,6 +601,7 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     P.W = net->W;
     P.ldw = net->ldw;
     P.n = n;
+    P.rows = n;
     P.model = model;
     for (int q = 0; q < RP_MAX_PARAMS; ++q) P.p[q] = net->p[q];
     P.dt = net->dt;

@@ -88,6 +88,25 @@ class HipBackend:
         with torch.cuda.device(device):
             self._lib_mod.check(self.lib.rp_outer_accum(n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
 
+    def outer_accum_rect(self, m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
+        with torch.cuda.device(device):
+            self._lib_mod.check(self.lib.rp_outer_accum_rect(m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
+
+    def bwd_prepare(self, net, bwd, device):
+        with torch.cuda.device(device):
+            self._lib_mod.check(self.lib.rp_bwd_prepare(C.byref(net), C.byref(bwd), self._stream(device)))
+
+    def bwd_partial(self, net, bwd, t, z_full, device):
+        with torch.cuda.device(device):
+            self._lib_mod.check(self.lib.rp_bwd_partial(C.byref(net), C.byref(bwd), t, z_full, self._stream(device)))
+
+    def bwd_apply(self, net, bwd, t, z_local, device):
+        with torch.cuda.device(device):
+            self._lib_mod.check(self.lib.rp_bwd_apply(C.byref(net), C.byref(bwd), t, z_local, self._stream(device)))
+
+    def shard_partial_rows(self, n, rows):
+        return int(self.lib.rp_bwd_shard_partial_rows(n, rows))
+
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
         with torch.cuda.device(device):
             self._lib_mod.check(self.lib.rp_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss,

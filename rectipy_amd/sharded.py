@@ -75,13 +75,116 @@ def _slice_rows(val, row0, rows, n):
     return val
 
 
+class _AllReduceSum(torch.autograd.Function):
+    """Sum of per-rank partial read-outs.  Every rank evaluates the same loss on the summed prediction, so the gradient
+    with respect to a rank's partial sum is the gradient of the total: backward is the identity (no second collective)."""
+
+    @staticmethod
+    def forward(ctx, part, group):
+        total = part.detach().clone().contiguous()
+        dist.all_reduce(total, group=group)
+        return total
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _ShardedRateWindow(torch.autograd.Function):
+    """T Euler steps of a row-sharded leaky-integrator population as one autograd node.
+
+    forward : per step  local fused step kernel -> all-gather of the source vector (and a copy of the full r_t for dW);
+    backward: per step  column-strip kernel over the rank's rows (full-length partial W_p^T u_p) -> reduce-scatter ->
+              local adjoint update (rp_bwd_prepare / rp_bwd_partial / rp_bwd_apply, SURVEY.md 8e);
+              dW_p = dt U_p^T R (rows x n) is local: one rectangular MFMA GEMM per window."""
+
+    @staticmethod
+    def forward(ctx, node, net, steps, x, v_in, W, tau, k, eta):
+        pop = node._pop
+        rows, n, dev = pop.rows, pop.n, pop.device
+        row0 = pop.row0
+        f32 = dict(dtype=torch.float32, device=dev)
+        traj_v = torch.empty(steps, rows, **f32)
+        traj_r = torch.empty(steps, rows, **f32)
+        traj_r_full = torch.empty(steps, n, **f32)
+        traj_acc = torch.empty(steps, rows, **f32) if k.requires_grad else None
+        for t in range(steps):
+            traj_r_full[t].copy_(pop.source)
+            pop.forward(1, x=None if x is None else x[t:t + 1], save_v=traj_v[t:t + 1], save_src=traj_r[t:t + 1],
+                        save_acc=None if traj_acc is None else traj_acc[t:t + 1])
+            net._gather(node, row0, rows)
+        ctx.node, ctx.net, ctx.steps = node, net, steps
+        ctx.x_width = None if x is None else x.shape[1]
+        ctx.saved = (traj_v, traj_r, traj_r_full, traj_acc)
+        node._last_window = (traj_v, traj_r)
+        out = traj_r if node._out_code == _abi.RP_OUT_SOURCE else traj_v
+        return out.clone(), pop.v.clone()
+
+    @staticmethod
+    def backward(ctx, g_traj, g_vend):
+        node, net, T = ctx.node, ctx.net, ctx.steps
+        pop = node._pop
+        rows, n, dev = pop.rows, pop.n, pop.device
+        traj_v, traj_r, traj_r_full, traj_acc = ctx.saved
+        f32 = dict(dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad  # (node, net, steps, x, v_in, W, tau, k, eta)
+        lam = torch.zeros(rows, **f32) if g_vend is None else g_vend.detach().to(**f32).clone().contiguous()
+        g_out = None if g_traj is None else g_traj.detach().to(**f32).contiguous()
+        u_traj = torch.empty(T, rows, **f32)
+        g_tau = torch.zeros(rows, **f32) if need[6] else None
+        g_k = torch.zeros(rows, **f32) if need[7] else None
+        g_eta = torch.zeros(rows, **f32) if need[8] else None
+        g_x = torch.empty(T, rows, **f32) if need[3] else None
+        be = pop.backend
+        partials = torch.empty(be.shard_partial_rows(n, rows), n, **f32)
+        z_full = torch.empty(n, **f32)
+        z_local = torch.empty(rows, **f32)
+
+        b = _abi.RpBwd()
+        b.steps = T
+        b.traj_v, b.traj_r = traj_v.data_ptr(), traj_r.data_ptr()
+        b.traj_acc = None if traj_acc is None else traj_acc.data_ptr()
+        b.ld = rows
+        b.grad_var = node._out_code
+        b.grad_out = None if g_out is None else g_out.data_ptr()
+        b.ldg = rows
+        b.lam, b.u_traj, b.partials = lam.data_ptr(), u_traj.data_ptr(), partials.data_ptr()
+        b.grad_tau = None if g_tau is None else g_tau.data_ptr()
+        b.grad_k = None if g_k is None else g_k.data_ptr()
+        b.grad_eta = None if g_eta is None else g_eta.data_ptr()
+        b.grad_x = None if g_x is None else g_x.data_ptr()
+        b.ldgx = rows
+        rnet = pop._net()
+        nccl = dist.get_backend(net.group) == "nccl"
+        be.bwd_prepare(rnet, b, dev)
+        for t in range(T - 1, -1, -1):
+            be.bwd_partial(rnet, b, t, z_full.data_ptr(), dev)
+            if nccl:
+                dist.reduce_scatter_tensor(z_local, z_full, group=net.group)
+            else:  # gloo has no reduce-scatter: all-reduce, then keep this rank's slice
+                dist.all_reduce(z_full, group=net.group)
+                z_local.copy_(z_full[pop.row0:pop.row0 + rows])
+            be.bwd_apply(rnet, b, t, z_local.data_ptr(), dev)
+        g_W = None
+        if need[5]:
+            g_W = torch.zeros(rows, n, **f32)
+            be.outer_accum_rect(rows, n, T, float(pop.dt), u_traj.data_ptr(), rows, traj_r_full.data_ptr(), n,
+                                g_W.data_ptr(), n, dev)
+        if g_x is not None and ctx.x_width == 1:
+            g_x = g_x.sum(dim=1, keepdim=True)
+            dist.all_reduce(g_x, group=net.group)  # a broadcast input feeds every shard
+        return None, None, None, g_x, (lam if need[4] else None), g_W, g_tau, g_k, g_eta
+
+
 class ShardedNetwork(Network):
     """``Network`` whose diff-eq population is row-sharded over the ranks of a ``torch.distributed`` group
     (one process per GPU).  Every rank builds the SAME graph from the SAME global arrays; this class keeps the
     rank's rows of the recurrent matrix, of per-neuron vectors and of input-edge weights, and the rank's columns of
     read-out weights.  ``run`` then integrates with one all-gather of the source vector per Euler step and one
     all-reduce of the (k-dimensional) read-out per window.  Node outputs, recorded variables and ``state`` are the
-    rank's slices; read-out node outputs are complete on every rank.  Forward integration only (``run`` / ``test``).
+    rank's slices; read-out node outputs are complete on every rank.  ``fit_bptt`` trains the rank's rows of the
+    recurrent matrix, its per-neuron parameters and its columns of a ``gd`` read-out with the sharded adjoint
+    (reduce-scatter of the transposed product, one per step).
     """
 
     def __init__(self, dt: float, device: str = "cuda:0", dtype: torch.dtype = torch.float32, backend=None, group=None):
@@ -102,8 +205,8 @@ class ShardedNetwork(Network):
             weights = weights[row0:row0 + rows]
         elif weights.shape[0] != rows:
             raise RuntimeError(f"weights must be [{n}, {n}] or this rank's [{rows}, {n}] block, got {tuple(weights.shape)}")
-        if kwargs.get("train_params"):
-            raise NotImplementedError("the sharded adjoint (reduce-scatter of W^T u) is not built yet: forward only")
+        if kwargs.get("spike_var") is not None and kwargs.get("train_params"):
+            raise NotImplementedError("sharded training is available for the rate (leaky-integrator) templates only")
         if "node_vars" in kwargs:
             kwargs["node_vars"] = {k: _slice_rows(v, row0, rows, n) for k, v in kwargs["node_vars"].items()}
         new = super().add_diffeq_node(label, node, input_var, output_var, weights=weights, shard=(row0, n), **kwargs)
@@ -143,13 +246,32 @@ class ShardedNetwork(Network):
             base_reset(y=y, idx=idx)
             net._gather(self_, row0, rows, clone=True)
 
+        def grad_window(self_, steps, x):
+            pop = self_._pop
+            v_in = self_._y_grad
+            if v_in is None:
+                v_in = pop.v.detach().clone().requires_grad_(self_._y_requires_grad)
+            traj, v_end = _ShardedRateWindow.apply(self_, net, steps, x, v_in, pop.W, pop.params["tau"], pop.params["k"],
+                                                   pop.params["eta"])
+            self_._y_grad = v_end
+            return traj
+
+        def forward_any(self_, x):  # per-step entry point: autograd window of one step when a gradient is wanted
+            x2 = self_._as_input(x)
+            if self_._wants_grad(x2):
+                return grad_window(self_, 1, x2)[0]
+            return forward(self_, x)
+
         node.run_window = types.MethodType(run_window, node)
-        node.forward = types.MethodType(forward, node)
+        node.forward = types.MethodType(forward_any, node)
         node.reset = types.MethodType(reset, node)
+        node._grad_window = types.MethodType(grad_window, node)
 
     def add_edge(self, source, target, weights=None, train=None, edge_attrs=None, **kwargs):
-        if train is not None and (source in self._sharded or target in self._sharded):
-            raise NotImplementedError("trained edges next to a sharded population are not supported yet")
+        if train is not None and target in self._sharded:
+            raise NotImplementedError("trained input edges of a sharded population are not supported yet")
+        if train not in (None, "gd") and source in self._sharded:
+            raise NotImplementedError("only 'gd' training is available for read-outs of a sharded population")
         if weights is None and (source in self._sharded or target in self._sharded):
             raise ValueError("edges of a sharded population need explicit global weights (every rank must hold the same)")
         if target in self._sharded:      # input edge: this rank's rows
@@ -161,19 +283,17 @@ class ShardedNetwork(Network):
             row0, rows, n = self._sharded[source]
             w = weights if isinstance(weights, torch.Tensor) else np.asarray(weights)
             weights = w[:, row0:row0 + rows] if w.shape[1] == n else w.T[:, row0:row0 + rows]
-            edge = super().add_edge(source, target, weights=weights, train=None, edge_attrs=edge_attrs, **kwargs)
+            edge = super().add_edge(source, target, weights=weights, train=train, edge_attrs=edge_attrs, **kwargs)
             plain, group = edge.forward, self.group
 
             def forward(self_, x, **kw):
-                part = plain(x, **kw).contiguous()
-                dist.all_reduce(part, group=group)
-                return part
+                return _AllReduceSum.apply(plain(x, **kw), group)
 
             edge.forward = types.MethodType(forward, edge)
             return edge
         return super().add_edge(source, target, weights=weights, train=train, edge_attrs=edge_attrs, **kwargs)
 
-    def fit_bptt(self, *a, **k):
-        raise NotImplementedError("sharded training is not built yet (forward integration only)")
+    def fit_rls(self, *a, **k):
+        raise NotImplementedError("RLS / ridge read-out training is not available on a sharded population")
 
-    fit_rls = fit_ridge = fit_bptt
+    fit_ridge = fit_rls

@@ -322,3 +322,52 @@ def test_run_to_run_determinism(hip_device):
     for other in runs[1:]:
         for a, b in zip(runs[0], other):
             assert torch.equal(a, b)
+
+
+def test_sharded_adjoint_steps_and_rect_gemm_bit_exact(oracle_backend, hip_device):
+    """rp_bwd_prepare / rp_bwd_partial / rp_bwd_apply on one row shard and the rectangular dW GEMM: HIP == oracle.
+    (The reduce-scatter between partial and apply is emulated by taking the shard's own slice.)"""
+    from rectipy_amd import _abi as A
+    N, T, P, p = 1024, 14, 4, 1
+    rows, row0 = N // P, (N // P) * p
+    W, params, v0 = make_li(N, seed=77)
+    gen = torch.Generator().manual_seed(78)
+    x = torch.randn(T, rows, generator=gen) * 0.5
+    g_out = torch.randn(T, rows, generator=gen) * 0.1
+    r_full = torch.tanh(torch.randn(T + 1, N, generator=gen))
+    res = []
+    for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+        pop = Population("li_tanh", W[row0:row0 + rows], {k: v[row0:row0 + rows] for k, v in params.items()}, 1e-2, dev,
+                         v0=v0[row0:row0 + rows], n=N, row0=row0, backend=backend)
+        be = pop.backend
+        tv, tr, ta, ut, gx = (torch.zeros(T, rows, device=dev) for _ in range(5))
+        for t in range(T):  # the other shards' source slices come from outside (all-gather)
+            pop.source.copy_(r_full[t].to(dev))
+            pop.forward(1, x=x[t:t + 1].to(dev), save_v=tv[t:t + 1], save_src=tr[t:t + 1], save_acc=ta[t:t + 1])
+        lam = torch.zeros(rows, device=dev)
+        gt, gk, ge = (torch.zeros(rows, device=dev) for _ in range(3))
+        partials = torch.zeros(be.shard_partial_rows(N, rows), N, device=dev)
+        z_full = torch.zeros(N, device=dev)
+        go = g_out.to(dev).contiguous()
+        b = A.RpBwd()
+        b.steps, b.ld, b.ldg, b.ldgx, b.grad_var = T, rows, rows, rows, A.RP_OUT_SOURCE
+        b.traj_v, b.traj_r, b.traj_acc = tv.data_ptr(), tr.data_ptr(), ta.data_ptr()
+        b.grad_out, b.lam, b.u_traj, b.partials = go.data_ptr(), lam.data_ptr(), ut.data_ptr(), partials.data_ptr()
+        b.grad_tau, b.grad_k, b.grad_eta, b.grad_x = gt.data_ptr(), gk.data_ptr(), ge.data_ptr(), gx.data_ptr()
+        net = pop._net()
+        be.bwd_prepare(net, b, pop.device)
+        zs = []
+        for t in range(T - 1, -1, -1):
+            be.bwd_partial(net, b, t, z_full.data_ptr(), pop.device)
+            zs.append(z_full.clone())
+            z_local = z_full[row0:row0 + rows].clone()
+            be.bwd_apply(net, b, t, z_local.data_ptr(), pop.device)
+        gW = torch.zeros(rows, N, device=dev)
+        rf = r_full[:T].to(dev).contiguous()
+        be.outer_accum_rect(rows, N, T, 1e-2, ut.data_ptr(), rows, rf.data_ptr(), N, gW.data_ptr(), N, pop.device)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        res.append((torch.stack(zs), lam, ut, gt, gk, ge, gx, gW))
+    for a, b_, name in zip(res[0], res[1], ("z_full", "lambda", "u_traj", "grad_tau", "grad_k", "grad_eta", "grad_x", "dW")):
+        assert_same(a, b_, f"sharded {name}")
+    assert float(res[0][7].abs().max()) > 0
