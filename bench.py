@@ -18,7 +18,6 @@ the 8 TB/s HBM peak) and, at N = 1, `cpu_baseline` (a torch-eager port of the re
 timed on this box's host cores for a bounded number of steps) plus `extra` with the fwd+bwd window.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -73,9 +72,6 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=dev)
-
-    from rectipy_amd import _abi
-    from rectipy_amd.engine import Population
 
     N, K, Wm = args.neurons, args.steps, args.warmup
     dt = 1e-2

@@ -183,7 +183,6 @@ class Population:
             self.refresh()
         self.acc = torch.zeros(self.rows, **f32)
         self.acc_count = 0
-        self._spike_count = None
 
     # -- helpers -------------------------------------------------------------------------
     def _vec(self, val) -> torch.Tensor:

@@ -3,7 +3,7 @@ rectipy/network.py:1196-1357).  Feed-forward edges define the evaluation order a
 a feedback edge delivers its source node's output of the PREVIOUS step (zero before the first step), so cycles
 through feedback edges are allowed.  Such networks are evaluated step by step; every diff-eq node still advances
 through the HIP step kernel."""
-from typing import Iterator, Optional
+from typing import Optional
 
 import torch
 from networkx import DiGraph, topological_sort

@@ -10,7 +10,7 @@ the readout is applied to the sampled trajectory afterwards.  Topologies that do
 back to a per-step walk in which every diff-eq node still steps through the HIP kernels.
 """
 from time import perf_counter
-from typing import Callable, Iterator, List, Optional, Tuple, Union
+from typing import Callable, Iterator, List, Optional, Union
 
 import numpy as np
 import torch

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _abi
-from .engine import PARAM_SLOTS, Population
+from .engine import Population
 from .templates import Template, resolve
 
 _warned_f64 = False
