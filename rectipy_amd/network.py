@@ -36,7 +36,10 @@ class Network:
     def __init__(self, dt: float, device: str = "cuda:0", dtype: torch.dtype = torch.float32, backend=None):
         self.graph = DiGraph()
         self.device = device
-        self.dtype = dtype
+        if dtype is not torch.float32:
+            from .nodes import _warn_f64
+            _warn_f64(torch.float64)  # one warning: the engine, its inputs and its edges are float32
+        self.dtype = torch.float32
         self.dt = dt
         self._backend = backend  # test seam, see rectipy_amd.engine
         self._var_map = {}

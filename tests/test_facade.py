@@ -258,3 +258,20 @@ def test_observer_api():
     assert obs["extra"][0].shape == (1,) and obs.recorded_state_variables == [("a", "v"), ("a", "w")]
     with pytest.raises(KeyError):
         _ = obs["missing"]
+
+
+def test_float64_request_is_held_as_float32(where):
+    """Documented difference: the reference defaults to float64 node state; the engine computes in float32."""
+    import warnings
+    n = 6
+    W = np.random.default_rng(9).standard_normal((n, n))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = Network(1e-2, dtype=torch.float64, **where)
+        net.add_diffeq_node("rnn", TANH, weights=W, input_var=IN, output_var=OUT, source_var=SRC, target_var=TGT)
+        net.add_func_node("out", 2, "identity")
+        edge = net.add_edge("rnn", "out", weights=np.ones((2, n)))
+    assert net.dtype is torch.float32 and edge.weights.dtype is torch.float32
+    assert net.get_node("rnn").y.dtype is torch.float32
+    obs = net.run(np.zeros((5, n)), verbose=False, enable_grad=False)
+    assert obs.to_numpy("out").shape == (5, 2) and obs.to_numpy("out").dtype == np.float32
