@@ -241,14 +241,14 @@ def facade_fit_bptt(pop, x, N, dev):
 
 
 def cpu_baseline(pop, x, dt, N):
-    """Torch-eager port of the reference's per-step CPU loop on this box's host cores: 3 warm-up + 30 timed
-    steps of the same network (per-step cost is stationary; ~60 ms/step on 8 cores)."""
+    """Torch-eager port of the reference's per-step CPU loop on this box's host cores: 5 warm-up + 100 timed
+    steps of the same network (per-step cost is stationary, ~0.1 s/step: about 12 s of CPU work)."""
     from oracle.torch_eager import time_eager
     W = pop.W.cpu()
     tau, k, eta = (pop.params[n].cpu() for n in ("tau", "k", "eta"))
     v = pop.v.cpu()
-    xs = x[:64].cpu().expand(64, N).contiguous()
-    warm, timed = 3, 30
+    warm, timed = 5, 100
+    xs = x[:warm + timed].cpu().expand(warm + timed, N).contiguous()
     sps = time_eager(W, tau, k, eta, v, xs, dt, warm, timed)
     return {"value": sps, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{warm} warm-up + {timed} timed Euler steps of the same N={N} network, torch {torch.__version__} "
