@@ -25,7 +25,7 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kMaxChunks = 32;
+constexpr int kMaxChunks = 64;
 
 __host__ __device__ inline int chunk_rows(int n) {  // RC(n): rows per chunk, multiple of 8
     int rc = (n + kMaxChunks - 1) / kMaxChunks;
@@ -163,9 +163,11 @@ void launch_wt_partial(const BwdParams& P, bool vec4, hipStream_t st) {
         hipLaunchKernelGGL((wt_partial_kernel<false, 1, 1>), dim3(blocks > 4096 ? 4096 : blocks), dim3(kThreads), 0, st, P);
         return;
     }
-    // measured at n = 32768 (scripts/tune_backward.py): 2-KiB strips with 6 rows in flight stream at 6.84 TB/s,
-    // 1-KiB strips with 8 rows at 6.27 TB/s; small n keeps the narrow strips for more waves.
-    const int U = g_bwd_U ? g_bwd_U : (P.n >= 8192 ? 6 : 8), SW = g_bwd_SW ? g_bwd_SW : (P.n >= 8192 ? 2 : 1);
+    // measured (scripts/size_sweep.py, scripts/tune_backward.py): 2-KiB strips with 4 rows in flight are the fastest
+    // shape from n = 8192 up (n = 32768: 6.7-6.8 TB/s vs 6.3 TB/s for 1-KiB strips); below that the narrow strips give
+    // more waves.  2-KiB strips need >= 1024 waves.
+    const bool wide = ((P.n + 511) / 512) * P.q >= 1024;
+    const int U = g_bwd_U ? g_bwd_U : (wide ? 4 : 8), SW = g_bwd_SW ? g_bwd_SW : (wide ? 2 : 1);
     const int strips = (P.n + 256 * SW - 1) / (256 * SW);
     int blocks = (strips * P.q + 3) / 4;
     if (blocks > 4096) blocks = 4096;
@@ -183,6 +185,22 @@ __device__ __forceinline__ float act_deriv(const BwdParams& P, int j, float r) {
     if (P.model == RP_MODEL_LI_TANH) return 1.0f - r * r;
     // d/dv [r_max / (1 + exp(s (v0 - v)))] = s r (1 - r / r_max)
     return P.p[RP_P_SLOPE][j] * r * (1.0f - r / P.p[RP_P_RMAX][j]);
+}
+
+// Sum of the chunk partials of column j in chunk order; loads are issued 8 at a time so that their latencies overlap
+// (the additions stay sequential: the order is part of the summation spec).
+__device__ __forceinline__ float chunk_sum(const BwdParams& P, int j) {
+    float z = 0.f;
+    int c = 0;
+    for (; c + 8 <= P.q; c += 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = P.partials[(int64_t)(c + k) * P.n + j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z = z + t[k];
+    }
+    for (; c < P.q; ++c) z = z + P.partials[(int64_t)c * P.n + j];
+    return z;
 }
 
 // u_next = k * lam and the per-neuron parameter gradients that pair lambda_{t+1} with step t
@@ -207,20 +225,13 @@ __global__ void prep_kernel(const BwdParams P) {
 __global__ void chunk_sum_kernel(const BwdParams P, float* z_full) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= P.n) return;
-    float z = 0.f;
-    for (int q = 0; q < P.q; ++q) z = z + P.partials[(int64_t)q * P.n + c];
-    z_full[c] = z;
+    z_full[c] = chunk_sum(P, c);
 }
 
 __global__ void finalize_kernel(const BwdParams P) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.rows) return;
-    float z = 0.f;
-    if (P.z_direct) {
-        z = P.z_direct[j];
-    } else {
-        for (int c = 0; c < P.q; ++c) z = z + P.partials[(int64_t)c * P.n + j];
-    }
+    const float z = P.z_direct ? P.z_direct[j] : chunk_sum(P, j);
     const float lam = P.lam[j];
     const float d = act_deriv(P, j, P.r_t[j]);
     const float g = P.g_t ? P.g_t[j] : 0.f;
@@ -318,8 +329,7 @@ __global__ void spk_prep_kernel(const BwdParams P, const SpkGrad G) {
 __global__ void spk_finalize_kernel(const BwdParams P, const SpkGrad G) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.n) return;
-    float z = 0.f;
-    for (int c = 0; c < P.q; ++c) z = z + P.partials[(int64_t)c * P.n + j];
+    const float z = chunk_sum(P, j);
     const float lv = P.lam[j];
     const float ls = P.lam_s[j];
     const float lx = P.lam_x ? P.lam_x[j] : 0.f;
