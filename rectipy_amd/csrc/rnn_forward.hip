@@ -468,12 +468,19 @@ void launch_step(const StepParams& P, hipStream_t st) {
             }
         }
     }
-    if (rows >= 8192)
+    // measured with scripts/tune_forward.py / tune_shard_shapes.py (us per step, best configuration):
+    //   n = 32768: (4,2) 625;  shards 16384/8192/4096 x 32768: (4,2) 312 / (4,2) 157 / (2,2) 79
+    //   n = 12288: (4,2) 90 vs (8,1) 99;  n = 8192 (W ~ Infinity-Cache sized): (8,1) 43 vs (4,2) 51;
+    //   n = 4096: (2,2) 11.8;  n = 2048: (1,4) 4.9 vs (2,2) 6.4
+    const bool cache_sized = (int64_t)rows * P.n * 4 <= (320ll << 20);
+    if (rows >= 8192 && !cache_sized)
         launch_cfg<MODEL, 4, 2, VEC4, true>(P, st, 2048);
-    else if (rows >= 1024)
+    else if (rows >= 8192)
+        launch_cfg<MODEL, 8, 1, VEC4, true>(P, st, 2048);
+    else if (rows > 2048)
         launch_cfg<MODEL, 2, 2, VEC4, true>(P, st, 0);
     else
-        launch_cfg<MODEL, 1, 2, VEC4, true>(P, st, 0);
+        launch_cfg<MODEL, 1, 4, VEC4, true>(P, st, 0);
 }
 
 template <bool VEC4>
