@@ -150,7 +150,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"tanh rate RNN N={N} dense W fp32, forward-only Euler, dt=1e-2, sampling_steps=100, "
                                f"broadcast sinusoid input (BASELINE.json configs[1])",
-                   "neurons": N, "rows_per_gpu": rows, "parallelism": f"row-shard x{world} + all-gather(r) per step"
+                   "neurons": N, "rows_per_gpu": rows, "parallelism": f"row-shard x{world} + RCCL all-gather(r) per step, enqueued in-library (rp_forward_sharded)"
                    if world > 1 else "single GPU, driven through rectipy_amd.Network.run"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

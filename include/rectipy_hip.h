@@ -24,11 +24,14 @@
  *   rp_outer_accum    <- the per-step outer-product accumulation autograd does
  *                        for `weights @ r`          (same call site)
  *   rp_rls_sweep      <- RLS.update                 rectipy/edges.py:227-234
+ *   rp_forward_sharded, rp_rate_backward_sharded, rp_bwd_prepare/partial/apply
+ *                     <- no reference counterpart: row shards over the GPUs of a node
  *
  * All functions return RP_OK (0) or a negative RP_ERR_* code;
  * rp_last_error() returns a thread-local description of the last failure.
  * The Python facade maps RP_ERR_ARG -> ValueError, RP_ERR_SHAPE -> RuntimeError
- * (as torch raises on size mismatch, rectipy_tests/test_nodes.py:148-151).
+ * (as torch raises on size mismatch, rectipy_tests/test_nodes.py:148-151),
+ * RP_ERR_HIP / RP_ERR_COMM -> RuntimeError.
  *
  * Arithmetic: fp32 storage and fp32 arithmetic, one rounding per operation,
  * no fast-math, no contraction.  The row dot product has a FIXED summation
@@ -44,13 +47,14 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 3
+#define RP_ABI_VERSION 4
 
 #define RP_OK 0
 #define RP_ERR_ARG (-1)      /* null pointer, bad enum, bad flag combination  */
 #define RP_ERR_SHAPE (-2)    /* inconsistent sizes / leading dimensions       */
 #define RP_ERR_ARCH (-3)     /* no gfx950 device visible                      */
 #define RP_ERR_HIP (-4)      /* HIP runtime error (text in rp_last_error)     */
+#define RP_ERR_COMM (-5)     /* RCCL collective returned an error              */
 
 /* neuron models (closed table replacing the PyRates code generator for this path) */
 #define RP_MODEL_LI_TANH 0    /* leaky_integrator.yaml: li_op + tanh_op      */
@@ -172,6 +176,10 @@ typedef struct rp_run {
     int32_t* spike_events;    /* optional QIF: (step, global index) int32 pairs */
     int32_t spike_capacity;   /* number of pairs that fit                     */
     int32_t* spike_count;     /* device counter (keeps counting past capacity) */
+    /* row t receives the FULL source vector the step read (all n entries, i.e. r_t / s_t
+       before the update) -- the B operand of the shard's rectangular dW GEMM. */
+    float* save_src_full;     /* [steps x ldfull] or NULL                     */
+    int64_t ldfull;
 } rp_run;
 
 /* Arguments of the adjoint sweep over a stored window (LI models). */
@@ -251,6 +259,29 @@ int rp_outer_accum(int32_t n, int32_t T, float alpha, const float* A, int64_t ld
 /* Rectangular form for a row shard: C[m x n] += alpha * A^T B with A = [T x m], B = [T x n]. */
 int rp_outer_accum_rect(int32_t m, int32_t n, int32_t T, float alpha, const float* A, int64_t lda, const float* B,
                         int64_t ldb, float* C, int64_t ldc, void* stream);
+
+/*
+ * Row shards over the GPUs of a node with the per-step exchange INSIDE the library: the
+ * collectives are RCCL calls enqueued on the same stream as the step kernels, so a whole run / adjoint sweep is
+ * one host call per rank and there is no cross-stream hand-over per step.  The library does not link RCCL: a
+ * communicator is only valid inside the RCCL instance that created it (PyTorch bundles its own copy), so the caller
+ * passes the addresses of ncclAllGather / ncclReduceScatter of THAT instance next to the ncclComm_t.
+ */
+typedef struct rp_comm {
+    void* comm;            /* ncclComm_t spanning the row shards, rank p owning rows [p*rows, (p+1)*rows)   */
+    void* all_gather;      /* ncclResult_t (*)(const void*, void*, size_t, int dtype, ncclComm_t, hipStream_t) */
+    void* reduce_scatter;  /* ncclResult_t (*)(const void*, void*, size_t, int dtype, int op, ncclComm_t, hipStream_t) */
+    int32_t rank, world;
+    float* work;           /* sharded adjoint only: n + rows floats (full-length partial, reduced slice)     */
+} rp_comm;
+int rp_sizeof_comm(void);
+
+/* rp_forward on a row shard (net->rows = n / world, net->row0 = rank * rows) followed, every step, by the in-place
+   all-gather of the ranks' slices of the next source vector.  Same arguments and results as rp_forward. */
+int rp_forward_sharded(rp_net* net, rp_run* run, const rp_comm* comm, void* stream);
+
+/* The whole sharded adjoint sweep (rp_bwd_prepare; t = T-1..0: rp_bwd_partial -> reduce-scatter -> rp_bwd_apply). */
+int rp_rate_backward_sharded(const rp_net* net, const rp_bwd* bwd, const rp_comm* comm, void* stream);
 
 /*
  * Recursive-least-squares training of a readout edge (reference RLS.update, rectipy/edges.py:227-234, driven by

@@ -5,13 +5,14 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 3
+RP_ABI_VERSION = 4
 
 RP_OK = 0
 RP_ERR_ARG = -1
 RP_ERR_SHAPE = -2
 RP_ERR_ARCH = -3
 RP_ERR_HIP = -4
+RP_ERR_COMM = -5
 
 RP_MODEL_LI_TANH = 0
 RP_MODEL_LI_SIGMOID = 1
@@ -90,6 +91,8 @@ class RpRun(C.Structure):
         ("spike_events", fp),
         ("spike_capacity", C.c_int32),
         ("spike_count", fp),
+        ("save_src_full", fp),
+        ("ldfull", C.c_int64),
     ]
 
 
@@ -139,6 +142,17 @@ class RpRls(C.Structure):
     ]
 
 
+class RpComm(C.Structure):
+    _fields_ = [
+        ("comm", C.c_void_p),
+        ("all_gather", C.c_void_p),
+        ("reduce_scatter", C.c_void_p),
+        ("rank", C.c_int32),
+        ("world", C.c_int32),
+        ("work", fp),
+    ]
+
+
 def declare(lib, prefix):
     """Attach argtypes/restypes for the entry points `<prefix>_*` that `lib` exports."""
     P = C.POINTER
@@ -170,6 +184,9 @@ def declare(lib, prefix):
         sig("rp_bwd_prepare", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
         sig("rp_bwd_partial", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp, C.c_void_p])
         sig("rp_bwd_apply", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp, C.c_void_p])
+        sig("rp_sizeof_comm", C.c_int, [])
+        sig("rp_forward_sharded", C.c_int, [P(RpNet), P(RpRun), P(RpComm), C.c_void_p])
+        sig("rp_rate_backward_sharded", C.c_int, [P(RpNet), P(RpBwd), P(RpComm), C.c_void_p])
         sig("rp_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp,
                                       C.c_void_p])
         sig("rp_stream_probe", C.c_int, [fp, C.c_int64, fp, C.c_void_p])
@@ -199,5 +216,6 @@ EXPORTS = [
     "rp_abi_version", "rp_last_error", "rp_device_check", "rp_sizeof_net", "rp_sizeof_run", "rp_sizeof_bwd",
     "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum", "rp_outer_accum_rect",
     "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial", "rp_bwd_apply",
+    "rp_sizeof_comm", "rp_forward_sharded", "rp_rate_backward_sharded",
     "rp_rls_sweep", "rp_stream_probe", "rp_set_tuning", "rp_set_bwd_tuning", "rp_set_rls_tuning",
 ]

@@ -36,7 +36,8 @@ def load():
     _abi.declare(lib, "rp")
     if lib.rp_abi_version() != _abi.RP_ABI_VERSION:
         raise HipLibraryError(f"ABI version mismatch: library {lib.rp_abi_version()}, python {_abi.RP_ABI_VERSION}")
-    for name, struct in (("rp_sizeof_net", _abi.RpNet), ("rp_sizeof_run", _abi.RpRun), ("rp_sizeof_bwd", _abi.RpBwd)):
+    for name, struct in (("rp_sizeof_net", _abi.RpNet), ("rp_sizeof_run", _abi.RpRun), ("rp_sizeof_bwd", _abi.RpBwd),
+                         ("rp_sizeof_comm", _abi.RpComm)):
         if getattr(lib, name)() != C.sizeof(struct):
             raise HipLibraryError(f"{name}() = {getattr(lib, name)()} but ctypes mirror is {C.sizeof(struct)} bytes")
     _LIB = lib
@@ -54,4 +55,6 @@ def check(rc):
         raise RuntimeError(msg)  # torch raises RuntimeError on size mismatch (rectipy_tests/test_nodes.py:148-151)
     if rc == _abi.RP_ERR_ARCH:
         raise HipLibraryError(msg)
+    if rc == _abi.RP_ERR_COMM:
+        raise RuntimeError(f"RCCL failure: {msg}")
     raise RuntimeError(f"HIP failure: {msg}")

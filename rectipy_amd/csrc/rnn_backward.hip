@@ -547,6 +547,33 @@ int rp_bwd_apply(const rp_net* net, const rp_bwd* b, int32_t t, const float* z_l
     return RP_OK;
 }
 
+int rp_rate_backward_sharded(const rp_net* net, const rp_bwd* b, const rp_comm* comm, void* stream) {
+    typedef int (*reduce_scatter_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+    if (!net || !b || !comm) RP_FAIL(RP_ERR_ARG, "net/bwd/comm is null");
+    if (!comm->comm || !comm->reduce_scatter || !comm->work)
+        RP_FAIL(RP_ERR_ARG, "rp_comm needs comm, reduce_scatter and work (n + rows floats)");
+    if (comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world ||
+        (int64_t)net->rows * comm->world != net->n || net->row0 != comm->rank * net->rows)
+        RP_FAIL(RP_ERR_SHAPE, "shard rows=%d row0=%d does not match rank %d of %d over n=%d", net->rows, net->row0,
+                comm->rank, comm->world, net->n);
+    if (reinterpret_cast<uintptr_t>(comm->work) & 15u) RP_FAIL(RP_ERR_ARG, "work must be 16-byte aligned");
+    float* z_full = comm->work;
+    float* z_local = comm->work + net->n;
+    int rc = rp_bwd_prepare(net, b, stream);
+    if (rc != RP_OK) return rc;
+    for (int t = b->steps - 1; t >= 0; --t) {
+        rc = rp_bwd_partial(net, b, t, z_full, stream);
+        if (rc != RP_OK) return rc;
+        const int nrc = reinterpret_cast<reduce_scatter_fn>(comm->reduce_scatter)(
+            z_full, z_local, (size_t)net->rows, 7 /* ncclFloat32 */, 0 /* ncclSum */, comm->comm,
+            static_cast<hipStream_t>(stream));
+        if (nrc != 0) RP_FAIL(RP_ERR_COMM, "ncclReduceScatter returned %d at step %d", nrc, t);
+        rc = rp_bwd_apply(net, b, t, z_local, stream);
+        if (rc != RP_OK) return rc;
+    }
+    return RP_OK;
+}
+
 int rp_set_bwd_tuning(int unroll, int strip_groups) {
     g_bwd_U = unroll;
     g_bwd_SW = strip_groups;

@@ -538,10 +538,28 @@ int rp_refresh_source(const rp_net* net, void* stream) {
     return RP_OK;
 }
 
-int rp_forward(rp_net* net, rp_run* run, void* stream) {
+}  // extern "C"
+
+namespace {
+
+typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+constexpr int kNcclFloat = 7;  // ncclFloat32 (rccl.h)
+
+// rp_forward / rp_forward_sharded: `comm` != nullptr adds the per-step all-gather of the source slices.
+int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     int rc = validate_net(net);
     if (rc != RP_OK) return rc;
     if (!run) RP_FAIL(RP_ERR_ARG, "run is null");
+    if (comm) {
+        if (!comm->comm || !comm->all_gather) RP_FAIL(RP_ERR_ARG, "rp_comm needs comm and all_gather");
+        if (comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world)
+            RP_FAIL(RP_ERR_ARG, "bad rank %d / world %d", comm->rank, comm->world);
+        if ((int64_t)net->rows * comm->world != net->n || net->row0 != comm->rank * net->rows)
+            RP_FAIL(RP_ERR_SHAPE, "shard rows=%d row0=%d does not match rank %d of %d over n=%d", net->rows, net->row0,
+                    comm->rank, comm->world, net->n);
+        if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP)
+            RP_FAIL(RP_ERR_ARG, "population-mean models cannot be row-sharded");
+    }
     if (run->steps < 0) RP_FAIL(RP_ERR_ARG, "steps < 0");
     if (run->sampling_steps < 1) RP_FAIL(RP_ERR_ARG, "sampling_steps must be >= 1");
     if (run->cutoff < 0 || run->step0 < 0) RP_FAIL(RP_ERR_ARG, "cutoff/step0 must be >= 0");
@@ -573,6 +591,7 @@ int rp_forward(rp_net* net, rp_run* run, void* stream) {
         if (run->ldsamples < net->rows) RP_FAIL(RP_ERR_SHAPE, "ldsamples < rows");
         if (!run->acc) RP_FAIL(RP_ERR_ARG, "acc buffer required when sampling");
     }
+    if (run->save_src_full && run->ldfull < net->n) RP_FAIL(RP_ERR_SHAPE, "ldfull < n");
     if (run->spike_count && (!run->spike_events || run->spike_capacity < 0))
         RP_FAIL(RP_ERR_ARG, "spike_count given without spike_events");
     const bool vec4 = use_vec4(net);
@@ -630,17 +649,38 @@ int rp_forward(rp_net* net, rp_run* run, void* stream) {
                 run->acc_count = 0;
             }
         }
+        if (run->save_src_full)
+            RP_HIP_CHECK(hipMemcpyAsync(run->save_src_full + (int64_t)t * run->ldfull, P.src_cur,
+                                        sizeof(float) * (size_t)net->n, hipMemcpyDeviceToDevice, st));
         if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP)
             hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, st, P);
         if (vec4)
             launch_step_model<true>(net->model, P, st);
         else
             launch_step_model<false>(net->model, P, st);
+        if (comm) {  // every rank wrote rows [row0, row0 + rows) of src_next: exchange in place, same stream
+            const int nrc = reinterpret_cast<all_gather_fn>(comm->all_gather)(
+                P.src_next + net->row0, P.src_next, (size_t)net->rows, kNcclFloat, comm->comm, st);
+            if (nrc != 0) RP_FAIL(RP_ERR_COMM, "ncclAllGather returned %d at step %lld", nrc, (long long)t_abs);
+        }
         net->cur ^= 1;
     }
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;
 }
+
+}  // namespace
+
+extern "C" {
+
+int rp_forward(rp_net* net, rp_run* run, void* stream) { return forward_impl(net, run, nullptr, stream); }
+
+int rp_forward_sharded(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
+    if (!comm) RP_FAIL(RP_ERR_ARG, "comm is null");
+    return forward_impl(net, run, comm, stream);
+}
+
+int rp_sizeof_comm(void) { return (int)sizeof(rp_comm); }
 
 int rp_set_tuning(int rows_per_wave, int unroll, int nontemporal, int max_blocks) {
     g_tune_R = rows_per_wave;

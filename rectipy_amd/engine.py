@@ -107,6 +107,16 @@ class HipBackend:
     def shard_partial_rows(self, n, rows):
         return int(self.lib.rp_bwd_shard_partial_rows(n, rows))
 
+    def forward_sharded(self, net, run, comm, device):
+        with torch.cuda.device(device):
+            self._lib_mod.check(self.lib.rp_forward_sharded(C.byref(net), C.byref(run), C.byref(comm),
+                                                            self._stream(device)))
+
+    def rate_backward_sharded(self, net, bwd, comm, device):
+        with torch.cuda.device(device):
+            self._lib_mod.check(self.lib.rp_rate_backward_sharded(C.byref(net), C.byref(bwd), C.byref(comm),
+                                                                  self._stream(device)))
+
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
         with torch.cuda.device(device):
             self._lib_mod.check(self.lib.rp_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss,
@@ -255,8 +265,11 @@ class Population:
                 save_src: Optional[torch.Tensor] = None, save_acc: Optional[torch.Tensor] = None,
                 spike_events: Optional[torch.Tensor] = None, spike_count: Optional[torch.Tensor] = None,
                 x_target: int = _abi.RP_XT_MEMBRANE, save_aux: Optional[torch.Tensor] = None,
-                save_aux2: Optional[torch.Tensor] = None) -> int:
+                save_aux2: Optional[torch.Tensor] = None, comm=None,
+                save_src_full: Optional[torch.Tensor] = None) -> int:
         """Integrate ``steps`` Euler steps in one library call.  Returns the next sample index.
+        ``comm`` (an ``RpComm``): this population is a row shard and every step ends with the in-library RCCL
+        all-gather of the source vector (rp_forward_sharded).
 
         x: None | [steps, rows] | [steps, 1] | [steps, m] together with ``w_in`` [rows, m].
         """
@@ -335,13 +348,22 @@ class Population:
                 run.rec[int(k)] = _ptr(t)
             run.ldsamples = ld_s
             run.max_samples = max_rows or 0
+        if save_src_full is not None:
+            t = save_src_full
+            if t.dtype != torch.float32 or t.device != self.device or t.dim() != 2 or t.stride(1) != 1 \
+                    or t.shape[1] < self.n or t.shape[0] < steps:
+                raise RuntimeError(f"save_src_full must be a float32 [>= {steps}, >= {self.n}] row-major tensor")
+            run.save_src_full, run.ldfull = t.data_ptr(), t.stride(0) if t.shape[0] > 1 else t.shape[1]
         if spike_count is not None:
             run.spike_events = spike_events.data_ptr()
             run.spike_capacity = spike_events.shape[0]
             run.spike_count = spike_count.data_ptr()
 
         net = self._net()
-        self.backend.forward(net, run, self.device)
+        if comm is None:
+            self.backend.forward(net, run, self.device)
+        else:
+            self.backend.forward_sharded(net, run, comm, self.device)
         self.cur = net.cur
         if sampling:
             self.acc_count = run.acc_count

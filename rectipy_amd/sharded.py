@@ -17,6 +17,30 @@ from . import _abi
 from .engine import Population
 
 
+def rccl_comm(group, device, backend) -> Optional[_abi.RpComm]:
+    """The group's RCCL communicator as an ``rp_comm`` for the in-library exchange (rp_forward_sharded /
+    rp_rate_backward_sharded), or None when the exchange has to go through ``torch.distributed`` (gloo group, the
+    CPU test backend, or RECTIPY_AMD_HOST_COLLECTIVES=1).  The communicator stays owned by ProcessGroupNCCL; the
+    function addresses come from the RCCL instance PyTorch loaded, the only one in which that communicator is valid."""
+    import ctypes
+    import os
+    if os.environ.get("RECTIPY_AMD_HOST_COLLECTIVES", "0") == "1" or not hasattr(backend, "forward_sharded"):
+        return None
+    if dist.get_backend(group) != "nccl":
+        return None
+    pg = group if group is not None else dist.distributed_c10d._get_default_group()
+    ptr = pg._get_backend(torch.device(device))._comm_ptr()
+    if not ptr:
+        raise RuntimeError("the RCCL communicator of the process group is not initialised on " + str(device))
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    comm = _abi.RpComm()
+    comm.comm = ptr
+    comm.all_gather = ctypes.cast(lib.ncclAllGather, ctypes.c_void_p).value
+    comm.reduce_scatter = ctypes.cast(lib.ncclReduceScatter, ctypes.c_void_p).value
+    comm.rank, comm.world = dist.get_rank(group), dist.get_world_size(group)
+    return comm
+
+
 def shard_bounds(n: int, world: int, rank: int):
     if n % world:
         raise ValueError(f"n={n} must be divisible by the number of ranks ({world})")
@@ -37,6 +61,7 @@ class ShardedPopulation:
                               row0=self.row0, backend=backend, **kw)
         self.n = n
         self._gather_source()  # every rank needs the full initial source vector
+        self.comm = rccl_comm(group, self.pop.device, self.pop.backend)
 
     def _gather_source(self):
         full = self.pop.source
@@ -46,6 +71,9 @@ class ShardedPopulation:
                 traj: Optional[torch.Tensor] = None, step0: int = 0, **sampling):
         """`steps` Euler steps; `x` and `traj` are LOCAL ([steps, rows] or [steps, 1])."""
         idx = sampling.pop("sample_idx", 0)
+        if self.comm is not None:  # one library call: step kernels and RCCL all-gathers back to back on one stream
+            return self.pop.forward(steps, x=x, out_var=out_var, traj=traj, step0=step0, sample_idx=idx,
+                                    comm=self.comm, **sampling)
         for t in range(steps):
             xt = None if x is None else x[t:t + 1]
             tr = None if traj is None else traj[t:t + 1]
@@ -108,11 +136,15 @@ class _ShardedRateWindow(torch.autograd.Function):
         traj_r = torch.empty(steps, rows, **f32)
         traj_r_full = torch.empty(steps, n, **f32)
         traj_acc = torch.empty(steps, rows, **f32) if k.requires_grad else None
-        for t in range(steps):
-            traj_r_full[t].copy_(pop.source)
-            pop.forward(1, x=None if x is None else x[t:t + 1], save_v=traj_v[t:t + 1], save_src=traj_r[t:t + 1],
-                        save_acc=None if traj_acc is None else traj_acc[t:t + 1])
-            net._gather(node, row0, rows)
+        if net.comm is not None:  # whole window in one library call (step kernels + RCCL all-gathers on one stream)
+            pop.forward(steps, x=x, save_v=traj_v, save_src=traj_r, save_acc=traj_acc, save_src_full=traj_r_full,
+                        comm=net.comm)
+        else:
+            for t in range(steps):
+                traj_r_full[t].copy_(pop.source)
+                pop.forward(1, x=None if x is None else x[t:t + 1], save_v=traj_v[t:t + 1], save_src=traj_r[t:t + 1],
+                            save_acc=None if traj_acc is None else traj_acc[t:t + 1])
+                net._gather(node, row0, rows)
         ctx.node, ctx.net, ctx.steps = node, net, steps
         ctx.x_width = None if x is None else x.shape[1]
         ctx.saved = (traj_v, traj_r, traj_r_full, traj_acc)
@@ -156,8 +188,16 @@ class _ShardedRateWindow(torch.autograd.Function):
         b.ldgx = rows
         rnet = pop._net()
         nccl = dist.get_backend(net.group) == "nccl"
-        be.bwd_prepare(rnet, b, dev)
-        for t in range(T - 1, -1, -1):
+        if net.comm is not None:  # whole sweep in one library call (reduce-scatter per step on the same stream)
+            work = torch.empty(n + rows, **f32)
+            net.comm.work = work.data_ptr()
+            be.rate_backward_sharded(rnet, b, net.comm, dev)
+            net.comm.work = None
+            T_loop = 0
+        else:
+            be.bwd_prepare(rnet, b, dev)
+            T_loop = T
+        for t in range(T_loop - 1, -1, -1):
             be.bwd_partial(rnet, b, t, z_full.data_ptr(), dev)
             if nccl:
                 dist.reduce_scatter_tensor(z_local, z_full, group=net.group)
@@ -195,6 +235,7 @@ class ShardedNetwork(Network):
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._sharded = {}  # label -> (row0, rows, n)
+        self.comm = None  # rp_comm for the in-library exchange, set once the first collective has run
 
     def add_diffeq_node(self, label, node, input_var, output_var, weights=None, **kwargs):
         if weights is None:
@@ -213,6 +254,8 @@ class ShardedNetwork(Network):
         self._sharded[label] = (row0, rows, n)
         self._wrap(new, row0, rows)
         self._gather(new, row0, rows, clone=True)
+        if self.comm is None:
+            self.comm = rccl_comm(self.group, new._pop.device, new._pop.backend)
         return new
 
     def _gather(self, node: RateNet, row0: int, rows: int, clone: bool = False):
@@ -231,6 +274,8 @@ class ShardedNetwork(Network):
             step0 = kw.pop("step0", 0)
             idx = kw.pop("sample_idx", 0)
             traj = kw.pop("traj", None)
+            if net.comm is not None:
+                return base_window(steps, x=x, w_in=w_in, step0=step0, sample_idx=idx, traj=traj, comm=net.comm, **kw)
             for t in range(steps):
                 idx = base_window(1, x=None if x is None else x[t:t + 1], w_in=w_in, step0=step0 + t, sample_idx=idx,
                                   traj=None if traj is None else traj[t:t + 1], **kw)
