@@ -102,6 +102,27 @@ def main():
         sp = ShardedPopulation("li_tanh", gen_rows(N, row0, rows, dev), params, dt, dev, n=N)
         pop = sp.pop
         samples = torch.zeros(n_samples, rows, device=dev)
+        exchange = "torch.distributed all_gather_into_tensor per step (host loop)"
+        if sp.comm is not None:
+            # the in-library RCCL exchange must reproduce the torch.distributed one bit for bit; otherwise do not use it
+            saved = (pop.v.clone(), pop.src[0].clone(), pop.src[1].clone(), pop.cur)
+
+            def three_steps(comm):
+                pop.v.copy_(saved[0]); pop.src[0].copy_(saved[1]); pop.src[1].copy_(saved[2]); pop.cur = saved[3]
+                keep, sp.comm = sp.comm, comm
+                sp.forward(3, x=x[:3])
+                sp.comm = keep
+                return pop.v.clone(), pop.source.clone()
+
+            a, b = three_steps(sp.comm), three_steps(None)
+            same = torch.tensor([int(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]))], device=dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            pop.v.copy_(saved[0]); pop.src[0].copy_(saved[1]); pop.src[1].copy_(saved[2]); pop.cur = saved[3]
+            if int(same.item()) == 1:
+                exchange = "RCCL all-gather enqueued in-library (rp_forward_sharded); checked == torch.distributed path"
+            else:
+                sp.comm = None
+                exchange += " [in-library exchange disagreed with it and was disabled]"
 
         def run(steps, step0, idx):
             return sp.forward(steps, x=x[step0:step0 + steps], step0=step0, sampling_steps=sampling,
@@ -150,8 +171,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"tanh rate RNN N={N} dense W fp32, forward-only Euler, dt=1e-2, sampling_steps=100, "
                                f"broadcast sinusoid input (BASELINE.json configs[1])",
-                   "neurons": N, "rows_per_gpu": rows, "parallelism": f"row-shard x{world} + RCCL all-gather(r) per step, enqueued in-library (rp_forward_sharded)"
-                   if world > 1 else "single GPU, driven through rectipy_amd.Network.run"},
+                   "neurons": N, "rows_per_gpu": rows, "parallelism": f"row-shard x{world}; " + exchange
+                   if use_dist else "single GPU, driven through rectipy_amd.Network.run"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": "step_kernel<LI_TANH,R=4,U=2,vec4,nt>", "algorithmic_bytes_per_launch": algo_bytes,
