@@ -313,6 +313,9 @@ int rp_set_tuning(int rows_per_wave, int unroll, int nontemporal, int max_blocks
 /* Benchmark-only: rows in flight per wave (unroll) and 1-KiB column groups per lane of the adjoint's column-strip
    kernel; 0, 0 restores the built-in choice.  Results are bit-identical for every configuration. */
 int rp_set_bwd_tuning(int unroll, int strip_groups);
+/* Benchmark-only: number of row chunks of the adjoint (0 = built-in RC(n)).  Unlike the two above this CHANGES the
+   summation order, i.e. results then differ from the oracle in the last bits; never set in production. */
+int rp_set_bwd_chunks(int max_chunks);
 
 /* Benchmark-only: rows per wave, column chunks in flight and store policy (-1 = default) of the RLS pass. */
 int rp_set_rls_tuning(int rows_per_wave, int unroll, int nontemporal_store);

@@ -79,12 +79,10 @@ class OracleBackend:
         assert self.lib.oracle_bwd_apply(C.byref(net), C.byref(bwd), t, z_local) == 0
 
     def shard_partial_rows(self, n, rows):
-        rc = max(8, ((n + 63) // 64 + 7) & ~7)
-        return (rows + rc - 1) // rc
+        return min(64, (rows + 7) // 8)  # upper bound of Q for every RC(n, rows) (chunks hold >= 8 rows, Q <= 64)
 
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
         assert self.lib.oracle_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss) == 0
 
     def partial_rows(self, n):
-        rc = max(8, ((n + 63) // 64 + 7) & ~7)
-        return (n + rc - 1) // rc
+        return min(64, (n + 7) // 8)

@@ -26,9 +26,16 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxChunks = 64;
+int g_bwd_chunks = 0;  // benchmark-only override of the chunk count (rp_set_bwd_chunks); changes the summation order
 
-__host__ __device__ inline int chunk_rows(int n) {  // RC(n): rows per chunk, multiple of 8
-    int rc = (n + kMaxChunks - 1) / kMaxChunks;
+// RC(n, rows): rows per chunk (multiple of 8) for `rows` rows of an n-column matrix.  The chunk count aims at ~1024
+// waves of 512-column strips, Q = clamp(1024 / ceil(n / 512), 8, 64): long row streams per wave are worth more than
+// extra waves once the chip is covered (n = 32768, scripts/tune_chunks.py: Q = 16 636 us, 32 644 us, 64 655 us per step).
+inline int chunk_rows(int n, int rows) {
+    int q = 1024 / ((n + 511) / 512);
+    q = q < 8 ? 8 : (q > kMaxChunks ? kMaxChunks : q);
+    if (g_bwd_chunks > 0) q = g_bwd_chunks;
+    int rc = (rows + q - 1) / q;
     rc = (rc + 7) & ~7;
     return rc < 8 ? 8 : rc;
 }
@@ -371,7 +378,7 @@ extern "C" {
 
 int32_t rp_bwd_partial_rows(int32_t n) {
     if (n <= 0) return 0;
-    int rc = chunk_rows(n);
+    int rc = chunk_rows(n, n);
     return (n + rc - 1) / rc;
 }
 
@@ -409,7 +416,7 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     P.model = net->model;
     for (int q = 0; q < RP_MAX_PARAMS; ++q) P.p[q] = net->p[q];
     P.dt = net->dt;
-    P.rc = chunk_rows(n);
+    P.rc = chunk_rows(n, n);
     P.q = (n + P.rc - 1) / P.rc;
     P.partials = b->partials;
     P.grad_var = b->grad_var;
@@ -478,7 +485,7 @@ static int sharded_params(const rp_net* net, const rp_bwd* b, BwdParams& P, bool
     P.model = net->model;
     for (int q = 0; q < RP_MAX_PARAMS; ++q) P.p[q] = net->p[q];
     P.dt = net->dt;
-    P.rc = chunk_rows(net->n);
+    P.rc = chunk_rows(net->n, net->rows);
     P.q = (net->rows + P.rc - 1) / P.rc;
     P.partials = b->partials;
     P.grad_var = b->grad_var;
@@ -498,7 +505,7 @@ static void sharded_set_prep(const rp_bwd* b, BwdParams& P, int tp) {
 
 int32_t rp_bwd_shard_partial_rows(int32_t n, int32_t rows) {
     if (n <= 0 || rows <= 0) return 0;
-    const int rc = chunk_rows(n);
+    const int rc = chunk_rows(n, rows);
     return (rows + rc - 1) / rc;
 }
 
@@ -574,6 +581,11 @@ int rp_rate_backward_sharded(const rp_net* net, const rp_bwd* b, const rp_comm* 
     return RP_OK;
 }
 
+int rp_set_bwd_chunks(int max_chunks) {
+    g_bwd_chunks = max_chunks;
+    return RP_OK;
+}
+
 int rp_set_bwd_tuning(int unroll, int strip_groups) {
     g_bwd_U = unroll;
     g_bwd_SW = strip_groups;
@@ -643,7 +655,7 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     for (int q = 0; q < RP_MAX_PARAMS; ++q) P.p[q] = net->p[q];
     P.dt = net->dt;
     P.inv_dt = 1.0f / net->dt;
-    P.rc = chunk_rows(n);
+    P.rc = chunk_rows(n, n);
     P.q = (n + P.rc - 1) / P.rc;
     P.partials = b->partials;
     P.grad_var = b->grad_var;
