@@ -212,7 +212,16 @@ typedef struct rp_bwd {
     float* lam3;              /* [n] adjoint of the second state (in: at T, out: at 0)                        */
     float* grad_p[RP_MAX_PARAMS]; /* optional per-neuron parameter gradients by slot RP_P_* (+=); the named
                                      fields above take precedence for tau / k / eta / tau_s                   */
+    /* Optional workspace for a transposed copy of W (unsharded sweeps).  When it is given and
+       n <= RP_BWD_TRANSPOSE_MAX_N, the sweep first writes W^T there (one pass, n^2 floats) and then computes
+       z = W^T u with the FORWARD's row-dot kernel on the rows of W^T, fused with the element-wise adjoint update:
+       ONE launch per step instead of two -- at these sizes the step is launch/latency-bound, not HBM-bound.
+       The summation order of z then is the forward's row order; the oracle mirrors the same rule. */
+    float* wt;                /* [n x ldwt] or NULL                                                            */
+    int64_t ldwt;
 } rp_bwd;
+
+#define RP_BWD_TRANSPOSE_MAX_N 4096
 
 int rp_abi_version(void);
 const char* rp_last_error(void);

@@ -13,6 +13,7 @@ RP_ERR_SHAPE = -2
 RP_ERR_ARCH = -3
 RP_ERR_HIP = -4
 RP_ERR_COMM = -5
+RP_BWD_TRANSPOSE_MAX_N = 4096
 
 RP_MODEL_LI_TANH = 0
 RP_MODEL_LI_SIGMOID = 1
@@ -124,6 +125,8 @@ class RpBwd(C.Structure):
         ("traj_aux", fp),
         ("lam3", fp),
         ("grad_p", fp * RP_MAX_PARAMS),
+        ("wt", fp),
+        ("ldwt", C.c_int64),
     ]
 
 

@@ -21,6 +21,7 @@
 // summation order is a function of n only (mirrored in oracle/rnn_oracle.c).
 
 #include "rp_common.h"
+#include "rp_dot.h"
 
 namespace {
 
@@ -235,10 +236,7 @@ __global__ void chunk_sum_kernel(const BwdParams P, float* z_full) {
     z_full[c] = chunk_sum(P, c);
 }
 
-__global__ void finalize_kernel(const BwdParams P) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.rows) return;
-    const float z = P.z_direct ? P.z_direct[j] : chunk_sum(P, j);
+__device__ __forceinline__ void finalize_elem(const BwdParams& P, int j, float z) {
     const float lam = P.lam[j];
     const float d = act_deriv(P, j, P.r_t[j]);
     const float g = P.g_t ? P.g_t[j] : 0.f;
@@ -246,6 +244,12 @@ __global__ void finalize_kernel(const BwdParams P) {
     const float lam_new = (lam + P.dt * (-lam / P.p[RP_P_TAU][j] + d * z)) + gv;
     P.lam[j] = lam_new;
     if (P.u_next) prep_step(P, j, lam_new);
+}
+
+__global__ void finalize_kernel(const BwdParams P) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.rows) return;
+    finalize_elem(P, j, P.z_direct ? P.z_direct[j] : chunk_sum(P, j));
 }
 
 // ---- spiking sweep (QIF, QIF_SFA, LIF, IK) -------------------------------------------------------------
@@ -333,10 +337,7 @@ __global__ void spk_prep_kernel(const BwdParams P, const SpkGrad G) {
     if (j < P.n) spk_prep_step(P, G, j, P.lam[j], P.lam_s[j], P.lam_x ? P.lam_x[j] : 0.f);
 }
 
-__global__ void spk_finalize_kernel(const BwdParams P, const SpkGrad G) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.n) return;
-    const float z = chunk_sum(P, j);
+__device__ __forceinline__ void spk_finalize_elem(const BwdParams& P, const SpkGrad& G, int j, float z) {
     const float lv = P.lam[j];
     const float ls = P.lam_s[j];
     const float lx = P.lam_x ? P.lam_x[j] : 0.f;
@@ -372,6 +373,94 @@ __global__ void spk_finalize_kernel(const BwdParams P, const SpkGrad G) {
     if (P.u_next) spk_prep_step(P, G, j, lv_new, ls_new, lx_new);
 }
 
+__global__ void spk_finalize_kernel(const BwdParams P, const SpkGrad G) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n) return;
+    spk_finalize_elem(P, G, j, chunk_sum(P, j));
+}
+
+// ---- transposed-copy sweep for small n (rp_bwd.wt) -------------------------------------------------------------
+// WT[j][i] = W[i][j]: 32 x 32 tiles through LDS (padded), both sides coalesced.  Once per sweep.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ W, int64_t ldw, int n,
+                                                        float* __restrict__ WT, int64_t ldwt) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int tiles = (n + 31) / 32;
+    const int bi = (blockIdx.x / tiles) * 32, bj = (blockIdx.x % tiles) * 32;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (bi + r < n && bj + tx < n) tile[r][tx] = W[(int64_t)(bi + r) * ldw + bj + tx];
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8)
+        if (bj + r < n && bi + tx < n) WT[(int64_t)(bj + r) * ldwt + bi + tx] = tile[tx][r];
+}
+
+// One adjoint step in ONE launch: z_j = <row j of W^T, u> with the forward's row-dot (same summation tree as the step
+// kernel), then the element-wise update of neuron j by the lane that owns the row.  P.W / P.ldw point at W^T.
+template <bool SPIKING, int R, int U, bool VEC4>
+__global__ __launch_bounds__(kThreads) void adj_rowdot_kernel(const BwdParams P, const SpkGrad G) {
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int groups = (P.n + R - 1) / R;
+    const RowDotArgs D{P.W, P.ldw, P.n, P.n, 0, P.u};
+    for (int g = blockIdx.x * (kThreads / 64) + wave; g < groups; g += gridDim.x * (kThreads / 64)) {
+        const int row_base = g * R;
+        float sum[R];
+        if constexpr (VEC4)
+            rp_dot_rows_v4<R, U, false>(D, row_base, lane, sum);
+        else
+            rp_dot_rows_s1<R>(D, row_base, lane, sum);
+        float mine = 0.f;
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (lane == j) mine = sum[j];
+        if (lane < R && row_base + lane < P.n) {
+            if constexpr (SPIKING)
+                spk_finalize_elem(P, G, row_base + lane, mine);
+            else
+                finalize_elem(P, row_base + lane, mine);
+        }
+    }
+}
+
+// Launch shapes follow the forward's small-n choices (rnn_forward.hip launch_step): 1 row x 4 chunks per wave up to
+// n = 2048, 2 rows x 2 chunks above.
+template <bool SPIKING>
+void launch_adj_rowdot(const BwdParams& P, const SpkGrad& G, bool vec4, hipStream_t st) {
+    const int wpb = kThreads / 64;
+    if (!vec4) {
+        hipLaunchKernelGGL((adj_rowdot_kernel<SPIKING, 1, 1, false>), dim3((P.n + wpb - 1) / wpb), dim3(kThreads), 0, st,
+                           P, G);
+    } else if (P.n <= 2048) {
+        hipLaunchKernelGGL((adj_rowdot_kernel<SPIKING, 1, 4, true>), dim3((P.n + wpb - 1) / wpb), dim3(kThreads), 0, st,
+                           P, G);
+    } else {
+        const int groups = (P.n + 1) / 2;
+        hipLaunchKernelGGL((adj_rowdot_kernel<SPIKING, 2, 2, true>), dim3((groups + wpb - 1) / wpb), dim3(kThreads), 0,
+                           st, P, G);
+    }
+}
+
+// true when the sweep uses the transposed copy; validates the workspace
+int transposed_mode(const rp_net* net, const rp_bwd* b, bool& use, bool& vec4_t) {
+    use = b->wt != nullptr && net->n <= RP_BWD_TRANSPOSE_MAX_N;
+    vec4_t = false;
+    if (!use) return RP_OK;
+    if (b->ldwt < net->n) RP_FAIL(RP_ERR_SHAPE, "ldwt < n");
+    vec4_t = (net->n % 4 == 0) && (b->ldwt % 4 == 0);
+    if (vec4_t && ((reinterpret_cast<uintptr_t>(b->wt) & 15u) || (reinterpret_cast<uintptr_t>(b->u_traj) & 15u) ||
+                   (b->ld % 4 != 0)))
+        RP_FAIL(RP_ERR_ARG, "wt and u_traj must be 16-byte aligned (ld a multiple of 4) for the transposed sweep");
+    return RP_OK;
+}
+
+void launch_transpose(const rp_net* net, const rp_bwd* b, hipStream_t st) {
+    const int tiles = (net->n + 31) / 32;
+    hipLaunchKernelGGL(transpose_kernel, dim3(tiles * tiles), dim3(256), 0, st, net->W, net->ldw, net->n, b->wt,
+                       b->ldwt);
+}
+
 }  // namespace
 
 extern "C" {
@@ -403,14 +492,19 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     const bool vec4 = (net->n % 4 == 0) && (net->ldw % 4 == 0);
     if (vec4 && ((reinterpret_cast<uintptr_t>(net->W) & 15u) || (reinterpret_cast<uintptr_t>(b->partials) & 15u)))
         RP_FAIL(RP_ERR_ARG, "W and partials must be 16-byte aligned");
+    bool use_wt, vec4_t;
+    {
+        int rc = transposed_mode(net, b, use_wt, vec4_t);
+        if (rc != RP_OK) return rc;
+    }
     if (b->steps == 0) return RP_OK;
 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int n = net->n;
     const int T = b->steps;
     BwdParams P = {};
-    P.W = net->W;
-    P.ldw = net->ldw;
+    P.W = use_wt ? b->wt : net->W;
+    P.ldw = use_wt ? b->ldwt : net->ldw;
     P.n = n;
     P.rows = n;
     P.model = net->model;
@@ -437,12 +531,13 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
         P.gx_prev = b->grad_x ? b->grad_x + (int64_t)tp * b->ldgx : nullptr;
     };
 
+    if (use_wt) launch_transpose(net, b, st);
     set_prep(T - 1);
     hipLaunchKernelGGL(prep_kernel, dim3(eblocks), dim3(256), 0, st, P);
     for (int t = T - 1; t >= 0; --t) {
         P.t = t;
         P.u = b->u_traj + (int64_t)t * b->ld;
-        launch_wt_partial(P, vec4, st);
+        if (!use_wt) launch_wt_partial(P, vec4, st);
         P.v_t = b->traj_v + (int64_t)t * b->ld;
         P.r_t = b->traj_r + (int64_t)t * b->ld;
         P.g_t = b->grad_out ? b->grad_out + (int64_t)t * b->ldg : nullptr;
@@ -450,7 +545,10 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
             set_prep(t - 1);
         else
             P.u_next = nullptr;
-        hipLaunchKernelGGL(finalize_kernel, dim3(eblocks), dim3(256), 0, st, P);
+        if (use_wt)
+            launch_adj_rowdot<false>(P, SpkGrad{}, vec4_t, st);
+        else
+            hipLaunchKernelGGL(finalize_kernel, dim3(eblocks), dim3(256), 0, st, P);
     }
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;
@@ -641,14 +739,19 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     const bool vec4 = (net->n % 4 == 0) && (net->ldw % 4 == 0);
     if (vec4 && ((reinterpret_cast<uintptr_t>(net->W) & 15u) || (reinterpret_cast<uintptr_t>(b->partials) & 15u)))
         RP_FAIL(RP_ERR_ARG, "W and partials must be 16-byte aligned");
+    bool use_wt, vec4_t;
+    {
+        int rc = transposed_mode(net, b, use_wt, vec4_t);
+        if (rc != RP_OK) return rc;
+    }
     if (b->steps == 0) return RP_OK;
 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int n = net->n;
     const int T = b->steps;
     BwdParams P = {};
-    P.W = net->W;
-    P.ldw = net->ldw;
+    P.W = use_wt ? b->wt : net->W;
+    P.ldw = use_wt ? b->ldwt : net->ldw;
     P.n = n;
     P.rows = n;
     P.model = model;
@@ -679,12 +782,13 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
         P.x_prev = b->x ? b->x + (int64_t)tp * b->ldx : nullptr;
     };
 
+    if (use_wt) launch_transpose(net, b, st);
     set_prep(T - 1);
     hipLaunchKernelGGL(spk_prep_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
     for (int t = T - 1; t >= 0; --t) {
         P.t = t;
         P.u = b->u_traj + (int64_t)t * b->ld;
-        launch_wt_partial(P, vec4, st);
+        if (!use_wt) launch_wt_partial(P, vec4, st);
         P.v_t = b->traj_v + (int64_t)t * b->ld;
         P.acc_t = b->traj_acc ? b->traj_acc + (int64_t)t * b->ld : nullptr;
         P.g_t = b->grad_out ? b->grad_out + (int64_t)t * b->ldg : nullptr;
@@ -692,7 +796,10 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
             set_prep(t - 1);
         else
             P.u_next = nullptr;
-        hipLaunchKernelGGL(spk_finalize_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
+        if (use_wt)
+            launch_adj_rowdot<true>(P, G, vec4_t, st);
+        else
+            hipLaunchKernelGGL(spk_finalize_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
     }
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;

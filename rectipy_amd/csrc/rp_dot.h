@@ -1,0 +1,111 @@
+// rp_dot.h -- streaming row dot products shared by the forward step kernel and the transposed-copy adjoint.
+// The summation tree per row is fixed (DESIGN.md "Summation order") and mirrored by oracle/rnn_oracle.c.
+#pragma once
+
+#include "rp_common.h"
+
+// Start chunk of the 8-row group g = (global row) >> 3 on the 16-byte path: m0 = (kStagger * g) mod M.
+// Without it all waves march through addresses that are equal modulo the row stride (a power of two at the
+// benchmark sizes) in lock step; rotating the start is worth +3 % of HBM bandwidth.  Part of the summation spec.
+constexpr unsigned kStagger = 3;
+
+struct RowDotArgs {
+    const float* W;    // [rows x ldw]
+    int64_t ldw;
+    int n, rows, row0;  // columns, local rows, global index of local row 0
+    const float* src;  // [n]
+};
+
+template <bool NT>
+__device__ __forceinline__ rp_f4 ld_w(const float* p) {
+    if constexpr (NT)
+        return rp_ld4_stream(p);
+    else
+        return rp_ld4(p);
+}
+
+// 16-byte path: requires n % 4 == 0, ldw % 4 == 0, 16-byte aligned W and src.
+template <int R, int U, bool NT>
+__device__ __forceinline__ void rp_dot_rows_v4(const RowDotArgs& P, int row_base, int lane, float (&sum)[R]) {
+    const float* wrow[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        int rr = row_base + j;
+        rr = rr < P.rows ? rr : P.rows - 1;  // clamp: tail rows re-read a valid row, result discarded
+        wrow[j] = P.W + (int64_t)rr * P.ldw + 4 * lane;
+    }
+    const float* sp = P.src + 4 * lane;
+    rp_f4 a[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) a[j] = rp_f4{0.f, 0.f, 0.f, 0.f};
+
+    const int M = P.n >> 8;  // full 256-column chunks
+    auto sweep = [&](int mA, int mB) {  // chunks [mA, mB) in ascending order
+        int m = mA;
+        for (; m + U <= mB; m += U) {
+            rp_f4 rv[U];
+            rp_f4 w[U][R];
+#pragma unroll
+            for (int u = 0; u < U; ++u) rv[u] = rp_ld4(sp + (int64_t)(m + u) * 256);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < R; ++j) w[u][j] = ld_w<NT>(wrow[j] + (int64_t)(m + u) * 256);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    a[j].x = fmaf(w[u][j].x, rv[u].x, a[j].x);
+                    a[j].y = fmaf(w[u][j].y, rv[u].y, a[j].y);
+                    a[j].z = fmaf(w[u][j].z, rv[u].z, a[j].z);
+                    a[j].w = fmaf(w[u][j].w, rv[u].w, a[j].w);
+                }
+        }
+        for (; m < mB; ++m) {
+            rp_f4 rv = rp_ld4(sp + (int64_t)m * 256);
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                rp_f4 w = ld_w<NT>(wrow[j] + (int64_t)m * 256);
+                a[j].x = fmaf(w.x, rv.x, a[j].x);
+                a[j].y = fmaf(w.y, rv.y, a[j].y);
+                a[j].z = fmaf(w.z, rv.z, a[j].z);
+                a[j].w = fmaf(w.w, rv.w, a[j].w);
+            }
+        }
+    };
+    const int m0 = M > 0 ? (int)(((unsigned)((P.row0 + row_base) >> 3) * kStagger) % (unsigned)M) : 0;
+    sweep(m0, M);
+    sweep(0, m0);
+    if ((M << 8) + 4 * lane < P.n) {  // partial last chunk (n % 4 == 0, so all 4 columns are valid)
+        rp_f4 rv = rp_ld4(sp + (int64_t)M * 256);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            rp_f4 w = ld_w<NT>(wrow[j] + (int64_t)M * 256);
+            a[j].x = fmaf(w.x, rv.x, a[j].x);
+            a[j].y = fmaf(w.y, rv.y, a[j].y);
+            a[j].z = fmaf(w.z, rv.z, a[j].z);
+            a[j].w = fmaf(w.w, rv.w, a[j].w);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) sum[j] = rp_wave_allreduce(rp_lane_sum4(a[j]));
+}
+
+// 4-byte path for sizes / alignments the 16-byte path cannot take (small test networks).
+template <int R>
+__device__ __forceinline__ void rp_dot_rows_s1(const RowDotArgs& P, int row_base, int lane, float (&sum)[R]) {
+    float a[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) a[j] = 0.f;
+    for (int col = lane; col < P.n; col += RP_WAVE) {
+        float rv = P.src[col];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            int rr = row_base + j;
+            rr = rr < P.rows ? rr : P.rows - 1;
+            a[j] = fmaf(P.W[(int64_t)rr * P.ldw + col], rv, a[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) sum[j] = rp_wave_allreduce(a[j]);
+}

@@ -184,6 +184,8 @@ class Population:
         self.aux = self._vec(0.0 if aux0 is None else aux0) if model in HAS_AUX else None
         self.aux2 = self._vec(0.0 if aux2_0 is None else aux2_0) if model in HAS_AUX2 else None
         self._scratch = torch.zeros(4, **f32) if model in NEEDS_MEANS else None
+        self._wt = None                  # workspace for W^T (adjoint of small networks), allocated on first use
+        self.transposed_adjoint = True   # False: always use the column-strip kernels (tests, measurements)
         self.spiking = model in SPIKING
         self.src = [torch.zeros(self.n, **f32), torch.zeros(self.n, **f32)]
         self.cur = 0
@@ -390,6 +392,11 @@ class Population:
         q = self.backend.partial_rows(self.n)
         partials = torch.empty(q, self.n, dtype=torch.float32, device=self.device)
         b.partials = partials.data_ptr()
+        if self.n <= _abi.RP_BWD_TRANSPOSE_MAX_N and self.transposed_adjoint:
+            # small networks: the sweep keeps W^T in this workspace and runs one fused launch per step (rp_bwd.wt)
+            if self._wt is None:
+                self._wt = torch.empty(self.n, (self.n + 3) // 4 * 4, dtype=torch.float32, device=self.device)
+            b.wt, b.ldwt = self._wt.data_ptr(), self._wt.stride(0)
         b.grad_tau, b.grad_k, b.grad_eta = _ptr(grad_tau), _ptr(grad_k), _ptr(grad_eta)
         b.grad_x = _ptr(grad_x)
         b.ldgx = 0 if grad_x is None else (grad_x.stride(0) if T > 1 else grad_x.shape[1])

@@ -1,10 +1,15 @@
-"""Forward / adjoint step time across network sizes (GPU box): where the path is launch-bound, cache-resident, HBM-bound."""
+"""Forward / adjoint step time across network sizes (GPU box): where the path is launch-bound, cache-resident, HBM-bound.
+Adjoint: the default layout (fused row-dot launch on the transposed copy up to RP_BWD_TRANSPOSE_MAX_N, column strips
+above; the per-sweep transposition is inside the timed call) and the column-strip kernels at every size."""
 import json
+import os
+import sys
 
 import torch
 
-from rectipy_amd import _abi
-from rectipy_amd.engine import Population
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rectipy_amd import _abi  # noqa: E402
+from rectipy_amd.engine import Population  # noqa: E402
 
 dev = torch.device("cuda:0")
 for N in (512, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
@@ -13,46 +18,38 @@ for N in (512, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
     del W
     T = 2000 if N <= 4096 else (400 if N <= 16384 else 100)
     x = torch.zeros(T, 1, device=dev)
-    Tb = min(T, 200 if N <= 16384 else 40)
+    Tb = min(T, 1000 if N <= 4096 else (200 if N <= 16384 else 40))
     tv, tr, ut = (torch.zeros(Tb, N, device=dev) for _ in range(3))
     g = torch.randn(Tb, N, device=dev) * 0.01
     pop.forward(20, x=x)
     torch.cuda.synchronize()
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     e[0].record()
     pop.forward(T, x=x)
     e[1].record()
-    pop.forward(Tb, x=x, save_v=tv, save_src=tr)
-    lam = torch.zeros(N, device=dev)
-    e[2].record()
-    keep = pop.backward(tv, tr, g, _abi.RP_OUT_STATE0, lam, ut)
-    e[3].record()
     torch.cuda.synchronize()
-    fwd, bwd = e[0].elapsed_time(e[1]) / T, e[2].elapsed_time(e[3]) / Tb
-    from rectipy_amd import _lib
-    alt = {}
-    for U, SW in ((8, 1), (16, 1), (6, 2), (4, 2)):
-        _lib.load().rp_set_bwd_tuning(U, SW)
-        lam = torch.zeros(N, device=dev)
-        keep = pop.backward(tv, tr, g, _abi.RP_OUT_STATE0, lam, ut)
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        lam = torch.zeros(N, device=dev)
-        a.record()
-        keep = pop.backward(tv, tr, g, _abi.RP_OUT_STATE0, lam, ut)
-        b.record()
-        torch.cuda.synchronize()
-        best = a.elapsed_time(b)
-        for _ in range(2):
+    fwd = e[0].elapsed_time(e[1]) / T
+    pop.forward(Tb, x=x, save_v=tv, save_src=tr)
+
+    def bwd_time(transposed):
+        pop.transposed_adjoint = transposed
+        best = None
+        for _ in range(3):
             lam = torch.zeros(N, device=dev)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             keep = pop.backward(tv, tr, g, _abi.RP_OUT_STATE0, lam, ut)
             b.record()
             torch.cuda.synchronize()
-            best = min(best, a.elapsed_time(b))
-        alt[f"U{U}SW{SW}"] = round(best / Tb * 1e3, 1)
-    _lib.load().rp_set_bwd_tuning(0, 0)
-    print(json.dumps(dict(N=N, bwd_alt_us=alt, W_MB=4.0 * N * N / 1e6, fwd_us=fwd * 1e3, fwd_steps_per_s=1e3 / fwd,
-                          fwd_GBps=4.0 * N * N / fwd / 1e6, bwd_us=bwd * 1e3, bwd_GBps=4.0 * N * N / bwd / 1e6)), flush=True)
-    del pop, tv, tr, ut, g, keep
+            del keep
+            t = a.elapsed_time(b) / Tb
+            best = t if best is None else min(best, t)
+        return best
+
+    bwd = bwd_time(True)
+    strip = bwd_time(False) if N <= _abi.RP_BWD_TRANSPOSE_MAX_N else bwd
+    print(json.dumps(dict(N=N, W_MB=round(4.0 * N * N / 1e6, 1), fwd_us=round(fwd * 1e3, 2),
+                          fwd_GBps=round(4.0 * N * N / fwd / 1e6, 1), bwd_us=round(bwd * 1e3, 2),
+                          bwd_GBps=round(4.0 * N * N / bwd / 1e6, 1), bwd_strip_us=round(strip * 1e3, 2))), flush=True)
+    del pop, tv, tr, ut, g
     torch.cuda.empty_cache()

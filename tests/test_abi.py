@@ -72,4 +72,19 @@ def test_no_oracle_import_in_product():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports the oracle"
-                assert "rnn_oracle" not in text or f in ("rnn_forward.hip", "rnn_backward.hip", "outer_gemm.hip"), f
+                assert "rnn_oracle" not in text or f in ("rnn_forward.hip", "rnn_backward.hip", "outer_gemm.hip", "rp_dot.h"), f
+
+
+def test_python_constants_match_header():
+    """Every `#define RP_* <int>` of include/rectipy_hip.h that _abi.py mirrors carries the same value."""
+    import re
+
+    from rectipy_amd import _abi
+    text = open(os.path.join(ROOT, "include", "rectipy_hip.h")).read()
+    checked = 0
+    for name, val in re.findall(r"^#define\s+(RP_[A-Z0-9_]+)\s+\(?(-?\d+)\)?\s*(?:/\*.*)?$", text, flags=re.M):
+        if hasattr(_abi, name):
+            assert getattr(_abi, name) == int(val), name
+            checked += 1
+    assert checked >= 30
+    assert _abi.RP_BWD_TRANSPOSE_MAX_N == 4096

@@ -132,8 +132,10 @@ def test_sharded_rows_match_unsharded(hip_device):
 @pytest.mark.parametrize("N,T", [(48, 20), (256, 16), (1000, 12), (1028, 9)])
 @pytest.mark.parametrize("model,grad_var", [("li_tanh", _abi.RP_OUT_STATE0), ("li_tanh", _abi.RP_OUT_SOURCE),
                                             ("li_sigmoid", _abi.RP_OUT_SOURCE)])
-def test_rate_backward_bit_exact(oracle_backend, hip_device, N, T, model, grad_var):
-    """Adjoint sweep (column-strip W^T u, finalize, parameter gradients): HIP == oracle, bit for bit."""
+@pytest.mark.parametrize("transposed", [False, True])
+def test_rate_backward_bit_exact(oracle_backend, hip_device, N, T, model, grad_var, transposed):
+    """Adjoint sweep, both layouts -- column-strip W^T u + finalize (large n) and the fused row-dot launch on the
+    transposed copy (rp_bwd.wt, small n) -- with parameter gradients: HIP == oracle, bit for bit."""
     W, params, v0 = make_li(N, seed=N + 7, model=model)
     gen = torch.Generator().manual_seed(9)
     x = torch.randn(T, N, generator=gen) * 0.5
@@ -142,6 +144,7 @@ def test_rate_backward_bit_exact(oracle_backend, hip_device, N, T, model, grad_v
     res = []
     for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
         pop = Population(model, W, params, 1e-2, dev, v0=v0, backend=backend)
+        pop.transposed_adjoint = transposed
         tv, tr, ta, ut, gx = (torch.zeros(T, N, device=dev) for _ in range(5))
         pop.forward(T, x=x.to(dev), save_v=tv, save_src=tr, save_acc=ta)
         lam = lam_T.clone().to(dev)

@@ -88,7 +88,8 @@ def test_g10_fit_bptt_through_network(target):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,T", [(24, 40), (256, 30), (1000, 12)])
 @pytest.mark.parametrize("grad_var,xw", [(_abi.RP_OUT_SOURCE, "full"), (_abi.RP_OUT_STATE0, "bcast")])
-def test_qif_backward_bit_exact(oracle_backend, hip_device, N, T, grad_var, xw):
+@pytest.mark.parametrize("transposed", [False, True])
+def test_qif_backward_bit_exact(oracle_backend, hip_device, N, T, grad_var, xw, transposed):
     gen = torch.Generator().manual_seed(N + T)
     W = torch.rand(N, N, generator=gen) * 20.0 / N
     params = dict(tau=torch.rand(N, generator=gen) * 0.4 + 0.8, k=torch.rand(N, generator=gen) * 0.4 + 0.8,
@@ -101,6 +102,7 @@ def test_qif_backward_bit_exact(oracle_backend, hip_device, N, T, grad_var, xw):
     res = []
     for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
         pop = Population("qif", W, params, 1e-3, dev, v0=v0, s0=s0, theta=100.0, v_reset=-100.0, backend=backend)
+        pop.transposed_adjoint = transposed
         tv, ts, ta, ut, gx = (torch.zeros(T, N, device=dev) for _ in range(5))
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
         ev = torch.zeros(N * T, 2, dtype=torch.int32, device=dev)

@@ -74,7 +74,8 @@ def test_gradients_match_reference_autograd(target, case):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("model", ["lif", "qif_sfa", "ik"])
-def test_spiking_backward_bit_exact(oracle_backend, hip_device, model):
+@pytest.mark.parametrize("transposed", [False, True])
+def test_spiking_backward_bit_exact(oracle_backend, hip_device, model, transposed):
     N, T = 256, 30
     gen = torch.Generator().manual_seed(31)
     W = torch.rand(N, N, generator=gen) * 10.0 / N
@@ -101,6 +102,7 @@ def test_spiking_backward_bit_exact(oracle_backend, hip_device, model):
     res = []
     for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
         pop = Population(model, W, params, dt, dev, backend=backend, **kw)
+        pop.transposed_adjoint = transposed
         tv, ts, ta, tx, ut, gx = (torch.zeros(T, N, device=dev) for _ in range(6))
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
         ev = torch.zeros(N * T, 2, dtype=torch.int32, device=dev)
