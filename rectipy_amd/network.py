@@ -505,12 +505,15 @@ class Network:
         return obs
 
     @staticmethod
-    def _bptt_step(predictions, targets, optimizer, loss, error_kwargs, step_kwargs) -> float:
+    def _bptt_step(predictions, targets, optimizer, loss, error_kwargs, step_kwargs, lazy: bool = False):
+        """One optimisation step (reference network.py:1123-1130).  ``lazy``: return the loss as a 0-dim device tensor
+        instead of a float, so that the window loop does not synchronise with the GPU once per window (the Observer
+        converts on read)."""
         error = loss(predictions, targets)
         optimizer.zero_grad()
         error.backward(**error_kwargs)
         optimizer.step(**step_kwargs)
-        return error.item()
+        return error.detach() if lazy else error.item()
 
     def _bptt(self, inp, target, loss, optimizer, obs: Observer, error_kwargs, step_kwargs, sampling_steps,
               optim_steps, verbose) -> Observer:
@@ -533,7 +536,8 @@ class Network:
                 preds = self._apply_chain(post, traj, label, None) if post else traj
                 prev_error = error
                 if b - a == optim_steps:  # only complete windows trigger an update (network.py:1035)
-                    error = self._bptt_step(preds, target[a:b], optimizer, loss, error_kwargs, step_kwargs)
+                    error = self._bptt_step(preds, target[a:b], optimizer, loss, error_kwargs, step_kwargs,
+                                            lazy=not verbose)
                     self.detach()
             sample_at = [t for t in range(a, b) if t % sampling_steps == 0]
             if sample_at:

@@ -73,6 +73,8 @@ class Observer:
         self._additional_storage[key] = val
 
     def to_numpy(self, item: Union[str, Tuple[str, str]]) -> np.ndarray:
+        if item == "loss" and item in self._chunks:
+            return np.asarray(self._flat("loss"), dtype=np.float64)
         if item in self._chunks:
             parts = []
             for c in self._chunks[item]:
@@ -151,4 +153,10 @@ class Observer:
         out = []
         for c in self._chunks[key]:
             out.extend(c.unbind(0) if isinstance(c, torch.Tensor) else c)
+        if key == "loss":  # losses recorded lazily as 0-dim device tensors: one transfer, python floats as the reference
+            lazy = [i for i, v in enumerate(out) if isinstance(v, torch.Tensor)]
+            if lazy:
+                vals = torch.stack([out[i].detach().reshape(()) for i in lazy]).cpu().tolist()
+                for i, v in zip(lazy, vals):
+                    out[i] = v
         return out
