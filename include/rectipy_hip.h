@@ -219,6 +219,10 @@ typedef struct rp_bwd {
        The summation order of z then is the forward's row order; the oracle mirrors the same rule. */
     float* wt;                /* [n x ldwt] or NULL                                                            */
     int64_t ldwt;
+    /* population-mean models (IKU, IK_BIEXP; ik.yaml:34-68) */
+    const float* traj_aux2;   /* IK_BIEXP: [T x ld] pre-update x (rise variable of the synapse) = save_state[2] */
+    float* lam4;              /* IK_BIEXP: [n] adjoint of x (in: at T, out: at 0)                              */
+    float* means;             /* IKU / IK_BIEXP: scratch [4] for the per-step population sums                  */
 } rp_bwd;
 
 #define RP_BWD_TRANSPOSE_MAX_N 4096

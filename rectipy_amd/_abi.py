@@ -127,6 +127,9 @@ class RpBwd(C.Structure):
         ("grad_p", fp * RP_MAX_PARAMS),
         ("wt", fp),
         ("ldwt", C.c_int64),
+        ("traj_aux2", fp),
+        ("lam4", fp),
+        ("means", fp),
     ]
 
 

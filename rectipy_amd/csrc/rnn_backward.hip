@@ -81,6 +81,10 @@ struct BwdParams {
     const float* acc_t;
     float inv_dt;
     int x_target;
+    // population-mean models (IKU, IK_BIEXP)
+    float* lam_x2;           // adjoint of the synaptic rise variable (IK_BIEXP)
+    const float* aux2_prev;  // x of step t-1
+    float* means;            // [4]: mean(lx b/tau_u), mean(kappa lx) of the current adjoint; mean(v), mean(spike/dt) of step t-1
 };
 
 // partials[q][j] = sum_{i in chunk q, ascending} W[i][j] * u[i]
@@ -262,6 +266,11 @@ __global__ void finalize_kernel(const BwdParams P) {
 //   QIF_SFA  u = k a            lv' = a + dt a (2v/tau)            + (ls + alpha lx) sg     lx' = lx + dt (-lx/tau_x - a/tau)
 //   IK       u = a g (E_r-v)/C  lv' = a + dt (a dfdv + lx b/tau_u) + (ls + kappa lx) sg     lx' = lx + dt (-lx/tau_u - a/C)
 //            dfdv = (k ((v-v_r) + (v-v_theta)) - g (W s)) / C
+//   IKU      as IK with the recovery driven by population means (ik.yaml:34-40): the local terms lx b/tau_u and
+//            kappa lx become the population means  A = mean_i(lx_i b_i/tau_u_i),  B = mean_i(kappa_i lx_i):
+//            lv' = a + dt (a dfdv + A) + (ls + B) sg
+//   IK_BIEXP as IKU with s' = -s/tau_d + x, x' = -x/tau_r + spike (ik.yaml:42-68): the spike feeds x,
+//            lv' = a + dt (a dfdv + A) + (lx2 + B) sg,   lx2' = lx2 + dt (-lx2/tau_r + ls)
 //   all      ls' = ls + dt (-ls/tau_s + z)            (+ G_t on the output variable)
 
 struct SpkGrad {  // per-neuron parameter gradient targets, resolved on the host
@@ -274,7 +283,8 @@ __device__ __forceinline__ float spk_input(const BwdParams& P, const float* row,
     return 0.f;
 }
 
-__device__ __forceinline__ void spk_prep_step(const BwdParams& P, const SpkGrad& G, int j, float lv, float ls, float lx) {
+__device__ __forceinline__ void spk_prep_step(const BwdParams& P, const SpkGrad& G, int j, float lv, float ls, float lx,
+                                              float lx2) {
     const float v = P.v_prev[j];
     const float sp = (v - P.theta >= 0.0f) ? 1.0f : 0.0f;
     const float a = lv * (1.0f - sp);
@@ -283,7 +293,7 @@ __device__ __forceinline__ void spk_prep_step(const BwdParams& P, const SpkGrad&
     const float Im = P.x_target == RP_XT_MEMBRANE ? I : 0.f;
     const float spike_in = sp * P.inv_dt;
     float gx = 0.f;
-    if (P.model == RP_MODEL_IK) {
+    if (P.model >= RP_MODEL_IK) {  // IK, IKU, IK_BIEXP
         const float C = P.p[RP_P_IK_C][j], vr = P.p[RP_P_V_R][j], vt = P.p[RP_P_V_THETA][j];
         const float g = P.p[RP_P_G][j], Er = P.p[RP_P_E_R][j], b = P.p[RP_P_B][j], tu = P.p[RP_P_TAU_U][j];
         const float acc = P.acc_prev[j], uu = P.aux_prev[j];
@@ -297,9 +307,19 @@ __device__ __forceinline__ void spk_prep_step(const BwdParams& P, const SpkGrad&
             const float num = ((((P.p[RP_P_K][j] * dvr) * dvt - uu) + Im) + P.p[RP_P_ETA][j]) + (g * acc) * (Er - v);
             G.p[RP_P_IK_C][j] += -(da * (num / (C * C)));
         }
-        if (G.p[RP_P_B]) G.p[RP_P_B][j] += dlx * (dvr / tu);
-        if (G.p[RP_P_TAU_U]) G.p[RP_P_TAU_U][j] += -(dlx * ((b * dvr - uu) / (tu * tu)));
-        if (G.p[RP_P_KAPPA]) G.p[RP_P_KAPPA][j] += dlx * spike_in;
+        // recovery equation: driven by the neuron's own v and spike (IK) or by the population means of step t-1
+        const float dvu = P.model == RP_MODEL_IK ? dvr : P.means[2] - vr;
+        const float spu = P.model == RP_MODEL_IK ? spike_in : P.means[3];
+        if (G.p[RP_P_B]) G.p[RP_P_B][j] += dlx * (dvu / tu);
+        if (G.p[RP_P_TAU_U]) G.p[RP_P_TAU_U][j] += -(dlx * ((b * dvu - uu) / (tu * tu)));
+        if (G.p[RP_P_KAPPA]) G.p[RP_P_KAPPA][j] += dlx * spu;
+        if (P.model == RP_MODEL_IK_BIEXP && G.p[RP_P_TAU_R]) {
+            const float tr = P.p[RP_P_TAU_R][j];
+            G.p[RP_P_TAU_R][j] += (P.dt * lx2) * (P.aux2_prev[j] / (tr * tr));
+        }
+        if (G.p[RP_P_V_R]) G.p[RP_P_V_R][j] += -(da * ((P.p[RP_P_K][j] * dvt) / C)) - dlx * (b / tu);
+        if (G.p[RP_P_V_THETA]) G.p[RP_P_V_THETA][j] += -(da * ((P.p[RP_P_K][j] * dvr) / C));
+        if (G.p[RP_P_E_R]) G.p[RP_P_E_R][j] += da * ((g * acc) / C);
         gx = da / C;
     } else {
         const float tau = P.p[RP_P_TAU][j];
@@ -332,15 +352,49 @@ __device__ __forceinline__ void spk_prep_step(const BwdParams& P, const SpkGrad&
     if (P.gx_prev) P.gx_prev[j] = gx;
 }
 
+// Population sums of one adjoint step of the mean-coupled models, one block: the adjoint means A, B over the CURRENT
+// lx (they enter lv of step t) and the forward means of v and spike/dt of step t-1 (they enter the parameter gradients
+// the prep step pairs with that step).  1024 strided partial sums + halving tree, as mean_kernel of the forward pass.
+__global__ __launch_bounds__(1024) void adj_mean_kernel(const BwdParams P) {
+    __shared__ float red[4][1024];
+    const int tid = threadIdx.x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int j = tid; j < P.n; j += 1024) {
+        const float lx = P.lam_x[j];
+        s0 = s0 + lx * (P.p[RP_P_B][j] / P.p[RP_P_TAU_U][j]);
+        s1 = s1 + P.p[RP_P_KAPPA][j] * lx;
+        if (P.u_next) {  // a step t-1 exists
+            const float v = P.v_prev[j];
+            s2 = s2 + v;
+            s3 = s3 + ((v - P.theta >= 0.0f) ? 1.0f : 0.0f) * P.inv_dt;
+        }
+    }
+    red[0][tid] = s0;
+    red[1][tid] = s1;
+    red[2][tid] = s2;
+    red[3][tid] = s3;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if (tid < off) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[q][tid] = red[q][tid] + red[q][tid + off];
+        }
+        __syncthreads();
+    }
+    if (tid < 4) P.means[tid] = red[tid][0] / (float)P.n;
+}
+
 __global__ void spk_prep_kernel(const BwdParams P, const SpkGrad G) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < P.n) spk_prep_step(P, G, j, P.lam[j], P.lam_s[j], P.lam_x ? P.lam_x[j] : 0.f);
+    if (j < P.n)
+        spk_prep_step(P, G, j, P.lam[j], P.lam_s[j], P.lam_x ? P.lam_x[j] : 0.f, P.lam_x2 ? P.lam_x2[j] : 0.f);
 }
 
 __device__ __forceinline__ void spk_finalize_elem(const BwdParams& P, const SpkGrad& G, int j, float z) {
     const float lv = P.lam[j];
     const float ls = P.lam_s[j];
     const float lx = P.lam_x ? P.lam_x[j] : 0.f;
+    const float lx2 = P.lam_x2 ? P.lam_x2[j] : 0.f;
     const float v = P.v_t[j];
     const float x = v - P.theta;
     const float reset = (x >= 0.0f) ? 1.0f : 0.0f;
@@ -350,7 +404,7 @@ __device__ __forceinline__ void spk_finalize_elem(const BwdParams& P, const SpkG
     const float g = P.g_t ? P.g_t[j] : 0.f;
     const float gv = (P.grad_var == RP_OUT_STATE0) ? g : 0.f;
     const float gs = (P.grad_var == RP_OUT_STATE0) ? 0.f : g;
-    float lv_new, lx_new = 0.f;
+    float lv_new, lx_new = 0.f, lx2_new = 0.f;
     if (P.model == RP_MODEL_QIF) {
         lv_new = ((a + P.dt * (a * ((2.0f * v) / P.p[RP_P_TAU][j]))) + ls * sg) + gv;
     } else if (P.model == RP_MODEL_LIF) {
@@ -359,18 +413,25 @@ __device__ __forceinline__ void spk_finalize_elem(const BwdParams& P, const SpkG
         const float tau = P.p[RP_P_TAU][j];
         lv_new = ((a + P.dt * (a * ((2.0f * v) / tau))) + (ls + P.p[RP_P_ALPHA][j] * lx) * sg) + gv;
         lx_new = lx + P.dt * (-lx / P.p[RP_P_TAU_X][j] - a / tau);
-    } else {  // IK
+    } else {  // IK family
         const float C = P.p[RP_P_IK_C][j], tu = P.p[RP_P_TAU_U][j];
         const float dfdv = (P.p[RP_P_K][j] * ((v - P.p[RP_P_V_R][j]) + (v - P.p[RP_P_V_THETA][j])) -
                             P.p[RP_P_G][j] * P.acc_t[j]) / C;
-        lv_new = ((a + P.dt * (a * dfdv + lx * (P.p[RP_P_B][j] / tu))) + (ls + P.p[RP_P_KAPPA][j] * lx) * sg) + gv;
+        if (P.model == RP_MODEL_IK) {
+            lv_new = ((a + P.dt * (a * dfdv + lx * (P.p[RP_P_B][j] / tu))) + (ls + P.p[RP_P_KAPPA][j] * lx) * sg) + gv;
+        } else {  // the recovery variables of ALL neurons see this neuron's v and spike through the means
+            const float into_spike = P.model == RP_MODEL_IK_BIEXP ? lx2 : ls;
+            lv_new = ((a + P.dt * (a * dfdv + P.means[0])) + (into_spike + P.means[1]) * sg) + gv;
+            if (P.model == RP_MODEL_IK_BIEXP) lx2_new = lx2 + P.dt * (-lx2 / P.p[RP_P_TAU_R][j] + ls);
+        }
         lx_new = lx + P.dt * (-lx / tu - a / C);
     }
     const float ls_new = (ls + P.dt * (-ls / P.p[RP_P_TAU_S][j] + z)) + gs;
     P.lam[j] = lv_new;
     P.lam_s[j] = ls_new;
     if (P.lam_x) P.lam_x[j] = lx_new;
-    if (P.u_next) spk_prep_step(P, G, j, lv_new, ls_new, lx_new);
+    if (P.lam_x2) P.lam_x2[j] = lx2_new;
+    if (P.u_next) spk_prep_step(P, G, j, lv_new, ls_new, lx_new, lx2_new);
 }
 
 __global__ void spk_finalize_kernel(const BwdParams P, const SpkGrad G) {
@@ -693,9 +754,11 @@ int rp_set_bwd_tuning(int unroll, int strip_groups) {
 int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     if (!net || !b) RP_FAIL(RP_ERR_ARG, "net/bwd is null");
     const int model = net->model;
-    if (model != RP_MODEL_QIF && model != RP_MODEL_QIF_SFA && model != RP_MODEL_LIF && model != RP_MODEL_IK)
+    if (model < RP_MODEL_QIF || model > RP_MODEL_IK_BIEXP)
         RP_FAIL(RP_ERR_ARG, "rp_qif_backward needs a spiking model (model=%d)", model);
-    const bool has_aux = model == RP_MODEL_QIF_SFA || model == RP_MODEL_IK;
+    const bool ik_family = model >= RP_MODEL_IK;
+    const bool mean_coupled = model == RP_MODEL_IKU || model == RP_MODEL_IK_BIEXP;
+    const bool has_aux = model == RP_MODEL_QIF_SFA || ik_family;
     if (net->rows != net->n || net->row0 != 0)
         RP_FAIL(RP_ERR_ARG, "rp_qif_backward needs the unsharded matrix (rows=%d n=%d)", net->rows, net->n);
     if (net->n <= 0 || net->ldw < net->n) RP_FAIL(RP_ERR_SHAPE, "bad n/ldw");
@@ -703,7 +766,10 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     if (!net->W || !b->traj_v || !b->traj_r || !b->lam || !b->lam2 || !b->u_traj || !b->partials)
         RP_FAIL(RP_ERR_ARG, "W, traj_v, traj_r (s_t), lam, lam2, u_traj, partials must be non-null");
     if (has_aux && (!b->traj_aux || !b->lam3)) RP_FAIL(RP_ERR_ARG, "model %d needs traj_aux and lam3", model);
-    if (model == RP_MODEL_IK && !b->traj_acc) RP_FAIL(RP_ERR_ARG, "the IK adjoint needs traj_acc (W s_t)");
+    if (ik_family && !b->traj_acc) RP_FAIL(RP_ERR_ARG, "the IK adjoint needs traj_acc (W s_t)");
+    if (mean_coupled && !b->means) RP_FAIL(RP_ERR_ARG, "model %d needs the means scratch (4 floats)", model);
+    if (model == RP_MODEL_IK_BIEXP && (!b->traj_aux2 || !b->lam4))
+        RP_FAIL(RP_ERR_ARG, "IK_BIEXP needs traj_aux2 and lam4");
     if (b->ld < net->n) RP_FAIL(RP_ERR_SHAPE, "ld < n");
     if (b->grad_out && b->ldg < net->n) RP_FAIL(RP_ERR_SHAPE, "ldg < n");
     if (b->grad_x && b->ldgx < net->n) RP_FAIL(RP_ERR_SHAPE, "ldgx < n");
@@ -718,15 +784,17 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     // parameter-gradient targets by slot; the named fields of rp_bwd cover the common four
     SpkGrad G = {};
     for (int q = 0; q < RP_MAX_PARAMS; ++q) G.p[q] = b->grad_p[q];
-    if (model != RP_MODEL_IK && b->grad_tau) G.p[RP_P_TAU] = b->grad_tau;
+    if (!ik_family && b->grad_tau) G.p[RP_P_TAU] = b->grad_tau;
     if (b->grad_k) G.p[RP_P_K] = b->grad_k;
     if (b->grad_eta) G.p[RP_P_ETA] = b->grad_eta;
     if (b->grad_tau_s) G.p[RP_P_TAU_S] = b->grad_tau_s;
     {
         bool ok[RP_MAX_PARAMS] = {};
         ok[RP_P_K] = ok[RP_P_ETA] = ok[RP_P_TAU_S] = true;
-        if (model == RP_MODEL_IK) {
+        if (ik_family) {
             ok[RP_P_IK_C] = ok[RP_P_G] = ok[RP_P_B] = ok[RP_P_TAU_U] = ok[RP_P_KAPPA] = true;
+            ok[RP_P_V_R] = ok[RP_P_V_THETA] = ok[RP_P_E_R] = true;
+            ok[RP_P_TAU_R] = model == RP_MODEL_IK_BIEXP;
         } else {
             ok[RP_P_TAU] = true;
             if (model == RP_MODEL_QIF_SFA) ok[RP_P_ALPHA] = ok[RP_P_TAU_X] = true;
@@ -735,7 +803,7 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
             if (G.p[q] && !ok[q]) RP_FAIL(RP_ERR_ARG, "no gradient kernel for parameter slot %d of model %d", q, model);
     }
     if (G.p[RP_P_K] && !b->traj_acc) RP_FAIL(RP_ERR_ARG, "grad_k needs traj_acc");
-    if (model == RP_MODEL_IK && G.p[RP_P_G] && !b->traj_acc) RP_FAIL(RP_ERR_ARG, "grad_g needs traj_acc");
+
     const bool vec4 = (net->n % 4 == 0) && (net->ldw % 4 == 0);
     if (vec4 && ((reinterpret_cast<uintptr_t>(net->W) & 15u) || (reinterpret_cast<uintptr_t>(b->partials) & 15u)))
         RP_FAIL(RP_ERR_ARG, "W and partials must be 16-byte aligned");
@@ -765,6 +833,8 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     P.lam = b->lam;
     P.lam_s = b->lam2;
     P.lam_x = has_aux ? b->lam3 : nullptr;
+    P.lam_x2 = model == RP_MODEL_IK_BIEXP ? b->lam4 : nullptr;
+    P.means = b->means;
     P.slope = b->slope;
     P.theta = net->theta;
     P.x_mode = b->x_mode;
@@ -777,6 +847,7 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
         P.v_prev = b->traj_v + (int64_t)tp * b->ld;
         P.s_prev = b->traj_r + (int64_t)tp * b->ld;
         P.aux_prev = b->traj_aux ? b->traj_aux + (int64_t)tp * b->ld : nullptr;
+        P.aux2_prev = b->traj_aux2 ? b->traj_aux2 + (int64_t)tp * b->ld : nullptr;
         P.acc_prev = b->traj_acc ? b->traj_acc + (int64_t)tp * b->ld : nullptr;
         P.gx_prev = b->grad_x ? b->grad_x + (int64_t)tp * b->ldgx : nullptr;
         P.x_prev = b->x ? b->x + (int64_t)tp * b->ldx : nullptr;
@@ -784,6 +855,7 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
 
     if (use_wt) launch_transpose(net, b, st);
     set_prep(T - 1);
+    if (mean_coupled) hipLaunchKernelGGL(adj_mean_kernel, dim3(1), dim3(1024), 0, st, P);
     hipLaunchKernelGGL(spk_prep_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
     for (int t = T - 1; t >= 0; --t) {
         P.t = t;
@@ -796,6 +868,7 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
             set_prep(t - 1);
         else
             P.u_next = nullptr;
+        if (mean_coupled) hipLaunchKernelGGL(adj_mean_kernel, dim3(1), dim3(1024), 0, st, P);
         if (use_wt)
             launch_adj_rowdot<true>(P, G, vec4_t, st);
         else

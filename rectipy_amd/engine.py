@@ -376,7 +376,8 @@ class Population:
     def backward(self, traj_v, traj_r, grad_out, grad_var, lam, u_traj, traj_acc=None,
                  grad_tau=None, grad_k=None, grad_eta=None, grad_x=None, lam_s=None, grad_tau_s=None,
                  slope: float = 0.5, x: Optional[torch.Tensor] = None, x_target: int = _abi.RP_XT_MEMBRANE,
-                 traj_aux=None, lam_x=None, grad_params: Optional[Dict[str, torch.Tensor]] = None):
+                 traj_aux=None, lam_x=None, grad_params: Optional[Dict[str, torch.Tensor]] = None,
+                 traj_aux2=None, lam_x2=None):
         """Adjoint sweep over a stored window (rp_rate_backward; rp_qif_backward for the spiking model, which
         additionally takes the adjoint of s, the surrogate slope and the window's input for grad_tau)."""
         T = int(traj_v.shape[0])
@@ -404,7 +405,11 @@ class Population:
             self.backend.rate_backward(self._net(), b, self.device)
             return partials  # returned so the caller keeps it alive until the stream has consumed it
         if self.model in NEEDS_MEANS:
-            raise NotImplementedError(f"no adjoint kernel for the '{self.model}' model (population-mean coupling)")
+            if self.rows != self.n:
+                raise NotImplementedError(f"the '{self.model}' model (population-mean coupling) cannot be row-sharded")
+            means = torch.zeros(4, dtype=torch.float32, device=self.device)
+            b.means = means.data_ptr()
+            b.traj_aux2, b.lam4 = _ptr(traj_aux2), _ptr(lam_x2)
         b.lam2 = lam_s.data_ptr()
         b.grad_tau_s = _ptr(grad_tau_s)
         b.slope = float(slope)
@@ -421,7 +426,7 @@ class Population:
             b.x_mode = _abi.RP_X_FULL if x.shape[1] == self.n and self.n != 1 else _abi.RP_X_BCAST
             b.x, b.ldx = x.data_ptr(), x.shape[1]
         self.backend.qif_backward(self._net(), b, self.device)
-        return partials, x
+        return partials, x, (means if self.model in NEEDS_MEANS else None)
 
     def outer_accum(self, alpha: float, A: torch.Tensor, B: torch.Tensor, Cmat: torch.Tensor):
         """Cmat += alpha * A^T @ B on the matrix cores (A, B: [T, n])."""

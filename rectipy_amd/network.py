@@ -384,9 +384,9 @@ class Network:
                 traj = rnn._grad_window(b - a, self._fit_width(X, N))
                 outs.append(self._apply_chain(post, traj, label, None) if post else traj)
                 if slots:
-                    tv, tr, ta = (tuple(rnn._last_window) + (None,))[:3]
+                    window = tuple(rnn._last_window) + (None, None)  # (v, source, aux, aux2) of the window
                     for j, slot in enumerate(slots):
-                        src = (tv, tr, ta)[slot]
+                        src = window[slot]
                         if spiking:  # SpikeResetNet exposes the pre-update state (nodes.py:387-392)
                             recs[j].append(src)
                         else:  # post-update values: row t+1, last row = current state

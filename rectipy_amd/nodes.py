@@ -541,8 +541,8 @@ class SpikeResetNet(RateNet):
         params = [pop.params[n] for n in TRAINABLE[pop.model]]
         traj, y_end = SpikeWindow.apply(self, steps, x, y_in, pop.W, *params)
         self._y_grad = y_end
-        tv, ts, ta = self._last_window
-        self._y_prev = self._pack(tv[-1], ts[-1], None if ta is None else ta[-1])
+        tv, ts, ta, tb = self._last_window
+        self._y_prev = self._pack(tv[-1], ts[-1], None if ta is None else ta[-1], None if tb is None else tb[-1])
         return traj
 
     def forward(self, x) -> torch.Tensor:

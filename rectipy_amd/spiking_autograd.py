@@ -12,7 +12,9 @@ TRAINABLE = {
     "qif": ("tau", "k", "eta", "tau_s"),
     "lif": ("tau", "k", "eta", "tau_s"),
     "qif_sfa": ("tau", "k", "eta", "tau_s", "alpha", "tau_x"),
-    "ik": ("C", "k", "eta", "tau_s", "g", "b", "tau_u", "kappa"),
+    "ik": ("C", "k", "eta", "tau_s", "g", "b", "tau_u", "kappa", "v_r", "v_theta", "E_r"),
+    "iku": ("C", "k", "eta", "tau_s", "g", "b", "tau_u", "kappa", "v_r", "v_theta", "E_r"),
+    "ik_biexp": ("C", "k", "eta", "tau_d", "g", "b", "tau_u", "kappa", "v_r", "v_theta", "E_r", "tau_r"),
 }
 
 
@@ -25,26 +27,28 @@ class SpikeWindow(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         names = TRAINABLE[pop.model]
         req = {n: p.requires_grad for n, p in zip(names, params)}
-        need_acc = pop.model == "ik" or req.get("k", False)
+        need_acc = pop.model in ("ik", "iku", "ik_biexp") or req.get("k", False)
         traj_v = torch.empty(steps, N, **f32)
         traj_s = torch.empty(steps, N, **f32)
         traj_aux = torch.empty(steps, N, **f32) if pop.aux is not None else None
+        traj_aux2 = torch.empty(steps, N, **f32) if pop.aux2 is not None else None
         traj_acc = torch.empty(steps, N, **f32) if need_acc else None
-        pop.forward(steps, x=x, save_v=traj_v, save_src=traj_s, save_aux=traj_aux, save_acc=traj_acc,
-                    x_target=node._x_target, spike_events=node.spike_events, spike_count=node._spike_count)
+        pop.forward(steps, x=x, save_v=traj_v, save_src=traj_s, save_aux=traj_aux, save_aux2=traj_aux2,
+                    save_acc=traj_acc, x_target=node._x_target, spike_events=node.spike_events,
+                    spike_count=node._spike_count)
         ctx.node, ctx.steps, ctx.names = node, steps, names
         ctx.x = None if x is None else x.detach()
-        ctx.saved = (traj_v, traj_s, traj_aux, traj_acc)
-        node._last_window = (traj_v, traj_s, traj_aux)
+        ctx.saved = (traj_v, traj_s, traj_aux, traj_acc, traj_aux2)
+        node._last_window = (traj_v, traj_s, traj_aux, traj_aux2)
         out = traj_s if node._out_code == _abi.RP_OUT_SOURCE else traj_v
-        return out.clone(), node._pack(pop.v, pop.source_local, pop.aux)
+        return out.clone(), node._pack(pop.v, pop.source_local, pop.aux, pop.aux2)
 
     @staticmethod
     def backward(ctx, g_traj, g_yend):
         node = ctx.node
         pop = node._pop
         N, dev, T = pop.rows, pop.device, ctx.steps
-        traj_v, traj_s, traj_aux, traj_acc = ctx.saved
+        traj_v, traj_s, traj_aux, traj_acc, traj_aux2 = ctx.saved
         f32 = dict(dtype=torch.float32, device=dev)
         tpl = node._template
 
@@ -56,6 +60,7 @@ class SpikeWindow(torch.autograd.Function):
 
         lam_v, lam_s = piece(tpl.reset_var), piece(tpl.source_var)
         lam_x = piece(node._aux_name) if node._aux_name else None
+        lam_x2 = piece(node._aux2_name) if node._aux2_name else None
         g_out = None if g_traj is None else g_traj.detach().to(**f32).contiguous()
         need = ctx.needs_input_grad  # (node, steps, x, y_in, W, *params)
         grads = {name: torch.zeros(N, **f32) for i, name in enumerate(ctx.names) if need[5 + i]}
@@ -63,7 +68,7 @@ class SpikeWindow(torch.autograd.Function):
         g_x = torch.empty(T, N, **f32) if need[2] else None
         keep = pop.backward(traj_v, traj_s, g_out, node._out_code, lam_v, u_traj, traj_acc=traj_acc, grad_x=g_x,
                             lam_s=lam_s, slope=node._spike_slope, x=ctx.x, x_target=node._x_target,
-                            traj_aux=traj_aux, lam_x=lam_x, grad_params=grads)
+                            traj_aux=traj_aux, lam_x=lam_x, grad_params=grads, traj_aux2=traj_aux2, lam_x2=lam_x2)
         g_W = None
         if need[4]:
             g_W = torch.zeros(N, N, **f32)
@@ -71,5 +76,5 @@ class SpikeWindow(torch.autograd.Function):
         if g_x is not None and ctx.x is not None and ctx.x.shape[1] == 1:
             g_x = g_x.sum(dim=1, keepdim=True)
         del keep
-        g_y = node._pack(lam_v, lam_s, lam_x) if need[3] else None
+        g_y = node._pack(lam_v, lam_s, lam_x, lam_x2) if need[3] else None
         return (None, None, g_x, g_y, g_W) + tuple(grads.get(name) for name in ctx.names)

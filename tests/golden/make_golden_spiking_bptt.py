@@ -65,13 +65,13 @@ def main():
     n, T, dt = 24, 200, 1e-1
     r = np.random.default_rng(171)
     W = r.uniform(0, 1, (n, n)) * 15.0 / n
-    P = dict(C=r.uniform(90, 110, n), k=r.uniform(0.6, 0.8, n), v_r=np.full(n, -60.0), v_theta=np.full(n, -40.0),
+    P = dict(C=r.uniform(90, 110, n), k=r.uniform(0.6, 0.8, n), v_r=np.full(n, -60.0), v_theta=np.full(n, -40.0),  # noqa
              eta=r.standard_normal(n) * 5.0, g=r.uniform(0.8, 1.2, n), E_r=np.zeros(n), b=r.uniform(-2.5, -1.5, n),
              tau_u=r.uniform(30, 36, n), kappa=r.uniform(8, 12, n), tau_s=r.uniform(5, 7, n))
     order = ("C", "k", "v_r", "v_theta", "eta", "g", "E_r", "b", "tau_u", "kappa", "tau_s")
     y0 = np.concatenate([r.uniform(-60.0, 35.0, n), r.uniform(0, 20, n), r.uniform(0, 0.5, n)])
     x = 120.0 + 5.0 * r.standard_normal((T, n))
-    # the field signature orders the parameters as `order`; train only those with a gradient kernel
+    # the field signature orders the parameters as `order`; every one of them is trained
     Network_, SpikeResetNet_ = Network, SpikeResetNet
 
     out = {}
@@ -81,7 +81,7 @@ def main():
         pm = {"in": 0, "spike_var": 1, "weights": 2}
         pm.update({q: 3 + i for i, q in enumerate(order)})
         vm = {"out": (2 * n, 3 * n), "reset_var": (0, n)}
-        train = ["weights", "C", "k", "eta", "g", "b", "tau_u", "kappa", "tau_s"]
+        train = ["weights"] + list(order)
         node = SpikeResetNet_(field_ik(n), args, vm, pm, spike_threshold=40.0, spike_reset=-55.0, dt=dt, dtype=dtype,
                               device="cpu", train_params=train)
         net = Network_(dt, dtype=dtype)

@@ -21,7 +21,7 @@ CASES = {
                     train=("tau", "k", "eta", "tau_s", "alpha", "tau_x")),
     "ik": dict(gold="g17_ik_bptt", template="ik.ik", op="ik_op", states=("v", "u", "s"),
                params=("C", "k", "v_r", "v_theta", "eta", "g", "E_r", "b", "tau_u", "kappa", "tau_s"),
-               train=("C", "k", "eta", "g", "b", "tau_u", "kappa", "tau_s")),
+               train=("C", "k", "eta", "g", "b", "tau_u", "kappa", "tau_s", "v_r", "v_theta", "E_r")),
 }
 
 
@@ -73,7 +73,7 @@ def test_gradients_match_reference_autograd(target, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["lif", "qif_sfa", "ik"])
+@pytest.mark.parametrize("model", ["lif", "qif_sfa", "ik", "iku", "ik_biexp"])
 @pytest.mark.parametrize("transposed", [False, True])
 def test_spiking_backward_bit_exact(oracle_backend, hip_device, model, transposed):
     N, T = 256, 30
@@ -96,30 +96,80 @@ def test_spiking_backward_bit_exact(oracle_backend, hip_device, model, transpose
                       b=rnd(-2.5, -1.5), tau_u=rnd(30, 36), kappa=rnd(8, 12), tau_s=rnd(5, 7))
         kw = dict(v0=rnd(-60, 38), s0=rnd(0, 0.5), aux0=rnd(0, 20), theta=40.0, v_reset=-55.0)
         dt, x, xt = 1e-1, 120.0 + 5 * torch.randn(T, N, generator=gen), _abi.RP_XT_MEMBRANE
-        names = ("C", "k", "eta", "tau_s", "g", "b", "tau_u", "kappa")
+        names = ("C", "k", "eta", "tau_s", "g", "b", "tau_u", "kappa", "v_r", "v_theta", "E_r")
+        if model == "ik_biexp":  # bi-exponential synapse: tau_s -> (tau_r, tau_d), extra state x
+            params["tau_d"], params["tau_r"] = params.pop("tau_s"), rnd(1.5, 2.5)
+            kw["aux2_0"] = rnd(0, 0.2)
+            names = tuple(q for q in names if q != "tau_s") + ("tau_d", "tau_r")
     g_out = torch.randn(T, N, generator=gen) * 0.1
-    l0 = [torch.randn(N, generator=gen) * 0.01 for _ in range(3)]
+    l0 = [torch.randn(N, generator=gen) * 0.01 for _ in range(4)]
     res = []
     for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
         pop = Population(model, W, params, dt, dev, backend=backend, **kw)
         pop.transposed_adjoint = transposed
-        tv, ts, ta, tx, ut, gx = (torch.zeros(T, N, device=dev) for _ in range(6))
+        tv, ts, ta, tx, ut, gx, tx2 = (torch.zeros(T, N, device=dev) for _ in range(7))
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
         ev = torch.zeros(N * T, 2, dtype=torch.int32, device=dev)
         pop.forward(T, x=x.to(dev), save_v=tv, save_src=ts, save_acc=ta, save_aux=tx if pop.aux is not None else None,
-                    spike_events=ev, spike_count=cnt, x_target=xt)
-        lv, ls, lx = (t.clone().to(dev) for t in l0)
+                    save_aux2=tx2 if pop.aux2 is not None else None, spike_events=ev, spike_count=cnt, x_target=xt)
+        lv, ls, lx, lx2 = (t.clone().to(dev) for t in l0)
         grads = {q: torch.zeros(N, device=dev) for q in names}
         keep = pop.backward(tv, ts, g_out.to(dev), _abi.RP_OUT_SOURCE, lv, ut, traj_acc=ta, grad_x=gx, lam_s=ls, slope=0.7,
                             x=x.to(dev), x_target=xt, traj_aux=tx if pop.aux is not None else None,
-                            lam_x=lx if pop.aux is not None else None, grad_params=grads)
+                            lam_x=lx if pop.aux is not None else None, grad_params=grads,
+                            traj_aux2=tx2 if pop.aux2 is not None else None, lam_x2=lx2 if pop.aux2 is not None else None)
         if dev != "cpu":
             torch.cuda.synchronize()
-        res.append(([lv, ls, lx, ut, gx] + [grads[q] for q in names], int(cnt.item())))
+        res.append(([lv, ls, lx, lx2, ut, gx] + [grads[q] for q in names], int(cnt.item())))
         del keep
     assert res[0][1] == res[1][1] and res[0][1] > 0
-    labels = ["lambda_v", "lambda_s", "lambda_aux", "u_traj", "grad_x"] + list(names)
+    labels = ["lambda_v", "lambda_s", "lambda_aux", "lambda_aux2", "u_traj", "grad_x"] + list(names)
     for a, b, name in zip(res[0][0], res[1][0], labels):
         a, b = a.cpu().numpy(), b.cpu().numpy()
         same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
         assert same.all(), f"{model} {name}: {np.count_nonzero(~same)} of {a.size} differ (max abs {np.abs(a - b).max()})"
+
+
+MEAN_CASES = {
+    "iku": dict(gold="g20_iku_bptt", template="ik.iku", op="iku_op", states=("v", "u", "s"),
+                params=("C", "k", "v_r", "v_theta", "eta", "g", "E_r", "b", "tau_u", "kappa", "tau_s")),
+    "ik_biexp": dict(gold="g21_ik_biexp_bptt", template="ik.ik_biexp", op="ik_biexp_op", states=("v", "u", "s", "x"),
+                     params=("C", "k", "v_r", "v_theta", "eta", "g", "E_r", "b", "tau_u", "kappa", "tau_r", "tau_d")),
+}
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("case", list(MEAN_CASES))
+def test_mean_coupled_gradients_match_reference_autograd(target, case):
+    """BPTT through the population-mean fields (iku_op, ik_biexp_op): every parameter gradient of one fit_bptt window
+    against the reference's float64 autograd (golden G20, G21)."""
+    c = MEAN_CASES[case]
+    g = dict(np.load(os.path.join(GOLD, c["gold"] + ".npz")))
+    n, op, dev = g["W"].shape[0], c["op"], target["device"]
+    node_vars = {f"all/{op}/{q}": g[q] for q in c["params"]}
+    for i, st in enumerate(c["states"]):
+        node_vars[f"all/{op}/{st}"] = g["y0"][i * n:(i + 1) * n]
+    node = SpikeResetNet.from_pyrates(
+        BASE + c["template"], input_var=f"{op}/I_ext", output_var=f"{op}/s", weights=g["W"], source_var=f"{op}/s",
+        target_var=f"{op}/s_in", spike_var=f"{op}/spike", reset_var=f"{op}/v", node_vars=node_vars,
+        spike_threshold=float(g["theta"]), spike_reset=float(g["v_reset"]), dt=float(g["dt"]), dtype=torch.float32,
+        train_params=["weights"] + [f"{op}/{q}" for q in c["params"]], **target)
+    node.enable_spike_recording(8192)
+    W_out = torch.tensor(g["W_out"], dtype=torch.float32, device=dev, requires_grad=True)
+    x = torch.tensor(g["x"], dtype=torch.float32, device=dev)
+    tgt = torch.tensor(g["target"], dtype=torch.float32, device=dev)
+    traj = node._grad_window(x.shape[0], x)
+    assert len(node.spikes()) >= 10, "the window must contain spikes"
+    loss = torch.nn.functional.mse_loss(traj @ W_out.T, tgt)
+    assert abs(loss.item() - g["loss_f64"][-1]) < 2e-5 * max(1.0, abs(g["loss_f64"][-1]))
+    loss.backward()
+    lr = float(g["lr"])
+    checks = [("W", node["weights"].grad, g["W"]), ("W_out", W_out.grad, g["W_out"])]
+    checks += [(q, node[f"{op}/{q}"].grad, g[q]) for q in c["params"]]
+    for key, got, before in checks:
+        ref = (before - g[f"{key}_after_f64"]) / lr
+        scale = np.abs(ref).max()
+        assert scale > 0, key
+        err = np.abs(got.cpu().numpy().astype(np.float64) - ref).max()
+        floor = np.abs(before).max() * 2.3e-16 / lr * 8
+        assert err <= 2e-3 * scale + floor, f"{case} grad {key}: err {err} vs scale {scale}"

@@ -157,11 +157,12 @@ def test_g18_g19_ik_population_mean_variants(target, name, op, states, extra):
         node_vars=node_vars, spike_threshold=float(g["theta"]), spike_reset=float(g["v_reset"]), **target)
     x = torch.full((T, 1), float(g["x_const"]), device=target["device"])
     check(node, g, T, x, n_state=len(states), tol_s=2e-3)
-    with pytest.raises(NotImplementedError):
-        SpikeResetNet.from_pyrates(
-            BASE + "ik." + op[:-3], input_var=f"{op}/I_ext", output_var=f"{op}/s", weights=g["W"], source_var=f"{op}/s",
-            target_var=f"{op}/s_in", spike_var=f"{op}/spike", reset_var=f"{op}/v", dtype=torch.float32,
-            train_params=["weights"], **target)
+    # trainable as well (adjoint with the population-mean terms; gradients are pinned by golden G20 / G21)
+    trained = SpikeResetNet.from_pyrates(
+        BASE + "ik." + op[:-3], input_var=f"{op}/I_ext", output_var=f"{op}/s", weights=g["W"], source_var=f"{op}/s",
+        target_var=f"{op}/s_in", spike_var=f"{op}/spike", reset_var=f"{op}/v", dtype=torch.float32,
+        train_params=["weights", f"{op}/b"], **target)
+    assert len(list(trained.parameters())) == 2
 
 
 @pytest.mark.gpu
