@@ -68,6 +68,7 @@ struct BwdParams {
     float* grad_k;
     float* grad_eta;
     float* gx_prev;
+    float* grad_act[3];  // LI_SIGMOID: gradients of r_max, s, v0 (rp_bwd.grad_p[RP_P_RMAX / SLOPE / V0]) or null
     // spiking (QIF) sweep
     float* lam_s;
     float* grad_tau_s;
@@ -247,6 +248,15 @@ __device__ __forceinline__ void finalize_elem(const BwdParams& P, int j, float z
     const float gv = (P.grad_var == RP_OUT_STATE0) ? g : g * d;
     const float lam_new = (lam + P.dt * (-lam / P.p[RP_P_TAU][j] + d * z)) + gv;
     P.lam[j] = lam_new;
+    if (P.model == RP_MODEL_LI_SIGMOID && (P.grad_act[0] || P.grad_act[1] || P.grad_act[2])) {
+        // r_t = r_max / (1 + exp(s (v0 - v_t))) enters step t through k (W r_t) and, for output r, through the loss:
+        // dL/dr_t = dt z (+ G_t);  dr/dr_max = r / r_max,  dr/ds = -(v0 - v) r (1 - r/r_max),  dr/dv0 = -act'(v)
+        const float r = P.r_t[j], rmax = P.p[RP_P_RMAX][j];
+        const float dr = P.dt * z + ((P.grad_var == RP_OUT_STATE0) ? 0.f : g);
+        if (P.grad_act[0]) P.grad_act[0][j] += dr * (r / rmax);
+        if (P.grad_act[1]) P.grad_act[1][j] += -(dr * ((P.p[RP_P_V0][j] - P.v_t[j]) * (r * (1.0f - r / rmax))));
+        if (P.grad_act[2]) P.grad_act[2][j] += -(dr * d);
+    }
     if (P.u_next) prep_step(P, j, lam_new);
 }
 
@@ -579,6 +589,12 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     P.grad_tau = b->grad_tau;
     P.grad_k = b->grad_k;
     P.grad_eta = b->grad_eta;
+    if (net->model == RP_MODEL_LI_SIGMOID) {
+        P.grad_act[0] = b->grad_p[RP_P_RMAX];
+        P.grad_act[1] = b->grad_p[RP_P_SLOPE];
+        P.grad_act[2] = b->grad_p[RP_P_V0];
+        if ((P.grad_act[1] || P.grad_act[2]) && !net->p[RP_P_V0]) RP_FAIL(RP_ERR_ARG, "sigmoid v0 null");
+    }
 
     const int eblocks = (n + 255) / 256;
     const int strips = vec4 ? (n + 255) / 256 : (n + 63) / 64;
@@ -652,6 +668,11 @@ static int sharded_params(const rp_net* net, const rp_bwd* b, BwdParams& P, bool
     P.grad_tau = b->grad_tau;
     P.grad_k = b->grad_k;
     P.grad_eta = b->grad_eta;
+    if (net->model == RP_MODEL_LI_SIGMOID) {
+        P.grad_act[0] = b->grad_p[RP_P_RMAX];
+        P.grad_act[1] = b->grad_p[RP_P_SLOPE];
+        P.grad_act[2] = b->grad_p[RP_P_V0];
+    }
     return RP_OK;
 }
 

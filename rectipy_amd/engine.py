@@ -402,6 +402,8 @@ class Population:
         b.grad_x = _ptr(grad_x)
         b.ldgx = 0 if grad_x is None else (grad_x.stride(0) if T > 1 else grad_x.shape[1])
         if not self.spiking:
+            for name, t in (grad_params or {}).items():  # the sigmoid's r_max / s / v0
+                b.grad_p[PARAM_SLOTS[self.model][name]] = t.data_ptr()
             self.backend.rate_backward(self._net(), b, self.device)
             return partials  # returned so the caller keeps it alive until the stream has consumed it
         if self.model in NEEDS_MEANS:

@@ -71,8 +71,10 @@ class _RateWindow(torch.autograd.Function):
     Replaces autograd over the Python-unrolled loop (reference rectipy/network.py:1028-1040).
     """
 
+    ACT_PARAMS = ("r_max", "s", "v0")  # the sigmoid's own parameters (leaky_integrator.yaml:22), extra autograd inputs
+
     @staticmethod
-    def forward(ctx, node, steps, x, v_in, W, tau, k, eta):
+    def forward(ctx, node, steps, x, v_in, W, tau, k, eta, *act):
         pop: Population = node._pop
         N, dev = pop.rows, pop.device
         need_acc = k.requires_grad
@@ -97,14 +99,16 @@ class _RateWindow(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         lam = torch.zeros(N, **f32) if g_vend is None else g_vend.detach().to(**f32).clone().contiguous()
         g_out = None if g_traj is None else g_traj.detach().to(**f32).contiguous()
-        need = ctx.needs_input_grad  # (node, steps, x, v_in, W, tau, k, eta)
+        need = ctx.needs_input_grad  # (node, steps, x, v_in, W, tau, k, eta, *act)
         u_traj = torch.empty(T, N, **f32)
         g_tau = torch.zeros(N, **f32) if need[5] else None
         g_k = torch.zeros(N, **f32) if need[6] else None
         g_eta = torch.zeros(N, **f32) if need[7] else None
         g_x = torch.empty(T, N, **f32) if need[2] else None
+        g_act = {name: torch.zeros(N, **f32) for i, name in enumerate(_RateWindow.ACT_PARAMS[:len(need) - 8])
+                 if need[8 + i]}
         keep = pop.backward(traj_v, traj_r, g_out, node._out_code, lam, u_traj, traj_acc=traj_acc,
-                            grad_tau=g_tau, grad_k=g_k, grad_eta=g_eta, grad_x=g_x)
+                            grad_tau=g_tau, grad_k=g_k, grad_eta=g_eta, grad_x=g_x, grad_params=g_act)
         g_W = None
         if need[4]:
             g_W = torch.zeros(N, N, **f32)
@@ -112,7 +116,8 @@ class _RateWindow(torch.autograd.Function):
         if g_x is not None and ctx.x_width == 1:
             g_x = g_x.sum(dim=1, keepdim=True)
         del keep
-        return None, None, g_x, (lam if need[3] else None), g_W, g_tau, g_k, g_eta
+        return (None, None, g_x, (lam if need[3] else None), g_W, g_tau, g_k, g_eta) + \
+            tuple(g_act.get(name) for name in _RateWindow.ACT_PARAMS[:len(need) - 8])
 
 
 class RateNet:
@@ -215,7 +220,7 @@ class RateNet:
         self._y_requires_grad = len(self._train_names) >= 1  # nodes.py:89-90
 
     def _check_trainable(self):
-        ok = {"weights", "tau", "k", "eta"}
+        ok = {"weights", "tau", "k", "eta"} | (set(_RateWindow.ACT_PARAMS) if self._pop.model == "li_sigmoid" else set())
         bad = [n for n in self._train_names if n not in ok]
         if bad:
             raise NotImplementedError(f"no adjoint kernel for parameters {bad}; trainable: {sorted(ok)}")
@@ -374,8 +379,9 @@ class RateNet:
         v_in = self._y_grad
         if v_in is None:
             v_in = pop.v.detach().clone().requires_grad_(self._y_requires_grad)
+        act = [pop.params[q] for q in _RateWindow.ACT_PARAMS] if pop.model == "li_sigmoid" else []
         traj, v_end = _RateWindow.apply(self, steps, x, v_in, pop.W, pop.params["tau"], pop.params["k"],
-                                        pop.params["eta"])
+                                        pop.params["eta"], *act)
         self._y_grad = v_end
         return traj
 

@@ -149,13 +149,17 @@ def test_rate_backward_bit_exact(oracle_backend, hip_device, N, T, model, grad_v
         pop.forward(T, x=x.to(dev), save_v=tv, save_src=tr, save_acc=ta)
         lam = lam_T.clone().to(dev)
         gt, gk, ge = (torch.zeros(N, device=dev) for _ in range(3))
+        # the sigmoid's own parameters (r_max, s, v0) have gradient kernels too
+        ga = {q: torch.zeros(N, device=dev) for q in (("r_max", "s", "v0") if model == "li_sigmoid" else ())}
         keep = pop.backward(tv, tr, g_out.to(dev), grad_var, lam, ut, traj_acc=ta, grad_tau=gt, grad_k=gk,
-                            grad_eta=ge, grad_x=gx)
+                            grad_eta=ge, grad_x=gx, grad_params=ga)
         if dev != "cpu":
             torch.cuda.synchronize()
-        res.append((lam, ut, gt, gk, ge, gx))
+        res.append((lam, ut, gt, gk, ge, gx) + tuple(ga.values()))
         del keep
-    for a, b, name in zip(res[0], res[1], ("lambda_0", "u_traj", "grad_tau", "grad_k", "grad_eta", "grad_x")):
+    assert model != "li_sigmoid" or all(float(t.abs().max()) > 0 for t in res[0][6:])
+    for a, b, name in zip(res[0], res[1], ("lambda_0", "u_traj", "grad_tau", "grad_k", "grad_eta", "grad_x", "grad_r_max",
+                                           "grad_s", "grad_v0")):
         assert_same(a, b, f"{model} N={N} {name}")
     assert float(res[0][0].abs().max()) > 0
 
