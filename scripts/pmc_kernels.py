@@ -1,0 +1,46 @@
+"""Workload for the per-kernel HBM-traffic passes (run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE by
+scripts/profile_kernels.sh): a few launches each of the tanh step kernel, the adjoint strip kernel, the QIF step kernel
+and the RLS pass at HBM-bound sizes.  Prints the algorithmic bytes per launch of each for the summary."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rectipy_amd import _abi  # noqa: E402
+from rectipy_amd.engine import Population  # noqa: E402
+from rectipy_amd.rls import RLS  # noqa: E402
+
+dev = torch.device("cuda:0")
+N, T = 32768, 12
+algo = {}
+
+W = torch.randn(N, N, device=dev) * (1.5 / N ** 0.5)
+pop = Population("li_tanh", W, dict(tau=10.0, k=1.0, eta=0.0), 1e-2, dev)
+tv, tr, ut = (torch.zeros(T, N, device=dev) for _ in range(3))
+x = torch.zeros(T, 1, device=dev)
+pop.forward(T, x=x, save_v=tv, save_src=tr)
+g = torch.randn(T, N, device=dev) * 0.01
+lam = torch.zeros(N, device=dev)
+keep = pop.backward(tv, tr, g, _abi.RP_OUT_STATE0, lam, ut)
+torch.cuda.synchronize()
+algo["step_kernel<0"] = 4.0 * N * N + 4.0 * (9 * N + 1)          # W + v r/w, tau, k, eta, r r/w, two trajectory rows, input
+algo["wt_partial_kernel"] = 4.0 * N * N + 4.0 * (N + 16 * N)     # W + u + the Q=16 chunk partials written
+del pop, W, keep
+
+Wq = torch.rand(N, N, device=dev) * (20.0 / N)
+qif = Population("qif", Wq, dict(tau=1.0, k=1.0, eta=-5.0, tau_s=1.0), 1e-3, dev, v0=-2.0, s0=0.0)
+qif.forward(T, x=torch.full((T, 1), 15.0, device=dev))
+torch.cuda.synchronize()
+algo["step_kernel<2"] = 4.0 * N * N + 4.0 * (8 * N + 1)
+del qif, Wq
+
+n_in = 16384
+edge = RLS(n_in, 3, beta=0.99).to(dev)
+X = torch.randn(6, n_in, device=dev) * 0.1
+Y = torch.randn(6, 3, device=dev)
+edge.sweep(X, Y, 1)
+torch.cuda.synchronize()
+algo["rls_pass_kernel"] = 8.0 * n_in * n_in                      # P read + written once per update
+print(json.dumps({"algorithmic_bytes_per_launch": algo}), flush=True)
