@@ -313,8 +313,13 @@ class ShardedNetwork(Network):
         node._grad_window = types.MethodType(grad_window, node)
 
     def add_edge(self, source, target, weights=None, train=None, edge_attrs=None, **kwargs):
-        if train is not None and target in self._sharded:
-            raise NotImplementedError("trained input edges of a sharded population are not supported yet")
+        if train is not None and source not in self._sharded and target not in self._sharded:
+            # a replicated trained edge sees the same gradient on every rank only downstream of a read-out; upstream of
+            # a shard each rank would hold a partial gradient (its rows' share) and the sum is not implemented
+            import networkx as nx
+            if not any(nx.has_path(self.graph, lab, source) for lab in self._sharded):
+                raise NotImplementedError("trained edges between replicated nodes upstream of a sharded population "
+                                          "are not supported (their gradient would need an all-reduce)")
         if train not in (None, "gd") and source in self._sharded:
             raise NotImplementedError("only 'gd' training is available for read-outs of a sharded population")
         if weights is None and (source in self._sharded or target in self._sharded):

@@ -197,3 +197,59 @@ def test_sharded_fit_bptt_matches_single_process(tmp_path, oracle_backend):
         assert np.abs(p["loss"] - obs.to_numpy("loss")).max() < 1e-6
         assert np.abs(p["out"] - obs.to_numpy("out")).max() < 1e-6
     assert np.abs(W_sh - _data()[0].numpy()).max() > 1e-7, "training did not change the weights"
+
+
+def _inp_build(cls, where):
+    """inp (3) --trained--> rnn (tanh, trained rows) --trained--> out (2)"""
+    W, params, v0, x, W_in, W_out, u = _net_data()
+    tgt = (torch.randn(T, 2, generator=torch.Generator().manual_seed(11)) * 0.1).numpy()
+    net = cls(1e-2, **where)
+    net.add_func_node("inp", 3, "identity")
+    node = net.add_diffeq_node("rnn", TANH, weights=W.numpy(), source_var="tanh_op/r", target_var="li_op/r_in",
+                               input_var="li_op/I_ext", output_var="tanh_op/r", dtype=torch.float32,
+                               train_params=["weights"],
+                               node_vars={"all/li_op/tau": params["tau"].numpy(), "all/li_op/k": params["k"].numpy(),
+                                          "all/li_op/eta": params["eta"].numpy(), "all/li_op/v": v0.numpy()})
+    net.add_func_node("out", 2, "identity")
+    e_in = net.add_edge("inp", "rnn", weights=W_in.numpy(), train="gd")
+    e_out = net.add_edge("rnn", "out", weights=W_out.numpy(), train="gd")
+    return net, node, e_in, e_out, u.numpy(), tgt
+
+
+def _inp_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from oracle.backend import OracleBackend
+        from rectipy_amd.sharded import ShardedNetwork
+        net, node, e_in, e_out, u, tgt = _inp_build(ShardedNetwork, dict(device="cpu", backend=OracleBackend()))
+        net.fit_bptt(u, tgt, optimizer="sgd", lr=5e-2, update_steps=15, sampling_steps=1, verbose=False)
+        np.savez(os.path.join(out_dir, f"inp_{rank}.npz"), W=node["weights"].detach().numpy(),
+                 W_in=e_in.weights.detach().numpy(), W_out=e_out.weights.detach().numpy())
+        try:  # a trained edge between replicated nodes upstream of the shard would need a gradient all-reduce
+            net.add_func_node("pre", 3, "identity")
+            net.add_edge("pre", "inp", weights=np.eye(3), train="gd")
+            raise AssertionError("expected NotImplementedError")
+        except NotImplementedError:
+            pass
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_fit_bptt_trains_the_input_edge(tmp_path, oracle_backend):
+    """The trained input edge of a sharded population: each rank holds the rows of W_in of its neurons; their gradient
+    is local (dL/dI_ext of the rank's neurons times the shared input)."""
+    from rectipy_amd import Network
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_inp_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    net, node, e_in, e_out, u, tgt = _inp_build(Network, dict(device="cpu", backend=oracle_backend))
+    W_in0 = e_in.weights.detach().numpy().copy()
+    net.fit_bptt(u, tgt, optimizer="sgd", lr=5e-2, update_steps=15, sampling_steps=1, verbose=False)
+    parts = [np.load(tmp_path / f"inp_{r}.npz") for r in range(WORLD)]
+    W_in_sh = np.concatenate([p["W_in"] for p in parts], axis=0)
+    assert np.abs(W_in_sh - e_in.weights.detach().numpy()).max() < 1e-6
+    assert np.abs(W_in_sh - W_in0).max() > 1e-6, "training did not change the input weights"
+    assert np.abs(np.concatenate([p["W"] for p in parts], axis=0) - node["weights"].detach().numpy()).max() < 1e-6
+    assert np.abs(np.concatenate([p["W_out"] for p in parts], axis=1) - e_out.weights.detach().numpy()).max() < 1e-6
