@@ -24,7 +24,7 @@
  *   rp_outer_accum    <- the per-step outer-product accumulation autograd does
  *                        for `weights @ r`          (same call site)
  *   rp_rls_sweep      <- RLS.update                 rectipy/edges.py:227-234
- *   rp_forward_sharded, rp_rate_backward_sharded, rp_bwd_prepare/partial/apply
+ *   rp_forward_sharded, rp_backward_sharded, rp_bwd_prepare/partial/apply
  *                     <- no reference counterpart: row shards over the GPUs of a node
  *
  * All functions return RP_OK (0) or a negative RP_ERR_* code;
@@ -251,7 +251,7 @@ int32_t rp_bwd_partial_rows(int32_t n);
 int rp_rate_backward(const rp_net* net, const rp_bwd* bwd, void* stream);
 
 /*
- * Row-sharded adjoint of the leaky-integrator models, one step at a time (W^T(k*lambda) from row shards
+ * Row-sharded adjoint (leaky-integrator models; spiking models QIF, QIF_SFA, LIF, IK), one step at a time (W^T(k*lambda) from row shards
  * gives full-length partial sums -> reduce-scatter).  Per-neuron vectors of rp_bwd are LOCAL (length net->rows);
  * partials needs rp_bwd_shard_partial_rows(n, rows) x n floats.  Sequence:
  *   rp_bwd_prepare;  for t = T-1 .. 0:  rp_bwd_partial(t, z_full[n]) -> caller reduce-scatters z_full over the ranks
@@ -293,8 +293,9 @@ int rp_sizeof_comm(void);
    all-gather of the ranks' slices of the next source vector.  Same arguments and results as rp_forward. */
 int rp_forward_sharded(rp_net* net, rp_run* run, const rp_comm* comm, void* stream);
 
-/* The whole sharded adjoint sweep (rp_bwd_prepare; t = T-1..0: rp_bwd_partial -> reduce-scatter -> rp_bwd_apply). */
-int rp_rate_backward_sharded(const rp_net* net, const rp_bwd* bwd, const rp_comm* comm, void* stream);
+/* The whole sharded adjoint sweep (rp_bwd_prepare; t = T-1..0: rp_bwd_partial -> reduce-scatter -> rp_bwd_apply), for
+   the leaky-integrator models and the spiking models QIF, QIF_SFA, LIF, IK. */
+int rp_backward_sharded(const rp_net* net, const rp_bwd* bwd, const rp_comm* comm, void* stream);
 
 /*
  * Recursive-least-squares training of a readout edge (reference RLS.update, rectipy/edges.py:227-234, driven by

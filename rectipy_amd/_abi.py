@@ -192,7 +192,7 @@ def declare(lib, prefix):
         sig("rp_bwd_apply", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp, C.c_void_p])
         sig("rp_sizeof_comm", C.c_int, [])
         sig("rp_forward_sharded", C.c_int, [P(RpNet), P(RpRun), P(RpComm), C.c_void_p])
-        sig("rp_rate_backward_sharded", C.c_int, [P(RpNet), P(RpBwd), P(RpComm), C.c_void_p])
+        sig("rp_backward_sharded", C.c_int, [P(RpNet), P(RpBwd), P(RpComm), C.c_void_p])
         sig("rp_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp,
                                       C.c_void_p])
         sig("rp_stream_probe", C.c_int, [fp, C.c_int64, fp, C.c_void_p])
@@ -223,6 +223,6 @@ EXPORTS = [
     "rp_abi_version", "rp_last_error", "rp_device_check", "rp_sizeof_net", "rp_sizeof_run", "rp_sizeof_bwd",
     "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum", "rp_outer_accum_rect",
     "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial", "rp_bwd_apply",
-    "rp_sizeof_comm", "rp_forward_sharded", "rp_rate_backward_sharded",
+    "rp_sizeof_comm", "rp_forward_sharded", "rp_backward_sharded",
     "rp_rls_sweep", "rp_stream_probe", "rp_set_tuning", "rp_set_bwd_tuning", "rp_set_bwd_chunks", "rp_set_rls_tuning",
 ]

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(1024) void adj_mean_kernel(const BwdParams P) {
 
 __global__ void spk_prep_kernel(const BwdParams P, const SpkGrad G) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < P.n)
+    if (j < P.rows)
         spk_prep_step(P, G, j, P.lam[j], P.lam_s[j], P.lam_x ? P.lam_x[j] : 0.f, P.lam_x2 ? P.lam_x2[j] : 0.f);
 }
 
@@ -446,8 +446,8 @@ __device__ __forceinline__ void spk_finalize_elem(const BwdParams& P, const SpkG
 
 __global__ void spk_finalize_kernel(const BwdParams P, const SpkGrad G) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.n) return;
-    spk_finalize_elem(P, G, j, chunk_sum(P, j));
+    if (j >= P.rows) return;
+    spk_finalize_elem(P, G, j, P.z_direct ? P.z_direct[j] : chunk_sum(P, j));
 }
 
 // ---- transposed-copy sweep for small n (rp_bwd.wt) -------------------------------------------------------------
@@ -689,9 +689,24 @@ int32_t rp_bwd_shard_partial_rows(int32_t n, int32_t rows) {
     return (rows + rc - 1) / rc;
 }
 
+static int spk_setup(const rp_net* net, const rp_bwd* b, BwdParams& P, SpkGrad& G, bool& vec4);
+static void spk_set_prep(const rp_bwd* b, BwdParams& P, int tp);
+static void spk_set_step(const rp_bwd* b, BwdParams& P, int t);
+static bool is_spiking(const rp_net* net) { return net && net->model >= RP_MODEL_QIF; }
+
 int rp_bwd_prepare(const rp_net* net, const rp_bwd* b, void* stream) {
     BwdParams P;
     bool vec4;
+    if (is_spiking(net)) {
+        SpkGrad G;
+        int rc = spk_setup(net, b, P, G, vec4);
+        if (rc != RP_OK) return rc;
+        if (b->steps <= 0) RP_FAIL(RP_ERR_ARG, "steps must be > 0");
+        spk_set_prep(b, P, b->steps - 1);
+        hipLaunchKernelGGL(spk_prep_kernel, dim3((P.rows + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), P, G);
+        RP_HIP_CHECK(hipGetLastError());
+        return RP_OK;
+    }
     int rc = sharded_params(net, b, P, vec4);
     if (rc != RP_OK) return rc;
     sharded_set_prep(b, P, b->steps - 1);
@@ -703,7 +718,8 @@ int rp_bwd_prepare(const rp_net* net, const rp_bwd* b, void* stream) {
 int rp_bwd_partial(const rp_net* net, const rp_bwd* b, int32_t t, float* z_full, void* stream) {
     BwdParams P;
     bool vec4;
-    int rc = sharded_params(net, b, P, vec4);
+    SpkGrad G;
+    int rc = is_spiking(net) ? spk_setup(net, b, P, G, vec4) : sharded_params(net, b, P, vec4);
     if (rc != RP_OK) return rc;
     if (t < 0 || t >= b->steps || !z_full) RP_FAIL(RP_ERR_ARG, "bad step index or null z_full");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -717,6 +733,18 @@ int rp_bwd_partial(const rp_net* net, const rp_bwd* b, int32_t t, float* z_full,
 int rp_bwd_apply(const rp_net* net, const rp_bwd* b, int32_t t, const float* z_local, void* stream) {
     BwdParams P;
     bool vec4;
+    if (is_spiking(net)) {
+        SpkGrad G;
+        int rc = spk_setup(net, b, P, G, vec4);
+        if (rc != RP_OK) return rc;
+        if (t < 0 || t >= b->steps || !z_local) RP_FAIL(RP_ERR_ARG, "bad step index or null z_local");
+        P.z_direct = z_local;
+        spk_set_step(b, P, t);
+        hipLaunchKernelGGL(spk_finalize_kernel, dim3((P.rows + 255) / 256), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), P, G);
+        RP_HIP_CHECK(hipGetLastError());
+        return RP_OK;
+    }
     int rc = sharded_params(net, b, P, vec4);
     if (rc != RP_OK) return rc;
     if (t < 0 || t >= b->steps || !z_local) RP_FAIL(RP_ERR_ARG, "bad step index or null z_local");
@@ -734,7 +762,7 @@ int rp_bwd_apply(const rp_net* net, const rp_bwd* b, int32_t t, const float* z_l
     return RP_OK;
 }
 
-int rp_rate_backward_sharded(const rp_net* net, const rp_bwd* b, const rp_comm* comm, void* stream) {
+int rp_backward_sharded(const rp_net* net, const rp_bwd* b, const rp_comm* comm, void* stream) {
     typedef int (*reduce_scatter_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
     if (!net || !b || !comm) RP_FAIL(RP_ERR_ARG, "net/bwd/comm is null");
     if (!comm->comm || !comm->reduce_scatter || !comm->work)
@@ -772,17 +800,20 @@ int rp_set_bwd_tuning(int unroll, int strip_groups) {
     return RP_OK;
 }
 
-int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
+// Validation and parameter block of a spiking sweep over the `net->rows` local neurons (rows == n: whole population;
+// rows < n: a row shard, all per-neuron vectors of rp_bwd local).
+static int spk_setup(const rp_net* net, const rp_bwd* b, BwdParams& P, SpkGrad& G, bool& vec4) {
     if (!net || !b) RP_FAIL(RP_ERR_ARG, "net/bwd is null");
     const int model = net->model;
     if (model < RP_MODEL_QIF || model > RP_MODEL_IK_BIEXP)
-        RP_FAIL(RP_ERR_ARG, "rp_qif_backward needs a spiking model (model=%d)", model);
+        RP_FAIL(RP_ERR_ARG, "the spiking sweep needs a spiking model (model=%d)", model);
     const bool ik_family = model >= RP_MODEL_IK;
     const bool mean_coupled = model == RP_MODEL_IKU || model == RP_MODEL_IK_BIEXP;
     const bool has_aux = model == RP_MODEL_QIF_SFA || ik_family;
-    if (net->rows != net->n || net->row0 != 0)
-        RP_FAIL(RP_ERR_ARG, "rp_qif_backward needs the unsharded matrix (rows=%d n=%d)", net->rows, net->n);
-    if (net->n <= 0 || net->ldw < net->n) RP_FAIL(RP_ERR_SHAPE, "bad n/ldw");
+    const int rows = net->rows;
+    if (net->n <= 0 || rows <= 0 || net->row0 < 0 || (int64_t)net->row0 + rows > net->n || net->ldw < net->n)
+        RP_FAIL(RP_ERR_SHAPE, "bad shape: n=%d rows=%d row0=%d ldw=%lld", net->n, rows, net->row0, (long long)net->ldw);
+    if (mean_coupled && rows != net->n) RP_FAIL(RP_ERR_ARG, "population-mean models cannot be row-sharded");
     if (b->steps < 0) RP_FAIL(RP_ERR_ARG, "steps < 0");
     if (!net->W || !b->traj_v || !b->traj_r || !b->lam || !b->lam2 || !b->u_traj || !b->partials)
         RP_FAIL(RP_ERR_ARG, "W, traj_v, traj_r (s_t), lam, lam2, u_traj, partials must be non-null");
@@ -791,19 +822,19 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     if (mean_coupled && !b->means) RP_FAIL(RP_ERR_ARG, "model %d needs the means scratch (4 floats)", model);
     if (model == RP_MODEL_IK_BIEXP && (!b->traj_aux2 || !b->lam4))
         RP_FAIL(RP_ERR_ARG, "IK_BIEXP needs traj_aux2 and lam4");
-    if (b->ld < net->n) RP_FAIL(RP_ERR_SHAPE, "ld < n");
-    if (b->grad_out && b->ldg < net->n) RP_FAIL(RP_ERR_SHAPE, "ldg < n");
-    if (b->grad_x && b->ldgx < net->n) RP_FAIL(RP_ERR_SHAPE, "ldgx < n");
+    if (b->ld < rows) RP_FAIL(RP_ERR_SHAPE, "ld < rows");
+    if (b->grad_out && b->ldg < rows) RP_FAIL(RP_ERR_SHAPE, "ldg < rows");
+    if (b->grad_x && b->ldgx < rows) RP_FAIL(RP_ERR_SHAPE, "ldgx < rows");
     if (b->grad_var != RP_OUT_STATE0 && b->grad_var != RP_OUT_SOURCE) RP_FAIL(RP_ERR_ARG, "bad grad_var");
     if (b->x_mode != RP_X_NONE && b->x_mode != RP_X_FULL && b->x_mode != RP_X_BCAST)
         RP_FAIL(RP_ERR_ARG, "x_mode must be NONE, FULL or BCAST");
-    if (b->x_mode != RP_X_NONE && (!b->x || b->ldx < (b->x_mode == RP_X_FULL ? net->n : 1)))
+    if (b->x_mode != RP_X_NONE && (!b->x || b->ldx < (b->x_mode == RP_X_FULL ? rows : 1)))
         RP_FAIL(RP_ERR_SHAPE, "x/ldx inconsistent with x_mode");
     if (b->x_target != RP_XT_MEMBRANE && !(b->x_target == RP_XT_SYNAPSE && model == RP_MODEL_LIF))
         RP_FAIL(RP_ERR_ARG, "x_target %d is not available for model %d", b->x_target, model);
 
     // parameter-gradient targets by slot; the named fields of rp_bwd cover the common four
-    SpkGrad G = {};
+    G = SpkGrad{};
     for (int q = 0; q < RP_MAX_PARAMS; ++q) G.p[q] = b->grad_p[q];
     if (!ik_family && b->grad_tau) G.p[RP_P_TAU] = b->grad_tau;
     if (b->grad_k) G.p[RP_P_K] = b->grad_k;
@@ -825,30 +856,21 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     }
     if (G.p[RP_P_K] && !b->traj_acc) RP_FAIL(RP_ERR_ARG, "grad_k needs traj_acc");
 
-    const bool vec4 = (net->n % 4 == 0) && (net->ldw % 4 == 0);
+    vec4 = (net->n % 4 == 0) && (net->ldw % 4 == 0);
     if (vec4 && ((reinterpret_cast<uintptr_t>(net->W) & 15u) || (reinterpret_cast<uintptr_t>(b->partials) & 15u)))
         RP_FAIL(RP_ERR_ARG, "W and partials must be 16-byte aligned");
-    bool use_wt, vec4_t;
-    {
-        int rc = transposed_mode(net, b, use_wt, vec4_t);
-        if (rc != RP_OK) return rc;
-    }
-    if (b->steps == 0) return RP_OK;
 
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int n = net->n;
-    const int T = b->steps;
-    BwdParams P = {};
-    P.W = use_wt ? b->wt : net->W;
-    P.ldw = use_wt ? b->ldwt : net->ldw;
-    P.n = n;
-    P.rows = n;
+    P = BwdParams{};
+    P.W = net->W;
+    P.ldw = net->ldw;
+    P.n = net->n;
+    P.rows = rows;
     P.model = model;
     for (int q = 0; q < RP_MAX_PARAMS; ++q) P.p[q] = net->p[q];
     P.dt = net->dt;
     P.inv_dt = 1.0f / net->dt;
-    P.rc = chunk_rows(n, n);
-    P.q = (n + P.rc - 1) / P.rc;
+    P.rc = chunk_rows(net->n, rows);
+    P.q = (rows + P.rc - 1) / P.rc;
     P.partials = b->partials;
     P.grad_var = b->grad_var;
     P.lam = b->lam;
@@ -860,35 +882,61 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     P.theta = net->theta;
     P.x_mode = b->x_mode;
     P.x_target = b->x_target;
+    return RP_OK;
+}
 
-    const int eblocks = (n + 255) / 256;
+static void spk_set_prep(const rp_bwd* b, BwdParams& P, int tp) {
+    P.u_next = b->u_traj + (int64_t)tp * b->ld;
+    P.v_prev = b->traj_v + (int64_t)tp * b->ld;
+    P.s_prev = b->traj_r + (int64_t)tp * b->ld;
+    P.aux_prev = b->traj_aux ? b->traj_aux + (int64_t)tp * b->ld : nullptr;
+    P.aux2_prev = b->traj_aux2 ? b->traj_aux2 + (int64_t)tp * b->ld : nullptr;
+    P.acc_prev = b->traj_acc ? b->traj_acc + (int64_t)tp * b->ld : nullptr;
+    P.gx_prev = b->grad_x ? b->grad_x + (int64_t)tp * b->ldgx : nullptr;
+    P.x_prev = b->x ? b->x + (int64_t)tp * b->ldx : nullptr;
+}
 
-    auto set_prep = [&](int tp) {
-        P.u_next = b->u_traj + (int64_t)tp * b->ld;
-        P.v_prev = b->traj_v + (int64_t)tp * b->ld;
-        P.s_prev = b->traj_r + (int64_t)tp * b->ld;
-        P.aux_prev = b->traj_aux ? b->traj_aux + (int64_t)tp * b->ld : nullptr;
-        P.aux2_prev = b->traj_aux2 ? b->traj_aux2 + (int64_t)tp * b->ld : nullptr;
-        P.acc_prev = b->traj_acc ? b->traj_acc + (int64_t)tp * b->ld : nullptr;
-        P.gx_prev = b->grad_x ? b->grad_x + (int64_t)tp * b->ldgx : nullptr;
-        P.x_prev = b->x ? b->x + (int64_t)tp * b->ldx : nullptr;
-    };
+static void spk_set_step(const rp_bwd* b, BwdParams& P, int t) {
+    P.t = t;
+    P.v_t = b->traj_v + (int64_t)t * b->ld;
+    P.acc_t = b->traj_acc ? b->traj_acc + (int64_t)t * b->ld : nullptr;
+    P.g_t = b->grad_out ? b->grad_out + (int64_t)t * b->ldg : nullptr;
+    if (t > 0)
+        spk_set_prep(b, P, t - 1);
+    else
+        P.u_next = nullptr;
+}
+
+int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
+    BwdParams P;
+    SpkGrad G;
+    bool vec4;
+    int rc = spk_setup(net, b, P, G, vec4);
+    if (rc != RP_OK) return rc;
+    if (net->rows != net->n || net->row0 != 0)
+        RP_FAIL(RP_ERR_ARG, "rp_qif_backward needs the unsharded matrix (rows=%d n=%d)", net->rows, net->n);
+    const bool mean_coupled = net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP;
+    bool use_wt, vec4_t;
+    rc = transposed_mode(net, b, use_wt, vec4_t);
+    if (rc != RP_OK) return rc;
+    if (b->steps == 0) return RP_OK;
+
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int T = b->steps;
+    if (use_wt) {
+        P.W = b->wt;
+        P.ldw = b->ldwt;
+    }
+    const int eblocks = (P.n + 255) / 256;
 
     if (use_wt) launch_transpose(net, b, st);
-    set_prep(T - 1);
+    spk_set_prep(b, P, T - 1);
     if (mean_coupled) hipLaunchKernelGGL(adj_mean_kernel, dim3(1), dim3(1024), 0, st, P);
     hipLaunchKernelGGL(spk_prep_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
     for (int t = T - 1; t >= 0; --t) {
-        P.t = t;
         P.u = b->u_traj + (int64_t)t * b->ld;
         if (!use_wt) launch_wt_partial(P, vec4, st);
-        P.v_t = b->traj_v + (int64_t)t * b->ld;
-        P.acc_t = b->traj_acc ? b->traj_acc + (int64_t)t * b->ld : nullptr;
-        P.g_t = b->grad_out ? b->grad_out + (int64_t)t * b->ldg : nullptr;
-        if (t > 0)
-            set_prep(t - 1);
-        else
-            P.u_next = nullptr;
+        spk_set_step(b, P, t);
         if (mean_coupled) hipLaunchKernelGGL(adj_mean_kernel, dim3(1), dim3(1024), 0, st, P);
         if (use_wt)
             launch_adj_rowdot<true>(P, G, vec4_t, st);

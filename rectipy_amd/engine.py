@@ -112,9 +112,9 @@ class HipBackend:
             self._lib_mod.check(self.lib.rp_forward_sharded(C.byref(net), C.byref(run), C.byref(comm),
                                                             self._stream(device)))
 
-    def rate_backward_sharded(self, net, bwd, comm, device):
+    def backward_sharded(self, net, bwd, comm, device):
         with torch.cuda.device(device):
-            self._lib_mod.check(self.lib.rp_rate_backward_sharded(C.byref(net), C.byref(bwd), C.byref(comm),
+            self._lib_mod.check(self.lib.rp_backward_sharded(C.byref(net), C.byref(bwd), C.byref(comm),
                                                                   self._stream(device)))
 
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
@@ -377,23 +377,29 @@ class Population:
                  grad_tau=None, grad_k=None, grad_eta=None, grad_x=None, lam_s=None, grad_tau_s=None,
                  slope: float = 0.5, x: Optional[torch.Tensor] = None, x_target: int = _abi.RP_XT_MEMBRANE,
                  traj_aux=None, lam_x=None, grad_params: Optional[Dict[str, torch.Tensor]] = None,
-                 traj_aux2=None, lam_x2=None):
-        """Adjoint sweep over a stored window (rp_rate_backward; rp_qif_backward for the spiking model, which
-        additionally takes the adjoint of s, the surrogate slope and the window's input for grad_tau)."""
+                 traj_aux2=None, lam_x2=None, exchange=None):
+        """Adjoint sweep over a stored window (rp_rate_backward; rp_qif_backward for the spiking models, which
+        additionally take the adjoint of s, the surrogate slope and the window's input for grad_tau).
+
+        Row shard (``rows < n``): every per-neuron tensor is local and ``exchange`` provides the cross-rank sum of the
+        full-length partial W_p^T u_p -- ``exchange.comm`` (an ``RpComm``: the whole sweep is one library call,
+        rp_backward_sharded) or ``exchange.reduce_scatter(z_full, z_local)`` called once per step."""
         T = int(traj_v.shape[0])
+        local = self.rows
+        sharded = self.rows != self.n
         b = RpBwd()
         b.steps = T
         b.traj_v, b.traj_r, b.traj_acc = traj_v.data_ptr(), traj_r.data_ptr(), _ptr(traj_acc)
-        b.ld = traj_v.stride(0) if T > 1 else max(traj_v.shape[1], self.n)
+        b.ld = traj_v.stride(0) if T > 1 else max(traj_v.shape[1], local)
         b.grad_var = grad_var
         b.grad_out = _ptr(grad_out)
         b.ldg = 0 if grad_out is None else (grad_out.stride(0) if T > 1 else grad_out.shape[1])
         b.lam = lam.data_ptr()
         b.u_traj = u_traj.data_ptr()
-        q = self.backend.partial_rows(self.n)
+        q = self.backend.shard_partial_rows(self.n, local) if sharded else self.backend.partial_rows(self.n)
         partials = torch.empty(q, self.n, dtype=torch.float32, device=self.device)
         b.partials = partials.data_ptr()
-        if self.n <= _abi.RP_BWD_TRANSPOSE_MAX_N and self.transposed_adjoint:
+        if not sharded and self.n <= _abi.RP_BWD_TRANSPOSE_MAX_N and self.transposed_adjoint:
             # small networks: the sweep keeps W^T in this workspace and runs one fused launch per step (rp_bwd.wt)
             if self._wt is None:
                 self._wt = torch.empty(self.n, (self.n + 3) // 4 * 4, dtype=torch.float32, device=self.device)
@@ -401,34 +407,52 @@ class Population:
         b.grad_tau, b.grad_k, b.grad_eta = _ptr(grad_tau), _ptr(grad_k), _ptr(grad_eta)
         b.grad_x = _ptr(grad_x)
         b.ldgx = 0 if grad_x is None else (grad_x.stride(0) if T > 1 else grad_x.shape[1])
-        if not self.spiking:
-            for name, t in (grad_params or {}).items():  # the sigmoid's r_max / s / v0
-                b.grad_p[PARAM_SLOTS[self.model][name]] = t.data_ptr()
-            self.backend.rate_backward(self._net(), b, self.device)
-            return partials  # returned so the caller keeps it alive until the stream has consumed it
-        if self.model in NEEDS_MEANS:
-            if self.rows != self.n:
-                raise NotImplementedError(f"the '{self.model}' model (population-mean coupling) cannot be row-sharded")
-            means = torch.zeros(4, dtype=torch.float32, device=self.device)
-            b.means = means.data_ptr()
-            b.traj_aux2, b.lam4 = _ptr(traj_aux2), _ptr(lam_x2)
-        b.lam2 = lam_s.data_ptr()
-        b.grad_tau_s = _ptr(grad_tau_s)
-        b.slope = float(slope)
-        b.x_target = int(x_target)
-        b.traj_aux, b.lam3 = _ptr(traj_aux), _ptr(lam_x)
-        for name, t in (grad_params or {}).items():  # gradients of model-specific parameters, by engine name
+        for name, t in (grad_params or {}).items():  # model-specific parameters by engine name (sigmoid, spiking)
             b.grad_p[PARAM_SLOTS[self.model][name]] = t.data_ptr()
-        if x is None:
-            b.x_mode = _abi.RP_X_NONE
-        else:
-            x = x.detach().to(dtype=torch.float32, device=self.device).contiguous()
-            if x.shape[1] not in (1, self.n) or x.shape[0] < T:
-                raise RuntimeError(f"window input must be [{T}, 1] or [{T}, {self.n}], got {tuple(x.shape)}")
-            b.x_mode = _abi.RP_X_FULL if x.shape[1] == self.n and self.n != 1 else _abi.RP_X_BCAST
-            b.x, b.ldx = x.data_ptr(), x.shape[1]
-        self.backend.qif_backward(self._net(), b, self.device)
-        return partials, x, (means if self.model in NEEDS_MEANS else None)
+        keep = [partials]  # returned so the caller keeps the workspaces alive until the stream has consumed them
+        if self.spiking:
+            if self.model in NEEDS_MEANS:
+                if sharded:
+                    raise NotImplementedError(f"the '{self.model}' model (population-mean coupling) cannot be row-sharded")
+                means = torch.zeros(4, dtype=torch.float32, device=self.device)
+                keep.append(means)
+                b.means = means.data_ptr()
+                b.traj_aux2, b.lam4 = _ptr(traj_aux2), _ptr(lam_x2)
+            b.lam2 = lam_s.data_ptr()
+            b.grad_tau_s = _ptr(grad_tau_s)
+            b.slope = float(slope)
+            b.x_target = int(x_target)
+            b.traj_aux, b.lam3 = _ptr(traj_aux), _ptr(lam_x)
+            if x is None:
+                b.x_mode = _abi.RP_X_NONE
+            else:
+                x = x.detach().to(dtype=torch.float32, device=self.device).contiguous()
+                if x.shape[1] not in (1, local) or x.shape[0] < T:
+                    raise RuntimeError(f"window input must be [{T}, 1] or [{T}, {local}], got {tuple(x.shape)}")
+                b.x_mode = _abi.RP_X_FULL if x.shape[1] == local and local != 1 else _abi.RP_X_BCAST
+                b.x, b.ldx = x.data_ptr(), x.shape[1]
+                keep.append(x)
+        net = self._net()
+        if not sharded:
+            (self.backend.qif_backward if self.spiking else self.backend.rate_backward)(net, b, self.device)
+            return keep
+        if exchange is None:
+            raise RuntimeError("the adjoint of a row shard needs an `exchange` (cross-rank sum of W_p^T u_p)")
+        f32 = dict(dtype=torch.float32, device=self.device)
+        if getattr(exchange, "comm", None) is not None:  # whole sweep in one call, RCCL reduce-scatter in-library
+            work = torch.empty(self.n + local, **f32)
+            keep.append(work)
+            exchange.comm.work = work.data_ptr()
+            self.backend.backward_sharded(net, b, exchange.comm, self.device)
+            exchange.comm.work = None
+            return keep
+        z_full, z_local = torch.empty(self.n, **f32), torch.empty(local, **f32)
+        self.backend.bwd_prepare(net, b, self.device)
+        for t in range(T - 1, -1, -1):
+            self.backend.bwd_partial(net, b, t, z_full.data_ptr(), self.device)
+            exchange.reduce_scatter(z_full, z_local)
+            self.backend.bwd_apply(net, b, t, z_local.data_ptr(), self.device)
+        return keep
 
     def outer_accum(self, alpha: float, A: torch.Tensor, B: torch.Tensor, Cmat: torch.Tensor):
         """Cmat += alpha * A^T @ B on the matrix cores (A, B: [T, n])."""

@@ -19,7 +19,7 @@ from .engine import Population
 
 def rccl_comm(group, device, backend) -> Optional[_abi.RpComm]:
     """The group's RCCL communicator as an ``rp_comm`` for the in-library exchange (rp_forward_sharded /
-    rp_rate_backward_sharded), or None when the exchange has to go through ``torch.distributed`` (gloo group, the
+    rp_backward_sharded), or None when the exchange has to go through ``torch.distributed`` (gloo group, the
     CPU test backend, or RECTIPY_AMD_HOST_COLLECTIVES=1).  The communicator stays owned by ProcessGroupNCCL; the
     function addresses come from the RCCL instance PyTorch loaded, the only one in which that communicator is valid."""
     import ctypes
@@ -167,53 +167,111 @@ class _ShardedRateWindow(torch.autograd.Function):
         g_k = torch.zeros(rows, **f32) if need[7] else None
         g_eta = torch.zeros(rows, **f32) if need[8] else None
         g_x = torch.empty(T, rows, **f32) if need[3] else None
-        be = pop.backend
-        partials = torch.empty(be.shard_partial_rows(n, rows), n, **f32)
-        z_full = torch.empty(n, **f32)
-        z_local = torch.empty(rows, **f32)
-
-        b = _abi.RpBwd()
-        b.steps = T
-        b.traj_v, b.traj_r = traj_v.data_ptr(), traj_r.data_ptr()
-        b.traj_acc = None if traj_acc is None else traj_acc.data_ptr()
-        b.ld = rows
-        b.grad_var = node._out_code
-        b.grad_out = None if g_out is None else g_out.data_ptr()
-        b.ldg = rows
-        b.lam, b.u_traj, b.partials = lam.data_ptr(), u_traj.data_ptr(), partials.data_ptr()
-        b.grad_tau = None if g_tau is None else g_tau.data_ptr()
-        b.grad_k = None if g_k is None else g_k.data_ptr()
-        b.grad_eta = None if g_eta is None else g_eta.data_ptr()
-        b.grad_x = None if g_x is None else g_x.data_ptr()
-        b.ldgx = rows
-        rnet = pop._net()
-        nccl = dist.get_backend(net.group) == "nccl"
-        if net.comm is not None:  # whole sweep in one library call (reduce-scatter per step on the same stream)
-            work = torch.empty(n + rows, **f32)
-            net.comm.work = work.data_ptr()
-            be.rate_backward_sharded(rnet, b, net.comm, dev)
-            net.comm.work = None
-            T_loop = 0
-        else:
-            be.bwd_prepare(rnet, b, dev)
-            T_loop = T
-        for t in range(T_loop - 1, -1, -1):
-            be.bwd_partial(rnet, b, t, z_full.data_ptr(), dev)
-            if nccl:
-                dist.reduce_scatter_tensor(z_local, z_full, group=net.group)
-            else:  # gloo has no reduce-scatter: all-reduce, then keep this rank's slice
-                dist.all_reduce(z_full, group=net.group)
-                z_local.copy_(z_full[pop.row0:pop.row0 + rows])
-            be.bwd_apply(rnet, b, t, z_local.data_ptr(), dev)
+        keep = pop.backward(traj_v, traj_r, g_out, node._out_code, lam, u_traj, traj_acc=traj_acc, grad_tau=g_tau,
+                            grad_k=g_k, grad_eta=g_eta, grad_x=g_x, exchange=_Exchange(net))
         g_W = None
         if need[5]:
             g_W = torch.zeros(rows, n, **f32)
-            be.outer_accum_rect(rows, n, T, float(pop.dt), u_traj.data_ptr(), rows, traj_r_full.data_ptr(), n,
-                                g_W.data_ptr(), n, dev)
+            pop.backend.outer_accum_rect(rows, n, T, float(pop.dt), u_traj.data_ptr(), rows, traj_r_full.data_ptr(), n,
+                                         g_W.data_ptr(), n, dev)
         if g_x is not None and ctx.x_width == 1:
             g_x = g_x.sum(dim=1, keepdim=True)
             dist.all_reduce(g_x, group=net.group)  # a broadcast input feeds every shard
+        del keep
         return None, None, None, g_x, (lam if need[4] else None), g_W, g_tau, g_k, g_eta
+
+
+class _Exchange:
+    """Cross-rank sum of the full-length partials of the sharded adjoint: in-library (``comm``) or one
+    ``torch.distributed`` reduce-scatter per step."""
+
+    def __init__(self, net):
+        self.comm = net.comm
+        self.group = net.group
+        self.nccl = dist.get_backend(net.group) == "nccl"
+
+    def reduce_scatter(self, z_full, z_local):
+        if self.nccl:
+            dist.reduce_scatter_tensor(z_local, z_full, group=self.group)
+        else:  # gloo has no reduce-scatter: all-reduce, then keep this rank's slice
+            dist.all_reduce(z_full, group=self.group)
+            rows = z_local.numel()
+            r0 = dist.get_rank(self.group) * rows
+            z_local.copy_(z_full[r0:r0 + rows])
+
+
+class _ShardedSpikeWindow(torch.autograd.Function):
+    """T steps of a row-sharded spiking population (QIF, QIF_SFA, LIF, IK) as one autograd node: forward as
+    `_ShardedRateWindow` with the all-gather of s; backward = surrogate-gradient adjoint on the rank's neurons with the
+    reduce-scatter of W_p^T u_p per step, dW_p = dt U_p^T S one rectangular MFMA GEMM."""
+
+    @staticmethod
+    def forward(ctx, node, net, steps, x, y_in, W, *params):
+        from .spiking_autograd import TRAINABLE
+        pop = node._pop
+        rows, n, dev = pop.rows, pop.n, pop.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        names = TRAINABLE[pop.model]
+        req = {q: p.requires_grad for q, p in zip(names, params)}
+        need_acc = pop.model == "ik" or req.get("k", False)
+        traj_v, traj_s = torch.empty(steps, rows, **f32), torch.empty(steps, rows, **f32)
+        traj_aux = torch.empty(steps, rows, **f32) if pop.aux is not None else None
+        traj_acc = torch.empty(steps, rows, **f32) if need_acc else None
+        traj_s_full = torch.empty(steps, n, **f32)
+        kw = dict(x_target=node._x_target, spike_events=node.spike_events, spike_count=node._spike_count)
+        if net.comm is not None:
+            pop.forward(steps, x=x, save_v=traj_v, save_src=traj_s, save_aux=traj_aux, save_acc=traj_acc,
+                        save_src_full=traj_s_full, comm=net.comm, **kw)
+        else:
+            row = lambda t_, i: None if t_ is None else t_[i:i + 1]
+            for t in range(steps):
+                traj_s_full[t].copy_(pop.source)
+                pop.forward(1, x=row(x, t), save_v=row(traj_v, t), save_src=row(traj_s, t), save_aux=row(traj_aux, t),
+                            save_acc=row(traj_acc, t), step0=t, **kw)
+                net._gather(node, pop.row0, rows)
+        ctx.node, ctx.net, ctx.steps, ctx.names = node, net, steps, names
+        ctx.x = None if x is None else x.detach()
+        ctx.saved = (traj_v, traj_s, traj_aux, traj_acc, traj_s_full)
+        node._last_window = (traj_v, traj_s, traj_aux, None)
+        out = traj_s if node._out_code == _abi.RP_OUT_SOURCE else traj_v
+        return out.clone(), node._pack(pop.v, pop.source_local, pop.aux)
+
+    @staticmethod
+    def backward(ctx, g_traj, g_yend):
+        node, net, T = ctx.node, ctx.net, ctx.steps
+        pop = node._pop
+        rows, n, dev = pop.rows, pop.n, pop.device
+        traj_v, traj_s, traj_aux, traj_acc, traj_s_full = ctx.saved
+        f32 = dict(dtype=torch.float32, device=dev)
+        tpl = node._template
+
+        def piece(name):
+            if g_yend is None or name is None:
+                return torch.zeros(rows, **f32)
+            lo, hi = node._var_map[name]
+            return g_yend.detach().to(**f32)[lo:hi].clone().contiguous()
+
+        lam_v, lam_s = piece(tpl.reset_var), piece(tpl.source_var)
+        lam_x = piece(node._aux_name) if node._aux_name else None
+        g_out = None if g_traj is None else g_traj.detach().to(**f32).contiguous()
+        need = ctx.needs_input_grad  # (node, net, steps, x, y_in, W, *params)
+        grads = {name: torch.zeros(rows, **f32) for i, name in enumerate(ctx.names) if need[6 + i]}
+        u_traj = torch.empty(T, rows, **f32)
+        g_x = torch.empty(T, rows, **f32) if need[3] else None
+        keep = pop.backward(traj_v, traj_s, g_out, node._out_code, lam_v, u_traj, traj_acc=traj_acc, grad_x=g_x,
+                            lam_s=lam_s, slope=node._spike_slope, x=ctx.x, x_target=node._x_target, traj_aux=traj_aux,
+                            lam_x=lam_x, grad_params=grads, exchange=_Exchange(net))
+        g_W = None
+        if need[5]:
+            g_W = torch.zeros(rows, n, **f32)
+            pop.backend.outer_accum_rect(rows, n, T, float(pop.dt), u_traj.data_ptr(), rows, traj_s_full.data_ptr(), n,
+                                         g_W.data_ptr(), n, dev)
+        if g_x is not None and ctx.x is not None and ctx.x.shape[1] == 1:
+            g_x = g_x.sum(dim=1, keepdim=True)
+            dist.all_reduce(g_x, group=net.group)
+        del keep
+        g_y = node._pack(lam_v, lam_s, lam_x) if need[4] else None
+        return (None, None, None, g_x, g_y, g_W) + tuple(grads.get(name) for name in ctx.names)
 
 
 class ShardedNetwork(Network):
@@ -246,8 +304,6 @@ class ShardedNetwork(Network):
             weights = weights[row0:row0 + rows]
         elif weights.shape[0] != rows:
             raise RuntimeError(f"weights must be [{n}, {n}] or this rank's [{rows}, {n}] block, got {tuple(weights.shape)}")
-        if kwargs.get("spike_var") is not None and kwargs.get("train_params"):
-            raise NotImplementedError("sharded training is available for the rate (leaky-integrator) templates only")
         if "node_vars" in kwargs:
             kwargs["node_vars"] = {k: _slice_rows(v, row0, rows, n) for k, v in kwargs["node_vars"].items()}
         new = super().add_diffeq_node(label, node, input_var, output_var, weights=weights, shard=(row0, n), **kwargs)
@@ -293,6 +349,21 @@ class ShardedNetwork(Network):
 
         def grad_window(self_, steps, x):
             pop = self_._pop
+            if pop.spiking:
+                from .spiking_autograd import TRAINABLE
+                if pop.model not in TRAINABLE or pop.aux2 is not None or pop.model == "iku":
+                    raise NotImplementedError(f"the '{pop.model}' template (population means) cannot be row-sharded")
+                y_in = self_._y_grad
+                if y_in is None:
+                    y_in = self_.current_state.detach().requires_grad_(self_._y_requires_grad)
+                params = [pop.params[q] for q in TRAINABLE[pop.model]]
+                traj, y_end = _ShardedSpikeWindow.apply(self_, net, steps, x, y_in, pop.W, *params)
+                self_._y_grad = y_end
+                tv, ts, ta, _ = self_._last_window
+                self_._y_prev = self_._pack(tv[-1], ts[-1], None if ta is None else ta[-1])
+                return traj
+            if pop.model == "li_sigmoid" and any(pop.params[q].requires_grad for q in ("r_max", "s", "v0")):
+                raise NotImplementedError("the sigmoid's r_max / s / v0 are trained on one GPU only")
             v_in = self_._y_grad
             if v_in is None:
                 v_in = pop.v.detach().clone().requires_grad_(self_._y_requires_grad)

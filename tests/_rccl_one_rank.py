@@ -1,5 +1,5 @@
 """Child process of tests/test_rccl_inlib.py: a one-rank RCCL group on cuda:0.  Checks that the in-library exchange
-(rp_forward_sharded / rp_rate_backward_sharded, RCCL calls enqueued by the C loop) gives the same bits as the
+(rp_forward_sharded / rp_backward_sharded, RCCL calls enqueued by the C loop) gives the same bits as the
 unsharded library call and the same results as the torch.distributed per-step path.  Prints RCCL_INLIB_OK."""
 import os
 import sys

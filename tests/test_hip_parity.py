@@ -378,3 +378,60 @@ def test_sharded_adjoint_steps_and_rect_gemm_bit_exact(oracle_backend, hip_devic
     for a, b_, name in zip(res[0], res[1], ("z_full", "lambda", "u_traj", "grad_tau", "grad_k", "grad_eta", "grad_x", "dW")):
         assert_same(a, b_, f"sharded {name}")
     assert float(res[0][7].abs().max()) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["qif", "ik"])
+def test_sharded_spiking_adjoint_bit_exact(oracle_backend, hip_device, model):
+    """The step-wise sharded adjoint of the spiking models (rp_bwd_prepare / partial / apply dispatching to the spiking
+    kernels) on one row shard: HIP == oracle, bit for bit.  The reduce-scatter is emulated by the shard's own slice."""
+    N, T, Pn, p = 1024, 20, 4, 2
+    rows, row0 = N // Pn, (N // Pn) * p
+    gen = torch.Generator().manual_seed(91)
+    rnd = lambda lo, hi, n=rows: torch.rand(n, generator=gen) * (hi - lo) + lo
+    W = torch.rand(rows, N, generator=gen) * 10.0 / N
+    if model == "qif":
+        params = dict(tau=rnd(0.8, 1.2), k=rnd(0.8, 1.2), eta=rnd(-6, -4), tau_s=rnd(0.5, 1.5))
+        kw = dict(v0=rnd(-5, 90), s0=rnd(0, 1), theta=100.0, v_reset=-100.0)
+        dt, x, names = 1e-3, 15.0 + torch.randn(T, 1, generator=gen), ("tau", "k", "eta", "tau_s")
+    else:
+        params = dict(C=rnd(90, 110), k=rnd(0.6, 0.8), v_r=-60.0, v_theta=-40.0, eta=rnd(-5, 5), g=rnd(0.8, 1.2), E_r=0.0,
+                      b=rnd(-2.5, -1.5), tau_u=rnd(30, 36), kappa=rnd(8, 12), tau_s=rnd(5, 7))
+        kw = dict(v0=rnd(-60, 38), s0=rnd(0, 0.5), aux0=rnd(0, 20), theta=40.0, v_reset=-55.0)
+        dt, x = 1e-1, 120.0 + 5 * torch.randn(T, rows, generator=gen)
+        names = ("C", "k", "eta", "tau_s", "g", "b", "tau_u", "kappa", "v_r", "v_theta", "E_r")
+    s_full = torch.rand(T + 1, N, generator=gen) * 0.5
+    g_out = torch.randn(T, rows, generator=gen) * 0.1
+    l0 = [torch.randn(rows, generator=gen) * 0.01 for _ in range(3)]
+
+    class OwnSlice:  # stands in for the cross-rank reduce-scatter
+        comm = None
+
+        @staticmethod
+        def reduce_scatter(z_full, z_local):
+            z_local.copy_(z_full[row0:row0 + rows])
+
+    res = []
+    for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+        pop = Population(model, W, params, dt, dev, n=N, row0=row0, backend=backend, **kw)
+        tv, ts, ta, tx, ut, gx = (torch.zeros(T, rows, device=dev) for _ in range(6))
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        ev = torch.zeros(rows * T, 2, dtype=torch.int32, device=dev)
+        for t in range(T):  # the other shards' slices of s come from outside (all-gather)
+            own = pop.source_local.clone()
+            pop.source.copy_(s_full[t].to(dev))
+            pop.set_source_local(own)
+            pop.forward(1, x=x[t:t + 1].to(dev), save_v=tv[t:t + 1], save_src=ts[t:t + 1], save_acc=ta[t:t + 1],
+                        save_aux=tx[t:t + 1] if pop.aux is not None else None, spike_events=ev, spike_count=cnt, step0=t)
+        lv, ls, lx = (t_.clone().to(dev) for t_ in l0)
+        grads = {q: torch.zeros(rows, device=dev) for q in names}
+        keep = pop.backward(tv, ts, g_out.to(dev), _abi.RP_OUT_SOURCE, lv, ut, traj_acc=ta, grad_x=gx, lam_s=ls, slope=0.7,
+                            x=x.to(dev), traj_aux=tx if pop.aux is not None else None,
+                            lam_x=lx if pop.aux is not None else None, grad_params=grads, exchange=OwnSlice)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        res.append(([lv, ls, lx, ut, gx] + [grads[q] for q in names], int(cnt.item())))
+        del keep
+    assert res[0][1] == res[1][1] and res[0][1] > 0, "the window must contain spikes"
+    for a, b_, name in zip(res[0][0], res[1][0], ["lambda_v", "lambda_s", "lambda_aux", "u_traj", "grad_x"] + list(names)):
+        assert_same(a, b_, f"sharded {model} {name}")

@@ -1,4 +1,4 @@
-"""In-library RCCL exchange (rp_forward_sharded / rp_rate_backward_sharded) on the GPU box: one-rank RCCL group in a
+"""In-library RCCL exchange (rp_forward_sharded / rp_backward_sharded) on the GPU box: one-rank RCCL group in a
 child process (the default process group must not leak into the other tests).  Multi-rank arithmetic is covered by the
 gloo tests in test_sharded.py; this one pins the RCCL call path itself (communicator hand-over, in-place all-gather,
 reduce-scatter, stream ordering) against the unsharded library call."""
