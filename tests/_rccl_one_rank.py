@@ -77,6 +77,34 @@ def main():
         scale = np.abs(c[key]).max()
         assert np.abs(a[key] - c[key]).max() <= 2e-6 * scale + 1e-7, f"sharded vs unsharded fit differ in {key}"
     assert np.abs(a["W"] - W.numpy()).max() > 0, "training did not change the weights"
+
+    # ---- spiking population: surrogate-gradient BPTT, in-library exchange vs torch.distributed vs unsharded ----
+    QIF = "neuron_model_templates.spiking_neurons.qif.qif"
+    Wq = (W.abs() * 2).numpy()
+    uq = (u + 15.0).numpy()
+
+    def fit_qif(cls, host_collectives):
+        os.environ["RECTIPY_AMD_HOST_COLLECTIVES"] = "1" if host_collectives else "0"
+        net = cls(1e-2, device="cuda:0")
+        node = net.add_diffeq_node("rnn", QIF, weights=Wq, source_var="qif_op/s", target_var="qif_op/s_in",
+                                   input_var="qif_op/I_ext", output_var="qif_op/s", spike_var="qif_op/spike",
+                                   reset_var="qif_op/v", spike_threshold=5.0, spike_reset=-5.0, dtype=torch.float32,
+                                   train_params=["weights", "qif_op/eta"],
+                                   node_vars={"all/qif_op/eta": (-5.0 + params["eta"]).numpy(), "all/qif_op/v": v0.numpy()})
+        net.add_func_node("out", 2, "identity")
+        edge = net.add_edge("rnn", "out", weights=W_out.numpy(), train="gd")
+        node.enable_spike_recording(1 << 16)
+        net.fit_bptt(uq, tgt.numpy(), optimizer="sgd", lr=0.05, update_steps=20, sampling_steps=1, verbose=False)
+        torch.cuda.synchronize()
+        assert len(node.spikes()) > 0, "the QIF window must contain spikes"
+        return {"W": node["weights"].detach().cpu().numpy().copy(), "eta": node["qif_op/eta"].detach().cpu().numpy().copy(),
+                "W_out": edge.weights.detach().cpu().numpy().copy()}
+
+    a, b, c = fit_qif(ShardedNetwork, False), fit_qif(ShardedNetwork, True), fit_qif(Network, True)
+    for key in a:
+        assert np.array_equal(a[key], b[key]), f"QIF: in-library vs torch.distributed exchange differ in {key}"
+        assert np.abs(a[key] - c[key]).max() <= 1e-5 * max(1.0, np.abs(c[key]).max()), f"QIF sharded vs unsharded: {key}"
+    assert np.abs(a["W"] - Wq).max() > 0
     dist.destroy_process_group()
     print("RCCL_INLIB_OK", flush=True)
 
