@@ -127,7 +127,7 @@ class _ShardedRateWindow(torch.autograd.Function):
               dW_p = dt U_p^T R (rows x n) is local: one rectangular MFMA GEMM per window."""
 
     @staticmethod
-    def forward(ctx, node, net, steps, x, v_in, W, tau, k, eta):
+    def forward(ctx, node, net, steps, x, v_in, W, tau, k, eta, *act):
         pop = node._pop
         rows, n, dev = pop.rows, pop.n, pop.device
         row0 = pop.row0
@@ -159,7 +159,9 @@ class _ShardedRateWindow(torch.autograd.Function):
         rows, n, dev = pop.rows, pop.n, pop.device
         traj_v, traj_r, traj_r_full, traj_acc = ctx.saved
         f32 = dict(dtype=torch.float32, device=dev)
-        need = ctx.needs_input_grad  # (node, net, steps, x, v_in, W, tau, k, eta)
+        need = ctx.needs_input_grad  # (node, net, steps, x, v_in, W, tau, k, eta, *act)
+        act_names = ("r_max", "s", "v0")[:len(need) - 9]
+        g_act = {q: torch.zeros(rows, **f32) for i, q in enumerate(act_names) if need[9 + i]}
         lam = torch.zeros(rows, **f32) if g_vend is None else g_vend.detach().to(**f32).clone().contiguous()
         g_out = None if g_traj is None else g_traj.detach().to(**f32).contiguous()
         u_traj = torch.empty(T, rows, **f32)
@@ -168,7 +170,7 @@ class _ShardedRateWindow(torch.autograd.Function):
         g_eta = torch.zeros(rows, **f32) if need[8] else None
         g_x = torch.empty(T, rows, **f32) if need[3] else None
         keep = pop.backward(traj_v, traj_r, g_out, node._out_code, lam, u_traj, traj_acc=traj_acc, grad_tau=g_tau,
-                            grad_k=g_k, grad_eta=g_eta, grad_x=g_x, exchange=_Exchange(net))
+                            grad_k=g_k, grad_eta=g_eta, grad_x=g_x, grad_params=g_act, exchange=_Exchange(net))
         g_W = None
         if need[5]:
             g_W = torch.zeros(rows, n, **f32)
@@ -178,7 +180,8 @@ class _ShardedRateWindow(torch.autograd.Function):
             g_x = g_x.sum(dim=1, keepdim=True)
             dist.all_reduce(g_x, group=net.group)  # a broadcast input feeds every shard
         del keep
-        return None, None, None, g_x, (lam if need[4] else None), g_W, g_tau, g_k, g_eta
+        return (None, None, None, g_x, (lam if need[4] else None), g_W, g_tau, g_k, g_eta) + \
+            tuple(g_act.get(q) for q in act_names)
 
 
 class _Exchange:
@@ -362,13 +365,12 @@ class ShardedNetwork(Network):
                 tv, ts, ta, _ = self_._last_window
                 self_._y_prev = self_._pack(tv[-1], ts[-1], None if ta is None else ta[-1])
                 return traj
-            if pop.model == "li_sigmoid" and any(pop.params[q].requires_grad for q in ("r_max", "s", "v0")):
-                raise NotImplementedError("the sigmoid's r_max / s / v0 are trained on one GPU only")
             v_in = self_._y_grad
             if v_in is None:
                 v_in = pop.v.detach().clone().requires_grad_(self_._y_requires_grad)
+            act = [pop.params[q] for q in ("r_max", "s", "v0")] if pop.model == "li_sigmoid" else []
             traj, v_end = _ShardedRateWindow.apply(self_, net, steps, x, v_in, pop.W, pop.params["tau"], pop.params["k"],
-                                                   pop.params["eta"])
+                                                   pop.params["eta"], *act)
             self_._y_grad = v_end
             return traj
 

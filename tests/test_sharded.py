@@ -314,3 +314,55 @@ def test_sharded_spiking_fit_bptt_matches_single_process(tmp_path, oracle_backen
     assert np.abs(W_out_sh - edge.weights.detach().numpy()).max() < 1e-5
     for p in parts:
         assert np.abs(p["loss"] - obs.to_numpy("loss")).max() < 1e-5 * max(1.0, np.abs(obs.to_numpy("loss")).max())
+
+
+SIGMOID = "neuron_model_templates.rate_neurons.leaky_integrator.sigmoid"
+
+
+def _sig_build(cls, where):
+    W, params, v0, x = _data()
+    g = torch.Generator().manual_seed(31)
+    act = dict(r_max=torch.rand(N, generator=g) + 0.5, s=torch.rand(N, generator=g) * 2 + 0.5, v0=torch.randn(N, generator=g) * 0.2)
+    W_out = (torch.randn(2, N, generator=g) / N ** 0.5).numpy()
+    tgt = (torch.randn(T, 2, generator=g) * 0.1).numpy()
+    net = cls(1e-2, **where)
+    nv = {f"all/li_op/{q}": params[q].numpy() for q in ("tau", "k", "eta")}
+    nv.update({f"all/sigmoid_op/{q}": act[q].numpy() for q in act})
+    nv["all/li_op/v"] = v0.numpy()
+    node = net.add_diffeq_node("rnn", SIGMOID, weights=W.numpy(), source_var="sigmoid_op/r", target_var="li_op/r_in",
+                               input_var="li_op/I_ext", output_var="sigmoid_op/r", dtype=torch.float32, node_vars=nv,
+                               train_params=["weights", "sigmoid_op/r_max", "sigmoid_op/s", "sigmoid_op/v0"])
+    net.add_func_node("out", 2, "identity")
+    edge = net.add_edge("rnn", "out", weights=W_out, train="gd")
+    return net, node, edge, x[:, :1].numpy().copy(), tgt
+
+
+def _sig_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from oracle.backend import OracleBackend
+        from rectipy_amd.sharded import ShardedNetwork
+        net, node, edge, x, tgt = _sig_build(ShardedNetwork, dict(device="cpu", backend=OracleBackend()))
+        net.fit_bptt(x, tgt, optimizer="sgd", lr=5e-2, update_steps=15, sampling_steps=1, verbose=False)
+        np.savez(os.path.join(out_dir, f"sig_{rank}.npz"), W=node["weights"].detach().numpy(),
+                 **{q: node[f"sigmoid_op/{q}"].detach().numpy() for q in ("r_max", "s", "v0")})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_fit_bptt_trains_the_sigmoid_parameters(tmp_path, oracle_backend):
+    from rectipy_amd import Network
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sig_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    net, node, edge, x, tgt = _sig_build(Network, dict(device="cpu", backend=oracle_backend))
+    before = {q: node[f"sigmoid_op/{q}"].detach().numpy().copy() for q in ("r_max", "s", "v0")}
+    net.fit_bptt(x, tgt, optimizer="sgd", lr=5e-2, update_steps=15, sampling_steps=1, verbose=False)
+    parts = [np.load(tmp_path / f"sig_{r}.npz") for r in range(WORLD)]
+    assert np.abs(np.concatenate([p["W"] for p in parts], axis=0) - node["weights"].detach().numpy()).max() < 1e-6
+    for q in ("r_max", "s", "v0"):
+        got = np.concatenate([p[q] for p in parts])
+        assert np.abs(got - node[f"sigmoid_op/{q}"].detach().numpy()).max() < 2e-6, q
+        assert np.abs(got - before[q]).max() > 1e-7, f"{q} was not trained"
