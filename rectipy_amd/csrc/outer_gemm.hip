@@ -68,8 +68,23 @@ __global__ __launch_bounds__(kThreads) void outer_accum_kernel(int m, int n, int
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (n + BN - 1) / BN;
-    const int i0 = (blockIdx.x / tiles_n) * BM;
-    const int j0 = (blockIdx.x % tiles_n) * BN;
+    const int tiles_m = (m + BM - 1) / BM;
+    int ti, tj;
+    if (((tiles_m | tiles_n) & 7) == 0 && (((tiles_m >> 3) * (tiles_n >> 3)) & 7) == 0) {
+        // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with its own L2.  Give
+        // every XCD whole 8 x 8 super-tiles of output tiles in sequence, so that the ~64 tiles resident on an XCD at a
+        // time share 8 A panels and 8 B panels and walk the reduction dimension roughly in step.
+        const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+        const int super = (l >> 6) * 8 + xcd, w = l & 63;
+        const int super_n = tiles_n >> 3;
+        ti = (super / super_n) * 8 + (w >> 3);
+        tj = (super % super_n) * 8 + (w & 7);
+    } else {
+        ti = blockIdx.x / tiles_n;
+        tj = blockIdx.x % tiles_n;
+    }
+    const int i0 = ti * BM;
+    const int j0 = tj * BN;
 
     f32x16 acc[2][2];
 #pragma unroll

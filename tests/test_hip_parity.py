@@ -435,3 +435,25 @@ def test_sharded_spiking_adjoint_bit_exact(oracle_backend, hip_device, model):
     assert res[0][1] == res[1][1] and res[0][1] > 0, "the window must contain spikes"
     for a, b_, name in zip(res[0][0], res[1][0], ["lambda_v", "lambda_s", "lambda_aux", "u_traj", "grad_x"] + list(names)):
         assert_same(a, b_, f"sharded {model} {name}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,T", [(1024, 8192, 6), (4096, 4096, 5)])
+def test_outer_accum_xcd_tile_order_bit_exact(oracle_backend, hip_device, m, n, T):
+    """Sizes at which the GEMM uses the XCD-aware tile order (8 x 8 super-tiles dealt to the 8 XCDs): which workgroup
+    computes which tile must not change a bit, and every tile must be computed exactly once."""
+    gen = torch.Generator().manual_seed(m + n + T)
+    A = torch.randn(T, m, generator=gen)
+    B = torch.randn(T, n, generator=gen)
+    C0 = torch.randn(m, n, generator=gen)
+    res = []
+    for be, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+        if be is None:
+            from rectipy_amd.engine import HipBackend
+            be = HipBackend()
+        a, b_, c = A.to(dev).contiguous(), B.to(dev).contiguous(), C0.clone().to(dev)
+        be.outer_accum_rect(m, n, T, 0.37, a.data_ptr(), m, b_.data_ptr(), n, c.data_ptr(), n, torch.device(dev))
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        res.append(c)
+    assert_same(res[0], res[1], f"outer_accum_rect {m}x{n} T={T}")
