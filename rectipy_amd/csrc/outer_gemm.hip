@@ -20,15 +20,16 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int BM = 128, BN = 128, BK = 16;  // BK = 32 measured 2.5 % slower (scripts/bench_gemm.py)
+constexpr int REPS = BK / 8;  // 256 threads move 8 rows x 128 columns per repetition
 constexpr int kThreads = 256;
 
 template <bool VEC4>
 __device__ __forceinline__ void load_slice(const float* __restrict__ G, int64_t ld, int n, int T, int t0, int c0,
-                                           int tid, rp_f4 (&reg)[2]) {
+                                           int tid, rp_f4 (&reg)[REPS]) {
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
-        const int row = (tid >> 5) + 8 * rep;  // 0..15
+    for (int rep = 0; rep < REPS; ++rep) {
+        const int row = (tid >> 5) + 8 * rep;  // 0..BK-1
         const int c = c0 + 4 * (tid & 31);
         const int t = t0 + row;
         rp_f4 v = {0.f, 0.f, 0.f, 0.f};
@@ -47,9 +48,9 @@ __device__ __forceinline__ void load_slice(const float* __restrict__ G, int64_t 
     }
 }
 
-__device__ __forceinline__ void store_slice(float* S, int tid, const rp_f4 (&reg)[2]) {
+__device__ __forceinline__ void store_slice(float* S, int tid, const rp_f4 (&reg)[REPS]) {
 #pragma unroll
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < REPS; ++rep) {
         const int row = (tid >> 5) + 8 * rep;
         *reinterpret_cast<rp_f4*>(S + row * BM + 4 * (tid & 31)) = reg[rep];
     }
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(kThreads) void outer_accum_kernel(int m, int n, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    rp_f4 ra[2], rb[2];
+    rp_f4 ra[REPS], rb[REPS];
     load_slice<VEC4>(A, lda, m, T, 0, i0, tid, ra);
     load_slice<VEC4>(B, ldb, n, T, 0, j0, tid, rb);
 
