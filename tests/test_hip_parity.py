@@ -457,3 +457,42 @@ def test_outer_accum_xcd_tile_order_bit_exact(oracle_backend, hip_device, m, n, 
             torch.cuda.synchronize()
         res.append(c)
     assert_same(res[0], res[1], f"outer_accum_rect {m}x{n} T={T}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["li_tanh", "qif"])
+def test_long_run_stays_bit_exact(oracle_backend, hip_device, model):
+    """3000 consecutive steps (chaotic regime for tanh, thousands of spikes for QIF): the HIP state, the sampled
+    output and the spike events equal the oracle's bit for bit at the end -- no drift, no order-dependent sums."""
+    N, T = 520, 3000
+    gen = torch.Generator().manual_seed(12)
+    if model == "li_tanh":
+        W, params, v0 = make_li(N, seed=5)
+        kw, dt = dict(v0=v0), 1e-2
+        x = torch.sin(torch.arange(T) * 0.01).reshape(-1, 1)
+    else:
+        W = torch.rand(N, N, generator=gen) * 20.0 / N
+        params = dict(tau=1.0, k=1.0, eta=-5.0 + torch.randn(N, generator=gen), tau_s=1.0)
+        kw, dt = dict(v0=-2.0, s0=0.0, theta=100.0, v_reset=-100.0), 1e-3
+        x = torch.full((T, 1), 15.0)
+    res = []
+    for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+        pop = Population(model, W, params, dt, dev, backend=backend, **kw)
+        samples = torch.zeros(T // 50 + 2, N, device=dev)
+        ev = torch.zeros(1 << 16, 2, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        extra = dict(spike_events=ev, spike_count=cnt) if model == "qif" else {}
+        n_s = pop.forward(T, x=x.to(dev), out_var=_abi.RP_OUT_SOURCE, sampling_steps=50, samples=samples, **extra)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        c = int(cnt.item())
+        events = ev[:c].cpu().numpy()
+        events = events[np.lexsort((events[:, 1], events[:, 0]))]  # the GPU appends a step's spikes in any order
+        res.append((pop.v.cpu(), pop.source.cpu(), samples[:n_s].cpu(), events))
+    for a, b_, name in zip(res[0][:3], res[1][:3], ("v", "source", "samples")):
+        assert_same(a, b_, f"{model} after {T} steps: {name}")
+    assert np.array_equal(res[0][3], res[1][3])
+    if model == "qif":
+        assert len(res[0][3]) > 500, "expected an actively spiking network"
+    else:
+        assert float(res[0][0].abs().max()) > 0.1
