@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 4
+#define RP_ABI_VERSION 5
 
 #define RP_OK 0
 #define RP_ERR_ARG (-1)      /* null pointer, bad enum, bad flag combination  */
@@ -138,6 +138,13 @@ typedef struct rp_net {
     float theta;              /* QIF spike threshold (nodes.py:338)           */
     float v_reset;            /* QIF reset value     (nodes.py:338)           */
     float* scratch;           /* device scratch [>= 4 floats]; required by IKU / IK_BIEXP (population means) */
+    /* Optional packed form of a FIXED coupling matrix (the reference multiplies its p = 0.1 random matrices densely,
+       rectipy/utility.py:153-178): per row and per slot s = 4*lane + component only the nonzeros, in the order the
+       dense kernel visits them, so that rp_forward gives bit-identical results while streaming 6 bytes per stored
+       entry (layout: rectipy_amd/sparse.py; n % 4 == 0).  When sp_vals is non-null rp_forward reads it, not W. */
+    const float* sp_vals;     /* [groups x 256] values, 0.0 where a slot has fewer entries than its row's longest    */
+    const uint16_t* sp_cidx;  /* [groups x 256] column chunk m of each entry (column = 256 m + s)                    */
+    const int32_t* sp_rowoff; /* [rows + 1] first group of each row                                                  */
 } rp_net;
 
 /*

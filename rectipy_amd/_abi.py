@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 4
+RP_ABI_VERSION = 5
 
 RP_OK = 0
 RP_ERR_ARG = -1
@@ -59,6 +59,9 @@ class RpNet(C.Structure):
         ("theta", C.c_float),
         ("v_reset", C.c_float),
         ("scratch", fp),
+        ("sp_vals", fp),
+        ("sp_cidx", fp),
+        ("sp_rowoff", fp),
     ]
 
 

@@ -58,6 +58,10 @@ struct StepParams {
     int spike_capacity;
     int* spike_count;
     int t_abs;
+    // packed W (rp_net.sp_*): streamed instead of W when non-null
+    const float* sp_vals;
+    const uint16_t* sp_cidx;
+    const int32_t* sp_rowoff;
 };
 
 // ---- row dot products (rp_dot.h) ---------------------------------------------
@@ -230,6 +234,123 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepParams P) {
     }
 }
 
+// ---- packed-W step (rp_net.sp_*) --------------------------------------------------------------------------------
+// Same arithmetic as step_kernel's 16-byte path, streaming only the stored nonzeros: lane l still owns the slots
+// 4l..4l+3 of a row; group k of the row holds, per slot, the k-th nonzero that the dense kernel would have met (value +
+// its column chunk m), so every accumulator sees the same fmaf sequence and the result is bit-identical.  One row per
+// wave at a time, U groups (1.5 KiB each) in flight.  The source vector is gathered per entry: from LDS when it fits
+// (n <= 32768: one 1024-thread workgroup per CU keeps all of it, stored with a per-64-block rotation by
+// (column >> 6) & 3 so that the 64 lanes of a gather hit 64 different banks whatever their chunks), else from L2.
+constexpr int kSparseThreads = 1024;
+constexpr int kSparseLdsMaxN = 32768;
+
+template <int MODEL, bool LDS_SRC, int U>
+__global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepParams P) {
+    extern __shared__ float lds_src[];
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    constexpr int kWaves = kSparseThreads / RP_WAVE;
+    int pos[4];  // this lane's four slots inside a 256-column chunk (rotated layout in LDS, plain in global memory)
+    if constexpr (LDS_SRC) {
+        for (int c4 = threadIdx.x * 4; c4 < P.n; c4 += kSparseThreads * 4) {
+            const rp_f4 v = rp_ld4(P.src_cur + c4);
+            const int base = c4 & ~63, h = (c4 >> 6) & 3, o = c4 & 63;
+            lds_src[base | ((o + 0 + h) & 63)] = v.x;
+            lds_src[base | ((o + 1 + h) & 63)] = v.y;
+            lds_src[base | ((o + 2 + h) & 63)] = v.z;
+            lds_src[base | ((o + 3 + h) & 63)] = v.w;
+        }
+        __syncthreads();
+        const int h = lane >> 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pos[c] = 64 * h + ((4 * (lane & 15) + c + h) & 63);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) pos[c] = 4 * lane + c;
+    }
+    const float* xs = LDS_SRC ? lds_src : P.src_cur;
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    for (int row = blockIdx.x * kWaves + wave; row < P.rows; row += gridDim.x * kWaves) {
+        const int g0 = P.sp_rowoff[row], g1 = P.sp_rowoff[row + 1];
+        const float* vp = P.sp_vals + (int64_t)g0 * 256 + 4 * lane;
+        const uint16_t* ip = P.sp_cidx + (int64_t)g0 * 256 + 4 * lane;
+        rp_f4 a = {0.f, 0.f, 0.f, 0.f};
+        int k = g0;
+        for (; k + U <= g1; k += U) {
+            rp_f4 v[U];
+            us4 m[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                v[u] = rp_ld4_stream(vp + (int64_t)u * 256);
+                m[u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(ip + (int64_t)u * 256));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                a.x = fmaf(v[u].x, xs[((int)m[u].x << 8) + pos[0]], a.x);
+                a.y = fmaf(v[u].y, xs[((int)m[u].y << 8) + pos[1]], a.y);
+                a.z = fmaf(v[u].z, xs[((int)m[u].z << 8) + pos[2]], a.z);
+                a.w = fmaf(v[u].w, xs[((int)m[u].w << 8) + pos[3]], a.w);
+            }
+            vp += (int64_t)U * 256;
+            ip += (int64_t)U * 256;
+        }
+        for (; k < g1; ++k) {
+            const rp_f4 v = rp_ld4_stream(vp);
+            const us4 m = __builtin_nontemporal_load(reinterpret_cast<const us4*>(ip));
+            a.x = fmaf(v.x, xs[((int)m.x << 8) + pos[0]], a.x);
+            a.y = fmaf(v.y, xs[((int)m.y << 8) + pos[1]], a.y);
+            a.z = fmaf(v.z, xs[((int)m.z << 8) + pos[2]], a.z);
+            a.w = fmaf(v.w, xs[((int)m.w << 8) + pos[3]], a.w);
+            vp += 256;
+            ip += 256;
+        }
+        const float sum = rp_wave_allreduce(rp_lane_sum4(a));
+        if (lane == 0) epilogue<MODEL>(P, row, sum);
+    }
+}
+
+template <int MODEL>
+int launch_step_sparse(const StepParams& P, hipStream_t st) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RP_ERR_HIP;
+        n_cu = prop.multiProcessorCount;
+    }
+    constexpr int kWaves = kSparseThreads / RP_WAVE;
+    int blocks = (P.rows + kWaves - 1) / kWaves;
+    if (P.n <= kSparseLdsMaxN) {
+        if (blocks > n_cu) blocks = n_cu;  // one resident workgroup per CU owns the LDS copy of the source vector
+        const size_t lds = sizeof(float) * (size_t)((P.n + 255) & ~255);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&step_sparse_kernel<MODEL, true, 4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(float) * kSparseLdsMaxN) != hipSuccess)
+                return RP_ERR_HIP;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((step_sparse_kernel<MODEL, true, 4>), dim3(blocks), dim3(kSparseThreads), lds, st, P);
+    } else {
+        if (blocks > 2 * n_cu) blocks = 2 * n_cu;
+        hipLaunchKernelGGL((step_sparse_kernel<MODEL, false, 4>), dim3(blocks), dim3(kSparseThreads), 0, st, P);
+    }
+    return RP_OK;
+}
+
+int launch_step_sparse_model(int model, const StepParams& P, hipStream_t st) {
+    switch (model) {
+        case RP_MODEL_LI_TANH: return launch_step_sparse<RP_MODEL_LI_TANH>(P, st);
+        case RP_MODEL_LI_SIGMOID: return launch_step_sparse<RP_MODEL_LI_SIGMOID>(P, st);
+        case RP_MODEL_QIF: return launch_step_sparse<RP_MODEL_QIF>(P, st);
+        case RP_MODEL_QIF_SFA: return launch_step_sparse<RP_MODEL_QIF_SFA>(P, st);
+        case RP_MODEL_LIF: return launch_step_sparse<RP_MODEL_LIF>(P, st);
+        case RP_MODEL_IK: return launch_step_sparse<RP_MODEL_IK>(P, st);
+        case RP_MODEL_IKU: return launch_step_sparse<RP_MODEL_IKU>(P, st);
+        default: return launch_step_sparse<RP_MODEL_IK_BIEXP>(P, st);
+    }
+}
+
 // Population means of the pre-update v and of the spike input (iku_op / ik_biexp_op, ik.yaml:34-46): one block,
 // 1024 strided partial sums combined by a halving tree (mirrored by the oracle).
 __global__ __launch_bounds__(1024) void mean_kernel(const StepParams P) {
@@ -347,6 +468,9 @@ void fill_static(StepParams& P, const rp_net* net) {
     P.theta = net->theta;
     P.v_reset = net->v_reset;
     P.scratch = net->scratch;
+    P.sp_vals = net->sp_vals;
+    P.sp_cidx = net->sp_cidx;
+    P.sp_rowoff = net->sp_rowoff;
 }
 
 // Tuning override (rp_set_tuning): 0 = use the built-in choice.
@@ -511,6 +635,13 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     const bool vec4 = use_vec4(net);
     if (vec4 && (!aligned16(net->W) || !aligned16(net->src[0]) || !aligned16(net->src[1])))
         RP_FAIL(RP_ERR_ARG, "W and src buffers must be 16-byte aligned when n and ldw are multiples of 4");
+    if (net->sp_vals) {
+        if (!net->sp_cidx || !net->sp_rowoff) RP_FAIL(RP_ERR_ARG, "sp_vals given without sp_cidx / sp_rowoff");
+        if (net->n % 4 != 0) RP_FAIL(RP_ERR_SHAPE, "the packed form of W needs n %% 4 == 0 (n=%d)", net->n);
+        if (!aligned16(net->sp_vals) || (reinterpret_cast<uintptr_t>(net->sp_cidx) & 7u) || !aligned16(net->src[0]) ||
+            !aligned16(net->src[1]))
+            RP_FAIL(RP_ERR_ARG, "sp_vals / src must be 16-byte and sp_cidx 8-byte aligned");
+    }
 
     // count the samples this call produces before touching anything
     {
@@ -568,10 +699,14 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
                                         sizeof(float) * (size_t)net->n, hipMemcpyDeviceToDevice, st));
         if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP)
             hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, st, P);
-        if (vec4)
+        if (net->sp_vals) {
+            const int src_rc = launch_step_sparse_model(net->model, P, st);
+            if (src_rc != RP_OK) RP_FAIL(src_rc, "sparse step launch failed (device properties / LDS attribute)");
+        } else if (vec4) {
             launch_step_model<true>(net->model, P, st);
-        else
+        } else {
             launch_step_model<false>(net->model, P, st);
+        }
         if (comm) {  // every rank wrote rows [row0, row0 + rows) of src_next: exchange in place, same stream
             const int nrc = reinterpret_cast<all_gather_fn>(comm->all_gather)(
                 P.src_next + net->row0, P.src_next, (size_t)net->rows, kNcclFloat, comm->comm, st);

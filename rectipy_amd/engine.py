@@ -184,6 +184,7 @@ class Population:
         self.aux = self._vec(0.0 if aux0 is None else aux0) if model in HAS_AUX else None
         self.aux2 = self._vec(0.0 if aux2_0 is None else aux2_0) if model in HAS_AUX2 else None
         self._scratch = torch.zeros(4, **f32) if model in NEEDS_MEANS else None
+        self.packed = None               # PackedRows of a fixed sparse W (sparse.py); the step kernel then streams it
         self._wt = None                  # workspace for W^T (adjoint of small networks), allocated on first use
         self.transposed_adjoint = True   # False: always use the column-strip kernels (tests, measurements)
         self.spiking = model in SPIKING
@@ -223,6 +224,9 @@ class Population:
             net.y[_abi.RP_Y_AUX2] = self.aux2.data_ptr()
         if self._scratch is not None:
             net.scratch = self._scratch.data_ptr()
+        if self.packed is not None:
+            net.sp_vals, net.sp_cidx = self.packed.vals.data_ptr(), self.packed.cidx.data_ptr()
+            net.sp_rowoff = self.packed.rowoff.data_ptr()
         net.src[0] = self.src[0].data_ptr()
         net.src[1] = self.src[1].data_ptr()
         net.cur = self.cur
@@ -254,6 +258,15 @@ class Population:
         if tuple(W.shape) != (self.rows, self.n):
             raise RuntimeError(f"weights shape {tuple(W.shape)} != {(self.rows, self.n)}")
         self.W = W.contiguous()
+        if self.packed is not None:
+            self.pack_weights()
+
+    def pack_weights(self, enable: bool = True):
+        """Stream the coupling matrix in its packed sparse form from now on (forward pass only; bit-identical results,
+        see sparse.py).  The dense matrix stays in place for the adjoint kernels.  Call again after changing W."""
+        from . import sparse
+        self.packed = sparse.pack_rows(self.W, row0=self.row0) if enable else None
+        return self.packed
 
     def reset_sampling(self):
         self.acc.zero_()

@@ -166,6 +166,7 @@ class RateNet:
                 kw["aux2_0"] = values[self._aux2_name]
         else:
             kw = dict(v0=values[state_names[0]])
+        self._sparse_mode = kwargs.pop("sparse_weights", "auto")  # True | False | "auto": packed storage of a fixed W
         shard = kwargs.pop("shard", None)  # (row0, n): this node holds rows [row0, row0+rows) of an n x n matrix
         if shard is not None:
             kw.update(row0=int(shard[0]), n=int(shard[1]))
@@ -218,6 +219,28 @@ class RateNet:
             self._tensor(name).requires_grad_(True)
         self._y_grad: Optional[torch.Tensor] = None  # autograd handle of the state (same values as pop.v)
         self._y_requires_grad = len(self._train_names) >= 1  # nodes.py:89-90
+        self._maybe_pack_weights()
+
+    def _maybe_pack_weights(self):
+        """A coupling matrix that is not trained and mostly zeros (`utility.random_connectivity`, p = 0.1 in the
+        reference's examples) is streamed in its packed form: same bits out, a fraction of the bytes in (sparse.py).
+        "auto" packs when the packed stream is measurably faster (scripts/bench_sparse.py): whenever it is at most 0.8x
+        the dense bytes with the source vector in LDS (n <= 32768), at most 0.3x with the L2 gather above that."""
+        pop = self._pop
+        mode = self._sparse_mode
+        if mode is False or "weights" in self._train_names or pop.n % 4 != 0 or pop.device.type != "cuda":
+            if mode is True and pop.device.type == "cuda":
+                raise ValueError("sparse_weights=True needs an untrained matrix with n % 4 == 0")
+            return
+        if mode == "auto" and pop.n < 2048:
+            return  # a handful of 256-column chunks per row: nothing to gain
+        from . import sparse
+        if mode == "auto" and sparse.density(pop.W) > 0.5:
+            return
+        packed = pop.pack_weights()
+        limit = 0.8 if pop.n <= 32768 else 0.3
+        if mode == "auto" and packed.stored_bytes > limit * 4.0 * pop.rows * pop.n:
+            pop.pack_weights(False)
 
     def _check_trainable(self):
         ok = {"weights", "tau", "k", "eta"} | (set(_RateWindow.ACT_PARAMS) if self._pop.model == "li_sigmoid" else set())

@@ -1,0 +1,134 @@
+"""Packed storage of a fixed sparse coupling matrix (rectipy_amd/sparse.py): the layout is checked on the CPU against a
+scalar emulation of the sparse kernel's arithmetic and the oracle's dense row dot (bit for bit); on the GPU the sparse
+step kernel must reproduce the dense oracle exactly for every model family, with the LDS and the L2 gather paths."""
+import numpy as np
+import pytest
+import torch
+
+from rectipy_amd import _abi, sparse
+from rectipy_amd.engine import Population
+
+
+def random_sparse(rows, n, p, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    W = torch.randn(rows, n, generator=g) * scale
+    return W * (torch.rand(rows, n, generator=g) < p)
+
+
+def emulate_row(packed, src, i):
+    """What one wave of step_sparse_kernel computes for row i: 256 slot accumulators fed by the row's groups in order,
+    then (a0+a1)+(a2+a3) per lane and the 64-lane butterfly."""
+    vals, cidx, off = packed.vals.numpy(), packed.cidx.numpy().view(np.uint16), packed.rowoff.numpy()
+    a = np.zeros(256, dtype=np.float32)
+    slots = np.arange(256)
+    for k in range(off[i], off[i + 1]):
+        v = vals[k * 256:(k + 1) * 256]
+        x = src[(cidx[k * 256:(k + 1) * 256].astype(np.int64) << 8) + slots]
+        a = (v.astype(np.float64) * x.astype(np.float64) + a.astype(np.float64)).astype(np.float32)  # fmaf: one rounding
+    s = np.array([np.float32(np.float32(a[4 * l] + a[4 * l + 1]) + np.float32(a[4 * l + 2] + a[4 * l + 3]))
+                  for l in range(64)], dtype=np.float32)
+    for offb in (32, 16, 8, 4, 2, 1):
+        s = np.array([np.float32(s[l] + s[l ^ offb]) for l in range(64)], dtype=np.float32)
+    return s[0]
+
+
+@pytest.mark.parametrize("rows,n,row0,p", [(24, 256, 0, 0.1), (40, 1028, 8, 0.2), (16, 2052, 64, 0.05), (8, 512, 0, 1.0)])
+def test_packed_rows_reproduce_the_dense_row_dot(oracle_backend, rows, n, row0, p):
+    W = random_sparse(rows, n, p, seed=rows + n)
+    W[3] = 0.0                                   # an empty row
+    packed = sparse.pack_rows(W, row0=row0, block_rows=16)
+    off = packed.rowoff.numpy()
+    assert off[0] == 0 and off[-1] * 256 == packed.vals.numel() and (np.diff(off) >= 0).all()
+    assert off[4] == off[3]                      # the empty row stores nothing
+    assert int((packed.vals != 0).sum()) == int((W != 0).sum())
+    src = torch.randn(n + 256, generator=torch.Generator().manual_seed(1)).numpy().astype(np.float32)
+    import ctypes as C
+    lib = oracle_backend.lib
+    for i in range(rows):
+        w = np.ascontiguousarray(W[i].numpy())
+        dense = lib.oracle_row_dot(w.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), n, 1, row0 + i)
+        got = emulate_row(packed, src, i)
+        assert np.float32(dense).view(np.uint32) == np.float32(got).view(np.uint32) or (dense == 0 and got == 0), i
+
+
+def test_pack_rejects_unaligned_width():
+    with pytest.raises(ValueError):
+        sparse.pack_rows(torch.zeros(4, 10))
+
+
+MODELS = {
+    "li_tanh": (dict(tau=8.0, k=1.0, eta=0.1), dict(), 1e-2, 0.5, _abi.RP_OUT_SOURCE),
+    "qif": (dict(tau=1.0, k=1.0, eta=-5.0, tau_s=1.0), dict(v0=-2.0, s0=0.0, theta=20.0, v_reset=-20.0), 1e-2, 15.0,
+            _abi.RP_OUT_SOURCE),
+    "ik": (dict(C=100.0, k=0.7, v_r=-60.0, v_theta=-40.0, eta=0.0, g=1.0, E_r=0.0, b=-2.0, tau_u=33.33, kappa=10.0,
+                tau_s=6.0), dict(v0=-60.0, s0=0.0, aux0=0.0, theta=40.0, v_reset=-55.0), 1e-1, 120.0, _abi.RP_OUT_STATE0),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", list(MODELS))
+@pytest.mark.parametrize("rows,n,row0", [(256, 256, 0), (1028, 1028, 0), (96, 33024, 64)])
+def test_sparse_step_kernel_equals_dense_oracle(oracle_backend, hip_device, model, rows, n, row0):
+    """n <= 32768: source vector gathered from LDS (rotated layout); the 96 x 33024 shard takes the L2 gather path."""
+    params, kw, dt, drive, out_var = MODELS[model]
+    T = 600 if model == "ik" else 200
+    positive = model != "li_tanh"
+    W = random_sparse(rows, n, 0.1, seed=n + rows, scale=(20.0 / n if positive else 1.5 / (0.1 * n) ** 0.5))
+    if positive:
+        W = W.abs()
+    x = torch.full((T, 1), drive) + torch.randn(T, 1, generator=torch.Generator().manual_seed(2)) * 0.1 * abs(drive)
+    src0 = torch.rand(n, generator=torch.Generator().manual_seed(3)) * 0.5
+    res = []
+    for backend, dev, pack in ((oracle_backend, "cpu", False), (None, hip_device, True)):
+        pop = Population(model, W, params, dt, dev, n=n, row0=row0, backend=backend, **kw)
+        if pack:
+            packed = pop.pack_weights()
+            if n >= 8192:  # the slot layout needs many chunks per row (n / 256 >> 1 / density) to pay off
+                assert packed.stored_bytes < 0.4 * 4 * rows * n
+        traj = torch.zeros(T, rows, device=dev)
+        if rows == n:
+            pop.forward(T, x=x.to(dev), traj=traj, out_var=out_var)
+        else:  # a row shard: the rest of the source vector comes from outside every step
+            for t in range(T):
+                own = pop.source_local.clone()
+                pop.source.copy_(src0.to(dev) * (1 + 0.01 * t))
+                pop.set_source_local(own)
+                pop.forward(1, x=x[t:t + 1].to(dev), traj=traj[t:t + 1], out_var=out_var, step0=t)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        res.append((traj.cpu(), pop.v.cpu(), pop.source_local.cpu()))
+    for a, b, name in zip(res[0], res[1], ("trajectory", "v", "source")):
+        a, b = a.numpy(), b.numpy()
+        same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
+        assert same.all(), f"{model} {rows}x{n} {name}: {np.count_nonzero(~same)} differ, max {np.abs(a - b).max()}"
+    assert np.isfinite(res[0][0].numpy()).all() and np.abs(np.diff(res[0][0].numpy(), axis=0)).max() > 0, "no dynamics"
+    if model != "li_tanh":  # the spiking runs must actually spike: the synaptic variable s has been kicked
+        assert res[0][2].numpy().max() > 0.05, "no spikes in the window"
+
+
+@pytest.mark.gpu
+def test_front_end_packs_a_fixed_sparse_matrix_automatically(hip_device):
+    """Network.add_diffeq_node with a p = 0.1 matrix (the reference's random_connectivity use): packed automatically
+    when W is not trained, never when it is; outputs identical to the dense path, bit for bit."""
+    from rectipy_amd import Network
+    N, T = 4096, 300
+    W = random_sparse(N, N, 0.1, seed=4, scale=1.5 / (0.1 * N) ** 0.5).numpy()
+    x = torch.randn(T, 1, generator=torch.Generator().manual_seed(5)).numpy() * 0.5
+    tanh = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
+    outs = {}
+    for mode, train in (("auto", None), (False, None), ("auto", ["weights"])):
+        net = Network(1e-2, device="cuda:0")
+        node = net.add_diffeq_node("rnn", tanh, input_var="li_op/I_ext", output_var="tanh_op/r", weights=W,
+                                   source_var="tanh_op/r", target_var="li_op/r_in", dtype=torch.float32,
+                                   train_params=train, sparse_weights=mode)
+        assert (node._pop.packed is not None) == (mode == "auto" and train is None)
+        outs[(mode, bool(train))] = net.run(x, sampling_steps=10, verbose=False, enable_grad=False).to_numpy("out")
+    a, b, c = outs[("auto", False)], outs[(False, False)], outs[("auto", True)]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and np.array_equal(b.view(np.uint32), c.view(np.uint32))
+    assert np.abs(a).max() > 0.01
+    # a dense matrix is left alone
+    net = Network(1e-2, device="cuda:0")
+    node = net.add_diffeq_node("rnn", tanh, input_var="li_op/I_ext", output_var="tanh_op/r",
+                               weights=np.random.default_rng(0).standard_normal((N, N)).astype(np.float32) / N ** 0.5,
+                               source_var="tanh_op/r", target_var="li_op/r_in", dtype=torch.float32)
+    assert node._pop.packed is None
