@@ -139,11 +139,12 @@ typedef struct rp_net {
     float v_reset;            /* QIF reset value     (nodes.py:338)           */
     float* scratch;           /* device scratch [>= 4 floats]; required by IKU / IK_BIEXP (population means) */
     /* Optional packed form of a FIXED coupling matrix (the reference multiplies its p = 0.1 random matrices densely,
-       rectipy/utility.py:153-178): per row and per slot s = 4*lane + component only the nonzeros, in the order the
-       dense kernel visits them, so that rp_forward gives bit-identical results while streaming 6 bytes per stored
-       entry (layout: rectipy_amd/sparse.py; n % 4 == 0).  When sp_vals is non-null rp_forward reads it, not W. */
-    const float* sp_vals;     /* [groups x 256] values, 0.0 where a slot has fewer entries than its row's longest    */
-    const uint16_t* sp_cidx;  /* [groups x 256] column chunk m of each entry (column = 256 m + s)                    */
+       rectipy/utility.py:153-178): per row and per lane only the nonzeros of the lane's four columns per chunk, in
+       the order the dense kernel visits them, four entries per lane per group, so that rp_forward gives bit-identical
+       results while streaming 6 bytes per stored entry (layout: rectipy_amd/sparse.py; n % 4 == 0).  When sp_vals is
+       non-null rp_forward reads it, not W. */
+    const float* sp_vals;     /* [groups x 256] entry 4k+e of lane l at (group k) * 256 + 4 l + e; 0.0 = padding    */
+    const uint16_t* sp_cidx;  /* [groups x 256] code of each entry: (component << 14) | column chunk m                */
     const int32_t* sp_rowoff; /* [rows + 1] first group of each row                                                  */
 } rp_net;
 

@@ -236,13 +236,29 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepParams P) {
 
 // ---- packed-W step (rp_net.sp_*) --------------------------------------------------------------------------------
 // Same arithmetic as step_kernel's 16-byte path, streaming only the stored nonzeros: lane l still owns the slots
-// 4l..4l+3 of a row; group k of the row holds, per slot, the k-th nonzero that the dense kernel would have met (value +
-// its column chunk m), so every accumulator sees the same fmaf sequence and the result is bit-identical.  One row per
-// wave at a time, U groups (1.5 KiB each) in flight.  The source vector is gathered per entry: from LDS when it fits
-// (n <= 32768: one 1024-thread workgroup per CU keeps all of it, stored with a per-64-block rotation by
-// (column >> 6) & 3 so that the 64 lanes of a gather hit 64 different banks whatever their chunks), else from L2.
+// 4l..4l+3 of a row and keeps their four accumulators; its nonzeros come as ONE list in the order the dense kernel
+// meets them (value + code = component << 14 | column chunk), four list entries per lane per group, so every
+// accumulator sees the same fmaf sequence and the result is bit-identical.  One row per wave at a time, U groups
+// (1.5 KiB each) in flight.  The source vector is gathered per entry: from LDS when it fits (n <= 32768: one
+// 1024-thread workgroup per CU keeps all of it, stored with a per-64-block rotation by (column >> 6) & 3 so that the
+// 64 lanes of a gather hit 64 different banks whatever their chunks and components), else from L2.
 constexpr int kSparseThreads = 1024;
 constexpr int kSparseLdsMaxN = 32768;
+
+template <bool LDS_SRC>
+__device__ __forceinline__ void sparse_entry(float v, unsigned code, const float* xs, int lane_base, int lane_rot,
+                                             float& a0, float& a1, float& a2, float& a3) {
+    const int c = (int)(code >> 14), m = (int)(code & 0x3fffu);
+    // LDS: position of column 256 m + 4 l + c in the rotated layout; global: the column itself
+    const int idx = LDS_SRC ? (m << 8) + lane_base + ((lane_rot + c) & 63) : (m << 8) + lane_base + c;
+    const float x = xs[idx];
+    const float acc = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
+    const float r = fmaf(v, x, acc);
+    a0 = c == 0 ? r : a0;
+    a1 = c == 1 ? r : a1;
+    a2 = c == 2 ? r : a2;
+    a3 = c == 3 ? r : a3;
+}
 
 template <int MODEL, bool LDS_SRC, int U>
 __global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepParams P) {
@@ -250,7 +266,6 @@ __global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepP
     const int lane = threadIdx.x & (RP_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     constexpr int kWaves = kSparseThreads / RP_WAVE;
-    int pos[4];  // this lane's four slots inside a 256-column chunk (rotated layout in LDS, plain in global memory)
     if constexpr (LDS_SRC) {
         for (int c4 = threadIdx.x * 4; c4 < P.n; c4 += kSparseThreads * 4) {
             const rp_f4 v = rp_ld4(P.src_cur + c4);
@@ -261,51 +276,60 @@ __global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepP
             lds_src[base | ((o + 3 + h) & 63)] = v.w;
         }
         __syncthreads();
-        const int h = lane >> 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) pos[c] = 64 * h + ((4 * (lane & 15) + c + h) & 63);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) pos[c] = 4 * lane + c;
     }
+    // LDS: 64-column block of this lane inside a chunk and its rotated offset; global: first of its four columns
+    const int lane_base = LDS_SRC ? 64 * (lane >> 4) : 4 * lane;
+    const int lane_rot = 4 * (lane & 15) + (lane >> 4);
     const float* xs = LDS_SRC ? lds_src : P.src_cur;
     typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-    for (int row = blockIdx.x * kWaves + wave; row < P.rows; row += gridDim.x * kWaves) {
-        const int g0 = P.sp_rowoff[row], g1 = P.sp_rowoff[row + 1];
-        const float* vp = P.sp_vals + (int64_t)g0 * 256 + 4 * lane;
-        const uint16_t* ip = P.sp_cidx + (int64_t)g0 * 256 + 4 * lane;
-        rp_f4 a = {0.f, 0.f, 0.f, 0.f};
-        int k = g0;
-        for (; k + U <= g1; k += U) {
-            rp_f4 v[U];
-            us4 m[U];
+    // two rows per wave, interleaved: twice the loads in flight and two independent accumulator chains, and a short
+    // row does not leave the wave idle at its end.  Row lengths are wave-uniform, so the guards do not diverge.
+    const int pairs = (P.rows + 1) >> 1;
+    for (int pair = blockIdx.x * kWaves + wave; pair < pairs; pair += gridDim.x * kWaves) {
+        const int rowA = 2 * pair, rowB = rowA + 1;
+        const bool hasB = rowB < P.rows;
+        const int gA = P.sp_rowoff[rowA], nA = P.sp_rowoff[rowA + 1] - gA;
+        const int gB = hasB ? P.sp_rowoff[rowB] : gA, nB = hasB ? P.sp_rowoff[rowB + 1] - gB : 0;
+        const float* vA = P.sp_vals + (int64_t)gA * 256 + 4 * lane;
+        const uint16_t* iA = P.sp_cidx + (int64_t)gA * 256 + 4 * lane;
+        const float* vB = P.sp_vals + (int64_t)gB * 256 + 4 * lane;
+        const uint16_t* iB = P.sp_cidx + (int64_t)gB * 256 + 4 * lane;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+        const int nmax = nA > nB ? nA : nB;
+        for (int k = 0; k < nmax; k += U) {
+            rp_f4 va[U], vb[U];
+            us4 ma[U], mb[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                v[u] = rp_ld4_stream(vp + (int64_t)u * 256);
-                m[u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(ip + (int64_t)u * 256));
+                if (k + u < nA) {
+                    va[u] = rp_ld4_stream(vA + (int64_t)(k + u) * 256);
+                    ma[u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(iA + (int64_t)(k + u) * 256));
+                }
+                if (k + u < nB) {
+                    vb[u] = rp_ld4_stream(vB + (int64_t)(k + u) * 256);
+                    mb[u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(iB + (int64_t)(k + u) * 256));
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                a.x = fmaf(v[u].x, xs[((int)m[u].x << 8) + pos[0]], a.x);
-                a.y = fmaf(v[u].y, xs[((int)m[u].y << 8) + pos[1]], a.y);
-                a.z = fmaf(v[u].z, xs[((int)m[u].z << 8) + pos[2]], a.z);
-                a.w = fmaf(v[u].w, xs[((int)m[u].w << 8) + pos[3]], a.w);
+                if (k + u < nA) {
+                    sparse_entry<LDS_SRC>(va[u].x, ma[u].x, xs, lane_base, lane_rot, a0, a1, a2, a3);
+                    sparse_entry<LDS_SRC>(va[u].y, ma[u].y, xs, lane_base, lane_rot, a0, a1, a2, a3);
+                    sparse_entry<LDS_SRC>(va[u].z, ma[u].z, xs, lane_base, lane_rot, a0, a1, a2, a3);
+                    sparse_entry<LDS_SRC>(va[u].w, ma[u].w, xs, lane_base, lane_rot, a0, a1, a2, a3);
+                }
+                if (k + u < nB) {
+                    sparse_entry<LDS_SRC>(vb[u].x, mb[u].x, xs, lane_base, lane_rot, b0, b1, b2, b3);
+                    sparse_entry<LDS_SRC>(vb[u].y, mb[u].y, xs, lane_base, lane_rot, b0, b1, b2, b3);
+                    sparse_entry<LDS_SRC>(vb[u].z, mb[u].z, xs, lane_base, lane_rot, b0, b1, b2, b3);
+                    sparse_entry<LDS_SRC>(vb[u].w, mb[u].w, xs, lane_base, lane_rot, b0, b1, b2, b3);
+                }
             }
-            vp += (int64_t)U * 256;
-            ip += (int64_t)U * 256;
         }
-        for (; k < g1; ++k) {
-            const rp_f4 v = rp_ld4_stream(vp);
-            const us4 m = __builtin_nontemporal_load(reinterpret_cast<const us4*>(ip));
-            a.x = fmaf(v.x, xs[((int)m.x << 8) + pos[0]], a.x);
-            a.y = fmaf(v.y, xs[((int)m.y << 8) + pos[1]], a.y);
-            a.z = fmaf(v.z, xs[((int)m.z << 8) + pos[2]], a.z);
-            a.w = fmaf(v.w, xs[((int)m.w << 8) + pos[3]], a.w);
-            vp += 256;
-            ip += 256;
-        }
-        const float sum = rp_wave_allreduce(rp_lane_sum4(a));
-        if (lane == 0) epilogue<MODEL>(P, row, sum);
+        const float sumA = rp_wave_allreduce((a0 + a1) + (a2 + a3));
+        const float sumB = rp_wave_allreduce((b0 + b1) + (b2 + b3));
+        if (lane == 0) epilogue<MODEL>(P, rowA, sumA);
+        if (lane == 1 && hasB) epilogue<MODEL>(P, rowB, sumB);
     }
 }
 
@@ -319,7 +343,7 @@ int launch_step_sparse(const StepParams& P, hipStream_t st) {
         n_cu = prop.multiProcessorCount;
     }
     constexpr int kWaves = kSparseThreads / RP_WAVE;
-    int blocks = (P.rows + kWaves - 1) / kWaves;
+    int blocks = ((P.rows + 1) / 2 + kWaves - 1) / kWaves;
     if (P.n <= kSparseLdsMaxN) {
         if (blocks > n_cu) blocks = n_cu;  // one resident workgroup per CU owns the LDS copy of the source vector
         const size_t lds = sizeof(float) * (size_t)((P.n + 255) & ~255);

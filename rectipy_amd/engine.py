@@ -225,7 +225,7 @@ class Population:
         if self._scratch is not None:
             net.scratch = self._scratch.data_ptr()
         if self.packed is not None:
-            net.sp_vals, net.sp_cidx = self.packed.vals.data_ptr(), self.packed.cidx.data_ptr()
+            net.sp_vals, net.sp_cidx = self.packed.vals.data_ptr(), self.packed.code.data_ptr()
             net.sp_rowoff = self.packed.rowoff.data_ptr()
         net.src[0] = self.src[0].data_ptr()
         net.src[1] = self.src[1].data_ptr()

@@ -224,8 +224,8 @@ class RateNet:
     def _maybe_pack_weights(self):
         """A coupling matrix that is not trained and mostly zeros (`utility.random_connectivity`, p = 0.1 in the
         reference's examples) is streamed in its packed form: same bits out, a fraction of the bytes in (sparse.py).
-        "auto" packs when the packed stream is measurably faster (scripts/bench_sparse.py): whenever it is at most 0.8x
-        the dense bytes with the source vector in LDS (n <= 32768), at most 0.3x with the L2 gather above that."""
+        "auto" packs when the packed stream is measurably faster (scripts/bench_sparse.py): when it is at most 0.6x the
+        dense bytes with the source vector in LDS (n <= 32768), at most 0.25x with the L2 gather above that."""
         pop = self._pop
         mode = self._sparse_mode
         if mode is False or "weights" in self._train_names or pop.n % 4 != 0 or pop.device.type != "cuda":
@@ -238,7 +238,7 @@ class RateNet:
         if mode == "auto" and sparse.density(pop.W) > 0.5:
             return
         packed = pop.pack_weights()
-        limit = 0.8 if pop.n <= 32768 else 0.3
+        limit = 0.6 if pop.n <= 32768 else 0.25
         if mode == "auto" and packed.stored_bytes > limit * 4.0 * pop.rows * pop.n:
             pop.pack_weights(False)
 

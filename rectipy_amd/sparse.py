@@ -4,14 +4,16 @@ The reference multiplies densely even when `utility.random_connectivity(p=0.1)` 
 (rectipy/utility.py:153-178), so a step streams 4 n^2 bytes of mostly zeros.  The dense step kernel gives every
 (lane l, component c) of a wave the columns 256 m + 4 l + c of a row and accumulates them in a fixed chunk order
 (DESIGN.md "Summation order"); a zero entry leaves that accumulator untouched (fma(0, r, a) == a).  The packed layout
-therefore keeps, per row and per slot s = 4 l + c, only the nonzeros IN THAT SAME ORDER:
+therefore keeps, per row and per LANE, only the nonzeros of the lane's four components, in the order the dense kernel
+meets them (chunk order of that row; inside a chunk c = 0..3), four entries per lane per group:
 
-    vals[(rowoff[i] + k) * 256 + s]   k-th nonzero of slot s of row i (0.0 where the slot has fewer than L_i entries)
-    cidx[(rowoff[i] + k) * 256 + s]   its column chunk m (uint16), i.e. column = 256 m + s
-    rowoff[i + 1] - rowoff[i] = L_i   the largest number of nonzeros any slot of row i holds
+    vals[(rowoff[i] + k) * 256 + 4 l + e]   entry 4 k + e of lane l of row i (0.0 past the end of the lane's list)
+    code[(rowoff[i] + k) * 256 + 4 l + e]   (c << 14) | m : its component and column chunk, column = 256 m + 4 l + c
+    rowoff[i + 1] - rowoff[i] = L_i          ceil(longest lane list of row i / 4)
 
-so the sparse step kernel reproduces the dense result bit for bit while streaming 6 bytes per stored entry.
-Only the 16-byte path (n % 4 == 0) has a packed form.
+Each of the 256 accumulators of a row still receives exactly its own nonzeros in the dense order, so the sparse step
+kernel reproduces the dense result bit for bit while streaming 6 bytes per stored entry.  Only the 16-byte path
+(n % 4 == 0) has a packed form; chunk indices take 14 bits (n < 4.2 million).
 """
 from typing import NamedTuple
 
@@ -22,7 +24,7 @@ STAGGER = 3  # kStagger of rp_dot.h: start chunk m0 = (3 * (global_row >> 3)) mo
 
 class PackedRows(NamedTuple):
     vals: torch.Tensor    # float32 [groups * 256]
-    cidx: torch.Tensor    # int16 (bit pattern of uint16) [groups * 256]
+    code: torch.Tensor    # int16 (bit pattern of uint16) [groups * 256]
     rowoff: torch.Tensor  # int32 [rows + 1], in groups of 256 entries
     density: float
     stored_bytes: int
@@ -40,11 +42,12 @@ def pack_rows(W: torch.Tensor, row0: int = 0, block_rows: int = 512) -> PackedRo
     dev = W.device
     M = n >> 8                      # full 256-column chunks
     Mp = M + (1 if n & 255 else 0)  # + the partial chunk, visited last
-    if Mp > 65535:
-        raise ValueError("n too large for 16-bit chunk indices")
+    if Mp > (1 << 14):
+        raise ValueError("n too large for 14-bit chunk indices")
     lens, chunks = [], []
     nnz = 0
     q = torch.arange(Mp, device=dev)
+    comp = torch.arange(4, device=dev, dtype=torch.int32)
     for r0 in range(0, rows, block_rows):
         r1 = min(r0 + block_rows, rows)
         B = r1 - r0
@@ -57,27 +60,31 @@ def pack_rows(W: torch.Tensor, row0: int = 0, block_rows: int = 512) -> PackedRo
         m0 = (STAGGER * g) % M if M > 0 else torch.zeros_like(g)
         order = torch.where(q[None, :] < M, (m0[:, None] + q[None, :]) % max(M, 1), q[None, :])   # [B, Mp]
         Wrot = torch.gather(Wb, 1, order[:, :, None].expand(B, Mp, 256))
-        nz = Wrot != 0
-        rank = nz.cumsum(dim=1, dtype=torch.int32) - 1                                               # [B, Mp, 256]
-        L = (rank[:, -1, :] + 1).max(dim=1).values                                                   # [B]
+        # a lane's sequence: position q major, component c minor -> [B, Mp * 4, 64]
+        seq = Wrot.reshape(B, Mp, 64, 4).permute(0, 1, 3, 2).reshape(B, Mp * 4, 64)
+        nz = seq != 0
+        rank = nz.cumsum(dim=1, dtype=torch.int32) - 1                                               # [B, Mp*4, 64]
+        L = ((rank[:, -1, :] + 1).max(dim=1).values + 3) // 4                                        # groups per row
         off = torch.cumsum(L, 0) - L                                                                 # block-local
         groups = int(L.sum().item())
         vals = torch.zeros(groups * 256, dtype=torch.float32, device=dev)
-        cidx = torch.zeros(groups * 256, dtype=torch.int16, device=dev)
-        bi, qi, si = nz.nonzero(as_tuple=True)
-        flat = (off[bi].to(torch.int64) + rank[bi, qi, si].to(torch.int64)) * 256 + si
-        vals[flat] = Wrot[bi, qi, si]
-        cidx[flat] = order[bi, qi].to(torch.int32).to(torch.int16)  # values < 65536 keep their low 16 bits
+        code = torch.zeros(groups * 256, dtype=torch.int16, device=dev)
+        bi, ji, li = nz.nonzero(as_tuple=True)
+        r = rank[bi, ji, li].to(torch.int64)
+        flat = (off[bi].to(torch.int64) + r // 4) * 256 + 4 * li + r % 4
+        vals[flat] = seq[bi, ji, li]
+        word = (comp[ji % 4] << 14) | order[bi, ji // 4].to(torch.int32)
+        code[flat] = word.to(torch.int16)  # keeps the low 16 bits
         nnz += int(bi.numel())
         lens.append(L.to(torch.int32))
-        chunks.append((vals, cidx))
+        chunks.append((vals, code))
     L_all = torch.cat(lens)
     rowoff = torch.zeros(rows + 1, dtype=torch.int32, device=dev)
     rowoff[1:] = torch.cumsum(L_all, 0).to(torch.int32)
     vals = torch.cat([c[0] for c in chunks]) if chunks else torch.zeros(0, device=dev)
-    cidx = torch.cat([c[1] for c in chunks]) if chunks else torch.zeros(0, dtype=torch.int16, device=dev)
+    code = torch.cat([c[1] for c in chunks]) if chunks else torch.zeros(0, dtype=torch.int16, device=dev)
     if vals.numel() == 0:  # an all-zero matrix: keep one (unused) group so that the pointers are valid
         vals = torch.zeros(256, dtype=torch.float32, device=dev)
-        cidx = torch.zeros(256, dtype=torch.int16, device=dev)
-    return PackedRows(vals.contiguous(), cidx.contiguous(), rowoff, nnz / max(1, rows * n),
+        code = torch.zeros(256, dtype=torch.int16, device=dev)
+    return PackedRows(vals.contiguous(), code.contiguous(), rowoff, nnz / max(1, rows * n),
                       int(vals.numel()) * 6 + int(rowoff.numel()) * 4)

@@ -16,17 +16,19 @@ def random_sparse(rows, n, p, seed, scale=1.0):
 
 
 def emulate_row(packed, src, i):
-    """What one wave of step_sparse_kernel computes for row i: 256 slot accumulators fed by the row's groups in order,
-    then (a0+a1)+(a2+a3) per lane and the 64-lane butterfly."""
-    vals, cidx, off = packed.vals.numpy(), packed.cidx.numpy().view(np.uint16), packed.rowoff.numpy()
-    a = np.zeros(256, dtype=np.float32)
-    slots = np.arange(256)
+    """What one wave of step_sparse_kernel computes for row i: every lane walks its entry list (4 per group) and feeds
+    the accumulator of the entry's component; then (a0+a1)+(a2+a3) per lane and the 64-lane butterfly."""
+    vals, code, off = packed.vals.numpy(), packed.code.numpy().view(np.uint16), packed.rowoff.numpy()
+    a = np.zeros((64, 4), dtype=np.float32)
     for k in range(off[i], off[i + 1]):
-        v = vals[k * 256:(k + 1) * 256]
-        x = src[(cidx[k * 256:(k + 1) * 256].astype(np.int64) << 8) + slots]
-        a = (v.astype(np.float64) * x.astype(np.float64) + a.astype(np.float64)).astype(np.float32)  # fmaf: one rounding
-    s = np.array([np.float32(np.float32(a[4 * l] + a[4 * l + 1]) + np.float32(a[4 * l + 2] + a[4 * l + 3]))
-                  for l in range(64)], dtype=np.float32)
+        for l in range(64):
+            for e in range(4):
+                v, w = vals[k * 256 + 4 * l + e], int(code[k * 256 + 4 * l + e])
+                c, m = w >> 14, w & 0x3fff
+                x = src[256 * m + 4 * l + c]
+                a[l, c] = np.float32(np.float64(v) * np.float64(x) + np.float64(a[l, c]))  # fmaf: one rounding
+    s = np.array([np.float32(np.float32(a[l, 0] + a[l, 1]) + np.float32(a[l, 2] + a[l, 3])) for l in range(64)],
+                 dtype=np.float32)
     for offb in (32, 16, 8, 4, 2, 1):
         s = np.array([np.float32(s[l] + s[l ^ offb]) for l in range(64)], dtype=np.float32)
     return s[0]
