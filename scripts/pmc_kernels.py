@@ -36,6 +36,18 @@ torch.cuda.synchronize()
 algo["step_kernel<2"] = 4.0 * N * N + 4.0 * (8 * N + 1)
 del qif, Wq
 
+gen = torch.Generator(device=dev).manual_seed(0)
+Ws = torch.randn(N, N, device=dev, generator=gen) * (1.5 / (0.1 * N) ** 0.5)
+Ws *= torch.rand(N, N, device=dev, generator=gen) < 0.1
+sp = Population("li_tanh", Ws, dict(tau=10.0, k=1.0, eta=0.0), 1e-2, dev)
+del Ws
+packed = sp.pack_weights()
+sp.forward(T, x=x)
+torch.cuda.synchronize()
+# packed stream + the source vector staged into LDS once per CU (256 x 128 KiB, served by L2) is not HBM traffic
+algo["step_sparse_kernel"] = float(packed.stored_bytes) + 4.0 * 8 * N
+del sp, packed
+
 n_in = 16384
 edge = RLS(n_in, 3, beta=0.99).to(dev)
 X = torch.randn(6, n_in, device=dev) * 0.1
