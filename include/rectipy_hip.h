@@ -332,6 +332,10 @@ int rp_rls_sweep(const rp_rls* rls, int32_t steps, int32_t stride, const float* 
    the built-in choice.  Results are bit-identical for every configuration. */
 int rp_set_tuning(int rows_per_wave, int unroll, int nontemporal, int max_blocks);
 
+/* Benchmark-only: rows per wave and groups in flight per row of the sparse step kernel (tanh model); 0, 0 restores the
+   built-in choice.  Results are bit-identical for every configuration. */
+int rp_set_sparse_tuning(int rows_per_wave, int groups_in_flight);
+
 /* Benchmark-only: rows in flight per wave (unroll) and 1-KiB column groups per lane of the adjoint's column-strip
    kernel; 0, 0 restores the built-in choice.  Results are bit-identical for every configuration. */
 int rp_set_bwd_tuning(int unroll, int strip_groups);

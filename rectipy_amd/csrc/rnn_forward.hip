@@ -247,20 +247,21 @@ constexpr int kSparseLdsMaxN = 32768;
 
 template <bool LDS_SRC>
 __device__ __forceinline__ void sparse_entry(float v, unsigned code, const float* xs, int lane_base, int lane_rot,
-                                             float& a0, float& a1, float& a2, float& a3) {
+                                             rp_f4& a) {
+    float a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w;
     const int c = (int)(code >> 14), m = (int)(code & 0x3fffu);
     // LDS: position of column 256 m + 4 l + c in the rotated layout; global: the column itself
     const int idx = LDS_SRC ? (m << 8) + lane_base + ((lane_rot + c) & 63) : (m << 8) + lane_base + c;
     const float x = xs[idx];
     const float acc = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
     const float r = fmaf(v, x, acc);
-    a0 = c == 0 ? r : a0;
-    a1 = c == 1 ? r : a1;
-    a2 = c == 2 ? r : a2;
-    a3 = c == 3 ? r : a3;
+    a.x = c == 0 ? r : a0;
+    a.y = c == 1 ? r : a1;
+    a.z = c == 2 ? r : a2;
+    a.w = c == 3 ? r : a3;
 }
 
-template <int MODEL, bool LDS_SRC, int U>
+template <int MODEL, bool LDS_SRC, int R, int U>
 __global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepParams P) {
     extern __shared__ float lds_src[];
     const int lane = threadIdx.x & (RP_WAVE - 1);
@@ -282,55 +283,82 @@ __global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepP
     const int lane_rot = 4 * (lane & 15) + (lane >> 4);
     const float* xs = LDS_SRC ? lds_src : P.src_cur;
     typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-    // two rows per wave, interleaved: twice the loads in flight and two independent accumulator chains, and a short
-    // row does not leave the wave idle at its end.  Row lengths are wave-uniform, so the guards do not diverge.
-    const int pairs = (P.rows + 1) >> 1;
-    for (int pair = blockIdx.x * kWaves + wave; pair < pairs; pair += gridDim.x * kWaves) {
-        const int rowA = 2 * pair, rowB = rowA + 1;
-        const bool hasB = rowB < P.rows;
-        const int gA = P.sp_rowoff[rowA], nA = P.sp_rowoff[rowA + 1] - gA;
-        const int gB = hasB ? P.sp_rowoff[rowB] : gA, nB = hasB ? P.sp_rowoff[rowB + 1] - gB : 0;
-        const float* vA = P.sp_vals + (int64_t)gA * 256 + 4 * lane;
-        const uint16_t* iA = P.sp_cidx + (int64_t)gA * 256 + 4 * lane;
-        const float* vB = P.sp_vals + (int64_t)gB * 256 + 4 * lane;
-        const uint16_t* iB = P.sp_cidx + (int64_t)gB * 256 + 4 * lane;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-        const int nmax = nA > nB ? nA : nB;
-        for (int k = 0; k < nmax; k += U) {
-            rp_f4 va[U], vb[U];
-            us4 ma[U], mb[U];
+    // R consecutive rows per wave, interleaved (R * U groups in flight, R independent accumulator sets); row lengths
+    // are wave-uniform, so the guards do not diverge.  Production uses R = 1.
+    const int groups = (P.rows + R - 1) / R;
+    for (int g = blockIdx.x * kWaves + wave; g < groups; g += gridDim.x * kWaves) {
+        const int row_base = g * R;
+        const float* vp[R];
+        const uint16_t* ip[R];
+        int len[R];
+        int nmax = 0;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (k + u < nA) {
-                    va[u] = rp_ld4_stream(vA + (int64_t)(k + u) * 256);
-                    ma[u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(iA + (int64_t)(k + u) * 256));
-                }
-                if (k + u < nB) {
-                    vb[u] = rp_ld4_stream(vB + (int64_t)(k + u) * 256);
-                    mb[u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(iB + (int64_t)(k + u) * 256));
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (k + u < nA) {
-                    sparse_entry<LDS_SRC>(va[u].x, ma[u].x, xs, lane_base, lane_rot, a0, a1, a2, a3);
-                    sparse_entry<LDS_SRC>(va[u].y, ma[u].y, xs, lane_base, lane_rot, a0, a1, a2, a3);
-                    sparse_entry<LDS_SRC>(va[u].z, ma[u].z, xs, lane_base, lane_rot, a0, a1, a2, a3);
-                    sparse_entry<LDS_SRC>(va[u].w, ma[u].w, xs, lane_base, lane_rot, a0, a1, a2, a3);
-                }
-                if (k + u < nB) {
-                    sparse_entry<LDS_SRC>(vb[u].x, mb[u].x, xs, lane_base, lane_rot, b0, b1, b2, b3);
-                    sparse_entry<LDS_SRC>(vb[u].y, mb[u].y, xs, lane_base, lane_rot, b0, b1, b2, b3);
-                    sparse_entry<LDS_SRC>(vb[u].z, mb[u].z, xs, lane_base, lane_rot, b0, b1, b2, b3);
-                    sparse_entry<LDS_SRC>(vb[u].w, mb[u].w, xs, lane_base, lane_rot, b0, b1, b2, b3);
-                }
-            }
+        for (int j = 0; j < R; ++j) {
+            const int row = row_base + j < P.rows ? row_base + j : P.rows - 1;
+            const int g0 = P.sp_rowoff[row];
+            len[j] = row_base + j < P.rows ? P.sp_rowoff[row + 1] - g0 : 0;
+            vp[j] = P.sp_vals + (int64_t)g0 * 256 + 4 * lane;
+            ip[j] = P.sp_cidx + (int64_t)g0 * 256 + 4 * lane;
+            nmax = len[j] > nmax ? len[j] : nmax;
         }
-        const float sumA = rp_wave_allreduce((a0 + a1) + (a2 + a3));
-        const float sumB = rp_wave_allreduce((b0 + b1) + (b2 + b3));
-        if (lane == 0) epilogue<MODEL>(P, rowA, sumA);
-        if (lane == 1 && hasB) epilogue<MODEL>(P, rowB, sumB);
+        rp_f4 acc[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) acc[j] = rp_f4{0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nmax; k += U) {
+            rp_f4 v[R][U];
+            us4 m[R][U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    if (k + u < len[j]) {
+                        v[j][u] = rp_ld4_stream(vp[j] + (int64_t)(k + u) * 256);
+                        m[j][u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(ip[j] + (int64_t)(k + u) * 256));
+                    }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    if (k + u < len[j]) {
+                        sparse_entry<LDS_SRC>(v[j][u].x, m[j][u].x, xs, lane_base, lane_rot, acc[j]);
+                        sparse_entry<LDS_SRC>(v[j][u].y, m[j][u].y, xs, lane_base, lane_rot, acc[j]);
+                        sparse_entry<LDS_SRC>(v[j][u].z, m[j][u].z, xs, lane_base, lane_rot, acc[j]);
+                        sparse_entry<LDS_SRC>(v[j][u].w, m[j][u].w, xs, lane_base, lane_rot, acc[j]);
+                    }
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const float sum = rp_wave_allreduce(rp_lane_sum4(acc[j]));
+            if (lane == j) mine = sum;
+        }
+        if (lane < R && row_base + lane < P.rows) epilogue<MODEL>(P, row_base + lane, mine);
     }
+}
+
+// benchmark-only: rows per wave / groups in flight per row of the sparse step (0 = built-in)
+int g_sparse_R = 0, g_sparse_U = 0;
+
+template <int MODEL, int R, int U>
+int launch_step_sparse_cfg(const StepParams& P, hipStream_t st, int n_cu) {
+    constexpr int kWaves = kSparseThreads / RP_WAVE;
+    int blocks = ((P.rows + R - 1) / R + kWaves - 1) / kWaves;
+    if (P.n <= kSparseLdsMaxN) {
+        if (blocks > n_cu) blocks = n_cu;  // one resident workgroup per CU owns the LDS copy of the source vector
+        const size_t lds = sizeof(float) * (size_t)((P.n + 255) & ~255);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&step_sparse_kernel<MODEL, true, R, U>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(float) * kSparseLdsMaxN) != hipSuccess)
+                return RP_ERR_HIP;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((step_sparse_kernel<MODEL, true, R, U>), dim3(blocks), dim3(kSparseThreads), lds, st, P);
+    } else {
+        if (blocks > 2 * n_cu) blocks = 2 * n_cu;
+        hipLaunchKernelGGL((step_sparse_kernel<MODEL, false, R, U>), dim3(blocks), dim3(kSparseThreads), 0, st, P);
+    }
+    return RP_OK;
 }
 
 template <int MODEL>
@@ -342,24 +370,23 @@ int launch_step_sparse(const StepParams& P, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RP_ERR_HIP;
         n_cu = prop.multiProcessorCount;
     }
-    constexpr int kWaves = kSparseThreads / RP_WAVE;
-    int blocks = ((P.rows + 1) / 2 + kWaves - 1) / kWaves;
-    if (P.n <= kSparseLdsMaxN) {
-        if (blocks > n_cu) blocks = n_cu;  // one resident workgroup per CU owns the LDS copy of the source vector
-        const size_t lds = sizeof(float) * (size_t)((P.n + 255) & ~255);
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&step_sparse_kernel<MODEL, true, 4>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(float) * kSparseLdsMaxN) != hipSuccess)
-                return RP_ERR_HIP;
-            attr_set = true;
+    if constexpr (MODEL == RP_MODEL_LI_TANH) {  // benchmark-only sweep (rp_set_sparse_tuning)
+        const int key = g_sparse_R * 10 + g_sparse_U;
+        switch (key) {
+            case 14: return launch_step_sparse_cfg<MODEL, 1, 4>(P, st, n_cu);
+            case 18: return launch_step_sparse_cfg<MODEL, 1, 8>(P, st, n_cu);
+            case 22: return launch_step_sparse_cfg<MODEL, 2, 2>(P, st, n_cu);
+            case 28: return launch_step_sparse_cfg<MODEL, 2, 8>(P, st, n_cu);
+            case 24: return launch_step_sparse_cfg<MODEL, 2, 4>(P, st, n_cu);
+            case 42: return launch_step_sparse_cfg<MODEL, 4, 2>(P, st, n_cu);
+            case 44: return launch_step_sparse_cfg<MODEL, 4, 4>(P, st, n_cu);
+            case 81: return launch_step_sparse_cfg<MODEL, 8, 1>(P, st, n_cu);
+            case 82: return launch_step_sparse_cfg<MODEL, 8, 2>(P, st, n_cu);
+            default: break;
         }
-        hipLaunchKernelGGL((step_sparse_kernel<MODEL, true, 4>), dim3(blocks), dim3(kSparseThreads), lds, st, P);
-    } else {
-        if (blocks > 2 * n_cu) blocks = 2 * n_cu;
-        hipLaunchKernelGGL((step_sparse_kernel<MODEL, false, 4>), dim3(blocks), dim3(kSparseThreads), 0, st, P);
     }
-    return RP_OK;
+    // measured (scripts/tune_sparse.py): one row per wave with 4 groups in flight is the fastest or tied at every size
+    return launch_step_sparse_cfg<MODEL, 1, 4>(P, st, n_cu);
 }
 
 int launch_step_sparse_model(int model, const StepParams& P, hipStream_t st) {
@@ -754,6 +781,12 @@ int rp_forward_sharded(rp_net* net, rp_run* run, const rp_comm* comm, void* stre
 }
 
 int rp_sizeof_comm(void) { return (int)sizeof(rp_comm); }
+
+int rp_set_sparse_tuning(int rows_per_wave, int groups_in_flight) {
+    g_sparse_R = rows_per_wave;
+    g_sparse_U = groups_in_flight;
+    return RP_OK;
+}
 
 int rp_set_tuning(int rows_per_wave, int unroll, int nontemporal, int max_blocks) {
     g_tune_R = rows_per_wave;

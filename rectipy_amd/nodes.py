@@ -224,7 +224,7 @@ class RateNet:
     def _maybe_pack_weights(self):
         """A coupling matrix that is not trained and mostly zeros (`utility.random_connectivity`, p = 0.1 in the
         reference's examples) is streamed in its packed form: same bits out, a fraction of the bytes in (sparse.py).
-        "auto" packs when the packed stream is measurably faster (scripts/bench_sparse.py): when it is at most 0.6x the
+        "auto" packs when the packed stream is measurably faster (scripts/bench_sparse.py): when it is at most 0.7x the
         dense bytes with the source vector in LDS (n <= 32768), at most 0.25x with the L2 gather above that."""
         pop = self._pop
         mode = self._sparse_mode
@@ -232,13 +232,13 @@ class RateNet:
             if mode is True and pop.device.type == "cuda":
                 raise ValueError("sparse_weights=True needs an untrained matrix with n % 4 == 0")
             return
-        if mode == "auto" and pop.n < 2048:
-            return  # a handful of 256-column chunks per row: nothing to gain
+        if mode == "auto" and pop.n < 4096:
+            return  # launch-bound sizes: the dense step is as fast (n = 2048: 4.8 vs 5.1 us)
         from . import sparse
         if mode == "auto" and sparse.density(pop.W) > 0.5:
             return
         packed = pop.pack_weights()
-        limit = 0.6 if pop.n <= 32768 else 0.25
+        limit = 0.7 if pop.n <= 32768 else 0.25
         if mode == "auto" and packed.stored_bytes > limit * 4.0 * pop.rows * pop.n:
             pop.pack_weights(False)
 
