@@ -613,8 +613,7 @@ class Network:
         Y = torch.as_tensor(targets).to(device=X.device, dtype=X.dtype)
         if Y.shape[0] != X.shape[0]:
             Y = Y[obs["steps"]]
-        eye = torch.eye(X.shape[1], device=X.device, dtype=X.dtype)
-        w_out = torch.linalg.solve(X.T @ X + alpha * eye, X.T @ Y)
+        w_out = self._ridge_solve(X, Y, alpha)
         y = X @ w_out
         print(f"Finished fitting of read-out weights after {perf_counter() - t0} s.")
         if add_readout_node:
@@ -624,6 +623,17 @@ class Network:
         obs.save("y", y)
         obs.save("w_out", w_out)
         return obs
+
+    @staticmethod
+    def _ridge_solve(X: torch.Tensor, Y: torch.Tensor, alpha: float) -> torch.Tensor:
+        """(X^T X + alpha I)^-1 X^T Y (reference network.py:765-768).  With fewer samples than neurons the identical
+        dual form X^T (X X^T + alpha I)^-1 Y is solved instead: an S x S system in place of an N x N one."""
+        S, N = X.shape
+        if S < N:
+            eye = torch.eye(S, device=X.device, dtype=X.dtype)
+            return X.T @ torch.linalg.solve(X @ X.T + alpha * eye, Y)
+        eye = torch.eye(N, device=X.device, dtype=X.dtype)
+        return torch.linalg.solve(X.T @ X + alpha * eye, X.T @ Y)
 
     def fit_rls(self, inputs: Union[list, np.ndarray], targets: Union[list, np.ndarray], update_steps: int = 1,
                 sampling_steps: int = 100, verbose: bool = True, **kwargs) -> Observer:

@@ -275,3 +275,15 @@ def test_float64_request_is_held_as_float32(where):
     assert net.get_node("rnn").y.dtype is torch.float32
     obs = net.run(np.zeros((5, n)), verbose=False, enable_grad=False)
     assert obs.to_numpy("out").shape == (5, 2) and obs.to_numpy("out").dtype == np.float32
+
+
+def test_ridge_solve_primal_and_dual_agree():
+    """fit_ridge solves the S x S dual system when there are fewer samples than neurons; same read-out weights."""
+    from rectipy_amd import Network
+    g = torch.Generator().manual_seed(0)
+    for S, N in ((40, 12), (12, 40)):
+        X = torch.randn(S, N, generator=g, dtype=torch.float64)
+        Y = torch.randn(S, 3, generator=g, dtype=torch.float64)
+        w = Network._ridge_solve(X, Y, 1e-2)
+        ref = torch.inverse(X.T @ X + 1e-2 * torch.eye(N, dtype=torch.float64)) @ X.T @ Y   # reference network.py:767
+        assert w.shape == (N, 3) and (w - ref).abs().max() < 1e-9 * max(1.0, float(ref.abs().max()))
