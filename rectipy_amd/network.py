@@ -627,13 +627,18 @@ class Network:
     @staticmethod
     def _ridge_solve(X: torch.Tensor, Y: torch.Tensor, alpha: float) -> torch.Tensor:
         """(X^T X + alpha I)^-1 X^T Y (reference network.py:765-768).  With fewer samples than neurons the identical
-        dual form X^T (X X^T + alpha I)^-1 Y is solved instead: an S x S system in place of an N x N one."""
+        dual form X^T (X X^T + alpha I)^-1 Y is solved instead: an S x S system in place of an N x N one.  Gram matrix
+        and solve run in float64 (the Gram matrix of thousands of states is too ill-conditioned for float32); the
+        weights come back in the dtype of X."""
         S, N = X.shape
+        Xd, Yd = X.double(), Y.double()
         if S < N:
-            eye = torch.eye(S, device=X.device, dtype=X.dtype)
-            return X.T @ torch.linalg.solve(X @ X.T + alpha * eye, Y)
-        eye = torch.eye(N, device=X.device, dtype=X.dtype)
-        return torch.linalg.solve(X.T @ X + alpha * eye, X.T @ Y)
+            eye = torch.eye(S, device=X.device, dtype=torch.float64)
+            w = Xd.T @ torch.linalg.solve(Xd @ Xd.T + alpha * eye, Yd)
+        else:
+            eye = torch.eye(N, device=X.device, dtype=torch.float64)
+            w = torch.linalg.solve(Xd.T @ Xd + alpha * eye, Xd.T @ Yd)
+        return w.to(X.dtype)
 
     def fit_rls(self, inputs: Union[list, np.ndarray], targets: Union[list, np.ndarray], update_steps: int = 1,
                 sampling_steps: int = 100, verbose: bool = True, **kwargs) -> Observer:
