@@ -35,5 +35,5 @@ tgt = torch.tensor(rng.standard_normal((T, 3)) * 0.1, dtype=torch.float32, devic
 w_before = node["weights"].detach().clone()
 obs = net.fit_bptt(inp, tgt, optimizer="sgd", lr=1e-3, update_steps=200, sampling_steps=100, verbose=False)
 if dist.get_rank() == 0:
-    print("losses:", [round(float(v), 6) for v in obs["loss"]], "max |dW|:", float((node["weights"] - w_before).abs().max()))
+    print("losses:", [round(float(v), 6) for v in obs["loss"]], "max |dW|:", float((node["weights"].detach() - w_before).abs().max()))
 dist.destroy_process_group()
