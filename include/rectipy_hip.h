@@ -231,6 +231,13 @@ typedef struct rp_bwd {
     const float* traj_aux2;   /* IK_BIEXP: [T x ld] pre-update x (rise variable of the synapse) = save_state[2] */
     float* lam4;              /* IK_BIEXP: [n] adjoint of x (in: at T, out: at 0)                              */
     float* means;             /* IKU / IK_BIEXP: scratch [4] for the per-step population sums                  */
+    /* Optional packed form of W^T for a FIXED sparse matrix (rectipy_amd/sparse.py applied to the transposed matrix,
+       unsharded sweeps): when spt_vals is non-null, z = W^T u is the row dot of the packed rows of W^T with u -- the
+       summation order of the transposed-copy sweep at any n -- fused with the element-wise update, one launch per step,
+       and neither W nor wt is read. */
+    const float* spt_vals;
+    const uint16_t* spt_cidx;
+    const int32_t* spt_rowoff;
 } rp_bwd;
 
 #define RP_BWD_TRANSPOSE_MAX_N 4096

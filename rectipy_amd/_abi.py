@@ -133,6 +133,9 @@ class RpBwd(C.Structure):
         ("traj_aux2", fp),
         ("lam4", fp),
         ("means", fp),
+        ("spt_vals", fp),
+        ("spt_cidx", fp),
+        ("spt_rowoff", fp),
     ]
 
 

@@ -86,6 +86,10 @@ struct BwdParams {
     float* lam_x2;           // adjoint of the synaptic rise variable (IK_BIEXP)
     const float* aux2_prev;  // x of step t-1
     float* means;            // [4]: mean(lx b/tau_u), mean(kappa lx) of the current adjoint; mean(v), mean(spike/dt) of step t-1
+    // packed W^T (rp_bwd.spt_*)
+    const float* spt_vals;
+    const uint16_t* spt_cidx;
+    const int32_t* spt_rowoff;
 };
 
 // partials[q][j] = sum_{i in chunk q, ascending} W[i][j] * u[i]
@@ -513,6 +517,98 @@ void launch_adj_rowdot(const BwdParams& P, const SpkGrad& G, bool vec4, hipStrea
     }
 }
 
+// One adjoint step on the packed rows of W^T (fixed sparse W): z_j = <packed row j of W^T, u> in the row-dot order of
+// the transposed-copy sweep, then the element-wise update of neuron j -- the sparse step kernel with u as the gathered
+// vector and the adjoint update as its epilogue.
+template <bool SPIKING, bool LDS_SRC, int U>
+__global__ __launch_bounds__(kSparseThreads) void adj_sparse_kernel(const BwdParams P, const SpkGrad G) {
+    extern __shared__ float lds_u[];
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    constexpr int kWaves = kSparseThreads / RP_WAVE;
+    if constexpr (LDS_SRC) rp_sparse_stage_source(lds_u, P.u, P.n);
+    const int lane_base = LDS_SRC ? 64 * (lane >> 4) : 4 * lane;
+    const int lane_rot = 4 * (lane & 15) + (lane >> 4);
+    const float* xs = LDS_SRC ? lds_u : P.u;
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    for (int j = blockIdx.x * kWaves + wave; j < P.n; j += gridDim.x * kWaves) {
+        const int g0 = P.spt_rowoff[j], len = P.spt_rowoff[j + 1] - g0;
+        const float* vp = P.spt_vals + (int64_t)g0 * 256 + 4 * lane;
+        const uint16_t* ip = P.spt_cidx + (int64_t)g0 * 256 + 4 * lane;
+        rp_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < len; k += U) {
+            rp_f4 v[U];
+            us4 m[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + u < len) {
+                    v[u] = rp_ld4_stream(vp + (int64_t)(k + u) * 256);
+                    m[u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(ip + (int64_t)(k + u) * 256));
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + u < len) {
+                    sparse_entry<LDS_SRC>(v[u].x, m[u].x, xs, lane_base, lane_rot, acc);
+                    sparse_entry<LDS_SRC>(v[u].y, m[u].y, xs, lane_base, lane_rot, acc);
+                    sparse_entry<LDS_SRC>(v[u].z, m[u].z, xs, lane_base, lane_rot, acc);
+                    sparse_entry<LDS_SRC>(v[u].w, m[u].w, xs, lane_base, lane_rot, acc);
+                }
+        }
+        const float z = rp_wave_allreduce(rp_lane_sum4(acc));
+        if (lane == 0) {
+            if constexpr (SPIKING)
+                spk_finalize_elem(P, G, j, z);
+            else
+                finalize_elem(P, j, z);
+        }
+    }
+}
+
+template <bool SPIKING>
+int launch_adj_sparse(const BwdParams& P, const SpkGrad& G, hipStream_t st) {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RP_ERR_HIP;
+        n_cu = prop.multiProcessorCount;
+    }
+    constexpr int kWaves = kSparseThreads / RP_WAVE;
+    int blocks = (P.n + kWaves - 1) / kWaves;
+    if (P.n <= kSparseLdsMaxN) {
+        if (blocks > n_cu) blocks = n_cu;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_sparse_kernel<SPIKING, true, 4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(float) * kSparseLdsMaxN) != hipSuccess)
+                return RP_ERR_HIP;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((adj_sparse_kernel<SPIKING, true, 4>), dim3(blocks), dim3(kSparseThreads),
+                           sizeof(float) * (size_t)((P.n + 255) & ~255), st, P, G);
+    } else {
+        if (blocks > 2 * n_cu) blocks = 2 * n_cu;
+        hipLaunchKernelGGL((adj_sparse_kernel<SPIKING, false, 4>), dim3(blocks), dim3(kSparseThreads), 0, st, P, G);
+    }
+    return RP_OK;
+}
+
+// packed W^T given: validates it and fills the pointers
+int sparse_t_mode(const rp_net* net, const rp_bwd* b, BwdParams& P, bool& use) {
+    use = b->spt_vals != nullptr;
+    if (!use) return RP_OK;
+    if (!b->spt_cidx || !b->spt_rowoff) RP_FAIL(RP_ERR_ARG, "spt_vals given without spt_cidx / spt_rowoff");
+    if (net->n % 4 != 0) RP_FAIL(RP_ERR_SHAPE, "the packed form of W^T needs n %% 4 == 0 (n=%d)", net->n);
+    if (net->rows != net->n) RP_FAIL(RP_ERR_ARG, "the packed W^T sweep needs the unsharded population");
+    if ((reinterpret_cast<uintptr_t>(b->spt_vals) & 15u) || (reinterpret_cast<uintptr_t>(b->spt_cidx) & 7u) ||
+        (reinterpret_cast<uintptr_t>(b->u_traj) & 15u) || (b->ld % 4 != 0))
+        RP_FAIL(RP_ERR_ARG, "spt_vals / u_traj must be 16-byte (ld a multiple of 4) and spt_cidx 8-byte aligned");
+    P.spt_vals = b->spt_vals;
+    P.spt_cidx = b->spt_cidx;
+    P.spt_rowoff = b->spt_rowoff;
+    return RP_OK;
+}
+
 // true when the sweep uses the transposed copy; validates the workspace
 int transposed_mode(const rp_net* net, const rp_bwd* b, bool& use, bool& vec4_t) {
     use = b->wt != nullptr && net->n <= RP_BWD_TRANSPOSE_MAX_N;
@@ -608,13 +704,19 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
         P.gx_prev = b->grad_x ? b->grad_x + (int64_t)tp * b->ldgx : nullptr;
     };
 
+    bool use_spt;
+    {
+        int rc = sparse_t_mode(net, b, P, use_spt);
+        if (rc != RP_OK) return rc;
+    }
+    if (use_spt) use_wt = false;
     if (use_wt) launch_transpose(net, b, st);
     set_prep(T - 1);
     hipLaunchKernelGGL(prep_kernel, dim3(eblocks), dim3(256), 0, st, P);
     for (int t = T - 1; t >= 0; --t) {
         P.t = t;
         P.u = b->u_traj + (int64_t)t * b->ld;
-        if (!use_wt) launch_wt_partial(P, vec4, st);
+        if (!use_wt && !use_spt) launch_wt_partial(P, vec4, st);
         P.v_t = b->traj_v + (int64_t)t * b->ld;
         P.r_t = b->traj_r + (int64_t)t * b->ld;
         P.g_t = b->grad_out ? b->grad_out + (int64_t)t * b->ldg : nullptr;
@@ -622,10 +724,13 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
             set_prep(t - 1);
         else
             P.u_next = nullptr;
-        if (use_wt)
+        if (use_spt) {
+            if (launch_adj_sparse<false>(P, SpkGrad{}, st) != RP_OK) RP_FAIL(RP_ERR_HIP, "sparse adjoint launch failed");
+        } else if (use_wt) {
             launch_adj_rowdot<false>(P, SpkGrad{}, vec4_t, st);
-        else
+        } else {
             hipLaunchKernelGGL(finalize_kernel, dim3(eblocks), dim3(256), 0, st, P);
+        }
     }
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;
@@ -923,6 +1028,10 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int T = b->steps;
+    bool use_spt;
+    rc = sparse_t_mode(net, b, P, use_spt);
+    if (rc != RP_OK) return rc;
+    if (use_spt) use_wt = false;
     if (use_wt) {
         P.W = b->wt;
         P.ldw = b->ldwt;
@@ -935,13 +1044,16 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     hipLaunchKernelGGL(spk_prep_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
     for (int t = T - 1; t >= 0; --t) {
         P.u = b->u_traj + (int64_t)t * b->ld;
-        if (!use_wt) launch_wt_partial(P, vec4, st);
+        if (!use_wt && !use_spt) launch_wt_partial(P, vec4, st);
         spk_set_step(b, P, t);
         if (mean_coupled) hipLaunchKernelGGL(adj_mean_kernel, dim3(1), dim3(1024), 0, st, P);
-        if (use_wt)
+        if (use_spt) {
+            if (launch_adj_sparse<true>(P, G, st) != RP_OK) RP_FAIL(RP_ERR_HIP, "sparse adjoint launch failed");
+        } else if (use_wt) {
             launch_adj_rowdot<true>(P, G, vec4_t, st);
-        else
+        } else {
             hipLaunchKernelGGL(spk_finalize_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
+        }
     }
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;

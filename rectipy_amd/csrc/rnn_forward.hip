@@ -242,42 +242,13 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepParams P) {
 // (1.5 KiB each) in flight.  The source vector is gathered per entry: from LDS when it fits (n <= 32768: one
 // 1024-thread workgroup per CU keeps all of it, stored with a per-64-block rotation by (column >> 6) & 3 so that the
 // 64 lanes of a gather hit 64 different banks whatever their chunks and components), else from L2.
-constexpr int kSparseThreads = 1024;
-constexpr int kSparseLdsMaxN = 32768;
-
-template <bool LDS_SRC>
-__device__ __forceinline__ void sparse_entry(float v, unsigned code, const float* xs, int lane_base, int lane_rot,
-                                             rp_f4& a) {
-    float a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w;
-    const int c = (int)(code >> 14), m = (int)(code & 0x3fffu);
-    // LDS: position of column 256 m + 4 l + c in the rotated layout; global: the column itself
-    const int idx = LDS_SRC ? (m << 8) + lane_base + ((lane_rot + c) & 63) : (m << 8) + lane_base + c;
-    const float x = xs[idx];
-    const float acc = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
-    const float r = fmaf(v, x, acc);
-    a.x = c == 0 ? r : a0;
-    a.y = c == 1 ? r : a1;
-    a.z = c == 2 ? r : a2;
-    a.w = c == 3 ? r : a3;
-}
-
 template <int MODEL, bool LDS_SRC, int R, int U>
 __global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepParams P) {
     extern __shared__ float lds_src[];
     const int lane = threadIdx.x & (RP_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     constexpr int kWaves = kSparseThreads / RP_WAVE;
-    if constexpr (LDS_SRC) {
-        for (int c4 = threadIdx.x * 4; c4 < P.n; c4 += kSparseThreads * 4) {
-            const rp_f4 v = rp_ld4(P.src_cur + c4);
-            const int base = c4 & ~63, h = (c4 >> 6) & 3, o = c4 & 63;
-            lds_src[base | ((o + 0 + h) & 63)] = v.x;
-            lds_src[base | ((o + 1 + h) & 63)] = v.y;
-            lds_src[base | ((o + 2 + h) & 63)] = v.z;
-            lds_src[base | ((o + 3 + h) & 63)] = v.w;
-        }
-        __syncthreads();
-    }
+    if constexpr (LDS_SRC) rp_sparse_stage_source(lds_src, P.src_cur, P.n);
     // LDS: 64-column block of this lane inside a chunk and its rotated offset; global: first of its four columns
     const int lane_base = LDS_SRC ? 64 * (lane >> 4) : 4 * lane;
     const int lane_rot = 4 * (lane & 15) + (lane >> 4);

@@ -109,3 +109,41 @@ __device__ __forceinline__ void rp_dot_rows_s1(const RowDotArgs& P, int row_base
 #pragma unroll
     for (int j = 0; j < R; ++j) sum[j] = rp_wave_allreduce(a[j]);
 }
+
+// ---- packed sparse rows (rectipy_amd/sparse.py) ------------------------------------------------------------------
+// Shared by the sparse step kernel and the sparse adjoint (packed W^T).  A lane walks its entry list (value + code =
+// component << 14 | column chunk, four entries per lane per group) and feeds the accumulator the code names; the source
+// vector is gathered per entry from LDS (rotated layout, conflict-free) or from L2.
+constexpr int kSparseThreads = 1024;
+constexpr int kSparseLdsMaxN = 32768;
+
+// Cooperative copy of src[0..n) into LDS: inside every 64-column block the element at offset o goes to
+// (o + ((column >> 6) & 3)) & 63, so that the 64 lanes of a gather (lane l asks for column 256 m_l + 4 l + c) hit 64
+// different banks whatever their chunks m_l.
+__device__ __forceinline__ void rp_sparse_stage_source(float* lds_src, const float* __restrict__ src, int n) {
+    for (int c4 = threadIdx.x * 4; c4 < n; c4 += kSparseThreads * 4) {
+        const rp_f4 v = rp_ld4(src + c4);
+        const int base = c4 & ~63, h = (c4 >> 6) & 3, o = c4 & 63;
+        lds_src[base | ((o + 0 + h) & 63)] = v.x;
+        lds_src[base | ((o + 1 + h) & 63)] = v.y;
+        lds_src[base | ((o + 2 + h) & 63)] = v.z;
+        lds_src[base | ((o + 3 + h) & 63)] = v.w;
+    }
+    __syncthreads();
+}
+
+template <bool LDS_SRC>
+__device__ __forceinline__ void sparse_entry(float v, unsigned code, const float* xs, int lane_base, int lane_rot,
+                                             rp_f4& a) {
+    float a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w;
+    const int c = (int)(code >> 14), m = (int)(code & 0x3fffu);
+    // LDS: position of column 256 m + 4 l + c in the rotated layout; global: the column itself
+    const int idx = LDS_SRC ? (m << 8) + lane_base + ((lane_rot + c) & 63) : (m << 8) + lane_base + c;
+    const float x = xs[idx];
+    const float acc = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
+    const float r = fmaf(v, x, acc);
+    a.x = c == 0 ? r : a0;
+    a.y = c == 1 ? r : a1;
+    a.z = c == 2 ? r : a2;
+    a.w = c == 3 ? r : a3;
+}

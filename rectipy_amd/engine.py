@@ -185,6 +185,8 @@ class Population:
         self.aux2 = self._vec(0.0 if aux2_0 is None else aux2_0) if model in HAS_AUX2 else None
         self._scratch = torch.zeros(4, **f32) if model in NEEDS_MEANS else None
         self.packed = None               # PackedRows of a fixed sparse W (sparse.py); the step kernel then streams it
+        self.packed_t = None             # PackedRows of W^T (adjoint of a fixed sparse W), built on first use
+        self.sparse_adjoint = True       # False: adjoint on the dense matrix even when a packed form exists
         self._wt = None                  # workspace for W^T (adjoint of small networks), allocated on first use
         self.transposed_adjoint = True   # False: always use the column-strip kernels (tests, measurements)
         self.spiking = model in SPIKING
@@ -266,7 +268,14 @@ class Population:
         see sparse.py).  The dense matrix stays in place for the adjoint kernels.  Call again after changing W."""
         from . import sparse
         self.packed = sparse.pack_rows(self.W, row0=self.row0) if enable else None
+        self.packed_t = None
         return self.packed
+
+    def _packed_transpose(self):
+        if self.packed_t is None:
+            from . import sparse
+            self.packed_t = sparse.pack_rows(self.W.T.contiguous(), row0=0)
+        return self.packed_t
 
     def reset_sampling(self):
         self.acc.zero_()
@@ -412,7 +421,14 @@ class Population:
         q = self.backend.shard_partial_rows(self.n, local) if sharded else self.backend.partial_rows(self.n)
         partials = torch.empty(q, self.n, dtype=torch.float32, device=self.device)
         b.partials = partials.data_ptr()
-        if not sharded and self.n <= _abi.RP_BWD_TRANSPOSE_MAX_N and self.transposed_adjoint:
+        if not sharded and self.packed is not None and self.sparse_adjoint:
+            # fixed sparse W: the sweep streams the packed rows of W^T (row-dot order of the transposed-copy sweep)
+            pt = self._packed_transpose()
+            if pt is not None:
+                b.spt_vals, b.spt_cidx, b.spt_rowoff = pt.vals.data_ptr(), pt.code.data_ptr(), pt.rowoff.data_ptr()
+        on_host = self.device.type == "cpu"  # the CPU checker evaluates the same order on a dense transposed copy
+        if not sharded and ((self.n <= _abi.RP_BWD_TRANSPOSE_MAX_N and self.transposed_adjoint and not b.spt_vals)
+                            or (b.spt_vals and on_host)):
             # small networks: the sweep keeps W^T in this workspace and runs one fused launch per step (rp_bwd.wt)
             if self._wt is None:
                 self._wt = torch.empty(self.n, (self.n + 3) // 4 * 4, dtype=torch.float32, device=self.device)

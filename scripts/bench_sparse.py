@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rectipy_amd.engine import Population  # noqa: E402
 
 dev = torch.device("cuda:0")
-for N, T in ((8192, 2000), (32768, 600), (65536, 200)):
+for N, T in ((8192, 2000), (32768, 600)):
     for p in (0.05, 0.1, 0.2):
         gen = torch.Generator(device=dev).manual_seed(0)
         W = torch.empty(N, N, device=dev)
@@ -44,7 +44,29 @@ for N, T in ((8192, 2000), (32768, 600), (65536, 200)):
         pop.forward(20 + T, x=torch.cat([x[:20], x]))
         pop.pack_weights(); pop.v.zero_(); pop.refresh()
         pop.forward(20 + T, x=torch.cat([x[:20], x]))
+        # adjoint sweep: dense column strips vs packed W^T
+        Tb = min(T, 100)
+        tv, ts, ut = (torch.zeros(Tb, N, device=dev) for _ in range(3))
+        pop.forward(Tb, x=x, save_v=tv, save_src=ts)
+        g = torch.randn(Tb, N, device=dev) * 0.01
+
+        def bwd(sparse_adj):
+            pop.sparse_adjoint = sparse_adj
+            best = 1e9
+            for _ in range(3):
+                lam = torch.zeros(N, device=dev)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                keep = pop.backward(tv, ts, g, 0, lam, ut)
+                torch.cuda.synchronize()
+                best = min(best, (time.perf_counter() - t1) / Tb)
+                del keep
+            return best
+
+        bwd_sparse, bwd_dense = bwd(True), bwd(False)
+        del tv, ts, ut, g
         print(json.dumps(dict(N=N, p=p, dense_us=round(dense * 1e6, 1), sparse_us=round(sparse * 1e6, 1),
+                              bwd_dense_us=round(bwd_dense * 1e6, 1), bwd_sparse_us=round(bwd_sparse * 1e6, 1),
                               speedup=round(dense / sparse, 2), stored_MB=round(packed.stored_bytes / 1e6, 1),
                               dense_MB=round(4.0 * N * N / 1e6, 1), stream_GBps=round(packed.stored_bytes / sparse / 1e9, 1),
                               pack_s=round(t_pack, 2))), flush=True)

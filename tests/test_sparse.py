@@ -134,3 +134,107 @@ def test_front_end_packs_a_fixed_sparse_matrix_automatically(hip_device):
                                weights=np.random.default_rng(0).standard_normal((N, N)).astype(np.float32) / N ** 0.5,
                                source_var="tanh_op/r", target_var="li_op/r_in", dtype=torch.float32)
     assert node._pop.packed is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,n", [("li_tanh", 1028), ("li_tanh", 8192), ("qif", 1024), ("ik", 2048)])
+def test_sparse_adjoint_equals_oracle(oracle_backend, hip_device, model, n):
+    """Adjoint sweep on the packed rows of W^T (fixed sparse W): HIP == oracle (row-dot order on W^T), bit for bit, for
+    the rate and the spiking sweeps; n = 8192 is beyond the dense transposed-copy threshold."""
+    params, kw, dt, drive, out_var = MODELS[model]
+    T = 12 if n > 4096 else 40
+    positive = model != "li_tanh"
+    W = random_sparse(n, n, 0.1, seed=n + 1, scale=(20.0 / n if positive else 1.5 / (0.1 * n) ** 0.5))
+    if positive:
+        W = W.abs()
+    gen = torch.Generator().manual_seed(6)
+    x = torch.full((T, 1), drive) + torch.randn(T, 1, generator=gen) * 0.1 * abs(drive)
+    g_out = torch.randn(T, n, generator=gen) * 0.1
+    l0 = [torch.randn(n, generator=gen) * 0.01 for _ in range(3)]
+    res = []
+    for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+        pop = Population(model, W, params, dt, dev, backend=backend, **kw)
+        pop.pack_weights()
+        tv, ts, ta, tx, ut, gx = (torch.zeros(T, n, device=dev) for _ in range(6))
+        pop.forward(T, x=x.to(dev), save_v=tv, save_src=ts, save_acc=ta, save_aux=tx if pop.aux is not None else None)
+        lv, ls, lx = (t_.clone().to(dev) for t_ in l0)
+        if model == "li_tanh":
+            gk = torch.zeros(n, device=dev)
+            keep = pop.backward(tv, ts, g_out.to(dev), _abi.RP_OUT_SOURCE, lv, ut, traj_acc=ta, grad_k=gk, grad_x=gx)
+            out = [lv, ut, gk, gx]
+        else:
+            grads = {"eta": torch.zeros(n, device=dev), "k": torch.zeros(n, device=dev)}
+            keep = pop.backward(tv, ts, g_out.to(dev), _abi.RP_OUT_SOURCE, lv, ut, traj_acc=ta, grad_x=gx, lam_s=ls,
+                                slope=0.7, x=x.to(dev), traj_aux=tx if pop.aux is not None else None,
+                                lam_x=lx if pop.aux is not None else None, grad_params=grads)
+            out = [lv, ls, lx, ut, gx, grads["eta"], grads["k"]]
+        assert pop.packed_t is not None
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        res.append([t_.cpu().numpy() for t_ in out])
+        del keep
+    for i, (a, b) in enumerate(zip(*res)):
+        same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
+        assert same.all(), f"{model} n={n} output {i}: {np.count_nonzero(~same)} differ, max {np.abs(a - b).max()}"
+    assert np.abs(res[0][0]).max() > 0
+
+
+@pytest.mark.gpu
+def test_sparse_and_dense_adjoints_agree(hip_device):
+    """Below the transposed-copy threshold both layouts use the row-dot order on W^T: identical bits.  Above it the
+    dense sweep sums column strips: equal to rounding."""
+    for n, exact in ((2048, True), (8192, False)):
+        W = random_sparse(n, n, 0.1, seed=n, scale=1.5 / (0.1 * n) ** 0.5)
+        T = 10
+        x = torch.randn(T, 1, generator=torch.Generator().manual_seed(1)) * 0.5
+        g_out = torch.randn(T, n, generator=torch.Generator().manual_seed(2)) * 0.1
+        outs = []
+        for sparse_adj in (True, False):
+            pop = Population("li_tanh", W, dict(tau=8.0, k=1.0, eta=0.1), 1e-2, hip_device)
+            pop.pack_weights()
+            pop.sparse_adjoint = sparse_adj
+            tv, ts, ut = (torch.zeros(T, n, device=hip_device) for _ in range(3))
+            pop.forward(T, x=x.to(hip_device), save_v=tv, save_src=ts)
+            lam = torch.zeros(n, device=hip_device)
+            keep = pop.backward(tv, ts, g_out.to(hip_device), _abi.RP_OUT_SOURCE, lam, ut)
+            torch.cuda.synchronize()
+            outs.append(lam.cpu().numpy())
+            del keep
+        if exact:
+            assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+        else:
+            assert np.abs(outs[0] - outs[1]).max() <= 2e-5 * np.abs(outs[1]).max()
+
+
+@pytest.mark.gpu
+def test_fit_bptt_through_a_fixed_sparse_reservoir(hip_device):
+    """Training the input and read-out edges by BPTT through a fixed sparse recurrent matrix (the pattern of the
+    reference's documentation/bptt_spiking_neurons_ffwd.py, where the fixed matrix is all zeros): forward and adjoint both
+    run on the packed forms; same trained weights as with dense storage."""
+    from rectipy_amd import Network
+    N, T, m, k = 4096, 120, 3, 2
+    g = torch.Generator().manual_seed(8)
+    W = random_sparse(N, N, 0.1, seed=9, scale=1.2 / (0.1 * N) ** 0.5).numpy()
+    W_in = (torch.randn(N, m, generator=g) * 0.5).numpy()
+    W_out = (torch.randn(k, N, generator=g) / N ** 0.5).numpy()
+    x = torch.randn(T, m, generator=g).numpy()
+    tgt = (torch.randn(T, k, generator=g) * 0.1).numpy()
+    tanh = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
+    res = []
+    for mode in ("auto", False):
+        net = Network(1e-2, device="cuda:0")
+        node = net.add_diffeq_node("rnn", tanh, input_var="li_op/I_ext", output_var="tanh_op/r", weights=W,
+                                   source_var="tanh_op/r", target_var="li_op/r_in", dtype=torch.float32,
+                                   sparse_weights=mode)
+        net.add_func_node("inp", m, "identity")
+        net.add_func_node("out", k, "identity")
+        e_in = net.add_edge("inp", "rnn", weights=W_in.copy(), train="gd")
+        e_out = net.add_edge("rnn", "out", weights=W_out.copy(), train="gd")
+        net.fit_bptt(x, tgt, optimizer="sgd", lr=0.1, update_steps=40, sampling_steps=1, verbose=False)
+        torch.cuda.synchronize()
+        assert (node._pop.packed is not None) == (mode == "auto")
+        assert (node._pop.packed_t is not None) == (mode == "auto")
+        res.append((e_in.weights.detach().cpu().numpy(), e_out.weights.detach().cpu().numpy()))
+    assert np.abs(res[0][0] - W_in).max() > 1e-6, "the input edge was not trained"
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
