@@ -46,6 +46,11 @@ class FeedbackNetwork(Network):
             return None
         return super()._chain_plan()
 
+    def _dag_plan(self, rec_vars):
+        if any(d.get("feedback") for _, _, d in self.graph.edges(data=True)):
+            return None  # a feedback edge needs the source's output of the previous step: step by step
+        return super()._dag_plan(rec_vars)
+
     def forward(self, x) -> torch.Tensor:
         if not self._order:
             self.compile()

@@ -333,8 +333,123 @@ class Network:
                 with (torch.enable_grad() if enable_grad else torch.no_grad()):
                     self._run_fused(plan, inputs, sampling_steps, cutoff, truncate_steps, obs, slots, verbose)
                 return obs
+        rec_slots = self._dag_plan(rec_vars) if plan is None else None
+        if rec_slots is not None:
+            with (torch.enable_grad() if enable_grad else torch.no_grad()):
+                self._run_windows(inputs, sampling_steps, cutoff, truncate_steps, obs, rec_vars, rec_slots, verbose)
+            return obs
         self._run_stepwise(inputs, sampling_steps, cutoff, truncate_steps, obs, rec_vars, enable_grad, verbose)
         return obs
+
+    # ---- several populations without cycles: one fused window per population ---------------------
+    def _dag_plan(self, rec_vars) -> Optional[List[int]]:
+        """Record slots of `rec_vars` when the (acyclic) graph can be evaluated window by window -- every node a
+        compiled population or an element-wise activation, every edge a plain Linear/RLS projection -- else None.
+        Inside one step a node only sees its predecessors' outputs of the SAME step (forward(), reference
+        network.py:462-478), so node n's whole window follows from its predecessors' whole windows."""
+        from .rls import RLS
+        if getattr(self, "_force_stepwise", False):
+            return None
+        if not any(isinstance(self.get_node(n), RateNet) for n in self._order):
+            return None
+        for n in self._order:
+            node = self.get_node(n)
+            if not isinstance(node, RateNet) and not (isinstance(node, InstantNode) and node.name in InstantNode.elementwise):
+                return None
+        for s_, t_ in self.graph.edges:
+            if type(self.get_edge(s_, t_)) not in (Linear, RLS):
+                return None
+        slots = []
+        for label, var in rec_vars:
+            node = self.get_node(label)
+            one = self._record_slots(node, [(label, var)]) if isinstance(node, RateNet) else None
+            if one is None:
+                return None
+            slots.append(one[0])
+        return slots
+
+    def _window_outputs(self, inputs_ab: torch.Tensor, a: int, grad: bool, rec: dict, cutoff: int, sampling_steps: int):
+        """Per-step output of every node over the window of steps [a, a + len): nodes in topological order, each
+        population as one fused window.  `rec`: label -> {slot: buffer, "idx": next sample row} (no-grad recording in
+        the step kernel) or label -> {slot: list} (grad mode: rows derived from the captured window)."""
+        steps = inputs_ab.shape[0]
+        outs = {}
+        for n in self._order:
+            preds = list(self.graph.predecessors(n))
+            if preds:
+                X = None
+                for p_ in preds:
+                    contrib = self.get_edge(p_, n).forward(outs[p_])
+                    X = contrib if X is None else X + contrib
+            else:
+                X = inputs_ab
+            node = self.get_node(n)
+            if not isinstance(node, RateNet):
+                outs[n] = node.forward(X)
+                continue
+            pop = node._pop
+            X = self._fit_width(X, pop.rows)
+            r = rec.get(n)
+            needs = grad and (X.requires_grad or node._wants_grad(None) or any(q.requires_grad for q in node.parameters()))
+            if needs or (grad and r):  # (a recorded population goes through the capturing window in a gradient run)
+                outs[n] = node._grad_window(steps, X)
+                if r:
+                    window = tuple(node._last_window) + (None, None)
+                    for slot, rows in r.items():
+                        src = window[slot]
+                        if isinstance(node, SpikeResetNet):
+                            rows.append(src)
+                        else:
+                            last = pop.v if slot == 0 else pop.source_local
+                            rows.append(torch.cat((src[1:], last.detach().reshape(1, -1))))
+            else:
+                traj = torch.empty(steps, pop.rows, dtype=torch.float32, device=pop.device)
+                kw = {}
+                if r and not grad:
+                    kw = dict(rec={k_: v_ for k_, v_ in r.items() if k_ != "idx"}, cutoff=cutoff,
+                              sampling_steps=sampling_steps, sample_idx=r["idx"])
+                idx = node.run_window(steps, x=X.detach(), traj=traj, step0=a, **kw)
+                if r:
+                    r["idx"] = idx
+                outs[n] = traj
+        return outs
+
+    def _run_windows(self, inputs, sampling_steps, cutoff, truncate_steps, obs: Observer, rec_vars, rec_slots, verbose):
+        T = inputs.shape[0]
+        sample_at = self._sample_steps(T, cutoff, sampling_steps)
+        S = len(sample_at)
+        grad = torch.is_grad_enabled() and (inputs.requires_grad or any(p_.requires_grad for p_ in self.parameters()) or
+                                            any(self.get_node(n)._wants_grad(None) for n in self._order
+                                                if isinstance(self.get_node(n), RateNet)))
+        widest = max(self.get_node(n)._pop.rows for n in self._order if isinstance(self.get_node(n), RateNet))
+        chunk = truncate_steps if grad else max(1, min(T, _WINDOW_BYTES // (4 * widest * max(1, len(self._order)))))
+        rec = {}
+        for (label, _), slot in zip(rec_vars, rec_slots):
+            pop = self.get_node(label)._pop
+            entry = rec.setdefault(label, {} if grad else {"idx": 0})
+            if slot not in entry:
+                entry[slot] = [] if grad else torch.empty(S, pop.rows, dtype=torch.float32, device=pop.device)
+            if not grad:
+                pop.reset_sampling()
+        pending = []
+        for a in range(0, T, chunk):
+            b = min(a + chunk, T)
+            outs = self._window_outputs(inputs[a:b], a, grad, rec, cutoff, sampling_steps)
+            pending.append(outs[self._out_node])
+            if grad and truncate_steps < T and b - a == truncate_steps:
+                self.detach()
+            if verbose:
+                print(f"Progress: {b}/{T} integration steps finished.")
+        per_step = torch.cat(pending)
+        rows, start = [], cutoff
+        for t in sample_at:  # mean over the steps buffered since the previous sample (network.py:595)
+            rows.append(per_step[start:t + 1].mean(dim=0))
+            start = t + 1
+        outputs = torch.stack(rows) if rows else per_step[:0]
+        rec_out = []
+        for (label, _), slot in zip(rec_vars, rec_slots):
+            rec_out.append(torch.cat(rec[label][slot])[sample_at] if grad else rec[label][slot])
+        obs.record_block(sample_at, outputs, 0.0, rec_out)
 
     def _record_slots(self, rnn: RateNet, rec_vars) -> Optional[List[int]]:
         """Kernel record slot of each requested variable of the population (0: first state variable,
@@ -520,20 +635,25 @@ class Network:
         plan = self._chain_plan()
         rec_vars = list(obs.recorded_state_variables)
         steps = inp.shape[0]
-        if plan is None or rec_vars:
+        windows = plan is None and not rec_vars and self._dag_plan([]) is not None  # several populations, no cycles
+        if (plan is None and not windows) or rec_vars:
             return self._bptt_stepwise(inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps,
                                        optim_steps, verbose)
-        pre, label, post = plan
-        rnn: RateNet = self.get_node(label)
-        N = rnn._pop.rows
+        if not windows:
+            pre, label, post = plan
+            rnn: RateNet = self.get_node(label)
+            N = rnn._pop.rows
         error = 0.0
         for a in range(0, steps, optim_steps):
             b = min(a + optim_steps, steps)
             with torch.enable_grad():
-                X = self._apply_chain(pre, inp[a:b], None, label) if pre else inp[a:b]
-                traj = rnn._grad_window(b - a, self._fit_width(X, N)) if self._wants_grad(plan, X) else \
-                    self._nograd_traj(rnn, b - a, self._fit_width(X, N))
-                preds = self._apply_chain(post, traj, label, None) if post else traj
+                if windows:
+                    preds = self._window_outputs(inp[a:b], a, True, {}, 0, 1)[self._out_node]
+                else:
+                    X = self._apply_chain(pre, inp[a:b], None, label) if pre else inp[a:b]
+                    traj = rnn._grad_window(b - a, self._fit_width(X, N)) if self._wants_grad(plan, X) else \
+                        self._nograd_traj(rnn, b - a, self._fit_width(X, N))
+                    preds = self._apply_chain(post, traj, label, None) if post else traj
                 prev_error = error
                 if b - a == optim_steps:  # only complete windows trigger an update (network.py:1035)
                     error = self._bptt_step(preds, target[a:b], optimizer, loss, error_kwargs, step_kwargs,

@@ -50,7 +50,8 @@ class Observer:
         """One sample (reference observer.py:79-105)."""
         self._append("steps", [step])
         for key, val, reduce in zip(self._state_vars, record_vars, self._reduce_vars):
-            self._append(key, [torch.mean(val) if reduce else val])
+            # state vectors are updated in place by the step kernels: store a copy, not a view of the live state
+            self._append(key, [torch.mean(val) if reduce else val.detach().clone()])
         if self._record_out:
             self._append("out", [output])
         if self._record_loss:
