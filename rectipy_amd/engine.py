@@ -48,6 +48,11 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+import contextlib
+
+_NO_CONTEXT = contextlib.nullcontext()
+
+
 class HipBackend:
     """Calls into librectipy_hip.so on the current HIP stream of the tensors' device."""
     name = "hip"
@@ -68,57 +73,65 @@ class HipBackend:
     def _stream(device):
         return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
+    @staticmethod
+    def _on(device):
+        """Context that makes `device` current for the library call; a no-op object when it already is (the common
+        case, and the one a per-step caller pays for)."""
+        if device.index is None or device.index == torch.cuda.current_device():
+            return _NO_CONTEXT
+        return torch.cuda.device(device)
+
     def refresh_source(self, net: RpNet, device):
-        with torch.cuda.device(device):
+        with self._on(device):
             self._lib_mod.check(self.lib.rp_refresh_source(C.byref(net), self._stream(device)))
 
     def forward(self, net: RpNet, run: RpRun, device):
-        with torch.cuda.device(device):
+        with self._on(device):
             self._lib_mod.check(self.lib.rp_forward(C.byref(net), C.byref(run), self._stream(device)))
 
     def rate_backward(self, net: RpNet, bwd: RpBwd, device):
-        with torch.cuda.device(device):
+        with self._on(device):
             self._lib_mod.check(self.lib.rp_rate_backward(C.byref(net), C.byref(bwd), self._stream(device)))
 
     def qif_backward(self, net: RpNet, bwd: RpBwd, device):
-        with torch.cuda.device(device):
+        with self._on(device):
             self._lib_mod.check(self.lib.rp_qif_backward(C.byref(net), C.byref(bwd), self._stream(device)))
 
     def outer_accum(self, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
-        with torch.cuda.device(device):
+        with self._on(device):
             self._lib_mod.check(self.lib.rp_outer_accum(n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
 
     def outer_accum_rect(self, m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
-        with torch.cuda.device(device):
+        with self._on(device):
             self._lib_mod.check(self.lib.rp_outer_accum_rect(m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
 
     def bwd_prepare(self, net, bwd, device):
-        with torch.cuda.device(device):
+        with self._on(device):
             self._lib_mod.check(self.lib.rp_bwd_prepare(C.byref(net), C.byref(bwd), self._stream(device)))
 
     def bwd_partial(self, net, bwd, t, z_full, device):
-        with torch.cuda.device(device):
+        with self._on(device):
             self._lib_mod.check(self.lib.rp_bwd_partial(C.byref(net), C.byref(bwd), t, z_full, self._stream(device)))
 
     def bwd_apply(self, net, bwd, t, z_local, device):
-        with torch.cuda.device(device):
+        with self._on(device):
             self._lib_mod.check(self.lib.rp_bwd_apply(C.byref(net), C.byref(bwd), t, z_local, self._stream(device)))
 
     def shard_partial_rows(self, n, rows):
         return int(self.lib.rp_bwd_shard_partial_rows(n, rows))
 
     def forward_sharded(self, net, run, comm, device):
-        with torch.cuda.device(device):
+        with self._on(device):
             self._lib_mod.check(self.lib.rp_forward_sharded(C.byref(net), C.byref(run), C.byref(comm),
                                                             self._stream(device)))
 
     def backward_sharded(self, net, bwd, comm, device):
-        with torch.cuda.device(device):
+        with self._on(device):
             self._lib_mod.check(self.lib.rp_backward_sharded(C.byref(net), C.byref(bwd), C.byref(comm),
                                                                   self._stream(device)))
 
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
-        with torch.cuda.device(device):
+        with self._on(device):
             self._lib_mod.check(self.lib.rp_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss,
                                                       self._stream(device)))
 
@@ -184,6 +197,7 @@ class Population:
         self.aux = self._vec(0.0 if aux0 is None else aux0) if model in HAS_AUX else None
         self.aux2 = self._vec(0.0 if aux2_0 is None else aux2_0) if model in HAS_AUX2 else None
         self._scratch = torch.zeros(4, **f32) if model in NEEDS_MEANS else None
+        self._net_cache = None           # (key, RpNet) reused across calls, see _net()
         self.packed = None               # PackedRows of a fixed sparse W (sparse.py); the step kernel then streams it
         self.packed_t = None             # PackedRows of W^T (adjoint of a fixed sparse W), built on first use
         self.sparse_adjoint = True       # False: adjoint on the dense matrix even when a packed form exists
@@ -212,6 +226,14 @@ class Population:
         return t.contiguous().clone()
 
     def _net(self) -> RpNet:
+        """The population as an rp_net.  The struct is cached: the tensors it points at are updated in place for the
+        lifetime of the population (only set_weights / pack_weights swap buffers), so a per-step caller does not pay
+        for rebuilding it."""
+        key = (self.W.data_ptr(), self.v.data_ptr(), id(self.packed))
+        if self._net_cache is not None and self._net_cache[0] == key:
+            net = self._net_cache[1]
+            net.cur, net.dt, net.theta, net.v_reset = self.cur, self.dt, self.theta, self.v_reset
+            return net
         net = RpNet()
         net.model = MODEL_IDS[self.model]
         net.n, net.rows, net.row0 = self.n, self.rows, self.row0
@@ -235,6 +257,7 @@ class Population:
         net.dt = self.dt
         net.theta = self.theta
         net.v_reset = self.v_reset
+        self._net_cache = (key, net)
         return net
 
     # -- state ---------------------------------------------------------------------------
