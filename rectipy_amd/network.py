@@ -827,6 +827,13 @@ class Network:
                 traj = self._nograd_traj(rnn, inp.shape[0], self._fit_width(X, rnn._pop.rows))
                 Xe = self._apply_chain(mid, traj, label, None) if mid else traj
                 return edge.sweep(Xe, tgt, optim_steps)
+        if (not rec_vars and dst == self._out_node and getattr(self.get_node(dst), "name", None) == "identity"
+                and self._chain_plan() is None and self._dag_plan([]) is not None):
+            # several populations without cycles: every node's whole window first (the read-out does not feed back),
+            # then the RLS sweep over the stored inputs of the trained edge
+            with torch.no_grad():
+                outs = self._window_outputs(inp, 0, False, {}, 0, 1)
+                return edge.sweep(outs[src], tgt, optim_steps)
         steps, loss, losses = inp.shape[0], 0.0, []
         with torch.no_grad():
             for step in range(steps):

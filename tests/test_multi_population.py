@@ -93,3 +93,25 @@ def test_fit_bptt_window_by_window_equals_step_by_step(target, spiking_second):
         assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max()), key
     assert np.abs(res[0][1] - res[1][1]).max() < 1e-5 and res[0][1].max() > 0
     assert np.abs(res[0][2] - res[1][2]).max() < 1e-5
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_fit_rls_behind_two_populations(target):
+    """RLS read-out behind inp -> p1 -> p2: the populations' windows first, then one RLS sweep; same weights, P matrix
+    and predictions as the step-by-step loop."""
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((80, 3)).astype(np.float32)
+    tgt = (rng.standard_normal((80, 2)) * 0.3).astype(np.float32)
+    res = []
+    for stepwise in (False, True):
+        net = build(target, stepwise=stepwise)
+        net.pop_edge("p2", "out")
+        net.pop_node("out")
+        net.add_func_node("out", 2, "identity")
+        edge = net.add_edge("p2", "out", train="rls", beta=0.98, alpha=1.0)
+        obs = net.fit_rls(x, tgt, update_steps=2, sampling_steps=1, verbose=False)
+        res.append((edge.weights.detach().cpu().numpy().copy(), edge.P.detach().cpu().numpy().copy(),
+                    obs.to_numpy("out"), obs.to_numpy("loss")))
+    for a, b in zip(res[0], res[1]):
+        assert a.shape == b.shape and np.abs(a - b).max() <= 2e-4 * max(1.0, np.abs(b).max())
+    assert np.abs(res[0][0]).max() > 0
