@@ -267,6 +267,8 @@ class Network:
         """(pre, rnn_label, post) when the graph is a simple chain around ONE diff-eq node whose other
         members are element-wise activation nodes and plain Linear edges; else None."""
         order = self._order
+        if getattr(self, "_force_stepwise", False):  # test seam: always walk the graph step by step
+            return None
         if any(self.graph.in_degree(n) > 1 or self.graph.out_degree(n) > 1 for n in order):
             return None
         diffeq = [n for n in order if self[n]["node_type"] == "diff_eq"]
@@ -274,7 +276,7 @@ class Network:
             return None
         for n in order:
             node = self.get_node(n)
-            if n != diffeq[0] and not (isinstance(node, InstantNode) and node.name in InstantNode.elementwise):
+            if n != diffeq[0] and not (isinstance(node, InstantNode) and node.name in InstantNode.batched):
                 return None
         for s, t in self.graph.edges:
             from .rls import RLS
@@ -354,7 +356,7 @@ class Network:
             return None
         for n in self._order:
             node = self.get_node(n)
-            if not isinstance(node, RateNet) and not (isinstance(node, InstantNode) and node.name in InstantNode.elementwise):
+            if not isinstance(node, RateNet) and not (isinstance(node, InstantNode) and node.name in InstantNode.batched):
                 return None
         for s_, t_ in self.graph.edges:
             if type(self.get_edge(s_, t_)) not in (Linear, RLS):
@@ -814,7 +816,7 @@ class Network:
         fused = (simple and len(diffeq) == 1 and isinstance(self.get_node(diffeq[0]), RateNet) and not rec_vars
                  and dst == self._out_node and getattr(self.get_node(dst), "name", None) == "identity"
                  and order.index(src) >= order.index(diffeq[0])
-                 and all(isinstance(self.get_node(n), InstantNode) and self.get_node(n).name in InstantNode.elementwise
+                 and all(isinstance(self.get_node(n), InstantNode) and self.get_node(n).name in InstantNode.batched
                          for n in order if n != diffeq[0])
                  and all(type(self.get_edge(s, t)) is Linear or (s, t) == (src, dst) for s, t in self.graph.edges))
         if fused:

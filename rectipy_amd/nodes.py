@@ -43,6 +43,9 @@ class InstantNode:
         "log_softmax": lambda kw: torch.nn.LogSoftmax(dim=kw.get("dim", 0)),
     }
     elementwise = ("tanh", "sigmoid", "identity")
+    # every activation can be applied to a whole [T, n] window: the element-wise ones as they are, the normalising ones
+    # (built with dim=0 for the reference's one-step vectors) along the neuron axis of each row
+    batched = ("tanh", "sigmoid", "identity", "softmax", "softmin", "log_softmax")
 
     def __init__(self, n: int, func: str, **kwargs):
         if func not in self._funcs:
@@ -52,11 +55,15 @@ class InstantNode:
         self.n_out = n
         self.name = func
         self.func = self._funcs[func](kwargs)
+        self._rowwise = {"softmax": torch.softmax, "softmin": torch.nn.functional.softmin,
+                         "log_softmax": torch.log_softmax}.get(func) if kwargs.get("dim", 0) == 0 else None
 
     def __getitem__(self, item):
         return None
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._rowwise is not None and x.dim() == 2:  # a window of steps: normalise every step's vector
+            return self._rowwise(x, dim=1)
         return self.func(x)
 
     def parameters(self, **kwargs):

@@ -115,3 +115,33 @@ def test_fit_rls_behind_two_populations(target):
     for a, b in zip(res[0], res[1]):
         assert a.shape == b.shape and np.abs(a - b).max() <= 2e-4 * max(1.0, np.abs(b).max())
     assert np.abs(res[0][0]).max() > 0
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_softmax_read_out_in_window_mode(target):
+    """A normalising read-out (softmax over the output units, the reference builds it with dim=0 for one-step vectors)
+    behind a population: applied per step inside the fused window evaluation; buffer means, training and outputs equal
+    the step-by-step walk."""
+    rng = np.random.default_rng(7)
+    n, k, T = 20, 4, 50
+    W, W_out = rng.standard_normal((n, n)) / 4, rng.standard_normal((k, n))
+    x = rng.standard_normal((T, 1)).astype(np.float32)
+    tgt = np.eye(k, dtype=np.float32)[rng.integers(0, k, T)]
+    res = []
+    for stepwise in (False, True):
+        net = Network(1e-2, **target)
+        net._force_stepwise = stepwise
+        net.add_diffeq_node("rnn", TANH, weights=W, source_var="tanh_op/r", target_var="li_op/r_in",
+                            input_var="li_op/I_ext", output_var="tanh_op/r", dtype=torch.float32,
+                            node_vars={"all/li_op/tau": 0.5})
+        net.add_func_node("out", k, "softmax")
+        edge = net.add_edge("rnn", "out", weights=W_out.copy(), train="gd")
+        obs = net.run(x, sampling_steps=3, cutoff=4, verbose=False, enable_grad=False)
+        out = obs.to_numpy("out")
+        assert np.abs(out.sum(axis=1) - 1.0).max() < 1e-5          # a mean of probability vectors
+        net.reset()
+        net.fit_bptt(x, tgt, optimizer="sgd", lr=0.5, update_steps=25, sampling_steps=5, verbose=False)
+        res.append((out, edge.weights.detach().cpu().numpy().copy()))
+    for a, b in zip(res[0], res[1]):
+        assert np.abs(a - b).max() < 1e-5
+    assert np.abs(res[0][1] - W_out).max() > 1e-4
