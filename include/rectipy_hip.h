@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 5
+#define RP_ABI_VERSION 6
 
 #define RP_OK 0
 #define RP_ERR_ARG (-1)      /* null pointer, bad enum, bad flag combination  */
@@ -145,7 +145,15 @@ typedef struct rp_net {
        non-null rp_forward reads it, not W. */
     const float* sp_vals;     /* [groups x 256] entry 4k+e of lane l at (group k) * 256 + 4 l + e; 0.0 = padding    */
     const uint16_t* sp_cidx;  /* [groups x 256] code of each entry: (component << 14) | column chunk m                */
-    const int32_t* sp_rowoff; /* [rows + 1] first group of each row                                                  */
+    const int32_t* sp_rowoff; /* [rows + 1] first group of each row (windowed form: [slots * sp_phases + 1])        */
+    /* Windowed form for n > 32768 (sparse.py: pack_rows_windowed), selected by sp_row_ids != NULL: the source vector
+       is staged in LDS one 32768-column window at a time; rows are regrouped into batches of 64 slots that start their
+       sweep in the same window, a lane's entries are stored per phase and codes hold window-relative chunks. */
+    const int32_t* sp_row_ids;      /* [sp_batches * 64] row of each slot, -1 = padding                               */
+    const int32_t* sp_batch_class;  /* [sp_batches] start window of a batch                                           */
+    const int32_t* sp_phase_window; /* [windows * sp_phases] window staged in phase ph of class c, -1 = none           */
+    int32_t sp_phases;
+    int32_t sp_batches;
 } rp_net;
 
 /*

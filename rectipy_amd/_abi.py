@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 5
+RP_ABI_VERSION = 6
 
 RP_OK = 0
 RP_ERR_ARG = -1
@@ -62,6 +62,11 @@ class RpNet(C.Structure):
         ("sp_vals", fp),
         ("sp_cidx", fp),
         ("sp_rowoff", fp),
+        ("sp_row_ids", fp),
+        ("sp_batch_class", fp),
+        ("sp_phase_window", fp),
+        ("sp_phases", C.c_int32),
+        ("sp_batches", C.c_int32),
     ]
 
 

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(kSparseThreads) void adj_sparse_kernel(const BwdPar
     const int lane = threadIdx.x & (RP_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     constexpr int kWaves = kSparseThreads / RP_WAVE;
-    if constexpr (LDS_SRC) rp_sparse_stage_source(lds_u, P.u, P.n);
+    if constexpr (LDS_SRC) rp_sparse_stage_source(lds_u, P.u, P.n, (P.n + 255) & ~255);
     const int lane_base = LDS_SRC ? 64 * (lane >> 4) : 4 * lane;
     const int lane_rot = 4 * (lane & 15) + (lane >> 4);
     const float* xs = LDS_SRC ? lds_u : P.u;

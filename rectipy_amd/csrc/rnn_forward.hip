@@ -62,6 +62,10 @@ struct StepParams {
     const float* sp_vals;
     const uint16_t* sp_cidx;
     const int32_t* sp_rowoff;
+    const int32_t* sp_row_ids;
+    const int32_t* sp_batch_class;
+    const int32_t* sp_phase_window;
+    int sp_phases, sp_batches;
 };
 
 // ---- row dot products (rp_dot.h) ---------------------------------------------
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepP
     const int lane = threadIdx.x & (RP_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     constexpr int kWaves = kSparseThreads / RP_WAVE;
-    if constexpr (LDS_SRC) rp_sparse_stage_source(lds_src, P.src_cur, P.n);
+    if constexpr (LDS_SRC) rp_sparse_stage_source(lds_src, P.src_cur, P.n, (P.n + 255) & ~255);
     // LDS: 64-column block of this lane inside a chunk and its rotated offset; global: first of its four columns
     const int lane_base = LDS_SRC ? 64 * (lane >> 4) : 4 * lane;
     const int lane_rot = 4 * (lane & 15) + (lane >> 4);
@@ -307,6 +311,93 @@ __global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepP
     }
 }
 
+// Windowed form (n > 32768): the source vector is staged in LDS one 32768-column window at a time.  A workgroup takes a
+// batch of 64 slots (rows whose sweeps start in the same window; 4 per wave) and walks the phases of that class: stage
+// the window of the phase, let every wave run its rows' entries of that phase (codes hold window-relative chunks), next
+// phase.  The accumulators stay in registers across the phases, so every one of them still sees its nonzeros in the
+// dense order.
+constexpr int kWindowChunks = 128;
+constexpr int kBatchRows = 64;
+
+template <int MODEL, int U>
+__global__ __launch_bounds__(kSparseThreads) void step_sparse_windowed_kernel(const StepParams P) {
+    extern __shared__ float lds_src[];
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    constexpr int RB = kBatchRows / (kSparseThreads / RP_WAVE);  // rows per wave
+    const int lane_base = 64 * (lane >> 4);
+    const int lane_rot = 4 * (lane & 15) + (lane >> 4);
+    const int NP = P.sp_phases;
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    for (int batch = blockIdx.x; batch < P.sp_batches; batch += gridDim.x) {
+        const int cls = P.sp_batch_class[batch];
+        int slot[RB], row[RB];
+        rp_f4 acc[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            slot[j] = batch * kBatchRows + wave * RB + j;
+            row[j] = P.sp_row_ids[slot[j]];
+            acc[j] = rp_f4{0.f, 0.f, 0.f, 0.f};
+        }
+        int staged = -1;
+        for (int ph = 0; ph < NP; ++ph) {
+            const int w = P.sp_phase_window[cls * NP + ph];
+            if (w < 0) continue;  // block-uniform
+            if (w != staged) {
+                __syncthreads();  // every wave is done with the previous window
+                const int col0 = w * kWindowChunks * 256;
+                const int cols = min(kWindowChunks * 256, P.n - col0);
+                rp_sparse_stage_source(lds_src, P.src_cur + col0, cols, min(kWindowChunks * 256, (cols + 255) & ~255));
+                staged = w;
+            }
+            const float* vp[RB];
+            const uint16_t* ip[RB];
+            int len[RB], nmax = 0;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int g0 = P.sp_rowoff[slot[j] * NP + ph];
+                len[j] = P.sp_rowoff[slot[j] * NP + ph + 1] - g0;
+                vp[j] = P.sp_vals + (int64_t)g0 * 256 + 4 * lane;
+                ip[j] = P.sp_cidx + (int64_t)g0 * 256 + 4 * lane;
+                nmax = len[j] > nmax ? len[j] : nmax;
+            }
+            for (int k = 0; k < nmax; k += U) {
+                rp_f4 v[RB][U];
+                us4 m[RB][U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < RB; ++j)
+                        if (k + u < len[j]) {
+                            v[j][u] = rp_ld4_stream(vp[j] + (int64_t)(k + u) * 256);
+                            m[j][u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(ip[j] + (int64_t)(k + u) * 256));
+                        }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < RB; ++j)
+                        if (k + u < len[j]) {
+                            sparse_entry<true>(v[j][u].x, m[j][u].x, lds_src, lane_base, lane_rot, acc[j]);
+                            sparse_entry<true>(v[j][u].y, m[j][u].y, lds_src, lane_base, lane_rot, acc[j]);
+                            sparse_entry<true>(v[j][u].z, m[j][u].z, lds_src, lane_base, lane_rot, acc[j]);
+                            sparse_entry<true>(v[j][u].w, m[j][u].w, lds_src, lane_base, lane_rot, acc[j]);
+                        }
+            }
+        }
+        float mine = 0.f;
+        int my_row = -1;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const float sum = rp_wave_allreduce(rp_lane_sum4(acc[j]));
+            if (lane == j) {
+                mine = sum;
+                my_row = row[j];
+            }
+        }
+        if (lane < RB && my_row >= 0) epilogue<MODEL>(P, my_row, mine);
+    }
+}
+
 // benchmark-only: rows per wave / groups in flight per row of the sparse step (0 = built-in)
 int g_sparse_R = 0, g_sparse_U = 0;
 
@@ -340,6 +431,21 @@ int launch_step_sparse(const StepParams& P, hipStream_t st) {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RP_ERR_HIP;
         n_cu = prop.multiProcessorCount;
+    }
+    if (P.sp_row_ids) {  // windowed form
+        static bool attr_set_w = false;
+        if (!attr_set_w) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&step_sparse_windowed_kernel<MODEL, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    sizeof(float) * kWindowChunks * 256) != hipSuccess)
+                return RP_ERR_HIP;
+            attr_set_w = true;
+        }
+        const int blocks = P.sp_batches < n_cu ? P.sp_batches : n_cu;
+        if (blocks > 0)
+            hipLaunchKernelGGL((step_sparse_windowed_kernel<MODEL, 2>), dim3(blocks), dim3(kSparseThreads),
+                               sizeof(float) * kWindowChunks * 256, st, P);
+        return RP_OK;
     }
     if constexpr (MODEL == RP_MODEL_LI_TANH) {  // benchmark-only sweep (rp_set_sparse_tuning)
         const int key = g_sparse_R * 10 + g_sparse_U;
@@ -493,6 +599,11 @@ void fill_static(StepParams& P, const rp_net* net) {
     P.sp_vals = net->sp_vals;
     P.sp_cidx = net->sp_cidx;
     P.sp_rowoff = net->sp_rowoff;
+    P.sp_row_ids = net->sp_row_ids;
+    P.sp_batch_class = net->sp_batch_class;
+    P.sp_phase_window = net->sp_phase_window;
+    P.sp_phases = net->sp_phases;
+    P.sp_batches = net->sp_batches;
 }
 
 // Tuning override (rp_set_tuning): 0 = use the built-in choice.
@@ -663,6 +774,8 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
         if (!aligned16(net->sp_vals) || (reinterpret_cast<uintptr_t>(net->sp_cidx) & 7u) || !aligned16(net->src[0]) ||
             !aligned16(net->src[1]))
             RP_FAIL(RP_ERR_ARG, "sp_vals / src must be 16-byte and sp_cidx 8-byte aligned");
+        if (net->sp_row_ids && (!net->sp_batch_class || !net->sp_phase_window || net->sp_phases < 3 || net->sp_batches < 0))
+            RP_FAIL(RP_ERR_ARG, "windowed packed form needs sp_batch_class, sp_phase_window, sp_phases >= 3, sp_batches");
     }
 
     // count the samples this call produces before touching anything

@@ -120,9 +120,12 @@ constexpr int kSparseLdsMaxN = 32768;
 // Cooperative copy of src[0..n) into LDS: inside every 64-column block the element at offset o goes to
 // (o + ((column >> 6) & 3)) & 63, so that the 64 lanes of a gather (lane l asks for column 256 m_l + 4 l + c) hit 64
 // different banks whatever their chunks m_l.
-__device__ __forceinline__ void rp_sparse_stage_source(float* lds_src, const float* __restrict__ src, int n) {
-    for (int c4 = threadIdx.x * 4; c4 < n; c4 += kSparseThreads * 4) {
-        const rp_f4 v = rp_ld4(src + c4);
+// Columns in [n_valid, n_total) are filled with zeros: padding entries (value 0, code 0) gather from chunk 0 of the staged
+// range and must meet a finite number there.
+__device__ __forceinline__ void rp_sparse_stage_source(float* lds_src, const float* __restrict__ src, int n_valid,
+                                                       int n_total) {
+    for (int c4 = threadIdx.x * 4; c4 < n_total; c4 += kSparseThreads * 4) {
+        const rp_f4 v = c4 < n_valid ? rp_ld4(src + c4) : rp_f4{0.f, 0.f, 0.f, 0.f};
         const int base = c4 & ~63, h = (c4 >> 6) & 3, o = c4 & 63;
         lds_src[base | ((o + 0 + h) & 63)] = v.x;
         lds_src[base | ((o + 1 + h) & 63)] = v.y;

@@ -201,6 +201,7 @@ class Population:
         self.packed = None               # PackedRows of a fixed sparse W (sparse.py); the step kernel then streams it
         self.packed_t = None             # PackedRows of W^T (adjoint of a fixed sparse W), built on first use
         self.sparse_adjoint = True       # False: adjoint on the dense matrix even when a packed form exists
+        self.windowed_sparse = True      # False: n > 32768 uses the plain packed form with the L2 gather
         self._wt = None                  # workspace for W^T (adjoint of small networks), allocated on first use
         self.transposed_adjoint = True   # False: always use the column-strip kernels (tests, measurements)
         self.spiking = model in SPIKING
@@ -251,6 +252,10 @@ class Population:
         if self.packed is not None:
             net.sp_vals, net.sp_cidx = self.packed.vals.data_ptr(), self.packed.code.data_ptr()
             net.sp_rowoff = self.packed.rowoff.data_ptr()
+            if self.packed.row_ids is not None:
+                net.sp_row_ids, net.sp_batch_class = self.packed.row_ids.data_ptr(), self.packed.batch_class.data_ptr()
+                net.sp_phase_window = self.packed.phase_window.data_ptr()
+                net.sp_phases, net.sp_batches = self.packed.phases, self.packed.batches
         net.src[0] = self.src[0].data_ptr()
         net.src[1] = self.src[1].data_ptr()
         net.cur = self.cur
@@ -290,8 +295,14 @@ class Population:
         """Stream the coupling matrix in its packed sparse form from now on (forward pass only; bit-identical results,
         see sparse.py).  The dense matrix stays in place for the adjoint kernels.  Call again after changing W."""
         from . import sparse
-        self.packed = sparse.pack_rows(self.W, row0=self.row0) if enable else None
+        if not enable:
+            self.packed = None
+        elif self.n > sparse.WINDOW_COLUMNS and self.windowed_sparse:
+            self.packed = sparse.pack_rows_windowed(self.W, row0=self.row0)  # source vector staged window by window
+        else:
+            self.packed = sparse.pack_rows(self.W, row0=self.row0)
         self.packed_t = None
+        self._net_cache = None
         return self.packed
 
     def _packed_transpose(self):

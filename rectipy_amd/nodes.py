@@ -231,8 +231,9 @@ class RateNet:
     def _maybe_pack_weights(self):
         """A coupling matrix that is not trained and mostly zeros (`utility.random_connectivity`, p = 0.1 in the
         reference's examples) is streamed in its packed form: same bits out, a fraction of the bytes in (sparse.py).
-        "auto" packs when the packed stream is measurably faster (scripts/bench_sparse.py): when it is at most 0.7x the
-        dense bytes with the source vector in LDS (n <= 32768), at most 0.25x with the L2 gather above that."""
+        "auto" packs when the packed stream is measurably faster (scripts/bench_sparse.py, bench_sparse_large.py): when
+        it is at most 0.7x the dense bytes (the source vector is gathered from LDS at every n: whole below n = 32768,
+        window by window above)."""
         pop = self._pop
         mode = self._sparse_mode
         if mode is False or "weights" in self._train_names or pop.n % 4 != 0 or pop.device.type != "cuda":
@@ -245,7 +246,7 @@ class RateNet:
         if mode == "auto" and sparse.density(pop.W) > 0.5:
             return
         packed = pop.pack_weights()
-        limit = 0.7 if pop.n <= 32768 else 0.25
+        limit = 0.7
         if mode == "auto" and packed.stored_bytes > limit * 4.0 * pop.rows * pop.n:
             pop.pack_weights(False)
 

@@ -238,3 +238,89 @@ def test_fit_bptt_through_a_fixed_sparse_reservoir(hip_device):
     assert np.abs(res[0][0] - W_in).max() > 1e-6, "the input edge was not trained"
     for a, b in zip(res[0], res[1]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def emulate_row_windowed(packed, src, n, slot):
+    """One row of the windowed sparse kernel: phases in order, each gathering from the window it stages (the code holds
+    the chunk index relative to that window)."""
+    vals, code, off = packed.vals.numpy(), packed.code.numpy().view(np.uint16), packed.rowoff.numpy()
+    NP, Wc = packed.phases, sparse.WINDOW_CHUNKS
+    cls = int(packed.batch_class[slot // sparse.BATCH_ROWS])
+    sched = packed.phase_window.numpy().reshape(-1, NP)[cls]
+    a = np.zeros((64, 4), dtype=np.float32)
+    padded = np.zeros(((n + 255) // 256 + Wc) * 256, dtype=np.float32)
+    padded[:n] = src[:n]
+    for ph in range(NP):
+        w = int(sched[ph])
+        g0, g1 = off[slot * NP + ph], off[slot * NP + ph + 1]
+        assert w >= 0 or g0 == g1
+        window = padded[w * Wc * 256:(w + 1) * Wc * 256] if w >= 0 else None
+        for k in range(g0, g1):
+            for l in range(64):
+                for e in range(4):
+                    v, word = vals[k * 256 + 4 * l + e], int(code[k * 256 + 4 * l + e])
+                    c, m = word >> 14, word & 0x3fff
+                    a[l, c] = np.float32(np.float64(v) * np.float64(window[256 * m + 4 * l + c]) + np.float64(a[l, c]))
+    s = np.array([np.float32(np.float32(a[l, 0] + a[l, 1]) + np.float32(a[l, 2] + a[l, 3])) for l in range(64)],
+                 dtype=np.float32)
+    for offb in (32, 16, 8, 4, 2, 1):
+        s = np.array([np.float32(s[l] + s[l ^ offb]) for l in range(64)], dtype=np.float32)
+    return s[0]
+
+
+@pytest.mark.parametrize("rows,n,row0", [(24, 256 * 300 + 8, 8), (16, 256 * 256, 1024), (12, 256 * 130, 40)])
+def test_windowed_packed_rows_reproduce_the_dense_row_dot(oracle_backend, rows, n, row0):
+    """n > 32768: phases / windows / batches of the windowed layout against the oracle's dense row dot, bit for bit
+    (three windows + partial chunk; exactly two windows, no partial chunk; rows starting in different windows)."""
+    import ctypes as C
+    W = random_sparse(rows, n, 0.02, seed=rows + n)
+    packed = sparse.pack_rows_windowed(W, row0=row0)
+    assert int((packed.vals != 0).sum()) == int((W != 0).sum())
+    ids = packed.row_ids.numpy()
+    assert sorted(i for i in ids if i >= 0) == list(range(rows)) and len(ids) % sparse.BATCH_ROWS == 0
+    src = torch.randn(n, generator=torch.Generator().manual_seed(1)).numpy().astype(np.float32)
+    lib = oracle_backend.lib
+    for slot, i in enumerate(ids):
+        if i < 0:
+            assert packed.rowoff[slot * packed.phases] == packed.rowoff[(slot + 1) * packed.phases]
+            continue
+        w = np.ascontiguousarray(W[i].numpy())
+        dense = lib.oracle_row_dot(w.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), n, 1, row0 + int(i))
+        got = emulate_row_windowed(packed, src, n, slot)
+        assert np.float32(dense).view(np.uint32) == np.float32(got).view(np.uint32) or (dense == 0 and got == 0), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["li_tanh", "qif"])
+@pytest.mark.parametrize("rows,n,row0", [(200, 33024, 64), (136, 65536, 1024), (96, 256 * 300 + 8, 8)])
+def test_windowed_sparse_step_kernel_equals_dense_oracle(oracle_backend, hip_device, model, rows, n, row0):
+    """n > 32768 on the windowed form (source vector staged in LDS window by window, rows batched by start window):
+    HIP == dense oracle, bit for bit, incl. padding slots, a start exactly on a window edge and the partial chunk."""
+    params, kw, dt, drive, out_var = MODELS[model]
+    T = 40 if model == "li_tanh" else 160  # the QIF rows need ~60 steps to their first spikes
+    positive = model != "li_tanh"
+    W = random_sparse(rows, n, 0.05, seed=n + rows, scale=(40.0 / n if positive else 1.5 / (0.05 * n) ** 0.5))
+    if positive:
+        W = W.abs()
+    x = torch.full((T, 1), drive) + torch.randn(T, 1, generator=torch.Generator().manual_seed(2)) * 0.1 * abs(drive)
+    src0 = torch.rand(n, generator=torch.Generator().manual_seed(3)) * 0.5
+    res = []
+    for backend, dev, pack in ((oracle_backend, "cpu", False), (None, hip_device, True)):
+        pop = Population(model, W, params, dt, dev, n=n, row0=row0, backend=backend, **kw)
+        if pack:
+            packed = pop.pack_weights()
+            assert packed.row_ids is not None and packed.phases >= 3
+        traj = torch.zeros(T, rows, device=dev)
+        for t in range(T):  # a row shard: the rest of the source vector comes from outside every step
+            own = pop.source_local.clone()
+            pop.source.copy_(src0.to(dev) * (1 + 0.01 * t))
+            pop.set_source_local(own)
+            pop.forward(1, x=x[t:t + 1].to(dev), traj=traj[t:t + 1], out_var=out_var, step0=t)
+        if dev != "cpu":
+            torch.cuda.synchronize()
+        res.append((traj.cpu(), pop.v.cpu(), pop.source_local.cpu()))
+    for a, b, name in zip(res[0], res[1], ("trajectory", "v", "source")):
+        a, b = a.numpy(), b.numpy()
+        same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
+        assert same.all(), f"{model} {rows}x{n} {name}: {np.count_nonzero(~same)} differ, max {np.abs(a - b).max()}"
+    assert np.isfinite(res[0][0].numpy()).all() and np.abs(np.diff(res[0][0].numpy(), axis=0)).max() > 0
