@@ -246,6 +246,12 @@ typedef struct rp_bwd {
     const float* spt_vals;
     const uint16_t* spt_cidx;
     const int32_t* spt_rowoff;
+    /* windowed form of the packed W^T for n > 32768 (as rp_net.sp_row_ids ...), selected by spt_row_ids != NULL */
+    const int32_t* spt_row_ids;
+    const int32_t* spt_batch_class;
+    const int32_t* spt_phase_window;
+    int32_t spt_phases;
+    int32_t spt_batches;
 } rp_bwd;
 
 #define RP_BWD_TRANSPOSE_MAX_N 4096

@@ -141,6 +141,11 @@ class RpBwd(C.Structure):
         ("spt_vals", fp),
         ("spt_cidx", fp),
         ("spt_rowoff", fp),
+        ("spt_row_ids", fp),
+        ("spt_batch_class", fp),
+        ("spt_phase_window", fp),
+        ("spt_phases", C.c_int32),
+        ("spt_batches", C.c_int32),
     ]
 
 

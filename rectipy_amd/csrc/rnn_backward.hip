@@ -90,6 +90,10 @@ struct BwdParams {
     const float* spt_vals;
     const uint16_t* spt_cidx;
     const int32_t* spt_rowoff;
+    const int32_t* spt_row_ids;
+    const int32_t* spt_batch_class;
+    const int32_t* spt_phase_window;
+    int spt_phases, spt_batches;
 };
 
 // partials[q][j] = sum_{i in chunk q, ascending} W[i][j] * u[i]
@@ -564,6 +568,20 @@ __global__ __launch_bounds__(kSparseThreads) void adj_sparse_kernel(const BwdPar
     }
 }
 
+// windowed form of the packed W^T (n > 32768): rp_sparse_windowed_rows with the adjoint update as the epilogue
+template <bool SPIKING, int U>
+__global__ __launch_bounds__(kSparseThreads) void adj_sparse_windowed_kernel(const BwdParams P, const SpkGrad G) {
+    extern __shared__ float lds_u[];
+    const SparseWindowed S{P.spt_vals, P.spt_cidx, P.spt_rowoff, P.spt_row_ids, P.spt_batch_class, P.spt_phase_window,
+                           P.spt_phases, P.spt_batches};
+    rp_sparse_windowed_rows<U>(S, P.u, P.n, lds_u, [&](int j, float z) {
+        if constexpr (SPIKING)
+            spk_finalize_elem(P, G, j, z);
+        else
+            finalize_elem(P, j, z);
+    });
+}
+
 template <bool SPIKING>
 int launch_adj_sparse(const BwdParams& P, const SpkGrad& G, hipStream_t st) {
     static int n_cu = 0;
@@ -572,6 +590,21 @@ int launch_adj_sparse(const BwdParams& P, const SpkGrad& G, hipStream_t st) {
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RP_ERR_HIP;
         n_cu = prop.multiProcessorCount;
+    }
+    if (P.spt_row_ids) {
+        static bool attr_set_w = false;
+        if (!attr_set_w) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_sparse_windowed_kernel<SPIKING, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    sizeof(float) * kWindowChunks * 256) != hipSuccess)
+                return RP_ERR_HIP;
+            attr_set_w = true;
+        }
+        const int wblocks = P.spt_batches < n_cu ? P.spt_batches : n_cu;
+        if (wblocks > 0)
+            hipLaunchKernelGGL((adj_sparse_windowed_kernel<SPIKING, 2>), dim3(wblocks), dim3(kSparseThreads),
+                               sizeof(float) * kWindowChunks * 256, st, P, G);
+        return RP_OK;
     }
     constexpr int kWaves = kSparseThreads / RP_WAVE;
     int blocks = (P.n + kWaves - 1) / kWaves;
@@ -606,6 +639,13 @@ int sparse_t_mode(const rp_net* net, const rp_bwd* b, BwdParams& P, bool& use) {
     P.spt_vals = b->spt_vals;
     P.spt_cidx = b->spt_cidx;
     P.spt_rowoff = b->spt_rowoff;
+    if (b->spt_row_ids && (!b->spt_batch_class || !b->spt_phase_window || b->spt_phases < 3 || b->spt_batches < 0))
+        RP_FAIL(RP_ERR_ARG, "windowed packed W^T needs spt_batch_class, spt_phase_window, spt_phases >= 3, spt_batches");
+    P.spt_row_ids = b->spt_row_ids;
+    P.spt_batch_class = b->spt_batch_class;
+    P.spt_phase_window = b->spt_phase_window;
+    P.spt_phases = b->spt_phases;
+    P.spt_batches = b->spt_batches;
     return RP_OK;
 }
 

@@ -311,91 +311,13 @@ __global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepP
     }
 }
 
-// Windowed form (n > 32768): the source vector is staged in LDS one 32768-column window at a time.  A workgroup takes a
-// batch of 64 slots (rows whose sweeps start in the same window; 4 per wave) and walks the phases of that class: stage
-// the window of the phase, let every wave run its rows' entries of that phase (codes hold window-relative chunks), next
-// phase.  The accumulators stay in registers across the phases, so every one of them still sees its nonzeros in the
-// dense order.
-constexpr int kWindowChunks = 128;
-constexpr int kBatchRows = 64;
-
+// Windowed form (n > 32768): rp_sparse_windowed_rows (rp_dot.h) with the step epilogue.
 template <int MODEL, int U>
 __global__ __launch_bounds__(kSparseThreads) void step_sparse_windowed_kernel(const StepParams P) {
     extern __shared__ float lds_src[];
-    const int lane = threadIdx.x & (RP_WAVE - 1);
-    const int wave = threadIdx.x >> 6;
-    constexpr int RB = kBatchRows / (kSparseThreads / RP_WAVE);  // rows per wave
-    const int lane_base = 64 * (lane >> 4);
-    const int lane_rot = 4 * (lane & 15) + (lane >> 4);
-    const int NP = P.sp_phases;
-    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
-    for (int batch = blockIdx.x; batch < P.sp_batches; batch += gridDim.x) {
-        const int cls = P.sp_batch_class[batch];
-        int slot[RB], row[RB];
-        rp_f4 acc[RB];
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            slot[j] = batch * kBatchRows + wave * RB + j;
-            row[j] = P.sp_row_ids[slot[j]];
-            acc[j] = rp_f4{0.f, 0.f, 0.f, 0.f};
-        }
-        int staged = -1;
-        for (int ph = 0; ph < NP; ++ph) {
-            const int w = P.sp_phase_window[cls * NP + ph];
-            if (w < 0) continue;  // block-uniform
-            if (w != staged) {
-                __syncthreads();  // every wave is done with the previous window
-                const int col0 = w * kWindowChunks * 256;
-                const int cols = min(kWindowChunks * 256, P.n - col0);
-                rp_sparse_stage_source(lds_src, P.src_cur + col0, cols, min(kWindowChunks * 256, (cols + 255) & ~255));
-                staged = w;
-            }
-            const float* vp[RB];
-            const uint16_t* ip[RB];
-            int len[RB], nmax = 0;
-#pragma unroll
-            for (int j = 0; j < RB; ++j) {
-                const int g0 = P.sp_rowoff[slot[j] * NP + ph];
-                len[j] = P.sp_rowoff[slot[j] * NP + ph + 1] - g0;
-                vp[j] = P.sp_vals + (int64_t)g0 * 256 + 4 * lane;
-                ip[j] = P.sp_cidx + (int64_t)g0 * 256 + 4 * lane;
-                nmax = len[j] > nmax ? len[j] : nmax;
-            }
-            for (int k = 0; k < nmax; k += U) {
-                rp_f4 v[RB][U];
-                us4 m[RB][U];
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int j = 0; j < RB; ++j)
-                        if (k + u < len[j]) {
-                            v[j][u] = rp_ld4_stream(vp[j] + (int64_t)(k + u) * 256);
-                            m[j][u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(ip[j] + (int64_t)(k + u) * 256));
-                        }
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int j = 0; j < RB; ++j)
-                        if (k + u < len[j]) {
-                            sparse_entry<true>(v[j][u].x, m[j][u].x, lds_src, lane_base, lane_rot, acc[j]);
-                            sparse_entry<true>(v[j][u].y, m[j][u].y, lds_src, lane_base, lane_rot, acc[j]);
-                            sparse_entry<true>(v[j][u].z, m[j][u].z, lds_src, lane_base, lane_rot, acc[j]);
-                            sparse_entry<true>(v[j][u].w, m[j][u].w, lds_src, lane_base, lane_rot, acc[j]);
-                        }
-            }
-        }
-        float mine = 0.f;
-        int my_row = -1;
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const float sum = rp_wave_allreduce(rp_lane_sum4(acc[j]));
-            if (lane == j) {
-                mine = sum;
-                my_row = row[j];
-            }
-        }
-        if (lane < RB && my_row >= 0) epilogue<MODEL>(P, my_row, mine);
-    }
+    const SparseWindowed S{P.sp_vals, P.sp_cidx, P.sp_rowoff, P.sp_row_ids, P.sp_batch_class, P.sp_phase_window,
+                           P.sp_phases, P.sp_batches};
+    rp_sparse_windowed_rows<U>(S, P.src_cur, P.n, lds_src, [&](int row, float sum) { epilogue<MODEL>(P, row, sum); });
 }
 
 // benchmark-only: rows per wave / groups in flight per row of the sparse step (0 = built-in)

@@ -150,3 +150,101 @@ __device__ __forceinline__ void sparse_entry(float v, unsigned code, const float
     a.z = c == 2 ? r : a2;
     a.w = c == 3 ? r : a3;
 }
+
+// ---- windowed form (n > 32768; sparse.py: pack_rows_windowed) ----------------------------------------------------
+// The gathered vector is staged in LDS one 32768-column window at a time.  A workgroup takes a batch of 64 slots (rows
+// whose sweeps start in the same window; 4 per wave) and walks the phases of that class: stage the window of the phase,
+// let every wave run its rows' entries of that phase (codes hold window-relative chunks), next phase.  The accumulators
+// stay in registers across the phases, so every one of them still sees its nonzeros in the dense order.  `epi(row, sum)`
+// is called by one lane per finished row.
+constexpr int kWindowChunks = 128;
+constexpr int kBatchRows = 64;
+
+struct SparseWindowed {
+    const float* vals;
+    const uint16_t* code;
+    const int32_t* rowoff;        // [slots * phases + 1]
+    const int32_t* row_ids;       // [batches * 64], -1 = padding
+    const int32_t* batch_class;   // [batches]
+    const int32_t* phase_window;  // [windows * phases], -1 = no such phase
+    int phases, batches;
+};
+
+template <int U, typename Epi>
+__device__ __forceinline__ void rp_sparse_windowed_rows(const SparseWindowed& S, const float* __restrict__ src, int n,
+                                                        float* lds_src, Epi epi) {
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    constexpr int RB = kBatchRows / (kSparseThreads / RP_WAVE);  // rows per wave
+    const int lane_base = 64 * (lane >> 4);
+    const int lane_rot = 4 * (lane & 15) + (lane >> 4);
+    const int NP = S.phases;
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    for (int batch = blockIdx.x; batch < S.batches; batch += gridDim.x) {
+        const int cls = S.batch_class[batch];
+        int slot[RB], row[RB];
+        rp_f4 acc[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            slot[j] = batch * kBatchRows + wave * RB + j;
+            row[j] = S.row_ids[slot[j]];
+            acc[j] = rp_f4{0.f, 0.f, 0.f, 0.f};
+        }
+        int staged = -1;
+        for (int ph = 0; ph < NP; ++ph) {
+            const int w = S.phase_window[cls * NP + ph];
+            if (w < 0) continue;  // block-uniform
+            if (w != staged) {
+                __syncthreads();  // every wave is done with the previous window
+                const int col0 = w * kWindowChunks * 256;
+                const int cols = min(kWindowChunks * 256, n - col0);
+                rp_sparse_stage_source(lds_src, src + col0, cols, min(kWindowChunks * 256, (cols + 255) & ~255));
+                staged = w;
+            }
+            const float* vp[RB];
+            const uint16_t* ip[RB];
+            int len[RB], nmax = 0;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int g0 = S.rowoff[slot[j] * NP + ph];
+                len[j] = S.rowoff[slot[j] * NP + ph + 1] - g0;
+                vp[j] = S.vals + (int64_t)g0 * 256 + 4 * lane;
+                ip[j] = S.code + (int64_t)g0 * 256 + 4 * lane;
+                nmax = len[j] > nmax ? len[j] : nmax;
+            }
+            for (int k = 0; k < nmax; k += U) {
+                rp_f4 v[RB][U];
+                us4 m[RB][U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < RB; ++j)
+                        if (k + u < len[j]) {
+                            v[j][u] = rp_ld4_stream(vp[j] + (int64_t)(k + u) * 256);
+                            m[j][u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(ip[j] + (int64_t)(k + u) * 256));
+                        }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < RB; ++j)
+                        if (k + u < len[j]) {
+                            sparse_entry<true>(v[j][u].x, m[j][u].x, lds_src, lane_base, lane_rot, acc[j]);
+                            sparse_entry<true>(v[j][u].y, m[j][u].y, lds_src, lane_base, lane_rot, acc[j]);
+                            sparse_entry<true>(v[j][u].z, m[j][u].z, lds_src, lane_base, lane_rot, acc[j]);
+                            sparse_entry<true>(v[j][u].w, m[j][u].w, lds_src, lane_base, lane_rot, acc[j]);
+                        }
+            }
+        }
+        float mine = 0.f;
+        int my_row = -1;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const float sum = rp_wave_allreduce(rp_lane_sum4(acc[j]));
+            if (lane == j) {
+                mine = sum;
+                my_row = row[j];
+            }
+        }
+        if (lane < RB && my_row >= 0) epi(my_row, mine);
+    }
+}

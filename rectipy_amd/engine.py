@@ -308,7 +308,9 @@ class Population:
     def _packed_transpose(self):
         if self.packed_t is None:
             from . import sparse
-            self.packed_t = sparse.pack_rows(self.W.T.contiguous(), row0=0)
+            Wt = self.W.T.contiguous()
+            self.packed_t = sparse.pack_rows_windowed(Wt) if self.n > sparse.WINDOW_COLUMNS and self.windowed_sparse \
+                else sparse.pack_rows(Wt)
         return self.packed_t
 
     def reset_sampling(self):
@@ -460,6 +462,9 @@ class Population:
             pt = self._packed_transpose()
             if pt is not None:
                 b.spt_vals, b.spt_cidx, b.spt_rowoff = pt.vals.data_ptr(), pt.code.data_ptr(), pt.rowoff.data_ptr()
+                if pt.row_ids is not None:
+                    b.spt_row_ids, b.spt_batch_class = pt.row_ids.data_ptr(), pt.batch_class.data_ptr()
+                    b.spt_phase_window, b.spt_phases, b.spt_batches = pt.phase_window.data_ptr(), pt.phases, pt.batches
         on_host = self.device.type == "cpu"  # the CPU checker evaluates the same order on a dense transposed copy
         if not sharded and ((self.n <= _abi.RP_BWD_TRANSPOSE_MAX_N and self.transposed_adjoint and not b.spt_vals)
                             or (b.spt_vals and on_host)):

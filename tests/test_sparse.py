@@ -324,3 +324,32 @@ def test_windowed_sparse_step_kernel_equals_dense_oracle(oracle_backend, hip_dev
         same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
         assert same.all(), f"{model} {rows}x{n} {name}: {np.count_nonzero(~same)} differ, max {np.abs(a - b).max()}"
     assert np.isfinite(res[0][0].numpy()).all() and np.abs(np.diff(res[0][0].numpy(), axis=0)).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [33024, 65536])
+def test_windowed_sparse_adjoint_equals_l2_gather_form(hip_device, n):
+    """Adjoint on the packed rows of W^T for n > 32768: the windowed form (LDS staging per window) must give the bits of
+    the plain packed form (L2 gather), which tests at smaller n pin against the oracle."""
+    T = 4
+    gen = torch.Generator(device=hip_device).manual_seed(n)
+    W = torch.randn(n, n, device=hip_device, generator=gen) * (1.5 / (0.02 * n) ** 0.5)
+    W *= torch.rand(n, n, device=hip_device, generator=gen) < 0.02
+    x = torch.randn(T, 1, generator=torch.Generator().manual_seed(1)).to(hip_device) * 0.5
+    g_out = torch.randn(T, n, device=hip_device, generator=gen) * 0.1
+    outs = []
+    for windowed in (True, False):
+        pop = Population("li_tanh", W, dict(tau=8.0, k=1.0, eta=0.1), 1e-2, hip_device)
+        pop.windowed_sparse = windowed
+        pop.pack_weights()
+        tv, ts, ta, ut, gx = (torch.zeros(T, n, device=hip_device) for _ in range(5))
+        pop.forward(T, x=x, save_v=tv, save_src=ts, save_acc=ta)
+        lam, gk = torch.zeros(n, device=hip_device), torch.zeros(n, device=hip_device)
+        keep = pop.backward(tv, ts, g_out, _abi.RP_OUT_SOURCE, lam, ut, traj_acc=ta, grad_k=gk, grad_x=gx)
+        torch.cuda.synchronize()
+        assert (pop.packed_t.row_ids is not None) == windowed
+        outs.append([t_.cpu().numpy() for t_ in (tv, lam, ut, gk, gx)])
+        del keep, pop
+    for a, b in zip(*outs):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.abs(outs[0][1]).max() > 0
