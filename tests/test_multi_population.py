@@ -145,3 +145,21 @@ def test_softmax_read_out_in_window_mode(target):
     for a, b in zip(res[0], res[1]):
         assert np.abs(a - b).max() < 1e-5
     assert np.abs(res[0][1] - W_out).max() > 1e-4
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_epoch_training_of_two_populations(target):
+    """fit_bptt with a LIST of inputs (one optimisation step per epoch, state restored in between, reference
+    network.py:983-1014) on the two-population network: window evaluation == step-by-step walk."""
+    rng = np.random.default_rng(8)
+    xs = [rng.standard_normal((30, 3)).astype(np.float32) for _ in range(3)]
+    ts = [(rng.standard_normal((30, 2)) * 0.2).astype(np.float32) for _ in range(3)]
+    res = []
+    for stepwise in (False, True):
+        net = build(target, train=True, stepwise=stepwise)
+        obs = net.fit_bptt(xs, ts, optimizer="sgd", lr=0.05, sampling_steps=1, verbose=False)
+        res.append((net.get_node("p1")["weights"].detach().cpu().numpy().copy(),
+                    net.get_edge("p1", "p2").weights.detach().cpu().numpy().copy(), np.asarray(obs["epoch_loss"])))
+    for a, b in zip(res[0], res[1]):
+        assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(b).max())
+    assert len(res[0][2]) == 3 and res[0][2].max() > 0
