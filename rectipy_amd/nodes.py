@@ -433,6 +433,27 @@ class RateNet:
         return self._pop.forward(steps, x=x, w_in=w_in, out_var=self._out_code, **kw)
 
 
+class Spike(torch.autograd.Function):
+    """The reference's spike non-linearity as a stand-alone torch function (rectipy/nodes.py:468-481), for user code that
+    builds its own nodes: forward = heaviside(x) with value `center` (1) at x == 0, backward = the surrogate gradient
+    g / (1 + slope |x|)^2.  The compiled spiking populations apply the same two formulas inside their kernels (per node:
+    ``spike_slope``); `slope` / `center` here are class attributes, as in the reference."""
+
+    slope = 10.0
+    center = 1.0
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor) -> torch.Tensor:
+        ctx.save_for_backward(x)
+        return torch.where(x == 0, torch.as_tensor(Spike.center, dtype=x.dtype, device=x.device), (x > 0).to(x.dtype))
+
+    @staticmethod
+    def backward(ctx, grad_output: torch.Tensor) -> torch.Tensor:
+        x, = ctx.saved_tensors
+        den = 1.0 + Spike.slope * x.abs()
+        return grad_output / (den * den)
+
+
 class SpikeResetNet(RateNet):
     """Spiking population with threshold + reset (reference ``SpikeResetNet``, rectipy/nodes.py:333-401).
 

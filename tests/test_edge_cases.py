@@ -123,3 +123,19 @@ def test_argument_errors(oracle_backend):
         net.fit_rls(np.zeros((4, 6)), np.zeros((4, 6)))
     with pytest.raises(NotImplementedError):
         net.fit_eprop(np.zeros((4, 6)), np.zeros((4, 6)))
+
+
+def test_g7_stand_alone_spike_function():
+    """rectipy_amd.Spike (the torch function the reference exposes as rectipy.nodes.Spike) on the reference's grid."""
+    from rectipy_amd import Spike
+    g = dict(np.load(os.path.join(GOLD, "g7_spike_fn.npz")))
+    old = Spike.slope
+    Spike.slope = float(g["slope"])
+    try:
+        x = torch.tensor(g["grid"], dtype=torch.float64, requires_grad=True)
+        y = Spike.apply(x)
+        y.sum().backward()
+        assert np.array_equal(y.detach().numpy(), g["fwd_f64"])
+        assert np.abs(x.grad.numpy() - g["bwd_f64"]).max() < 1e-12
+    finally:
+        Spike.slope = old
