@@ -32,6 +32,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def step_kernel_label(rows, n):
+    """Launch shape the library picks for a rows x n shard (rnn_forward.hip: launch_step)."""
+    cache_sized = rows * n * 4 <= (320 << 20)
+    r, u = (4, 2) if rows >= 8192 and not cache_sized else (8, 1) if rows >= 8192 else (2, 2) if rows > 2048 else (1, 4)
+    return f"step_kernel<LI_TANH,R={r},U={u},vec4,nt>"
+
+
 def gen_rows(n, row0, rows, device, g=1.5, block=1024):
     """Rows [row0, row0+rows) of the synthetic coupling matrix; identical for every sharding."""
     W = torch.empty(rows, n, dtype=torch.float32, device=device)
@@ -181,7 +188,7 @@ def main():
                    if use_dist else "single GPU, driven through rectipy_amd.Network.run"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                     "kernel": "step_kernel<LI_TANH,R=4,U=2,vec4,nt>", "algorithmic_bytes_per_launch": algo_bytes,
+                     "kernel": step_kernel_label(rows, N), "algorithmic_bytes_per_launch": algo_bytes,
                      "avg_launch_ms": kernel_ms},
         "state_finite": finite,
     }
