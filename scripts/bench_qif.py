@@ -1,6 +1,10 @@
 """BASELINE.json configs[3]: QIF spiking population, N = 65536 dense, spike/reset path (GPU box).
 W = rand(N, N) * 20 / N, tau = k = tau_s = 1, eta = -5, v0 = -2, theta = 100, v_reset = -100, dt = 1e-3,
 constant input 15 (SURVEY.md 8d "C4")."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import json
 import sys
 import time

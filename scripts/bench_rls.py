@@ -1,4 +1,8 @@
 """RLS sweep at large n_in: achieved HBM bandwidth of the fused rank-1 update + next mat-vec pass (8 n^2 B/update)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import json
 import sys
 

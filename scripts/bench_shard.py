@@ -1,6 +1,10 @@
 """BASELINE.json configs[4] per-GPU shape on ONE GPU: rank 0's shard of an N = 262144 network row-sharded over 8
 GPUs (32768 rows x 262144 columns = 34.4 GB), stepped without the all-gather (the source vector is left stale, the
 kernel's work and traffic are identical).  Also config 1 through the front end (N = 512, 2000 steps)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import json
 import time
 

@@ -1,4 +1,8 @@
 """Host-side cost per library call vs per in-library step at small N (GPU box)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import json
 import time
 

@@ -1,4 +1,8 @@
 """Sweep (unroll, strip width) of the adjoint column-strip kernel at N=32768 (GPU box)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import json
 import sys
 

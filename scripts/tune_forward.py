@@ -1,4 +1,8 @@
 """Sweep the streaming configuration of the tanh step kernel at N=32768 (GPU box only)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes as C
 import json
 import sys

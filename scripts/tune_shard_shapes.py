@@ -1,4 +1,8 @@
 """Step-kernel configuration for the row shards of the strong-scaling bench (rows = 32768 / P, n = 32768)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import json
 
 import torch

@@ -1,5 +1,9 @@
 """Experiment: rotate the start column chunk per 8-row group (decorrelates the lock-step march of all waves
 through addresses that are equal modulo the 128 KiB row stride)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import json
 import sys
 
