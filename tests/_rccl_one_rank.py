@@ -45,6 +45,19 @@ def main():
     assert torch.equal(sp.pop.source, full.source)
     assert torch.equal(r_full, traj_f), "save_src_full must hold the source vector each step read"
 
+    # ---- packed sparse shard + in-library exchange == dense unsharded ------------------------------------------
+    Ns = 4096
+    Ws = torch.randn(Ns, Ns, generator=g) * (1.5 / (0.1 * Ns) ** 0.5) * (torch.rand(Ns, Ns, generator=g) < 0.1)
+    sps = ShardedPopulation("li_tanh", Ws, dict(tau=8.0, k=1.0, eta=0.0), 1e-2, dev, n=Ns)
+    assert sps.pop.pack_weights().row_ids is None and sps.comm is not None
+    dense = Population("li_tanh", Ws, dict(tau=8.0, k=1.0, eta=0.0), 1e-2, dev)
+    xs = x[:, :1].contiguous()
+    ta, tb = torch.zeros(T, Ns, device=dev), torch.zeros(T, Ns, device=dev)
+    sps.forward(T, x=xs, traj=ta)
+    dense.forward(T, x=xs, traj=tb)
+    torch.cuda.synchronize()
+    assert torch.equal(ta, tb) and torch.equal(sps.pop.v, dense.v), "packed sparse shard differs from the dense run"
+
     # ---- front end: ShardedNetwork.fit_bptt with the in-library exchange vs the torch.distributed path ------
     W_out = torch.randn(2, N, generator=g) / N ** 0.5
     u = torch.randn(40, 1, generator=g) * 0.5
