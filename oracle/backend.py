@@ -36,13 +36,42 @@ def load():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             build()
-        _LIB = _abi.declare(C.CDLL(LIB_PATH), "oracle")
+        _LIB = _declare(C.CDLL(LIB_PATH))
     return _LIB
+
+
+def _declare(lib):
+    """argtypes/restypes of the oracle's entry points (oracle/rnn_oracle.c, rls_oracle.c): the rp_* signatures of
+    include/rectipy_hip.h without the stream argument, on host pointers."""
+    P, fp = C.POINTER, _abi.fp
+    RpNet, RpRun, RpBwd, RpRls = _abi.RpNet, _abi.RpRun, _abi.RpBwd, _abi.RpRls
+
+    def sig(name, restype, argtypes):
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+
+    sig("oracle_refresh_source", C.c_int, [P(RpNet)])
+    sig("oracle_forward", C.c_int, [P(RpNet), P(RpRun)])
+    sig("oracle_rate_backward", C.c_int, [P(RpNet), P(RpBwd)])
+    sig("oracle_qif_backward", C.c_int, [P(RpNet), P(RpBwd)])
+    sig("oracle_outer_accum", C.c_int, [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64])
+    sig("oracle_outer_accum_rect", C.c_int,
+        [C.c_int32, C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64])
+    sig("oracle_bwd_prepare", C.c_int, [P(RpNet), P(RpBwd)])
+    sig("oracle_bwd_partial", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp])
+    sig("oracle_bwd_apply", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp])
+    sig("oracle_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp])
+    sig("oracle_expf", C.c_float, [C.c_float])
+    sig("oracle_tanhf", C.c_float, [C.c_float])
+    sig("oracle_row_dot", C.c_float, [fp, fp, C.c_int, C.c_int, C.c_int])
+    return lib
 
 
 class OracleBackend:
     """Same methods as rectipy_amd.engine.HipBackend, host pointers, synchronous."""
     name = "oracle"
+    # the oracle evaluates the packed-W^T adjoint (same summation order) on a dense transposed copy
+    wants_dense_wt_with_packed = True
 
     def __init__(self):
         self.lib = load()

@@ -175,8 +175,8 @@ class RpComm(C.Structure):
     ]
 
 
-def declare(lib, prefix):
-    """Attach argtypes/restypes for the entry points `<prefix>_*` that `lib` exports."""
+def declare(lib):
+    """Attach argtypes/restypes for the `rp_*` entry points of include/rectipy_hip.h that `lib` exports."""
     P = C.POINTER
 
     def sig(name, restype, argtypes):
@@ -186,53 +186,36 @@ def declare(lib, prefix):
             fn.argtypes = argtypes
         return fn
 
-    if prefix == "rp":
-        sig("rp_abi_version", C.c_int, [])
-        sig("rp_last_error", C.c_char_p, [])
-        sig("rp_device_check", C.c_int, [C.c_int])
-        sig("rp_sizeof_net", C.c_int, [])
-        sig("rp_sizeof_run", C.c_int, [])
-        sig("rp_sizeof_bwd", C.c_int, [])
-        sig("rp_refresh_source", C.c_int, [P(RpNet), C.c_void_p])
-        sig("rp_forward", C.c_int, [P(RpNet), P(RpRun), C.c_void_p])
-        sig("rp_bwd_partial_rows", C.c_int32, [C.c_int32])
-        sig("rp_rate_backward", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
-        sig("rp_qif_backward", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
-        sig("rp_outer_accum", C.c_int,
-            [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
-        sig("rp_outer_accum_rect", C.c_int,
-            [C.c_int32, C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
-        sig("rp_bwd_shard_partial_rows", C.c_int32, [C.c_int32, C.c_int32])
-        sig("rp_bwd_prepare", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
-        sig("rp_bwd_partial", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp, C.c_void_p])
-        sig("rp_bwd_apply", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp, C.c_void_p])
-        sig("rp_sizeof_comm", C.c_int, [])
-        sig("rp_forward_sharded", C.c_int, [P(RpNet), P(RpRun), P(RpComm), C.c_void_p])
-        sig("rp_backward_sharded", C.c_int, [P(RpNet), P(RpBwd), P(RpComm), C.c_void_p])
-        sig("rp_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp,
-                                      C.c_void_p])
-        sig("rp_stream_probe", C.c_int, [fp, C.c_int64, fp, C.c_void_p])
-        sig("rp_set_tuning", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int])
-        sig("rp_set_sparse_tuning", C.c_int, [C.c_int, C.c_int])
-        sig("rp_set_bwd_tuning", C.c_int, [C.c_int, C.c_int])
-        sig("rp_set_bwd_chunks", C.c_int, [C.c_int])
-        sig("rp_set_rls_tuning", C.c_int, [C.c_int, C.c_int, C.c_int])
-    else:
-        sig("oracle_refresh_source", C.c_int, [P(RpNet)])
-        sig("oracle_forward", C.c_int, [P(RpNet), P(RpRun)])
-        sig("oracle_rate_backward", C.c_int, [P(RpNet), P(RpBwd)])
-        sig("oracle_qif_backward", C.c_int, [P(RpNet), P(RpBwd)])
-        sig("oracle_outer_accum", C.c_int,
-            [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64])
-        sig("oracle_outer_accum_rect", C.c_int,
-            [C.c_int32, C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64])
-        sig("oracle_bwd_prepare", C.c_int, [P(RpNet), P(RpBwd)])
-        sig("oracle_bwd_partial", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp])
-        sig("oracle_bwd_apply", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp])
-        sig("oracle_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp])
-        sig("oracle_expf", C.c_float, [C.c_float])
-        sig("oracle_tanhf", C.c_float, [C.c_float])
-        sig("oracle_row_dot", C.c_float, [fp, fp, C.c_int, C.c_int, C.c_int])
+    sig("rp_abi_version", C.c_int, [])
+    sig("rp_last_error", C.c_char_p, [])
+    sig("rp_device_check", C.c_int, [C.c_int])
+    sig("rp_sizeof_net", C.c_int, [])
+    sig("rp_sizeof_run", C.c_int, [])
+    sig("rp_sizeof_bwd", C.c_int, [])
+    sig("rp_refresh_source", C.c_int, [P(RpNet), C.c_void_p])
+    sig("rp_forward", C.c_int, [P(RpNet), P(RpRun), C.c_void_p])
+    sig("rp_bwd_partial_rows", C.c_int32, [C.c_int32])
+    sig("rp_rate_backward", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
+    sig("rp_qif_backward", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
+    sig("rp_outer_accum", C.c_int,
+        [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
+    sig("rp_outer_accum_rect", C.c_int,
+        [C.c_int32, C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
+    sig("rp_bwd_shard_partial_rows", C.c_int32, [C.c_int32, C.c_int32])
+    sig("rp_bwd_prepare", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
+    sig("rp_bwd_partial", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp, C.c_void_p])
+    sig("rp_bwd_apply", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp, C.c_void_p])
+    sig("rp_sizeof_comm", C.c_int, [])
+    sig("rp_forward_sharded", C.c_int, [P(RpNet), P(RpRun), P(RpComm), C.c_void_p])
+    sig("rp_backward_sharded", C.c_int, [P(RpNet), P(RpBwd), P(RpComm), C.c_void_p])
+    sig("rp_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp,
+                                  C.c_void_p])
+    sig("rp_stream_probe", C.c_int, [fp, C.c_int64, fp, C.c_void_p])
+    sig("rp_set_tuning", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int])
+    sig("rp_set_sparse_tuning", C.c_int, [C.c_int, C.c_int])
+    sig("rp_set_bwd_tuning", C.c_int, [C.c_int, C.c_int])
+    sig("rp_set_bwd_chunks", C.c_int, [C.c_int])
+    sig("rp_set_rls_tuning", C.c_int, [C.c_int, C.c_int, C.c_int])
     return lib
 
 

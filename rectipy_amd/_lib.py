@@ -33,7 +33,7 @@ def load():
     missing = [s for s in _abi.EXPORTS if not hasattr(lib, s)]
     if missing:
         raise HipLibraryError(f"{path} does not export {missing}; rebuild with `python -m rectipy_amd.build --force`")
-    _abi.declare(lib, "rp")
+    _abi.declare(lib)
     if lib.rp_abi_version() != _abi.RP_ABI_VERSION:
         raise HipLibraryError(f"ABI version mismatch: library {lib.rp_abi_version()}, python {_abi.RP_ABI_VERSION}")
     for name, struct in (("rp_sizeof_net", _abi.RpNet), ("rp_sizeof_run", _abi.RpRun), ("rp_sizeof_bwd", _abi.RpBwd),

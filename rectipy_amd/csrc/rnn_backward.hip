@@ -584,22 +584,11 @@ __global__ __launch_bounds__(kSparseThreads) void adj_sparse_windowed_kernel(con
 
 template <bool SPIKING>
 int launch_adj_sparse(const BwdParams& P, const SpkGrad& G, hipStream_t st) {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RP_ERR_HIP;
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = rp_cu_count();
+    if (n_cu == 0) return RP_ERR_HIP;
     if (P.spt_row_ids) {
-        static bool attr_set_w = false;
-        if (!attr_set_w) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_sparse_windowed_kernel<SPIKING, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    sizeof(float) * kWindowChunks * 256) != hipSuccess)
-                return RP_ERR_HIP;
-            attr_set_w = true;
-        }
+        if (rp_allow_dynamic_lds<&adj_sparse_windowed_kernel<SPIKING, 2>>(sizeof(float) * kWindowChunks * 256) != RP_OK)
+            return RP_ERR_HIP;
         const int wblocks = P.spt_batches < n_cu ? P.spt_batches : n_cu;
         if (wblocks > 0)
             hipLaunchKernelGGL((adj_sparse_windowed_kernel<SPIKING, 2>), dim3(wblocks), dim3(kSparseThreads),
@@ -610,13 +599,8 @@ int launch_adj_sparse(const BwdParams& P, const SpkGrad& G, hipStream_t st) {
     int blocks = (P.n + kWaves - 1) / kWaves;
     if (P.n <= kSparseLdsMaxN) {
         if (blocks > n_cu) blocks = n_cu;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&adj_sparse_kernel<SPIKING, true, 4>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(float) * kSparseLdsMaxN) != hipSuccess)
-                return RP_ERR_HIP;
-            attr_set = true;
-        }
+        if (rp_allow_dynamic_lds<&adj_sparse_kernel<SPIKING, true, 4>>(sizeof(float) * kSparseLdsMaxN) != RP_OK)
+            return RP_ERR_HIP;
         hipLaunchKernelGGL((adj_sparse_kernel<SPIKING, true, 4>), dim3(blocks), dim3(kSparseThreads),
                            sizeof(float) * (size_t)((P.n + 255) & ~255), st, P, G);
     } else {

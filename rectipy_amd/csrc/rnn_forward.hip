@@ -330,13 +330,8 @@ int launch_step_sparse_cfg(const StepParams& P, hipStream_t st, int n_cu) {
     if (P.n <= kSparseLdsMaxN) {
         if (blocks > n_cu) blocks = n_cu;  // one resident workgroup per CU owns the LDS copy of the source vector
         const size_t lds = sizeof(float) * (size_t)((P.n + 255) & ~255);
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&step_sparse_kernel<MODEL, true, R, U>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, sizeof(float) * kSparseLdsMaxN) != hipSuccess)
-                return RP_ERR_HIP;
-            attr_set = true;
-        }
+        if (rp_allow_dynamic_lds<&step_sparse_kernel<MODEL, true, R, U>>(sizeof(float) * kSparseLdsMaxN) != RP_OK)
+            return RP_ERR_HIP;
         hipLaunchKernelGGL((step_sparse_kernel<MODEL, true, R, U>), dim3(blocks), dim3(kSparseThreads), lds, st, P);
     } else {
         if (blocks > 2 * n_cu) blocks = 2 * n_cu;
@@ -347,22 +342,11 @@ int launch_step_sparse_cfg(const StepParams& P, hipStream_t st, int n_cu) {
 
 template <int MODEL>
 int launch_step_sparse(const StepParams& P, hipStream_t st) {
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RP_ERR_HIP;
-        n_cu = prop.multiProcessorCount;
-    }
+    const int n_cu = rp_cu_count();
+    if (n_cu == 0) return RP_ERR_HIP;
     if (P.sp_row_ids) {  // windowed form
-        static bool attr_set_w = false;
-        if (!attr_set_w) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&step_sparse_windowed_kernel<MODEL, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    sizeof(float) * kWindowChunks * 256) != hipSuccess)
-                return RP_ERR_HIP;
-            attr_set_w = true;
-        }
+        if (rp_allow_dynamic_lds<&step_sparse_windowed_kernel<MODEL, 2>>(sizeof(float) * kWindowChunks * 256) != RP_OK)
+            return RP_ERR_HIP;
         const int blocks = P.sp_batches < n_cu ? P.sp_batches : n_cu;
         if (blocks > 0)
             hipLaunchKernelGGL((step_sparse_windowed_kernel<MODEL, 2>), dim3(blocks), dim3(kSparseThreads),
@@ -764,6 +748,7 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
         } else {
             launch_step_model<false>(net->model, P, st);
         }
+        if (t == 0) RP_HIP_CHECK(hipGetLastError());  // a rejected launch configuration shows on the first step
         if (comm) {  // every rank wrote rows [row0, row0 + rows) of src_next: exchange in place, same stream
             const int nrc = reinterpret_cast<all_gather_fn>(comm->all_gather)(
                 P.src_next + net->row0, P.src_next, (size_t)net->rows, kNcclFloat, comm->comm, st);

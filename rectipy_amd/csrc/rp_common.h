@@ -27,6 +27,37 @@ extern thread_local char rp_err_buf[512];
                     __FILE__, __LINE__);                                              \
     } while (0)
 
+// ---- per-device host-side caches: one process may drive several GPUs (engine.py: HipBackend._on) ----------------
+#define RP_MAX_DEVICES 64
+
+// number of CUs of the CURRENT device (0 on error)
+inline int rp_cu_count() {
+    static int cu[RP_MAX_DEVICES];  // benign race: every writer stores the same value
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RP_MAX_DEVICES) return 0;
+    if (cu[dev] == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        cu[dev] = prop.multiProcessorCount;
+    }
+    return cu[dev];
+}
+
+// raise the dynamic-LDS limit of `Kernel` on the CURRENT device (once per kernel and device)
+template <auto Kernel>
+inline int rp_allow_dynamic_lds(size_t bytes) {
+    static unsigned char done[RP_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RP_MAX_DEVICES) return RP_ERR_HIP;
+    if (!done[dev]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes) != hipSuccess)
+            return RP_ERR_HIP;
+        done[dev] = 1;
+    }
+    return RP_OK;
+}
+
 typedef float rp_f4 __attribute__((ext_vector_type(4)));
 
 // 16-byte streaming load of the once-read coupling matrix (non-temporal: keep the

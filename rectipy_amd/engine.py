@@ -199,6 +199,7 @@ class Population:
         self._scratch = torch.zeros(4, **f32) if model in NEEDS_MEANS else None
         self._net_cache = None           # (key, RpNet) reused across calls, see _net()
         self.packed = None               # PackedRows of a fixed sparse W (sparse.py); the step kernel then streams it
+        self._packed_version = -1        # W._version when `packed` was built (see _sync_packed)
         self.packed_t = None             # PackedRows of W^T (adjoint of a fixed sparse W), built on first use
         self.sparse_adjoint = True       # False: adjoint on the dense matrix even when a packed form exists
         self.windowed_sparse = True      # False: n > 32768 uses the plain packed form with the L2 gather
@@ -230,6 +231,7 @@ class Population:
         """The population as an rp_net.  The struct is cached: the tensors it points at are updated in place for the
         lifetime of the population (only set_weights / pack_weights swap buffers), so a per-step caller does not pay
         for rebuilding it."""
+        self._sync_packed()
         key = (self.W.data_ptr(), self.v.data_ptr(), id(self.packed))
         if self._net_cache is not None and self._net_cache[0] == key:
             net = self._net_cache[1]
@@ -291,6 +293,12 @@ class Population:
         if self.packed is not None:
             self.pack_weights()
 
+    def _sync_packed(self):
+        """Re-pack when the dense matrix was edited in place after packing (``node["weights"]`` is the live tensor, as
+        in the reference; ``set_param`` copies into it): torch bumps ``W._version`` on every in-place write."""
+        if self.packed is not None and self.W._version != self._packed_version:
+            self.pack_weights()
+
     def pack_weights(self, enable: bool = True):
         """Stream the coupling matrix in its packed sparse form from now on (forward pass only; bit-identical results,
         see sparse.py).  The dense matrix stays in place for the adjoint kernels.  Call again after changing W."""
@@ -302,6 +310,7 @@ class Population:
         else:
             self.packed = sparse.pack_rows(self.W, row0=self.row0)
         self.packed_t = None
+        self._packed_version = self.W._version
         self._net_cache = None
         return self.packed
 
@@ -445,6 +454,7 @@ class Population:
         T = int(traj_v.shape[0])
         local = self.rows
         sharded = self.rows != self.n
+        self._sync_packed()
         b = RpBwd()
         b.steps = T
         b.traj_v, b.traj_r, b.traj_acc = traj_v.data_ptr(), traj_r.data_ptr(), _ptr(traj_acc)
@@ -465,9 +475,9 @@ class Population:
                 if pt.row_ids is not None:
                     b.spt_row_ids, b.spt_batch_class = pt.row_ids.data_ptr(), pt.batch_class.data_ptr()
                     b.spt_phase_window, b.spt_phases, b.spt_batches = pt.phase_window.data_ptr(), pt.phases, pt.batches
-        on_host = self.device.type == "cpu"  # the CPU checker evaluates the same order on a dense transposed copy
+        # (a backend may ask for the W^T workspace next to the packed rows of W^T: `wants_dense_wt_with_packed`)
         if not sharded and ((self.n <= _abi.RP_BWD_TRANSPOSE_MAX_N and self.transposed_adjoint and not b.spt_vals)
-                            or (b.spt_vals and on_host)):
+                            or (b.spt_vals and getattr(self.backend, "wants_dense_wt_with_packed", False))):
             # small networks: the sweep keeps W^T in this workspace and runs one fused launch per step (rp_bwd.wt)
             if self._wt is None:
                 self._wt = torch.empty(self.n, (self.n + 3) // 4 * 4, dtype=torch.float32, device=self.device)

@@ -99,10 +99,11 @@ class Network:
             try:
                 n.set_param(self._relabel_var(var), val)
             except KeyError:
-                with torch.no_grad():
-                    n[self._relabel_var(var)][:] = torch.as_tensor(val)
-                if hasattr(n, "_pop"):
-                    n._pop.refresh()
+                if hasattr(n, "set_state"):   # compiled population: write the device state itself
+                    n.set_state(self._relabel_var(var), val)
+                else:
+                    with torch.no_grad():
+                        n[self._relabel_var(var)][:] = torch.as_tensor(val)
         except KeyError:
             raise KeyError(f"Variable {var} was not found on node {node}.")
 

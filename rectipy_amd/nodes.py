@@ -225,6 +225,7 @@ class RateNet:
         for name in self._train_names:
             self._tensor(name).requires_grad_(True)
         self._y_grad: Optional[torch.Tensor] = None  # autograd handle of the state (same values as pop.v)
+        self._v_exposed = False  # pop.v was handed out through `y`: the next step continues on a copy
         self._y_requires_grad = len(self._train_names) >= 1  # nodes.py:89-90
         self._maybe_pack_weights()
 
@@ -302,7 +303,9 @@ class RateNet:
         if item in self._param_map:
             return self._tensor(self._param_map[item])
         if item in self._template.derived:
-            return self._pop.source_local
+            # r = act(v) lives in a ping-pong buffer the kernels overwrite two steps later; the reference computes a
+            # fresh tensor per step, so hand out a copy that a per-step recorder may keep (observer.py:100-101)
+            return self._pop.source_local.clone()
         lo, hi = self._var_map[item]  # KeyError for unknown names, as the reference (test_nodes.py:78-79)
         return self.y[lo:hi]
 
@@ -342,11 +345,40 @@ class RateNet:
     # ---- state --------------------------------------------------------------------------
     @property
     def y(self) -> torch.Tensor:
-        """State vector.  Live view of the device state (the reference also hands out the live tensor,
-        network.py:96); carries the autograd history of the current window when one is being recorded."""
+        """State vector: the live device state (the reference also hands out the live tensor, network.py:96), or the
+        autograd handle of the current window when one is being recorded.
+
+        The reference REBINDS ``self.y`` to a new tensor at every step (nodes.py:169), so a tensor obtained from
+        ``y`` / ``node[var]`` keeps its values afterwards -- its Observer stores such references per step
+        (observer.py:100-101).  The kernels update the state in place; to keep the reference's behaviour the node
+        remembers that the live tensor was handed out and, at the next step, continues on a fresh copy
+        (:meth:`_before_step`): the handed-out tensor then holds the state it showed when it was read, and writes made
+        into it before the next step (``net.state[...][:] = ...``) are part of the state, as in the reference.
+        Fused windows never read ``y`` and stay zero-copy."""
         if self._y_grad is None and self._y_requires_grad:
             self._y_grad = self._pop.v.detach().clone().requires_grad_(True)
-        return self._pop.v if self._y_grad is None else self._y_grad
+        if self._y_grad is None:
+            self._v_exposed = True
+            return self._pop.v
+        return self._y_grad
+
+    def _before_step(self):
+        """Copy-on-step for a state tensor that was handed out (see :attr:`y`)."""
+        if self._v_exposed:
+            pop = self._pop
+            pop.v = pop.v.clone()        # the old tensor stays with whoever holds it
+            pop.refresh()                # the holder may have written into it: r = act(v) again (bit-identical otherwise)
+            self._v_exposed = False
+
+    def set_state(self, var: str, val):
+        """Write a state variable (``Network.set_var`` on a state name): goes to the device state itself, also when
+        ``y`` currently is the autograd handle of a window (whose history the write cuts, as an in-place write to the
+        reference's ``y`` under no_grad would)."""
+        lo, hi = self._var_map[var]
+        with torch.no_grad():
+            self._pop.v[lo:hi] = torch.as_tensor(val, dtype=torch.float32).to(self._pop.device)
+        self._y_grad = None
+        self._pop.refresh()
 
     def detach(self, requires_grad: bool = False, detach_params: bool = False):
         """Cut the autograd history of the state (reference nodes.py:176-196)."""
@@ -364,16 +396,21 @@ class RateNet:
                 new = torch.zeros_like(pop.v)
             else:
                 new = torch.as_tensor(y).detach().to(dtype=torch.float32, device=pop.device).reshape(-1).clone()
+            # the state is REBOUND to a new tensor (the reference does the same, nodes.py:202-211), so a tensor handed
+            # out through `y` before the reset keeps its values
             if idx is None:
                 if new.numel() != pop.v.numel():
                     raise RuntimeError(f"state has {pop.v.numel()} entries, got {new.numel()}")
-                pop.v.copy_(new)
+                pop.v = new.contiguous()
             else:
                 index = torch.as_tensor(np.asarray(idx), dtype=torch.long, device=pop.device)
                 if index.numel() != new.numel() or (index.numel() and int(index.max()) >= pop.v.numel()):
                     raise RuntimeError("index/value size mismatch in reset")
-                pop.v[index] = new
+                v_new = pop.v.clone()
+                v_new[index] = new
+                pop.v = v_new
         self._y_grad = None
+        self._v_exposed = False
         pop.refresh()
         pop.reset_sampling()
 
@@ -406,6 +443,7 @@ class RateNet:
 
     def _grad_window(self, steps: int, x: Optional[torch.Tensor]) -> torch.Tensor:
         """`steps` Euler steps recorded as one autograd node; returns the [steps, N] output trajectory."""
+        self._before_step()
         pop = self._pop
         v_in = self._y_grad
         if v_in is None:
@@ -421,6 +459,7 @@ class RateNet:
         x2 = self._as_input(x)
         if self._wants_grad(x2):
             return self._grad_window(1, x2)[0]
+        self._before_step()
         out = torch.empty(1, self._pop.rows, dtype=torch.float32, device=self._pop.device)
         self._pop.forward(1, x=x2, traj=out, out_var=self._out_code)
         self._y_grad = None
@@ -429,6 +468,7 @@ class RateNet:
     def run_window(self, steps: int, x: Optional[torch.Tensor] = None, w_in: Optional[torch.Tensor] = None,
                    **kw):
         """Fused multi-step integration without autograd (see Population.forward for kwargs)."""
+        self._before_step()
         self._y_grad = None
         return self._pop.forward(steps, x=x, w_in=w_in, out_var=self._out_code, **kw)
 
@@ -555,6 +595,16 @@ class SpikeResetNet(RateNet):
             raise RuntimeError(f"spike buffer overflow: {count} events, capacity {self.spike_events.shape[0]}")
         ev = self.spike_events[:count].cpu().numpy()
         return ev[np.lexsort((ev[:, 1], ev[:, 0]))]
+
+    def set_state(self, var: str, val):
+        """As in the reference, `y` of a spiking node is the lagging pre-update copy (nodes.py:387-392): writing a
+        state variable through ``Network.set_var`` lands in that copy and leaves the integration state (the
+        reference's _y_start/_y_spike/_y_stop) untouched.  Use :meth:`reset` to set the state."""
+        lo, hi = self._var_map[var]
+        if self._y_prev is None:
+            self._y_prev = self.current_state
+        with torch.no_grad():
+            self._y_prev[lo:hi] = torch.as_tensor(val, dtype=torch.float32).to(self._pop.device)
 
     def reset(self, y=None, idx=None):
         pop = self._pop

@@ -24,21 +24,47 @@ def rccl_comm(group, device, backend) -> Optional[_abi.RpComm]:
     function addresses come from the RCCL instance PyTorch loaded, the only one in which that communicator is valid."""
     import ctypes
     import os
+    import warnings
     if os.environ.get("RECTIPY_AMD_HOST_COLLECTIVES", "0") == "1" or not hasattr(backend, "forward_sharded"):
         return None
     if dist.get_backend(group) != "nccl":
         return None
     pg = group if group is not None else dist.distributed_c10d._get_default_group()
-    ptr = pg._get_backend(torch.device(device))._comm_ptr()
-    if not ptr:
-        raise RuntimeError("the RCCL communicator of the process group is not initialised on " + str(device))
-    lib = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
-    comm = _abi.RpComm()
-    comm.comm = ptr
-    comm.all_gather = ctypes.cast(lib.ncclAllGather, ctypes.c_void_p).value
-    comm.reduce_scatter = ctypes.cast(lib.ncclReduceScatter, ctypes.c_void_p).value
+    try:
+        ptr = pg._get_backend(torch.device(device))._comm_ptr()  # private torch API: may be absent in other builds
+        if not ptr:
+            raise RuntimeError("communicator not initialised on " + str(device))
+        lib = _loaded_rccl()
+        comm = _abi.RpComm()
+        comm.comm = ptr
+        comm.all_gather = ctypes.cast(lib.ncclAllGather, ctypes.c_void_p).value
+        comm.reduce_scatter = ctypes.cast(lib.ncclReduceScatter, ctypes.c_void_p).value
+    except (AttributeError, OSError, RuntimeError) as e:
+        global _warned_fallback
+        if not _warned_fallback:
+            warnings.warn(f"in-library RCCL exchange unavailable ({type(e).__name__}: {e}); the per-step exchange goes "
+                          "through torch.distributed from the host loop (same results, higher per-step overhead)")
+            _warned_fallback = True
+        return None
     comm.rank, comm.world = dist.get_rank(group), dist.get_world_size(group)
     return comm
+
+
+_warned_fallback = False
+
+
+def _loaded_rccl():
+    """The RCCL instance that owns PyTorch's communicators: torch's bundled lib/librccl.so when it ships one (dlopen
+    returns the already-loaded instance), else the symbols visible in the process (torch linked against a system
+    RCCL)."""
+    import ctypes
+    import os
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if os.path.exists(bundled):
+        return ctypes.CDLL(bundled)
+    lib = ctypes.CDLL(None)
+    lib.ncclAllGather, lib.ncclReduceScatter  # AttributeError when not visible -> host collectives
+    return lib
 
 
 def shard_bounds(n: int, world: int, rank: int):

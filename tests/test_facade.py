@@ -287,3 +287,45 @@ def test_ridge_solve_primal_and_dual_agree():
         w = Network._ridge_solve(X, Y, 1e-2)
         ref = torch.inverse(X.T @ X + 1e-2 * torch.eye(N, dtype=torch.float64)) @ X.T @ Y   # reference network.py:767
         assert w.shape == (N, 3) and (w - ref).abs().max() < 1e-9 * max(1.0, float(ref.abs().max()))
+
+
+def test_state_writes_reach_the_device_state_of_a_trained_node(where):
+    """With train_params the node's `y` is the autograd handle of the window; Network.set_var on a state variable and
+    reset() must still change the integration state (the reference's `y` IS the state, nodes.py:166-170)."""
+    n = 12
+    r = np.random.default_rng(3)
+    W, y1 = r.standard_normal((n, n)) / n ** 0.5, r.standard_normal(n).astype(np.float32)
+    x = torch.tensor(r.standard_normal((4, n)), dtype=torch.float32)
+    outs = []
+    for how in ("reset", "set_var"):
+        net = Network(1e-2, **where)
+        net.add_diffeq_node("rnn", TANH, input_var=IN, output_var="li_op/v", weights=W, source_var=SRC, target_var=TGT,
+                            train_params=["weights"], dtype=torch.float32)
+        net.compile()
+        net.forward(x[0])
+        assert net.state["rnn"].requires_grad
+        if how == "reset":
+            net.reset({"rnn": y1})
+        else:
+            net.set_var("rnn", "li_op/v", y1)
+        outs.append(torch.stack([net.forward(x[t]) for t in range(1, 4)]).detach())
+        assert np.array_equal(outs[-1][0].numpy(), y1)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_recorded_state_rows_do_not_alias(where):
+    """A per-step recorder that keeps the tensors it gets from `node[var]` / `net.state` (what the reference's Observer
+    does, observer.py:100-101) sees one distinct state per step."""
+    n = 8
+    W = np.random.default_rng(5).standard_normal((n, n))
+    node = RateNet.from_pyrates(TANH, weights=W, source_var=SRC, target_var=TGT, input_var=IN, output_var="li_op/v",
+                                dtype=torch.float32, dt=1e-1, **where)
+    x = torch.ones(n)
+    kept_v, kept_r, outs = [], [], []
+    for _ in range(5):
+        outs.append(node.forward(x))
+        kept_v.append(node["li_op/v"])
+        kept_r.append(node["tanh_op/r"])
+    for t in range(4):  # state after step t == output (pre-update state) of step t+1
+        assert torch.equal(kept_v[t], outs[t + 1])
+        assert torch.allclose(kept_r[t], torch.tanh(outs[t + 1]), atol=1e-6)

@@ -137,6 +137,45 @@ def test_front_end_packs_a_fixed_sparse_matrix_automatically(hip_device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("how", ["set_var", "in_place"])
+def test_weight_writes_reach_the_packed_form(hip_device, how):
+    """A packed (auto) node whose weights are replaced through Network.set_var / edited through the live
+    ``node["weights"]`` tensor integrates with the NEW matrix, forward and adjoint (the packed copies are rebuilt)."""
+    from rectipy_amd import Network
+    N, T = 4096, 50
+    tanh = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
+    W0 = random_sparse(N, N, 0.1, seed=6, scale=1.5 / (0.1 * N) ** 0.5)
+    W1 = random_sparse(N, N, 0.1, seed=7, scale=1.5 / (0.1 * N) ** 0.5)
+    x = torch.randn(T, 1, generator=torch.Generator().manual_seed(8)).numpy() * 0.5
+
+    def build(W, mode):
+        net = Network(1e-2, device="cuda:0")
+        node = net.add_diffeq_node("rnn", tanh, input_var="li_op/I_ext", output_var="tanh_op/r", weights=W.numpy(),
+                                   source_var="tanh_op/r", target_var="li_op/r_in", dtype=torch.float32,
+                                   sparse_weights=mode, train_params=["li_op/eta"])
+        return net, node
+
+    net, node = build(W0, "auto")
+    assert node._pop.packed is not None
+    net.run(x, sampling_steps=10, verbose=False, enable_grad=False)  # the packed forms are in use
+    net.reset()
+    if how == "set_var":
+        net.set_var("rnn", "weights", W1)
+    else:
+        with torch.no_grad():
+            node["weights"].copy_(W1.to("cuda:0"))
+    ref_net, ref_node = build(W1, False)
+    res = []
+    for nt, nd in ((net, node), (ref_net, ref_node)):
+        xs = torch.tensor(x, device="cuda:0")
+        traj = nd._grad_window(T, xs)
+        traj.square().sum().backward()
+        res.append((traj.detach().cpu().numpy(), nd["li_op/eta"].grad.cpu().numpy()))
+    assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32)), "forward used a stale packed W"
+    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-5 * np.abs(res[1][1]).max(), "adjoint used a stale packed W^T"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model,n", [("li_tanh", 1028), ("li_tanh", 8192), ("qif", 1024), ("ik", 2048)])
 def test_sparse_adjoint_equals_oracle(oracle_backend, hip_device, model, n):
     """Adjoint sweep on the packed rows of W^T (fixed sparse W): HIP == oracle (row-dot order on W^T), bit for bit, for
