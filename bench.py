@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded (RCCL) path even with one rank")
+    ap.add_argument("--config5-neurons", type=int, default=262144,
+                    help="N of the row-sharded BASELINE configs[4] leg that runs with --gpus > 1 (0: skip)")
+    ap.add_argument("--config5-steps", type=int, default=200)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,29 +115,10 @@ def main():
         samples = torch.zeros(n_samples, rows, device=dev)
         exchange = "torch.distributed all_gather_into_tensor per step (host loop)"
         if sp.comm is not None:
-            # the in-library RCCL exchange must reproduce the torch.distributed one bit for bit; otherwise do not use it
-            saved = (pop.v.clone(), pop.src[0].clone(), pop.src[1].clone(), pop.cur)
-
-            def three_steps(comm):
-                pop.v.copy_(saved[0]); pop.src[0].copy_(saved[1]); pop.src[1].copy_(saved[2]); pop.cur = saved[3]
-                keep, sp.comm = sp.comm, comm
-                sp.forward(3, x=x[:3])
-                sp.comm = keep
-                return pop.v.clone(), pop.source.clone()
-
-            try:
-                a, b = three_steps(sp.comm), three_steps(None)
-                agree = int(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]))
-            except RuntimeError as err:  # RP_ERR_COMM / RP_ERR_HIP from the library: keep the host loop
-                print(f"[bench] in-library exchange failed on rank {rank}: {err}", file=sys.stderr)
-                agree = 0
-            same = torch.tensor([agree], device=dev)
-            dist.all_reduce(same, op=dist.ReduceOp.MIN)
-            pop.v.copy_(saved[0]); pop.src[0].copy_(saved[1]); pop.src[1].copy_(saved[2]); pop.cur = saved[3]
-            if int(same.item()) == 1:
+            # the in-library RCCL exchange must reproduce the torch.distributed one bit for bit; otherwise it is dropped
+            if sp.check_inlib_exchange(3):
                 exchange = "RCCL all-gather enqueued in-library (rp_forward_sharded); checked == torch.distributed path"
             else:
-                sp.comm = None
                 exchange += " [in-library exchange disagreed with it and was disabled]"
 
         def run(steps, step0, idx):
@@ -165,6 +149,12 @@ def main():
         wall = float(tmax.item())
     finite = bool(torch.isfinite(pop.v).all().item())
 
+    config5 = None
+    if use_dist and args.config5_neurons > 0:
+        sp = pop = samples = None  # release the strong-scaling shard first
+        torch.cuda.empty_cache()
+        config5 = config5_leg(args.config5_neurons, args.config5_steps, world, rank, dev, dt)
+
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -173,10 +163,16 @@ def main():
     # algorithmic bytes per launch: W once + per-neuron vectors (v r/w, tau, k, eta, r r/w) + input
     algo_bytes = 4.0 * rows * N + 4.0 * (7 * rows + 1)
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_step_kernel_traffic.json")
-    if world == 1 and N == 32768 and os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+    # HBM bytes per launch from the PMC counters need their own rocprofv3 passes (scripts/profile_kernels.sh); the
+    # figure is read from the committed summary of that run and labelled as such -- it is NOT measured by this run
+    traffic, traffic_source = None, None
+    for name in ("r02_step_kernel_traffic.json", "r01_step_kernel_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if world == 1 and N == 32768 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic_source = (f"profiles/{name} (separate rocprofv3 --pmc passes of the same kernel and shape; "
+                              "not measured in this run)")
+            break
     out = {
         "metric": "integration steps/sec (fwd), N-neuron dense tanh rate RNN",
         "value": steps_per_s, "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -187,20 +183,26 @@ def main():
                    "neurons": N, "rows_per_gpu": rows, "parallelism": f"row-shard x{world}; " + exchange
                    if use_dist else "single GPU, driven through rectipy_amd.Network.run"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": step_kernel_label(rows, N), "algorithmic_bytes_per_launch": algo_bytes,
                      "avg_launch_ms": kernel_ms},
         "state_finite": finite,
     }
 
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(pop, x, dt, N)
-    if world == 1 and not args.no_extra:
+    if config5 is not None:
+        out.setdefault("extra", {})["config5"] = config5
+    cpu_threads = None
+    if world == 1 and not use_dist and not args.no_cpu_baseline:
+        out["cpu_baseline"], cpu_threads = cpu_baseline(pop, x, dt, N)
+    if world == 1 and not use_dist and not args.no_extra:
         out["extra"] = fwd_bwd_extra(pop, x, N, dev)
+        if cpu_threads is not None:
+            out["extra"]["cpu_fwd_bwd"] = cpu_fwd_bwd(pop, x, dt, N, cpu_threads)
+        out["extra"]["fit_ridge"] = ridge_extra(net, x, N, dev)
         out["extra"].update(facade_fit_bptt(pop, x, N, dev))  # it trains (modifies) the shared weight matrix
         pop = net = sp = None  # release the 4.3 GB network before the two larger side workloads
         torch.cuda.empty_cache()
-        out["extra"]["qif_n65536"] = qif_extra(dev)
+        out["extra"]["qif_n65536"] = qif_extra(dev, cpu_threads=cpu_threads)
         out["extra"]["sparse_p0.1_n32768"] = sparse_extra(dev)
     print(json.dumps(out), flush=True)
     if use_dist:
@@ -272,13 +274,16 @@ def facade_fit_bptt(pop, x, N, dev):
         net.fit_bptt(inp[:100], tgt[:100], optimizer="sgd", lr=1e-4, update_steps=100, sampling_steps=100, verbose=False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        obs = net.fit_bptt(inp, tgt, optimizer="sgd", lr=1e-4, update_steps=win, sampling_steps=100, verbose=False)
+        obs = net.fit_bptt(inp, tgt, optimizer="sgd", lr=1e-4, update_steps=win, sampling_steps=1, verbose=False)
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    return {"facade_fit_bptt_steps_per_s": T / wall, "facade_fit_bptt_loss": [float(v) for v in obs["loss"][-2:]]}
+    # the loss recorded at the LAST step of a window is that window's loss (reference network.py:1043-1046)
+    losses = obs["loss"]
+    return {"facade_fit_bptt_steps_per_s": T / wall,
+            "facade_fit_bptt_window_losses": [float(losses[b - 1]) for b in range(win, T + 1, win)]}
 
 
-def qif_extra(dev, N=65536, T=400):
+def qif_extra(dev, N=65536, T=400, cpu_threads=None):
     """BASELINE.json configs[3] at a reduced step count (the per-step cost is stationary): QIF population, dense
     W = rand * 20 / N, spike + reset path, through the engine."""
     from rectipy_amd import _abi
@@ -305,10 +310,25 @@ def qif_extra(dev, N=65536, T=400):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / T
     gbps = (4.0 * N * N + 48.0 * N) / (ms * 1e-3) / 1e9
-    res = {"workload": f"QIF N={N} dense, spike/reset path, {T} timed steps (BASELINE.json configs[3])",
+    res = {"workload": f"QIF N={N} dense W = rand*20/N, eta=-5, constant input 15, dt=1e-3, spike/reset path; {T} timed "
+                       f"steps after 50 warm-up steps from v0 = linspace(-2, 99) (BASELINE.json configs[3] shape; the "
+                       f"stated recipe starts at v0=-2 and runs 20000 steps -- per-step cost is stationary and the spread "
+                       f"start puts threshold crossings into every timed step)",
            "steps_per_s": 1e3 / ms, "ms_per_step": ms, "spikes": int(cnt.item()),
            "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS},
            "state_finite": bool(torch.isfinite(pop.v).all().item())}
+    if cpu_threads is not None:
+        from oracle.torch_eager import time_eager_qif
+        Wc = pop.W.cpu()
+        one = torch.ones(N)
+        torch.set_num_threads(cpu_threads)
+        warm, timed = 1, 8
+        sps = time_eager_qif(Wc, one, one, torch.full((N,), -5.0), one, torch.linspace(-2.0, 99.0, N), torch.zeros(N), 15.0,
+                             1e-3, 100.0, -100.0, warm, timed)
+        res["cpu"] = {"value": sps, "unit": "steps/s", "cores": cpu_threads, "kind": "port",
+                      "sample": f"{warm} warm-up + {timed} timed steps of the same QIF network, torch CPU eager loop "
+                                f"(oracle/torch_eager.py: time_eager_qif), fp32, no_grad"}
+        del Wc
     del pop
     torch.cuda.empty_cache()
     return res
@@ -348,18 +368,105 @@ def sparse_extra(dev, N=32768, p=0.1, T=1000):
 
 
 def cpu_baseline(pop, x, dt, N):
-    """Torch-eager port of the reference's per-step CPU loop on this box's host cores: 5 warm-up + 100 timed
-    steps of the same network (per-step cost is stationary, ~0.1 s/step: about 12 s of CPU work)."""
-    from oracle.torch_eager import time_eager
+    """Torch-eager port of the reference's per-step CPU loop on this box's host cores.  The mat-vec is DRAM-bound, so
+    the default thread count (all hardware threads) is not the fastest: a short sweep picks the thread count, then 5
+    warm-up + 60 timed steps at the winner (per-step cost is stationary; about 15-25 s of CPU work in total)."""
+    from oracle.torch_eager import sweep_threads, time_eager
     W = pop.W.cpu()
     tau, k, eta = (pop.params[n].cpu() for n in ("tau", "k", "eta"))
     v = pop.v.cpu()
-    warm, timed = 5, 100
+    warm, timed = 5, 60
     xs = x[:warm + timed].cpu().expand(warm + timed, N).contiguous()
+    hw = os.cpu_count() or torch.get_num_threads()
+    cands = sorted({t for t in (8, 16, 32, 64, hw // 2, hw) if 1 <= t <= hw})
+    best, _, table = sweep_threads(lambda: time_eager(W, tau, k, eta, v, xs, dt, 2, 10), cands)
+    torch.set_num_threads(best)
     sps = time_eager(W, tau, k, eta, v, xs, dt, warm, timed)
-    return {"value": sps, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{warm} warm-up + {timed} timed Euler steps of the same N={N} network, torch {torch.__version__} "
-                      f"CPU eager loop (oracle/torch_eager.py), fp32, no_grad"}
+    res = {"value": sps, "unit": "steps/s", "cores": best, "kind": "port",
+           "sample": f"{warm} warm-up + {timed} timed Euler steps of the same N={N} network, torch {torch.__version__} "
+                     f"CPU eager loop (oracle/torch_eager.py), fp32, no_grad; thread count = best of a sweep "
+                     f"(2 warm-up + 10 timed steps each) over {cands} on {hw} hardware threads",
+           "thread_sweep_steps_per_s": {str(t): round(v_, 2) for t, v_ in table.items()}}
+    return res, best
+
+
+def cpu_fwd_bwd(pop, x, dt, N, threads, T=20):
+    """the CPU counterpart of the BPTT window -- the eager loop under autograd, MSE on a k=3
+    read-out, backward(); window T=20 (autograd materialises a 4 GiB outer product per step)."""
+    from oracle.torch_eager import time_eager_bptt
+    torch.set_num_threads(threads)
+    gen = torch.Generator().manual_seed(2)
+    W_out = torch.randn(3, N, generator=gen) / N ** 0.5
+    target = torch.randn(T, 3, generator=gen) * 0.1
+    xs = x[:T].cpu().expand(T, N).contiguous()
+    tau, k, eta = (pop.params[n].cpu() for n in ("tau", "k", "eta"))
+    sps = time_eager_bptt(pop.W.cpu(), tau, k, eta, pop.v.cpu(), xs, W_out, target, dt, T)
+    return {"value": sps, "unit": "steps/s (fwd+bwd)", "cores": threads, "kind": "port",
+            "sample": f"one autograd window of T={T} steps, N={N}, trainable W, MSE read-out k=3 "
+                      f"(oracle/torch_eager.py: time_eager_bptt)"}
+
+
+def ridge_extra(net, x, N, dev, T=2000, sampling=10, k=3):
+    """Network.fit_ridge -- state collection over T steps on the fused window (sampled every
+    `sampling` steps) + the closed-form read-out solve (float64 Gram matrix and solve in torch, dual form S x S)."""
+    import contextlib
+    gen = torch.Generator(device=dev).manual_seed(4)
+    targets = torch.randn(T, k, generator=gen, device=dev)
+    with contextlib.redirect_stdout(sys.stderr):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        obs = net.fit_ridge(x[:T], targets, sampling_steps=sampling, alpha=1e-2, verbose=False, add_readout_node=False)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+    w = obs["w_out"]
+    return {"workload": f"Network.fit_ridge, N={N}, {T} steps, sampling_steps={sampling}, k={k}",
+            "steps_per_s": T / wall, "wall_s": wall, "w_out_shape": list(w.shape),
+            "w_out_finite": bool(torch.isfinite(w).all().item())}
+
+
+def config5_leg(n5, steps, world, rank, dev, dt):
+    """BASELINE.json configs[4]: tanh rate network with N = 262144 neurons row-sharded over the ranks (W generated
+    shard-wise on device, 34.4 GB per GPU at 8 ranks), one RCCL all-gather of the source vector per step.  Collective:
+    every rank runs it.  Returns the record on rank 0 (None elsewhere)."""
+    import torch.distributed as dist
+    from rectipy_amd.sharded import ShardedPopulation, shard_bounds
+    row0, rows = shard_bounds(n5, world, rank)
+    if 4.0 * rows * n5 > 200e9:
+        return None if rank else {"skipped": f"a {rows} x {n5} shard does not fit one GPU"}
+    sp = ShardedPopulation("li_tanh", gen_rows(n5, row0, rows, dev), dict(tau=10.0, k=1.0, eta=0.0), dt, dev, n=n5)
+    exchange = "torch.distributed all_gather_into_tensor per step (host loop)"
+    if sp.comm is not None and sp.check_inlib_exchange(2):
+        exchange = "RCCL all-gather enqueued in-library"
+    warm = 20
+    tt = torch.arange(warm + steps, device=dev, dtype=torch.float32) * dt
+    x = torch.sin(2 * torch.pi * 0.2 * tt).reshape(-1, 1).contiguous()
+    sp.forward(warm, x=x[:warm])
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    sp.forward(steps, x=x[warm:], step0=warm)
+    e1.record()
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    wall = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    finite = torch.tensor([int(torch.isfinite(sp.pop.v).all().item())], device=dev)
+    dist.all_reduce(finite, op=dist.ReduceOp.MIN)
+    ms_dev = e0.elapsed_time(e1) / steps
+    del sp
+    torch.cuda.empty_cache()
+    if rank:
+        return None
+    wall = float(wall.item())
+    algo = 4.0 * rows * n5 + 4.0 * (7 * rows + n5)
+    gbps = algo / (ms_dev * 1e-3) / 1e9
+    return {"workload": f"tanh rate RNN N={n5}, dense W row-sharded x{world} ({rows} rows = {4.0 * rows * n5 / 1e9:.1f} GB "
+                        f"per GPU), {steps} timed steps after {warm} warm-up; {exchange} (BASELINE.json configs[4])",
+            "steps_per_s": steps / wall, "ms_per_step": wall / steps * 1e3, "n_gpus": world,
+            "per_gpu_roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": gbps / HBM_PEAK_GBPS, "rank0_ms_per_step_incl_exchange": ms_dev,
+                                 "algorithmic_bytes_per_step_per_gpu": algo},
+            "state_finite": bool(finite.item())}
 
 
 if __name__ == "__main__":

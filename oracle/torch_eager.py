@@ -37,3 +37,63 @@ def time_eager(W, tau, k, eta, y, x, dt, warmup, steps):
     t0 = time.perf_counter()
     run_eager(W, tau, k, eta, y, x[warmup:], dt, steps)
     return steps / (time.perf_counter() - t0)
+
+
+def sweep_threads(fn, candidates):
+    """Run ``fn()`` (returns steps/s) under each intra-op thread count; returns (best_threads, best, table).
+    The default thread count (all hardware threads) is rarely the best for a DRAM-bound mat-vec."""
+    default = torch.get_num_threads()
+    table = {}
+    try:
+        for t in candidates:
+            torch.set_num_threads(int(t))
+            table[int(t)] = fn()
+    finally:
+        torch.set_num_threads(default)
+    best = max(table, key=table.get)
+    return best, table[best], table
+
+
+def time_eager_bptt(W, tau, k, eta, y, x, W_out, target, dt, steps):
+    """One BPTT window of `steps` steps the way the reference runs it on the CPU: the per-step loop under autograd
+    (recurrent weights trained), `MSELoss` on the stacked read-out predictions, `backward()`
+    (reference rectipy/network.py:1028-1040, 1123-1130).  Returns steps/s of forward + backward."""
+    W = W.clone().requires_grad_(True)
+    y = y.clone().requires_grad_(True)
+    loss_fn = torch.nn.MSELoss()
+    t0 = time.perf_counter()
+    preds = []
+    for step in range(steps):
+        y_old = y
+        y = y_old + dt * li_tanh_field(0, y_old, x[step, :], W, tau, k, eta)
+        preds.append(W_out @ y_old)
+    loss = loss_fn(torch.stack(preds), target[:steps])
+    loss.backward()
+    return steps / (time.perf_counter() - t0)
+
+
+def qif_field(n):
+    def qif(t, y, I_ext, spike, weights, tau, k, eta, tau_s):  # qif.yaml:11-12
+        v, s = y[:n], y[n:]
+        return torch.cat(((v ** 2 + eta + I_ext) / tau + k * (weights @ s), -s / tau_s + spike), 0)
+    return qif
+
+
+def time_eager_qif(W, tau, k, eta, tau_s, v, s, x_const, dt, theta, v_reset, warmup, steps):
+    """steps/s of the reference's spiking step on the CPU (rectipy/nodes.py:382-392: spike detection on the old v,
+    `spike / dt` input, Euler on the concatenated state, reset blend), op for op, no_grad."""
+    n = v.shape[0]
+    f = qif_field(n)
+    x = torch.tensor([x_const], dtype=v.dtype)
+    t0 = None
+    with torch.no_grad():
+        for step in range(warmup + steps):
+            if step == warmup:
+                t0 = time.perf_counter()
+            spikes = torch.heaviside(v - theta, torch.ones((), dtype=v.dtype))
+            y = torch.cat((v, s), 0)
+            y_new = y + dt * f(0, y, x, spikes / dt, W, tau, k, eta, tau_s)
+            reset = spikes.detach()
+            v = y_new[:n] * (1.0 - reset) + reset * v_reset
+            s = y_new[n:]
+    return steps / (time.perf_counter() - t0)

@@ -93,6 +93,14 @@ class ShardedPopulation:
         full = self.pop.source
         dist.all_gather_into_tensor(full, full[self.row0:self.row0 + self.rows].clone(), group=self.group)
 
+    def check_inlib_exchange(self, steps: int = 3) -> bool:
+        """One-time guard for the in-library RCCL exchange (it runs on the compute stream with ProcessGroupNCCL's
+        communicator, outside the process group's own bookkeeping): `steps` steps with it must reproduce, bit for bit,
+        the same steps with the ``torch.distributed`` all-gather from the host loop.  On disagreement or a library
+        error on ANY rank, every rank drops to the host loop (``self.comm = None``).  State is restored.  Collective:
+        all ranks must call it."""
+        return check_inlib_exchange(self.pop, self, steps, self.group)
+
     def forward(self, steps: int, x: Optional[torch.Tensor] = None, out_var: int = _abi.RP_OUT_STATE0,
                 traj: Optional[torch.Tensor] = None, step0: int = 0, **sampling):
         """`steps` Euler steps; `x` and `traj` are LOCAL ([steps, rows] or [steps, 1])."""
@@ -107,6 +115,48 @@ class ShardedPopulation:
             full = self.pop.source  # the buffer the kernel just wrote this rank's slice into
             dist.all_gather_into_tensor(full, full[self.row0:self.row0 + self.rows], group=self.group)
         return idx
+
+
+def check_inlib_exchange(pop: Population, holder, steps: int, group) -> bool:
+    """See ShardedPopulation.check_inlib_exchange; `holder.comm` is the rp_comm in use (set to None on failure)."""
+    if holder.comm is None:
+        return False
+    saved = (pop.v.clone(), pop.src[0].clone(), pop.src[1].clone(), pop.cur,
+             None if pop.aux is None else pop.aux.clone(), None if pop.aux2 is None else pop.aux2.clone())
+    row0, rows = pop.row0, pop.rows
+
+    def restore():
+        pop.v.copy_(saved[0]); pop.src[0].copy_(saved[1]); pop.src[1].copy_(saved[2]); pop.cur = saved[3]
+        if saved[4] is not None:
+            pop.aux.copy_(saved[4])
+        if saved[5] is not None:
+            pop.aux2.copy_(saved[5])
+
+    def run(comm):
+        restore()
+        if comm is not None:
+            pop.forward(steps, comm=comm)
+        else:
+            for _ in range(steps):
+                pop.forward(1)
+                full = pop.source
+                dist.all_gather_into_tensor(full, full[row0:row0 + rows], group=group)
+        return pop.v.clone(), pop.source.clone()
+
+    try:
+        a, b = run(holder.comm), run(None)
+        agree = int(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]))
+    except RuntimeError as err:  # RP_ERR_COMM / RP_ERR_HIP from the library: keep the host loop
+        import warnings
+        warnings.warn(f"in-library RCCL exchange failed on rank {dist.get_rank(group)}: {err}")
+        agree = 0
+    same = torch.tensor([agree], device=pop.device)
+    dist.all_reduce(same, op=dist.ReduceOp.MIN, group=group)
+    restore()
+    if int(same.item()) != 1:
+        holder.comm = None
+        return False
+    return True
 
 
 # ---- front end ---------------------------------------------------------------------------------------------
@@ -323,6 +373,7 @@ class ShardedNetwork(Network):
         self.rank = dist.get_rank(group)
         self._sharded = {}  # label -> (row0, rows, n)
         self.comm = None  # rp_comm for the in-library exchange, set once the first collective has run
+        self._exchange_checked = False
 
     def add_diffeq_node(self, label, node, input_var, output_var, weights=None, **kwargs):
         if weights is None:
@@ -339,8 +390,10 @@ class ShardedNetwork(Network):
         self._sharded[label] = (row0, rows, n)
         self._wrap(new, row0, rows)
         self._gather(new, row0, rows, clone=True)
-        if self.comm is None:
+        if self.comm is None and not self._exchange_checked:
             self.comm = rccl_comm(self.group, new._pop.device, new._pop.backend)
+            check_inlib_exchange(new._pop, self, 3, self.group)  # one-time guard; drops to the host loop on disagreement
+            self._exchange_checked = True
         return new
 
     def _gather(self, node: RateNet, row0: int, rows: int, clone: bool = False):
