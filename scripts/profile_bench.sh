@@ -5,7 +5,8 @@ set -o pipefail
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 300 --warmup 20 --no-cpu-baseline > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+# the stats pass profiles the driver's own command line
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra > $OUT/fetch.log 2>&1 || { tail -5 $OUT/fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-extra > $OUT/write.log 2>&1 || { tail -5 $OUT/write.log; exit 1; }
 find $OUT -name "*.csv" | head -30
