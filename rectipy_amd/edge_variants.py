@@ -36,7 +36,7 @@ class LinearMasked(_Stateful):
     def __init__(self, n_in: int, n_out: int, mask: Union[np.ndarray, torch.Tensor], weights=None,
                  dtype: torch.dtype = torch.float32, detach: bool = True, **kwargs):
         mask = torch.as_tensor(np.asarray(mask) if not isinstance(mask, torch.Tensor) else mask, dtype=dtype)
-        if mask.shape[0] == n_in and mask.shape[1] == n_out and n_in != n_out:
+        if mask.shape[0] == n_in and mask.shape[1] == n_out:  # square masks are transposed too (edges.py:161-162)
             mask = mask.T
         elif mask.shape[0] != n_out or mask.shape[1] != n_in:
             raise ValueError("Shape of the provided mask does not match the input and output dimensions of the "

@@ -25,9 +25,10 @@ class Linear:
             weights = weights.detach().to(dtype).clone()
         if weights.dim() != 2:
             raise ValueError("edge weights must be a matrix")
-        # the reference accepts either orientation and transposes (n_in, n_out) input (edges.py:22-26);
-        # square matrices are kept as given.
-        if weights.shape[0] == n_in and weights.shape[1] == n_out and n_in != n_out:
+        # the reference accepts either orientation and transposes whatever matches (n_in, n_out) FIRST (edges.py:22-26)
+        # -- a square matrix therefore IS transposed: edge weights are read as [source, target] when ambiguous
+        # (verified against the reference's class; fixture G27).
+        if weights.shape[0] == n_in and weights.shape[1] == n_out:
             weights = weights.T.contiguous()
         elif weights.shape[0] != n_out or weights.shape[1] != n_in:
             raise ValueError("Shape of the provided weights does not match the input and output dimensions of the "

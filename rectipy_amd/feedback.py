@@ -1,8 +1,16 @@
 """``FeedbackNetwork``: a Network whose edges may be flagged ``feedback=True`` (reference
-rectipy/network.py:1196-1357).  Feed-forward edges define the evaluation order and the input / output nodes;
-a feedback edge delivers its source node's output of the PREVIOUS step (zero before the first step), so cycles
-through feedback edges are allowed.  Such networks are evaluated step by step; every diff-eq node still advances
-through the HIP step kernel."""
+rectipy/network.py:1196-1357).  Feed-forward edges define the evaluation order and the input / output nodes; feedback
+edges are added to a node's input without taking part in the ordering, so cycles through them are allowed.
+
+What a feedback edge delivers follows the reference (`_edge_bwd`, network.py:1354-1357): ``source_node["out"]`` read at
+the moment the target is evaluated -- the output slice of the source's state vector `y` as it stands then, NOT the
+value the source returned from `forward`.  For a rate population that has not been stepped yet in this step (the usual
+case: the source sits downstream of the target) this is its current state, i.e. what it is about to emit; for a
+spiking population `y` lags one step (nodes.py:387-392), so it is the previous step's output; a source that was already
+stepped in this step delivers its post-update state.  Pinned by fixture G28 (tests/golden/make_golden_topologies.py).
+The reference cannot feed back from an activation node (``InstantNode["out"]`` is None -> TypeError); here such an edge
+delivers the node's output of the previous step (zero before the first step) -- an extension.
+Such networks are evaluated step by step; every diff-eq node still advances through the HIP step kernel."""
 from typing import Optional
 
 import torch
@@ -61,9 +69,13 @@ class FeedbackNetwork(Network):
             for p in self.graph.predecessors(n):
                 fb = self.graph[p][n].get("feedback")
                 if fb:
-                    src = self._prev_out.get(p)
-                    if src is None:
-                        continue  # nothing has been emitted yet: zero feedback
+                    node_p = self.get_node(p)
+                    if hasattr(node_p, "y"):
+                        src = node_p["out"]  # the reference's `self.get_node(source)["out"]` (network.py:1355)
+                    else:
+                        src = self._prev_out.get(p)
+                        if src is None:
+                            continue  # nothing has been emitted yet: zero feedback
                 else:
                     has_ffwd = True
                     src = new_out[p]

@@ -302,6 +302,8 @@ class RateNet:
     def __getitem__(self, item):
         if item in self._param_map:
             return self._tensor(self._param_map[item])
+        if item == "out" and not self._spiking and self._out_code == _abi.RP_OUT_SOURCE:
+            return self._pop.source_local.clone()   # output variable r = act(v) of the current state
         if item in self._template.derived:
             # r = act(v) lives in a ping-pong buffer the kernels overwrite two steps later; the reference computes a
             # fresh tensor per step, so hand out a copy that a per-step recorder may keep (observer.py:100-101)

@@ -1,14 +1,23 @@
-"""Edge variants and FeedbackNetwork (reference rectipy/edges.py:68-174, network.py:1196-1357): stepwise graph
-evaluation with the diff-eq node on the engine; checked against a straightforward numpy re-statement."""
+"""Edge variants and FeedbackNetwork against fixtures captured from the REFERENCE's own classes
+(tests/golden/make_golden_topologies.py; reference rectipy/edges.py:68-174, rectipy/network.py:1196-1357).
+Networks with such edges are evaluated step by step, every diff-eq node on the engine (oracle / HIP)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from rectipy_amd import FeedbackNetwork, Network
+from rectipy_amd import FeedbackNetwork, Network, SpikeResetNet
 from rectipy_amd.edge_variants import LinearFilter, LinearMasked, LinearMemory, LinearMemoryFilter
 
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TANH = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
+QIF = "neuron_model_templates.spiking_neurons.qif.qif"
 TARGETS = [pytest.param("oracle", id="oracle"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+def gold(name):
+    return dict(np.load(os.path.join(GOLD, name + ".npz")))
 
 
 @pytest.fixture
@@ -20,67 +29,123 @@ def target(request, oracle_backend):
     return dict(device="cuda:0", backend=None)
 
 
-def li_step(v, W, x, dt=1e-2):
-    return v + dt * (-v / 10.0 + W @ np.tanh(v) + x)
+def err(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return np.abs(a.astype(np.float64) - np.asarray(b, dtype=np.float64)).max()
 
 
-@pytest.mark.parametrize("target", TARGETS, indirect=True)
-def test_masked_and_filter_edges(target):
-    rng = np.random.default_rng(0)
-    n, m, k, T = 12, 4, 3, 25
-    W, W_in, W_out = rng.standard_normal((n, n)) / 3, rng.standard_normal((n, m)), rng.standard_normal((k, n))
-    mask = (rng.uniform(size=(n, m)) > 0.5).astype(np.float32)
-    F = rng.standard_normal((n, n)) * 0.1
-    net = Network(1e-2, **target)
-    net.add_func_node("inp", m, "identity")
-    net.add_diffeq_node("rnn", TANH, weights=W, source_var="tanh_op/r", target_var="li_op/r_in",
-                        input_var="li_op/I_ext", output_var="li_op/v", dtype=torch.float32)
-    net.add_func_node("out", k, "identity")
-    e1 = net.add_edge("inp", "rnn", weights=W_in, mask=mask)
-    e2 = net.add_edge("rnn", "out", weights=W_out, filter_weights=F)
-    assert isinstance(e1, LinearMasked) and isinstance(e2, LinearFilter)
-    x = rng.standard_normal((T, m)).astype(np.float32)
-    obs = net.run(x, sampling_steps=1, verbose=False, enable_grad=False)
-    v, y, ref = np.zeros(n), np.zeros(n), []
-    for t in range(T):
-        y = F @ y + v                      # the filter sees the node's pre-update output
-        ref.append(W_out @ y)
-        v = li_step(v, W, (W_in * mask) @ x[t])
-    assert np.abs(obs.to_numpy("out") - np.asarray(ref)).max() < 1e-4
+def li_node_kwargs(g, suffix=""):
+    return dict(weights=g["W" + suffix], source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                output_var="li_op/v", dtype=torch.float32,
+                node_vars={"all/li_op/tau": g["tau" + suffix], "all/li_op/k": g["k" + suffix],
+                           "all/li_op/eta": g["eta" + suffix], "all/li_op/v": g["y0" + suffix]})
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float64, 1e-12), (torch.float32, 2e-5)])
+def test_g27a_edge_classes_match_the_reference(dtype, tol):
+    """The four edge classes driven directly: orientation rules (non-square (n_in, n_out) input AND square matrices are
+    transposed, edges.py:22-26, 161-162), delay-buffer indexing with repeated delays (edges.py:91-94), filters."""
+    g = gold("g27a_edge_variants")
+    n_in, n_out = g["W"].shape[1], g["W"].shape[0]
+
+    def seq(edge, data):
+        return torch.stack([edge.forward(torch.tensor(row, dtype=dtype)) for row in data])
+
+    cases = {
+        "masked": (LinearMasked(n_in, n_out, mask=g["mask"], weights=g["W"], dtype=dtype), g["x"]),
+        "masked_T": (LinearMasked(n_in, n_out, mask=np.ascontiguousarray(g["mask"].T), weights=g["Wt"], dtype=dtype), g["x"]),
+        "masked_sq": (LinearMasked(5, 5, mask=g["mask_s"], weights=g["Ws"], dtype=dtype), g["xs"]),
+        "memory": (LinearMemory(n_in, n_out, delays=g["delays"], weights=g["W"], dtype=dtype), g["x"]),
+        "filter": (LinearFilter(n_in, n_out, filter_weights=g["F"], weights=g["W"], dtype=dtype), g["x"]),
+        "memfilter": (LinearMemoryFilter(n_in, n_out, delays=g["delays"], filter_weights=g["F"], weights=g["W"],
+                                         dtype=dtype), g["x"]),
+    }
+    for name, (edge, data) in cases.items():
+        assert err(seq(edge, data), g[name + "_f64"]) <= tol, name
     with pytest.raises(ValueError):
-        net.add_edge("rnn", "out", weights=W_out, filter_weights=np.zeros((3, 3)))
+        LinearFilter(n_in, n_out, filter_weights=np.zeros((3, 3)), weights=g["W"])
+    with pytest.raises(ValueError):
+        LinearMemory(n_in, n_out, delays=np.array([0, 1]), weights=g["W"])
+    with pytest.raises(ValueError):
+        LinearMasked(n_in, n_out, mask=np.zeros((3, 3)), weights=g["W"])
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
-def test_memory_edges_follow_reference_indexing(target):
-    rng = np.random.default_rng(1)
-    n, k, T = 6, 2, 12
-    W, W_out = rng.standard_normal((n, n)) / 3, rng.standard_normal((k, n))
-    delays = np.array([0, 1, 2, 0, 1, 2])
-    for with_filter in (False, True):
-        F = np.eye(n) * 0.5
-        net = Network(1e-2, **target)
-        net.add_diffeq_node("rnn", TANH, weights=W, source_var="tanh_op/r", target_var="li_op/r_in",
-                            input_var="li_op/I_ext", output_var="li_op/v", dtype=torch.float32)
+def test_g27b_edge_variants_inside_network_run(target):
+    g = gold("g27b_edge_variants_in_network")
+    n, m, k = g["W"].shape[0], g["W_in"].shape[1], g["W_out"].shape[0]
+    net = Network(float(g["dt"]), **target)
+    net.add_func_node("inp", m, "identity")
+    net.add_diffeq_node("rnn", TANH, **li_node_kwargs(g))
+    net.add_func_node("out", k, "identity")
+    e1 = net.add_edge("inp", "rnn", weights=g["W_in"], mask=g["mask"])
+    e2 = net.add_edge("rnn", "out", weights=g["W_out"], filter_weights=g["F"])
+    assert isinstance(e1, LinearMasked) and isinstance(e2, LinearFilter)
+    obs = net.run(g["x_m"], sampling_steps=1, verbose=False, enable_grad=False)
+    assert err(obs.to_numpy("out"), g["masked_filter_f64"]) <= 2e-5
+    for name, kw, cls in (("memory", dict(delays=g["delays"]), LinearMemory),
+                          ("memfilter", dict(delays=g["delays"], filter_weights=g["F"]), LinearMemoryFilter)):
+        net = Network(float(g["dt"]), **target)
+        net.add_diffeq_node("rnn", TANH, **li_node_kwargs(g))
         net.add_func_node("out", k, "identity")
-        kw = dict(filter_weights=F) if with_filter else {}
-        e = net.add_edge("rnn", "out", weights=W_out, delays=delays, **kw)
-        assert isinstance(e, LinearMemoryFilter if with_filter else LinearMemory)
-        x = rng.standard_normal((T, n)).astype(np.float32)
-        obs = net.run(x, sampling_steps=1, verbose=False, enable_grad=False)
-        v, buf, ref = np.zeros(n), np.zeros((n, 3)), []
-        for t in range(T):
-            buf = np.roll(buf, -1, axis=1)
-            if with_filter:
-                buf = F @ buf
-            buf[:, delays] = v           # reference indexing (edges.py:93): column delays[j] <- x[j] on every row
-            ref.append(W_out @ buf[:, 0])
-            v = li_step(v, W, x[t])
-        assert np.abs(obs.to_numpy("out") - np.asarray(ref)).max() < 1e-4
+        assert type(net.add_edge("rnn", "out", weights=g["W_out"], **kw)) is cls
+        obs = net.run(g["x_n"], sampling_steps=1, verbose=False, enable_grad=False)
+        assert err(obs.to_numpy("out"), g[name + "_f64"]) <= 2e-5, name
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
-def test_feedback_network_uses_previous_step_output(target):
+def test_g28_feedback_between_rate_populations(target):
+    """(a) a -> b with feedback b -> a: the feedback edge reads b's CURRENT state (b is stepped after a);
+    (c) a -> b -> c with a feedback edge a -> c: its source has already been stepped (network.py:1354-1357).
+    Square edge matrices, i.e. the transposition rule is part of what is pinned."""
+    g = gold("g28_feedback")
+    net = FeedbackNetwork(float(g["dt"]), **target)
+    net.add_diffeq_node("a", TANH, **li_node_kwargs(g, "_a"))
+    net.add_diffeq_node("b", TANH, **li_node_kwargs(g, "_b"))
+    net.add_edge("a", "b", weights=g["W_ab"])
+    net.add_edge("b", "a", weights=g["W_ba"], feedback=True)
+    net.compile()
+    assert net._in_node == "a" and net._out_node == "b"
+    obs = net.run(g["x"], sampling_steps=1, verbose=False, enable_grad=False)
+    assert err(obs.to_numpy("out"), g["rate_ab_f64"]) <= 2e-5
+    assert err(net.state["a"], g["rate_ab_state_a_f64"]) <= 2e-5 and err(net.state["b"], g["rate_ab_state_b_f64"]) <= 2e-5
+
+    net = FeedbackNetwork(float(g["dt"]), **target)
+    for lab in "abc":
+        net.add_diffeq_node(lab, TANH, **li_node_kwargs(g, "_" + lab))
+    net.add_edge("a", "b", weights=g["W_ab"])
+    net.add_edge("b", "c", weights=g["W_bc"])
+    net.add_edge("a", "c", weights=g["W_ac"], feedback=True)
+    obs = net.run(g["x"], sampling_steps=1, verbose=False, enable_grad=False)
+    assert err(obs.to_numpy("out"), g["rate_abc_f64"]) <= 2e-5
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_g28_feedback_between_spiking_populations(target):
+    """QIF a -> QIF b with inhibitory feedback b -> a: a spiking node's `y` lags one step (nodes.py:387-392), so the
+    feedback edge delivers b's previous output.  1500 steps with spikes in both populations."""
+    g = gold("g28_feedback")
+    nq, T = g["Wq0"].shape[0], int(g["Tq"])
+    assert float(g["qif_ab_peak_f64"]) > 0.5, "the fixture must contain spikes"
+    net = FeedbackNetwork(float(g["dtq"]), **target)
+    for lab, i in (("a", 0), ("b", 1)):
+        node = SpikeResetNet.from_pyrates(
+            QIF, input_var="qif_op/I_ext", output_var="qif_op/s", weights=g[f"Wq{i}"], source_var="qif_op/s",
+            target_var="qif_op/s_in", spike_var="qif_op/spike", reset_var="qif_op/v",
+            node_vars={"all/qif_op/eta": g[f"etaq{i}"], "all/qif_op/v": g["y0q"][:nq], "all/qif_op/s": g["y0q"][nq:]},
+            spike_threshold=100.0, spike_reset=-100.0, dt=float(g["dtq"]), dtype=torch.float32, **target)
+        net.add_node(lab, node, node_type="diff_eq")
+    net.add_edge("a", "b", weights=g["Wq_ab"])
+    net.add_edge("b", "a", weights=g["Wq_ba"], feedback=True)
+    x = np.full((T, nq), 15.0, dtype=np.float32)
+    obs = net.run(x, sampling_steps=1, verbose=False, enable_grad=False)
+    assert err(obs.to_numpy("out")[::5], g["qif_ab_f64"]) <= 5e-5
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_feedback_from_an_activation_node_and_fused_fallback(target):
+    """Extension (the reference raises TypeError here: InstantNode["out"] is None): feedback from an activation node
+    delivers its previous output.  Without feedback edges the class takes the fused path and agrees with Network."""
     rng = np.random.default_rng(2)
     n, k, T = 10, 2, 30
     W, W_out, W_fb = rng.standard_normal((n, n)) / 3, rng.standard_normal((k, n)), rng.standard_normal((n, k)) * 0.5
@@ -90,8 +155,6 @@ def test_feedback_network_uses_previous_step_output(target):
     net.add_func_node("out", k, "tanh")
     net.add_edge("rnn", "out", weights=W_out)
     net.add_edge("out", "rnn", weights=W_fb, feedback=True)
-    net.compile()
-    assert net._in_node == "rnn" and net._out_node == "out"
     x = rng.standard_normal((T, n)).astype(np.float32)
     obs = net.run(x, sampling_steps=1, verbose=False, enable_grad=False)
     v, prev, ref = np.zeros(n), None, []
@@ -99,11 +162,15 @@ def test_feedback_network_uses_previous_step_output(target):
         inp = x[t] + (W_fb @ prev if prev is not None else 0.0)
         out = np.tanh(W_out @ v)
         ref.append(out)
-        v = li_step(v, W, inp)
+        v = v + 1e-2 * (-v / 10.0 + W @ np.tanh(v) + inp)
         prev = out
-    assert np.abs(obs.to_numpy("out") - np.asarray(ref)).max() < 1e-4
-    # without feedback edges the same class takes the fused path and agrees with Network
+    assert err(obs.to_numpy("out"), np.asarray(ref)) < 1e-4
     net2 = FeedbackNetwork(1e-2, **target)
     net2.add_diffeq_node("rnn", TANH, weights=W, source_var="tanh_op/r", target_var="li_op/r_in",
                          input_var="li_op/I_ext", output_var="li_op/v", dtype=torch.float32)
-    assert net2.run(x, verbose=False, enable_grad=False).to_numpy("out").shape == (T, n)
+    net1 = Network(1e-2, **target)
+    net1.add_diffeq_node("rnn", TANH, weights=W, source_var="tanh_op/r", target_var="li_op/r_in",
+                         input_var="li_op/I_ext", output_var="li_op/v", dtype=torch.float32)
+    a = net2.run(x, verbose=False, enable_grad=False).to_numpy("out")
+    b = net1.run(x, verbose=False, enable_grad=False).to_numpy("out")
+    assert a.shape == (T, n) and np.array_equal(a, b)
