@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 6
+#define RP_ABI_VERSION 7
 
 #define RP_OK 0
 #define RP_ERR_ARG (-1)      /* null pointer, bad enum, bad flag combination  */
@@ -196,6 +196,11 @@ typedef struct rp_run {
        before the update) -- the B operand of the shard's rectangular dW GEMM. */
     float* save_src_full;     /* [steps x ldfull] or NULL                     */
     int64_t ldfull;
+    /* Spiking models, optional [rows]: the FIRST step of the call detects spikes (and applies the reset mask) on these
+       values instead of on v -- MultiSpikeResetNet keeps its own spike-detector copy of the reset variable, which
+       starts at zero and is not refreshed by reset() (rectipy/nodes.py:428-431, 451-456).  Later steps of the call
+       use v.  Not available for the population-mean models (IKU, IK_BIEXP). */
+    const float* spike_src;
 } rp_run;
 
 /* Arguments of the adjoint sweep over a stored window (LI models). */

@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 6
+RP_ABI_VERSION = 7
 
 RP_OK = 0
 RP_ERR_ARG = -1
@@ -102,6 +102,7 @@ class RpRun(C.Structure):
         ("spike_count", fp),
         ("save_src_full", fp),
         ("ldfull", C.c_int64),
+        ("spike_src", fp),
     ]
 
 

@@ -57,6 +57,7 @@ struct StepParams {
     int* spike_events;
     int spike_capacity;
     int* spike_count;
+    const float* spike_src;  // this step detects spikes on these values instead of v (rp_run.spike_src, first step only)
     int t_abs;
     // packed W (rp_net.sp_*): streamed instead of W when non-null
     const float* sp_vals;
@@ -136,7 +137,8 @@ __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum)
         //                               u' = (b(v-v_r) - u)/tau_u + kappa spike;    s' = -s/tau_s + spike
         const float v = P.y[RP_Y_V][i];
         const float s = P.src_cur[gi];
-        const float spike = (v - P.theta >= 0.0f) ? 1.0f : 0.0f;  // heaviside(v-theta, 1): equality spikes
+        const float v_det = P.spike_src ? P.spike_src[i] : v;     // MultiSpikeResetNet's detector copy (nodes.py:451-453)
+        const float spike = (v_det - P.theta >= 0.0f) ? 1.0f : 0.0f;  // heaviside(v-theta, 1): equality spikes
         const float spike_in = spike * P.inv_dt;                   // nodes.py:385
         float dv, aux = 0.f, aux_new = 0.f, aux2 = 0.f, aux2_new = 0.f;
         float ds = -s / P.p[RP_P_TAU_S][i] + spike_in;
@@ -637,6 +639,8 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
         if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP)
             RP_FAIL(RP_ERR_ARG, "population-mean models cannot be row-sharded");
     }
+    if (run->spike_src && (net->model < RP_MODEL_QIF || net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP))
+        RP_FAIL(RP_ERR_ARG, "spike_src is for the spiking models without population means (model %d)", net->model);
     if (run->steps < 0) RP_FAIL(RP_ERR_ARG, "steps < 0");
     if (run->sampling_steps < 1) RP_FAIL(RP_ERR_ARG, "sampling_steps must be >= 1");
     if (run->cutoff < 0 || run->step0 < 0) RP_FAIL(RP_ERR_ARG, "cutoff/step0 must be >= 0");
@@ -719,6 +723,7 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
         P.save_src_t = run->save_src ? run->save_src + (int64_t)t * run->ldsave : nullptr;
         P.save_acc_t = run->save_acc ? run->save_acc + (int64_t)t * run->ldsave : nullptr;
         P.t_abs = (int)t_abs;
+        P.spike_src = t == 0 ? run->spike_src : nullptr;
         P.flags = 0;
         P.sample_row = nullptr;
         for (int q = 0; q < RP_MAX_STATE; ++q) P.rec_row[q] = nullptr;

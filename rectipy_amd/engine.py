@@ -335,7 +335,7 @@ class Population:
                 spike_events: Optional[torch.Tensor] = None, spike_count: Optional[torch.Tensor] = None,
                 x_target: int = _abi.RP_XT_MEMBRANE, save_aux: Optional[torch.Tensor] = None,
                 save_aux2: Optional[torch.Tensor] = None, comm=None,
-                save_src_full: Optional[torch.Tensor] = None) -> int:
+                save_src_full: Optional[torch.Tensor] = None, spike_src: Optional[torch.Tensor] = None) -> int:
         """Integrate ``steps`` Euler steps in one library call.  Returns the next sample index.
         ``comm`` (an ``RpComm``): this population is a row shard and every step ends with the in-library RCCL
         all-gather of the source vector (rp_forward_sharded).
@@ -423,6 +423,12 @@ class Population:
                     or t.shape[1] < self.n or t.shape[0] < steps:
                 raise RuntimeError(f"save_src_full must be a float32 [>= {steps}, >= {self.n}] row-major tensor")
             run.save_src_full, run.ldfull = t.data_ptr(), t.stride(0) if t.shape[0] > 1 else t.shape[1]
+        if spike_src is not None:  # first step detects spikes on these values (rp_run.spike_src)
+            if spike_src.dtype != torch.float32 or spike_src.device != self.device or spike_src.numel() != self.rows \
+                    or not spike_src.is_contiguous():
+                raise RuntimeError(f"spike_src must be a contiguous float32 [{self.rows}] tensor on {self.device}")
+            run.spike_src = spike_src.data_ptr()
+            keep.append(spike_src)
         if spike_count is not None:
             run.spike_events = spike_events.data_ptr()
             run.spike_capacity = spike_events.shape[0]

@@ -273,7 +273,8 @@ class Network:
         if any(self.graph.in_degree(n) > 1 or self.graph.out_degree(n) > 1 for n in order):
             return None
         diffeq = [n for n in order if self[n]["node_type"] == "diff_eq"]
-        if len(diffeq) != 1 or not isinstance(self.get_node(diffeq[0]), RateNet):
+        if len(diffeq) != 1 or not isinstance(self.get_node(diffeq[0]), RateNet) \
+                or not getattr(self.get_node(diffeq[0]), "_fusable", True):
             return None
         for n in order:
             node = self.get_node(n)
@@ -358,6 +359,8 @@ class Network:
         for n in self._order:
             node = self.get_node(n)
             if not isinstance(node, RateNet) and not (isinstance(node, InstantNode) and node.name in InstantNode.batched):
+                return None
+            if not getattr(node, "_fusable", True):
                 return None
         for s_, t_ in self.graph.edges:
             if type(self.get_edge(s_, t_)) not in (Linear, RLS):

@@ -535,8 +535,10 @@ class SpikeResetNet(RateNet):
     def from_pyrates(cls, node, input_var: str, output_var: str, weights: np.ndarray = None,
                      source_var: str = None, target_var: str = None, spike_var: str = "spike",
                      reset_var: str = "v", train_params: list = None, **kwargs):
-        if isinstance(spike_var, list):
-            raise NotImplementedError("multiple spike/reset variable pairs (MultiSpikeResetNet) are out of scope")
+        if isinstance(spike_var, (list, tuple)):  # several spike/reset pairs: one node, several populations
+            return MultiSpikeResetNet.from_pyrates(node, input_var, output_var, weights=weights, source_var=source_var,
+                                                   target_var=target_var, spike_var=list(spike_var),
+                                                   reset_var=list(reset_var), train_params=train_params, **kwargs)
         kwargs["spike_var"] = spike_var
         kwargs["reset_var"] = reset_var
         return super().from_pyrates(node, input_var, output_var, weights=weights, source_var=source_var,
@@ -693,3 +695,236 @@ class SpikeResetNet(RateNet):
                           save_v=sv, save_src=ss, save_aux=sa, save_aux2=sb, **kw)
         self._y_prev = self._pack(sv[0], ss[0], None if sa is None else sa[0], None if sb is None else sb[0])
         return idx
+
+
+class MultiSpikeResetNet(SpikeResetNet):
+    """Several spiking populations in ONE node, each with its own spike / reset variable pair (reference
+    ``MultiSpikeResetNet``, rectipy/nodes.py:404-465, which PyRates builds from a multi-population circuit).
+
+    Here the populations share one compiled template; they differ in their per-neuron parameters and are coupled
+    through the blocks of one ``N x N`` matrix (N = sum of the population sizes), so the whole node is still ONE fused
+    step kernel launch per Euler step.  ``populations`` maps population labels to sizes; ``spike_var[i]`` /
+    ``reset_var[i]`` name population i's pair as ``"<label>/<op>/<var>"``; ``node_vars`` keys are
+    ``"all/<op>/<var>"`` (scalar or length N) or ``"<label>/<op>/<var>"`` (scalar or length n_label).
+
+    What the reference's class does differently from ``SpikeResetNet`` is kept:
+      * ``forward`` returns the POST-update output slice and ``y`` is the current state (nodes.py:457-465);
+      * spikes are detected on a private copy of every reset variable (``_y_reset``) that starts at ZERO, is refreshed
+        after every step and is NOT touched by ``reset()`` (nodes.py:428-431, 451-462) -- the first step therefore never
+        spikes, and the first step after a ``reset`` detects on the values from before it (``rp_run.spike_src``);
+      * the reset is a masked assignment (same values as the blend of SpikeResetNet).
+    The exposed state vector is population-major: [vars of population 0 in template order, vars of population 1, ...].
+    Networks evaluate such a node step by step (its output timing differs from the fused windows' pre-update rule).
+    """
+
+    state_vars = ["_y_reset"]
+    _fusable = False  # Network: no fused window (post-update output timing)
+
+    def __init__(self, template: Template, weights, node_vars, input_var, output_var, spike_var: list, reset_var: list,
+                 populations: dict, **kwargs):
+        if not isinstance(populations, dict) or not populations:
+            raise ValueError("`populations` must map population labels to sizes, e.g. {'exc': 800, 'inh': 200}")
+        if not template.spike_var:
+            raise ValueError(f"template '{template.name}' is not a spiking model")
+        labels = list(populations)
+        sizes = [int(populations[q]) for q in labels]
+        N = sum(sizes)
+        offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(int)
+        if len(spike_var) != len(labels) or len(reset_var) != len(labels):
+            raise ValueError("one spike variable and one reset variable per population are required")
+        for i, lab in enumerate(labels):
+            if spike_var[i] not in (f"{lab}/{template.spike_var}", template.spike_var):
+                raise KeyError(f"Variable {spike_var[i]} was not found on population '{lab}' as a spike input.")
+            if reset_var[i] not in (f"{lab}/{template.reset_var}", template.reset_var):
+                raise NotImplementedError(f"reset_var='{reset_var[i]}': the kernel resets '{template.reset_var}'")
+
+        def split(name):  # "[label/]op/var" -> (label or None, "op/var")
+            parts = name.split("/")
+            if len(parts) == 3 and parts[0] in labels:
+                return parts[0], "/".join(parts[1:])
+            return None, "/".join(parts[-2:])
+
+        # per-neuron vectors of the whole node from population-wise values
+        full = {}
+        known = dict(template.params)
+        known.update(dict(template.state))
+        for key, val in (node_vars or {}).items():
+            parts = key.split("/")
+            scope, name = (parts[0], "/".join(parts[1:])) if len(parts) == 3 else ("all", key)
+            if name not in known:
+                raise KeyError(f"Variable {name} was not found on template '{template.name}'.")
+            vec = full.setdefault(name, np.full(N, known[name], dtype=np.float32))
+            arr = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val, dtype=np.float32)
+            if scope == "all":
+                vec[:] = arr
+            elif scope in labels:
+                p = labels.index(scope)
+                vec[offsets[p]:offsets[p + 1]] = arr
+            else:
+                raise KeyError(f"node_vars key '{key}': unknown population '{scope}' (populations: {labels})")
+        in_label, in_name = split(input_var)
+        out_label, out_name = split(output_var)
+        super().__init__(template, weights, {f"all/{k}": v for k, v in full.items()}, in_name, out_name, **kwargs)
+        if self._pop.rows != N:
+            raise RuntimeError(f"weights are {self._pop.rows} x {self._pop.n}, the populations hold {N} neurons")
+        if self._pop.model in ("iku", "ik_biexp"):
+            raise NotImplementedError("population-mean templates cannot be split into several spike/reset pairs")
+        self._labels, self._sizes, self._offsets = labels, sizes, offsets
+        dev = self._pop.device
+        state_names = [q for q, _ in template.state]
+        # exposed layout: population-major; internal layout (engine, autograd): variable-major over all N neurons
+        perm, var_map, pos = [], {}, 0
+        for p, lab in enumerate(labels):
+            for j, name in enumerate(state_names):
+                perm.append(torch.arange(j * N + offsets[p], j * N + offsets[p + 1]))
+                var_map[f"{lab}/{name}"] = (pos, pos + sizes[p])
+                pos += sizes[p]
+        self._perm = torch.cat(perm).to(dev)
+        self._inv_perm = torch.empty_like(self._perm)
+        self._inv_perm[self._perm] = torch.arange(self._perm.numel(), device=dev)
+        for i, lab in enumerate(labels):
+            var_map[f"spike_reset_{i}"] = var_map[f"{lab}/{template.reset_var}"]
+            self._param_map[f"spike_var_{i}"] = "spike"
+        self._param_map.pop("spike_var", None)
+        # output: one population's variable (a slice, as the reference) or the variable of every neuron
+        if out_label is not None:
+            self._out_index = torch.arange(*var_map[f"{out_label}/{out_name}"], device=dev)
+            var_map["out"] = var_map[f"{out_label}/{out_name}"]
+        else:
+            self._out_index = torch.cat([torch.arange(*var_map[f"{lab}/{out_name}"]) for lab in labels]).to(dev)
+        self.n_out = int(self._out_index.numel())
+        # input: into one population (zeros elsewhere) or into every neuron
+        self._in_slice = None
+        if in_label is not None:
+            p = labels.index(in_label)
+            self._in_slice = (int(offsets[p]), int(offsets[p + 1]))
+            self.n_in = sizes[p]
+        self._internal_var_map = {name: (j * N, (j + 1) * N) for j, name in enumerate(state_names)}  # autograd layout
+        self._var_map = var_map
+        self._detector = torch.zeros(N, dtype=torch.float32, device=dev)  # the reference's _y_reset copies
+
+    def __getitem__(self, item):
+        if item == "out":
+            return self.y[self._out_index]
+        return super().__getitem__(item)
+
+    @classmethod
+    def from_pyrates(cls, node, input_var: str, output_var: str, weights: np.ndarray = None, source_var: str = None,
+                     target_var: str = None, spike_var: list = None, reset_var: list = None, train_params: list = None,
+                     **kwargs):
+        kwargs["spike_var"], kwargs["reset_var"] = spike_var, reset_var
+        if "populations" not in kwargs:
+            raise ValueError("several spike/reset pairs need `populations={label: size, ...}` (PyRates circuits are "
+                             "not parsed; the populations share the node template)")
+        strip = lambda v: None if v is None else "/".join(v.split("/")[-2:])
+        return RateNet.from_pyrates.__func__(cls, node, input_var, output_var, weights=weights, source_var=strip(source_var),
+                                             target_var=strip(target_var), train_params=train_params, **kwargs)
+
+    # ---- state ------------------------------------------------------------------------------------------------
+    def _internal_state(self) -> torch.Tensor:
+        return self.current_state if self._y_grad is None else self._y_grad
+
+    @property
+    def y(self) -> torch.Tensor:
+        """Current state (post-update), population-major."""
+        return self._internal_state()[self._perm]
+
+    def set_state(self, var: str, val):
+        lo, hi = self._var_map[var]
+        cur = self.y.detach().clone()
+        cur[lo:hi] = torch.as_tensor(val, dtype=torch.float32).to(cur.device)
+        self.reset(cur)
+
+    def reset(self, y=None, idx=None):
+        total = self._perm.numel()
+        dev = self._pop.device
+        with torch.no_grad():
+            if y is None:
+                new = torch.zeros(total, dtype=torch.float32, device=dev)
+            else:
+                new = torch.as_tensor(y).detach().to(dtype=torch.float32, device=dev).reshape(-1).clone()
+            if idx is not None:
+                cur = self.y.detach().clone()
+                cur[torch.as_tensor(np.asarray(idx), dtype=torch.long, device=dev)] = new
+                new = cur
+            if new.numel() != total:
+                raise RuntimeError(f"state has {total} entries, got {new.numel()}")
+            internal = torch.empty_like(new)
+            internal[self._perm] = new  # exposed = internal[perm]
+            pop, N = self._pop, self._pop.rows
+            for j, (name, _) in enumerate(self._template.state):
+                chunk = internal[j * N:(j + 1) * N]
+                if name == self._template.reset_var:
+                    pop.v.copy_(chunk)
+                elif name == self._template.source_var:
+                    pop.set_source_local(chunk)
+                elif name == self._aux_name:
+                    pop.aux.copy_(chunk)
+                else:
+                    pop.aux2.copy_(chunk)
+        self._y_prev = None
+        self._y_grad = None
+        self._pop.reset_sampling()  # the spike detector keeps its old values (the reference has no reset override)
+
+    # ---- integration ------------------------------------------------------------------------------------------
+    def _embed(self, x2: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        if x2 is None or self._in_slice is None:
+            return x2
+        lo, hi = self._in_slice
+        if x2.shape[1] not in (1, hi - lo):
+            raise RuntimeError(f"The size of the input ({x2.shape[1]}) must match the population ({hi - lo}) or be 1")
+        full = torch.zeros(x2.shape[0], self._pop.rows, dtype=torch.float32, device=x2.device)
+        full[:, lo:hi] = x2
+        return full
+
+    def _as_input(self, x, steps=None):
+        if self._in_slice is None:
+            return super()._as_input(x, steps)
+        rows = self._pop.rows
+        try:  # validate against the population's width, then embed
+            self._pop.rows = self._in_slice[1] - self._in_slice[0]
+            x2 = super()._as_input(x, steps)
+        finally:
+            self._pop.rows = rows
+        return self._embed(x2)
+
+    def forward(self, x) -> torch.Tensor:
+        """One step; returns the POST-update output slice (reference nodes.py:449-465)."""
+        x2 = self._as_input(x)
+        pop = self._pop
+        if self._wants_grad(x2):
+            if not torch.equal(self._detector >= pop.theta, pop.v >= pop.theta):
+                raise NotImplementedError("BPTT through a step whose spike detector differs from the state (the first "
+                                          "step after construction / reset with neurons above threshold)")
+            self._grad_window(1, x2)
+        else:
+            self._y_grad = None
+            pop.forward(1, x=x2, out_var=self._out_code, x_target=self._x_target, spike_events=self.spike_events,
+                        spike_count=self._spike_count, spike_src=self._detector)
+        self._detector = pop.v.detach().clone()
+        return self.y[self._out_index]
+
+    def run_window(self, steps: int, x=None, w_in=None, traj=None, step0: int = 0, **kw):
+        """`steps` steps in one library call; ``traj`` receives the POST-update output of every step."""
+        if w_in is not None or any(kw.get(q) is not None for q in ("samples", "rec")):
+            raise NotImplementedError("MultiSpikeResetNet windows deliver `traj` only (post-update output timing)")
+        self._y_grad = None
+        pop = self._pop
+        x2 = self._embed(x)
+        mk = lambda: torch.empty(steps, pop.rows, dtype=torch.float32, device=pop.device)
+        saves = dict(save_v=mk(), save_src=mk(), save_aux=mk() if self._aux_name else None)
+        pop.forward(steps, x=x2, out_var=self._out_code, step0=step0, x_target=self._x_target,
+                    spike_events=self.spike_events, spike_count=self._spike_count, spike_src=self._detector, **saves)
+        self._detector = pop.v.detach().clone()
+        if traj is not None:
+            # post-update state of step t = pre-update state of step t+1; the last row is the current state
+            pre = self._pack_rows(saves["save_v"], saves["save_src"], saves["save_aux"])  # [steps, total] internal layout
+            post = torch.cat((pre[1:], self.current_state.reshape(1, -1)))
+            traj.copy_(post[:, self._perm][:, self._out_index])
+        return 0
+
+    def _pack_rows(self, v, s, aux):
+        parts = {self._template.reset_var: v, self._template.source_var: s}
+        if self._aux_name:
+            parts[self._aux_name] = aux
+        return torch.cat([parts[name] for name, _ in self._template.state], dim=1)

@@ -55,7 +55,7 @@ class SpikeWindow(torch.autograd.Function):
         def piece(name):
             if g_yend is None or name is None:
                 return torch.zeros(N, **f32)
-            lo, hi = node._var_map[name]
+            lo, hi = getattr(node, "_internal_var_map", node._var_map)[name]  # layout of y_end (template order)
             return g_yend.detach().to(**f32)[lo:hi].clone().contiguous()
 
         lam_v, lam_s = piece(tpl.reset_var), piece(tpl.source_var)
