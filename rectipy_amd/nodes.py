@@ -134,9 +134,22 @@ class RateNet:
     _spiking = False
 
     # ---- construction ----------------------------------------------------------------
-    def __init__(self, template: Template, weights, node_vars: dict, input_var: str, output_var: str,
+    def __init__(self, template: Template, weights, node_vars: dict, input_var: str, output_var: str = None,
                  dt: float = 1e-3, dtype: torch.dtype = torch.float64, train_params: list = None,
                  device: str = "cuda:0", backend=None, **kwargs):
+        """Two calling conventions:
+
+        * ``RateNet(template, weights, node_vars, input_var, output_var, ...)`` -- what ``from_pyrates`` /
+          ``Network.add_diffeq_node`` use (``template``: a :class:`rectipy_amd.templates.Template`);
+        * the reference's own constructor ``RateNet(rnn_func, rnn_args, var_map, param_map, dt=, dtype=, train_params=,
+          device=)`` (rectipy/nodes.py:58-90; rectipy_tests/test_nodes.py:40-79): ``rnn_func`` is recognised as one of
+          the compiled vector fields (:mod:`rectipy_amd.field_match`) or names one (template path / ``"li_tanh"``);
+          ``rnn_args[0]`` is the initial state, ``param_map["in"]`` the input slot, ``var_map["out"]`` the output slice.
+        """
+        ref_style = None
+        if not isinstance(template, Template):
+            ref_style = self._from_reference_args(template, weights, node_vars, input_var, train_params)
+            template, weights, node_vars, input_var, output_var, train_params = ref_style[:6]
         _warn_f64(dtype)
         self._template = template
         self.dt = dt
@@ -227,7 +240,67 @@ class RateNet:
         self._y_grad: Optional[torch.Tensor] = None  # autograd handle of the state (same values as pop.v)
         self._v_exposed = False  # pop.v was handed out through `y`: the next step continues on a copy
         self._y_requires_grad = len(self._train_names) >= 1  # nodes.py:89-90
+        self._out_slice = None
+        if ref_style is not None:
+            self._apply_reference_maps(*ref_style[6:])
         self._maybe_pack_weights()
+
+    # ---- the reference's constructor convention (seam 2) ----------------------------------------------------------
+    @staticmethod
+    def _from_reference_args(rnn_func, rnn_args, var_map, param_map, train_params):
+        """(template, weights, node_vars, input_var, output_var, train_params, var_map, roles, n_in) for
+        ``RateNet(rnn_func, rnn_args, var_map, param_map, ...)``."""
+        from . import field_match
+        if not isinstance(rnn_args, (tuple, list)) or not isinstance(var_map, dict) or not isinstance(param_map, dict):
+            raise TypeError("expected RateNet(rnn_func, rnn_args: tuple, var_map: dict, param_map: dict, ...)")
+        tpl = resolve("neuron_model_templates.rate_neurons.leaky_integrator.tanh")
+        y0 = rnn_args[0]
+        n = int(y0.shape[0])
+        if callable(rnn_func):
+            W, vals, roles = field_match.recognise_rate_field(rnn_func, tuple(rnn_args), param_map)
+        else:
+            named = resolve(rnn_func) if isinstance(rnn_func, str) and "." in rnn_func else None
+            if (named is not None and named.model != "li_tanh") or (named is None and rnn_func != "li_tanh"):
+                raise NotImplementedError("the reference-style constructor covers the tanh leaky-integrator field; use "
+                                          "from_pyrates for the other templates")
+            args = list(rnn_args[1:])
+            W = args[param_map["weights"]]
+            roles, vals = {}, {q: d for (_, d), q in zip(tpl.params, ("tau", "k", "eta"))}
+            for name, idx in param_map.items():
+                short = name.split("/")[-1]
+                if short in ("tau", "k", "eta"):
+                    roles[name], vals[short] = short, args[idx]
+        node_vars = {f"all/li_op/{q}": (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v)
+                     for q, v in vals.items()}
+        node_vars["all/li_op/v"] = y0.detach().cpu().numpy() if isinstance(y0, torch.Tensor) else np.asarray(y0)
+        train = []
+        for p in (train_params or []):
+            if p == "weights":
+                train.append("weights")
+            elif p in roles:
+                train.append(f"li_op/{roles[p]}")
+            else:
+                raise KeyError(f"Parameter {p} was not found on the node.")
+        in_arg = rnn_args[1 + int(param_map["in"])]
+        n_in = int(in_arg.shape[0]) if hasattr(in_arg, "shape") and len(in_arg.shape) else 1
+        weights = W.detach().cpu().numpy() if isinstance(W, torch.Tensor) else np.asarray(W)
+        return tpl, weights, node_vars, tpl.input_var, "li_op/v", train, dict(var_map), roles, n_in
+
+    def _apply_reference_maps(self, var_map: dict, roles: dict, n_in: int):
+        """Names and slices as the caller's ``var_map`` / ``param_map`` define them (nodes.py:64-69, 92-99)."""
+        N = self._pop.rows
+        self._param_map = {"weights": "weights", **roles}
+        self._var_map = {k: (int(v[0]), int(v[-1])) if isinstance(v, (tuple, list)) else (int(v), int(v) + 1)
+                         for k, v in var_map.items()}
+        if "out" not in self._var_map:
+            raise KeyError("var_map needs the output slice ('out')")
+        lo, hi = self._var_map["out"]
+        if not (0 <= lo < hi <= N):
+            raise RuntimeError(f"output slice {(lo, hi)} outside the state vector of length {N}")
+        self.n_out, self.n_in = hi - lo, n_in
+        if (lo, hi) != (0, N):
+            self._out_slice = (lo, hi)
+            self._fusable = False  # Network: step by step (the fused windows emit all N outputs)
 
     def _maybe_pack_weights(self):
         """A coupling matrix that is not trained and mostly zeros (`utility.random_connectivity`, p = 0.1 in the
@@ -460,12 +533,14 @@ class RateNet:
         """One Euler step; returns the PRE-update output slice (reference nodes.py:166-170)."""
         x2 = self._as_input(x)
         if self._wants_grad(x2):
-            return self._grad_window(1, x2)[0]
-        self._before_step()
-        out = torch.empty(1, self._pop.rows, dtype=torch.float32, device=self._pop.device)
-        self._pop.forward(1, x=x2, traj=out, out_var=self._out_code)
-        self._y_grad = None
-        return out[0]
+            out = self._grad_window(1, x2)[0]
+        else:
+            self._before_step()
+            out = torch.empty(1, self._pop.rows, dtype=torch.float32, device=self._pop.device)
+            self._pop.forward(1, x=x2, traj=out, out_var=self._out_code)
+            self._y_grad = None
+            out = out[0]
+        return out if self._out_slice is None else out[self._out_slice[0]:self._out_slice[1]]
 
     def run_window(self, steps: int, x: Optional[torch.Tensor] = None, w_in: Optional[torch.Tensor] = None,
                    **kw):

@@ -329,3 +329,57 @@ def test_recorded_state_rows_do_not_alias(where):
     for t in range(4):  # state after step t == output (pre-update state) of step t+1
         assert torch.equal(kept_v[t], outs[t + 1])
         assert torch.allclose(kept_r[t], torch.tanh(outs[t + 1]), atol=1e-6)
+
+
+def _rate(t, y, I_ext, weights, tau):  # the hand-written field of rectipy_tests/test_nodes.py:32-33
+    return -y / tau + I_ext + weights @ torch.tanh(y)
+
+
+def test_reference_style_constructor_recognises_the_field(where):
+    """Seam 2 (reference nodes.py:58-90): RateNet(rnn_func, rnn_args, var_map, param_map) as rectipy_tests/test_nodes.py
+    test_2_1 / test_2_3 / test_2_4 use it -- the callable is recognised as the compiled tanh field, a foreign one refused."""
+    n = 10
+    rng = np.random.default_rng(11)
+    W = rng.standard_normal((n, n))
+    args = (torch.zeros(n), torch.zeros(n), torch.tensor(W), 1.0)
+    rnn1 = RateNet(_rate, args, {"out": [0, n]}, {"in": 0}, dt=1e-3, dtype=torch.float32, **where)
+    rnn2 = RateNet.from_pyrates(TANH, weights=W, source_var=SRC, target_var=TGT, input_var=IN, output_var="li_op/v",
+                                node_vars={"all/li_op/tau": 1.0}, dt=1e-3, dtype=torch.float32, **where)
+    rnn5 = RateNet(_rate, args, {"out": [0, 3]}, {"in": 0}, dtype=torch.float32, **where)
+    assert isinstance(rnn1, RateNet) and rnn1.n_out == n and rnn1.n_in == n and rnn5.n_out == 3
+    inp = torch.tensor(rng.standard_normal(n), dtype=torch.float32)
+    for _ in range(10):
+        o1, o2 = rnn1.forward(inp), rnn2.forward(inp)
+        assert torch.equal(o1, o2)
+    assert rnn5.forward(inp).shape[0] == 3
+    # the reference's float64 loop on the same callable
+    y = torch.zeros(n, dtype=torch.float64)
+    for _ in range(10):
+        y = y + 1e-3 * _rate(0, y, inp.double(), torch.tensor(W), 1.0)
+    assert float((rnn1.y.double() - y).abs().max()) < 1e-5
+    # named parameters: roles are found by perturbation, whatever the names are
+    def field(t, y, I_ext, weights, a, b, c):
+        return -y / a + c * (weights @ torch.tanh(y)) + I_ext + b
+    tau, eta, k = torch.full((n,), 4.0), torch.tensor(rng.standard_normal(n)), torch.tensor(rng.uniform(0.5, 1.5, n))
+    node = RateNet(field, (torch.zeros(n), torch.zeros(n), torch.tensor(W), tau, eta, k), {"out": (0, n), "v": (0, n)},
+                   {"in": 0, "weights": 1, "leak": 2, "drive": 3, "gain": 4}, train_params=["weights", "gain"],
+                   dtype=torch.float32, **where)
+    assert node._param_map == {"weights": "weights", "leak": "tau", "drive": "eta", "gain": "k"}
+    assert torch.allclose(node["drive"].cpu(), eta.float()) and node["gain"].requires_grad and node.y.requires_grad
+    assert len(list(node.parameters())) == 2 and node["v"].shape[0] == n
+    with pytest.raises(KeyError):
+        _ = node["li_op/u"]
+    # reset round trip (test_2_4)
+    r1 = rnn1.forward(inp)
+    rnn1.reset(np.zeros(n))
+    assert torch.equal(rnn1.forward(inp), torch.zeros(n))
+    with pytest.raises(RuntimeError):
+        rnn1.reset(np.zeros(n + 1))
+    # not a member of the compiled family -> refused, no interpreter fallback
+    with pytest.raises(NotImplementedError):
+        RateNet(lambda t, y, I, w, tau: -y ** 3 / tau + I + w @ torch.tanh(y), args, {"out": [0, n]}, {"in": 0}, **where)
+    with pytest.raises(NotImplementedError):
+        RateNet(_rate, args, {"out": [0, n]}, {"in": 2}, **where)  # the input slot is not an additive input
+    named = RateNet("li_tanh", (torch.zeros(n), torch.zeros(n), torch.tensor(W), 2.0), {"out": [0, n]},
+                    {"in": 0, "weights": 1, "li_op/tau": 2}, dtype=torch.float32, **where)
+    assert float(named["li_op/tau"][0]) == 2.0
