@@ -48,6 +48,7 @@ extern "C" {
 #endif
 
 #define RP_ABI_VERSION 7
+#define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0
 #define RP_ERR_ARG (-1)      /* null pointer, bad enum, bad flag combination  */
@@ -154,6 +155,10 @@ typedef struct rp_net {
     const int32_t* sp_phase_window; /* [windows * sp_phases] window staged in phase ph of class c, -1 = none           */
     int32_t sp_phases;
     int32_t sp_batches;
+    /* Blocked form for n <= 32768 (sparse.py: pack_rows_blocked), selected by sp_block_rows > 0: sp_block_rows
+       consecutive rows share one padded stream (sp_rowoff = [blocks + 1]); bit 13 of a code (RP_SPARSE_END) closes the
+       lane's segment of a row, chunk indices take 13 bits. */
+    int32_t sp_block_rows;
 } rp_net;
 
 /*
@@ -257,6 +262,7 @@ typedef struct rp_bwd {
     const int32_t* spt_phase_window;
     int32_t spt_phases;
     int32_t spt_batches;
+    int32_t spt_block_rows;   /* > 0: blocked form of the packed W^T (as rp_net.sp_block_rows) */
 } rp_bwd;
 
 #define RP_BWD_TRANSPOSE_MAX_N 4096
@@ -361,6 +367,7 @@ int rp_set_tuning(int rows_per_wave, int unroll, int nontemporal, int max_blocks
 /* Benchmark-only: rows per wave and groups in flight per row of the sparse step kernel (tanh model); 0, 0 restores the
    built-in choice.  Results are bit-identical for every configuration. */
 int rp_set_sparse_tuning(int rows_per_wave, int groups_in_flight);
+int rp_set_blocked_tuning(int waves_per_workgroup, int groups_in_flight); /* blocked sparse step; 0 = built-in */
 
 /* Benchmark-only: rows in flight per wave (unroll) and 1-KiB column groups per lane of the adjoint's column-strip
    kernel; 0, 0 restores the built-in choice.  Results are bit-identical for every configuration. */

@@ -67,6 +67,7 @@ class RpNet(C.Structure):
         ("sp_phase_window", fp),
         ("sp_phases", C.c_int32),
         ("sp_batches", C.c_int32),
+        ("sp_block_rows", C.c_int32),
     ]
 
 
@@ -147,6 +148,7 @@ class RpBwd(C.Structure):
         ("spt_phase_window", fp),
         ("spt_phases", C.c_int32),
         ("spt_batches", C.c_int32),
+        ("spt_block_rows", C.c_int32),
     ]
 
 
@@ -214,6 +216,7 @@ def declare(lib):
     sig("rp_stream_probe", C.c_int, [fp, C.c_int64, fp, C.c_void_p])
     sig("rp_set_tuning", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int])
     sig("rp_set_sparse_tuning", C.c_int, [C.c_int, C.c_int])
+    sig("rp_set_blocked_tuning", C.c_int, [C.c_int, C.c_int])
     sig("rp_set_bwd_tuning", C.c_int, [C.c_int, C.c_int])
     sig("rp_set_bwd_chunks", C.c_int, [C.c_int])
     sig("rp_set_rls_tuning", C.c_int, [C.c_int, C.c_int, C.c_int])
@@ -225,5 +228,5 @@ EXPORTS = [
     "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum", "rp_outer_accum_rect",
     "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial", "rp_bwd_apply",
     "rp_sizeof_comm", "rp_forward_sharded", "rp_backward_sharded",
-    "rp_rls_sweep", "rp_stream_probe", "rp_set_tuning", "rp_set_sparse_tuning", "rp_set_bwd_tuning", "rp_set_bwd_chunks", "rp_set_rls_tuning",
+    "rp_rls_sweep", "rp_stream_probe", "rp_set_tuning", "rp_set_sparse_tuning", "rp_set_blocked_tuning", "rp_set_bwd_tuning", "rp_set_bwd_chunks", "rp_set_rls_tuning",
 ]

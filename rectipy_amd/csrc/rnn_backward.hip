@@ -93,7 +93,7 @@ struct BwdParams {
     const int32_t* spt_row_ids;
     const int32_t* spt_batch_class;
     const int32_t* spt_phase_window;
-    int spt_phases, spt_batches;
+    int spt_phases, spt_batches, spt_block_rows;
 };
 
 // partials[q][j] = sum_{i in chunk q, ascending} W[i][j] * u[i]
@@ -582,10 +582,45 @@ __global__ __launch_bounds__(kSparseThreads) void adj_sparse_windowed_kernel(con
     });
 }
 
+// blocked form of the packed W^T (n <= 32768): rp_sparse_blocked_rows with the adjoint update as the epilogue
+template <bool SPIKING, int WAVES, int U>
+__global__ __launch_bounds__(WAVES * RP_WAVE) void adj_sparse_blocked_kernel(const BwdParams P, const SpkGrad G) {
+    extern __shared__ float lds_u[];
+    const int n_pad = (P.n + 255) & ~255;
+    rp_sparse_stage_source<WAVES * RP_WAVE>(lds_u, P.u, P.n, n_pad);
+    rp_sparse_blocked_rows<WAVES, U>(P.spt_vals, P.spt_cidx, P.spt_rowoff, P.n, P.spt_block_rows, lds_u, lds_u + n_pad,
+                                     [&](int j, float z) {
+                                         if constexpr (SPIKING)
+                                             spk_finalize_elem(P, G, j, z);
+                                         else
+                                             finalize_elem(P, j, z);
+                                     });
+}
+
+template <bool SPIKING, int WAVES, int U>
+int launch_adj_sparse_blocked_cfg(const BwdParams& P, const SpkGrad& G, hipStream_t st, int n_cu, size_t lds) {
+    if (rp_allow_dynamic_lds<&adj_sparse_blocked_kernel<SPIKING, WAVES, U>>(rp_lds_limit()) != RP_OK) return RP_ERR_HIP;
+    const int nblocks = (P.n + P.spt_block_rows - 1) / P.spt_block_rows;
+    int blocks = (nblocks + WAVES - 1) / WAVES;
+    if (blocks > n_cu) blocks = n_cu;
+    hipLaunchKernelGGL((adj_sparse_blocked_kernel<SPIKING, WAVES, U>), dim3(blocks), dim3(WAVES * RP_WAVE), lds, st, P, G);
+    return RP_OK;
+}
+
 template <bool SPIKING>
 int launch_adj_sparse(const BwdParams& P, const SpkGrad& G, hipStream_t st) {
     const int n_cu = rp_cu_count();
     if (n_cu == 0) return RP_ERR_HIP;
+    if (P.spt_block_rows > 0) {
+        const size_t src_bytes = sizeof(float) * (size_t)((P.n + 255) & ~255);
+        const size_t per_wave = sizeof(float) * RP_WAVE * (size_t)P.spt_block_rows;
+        const size_t limit = rp_lds_limit();
+        if (src_bytes + 16 * per_wave <= limit)
+            return launch_adj_sparse_blocked_cfg<SPIKING, 16, 4>(P, G, st, n_cu, src_bytes + 16 * per_wave);
+        if (src_bytes + 8 * per_wave <= limit)
+            return launch_adj_sparse_blocked_cfg<SPIKING, 8, 8>(P, G, st, n_cu, src_bytes + 8 * per_wave);
+        return RP_ERR_HIP;
+    }
     if (P.spt_row_ids) {
         if (rp_allow_dynamic_lds<&adj_sparse_windowed_kernel<SPIKING, 2>>(sizeof(float) * kWindowChunks * 256) != RP_OK)
             return RP_ERR_HIP;
@@ -630,6 +665,9 @@ int sparse_t_mode(const rp_net* net, const rp_bwd* b, BwdParams& P, bool& use) {
     P.spt_phase_window = b->spt_phase_window;
     P.spt_phases = b->spt_phases;
     P.spt_batches = b->spt_batches;
+    P.spt_block_rows = b->spt_block_rows;
+    if (b->spt_block_rows < 0 || b->spt_block_rows > 64 || (b->spt_block_rows > 0 && (b->spt_row_ids || net->n > kSparseLdsMaxN)))
+        RP_FAIL(RP_ERR_ARG, "spt_block_rows must be in [0, 64], without the windowed form and with n <= %d", kSparseLdsMaxN);
     return RP_OK;
 }
 

@@ -66,7 +66,7 @@ struct StepParams {
     const int32_t* sp_row_ids;
     const int32_t* sp_batch_class;
     const int32_t* sp_phase_window;
-    int sp_phases, sp_batches;
+    int sp_phases, sp_batches, sp_block_rows;
 };
 
 // ---- row dot products (rp_dot.h) ---------------------------------------------
@@ -322,6 +322,52 @@ __global__ __launch_bounds__(kSparseThreads) void step_sparse_windowed_kernel(co
     rp_sparse_windowed_rows<U>(S, P.src_cur, P.n, lds_src, [&](int row, float sum) { epilogue<MODEL>(P, row, sum); });
 }
 
+// Blocked form (n <= 32768): rp_sparse_blocked_rows (rp_dot.h) with the step epilogue.  Dynamic LDS = the rotated
+// source vector + WAVES x sp_block_rows x 64 parked lane sums.
+template <int MODEL, int WAVES, int U>
+__global__ __launch_bounds__(WAVES * RP_WAVE) void step_sparse_blocked_kernel(const StepParams P) {
+    extern __shared__ float lds_src[];
+    const int n_pad = (P.n + 255) & ~255;
+    rp_sparse_stage_source<WAVES * RP_WAVE>(lds_src, P.src_cur, P.n, n_pad);
+    rp_sparse_blocked_rows<WAVES, U>(P.sp_vals, P.sp_cidx, P.sp_rowoff, P.rows, P.sp_block_rows, lds_src, lds_src + n_pad,
+                                     [&](int row, float sum) { epilogue<MODEL>(P, row, sum); });
+}
+
+// benchmark-only: waves per workgroup / groups in flight of the blocked sparse step (0 = built-in)
+int g_blocked_waves = 0, g_blocked_U = 0;
+
+template <int MODEL, int WAVES, int U>
+int launch_step_sparse_blocked_cfg(const StepParams& P, hipStream_t st, int n_cu, size_t lds) {
+    if (rp_allow_dynamic_lds<&step_sparse_blocked_kernel<MODEL, WAVES, U>>(rp_lds_limit()) != RP_OK) return RP_ERR_HIP;
+    const int nblocks = (P.rows + P.sp_block_rows - 1) / P.sp_block_rows;
+    int blocks = (nblocks + WAVES - 1) / WAVES;
+    if (blocks > n_cu) blocks = n_cu;  // one resident workgroup per CU owns the LDS copy of the source vector
+    hipLaunchKernelGGL((step_sparse_blocked_kernel<MODEL, WAVES, U>), dim3(blocks), dim3(WAVES * RP_WAVE), lds, st, P);
+    return RP_OK;
+}
+
+template <int MODEL>
+int launch_step_sparse_blocked(const StepParams& P, hipStream_t st, int n_cu) {
+    const size_t src_bytes = sizeof(float) * (size_t)((P.n + 255) & ~255);
+    const size_t per_wave = sizeof(float) * RP_WAVE * (size_t)P.sp_block_rows;
+    const size_t limit = rp_lds_limit();
+    // 16 waves per workgroup when source + parked sums fit the LDS, else 8 (n = 32768 with 16-row blocks: 128 + 32 KiB)
+    int waves = src_bytes + 16 * per_wave <= limit ? 16 : 8;
+    if (g_blocked_waves == 8 || g_blocked_waves == 16) waves = g_blocked_waves;
+    const size_t lds = src_bytes + waves * per_wave;
+    if (lds > limit) return RP_ERR_SHAPE;
+    if constexpr (MODEL == RP_MODEL_LI_TANH) {  // benchmark-only sweep (rp_set_blocked_tuning)
+        if (g_blocked_U == 4) return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 4>(P, st, n_cu, lds)
+                                                 : launch_step_sparse_blocked_cfg<MODEL, 8, 4>(P, st, n_cu, lds);
+        if (g_blocked_U == 8) return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 8>(P, st, n_cu, lds)
+                                                 : launch_step_sparse_blocked_cfg<MODEL, 8, 8>(P, st, n_cu, lds);
+        if (g_blocked_U == 2) return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 2>(P, st, n_cu, lds)
+                                                 : launch_step_sparse_blocked_cfg<MODEL, 8, 2>(P, st, n_cu, lds);
+    }
+    return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 4>(P, st, n_cu, lds)
+                       : launch_step_sparse_blocked_cfg<MODEL, 8, 8>(P, st, n_cu, lds);
+}
+
 // benchmark-only: rows per wave / groups in flight per row of the sparse step (0 = built-in)
 int g_sparse_R = 0, g_sparse_U = 0;
 
@@ -346,6 +392,7 @@ template <int MODEL>
 int launch_step_sparse(const StepParams& P, hipStream_t st) {
     const int n_cu = rp_cu_count();
     if (n_cu == 0) return RP_ERR_HIP;
+    if (P.sp_block_rows > 0) return launch_step_sparse_blocked<MODEL>(P, st, n_cu);
     if (P.sp_row_ids) {  // windowed form
         if (rp_allow_dynamic_lds<&step_sparse_windowed_kernel<MODEL, 2>>(sizeof(float) * kWindowChunks * 256) != RP_OK)
             return RP_ERR_HIP;
@@ -510,6 +557,7 @@ void fill_static(StepParams& P, const rp_net* net) {
     P.sp_row_ids = net->sp_row_ids;
     P.sp_batch_class = net->sp_batch_class;
     P.sp_phase_window = net->sp_phase_window;
+    P.sp_block_rows = net->sp_block_rows;
     P.sp_phases = net->sp_phases;
     P.sp_batches = net->sp_batches;
 }
@@ -686,6 +734,9 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
             RP_FAIL(RP_ERR_ARG, "sp_vals / src must be 16-byte and sp_cidx 8-byte aligned");
         if (net->sp_row_ids && (!net->sp_batch_class || !net->sp_phase_window || net->sp_phases < 3 || net->sp_batches < 0))
             RP_FAIL(RP_ERR_ARG, "windowed packed form needs sp_batch_class, sp_phase_window, sp_phases >= 3, sp_batches");
+        if (net->sp_block_rows < 0 || net->sp_block_rows > 64 ||
+            (net->sp_block_rows > 0 && (net->sp_row_ids || net->n > kSparseLdsMaxN)))
+            RP_FAIL(RP_ERR_ARG, "sp_block_rows must be in [0, 64], without the windowed form and with n <= %d", kSparseLdsMaxN);
     }
 
     // count the samples this call produces before touching anything
@@ -777,6 +828,12 @@ int rp_forward_sharded(rp_net* net, rp_run* run, const rp_comm* comm, void* stre
 }
 
 int rp_sizeof_comm(void) { return (int)sizeof(rp_comm); }
+
+int rp_set_blocked_tuning(int waves, int groups_in_flight) {
+    g_blocked_waves = waves;
+    g_blocked_U = groups_in_flight;
+    return RP_OK;
+}
 
 int rp_set_sparse_tuning(int rows_per_wave, int groups_in_flight) {
     g_sparse_R = rows_per_wave;

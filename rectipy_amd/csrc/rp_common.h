@@ -43,6 +43,19 @@ inline int rp_cu_count() {
     return cu[dev];
 }
 
+// LDS bytes one workgroup may allocate on the CURRENT device (0 on error); 160 KiB on gfx950
+inline size_t rp_lds_limit() {
+    static size_t lim[RP_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= RP_MAX_DEVICES) return 0;
+    if (lim[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return 0;
+        lim[dev] = (size_t)v;
+    }
+    return lim[dev];
+}
+
 // raise the dynamic-LDS limit of `Kernel` on the CURRENT device (once per kernel and device)
 template <auto Kernel>
 inline int rp_allow_dynamic_lds(size_t bytes) {

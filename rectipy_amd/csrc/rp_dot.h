@@ -122,9 +122,10 @@ constexpr int kSparseLdsMaxN = 32768;
 // different banks whatever their chunks m_l.
 // Columns in [n_valid, n_total) are filled with zeros: padding entries (value 0, code 0) gather from chunk 0 of the staged
 // range and must meet a finite number there.
+template <int THREADS = kSparseThreads>
 __device__ __forceinline__ void rp_sparse_stage_source(float* lds_src, const float* __restrict__ src, int n_valid,
                                                        int n_total) {
-    for (int c4 = threadIdx.x * 4; c4 < n_total; c4 += kSparseThreads * 4) {
+    for (int c4 = threadIdx.x * 4; c4 < n_total; c4 += THREADS * 4) {
         const rp_f4 v = c4 < n_valid ? rp_ld4(src + c4) : rp_f4{0.f, 0.f, 0.f, 0.f};
         const int base = c4 & ~63, h = (c4 >> 6) & 3, o = c4 & 63;
         lds_src[base | ((o + 0 + h) & 63)] = v.x;
@@ -149,6 +150,66 @@ __device__ __forceinline__ void sparse_entry(float v, unsigned code, const float
     a.y = c == 1 ? r : a1;
     a.z = c == 2 ? r : a2;
     a.w = c == 3 ? r : a3;
+}
+
+// ---- blocked form (n <= 32768; sparse.py: pack_rows_blocked) -----------------------------------------------------
+// RB consecutive rows share one padded stream: a lane's list is the concatenation of its lists of the block's rows, the
+// last entry of every row segment carries RP_SPARSE_END.  Lanes move from row to row at their own pace: at END a lane
+// parks the lane sum (a0+a1)+(a2+a3) of the finished row in its own LDS slot stash[row][lane] and clears its
+// accumulators; when the block's stream is exhausted every lane has parked RB sums and the rows' butterflies run.  Only
+// the block is padded to its longest lane list (1.08x the ideal bytes at RB = 16, p = 0.1, n = 32768; per-row: 1.35x).
+// A lane only ever reads back its own slots, so no barrier is needed.  `epi(row, sum)` is called by one lane per row.
+template <int WAVES, int U, typename Epi>
+__device__ __forceinline__ void rp_sparse_blocked_rows(const float* __restrict__ vals, const uint16_t* __restrict__ code,
+                                                       const int32_t* __restrict__ blkoff, int rows, int RB,
+                                                       const float* lds_src, float* lds_stash, Epi epi) {
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int lane_base = 64 * (lane >> 4);
+    const int lane_rot = 4 * (lane & 15) + (lane >> 4);
+    float* const stash = lds_stash + (size_t)wave * RB * RP_WAVE + lane;
+    typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+    const int nblocks = (rows + RB - 1) / RB;
+    for (int b = blockIdx.x * WAVES + wave; b < nblocks; b += gridDim.x * WAVES) {
+        const int g0 = blkoff[b], len = blkoff[b + 1] - g0;
+        const float* vp = vals + (int64_t)g0 * 256 + 4 * lane;
+        const uint16_t* ip = code + (int64_t)g0 * 256 + 4 * lane;
+        rp_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        float* st = stash;
+        auto entry = [&](float v, unsigned cd) {
+            sparse_entry<true>(v, cd & ~(unsigned)RP_SPARSE_END, lds_src, lane_base, lane_rot, acc);
+            if (cd & RP_SPARSE_END) {
+                *st = rp_lane_sum4(acc);
+                st += RP_WAVE;
+                acc = rp_f4{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        for (int k = 0; k < len; k += U) {
+            rp_f4 v[U];
+            us4 m[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + u < len) {
+                    v[u] = rp_ld4_stream(vp + (int64_t)(k + u) * 256);
+                    m[u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(ip + (int64_t)(k + u) * 256));
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + u < len) {
+                    entry(v[u].x, m[u].x);
+                    entry(v[u].y, m[u].y);
+                    entry(v[u].z, m[u].z);
+                    entry(v[u].w, m[u].w);
+                }
+        }
+        const int nr = min(RB, rows - b * RB);
+        float mine = 0.f;
+        for (int r = 0; r < nr; ++r) {
+            const float sum = rp_wave_allreduce(stash[r * RP_WAVE]);
+            if (lane == r) mine = sum;
+        }
+        if (lane < nr) epi(b * RB + lane, mine);
+    }
 }
 
 // ---- windowed form (n > 32768; sparse.py: pack_rows_windowed) ----------------------------------------------------

@@ -203,6 +203,8 @@ class Population:
         self.packed_t = None             # PackedRows of W^T (adjoint of a fixed sparse W), built on first use
         self.sparse_adjoint = True       # False: adjoint on the dense matrix even when a packed form exists
         self.windowed_sparse = True      # False: n > 32768 uses the plain packed form with the L2 gather
+        self.sparse_block_rows = 0       # rows per block of the blocked form (0: sparse.BLOCK_ROWS)
+        self.blocked_sparse = True       # False: n <= 32768 uses the per-row packed form (1.35x the bytes at p = 0.1)
         self._wt = None                  # workspace for W^T (adjoint of small networks), allocated on first use
         self.transposed_adjoint = True   # False: always use the column-strip kernels (tests, measurements)
         self.spiking = model in SPIKING
@@ -254,6 +256,7 @@ class Population:
         if self.packed is not None:
             net.sp_vals, net.sp_cidx = self.packed.vals.data_ptr(), self.packed.code.data_ptr()
             net.sp_rowoff = self.packed.rowoff.data_ptr()
+            net.sp_block_rows = self.packed.block_rows
             if self.packed.row_ids is not None:
                 net.sp_row_ids, net.sp_batch_class = self.packed.row_ids.data_ptr(), self.packed.batch_class.data_ptr()
                 net.sp_phase_window = self.packed.phase_window.data_ptr()
@@ -307,6 +310,8 @@ class Population:
             self.packed = None
         elif self.n > sparse.WINDOW_COLUMNS and self.windowed_sparse:
             self.packed = sparse.pack_rows_windowed(self.W, row0=self.row0)  # source vector staged window by window
+        elif self.n <= sparse.WINDOW_COLUMNS and self.blocked_sparse and self._block_rows() > 0:
+            self.packed = sparse.pack_rows_blocked(self.W, row0=self.row0, block_rows=self._block_rows())
         else:
             self.packed = sparse.pack_rows(self.W, row0=self.row0)
         self.packed_t = None
@@ -314,12 +319,30 @@ class Population:
         self._net_cache = None
         return self.packed
 
+    def _block_rows(self, rows: Optional[int] = None) -> int:
+        """Rows per block of the blocked packed form, 0 = per-row form.  A wave walks one block at a time, so the chip
+        needs >= 16 waves x CUs blocks to stay busy: 8-row blocks from 32768 rows, 4-row blocks from 16384 rows, the
+        per-row form below (measured, scripts/tune_blocked.py: N = 32768, p = 0.1: 122 us vs 144 us per row-form step;
+        N = 16384: 39.5 vs 42.1; N = 8192: 17.8 vs 15.2)."""
+        if self.sparse_block_rows:
+            return int(self.sparse_block_rows)
+        rows = self.rows if rows is None else rows
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
+        for rb in (8, 4):
+            if rows // rb >= 16 * cus:
+                return rb
+        return 0
+
     def _packed_transpose(self):
         if self.packed_t is None:
             from . import sparse
             Wt = self.W.T.contiguous()
-            self.packed_t = sparse.pack_rows_windowed(Wt) if self.n > sparse.WINDOW_COLUMNS and self.windowed_sparse \
-                else sparse.pack_rows(Wt)
+            if self.n > sparse.WINDOW_COLUMNS and self.windowed_sparse:
+                self.packed_t = sparse.pack_rows_windowed(Wt)
+            elif self.n <= sparse.WINDOW_COLUMNS and self.blocked_sparse and self._block_rows(self.n) > 0:
+                self.packed_t = sparse.pack_rows_blocked(Wt, block_rows=self._block_rows(self.n))
+            else:
+                self.packed_t = sparse.pack_rows(Wt)
         return self.packed_t
 
     def reset_sampling(self):
@@ -478,6 +501,7 @@ class Population:
             pt = self._packed_transpose()
             if pt is not None:
                 b.spt_vals, b.spt_cidx, b.spt_rowoff = pt.vals.data_ptr(), pt.code.data_ptr(), pt.rowoff.data_ptr()
+                b.spt_block_rows = pt.block_rows
                 if pt.row_ids is not None:
                     b.spt_row_ids, b.spt_batch_class = pt.row_ids.data_ptr(), pt.batch_class.data_ptr()
                     b.spt_phase_window, b.spt_phases, b.spt_batches = pt.phase_window.data_ptr(), pt.phases, pt.batches

@@ -53,6 +53,68 @@ def test_packed_rows_reproduce_the_dense_row_dot(oracle_backend, rows, n, row0, 
         assert np.float32(dense).view(np.uint32) == np.float32(got).view(np.uint32) or (dense == 0 and got == 0), i
 
 
+def emulate_block(packed, src, b, rows):
+    """What one wave of the blocked kernel computes for block b: lanes walk the block's stream at their own pace, park
+    the lane sum at every END entry; afterwards one butterfly per row."""
+    vals, code, off = packed.vals.numpy(), packed.code.numpy().view(np.uint16), packed.rowoff.numpy()
+    RB = packed.block_rows
+    nr = min(RB, rows - b * RB)
+    stash = np.zeros((RB + 1, 64), dtype=np.float32)
+    for l in range(64):
+        a, r = np.zeros(4, dtype=np.float32), 0
+        for k in range(off[b], off[b + 1]):
+            for e in range(4):
+                v, w = vals[k * 256 + 4 * l + e], int(code[k * 256 + 4 * l + e])
+                c, m = w >> 14, w & 0x1fff
+                a[c] = np.float32(np.float64(v) * np.float64(src[256 * m + 4 * l + c]) + np.float64(a[c]))
+                if w & sparse.END_FLAG:
+                    stash[r, l] = np.float32(np.float32(a[0] + a[1]) + np.float32(a[2] + a[3]))
+                    a[:] = 0
+                    r += 1
+        assert r == nr, f"lane {l} of block {b} closed {r} row segments, the block has {nr} rows"
+    out = []
+    for r in range(nr):
+        s = stash[r].copy()
+        for offb in (32, 16, 8, 4, 2, 1):
+            s = np.array([np.float32(s[l] + s[l ^ offb]) for l in range(64)], dtype=np.float32)
+        out.append(s[0])
+    return out
+
+
+@pytest.mark.parametrize("rows,n,row0,p,rb", [(24, 256, 0, 0.1, 16), (40, 1028, 8, 0.2, 16), (21, 2052, 64, 0.02, 4),
+                                              (8, 512, 0, 1.0, 8)])
+def test_blocked_packed_rows_reproduce_the_dense_row_dot(oracle_backend, rows, n, row0, p, rb):
+    """Blocked form: row blocks share one padded stream, END entries close a lane's row segments (dummy END entries for
+    empty segments, an all-zero row included)."""
+    W = random_sparse(rows, n, p, seed=rows + n)
+    W[3] = 0.0
+    packed = sparse.pack_rows_blocked(W, row0=row0, block_rows=rb, proc_rows=2 * rb)
+    off = packed.rowoff.numpy()
+    nb = -(-rows // rb)
+    assert packed.block_rows == rb and off.size == nb + 1 and off[-1] * 256 == packed.vals.numel()
+    assert int((packed.vals != 0).sum()) == int((W != 0).sum())
+    ends = (packed.code.numpy().view(np.uint16) & sparse.END_FLAG) != 0
+    assert int(ends.sum()) == rows * 64          # every (row, lane) segment is closed exactly once
+    src = torch.randn(n + 256, generator=torch.Generator().manual_seed(1)).numpy().astype(np.float32)
+    import ctypes as C
+    lib = oracle_backend.lib
+    for b in range(nb):
+        got = emulate_block(packed, src, b, rows)
+        for j, g in enumerate(got):
+            i = b * rb + j
+            w = np.ascontiguousarray(W[i].numpy())
+            dense = lib.oracle_row_dot(w.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), n, 1, row0 + i)
+            assert np.float32(dense).view(np.uint32) == np.float32(g).view(np.uint32) or (dense == 0 and g == 0), i
+
+
+def test_blocked_form_pads_less_than_the_per_row_form():
+    W = random_sparse(128, 32768, 0.1, seed=9)
+    ideal = 6 * int((W != 0).sum())
+    per_row, b8, b16 = sparse.pack_rows(W), sparse.pack_rows_blocked(W, block_rows=8, proc_rows=64), \
+        sparse.pack_rows_blocked(W, block_rows=16, proc_rows=64)
+    assert per_row.stored_bytes > 1.3 * ideal and b8.stored_bytes < 1.13 * ideal and b16.stored_bytes < 1.09 * ideal
+
+
 def test_pack_rejects_unaligned_width():
     with pytest.raises(ValueError):
         sparse.pack_rows(torch.zeros(4, 10))
@@ -69,9 +131,12 @@ MODELS = {
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("model", list(MODELS))
-@pytest.mark.parametrize("rows,n,row0", [(256, 256, 0), (1028, 1028, 0), (96, 33024, 64)])
-def test_sparse_step_kernel_equals_dense_oracle(oracle_backend, hip_device, model, rows, n, row0):
-    """n <= 32768: source vector gathered from LDS (rotated layout); the 96 x 33024 shard takes the L2 gather path."""
+@pytest.mark.parametrize("rows,n,row0,form", [(256, 256, 0, "blocked8"), (1028, 1028, 0, "blocked16"), (1000, 4100, 0, "blocked4"),
+                                              (256, 256, 0, "per_row"), (1028, 1028, 0, "per_row"),
+                                              (96, 33024, 64, "windowed")])
+def test_sparse_step_kernel_equals_dense_oracle(oracle_backend, hip_device, model, rows, n, row0, form):
+    """n <= 32768: source vector gathered from LDS (rotated layout), blocked form (row blocks share one padded stream) or
+    the per-row form; the 96 x 33024 shard takes the windowed form."""
     params, kw, dt, drive, out_var = MODELS[model]
     T = 600 if model == "ik" else 200
     positive = model != "li_tanh"
@@ -84,7 +149,10 @@ def test_sparse_step_kernel_equals_dense_oracle(oracle_backend, hip_device, mode
     for backend, dev, pack in ((oracle_backend, "cpu", False), (None, hip_device, True)):
         pop = Population(model, W, params, dt, dev, n=n, row0=row0, backend=backend, **kw)
         if pack:
+            pop.blocked_sparse = form.startswith("blocked")
+            pop.sparse_block_rows = int(form[7:]) if pop.blocked_sparse else 0
             packed = pop.pack_weights()
+            assert packed.block_rows == pop.sparse_block_rows and (packed.row_ids is not None) == (form == "windowed")
             if n >= 8192:  # the slot layout needs many chunks per row (n / 256 >> 1 / density) to pay off
                 assert packed.stored_bytes < 0.4 * 4 * rows * n
         traj = torch.zeros(T, rows, device=dev)
@@ -176,10 +244,11 @@ def test_weight_writes_reach_the_packed_form(hip_device, how):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rb", [0, 8], ids=["per_row", "blocked8"])
 @pytest.mark.parametrize("model,n", [("li_tanh", 1028), ("li_tanh", 8192), ("qif", 1024), ("ik", 2048)])
-def test_sparse_adjoint_equals_oracle(oracle_backend, hip_device, model, n):
-    """Adjoint sweep on the packed rows of W^T (fixed sparse W): HIP == oracle (row-dot order on W^T), bit for bit, for
-    the rate and the spiking sweeps; n = 8192 is beyond the dense transposed-copy threshold."""
+def test_sparse_adjoint_equals_oracle(oracle_backend, hip_device, model, n, rb):
+    """Adjoint sweep on the packed rows of W^T (fixed sparse W; per-row and blocked form): HIP == oracle (row-dot order
+    on W^T), bit for bit, for the rate and the spiking sweeps; n = 8192 is beyond the dense transposed-copy threshold."""
     params, kw, dt, drive, out_var = MODELS[model]
     T = 12 if n > 4096 else 40
     positive = model != "li_tanh"
@@ -193,6 +262,7 @@ def test_sparse_adjoint_equals_oracle(oracle_backend, hip_device, model, n):
     res = []
     for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
         pop = Population(model, W, params, dt, dev, backend=backend, **kw)
+        pop.blocked_sparse, pop.sparse_block_rows = rb > 0, rb
         pop.pack_weights()
         tv, ts, ta, tx, ut, gx = (torch.zeros(T, n, device=dev) for _ in range(6))
         pop.forward(T, x=x.to(dev), save_v=tv, save_src=ts, save_acc=ta, save_aux=tx if pop.aux is not None else None)
@@ -207,7 +277,7 @@ def test_sparse_adjoint_equals_oracle(oracle_backend, hip_device, model, n):
                                 slope=0.7, x=x.to(dev), traj_aux=tx if pop.aux is not None else None,
                                 lam_x=lx if pop.aux is not None else None, grad_params=grads)
             out = [lv, ls, lx, ut, gx, grads["eta"], grads["k"]]
-        assert pop.packed_t is not None
+        assert pop.packed_t is not None and pop.packed_t.block_rows == rb and pop.packed.block_rows == rb
         if dev != "cpu":
             torch.cuda.synchronize()
         res.append([t_.cpu().numpy() for t_ in out])
