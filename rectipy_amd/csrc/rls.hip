@@ -109,7 +109,7 @@ __global__ void rls_predict_kernel(const float* W, int64_t ldw, int n_in, int n_
 }
 
 // Fused pass over P: (UPDATE) P[i][:] -= (k z_i) z[:], then zn_i = beta_inv * (P_new[i][:] . x_next)
-template <int R, int U, bool NTS, bool VEC4, bool UPDATE>
+template <int R, int U, bool NTS, bool VEC4, bool UPDATE, bool NTL = true>
 __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -163,7 +163,8 @@ __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
                     zv[u] = UPDATE ? rp_ld4(P.z + col + 256 * u) : zero4;
                     xv[u] = dot ? rp_ld4(P.x_next + col + 256 * u) : zero4;
 #pragma unroll
-                    for (int j = 0; j < R; ++j) p[u][j] = rp_ld4_stream(prow[j] + col + 256 * u);
+                    for (int j = 0; j < R; ++j)
+                        p[u][j] = NTL ? rp_ld4_stream(prow[j] + col + 256 * u) : rp_ld4(prow[j] + col + 256 * u);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) body(col + 256 * u, p[u], zv[u], xv[u]);
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
                 const rp_f4 zv = UPDATE ? rp_ld4(P.z + col) : zero4;
                 const rp_f4 xv = dot ? rp_ld4(P.x_next + col) : zero4;
 #pragma unroll
-                for (int j = 0; j < R; ++j) p[j] = rp_ld4_stream(prow[j] + col);
+                for (int j = 0; j < R; ++j) p[j] = NTL ? rp_ld4_stream(prow[j] + col) : rp_ld4(prow[j] + col);
                 body(col, p, zv, xv);
             }
 #pragma unroll
@@ -210,12 +211,17 @@ __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
 
 int g_rls_R = 0, g_rls_U = 0, g_rls_nts = -1;  // benchmark-only override (rp_set_rls_tuning)
 
+int g_rls_blocks = 0;  // benchmark-only: grid cap override
+
 template <int R, int U, bool NTS, bool UPDATE>
 void launch_cfg(const RlsParams& P, bool vec4, hipStream_t st) {
     int groups = (P.n_in + R - 1) / R;
     int blocks = (groups + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    if (vec4)
+    const int cap = g_rls_blocks > 0 ? g_rls_blocks : 2048;
+    if (blocks > cap) blocks = cap;
+    if (vec4 && (g_rls_nts & 2))
+        hipLaunchKernelGGL((rls_pass_kernel<R, U, NTS, true, UPDATE, false>), dim3(blocks), dim3(kThreads), 0, st, P);
+    else if (vec4)
         hipLaunchKernelGGL((rls_pass_kernel<R, U, NTS, true, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
     else
         hipLaunchKernelGGL((rls_pass_kernel<R, 1, NTS, false, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
@@ -224,7 +230,7 @@ void launch_cfg(const RlsParams& P, bool vec4, hipStream_t st) {
 template <bool UPDATE>
 void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
     const int R = g_rls_R ? g_rls_R : 2, U = g_rls_U ? g_rls_U : 4;
-    const bool nts = g_rls_nts < 0 ? true : g_rls_nts != 0;
+    const bool nts = g_rls_nts < 0 ? true : (g_rls_nts & 1) != 0;
 #define RP_RLS(R_, U_)                                            \
     if (R == R_ && U == U_) {                                     \
         if (nts)                                                  \
@@ -233,7 +239,7 @@ void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
             launch_cfg<R_, U_, false, UPDATE>(P, vec4, st);       \
         return;                                                   \
     }
-    RP_RLS(2, 4) RP_RLS(1, 4) RP_RLS(1, 8) RP_RLS(2, 2) RP_RLS(4, 2) RP_RLS(4, 1) RP_RLS(2, 8)
+    RP_RLS(2, 4) RP_RLS(1, 4) RP_RLS(1, 8) RP_RLS(2, 2) RP_RLS(4, 2) RP_RLS(4, 1) RP_RLS(2, 8) RP_RLS(1, 16) RP_RLS(4, 4)
 #undef RP_RLS
     launch_cfg<2, 4, true, UPDATE>(P, vec4, st);
 }
@@ -242,8 +248,9 @@ void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
 
 extern "C" int rp_set_rls_tuning(int rows_per_wave, int unroll, int nontemporal_store) {
     g_rls_R = rows_per_wave;
-    g_rls_U = unroll;
-    g_rls_nts = nontemporal_store;
+    g_rls_U = unroll & 0xff;          // bits 8..: grid cap in blocks (benchmark only)
+    g_rls_blocks = unroll >> 8;
+    g_rls_nts = nontemporal_store;    // -1 default; bit 0: non-temporal stores, bit 1: cached (not streaming) loads
     return RP_OK;
 }
 

@@ -45,7 +45,7 @@ packed = sp.pack_weights()
 sp.forward(T, x=x)
 torch.cuda.synchronize()
 # packed stream + the source vector staged into LDS once per CU (256 x 128 KiB, served by L2) is not HBM traffic
-algo["step_sparse_kernel"] = float(packed.stored_bytes) + 4.0 * 8 * N
+algo["step_sparse_blocked_kernel"] = float(packed.stored_bytes) + 4.0 * 8 * N
 del sp, packed
 
 n_in = 16384
