@@ -38,6 +38,7 @@ struct RlsParams {
     float* err;        // [n_out] workspace
     float* loss_out;   // loss of this update, replicated for the steps it stays valid for
     int loss_count;
+    int no_dot;  // benchmark-only: skip the mat-vec half of the pass
 };
 
 // One block: d = x.z (fixed tree), k = 1/(1+d), y_hat = W x, err = y - y_hat, loss = err.err
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
             prow[j] = P.P + (int64_t)rr * P.ldp;
             kz[j] = UPDATE ? k * P.z[rr] : 0.f;
         }
-        const bool dot = P.x_next != nullptr;
+        const bool dot = P.x_next != nullptr && !P.no_dot;
         if constexpr (VEC4) {
             rp_f4 a[R];
 #pragma unroll
@@ -219,7 +220,7 @@ void launch_cfg(const RlsParams& P, bool vec4, hipStream_t st) {
     int blocks = (groups + 3) / 4;
     const int cap = g_rls_blocks > 0 ? g_rls_blocks : 2048;
     if (blocks > cap) blocks = cap;
-    if (vec4 && (g_rls_nts & 2))
+    if (vec4 && g_rls_nts >= 0 && (g_rls_nts & 2))
         hipLaunchKernelGGL((rls_pass_kernel<R, U, NTS, true, UPDATE, false>), dim3(blocks), dim3(kThreads), 0, st, P);
     else if (vec4)
         hipLaunchKernelGGL((rls_pass_kernel<R, U, NTS, true, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
@@ -270,6 +271,7 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
 
     RlsParams P = {};
+    P.no_dot = (g_rls_nts >= 0 && (g_rls_nts & 4)) ? 1 : 0;
     P.P = r->P;
     P.ldp = r->ldp;
     P.n_in = r->n_in;

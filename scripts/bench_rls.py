@@ -19,7 +19,7 @@ Y = torch.randn(T, k, device=dev)
 from rectipy_amd import _lib
 lib = _lib.load()
 if len(sys.argv) > 2:
-    for R, U, nts in ((2, 4, 1), (2, 4, 0), (2, 4, 3), (2, 4, 2), (1, 8, 1), (1, 16, 1), (1, 16, 0), (4, 4, 1), (2, 8, 1), (2, 8, 3),
+    for R, U, nts in ((2, 4, 5), (1, 16, 5), (2, 8, 5), (2, 4, 1), (2, 4, 0), (2, 4, 3), (2, 4, 2), (1, 8, 1), (1, 16, 1), (1, 16, 0), (4, 4, 1), (2, 8, 1), (2, 8, 3),
                       (2, 4 + (512 << 8), 1), (2, 4 + (1024 << 8), 1), (2, 4 + (4096 << 8), 1), (2, 8 + (512 << 8), 1),
                       (1, 16 + (512 << 8), 1), (1, 16 + (256 << 8), 1)):
         lib.rp_set_rls_tuning(R, U, nts)
