@@ -45,6 +45,14 @@ class Observer:
     def recorded_variables(self) -> list:
         return list(self._keys)
 
+    @property
+    def recordings(self):
+        """All recorded quantities as one DataFrame indexed by time (reference observer.py:62-70)."""
+        from pandas import DataFrame
+        columns = list(self._state_vars) + (["out"] if self._record_out else []) + (["loss"] if self._record_loss else [])
+        data = {str(c): list(self.to_numpy(c)) for c in columns}
+        return DataFrame(index=np.asarray(self["steps"]) * self._dt, data=data)
+
     def record(self, step: int, output: torch.Tensor, loss: Union[float, torch.Tensor],
                record_vars: Iterable[torch.Tensor]) -> None:
         """One sample (reference observer.py:79-105)."""
