@@ -955,13 +955,18 @@ class MultiSpikeResetNet(SpikeResetNet):
     def _as_input(self, x, steps=None):
         if self._in_slice is None:
             return super()._as_input(x, steps)
-        rows = self._pop.rows
-        try:  # validate against the population's width, then embed
-            self._pop.rows = self._in_slice[1] - self._in_slice[0]
-            x2 = super()._as_input(x, steps)
-        finally:
-            self._pop.rows = rows
-        return self._embed(x2)
+        if x is None:
+            return None
+        if not isinstance(x, torch.Tensor):
+            if isinstance(x, np.ndarray):
+                raise RuntimeError("node inputs must be torch tensors (the reference raises here as well)")
+            x = torch.tensor([float(x)], dtype=torch.float32)
+        x = x.to(device=self._pop.device, dtype=torch.float32)
+        if steps is None:
+            x = x.reshape(1, -1)
+        if x.dim() != 2:
+            raise RuntimeError(f"inputs must be [steps, m], got {tuple(x.shape)}")
+        return self._embed(x)  # checks the width against the addressed population and places it among zeros
 
     def forward(self, x) -> torch.Tensor:
         """One step; returns the POST-update output slice (reference nodes.py:449-465)."""

@@ -28,10 +28,10 @@ def err(a, b):
     return np.abs(a.astype(np.float64) - np.asarray(b, dtype=np.float64)).max()
 
 
-def build(g, target, more_vars=None):
+def build(g, target, more_vars=None, input_var="qif_op/I_ext", output_var="e/qif_op/s"):
     ne, ni = int(g["ne"]), int(g["ni"])
     return SpikeResetNet.from_pyrates(
-        QIF, input_var="qif_op/I_ext", output_var="e/qif_op/s", weights=g["W"], source_var="qif_op/s",
+        QIF, input_var=input_var, output_var=output_var, weights=g["W"], source_var="qif_op/s",
         target_var="qif_op/s_in", spike_var=["e/qif_op/spike", "i/qif_op/spike"], reset_var=["e/qif_op/v", "i/qif_op/v"],
         populations={"e": ne, "i": ni},
         node_vars={"all/qif_op/eta": g["eta"], "e/qif_op/tau": 1.0, "i/qif_op/tau": 0.8, "all/qif_op/tau_s": g["tau_s"],
@@ -109,3 +109,22 @@ def test_multispike_argument_errors(oracle_backend):
                                    dtype=torch.float32, **where)  # populations missing
     with pytest.raises(KeyError):
         build(g, where, more_vars={"x/qif_op/eta": 1.0})
+
+
+def test_multispike_input_and_output_addressing(oracle_backend):
+    """Input into ONE population (zeros elsewhere) and the output variable of EVERY population."""
+    g = dict(np.load(os.path.join(GOLD, "g29_multispike.npz")))
+    ne, ni = int(g["ne"]), int(g["ni"])
+    where = dict(device="cpu", backend=oracle_backend)
+    a = build(g, where, input_var="e/qif_op/I_ext", output_var="qif_op/s")
+    b = build(g, where, output_var="qif_op/s")
+    assert a.n_in == ne and a.n_out == ne + ni and b.n_in == ne + ni
+    xe = torch.linspace(5.0, 20.0, ne)
+    xfull = torch.cat([xe, torch.zeros(ni)])
+    for _ in range(300):
+        oa, ob = a.forward(xe), b.forward(xfull)
+        assert torch.equal(oa, ob)
+    assert torch.equal(a.y, b.y) and oa.shape[0] == ne + ni
+    assert torch.equal(oa[:ne], a["e/qif_op/s"]) and torch.equal(oa[ne:], a["i/qif_op/s"])
+    with pytest.raises(RuntimeError):
+        a.forward(torch.zeros(ne + 1))
