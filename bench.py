@@ -189,6 +189,9 @@ def main():
         "state_finite": finite,
     }
 
+    if use_dist:
+        out["roofline"]["note"] = ("row-sharded run: avg_launch_ms is the per-step time on rank 0's stream, i.e. the shard's "
+                                   "step kernel PLUS the in-stream all-gather; achieved/frac therefore understate the kernel")
     if config5 is not None:
         out.setdefault("extra", {})["config5"] = config5
     cpu_threads = None
