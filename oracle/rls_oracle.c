@@ -57,15 +57,45 @@ static float pass_row(float* p, int n, int vec4, int update, float kz, const flo
     return butterfly64(s);
 }
 
+/* tiled pass (rp_rls.partials given, 16-byte path): row i is cut into tiles of 4096 columns; inside a tile, wave w owns
+   the columns 1024 u + 256 w + 4 l + c (u = 0..3): accumulators a[l][c] over u ascending, lane sum, butterfly -> s_w; the
+   tile partial is ((s_0 + s_1) + s_2) + s_3; the row's dot = tile partials added ascending (rls_tile_kernel) */
+static float pass_row_tiled(float* p, int n, int update, float kz, const float* z, const float* x_next) {
+    if (update)
+        for (int j = 0; j < n; ++j) p[j] = p[j] - kz * z[j];
+    if (!x_next) return 0.0f;
+    float total = 0.0f;
+    for (int c0 = 0, c = 0; c0 < n; c0 += 4096, ++c) {
+        float sw[4];
+        for (int w = 0; w < 4; ++w) {
+            float a[256], s[64];
+            for (int q = 0; q < 256; ++q) a[q] = 0.0f;
+            for (int u = 0; u < 4; ++u)
+                for (int q = 0; q < 256; ++q) {
+                    const int j = c0 + 1024 * u + 256 * w + q;
+                    if (j < n) a[q] = fmaf(p[j], x_next[j], a[q]);
+                }
+            for (int l = 0; l < 64; ++l) s[l] = (a[4 * l] + a[4 * l + 1]) + (a[4 * l + 2] + a[4 * l + 3]);
+            sw[w] = butterfly64(s);
+        }
+        const float part = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+        total = c == 0 ? part : total + part;
+    }
+    return total;
+}
+
 int oracle_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, const float* X, int64_t ldx, const float* Y,
                      int64_t ldy, float* pred, int64_t ldpred, float* loss) {
     const int n = r->n_in, m = r->n_out;
     if (steps == 0) return RP_OK;
     const int vec4 = (n % 4 == 0) && (r->ldp % 4 == 0) && (ldx % 4 == 0);
+    const int tiled = vec4 && r->partials != 0;
     float* za = r->z;
     float* zb = r->zn;
     float* err = r->scratch + 4;
-    for (int i = 0; i < n; ++i) za[i] = r->beta_inv * pass_row(r->P + (int64_t)i * r->ldp, n, vec4, 0, 0.0f, 0, X);
+    for (int i = 0; i < n; ++i)
+        za[i] = r->beta_inv * (tiled ? pass_row_tiled(r->P + (int64_t)i * r->ldp, n, 0, 0.0f, 0, X)
+                                     : pass_row(r->P + (int64_t)i * r->ldp, n, vec4, 0, 0.0f, 0, X));
     for (int t = 0; t < steps; t += stride) {
         const float* x = X + (int64_t)t * ldx;
         const float* y = Y + (int64_t)t * ldy;
@@ -90,7 +120,8 @@ int oracle_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, const float
         const float* x_next = next < steps ? X + (int64_t)next * ldx : 0;
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < n; ++i) {
-            const float v = pass_row(r->P + (int64_t)i * r->ldp, n, vec4, 1, k * za[i], za, x_next);
+            const float v = tiled ? pass_row_tiled(r->P + (int64_t)i * r->ldp, n, 1, k * za[i], za, x_next)
+                                  : pass_row(r->P + (int64_t)i * r->ldp, n, vec4, 1, k * za[i], za, x_next);
             if (x_next) zb[i] = r->beta_inv * v;
         }
         if (pred)

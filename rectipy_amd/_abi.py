@@ -164,6 +164,7 @@ class RpRls(C.Structure):
         ("z", fp),
         ("zn", fp),
         ("scratch", fp),
+        ("partials", fp),
     ]
 
 

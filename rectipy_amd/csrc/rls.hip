@@ -39,6 +39,7 @@ struct RlsParams {
     float* loss_out;   // loss of this update, replicated for the steps it stays valid for
     int loss_count;
     int no_dot;  // benchmark-only: skip the mat-vec half of the pass
+    float* partials;  // tiled pass: [n_in x tiles_per_row] partial dot products
 };
 
 // One block: d = x.z (fixed tree), k = 1/(1+d), y_hat = W x, err = y - y_hat, loss = err.err
@@ -210,6 +211,80 @@ __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
     }
 }
 
+// Tiled pass (rp_rls.partials given).  How the chip walks P decides the speed of an in-place update, not its arithmetic
+// (scripts/probes/rmw_probe.hip, 4 GiB read-modify-write on one MI355X): one wave per row keeps 8192 far-apart row
+// streams open -- 5.1 TB/s; ONE-SHOT workgroups that each take 16 KiB of contiguous memory in address order, all loads
+// first, then all stores -- 6.2 TB/s.  Here a workgroup (4 waves) takes the tile (row i, columns [4096 c, 4096 c + 4096)):
+// thread (wave w, lane l) owns columns 4096 c + 1024 u + 256 w + 4 l .. +3 for u = 0..3, i.e. every wave instruction
+// touches 1 KiB and the four waves 4 KiB of contiguous memory per u.  The tile's share of the mat-vec: per wave the
+// accumulators a[l][comp] over u ascending, lane sum (a0+a1)+(a2+a3), butterfly; the four wave sums are added in wave
+// order; rls_zn_kernel adds a row's tile partials in ascending order (mirrored by oracle/rls_oracle.c).
+constexpr int kTileCols = 4096;
+
+template <bool NTS, bool UPDATE>
+__global__ __launch_bounds__(kThreads) void rls_tile_kernel(const RlsParams P) {
+    __shared__ float wsum[kThreads / 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = P.n_in;
+    const int tpr = (n + kTileCols - 1) / kTileCols;
+    const int row = blockIdx.x / tpr;
+    const int ct = blockIdx.x - row * tpr;
+    const int col0 = ct * kTileCols + 256 * wave + 4 * lane;
+    float* prow = P.P + (int64_t)row * P.ldp;
+    const bool dot = P.x_next != nullptr && !P.no_dot;
+    const float kz = UPDATE ? P.scal[0] * P.z[row] : 0.f;
+    const rp_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    rp_f4 p[4], zv[4], xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int col = col0 + 1024 * u;
+        if (col < n) {
+            p[u] = rp_ld4_stream(prow + col);
+            zv[u] = UPDATE ? rp_ld4(P.z + col) : zero4;
+            xv[u] = dot ? rp_ld4(P.x_next + col) : zero4;
+        }
+    }
+    rp_f4 a = zero4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int col = col0 + 1024 * u;
+        if (col < n) {
+            if constexpr (UPDATE) {
+                p[u].x = p[u].x - kz * zv[u].x;
+                p[u].y = p[u].y - kz * zv[u].y;
+                p[u].z = p[u].z - kz * zv[u].z;
+                p[u].w = p[u].w - kz * zv[u].w;
+                if constexpr (NTS)
+                    __builtin_nontemporal_store(p[u], reinterpret_cast<rp_f4*>(prow + col));
+                else
+                    *reinterpret_cast<rp_f4*>(prow + col) = p[u];
+            }
+            a.x = fmaf(p[u].x, xv[u].x, a.x);
+            a.y = fmaf(p[u].y, xv[u].y, a.y);
+            a.z = fmaf(p[u].z, xv[u].z, a.z);
+            a.w = fmaf(p[u].w, xv[u].w, a.w);
+        }
+    }
+    if (dot) {
+        const float s = rp_wave_allreduce(rp_lane_sum4(a));
+        if (lane == 0) wsum[wave] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) P.partials[blockIdx.x] = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+    }
+}
+
+// z'_i = beta_inv * (part[i][0] + part[i][1] + ...), ascending
+__global__ void rls_zn_kernel(const RlsParams P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_in) return;
+    const int tpr = (P.n_in + kTileCols - 1) / kTileCols;
+    const float* part = P.partials + (int64_t)i * tpr;
+    float s = part[0];
+    for (int c = 1; c < tpr; ++c) s = s + part[c];
+    P.zn[i] = P.beta_inv * s;
+}
+
 int g_rls_R = 0, g_rls_U = 0, g_rls_nts = -1;  // benchmark-only override (rp_set_rls_tuning)
 
 int g_rls_blocks = 0;  // benchmark-only: grid cap override
@@ -232,6 +307,17 @@ template <bool UPDATE>
 void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
     const int R = g_rls_R ? g_rls_R : 2, U = g_rls_U ? g_rls_U : 4;
     const bool nts = g_rls_nts < 0 ? true : (g_rls_nts & 1) != 0;
+    if (vec4 && P.partials) {  // one-shot tiles in address order + the per-row sum of the tile partials
+        const int tpr = (P.n_in + kTileCols - 1) / kTileCols;
+        const unsigned blocks = (unsigned)P.n_in * (unsigned)tpr;
+        if (nts)
+            hipLaunchKernelGGL((rls_tile_kernel<true, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
+        else
+            hipLaunchKernelGGL((rls_tile_kernel<false, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
+        if (P.x_next && !P.no_dot)
+            hipLaunchKernelGGL(rls_zn_kernel, dim3((P.n_in + 255) / 256), dim3(256), 0, st, P);
+        return;
+    }
 #define RP_RLS(R_, U_)                                            \
     if (R == R_ && U == U_) {                                     \
         if (nts)                                                  \
@@ -281,6 +367,7 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
     P.beta_inv = r->beta_inv;
     P.scal = r->scratch;
     P.err = r->scratch + 4;
+    P.partials = vec4 ? r->partials : nullptr;
     float* za = r->z;
     float* zb = r->zn;
 

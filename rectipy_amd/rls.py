@@ -32,6 +32,10 @@ class RLS(Linear):
         self.loss = 0.0
         self._backend = backend
         self._scratch = None
+        self._partials = None
+        self.tiled = None  # None: by size; True / False: force the tiled / row-per-wave pass (tests, measurements)
+
+    TILED_MIN_N = 24576  # measured (scripts/bench_rls.py): n_in = 32768: 1.54 vs 1.67 ms per update; 16384 and below: tie
 
     def to(self, device: str, **kwargs):
         self.weights = self.weights.detach().to(device).contiguous()
@@ -49,6 +53,12 @@ class RLS(Linear):
             self._scratch = (torch.zeros(self.n_in, dtype=torch.float32, device=dev),
                              torch.zeros(self.n_in, dtype=torch.float32, device=dev),
                              torch.zeros(4 + self.n_out, dtype=torch.float32, device=dev))
+            # tiled pass (P walked in address order by one-shot workgroups) once P is far beyond
+            # the caches; below that the update is launch-bound and one wave per row is as fast
+            tiles = (self.n_in + 4095) // 4096
+            use = self.tiled is True or (self.tiled is None and self.n_in >= self.TILED_MIN_N)
+            self._partials = torch.zeros(self.n_in * tiles, dtype=torch.float32, device=dev) \
+                if use and self.n_in % 4 == 0 else None
 
     def sweep(self, X: torch.Tensor, Y: torch.Tensor, stride: int = 1):
         """Train over T consecutive steps: X [T, n_in] edge inputs, Y [T, n_out] targets, an update every `stride`
@@ -74,6 +84,7 @@ class RLS(Linear):
         r.P, r.W = self.P.data_ptr(), self.weights.data_ptr()
         r.beta_inv = float(self.beta)
         r.z, r.zn, r.scratch = z.data_ptr(), zn.data_ptr(), scratch.data_ptr()
+        r.partials = None if self._partials is None else self._partials.data_ptr()
         self._backend.rls_sweep(r, T, int(stride), X.data_ptr(), X.stride(0) if T > 1 else self.n_in, Y.data_ptr(),
                                 Y.stride(0) if T > 1 else self.n_out, pred.data_ptr(), self.n_out, loss.data_ptr(), dev)
         self.loss = loss[-1]

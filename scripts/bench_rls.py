@@ -14,6 +14,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 T, k = 20, 3
 dev = torch.device("cuda:0")
 edge = RLS(n, k, beta=0.99, alpha=1.0).to(dev)
+edge.tiled = None if os.environ.get("RLS_TILED", "auto") == "auto" else os.environ["RLS_TILED"] == "1"
 X = torch.randn(T, n, device=dev) * 0.1
 Y = torch.randn(T, k, device=dev)
 from rectipy_amd import _lib

@@ -36,9 +36,11 @@ def build(g, target):
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
 @pytest.mark.parametrize("stride", [1, 4])
-def test_g14_fit_rls_matches_reference(target, stride):
+@pytest.mark.parametrize("tiled", [False, True], ids=["row-per-wave", "tiled"])
+def test_g14_fit_rls_matches_reference(target, stride, tiled):
     g = dict(np.load(os.path.join(GOLD, "g14_rls.npz")))
     net, edge = build(g, target)
+    edge.tiled = tiled and g["W"].shape[0] % 4 == 0
     assert isinstance(edge, RLS) and abs(edge.beta - 1 / 0.95) < 1e-12
     obs = net.fit_rls(g["x"], g["target"], update_steps=stride, sampling_steps=1, verbose=False)
     key = f"s{stride}_f64"
@@ -86,8 +88,12 @@ def test_fit_rls_epochs_recovers_readout(target):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_in,n_out,T,stride", [(40, 3, 30, 1), (256, 2, 25, 3), (1000, 4, 12, 1), (1030, 1, 9, 2)])
-def test_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride):
+@pytest.mark.parametrize("n_in,n_out,T,stride,tiled", [(40, 3, 30, 1, False), (256, 2, 25, 3, False), (1000, 4, 12, 1, False),
+                                                       (1030, 1, 9, 2, False), (256, 2, 25, 3, True), (1000, 4, 12, 1, True),
+                                                       (4100, 2, 6, 1, True), (9000, 3, 4, 2, None)])
+def test_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride, tiled):
+    """Row-per-wave pass and the tiled pass (P walked in address order by one-shot workgroups, 4096-column tiles with
+    per-tile partial sums; chosen by size from n_in = 24576), ragged last tiles included."""
     gen = torch.Generator().manual_seed(n_in + T)
     X = torch.randn(T, n_in, generator=gen)
     Y = torch.randn(T, n_out, generator=gen)
@@ -95,7 +101,9 @@ def test_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride)
     res = []
     for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
         edge = RLS(n_in, n_out, weights=W0.clone(), beta=0.97, alpha=1.5, backend=backend).to(dev)
+        edge.tiled = tiled
         pred, loss = edge.sweep(X.to(dev), Y.to(dev), stride)
+        assert (edge._partials is not None) == (tiled is True or (tiled is None and n_in >= RLS.TILED_MIN_N))
         res.append([t.cpu().numpy() for t in (pred, loss, edge.weights, edge.P)])
     for a, b, name in zip(res[0], res[1], ("pred", "loss", "weights", "P")):
         same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
