@@ -201,6 +201,7 @@ def main():
         out["extra"] = fwd_bwd_extra(pop, x, N, dev)
         if cpu_threads is not None:
             out["extra"]["cpu_fwd_bwd"] = cpu_fwd_bwd(pop, x, dt, N, cpu_threads)
+        out["extra"]["batched_trajectories"] = batched_extra(pop, N, dev, out["ms_per_step"])
         out["extra"]["fit_ridge"] = ridge_extra(net, x, N, dev)
         out["extra"].update(facade_fit_bptt(pop, x, N, dev, teacher_net=net))  # it trains (modifies) the shared weight matrix
         pop = net = sp = None  # release the 4.3 GB network before the two larger side workloads
@@ -424,6 +425,37 @@ def cpu_fwd_bwd(pop, x, dt, N, threads, T=20):
     return {"value": sps, "unit": "steps/s (fwd+bwd)", "cores": threads, "kind": "port",
             "sample": f"one autograd window of T={T} steps, N={N}, trainable W, MSE read-out k=3 "
                       f"(oracle/torch_eager.py: time_eager_bptt)"}
+
+
+def batched_extra(pop, N, dev, ms_single, T=200):
+    """B independent trajectories of the same network in one pass over W per step (rp_forward_batched; the "batched-input
+    dense W @ state contraction" of the brief -- the reference has no batch axis and would run them one after the other).
+    Every trajectory is bit-identical to an unbatched run (tests/test_batched.py)."""
+    from rectipy_amd.engine import BatchedPopulation
+    if N % 4:
+        return {"skipped": "n % 4 != 0"}
+    res = {"workload": f"tanh rate RNN N={N}, B trajectories per pass over W, {T} timed steps each, broadcast input",
+           "unit": "trajectory-steps/s"}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for B in (2, 4, 8, 16):
+        bp = BatchedPopulation(pop, B)
+        bp.v.normal_(generator=torch.Generator(device=dev).manual_seed(B))
+        bp.refresh()
+        xb = torch.randn(T + 10, B, 1, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + B))
+        bp.forward(10, x=xb[:10])
+        torch.cuda.synchronize()
+        e0.record()
+        bp.forward(T, x=xb[10:])
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / T
+        res[f"B{B}"] = {"trajectory_steps_per_s": B * 1e3 / ms, "ms_per_step": ms,
+                        "vs_unbatched": B * ms_single / ms, "W_stream_GBps": 4.0 * N * N / (ms * 1e-3) / 1e9,
+                        "fma_TFLOPs": 2.0 * N * N * B / (ms * 1e-3) / 1e12,
+                        "state_finite": bool(torch.isfinite(bp.v).all().item())}
+        del bp, xb
+    torch.cuda.empty_cache()
+    return res
 
 
 def ridge_extra(net, x, N, dev, T=2000, sampling=10, k=3):

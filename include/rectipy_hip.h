@@ -338,6 +338,36 @@ int rp_forward_sharded(rp_net* net, rp_run* run, const rp_comm* comm, void* stre
 int rp_backward_sharded(const rp_net* net, const rp_bwd* bwd, const rp_comm* comm, void* stream);
 
 /*
+ * B independent trajectories through ONE coupling matrix (the "batched-input dense W @ state contraction" of the build's
+ * brief; the reference has no batch axis -- it would run the B trajectories one after the other, streaming W B times).
+ * Every Euler step streams W once and advances all B state vectors: lane l still owns columns 256 m + 4 l .. +3 of a row,
+ * holds one set of four accumulators PER trajectory and feeds them from the B source vectors (L2-resident), so each
+ * trajectory sees exactly the fmaf sequence of rp_forward: trajectory b of a batched call is bit-identical to an
+ * unbatched call on the same state.  Rate models (LI_TANH, LI_SIGMOID), 16-byte path (n % 4 == 0), B in {2, 4, 8, 16}.
+ * State lives in the caller's [B x ld] buffers; rp_net supplies W, the per-neuron parameters, dt and the shard geometry
+ * (rp_net.y / src / cur are not used).
+ */
+typedef struct rp_batch {
+    int32_t batch;            /* B                                                              */
+    int32_t steps;
+    float* v;                 /* [B x ldv] states v_b (in/out)                                   */
+    int64_t ldv;
+    float* src[2];            /* [B x ldsrc] ping-pong source vectors r_b = act(v_b), global length n (in/out) */
+    int64_t ldsrc;
+    int32_t cur;              /* [host, in/out] index of the current source buffer               */
+    int32_t x_mode;           /* RP_X_NONE / RP_X_FULL / RP_X_BCAST                              */
+    const float* x;           /* inputs: row (t, b) at x + (t * B + b) * ldx                     */
+    int64_t ldx;
+    int32_t out_var;          /* RP_OUT_*                                                        */
+    float* traj;              /* optional: pre-update output of (t, b) at traj + (t * B + b) * ldtraj */
+    int64_t ldtraj;
+} rp_batch;
+
+int rp_sizeof_batch(void);
+int rp_forward_batched(const rp_net* net, rp_batch* batch, void* stream);
+int rp_set_batched_tuning(int rows_per_wave, int unroll); /* benchmark-only; 0 = built-in */
+
+/*
  * Recursive-least-squares training of a readout edge (reference RLS.update, rectipy/edges.py:227-234, driven by
  * Network._rls, rectipy/network.py:1093-1121).  P is the n_in x n_in state-error correlation matrix.
  */

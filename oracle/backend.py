@@ -110,6 +110,26 @@ class OracleBackend:
     def shard_partial_rows(self, n, rows):
         return min(64, (rows + 7) // 8)  # upper bound of Q for every RC(n, rows) (chunks hold >= 8 rows, Q <= 64)
 
+    def forward_batched(self, net, bt, device):
+        """rp_forward_batched on the oracle: the B trajectories are independent, so each is one oracle_forward on its own
+        rows of the [B x ld] buffers (the batched kernel must reproduce exactly that, bit for bit)."""
+        B = int(bt.batch)
+        for b in range(B):
+            nb = _abi.RpNet()
+            C.memmove(C.byref(nb), C.byref(net), C.sizeof(_abi.RpNet))
+            nb.y[_abi.RP_Y_V] = bt.v + 4 * b * bt.ldv
+            nb.src[0], nb.src[1] = bt.src[0] + 4 * b * bt.ldsrc, bt.src[1] + 4 * b * bt.ldsrc
+            nb.cur = bt.cur
+            nb.sp_vals = None
+            run = _abi.RpRun()
+            run.steps, run.x_mode, run.out_var, run.sampling_steps = bt.steps, bt.x_mode, bt.out_var, 1
+            if bt.x:
+                run.x, run.ldx = bt.x + 4 * b * bt.ldx, B * bt.ldx
+            if bt.traj:
+                run.traj, run.ldtraj = bt.traj + 4 * b * bt.ldtraj, B * bt.ldtraj
+            assert self.lib.oracle_forward(C.byref(nb), C.byref(run)) == 0
+        bt.cur = (bt.cur + bt.steps) % 2
+
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
         assert self.lib.oracle_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss) == 0
 

@@ -1,0 +1,251 @@
+// rnn_batched.hip -- B independent trajectories through one coupling matrix (rp_forward_batched).
+//
+// The unbatched step is a mat-vec: 4 N^2 bytes of W for 2 N^2 flop, HBM-bound at 0.5 flop/byte.  B trajectories that
+// share W (trials of one network, an ensemble of initial conditions, input sweeps) turn the step into W @ [r_0 .. r_B-1]:
+// W is streamed ONCE per step and reused B times from registers, so the cost per trajectory-step drops by up to B until
+// the vector ALUs bind (0.5 B flop/byte).  The reference (rectipy/nodes.py:166-170, rectipy/network.py:588-599) has no
+// batch axis and would run the trajectories one after the other.
+//
+// Summation order: exactly that of rp_dot_rows_v4 (rp_dot.h) per trajectory -- lane l keeps four accumulators per
+// (row, trajectory) for the columns 256 m + 4 l .. +3, chunks from the staggered start m0 with wrap-around, partial
+// chunk last, lane sum (a0+a1)+(a2+a3), fixed butterfly -- so trajectory b of a batched call reproduces an unbatched
+// rp_forward on the same state bit for bit (tests/test_batched.py).
+
+#include "rp_common.h"
+#include "rp_dot.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct BatchParams {
+    const float* W;
+    int64_t ldw;
+    int n, rows, row0;
+    const float* p[RP_MAX_PARAMS];
+    float dt;
+    float* v;
+    int64_t ldv;
+    const float* src_cur;
+    float* src_next;
+    int64_t ldsrc;
+    int x_mode;
+    const float* x_t;  // row (t, 0)
+    int64_t ldx;
+    int out_var;
+    float* traj_t;     // row (t, 0)
+    int64_t ldtraj;
+};
+
+template <int MODEL>
+__device__ __forceinline__ float act(const BatchParams& P, int i, float v) {
+    if constexpr (MODEL == RP_MODEL_LI_TANH) {
+        return rp_tanhf(v);
+    } else {  // leaky_integrator.yaml:22
+        const float e = rp_expf(P.p[RP_P_SLOPE][i] * (P.p[RP_P_V0][i] - v));
+        return P.p[RP_P_RMAX][i] / (1.0f + e);
+    }
+}
+
+// RateNet.forward (nodes.py:166-170) with the field of leaky_integrator.yaml:10 for neuron i of trajectory b
+template <int MODEL>
+__device__ __forceinline__ void epilogue(const BatchParams& P, int i, int b, float wsum) {
+    const int gi = P.row0 + i;
+    float I = 0.f;
+    if (P.x_mode == RP_X_FULL) I = P.x_t[(int64_t)b * P.ldx + i];
+    else if (P.x_mode == RP_X_BCAST) I = P.x_t[(int64_t)b * P.ldx];
+    float* vb = P.v + (int64_t)b * P.ldv;
+    const float v = vb[i];
+    const float dv = ((-v / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * wsum) + I) + P.p[RP_P_ETA][i];
+    const float v_new = v + P.dt * dv;
+    vb[i] = v_new;
+    P.src_next[(int64_t)b * P.ldsrc + gi] = act<MODEL>(P, i, v_new);
+    if (P.traj_t)
+        P.traj_t[(int64_t)b * P.ldtraj + i] = P.out_var == RP_OUT_STATE0 ? v : P.src_cur[(int64_t)b * P.ldsrc + gi];
+}
+
+// one 256-column chunk: R loads of W, B loads of the sources, R * B * 4 fmaf (fully unrolled: the accumulators must
+// stay in registers)
+template <int R, int B>
+__device__ __forceinline__ void batched_chunk(const float* const (&wrow)[R], const float* sp, int64_t ldsrc, int m,
+                                              rp_f4 (&a)[R][B]) {
+    rp_f4 w[R];
+#pragma clang loop unroll(full)
+    for (int j = 0; j < R; ++j) w[j] = rp_ld4_stream(wrow[j] + (int64_t)m * 256);
+#pragma clang loop unroll(full)
+    for (int b = 0; b < B; ++b) {
+        const rp_f4 s = rp_ld4(sp + (int64_t)b * ldsrc + (int64_t)m * 256);
+#pragma clang loop unroll(full)
+        for (int j = 0; j < R; ++j) {
+            a[j][b].x = fmaf(w[j].x, s.x, a[j][b].x);
+            a[j][b].y = fmaf(w[j].y, s.y, a[j][b].y);
+            a[j][b].z = fmaf(w[j].z, s.z, a[j][b].z);
+            a[j][b].w = fmaf(w[j].w, s.w, a[j][b].w);
+        }
+    }
+}
+
+// One wave owns R consecutive rows and all B trajectories: R * B accumulator sets (R * B <= 32).
+template <int MODEL, int R, int B, int U>
+__global__ __launch_bounds__(kThreads) void step_batched_kernel(const BatchParams P) {
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int groups = (P.rows + R - 1) / R;
+    const int M = P.n >> 8;
+    for (int g = blockIdx.x * (kThreads / RP_WAVE) + wave; g < groups; g += gridDim.x * (kThreads / RP_WAVE)) {
+        const int row_base = g * R;
+        const float* wrow[R];
+#pragma clang loop unroll(full)
+        for (int j = 0; j < R; ++j) {
+            int rr = row_base + j;
+            rr = rr < P.rows ? rr : P.rows - 1;  // clamp: tail rows re-read a valid row, result discarded
+            wrow[j] = P.W + (int64_t)rr * P.ldw + 4 * lane;
+        }
+        const float* sp = P.src_cur + 4 * lane;
+        rp_f4 a[R][B];
+#pragma clang loop unroll(full)
+        for (int j = 0; j < R; ++j)
+#pragma clang loop unroll(full)
+            for (int b = 0; b < B; ++b) a[j][b] = rp_f4{0.f, 0.f, 0.f, 0.f};
+        const int m0 = M > 0 ? (int)(((unsigned)((P.row0 + row_base) >> 3) * kStagger) % (unsigned)M) : 0;
+        // chunks m0 .. M-1, then 0 .. m0-1 (two ascending sweeps, U chunks per iteration), the partial chunk last
+        for (int pass = 0; pass < 2; ++pass) {
+            int m = pass == 0 ? m0 : 0;
+            const int mB = pass == 0 ? M : m0;
+            for (; m + U <= mB; m += U) {
+#pragma clang loop unroll(full)
+                for (int u = 0; u < U; ++u) batched_chunk<R, B>(wrow, sp, P.ldsrc, m + u, a);
+            }
+            for (; m < mB; ++m) batched_chunk<R, B>(wrow, sp, P.ldsrc, m, a);
+        }
+        if ((M << 8) + 4 * lane < P.n) batched_chunk<R, B>(wrow, sp, P.ldsrc, M, a);  // partial last chunk (n % 4 == 0)
+        float mine = 0.f;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < R; ++j)
+#pragma clang loop unroll(full)
+            for (int b = 0; b < B; ++b) {
+                const float sum = rp_wave_allreduce(rp_lane_sum4(a[j][b]));
+                if (lane == j * B + b) mine = sum;
+            }
+        if (lane < R * B) {
+            const int j = lane / B, b = lane - j * B;
+            if (row_base + j < P.rows) epilogue<MODEL>(P, row_base + j, b, mine);
+        }
+    }
+}
+
+template <int MODEL, int R, int B, int U>
+void launch(const BatchParams& P, hipStream_t st) {
+    const int groups = (P.rows + R - 1) / R;
+    int blocks = (groups + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((step_batched_kernel<MODEL, R, B, U>), dim3(blocks), dim3(kThreads), 0, st, P);
+}
+
+int g_bt_R = 0, g_bt_U = 0;  // benchmark-only override (rp_set_batched_tuning)
+
+template <int MODEL>
+int launch_model(const BatchParams& P, int B, hipStream_t st) {
+    // R * B accumulator sets of four floats per lane; W chunks in flight per wave: R * U KiB
+    if constexpr (MODEL == RP_MODEL_LI_TANH) {  // benchmark-only sweep
+        const int key = B * 100 + g_bt_R * 10 + g_bt_U;
+        switch (key) {
+            case 481: launch<MODEL, 8, 4, 1>(P, st); return RP_OK;
+            case 482: launch<MODEL, 8, 4, 2>(P, st); return RP_OK;
+            case 441: launch<MODEL, 4, 4, 1>(P, st); return RP_OK;
+            case 822: launch<MODEL, 2, 8, 2>(P, st); return RP_OK;
+            case 824: launch<MODEL, 2, 8, 4>(P, st); return RP_OK;
+            case 842: launch<MODEL, 4, 8, 2>(P, st); return RP_OK;
+            case 1621: launch<MODEL, 2, 16, 1>(P, st); return RP_OK;
+            case 1614: launch<MODEL, 1, 16, 4>(P, st); return RP_OK;
+            case 1612: launch<MODEL, 1, 16, 2>(P, st); return RP_OK;
+            default: break;
+        }
+    }
+    switch (B) {
+        case 2: launch<MODEL, 4, 2, 2>(P, st); return RP_OK;
+        // measured at N = 32768 (scripts/bench_batched.py): B=2 1.98x, B=4 3.91x, B=8 5.74x, B=16 5.92x the throughput of
+        // B unbatched runs; from B = 8 the L2 -> CU path (B source loads per R rows of W) and the register budget bind
+        case 4: launch<MODEL, 8, 4, 2>(P, st); return RP_OK;
+        case 8: launch<MODEL, 4, 8, 1>(P, st); return RP_OK;
+        case 16: launch<MODEL, 2, 16, 1>(P, st); return RP_OK;
+        default: return RP_ERR_ARG;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rp_sizeof_batch(void) { return (int)sizeof(rp_batch); }
+
+int rp_set_batched_tuning(int rows_per_wave, int unroll) {
+    g_bt_R = rows_per_wave;
+    g_bt_U = unroll;
+    return RP_OK;
+}
+
+int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
+    if (!net || !bt) RP_FAIL(RP_ERR_ARG, "net / batch is null");
+    if (net->model != RP_MODEL_LI_TANH && net->model != RP_MODEL_LI_SIGMOID)
+        RP_FAIL(RP_ERR_ARG, "rp_forward_batched covers the rate models (LI_TANH, LI_SIGMOID), got model %d", net->model);
+    const int B = bt->batch;
+    if (B != 2 && B != 4 && B != 8 && B != 16) RP_FAIL(RP_ERR_ARG, "batch must be 2, 4, 8 or 16, got %d", B);
+    if (net->n <= 0 || net->rows <= 0 || net->row0 < 0 || net->row0 + net->rows > net->n)
+        RP_FAIL(RP_ERR_SHAPE, "bad shard geometry n=%d rows=%d row0=%d", net->n, net->rows, net->row0);
+    if (net->row0 % 8 != 0) RP_FAIL(RP_ERR_ARG, "row0=%d must be a multiple of 8", net->row0);
+    if (net->n % 4 != 0 || net->ldw % 4 != 0 || net->ldw < net->n)
+        RP_FAIL(RP_ERR_SHAPE, "the batched step needs n %% 4 == 0 and ldw %% 4 == 0 (n=%d, ldw=%lld)", net->n, (long long)net->ldw);
+    if (!net->W || !bt->v || !bt->src[0] || !bt->src[1] || bt->src[0] == bt->src[1])
+        RP_FAIL(RP_ERR_ARG, "W, v, src[0], src[1] must be non-null (and the two source buffers distinct)");
+    if (bt->ldv < net->rows || bt->ldsrc < net->n || bt->ldsrc % 4 != 0)
+        RP_FAIL(RP_ERR_SHAPE, "ldv >= rows, ldsrc >= n and ldsrc %% 4 == 0 required");
+    if ((reinterpret_cast<uintptr_t>(net->W) & 15u) || (reinterpret_cast<uintptr_t>(bt->src[0]) & 15u) ||
+        (reinterpret_cast<uintptr_t>(bt->src[1]) & 15u))
+        RP_FAIL(RP_ERR_ARG, "W and the source buffers must be 16-byte aligned");
+    if (bt->cur != 0 && bt->cur != 1) RP_FAIL(RP_ERR_ARG, "cur must be 0 or 1");
+    if (bt->steps < 0) RP_FAIL(RP_ERR_ARG, "steps < 0");
+    if (bt->x_mode != RP_X_NONE && bt->x_mode != RP_X_FULL && bt->x_mode != RP_X_BCAST)
+        RP_FAIL(RP_ERR_ARG, "x_mode must be RP_X_NONE, RP_X_FULL or RP_X_BCAST");
+    if (bt->x_mode != RP_X_NONE && (!bt->x || bt->ldx < (bt->x_mode == RP_X_FULL ? net->rows : 1)))
+        RP_FAIL(RP_ERR_SHAPE, "inputs missing or rows too short");
+    if (bt->traj && bt->ldtraj < net->rows) RP_FAIL(RP_ERR_SHAPE, "ldtraj < rows");
+    const int need[] = {RP_P_TAU, RP_P_K, RP_P_ETA};
+    for (int q = 0; q < 3; ++q)
+        if (!net->p[need[q]]) RP_FAIL(RP_ERR_ARG, "parameter slot %d is null", need[q]);
+    if (net->model == RP_MODEL_LI_SIGMOID && (!net->p[RP_P_RMAX] || !net->p[RP_P_SLOPE] || !net->p[RP_P_V0]))
+        RP_FAIL(RP_ERR_ARG, "sigmoid parameters missing");
+    if (!(net->dt > 0.f)) RP_FAIL(RP_ERR_ARG, "dt must be > 0");
+
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    BatchParams P = {};
+    P.W = net->W;
+    P.ldw = net->ldw;
+    P.n = net->n;
+    P.rows = net->rows;
+    P.row0 = net->row0;
+    for (int q = 0; q < RP_MAX_PARAMS; ++q) P.p[q] = net->p[q];
+    P.dt = net->dt;
+    P.v = bt->v;
+    P.ldv = bt->ldv;
+    P.ldsrc = bt->ldsrc;
+    P.x_mode = bt->x_mode;
+    P.ldx = bt->ldx;
+    P.out_var = bt->out_var;
+    P.ldtraj = bt->ldtraj;
+    for (int t = 0; t < bt->steps; ++t) {
+        P.src_cur = bt->src[bt->cur];
+        P.src_next = bt->src[bt->cur ^ 1];
+        P.x_t = bt->x ? bt->x + (int64_t)t * B * bt->ldx : nullptr;
+        P.traj_t = bt->traj ? bt->traj + (int64_t)t * B * bt->ldtraj : nullptr;
+        const int rc = net->model == RP_MODEL_LI_TANH ? launch_model<RP_MODEL_LI_TANH>(P, B, st)
+                                                      : launch_model<RP_MODEL_LI_SIGMOID>(P, B, st);
+        if (rc != RP_OK) RP_FAIL(rc, "no batched kernel for batch %d", B);
+        if (t == 0) RP_HIP_CHECK(hipGetLastError());
+        bt->cur ^= 1;
+    }
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
+}  // extern "C"

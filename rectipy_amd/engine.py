@@ -130,6 +130,10 @@ class HipBackend:
             self._lib_mod.check(self.lib.rp_backward_sharded(C.byref(net), C.byref(bwd), C.byref(comm),
                                                                   self._stream(device)))
 
+    def forward_batched(self, net, batch, device):
+        with self._on(device):
+            self._lib_mod.check(self.lib.rp_forward_batched(C.byref(net), C.byref(batch), self._stream(device)))
+
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
         with self._on(device):
             self._lib_mod.check(self.lib.rp_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss,
@@ -568,3 +572,76 @@ class Population:
         self.backend.outer_accum(self.n, T, float(alpha), A.data_ptr(), A.stride(0) if T > 1 else A.shape[1],
                                  B.data_ptr(), B.stride(0) if T > 1 else B.shape[1], Cmat.data_ptr(),
                                  Cmat.stride(0), self.device)
+
+
+class BatchedPopulation:
+    """B independent trajectories of ONE rate population (same W, same per-neuron parameters; different states and
+    inputs) advanced together: every Euler step streams W once for all of them (``rp_forward_batched``).  The reference
+    has no batch axis -- B trials of a network are B passes of its time loop, each streaming W again.  Trajectory b is
+    bit-identical to an unbatched :class:`Population` run on the same state.  Rate models, n % 4 == 0, B in {2, 4, 8, 16}.
+    """
+
+    BATCHES = (2, 4, 8, 16)
+
+    def __init__(self, pop: Population, batch: int, v0=None):
+        if pop.spiking:
+            raise NotImplementedError("batched trajectories cover the rate models (li_tanh, li_sigmoid)")
+        if batch not in self.BATCHES:
+            raise ValueError(f"batch must be one of {self.BATCHES}, got {batch}")
+        if pop.n % 4 or pop.W.stride(0) % 4:
+            raise ValueError("batched trajectories need n % 4 == 0")
+        self.pop, self.batch = pop, int(batch)
+        f32 = dict(dtype=torch.float32, device=pop.device)
+        self.v = torch.zeros(batch, pop.rows, **f32)
+        if v0 is not None:
+            self.v.copy_(torch.as_tensor(v0, dtype=torch.float32).to(pop.device).expand(batch, pop.rows))
+        self.src = [torch.zeros(batch, pop.n, **f32), torch.zeros(batch, pop.n, **f32)]
+        self.cur = 0
+        self.refresh()
+
+    def refresh(self):
+        """r_b = act(v_b) after the states were set from the host (through the unbatched refresh kernel, row by row)."""
+        pop = self.pop
+        keep_v, keep_src, keep_cur = pop.v, pop.src, pop.cur
+        try:
+            for b in range(self.batch):
+                pop.v, pop.src, pop.cur = self.v[b], [self.src[self.cur][b], self.src[self.cur ^ 1][b]], 0
+                pop._net_cache = None
+                pop.refresh()
+        finally:
+            pop.v, pop.src, pop.cur = keep_v, keep_src, keep_cur
+            pop._net_cache = None
+
+    @property
+    def source(self) -> torch.Tensor:
+        return self.src[self.cur]
+
+    def forward(self, steps: int, x: Optional[torch.Tensor] = None, traj: Optional[torch.Tensor] = None,
+                out_var: int = _abi.RP_OUT_STATE0):
+        """`steps` Euler steps of all trajectories.  x: None | [steps, B, rows] | [steps, B, 1];
+        traj: optional [steps, B, rows] receiving the pre-update outputs."""
+        pop, B = self.pop, self.batch
+        bt = _abi.RpBatch()
+        bt.batch, bt.steps = B, int(steps)
+        bt.v, bt.ldv = self.v.data_ptr(), self.v.stride(0)
+        bt.src[0], bt.src[1], bt.ldsrc = self.src[0].data_ptr(), self.src[1].data_ptr(), self.src[0].stride(0)
+        bt.cur = self.cur
+        keep = []
+        if x is None:
+            bt.x_mode = _abi.RP_X_NONE
+        else:
+            if x.dim() != 3 or x.shape[0] < steps or x.shape[1] != B or x.shape[2] not in (1, pop.rows):
+                raise RuntimeError(f"inputs must be [>= {steps}, {B}, {pop.rows} or 1], got {tuple(x.shape)}")
+            x = x.detach().to(dtype=torch.float32, device=pop.device).contiguous()
+            keep.append(x)
+            bt.x, bt.ldx = x.data_ptr(), x.shape[2]
+            bt.x_mode = _abi.RP_X_FULL if x.shape[2] == pop.rows and pop.rows != 1 else _abi.RP_X_BCAST
+        bt.out_var = int(out_var)
+        if traj is not None:
+            if traj.dtype != torch.float32 or traj.device != pop.device or traj.dim() != 3 or not traj.is_contiguous() \
+                    or traj.shape[0] < steps or traj.shape[1] != B or traj.shape[2] < pop.rows:
+                raise RuntimeError(f"traj must be a contiguous float32 [>= {steps}, {B}, >= {pop.rows}] tensor on {pop.device}")
+            bt.traj, bt.ldtraj = traj.data_ptr(), traj.shape[2]
+        pop.backend.forward_batched(pop._net(), bt, pop.device)
+        self.cur = bt.cur
+        del keep

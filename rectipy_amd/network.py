@@ -345,6 +345,71 @@ class Network:
         self._run_stepwise(inputs, sampling_steps, cutoff, truncate_steps, obs, rec_vars, enable_grad, verbose)
         return obs
 
+    # ---- B trajectories through one pass over W -------------------------------------------------------
+    def run_batch(self, inputs, sampling_steps: int = 1, cutoff: int = 0, y0=None, verbose: bool = False) -> List[Observer]:
+        """Integrate B independent trajectories of the SAME network -- ``inputs``: [B, T, m] -- and return one
+        :class:`Observer` per trajectory, each as :meth:`run` would have produced it for ``inputs[b]`` from the same
+        initial state (``y0``: [B, N] initial states of the population; default: its current state for every b).
+
+        Not part of the reference's API (it has no batch axis: B trials are B passes of its time loop, each streaming W
+        again).  Here every Euler step streams W ONCE for all B trajectories (``rp_forward_batched``), trajectory b being
+        bit-identical to an unbatched run.  Chain topologies around one RATE population; the network's own state is
+        left untouched."""
+        from .engine import BatchedPopulation
+        self.compile()
+        plan = self._chain_plan()
+        if plan is None:
+            raise NotImplementedError("run_batch needs a chain [inputs] -> one population -> [read-out]")
+        pre, label, post = plan
+        rnn: RateNet = self.get_node(label)
+        pop = rnn._pop
+        if isinstance(rnn, SpikeResetNet):
+            raise NotImplementedError("run_batch covers the rate templates")
+        dev = self.device if self._backend is None else "cpu"
+        X = torch.as_tensor(inputs).to(device=dev, dtype=torch.float32)
+        if X.dim() != 3:
+            raise RuntimeError(f"inputs must be [B, T, m], got {tuple(X.shape)}")
+        B, T = int(X.shape[0]), int(X.shape[1])
+        sample_at = self._sample_steps(T, cutoff, sampling_steps)
+        N = pop.rows
+        start = pop.v.detach().clone().expand(B, N) if y0 is None else \
+            torch.as_tensor(y0).to(device=dev, dtype=torch.float32).reshape(B, N)
+        if pre:  # input nodes / edges act on every (b, t) row alike
+            X = self._apply_chain(pre, X.reshape(B * T, -1), None, label).reshape(B, T, -1)
+        self._fit_width(X.reshape(B * T, -1), N)
+        per_step = torch.empty(B, T, N, dtype=torch.float32, device=pop.device)
+        finals = torch.empty(B, N, dtype=torch.float32, device=pop.device)
+        chunk = max(1, min(T, _WINDOW_BYTES // (4 * N * 16)))
+        for b0 in range(0, B, 16):  # groups of at most 16 trajectories, padded to a supported batch size
+            nb = min(16, B - b0)
+            size = next(q for q in BatchedPopulation.BATCHES if q >= nb) if nb > 1 else 2
+            bp = BatchedPopulation(pop, size)
+            bp.v.zero_()
+            bp.v[:nb] = start[b0:b0 + nb]
+            bp.refresh()
+            xb = torch.zeros(T, size, X.shape[2], dtype=torch.float32, device=pop.device)
+            xb[:, :nb] = X[b0:b0 + nb].transpose(0, 1)
+            for a in range(0, T, chunk):
+                e = min(a + chunk, T)
+                traj = torch.empty(e - a, size, N, dtype=torch.float32, device=pop.device)
+                bp.forward(e - a, x=xb[a:e], traj=traj, out_var=rnn._out_code)
+                per_step[b0:b0 + nb, a:e] = traj[:, :nb].transpose(0, 1)
+                if verbose:
+                    print(f"Progress: trajectories {b0}..{b0 + nb - 1}, {e}/{T} integration steps finished.")
+            finals[b0:b0 + nb] = bp.v[:nb]
+        out = per_step if not post else self._apply_chain(post, per_step.reshape(B * T, N), label, None).reshape(B, T, -1)
+        observers = []
+        for b in range(B):
+            rows, begin = [], cutoff
+            for t in sample_at:  # mean over the steps buffered since the previous sample (network.py:595)
+                rows.append(out[b, begin:t + 1].mean(dim=0))
+                begin = t + 1
+            obs = Observer(dt=self.dt, record_loss=False)
+            obs.record_block(sample_at, torch.stack(rows) if rows else out[b, :0], 0.0, [])
+            obs.save("state", finals[b].clone())
+            observers.append(obs)
+        return observers
+
     # ---- several populations without cycles: one fused window per population ---------------------
     def _dag_plan(self, rec_vars) -> Optional[List[int]]:
         """Record slots of `rec_vars` when the (acyclic) graph can be evaluated window by window -- every node a

@@ -1,0 +1,127 @@
+"""B independent trajectories through one coupling matrix (rp_forward_batched, engine.BatchedPopulation): W is streamed
+once per step for all of them.  Trajectory b of a batched run must reproduce an UNBATCHED run on the same state bit for
+bit (same accumulators, same chunk order, same butterfly), on the oracle (host logic) and on the GPU (kernel)."""
+import numpy as np
+import pytest
+import torch
+
+from rectipy_amd import _abi
+from rectipy_amd.engine import BatchedPopulation, Population
+
+TARGETS = [pytest.param("oracle", id="oracle"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture
+def target(request, oracle_backend):
+    if request.param == "oracle":
+        return dict(device="cpu", backend=oracle_backend)
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    return dict(device="cuda:0", backend=None)
+
+
+def network(n, model, seed):
+    g = torch.Generator().manual_seed(seed)
+    W = torch.randn(n, n, generator=g) * 1.5 / n ** 0.5
+    params = dict(tau=torch.rand(n, generator=g) * 5 + 5, k=torch.rand(n, generator=g) + 0.5, eta=torch.randn(n, generator=g) * 0.1)
+    if model == "li_sigmoid":
+        params.update(r_max=torch.rand(n, generator=g) + 0.5, s=torch.rand(n, generator=g) * 2 + 0.5,
+                      v0=torch.randn(n, generator=g) * 0.2)
+    return W, params
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("model,n,B,xw", [("li_tanh", 64, 2, "full"), ("li_tanh", 260, 4, "bcast"), ("li_sigmoid", 516, 8, "full"),
+                                         ("li_tanh", 1028, 16, "none"), ("li_tanh", 2048, 8, "full")])
+def test_batched_equals_unbatched_runs(target, model, n, B, xw):
+    dev, backend = target["device"], target["backend"]
+    W, params = network(n, model, seed=n + B)
+    g = torch.Generator().manual_seed(7)
+    T = 25
+    v0 = torch.randn(B, n, generator=g)
+    x = {"full": torch.randn(T, B, n, generator=g) * 0.5, "bcast": torch.randn(T, B, 1, generator=g), "none": None}[xw]
+    pop = Population(model, W, params, 1e-2, dev, backend=backend)
+    bp = BatchedPopulation(pop, B)
+    bp.v.copy_(v0.to(dev))
+    bp.refresh()
+    traj = torch.zeros(T, B, n, device=dev)
+    bp.forward(10, x=None if x is None else x[:10].to(dev), traj=traj[:10], out_var=_abi.RP_OUT_SOURCE)
+    bp.forward(T - 10, x=None if x is None else x[10:].to(dev), traj=traj[10:], out_var=_abi.RP_OUT_SOURCE)
+    for b in range(B):
+        single = Population(model, W, params, 1e-2, dev, backend=backend, v0=v0[b])
+        tr = torch.zeros(T, n, device=dev)
+        single.forward(T, x=None if x is None else x[:, b].to(dev), traj=tr, out_var=_abi.RP_OUT_SOURCE)
+        for a, c, name in ((traj[:, b], tr, "trajectory"), (bp.v[b], single.v, "v"), (bp.source[b], single.source, "source")):
+            a, c = a.cpu().numpy(), c.cpu().numpy()
+            same = (a.view(np.uint32) == c.view(np.uint32)) | ((a == 0) & (c == 0))
+            assert same.all(), f"{model} n={n} B={B} trajectory {b} {name}: {np.count_nonzero(~same)} differ"
+    assert np.abs(np.diff(traj.cpu().numpy(), axis=0)).max() > 0
+
+
+@pytest.mark.gpu
+def test_batched_hip_equals_oracle(oracle_backend, hip_device):
+    """The kernel against the oracle directly (ragged row count, partial last chunk, state-variable output)."""
+    n, B, T = 1036, 4, 30
+    W, params = network(n, "li_tanh", seed=3)
+    g = torch.Generator().manual_seed(9)
+    v0 = torch.randn(B, n, generator=g)
+    x = torch.randn(T, B, n, generator=g) * 0.5
+    res = []
+    for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+        bp = BatchedPopulation(Population("li_tanh", W, params, 1e-2, dev, backend=backend), B)
+        bp.v.copy_(v0.to(dev))
+        bp.refresh()
+        traj = torch.zeros(T, B, n, device=dev)
+        bp.forward(T, x=x.to(dev), traj=traj)
+        res.append((traj.cpu().numpy(), bp.v.cpu().numpy(), bp.source.cpu().numpy()))
+    for a, c in zip(*res):
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+
+
+def test_batched_argument_errors(oracle_backend):
+    W, params = network(64, "li_tanh", seed=1)
+    pop = Population("li_tanh", W, params, 1e-2, "cpu", backend=oracle_backend)
+    with pytest.raises(ValueError):
+        BatchedPopulation(pop, 3)
+    bp = BatchedPopulation(pop, 2)
+    with pytest.raises(RuntimeError):
+        bp.forward(5, x=torch.zeros(5, 3, 64))
+    qif = Population("qif", W.abs(), dict(tau=1.0, k=1.0, eta=-5.0, tau_s=1.0), 1e-3, "cpu", backend=oracle_backend)
+    with pytest.raises(NotImplementedError):
+        BatchedPopulation(qif, 2)
+    odd = Population("li_tanh", torch.zeros(10, 10), dict(tau=1.0, k=1.0, eta=0.0), 1e-2, "cpu", backend=oracle_backend)
+    with pytest.raises(ValueError):
+        BatchedPopulation(odd, 2)
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_network_run_batch_equals_separate_runs(target):
+    """Network.run_batch: B = 3 trajectories (padded to 4 inside) through inp -> Linear -> rnn -> Linear -> out with
+    cutoff and buffer-mean sampling equal three separate Network.run calls from the same initial state, bit for bit."""
+    from rectipy_amd import Network
+    n, m, k, T, B = 64, 3, 2, 40, 3
+    rng = np.random.default_rng(5)
+    W, W_in, W_out = rng.standard_normal((n, n)) / n ** 0.5, rng.standard_normal((n, m)), rng.standard_normal((k, n))
+    x = rng.standard_normal((B, T, m)).astype(np.float32)
+    y0 = rng.standard_normal(n).astype(np.float32)
+
+    def build():
+        net = Network(1e-2, **target)
+        net.add_func_node("inp", m, "identity")
+        net.add_diffeq_node("rnn", "neuron_model_templates.rate_neurons.leaky_integrator.tanh", weights=W,
+                            source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext", output_var="tanh_op/r",
+                            node_vars={"all/li_op/v": y0}, dtype=torch.float32)
+        net.add_func_node("out", k, "identity")
+        net.add_edge("inp", "rnn", weights=W_in)
+        net.add_edge("rnn", "out", weights=W_out)
+        return net
+
+    net = build()
+    batch = net.run_batch(x, sampling_steps=3, cutoff=4)
+    assert len(batch) == B and np.array_equal(net.state["rnn"].cpu().numpy(), y0)  # the network's own state is untouched
+    for b in range(B):
+        single = build()
+        obs = single.run(x[b], sampling_steps=3, cutoff=4, verbose=False, enable_grad=False)
+        assert list(obs["steps"]) == list(batch[b]["steps"])
+        assert np.allclose(obs.to_numpy("out"), batch[b].to_numpy("out"), atol=1e-6)
+        assert torch.equal(single.state["rnn"], batch[b]["state"])
