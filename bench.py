@@ -437,7 +437,7 @@ def batched_extra(pop, N, dev, ms_single, T=200):
     res = {"workload": f"tanh rate RNN N={N}, B trajectories per pass over W, {T} timed steps each, broadcast input",
            "unit": "trajectory-steps/s"}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for B in (2, 4, 8, 16):
+    for B in (2, 4, 8, 16, 32):  # 2..8: vector ALUs (bit-identical to unbatched runs); 16, 32: exact-fp32 MFMA
         bp = BatchedPopulation(pop, B)
         bp.v.normal_(generator=torch.Generator(device=dev).manual_seed(B))
         bp.refresh()
@@ -449,7 +449,7 @@ def batched_extra(pop, N, dev, ms_single, T=200):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / T
-        res[f"B{B}"] = {"trajectory_steps_per_s": B * 1e3 / ms, "ms_per_step": ms,
+        res[f"B{B}"] = {"form": "mfma_f32_32x32x2" if bp.mfma else "valu", "trajectory_steps_per_s": B * 1e3 / ms, "ms_per_step": ms,
                         "vs_unbatched": B * ms_single / ms, "W_stream_GBps": 4.0 * N * N / (ms * 1e-3) / 1e9,
                         "fma_TFLOPs": 2.0 * N * N * B / (ms * 1e-3) / 1e12,
                         "state_finite": bool(torch.isfinite(bp.v).all().item())}

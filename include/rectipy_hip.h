@@ -361,7 +361,18 @@ typedef struct rp_batch {
     int32_t out_var;          /* RP_OUT_*                                                        */
     float* traj;              /* optional: pre-update output of (t, b) at traj + (t * B + b) * ldtraj */
     int64_t ldtraj;
+    /* layout = RP_BATCH_MFMA: the contraction W @ [r_0 .. r_31] runs on the matrix cores (v_mfma_f32_32x32x2_f32, exact
+       fp32) with up to 32 trajectories per pass over W.  State is NEURON-major then: v = [rows x 32], src[k] = [n x 32]
+       (slot b of neuron i at i * 32 + b; ldv / ldsrc are ignored), batch <= 32 names the slots in use.  Summation order
+       per (row i, trajectory b): column tiles of 64 from tile (3 * ((row0 + i) >> 7)) mod tiles with wrap-around; inside
+       a tile the columns 8 q + {0, 4, 1, 5, 2, 6, 3, 7} for q = 0..7, one fmaf chain (mirrored by the oracle).  Equal to
+       the unbatched run up to fp32 rounding (different order), not bit for bit. */
+    int32_t layout;           /* RP_BATCH_VALU (0) | RP_BATCH_MFMA (1)                               */
 } rp_batch;
+
+#define RP_BATCH_VALU 0
+#define RP_BATCH_MFMA 1
+#define RP_BATCH_SLOTS 32
 
 int rp_sizeof_batch(void);
 int rp_forward_batched(const rp_net* net, rp_batch* batch, void* stream);

@@ -60,6 +60,7 @@ def _declare(lib):
     sig("oracle_bwd_prepare", C.c_int, [P(RpNet), P(RpBwd)])
     sig("oracle_bwd_partial", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp])
     sig("oracle_bwd_apply", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp])
+    sig("oracle_forward_batched_mfma", C.c_int, [P(RpNet), P(_abi.RpBatch)])
     sig("oracle_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp])
     sig("oracle_expf", C.c_float, [C.c_float])
     sig("oracle_tanhf", C.c_float, [C.c_float])
@@ -114,6 +115,9 @@ class OracleBackend:
         """rp_forward_batched on the oracle: the B trajectories are independent, so each is one oracle_forward on its own
         rows of the [B x ld] buffers (the batched kernel must reproduce exactly that, bit for bit)."""
         B = int(bt.batch)
+        if bt.layout == _abi.RP_BATCH_MFMA:  # its own summation order: mirrored in C (oracle_forward_batched_mfma)
+            assert self.lib.oracle_forward_batched_mfma(C.byref(net), C.byref(bt)) == 0
+            return
         for b in range(B):
             nb = _abi.RpNet()
             C.memmove(C.byref(nb), C.byref(net), C.sizeof(_abi.RpNet))

@@ -6,6 +6,7 @@ struct sizes against the values the compiled library reports.
 import ctypes as C
 
 RP_ABI_VERSION = 7
+RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_SLOTS = 0, 1, 32
 
 RP_OK = 0
 RP_ERR_ARG = -1
@@ -167,6 +168,7 @@ class RpBatch(C.Structure):
         ("out_var", C.c_int32),
         ("traj", fp),
         ("ldtraj", C.c_int64),
+        ("layout", C.c_int32),
     ]
 
 

@@ -142,6 +142,106 @@ void launch(const BatchParams& P, hipStream_t st) {
     hipLaunchKernelGGL((step_batched_kernel<MODEL, R, B, U>), dim3(blocks), dim3(kThreads), 0, st, P);
 }
 
+// ---- matrix-core form: up to 32 trajectories per pass over W --------------------------------------------------------
+// C[128 rows x 32 slots] per workgroup = W[128 x n] @ R[n x 32] with v_mfma_f32_32x32x2_f32 (exact fp32: one fmaf chain
+// per output element).  Wave w owns rows 32 w .. 32 w + 31 of the block; the four waves walk the column tiles (64 columns)
+// in step, so one source tile R[64 x 32] per tile is shared through LDS.  W tiles are loaded coalesced (4 rows x 256 B per
+// wave instruction, non-temporal), parked in registers while the previous tile is multiplied, and written to the wave's
+// own LDS tile; MFMA operands are read back as one 16-byte LDS read (A: row l & 31, columns 8 q + 4 (l >> 5) .. +3) and
+// four 4-byte reads (B) per four MFMAs.  State is neuron-major ([n x 32]), so the C fragment (slot = lane & 31) reads
+// and writes it coalesced.  At 32 slots the MFMA pipe needs 0.7 of the time HBM needs to deliver the tile.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kMT = 64;        // columns per tile
+constexpr int kWs = 68;        // LDS row stride of a W tile (floats): rows 16-byte aligned, quarter-wave reads conflict-free
+constexpr int kRs = 40;        // LDS row stride of the source tile: the two half-waves of a B read hit disjoint banks
+constexpr int kSlots = RP_BATCH_SLOTS;
+
+template <int MODEL>
+__global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const BatchParams P, int batch) {
+    __shared__ __attribute__((aligned(16))) float Ws[4 * 32 * kWs];
+    __shared__ __attribute__((aligned(16))) float Rs[kMT * kRs];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int row_blk = blockIdx.x * 128;           // first local row of this workgroup
+    const int tiles = (P.n + kMT - 1) / kMT;
+    const int t0 = (int)((3u * (unsigned)((P.row0 + row_blk) >> 7)) % (unsigned)tiles);
+    float* myW = Ws + wave * 32 * kWs;
+
+    // global -> registers: the wave's 32 x 64 tile of W (8 loads of 4 rows x 256 B) and the block's 64 x 32 source tile
+    rp_f4 wreg[8], rreg[2];
+    auto load_tile = [&](int tile) {
+        const int c = tile * kMT + 4 * (lane & 15);
+#pragma clang loop unroll(full)
+        for (int q = 0; q < 8; ++q) {
+            int row = row_blk + 32 * wave + 4 * q + (lane >> 4);
+            row = row < P.rows ? row : P.rows - 1;  // clamp: rows past the end re-read a valid row, results discarded
+            wreg[q] = c < P.n ? rp_ld4_stream(P.W + (int64_t)row * P.ldw + c) : rp_f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma clang loop unroll(full)
+        for (int q = 0; q < 2; ++q) {  // 64 x 32 floats = 512 float4: thread t takes float4 t and t + 256
+            const int f = tid + 256 * q;
+            const int k = tile * kMT + (f >> 3);
+            rreg[q] = k < P.n ? rp_ld4(P.src_cur + (int64_t)k * kSlots + 4 * (f & 7)) : rp_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_tile = [&]() {
+#pragma clang loop unroll(full)
+        for (int q = 0; q < 8; ++q)
+            *reinterpret_cast<rp_f4*>(myW + (4 * q + (lane >> 4)) * kWs + 4 * (lane & 15)) = wreg[q];
+#pragma clang loop unroll(full)
+        for (int q = 0; q < 2; ++q) {
+            const int f = tid + 256 * q;
+            *reinterpret_cast<rp_f4*>(Rs + (f >> 3) * kRs + 4 * (f & 7)) = rreg[q];
+        }
+    };
+
+    f32x16 acc;
+#pragma clang loop unroll(full)
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    load_tile(t0);
+    for (int q = 0; q < tiles; ++q) {
+        __syncthreads();  // every wave is done with the previous source tile
+        store_tile();
+        __syncthreads();
+        if (q + 1 < tiles) load_tile((t0 + q + 1) % tiles);  // next tile in flight behind the MFMAs
+        const float* ap = myW + lr * kWs + 4 * lh;
+        const float* bp = Rs + (4 * lh) * kRs + lr;
+#pragma clang loop unroll(full)
+        for (int g = 0; g < kMT / 8; ++g) {
+            const rp_f4 a = *reinterpret_cast<const rp_f4*>(ap + 8 * g);
+            const float b0 = bp[(8 * g + 0) * kRs], b1 = bp[(8 * g + 1) * kRs];
+            const float b2 = bp[(8 * g + 2) * kRs], b3 = bp[(8 * g + 3) * kRs];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
+        }
+    }
+    // C/D layout of the 32x32 MFMA: slot = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (lr < batch) {
+#pragma clang loop unroll(full)
+        for (int r = 0; r < 16; ++r) {
+            const int i = row_blk + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (i < P.rows) {
+                const int gi = P.row0 + i, b = lr;
+                float I = 0.f;
+                if (P.x_mode == RP_X_FULL) I = P.x_t[(int64_t)b * P.ldx + i];
+                else if (P.x_mode == RP_X_BCAST) I = P.x_t[(int64_t)b * P.ldx];
+                float* vp = P.v + (int64_t)i * kSlots + b;
+                const float v = *vp;
+                const float dv = ((-v / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * acc[r]) + I) + P.p[RP_P_ETA][i];
+                const float v_new = v + P.dt * dv;
+                *vp = v_new;
+                P.src_next[(int64_t)gi * kSlots + b] = act<MODEL>(P, i, v_new);
+                if (P.traj_t)
+                    P.traj_t[(int64_t)b * P.ldtraj + i] =
+                        P.out_var == RP_OUT_STATE0 ? v : P.src_cur[(int64_t)gi * kSlots + b];
+            }
+        }
+    }
+}
+
 int g_bt_R = 0, g_bt_U = 0;  // benchmark-only override (rp_set_batched_tuning)
 
 template <int MODEL>
@@ -190,7 +290,10 @@ int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
     if (net->model != RP_MODEL_LI_TANH && net->model != RP_MODEL_LI_SIGMOID)
         RP_FAIL(RP_ERR_ARG, "rp_forward_batched covers the rate models (LI_TANH, LI_SIGMOID), got model %d", net->model);
     const int B = bt->batch;
-    if (B != 2 && B != 4 && B != 8 && B != 16) RP_FAIL(RP_ERR_ARG, "batch must be 2, 4, 8 or 16, got %d", B);
+    const bool mfma = bt->layout == RP_BATCH_MFMA;
+    if (bt->layout != RP_BATCH_VALU && !mfma) RP_FAIL(RP_ERR_ARG, "unknown batch layout %d", bt->layout);
+    if (mfma && (B < 1 || B > RP_BATCH_SLOTS)) RP_FAIL(RP_ERR_ARG, "the matrix-core form holds 1..%d trajectories, got %d", RP_BATCH_SLOTS, B);
+    if (!mfma && B != 2 && B != 4 && B != 8 && B != 16) RP_FAIL(RP_ERR_ARG, "batch must be 2, 4, 8 or 16, got %d", B);
     if (net->n <= 0 || net->rows <= 0 || net->row0 < 0 || net->row0 + net->rows > net->n)
         RP_FAIL(RP_ERR_SHAPE, "bad shard geometry n=%d rows=%d row0=%d", net->n, net->rows, net->row0);
     if (net->row0 % 8 != 0) RP_FAIL(RP_ERR_ARG, "row0=%d must be a multiple of 8", net->row0);
@@ -198,8 +301,9 @@ int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
         RP_FAIL(RP_ERR_SHAPE, "the batched step needs n %% 4 == 0 and ldw %% 4 == 0 (n=%d, ldw=%lld)", net->n, (long long)net->ldw);
     if (!net->W || !bt->v || !bt->src[0] || !bt->src[1] || bt->src[0] == bt->src[1])
         RP_FAIL(RP_ERR_ARG, "W, v, src[0], src[1] must be non-null (and the two source buffers distinct)");
-    if (bt->ldv < net->rows || bt->ldsrc < net->n || bt->ldsrc % 4 != 0)
+    if (!mfma && (bt->ldv < net->rows || bt->ldsrc < net->n || bt->ldsrc % 4 != 0))
         RP_FAIL(RP_ERR_SHAPE, "ldv >= rows, ldsrc >= n and ldsrc %% 4 == 0 required");
+    if (mfma && net->row0 % 128 != 0) RP_FAIL(RP_ERR_ARG, "row0=%d must be a multiple of 128 for the matrix-core form", net->row0);
     if ((reinterpret_cast<uintptr_t>(net->W) & 15u) || (reinterpret_cast<uintptr_t>(bt->src[0]) & 15u) ||
         (reinterpret_cast<uintptr_t>(bt->src[1]) & 15u))
         RP_FAIL(RP_ERR_ARG, "W and the source buffers must be 16-byte aligned");
@@ -238,9 +342,17 @@ int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
         P.src_next = bt->src[bt->cur ^ 1];
         P.x_t = bt->x ? bt->x + (int64_t)t * B * bt->ldx : nullptr;
         P.traj_t = bt->traj ? bt->traj + (int64_t)t * B * bt->ldtraj : nullptr;
-        const int rc = net->model == RP_MODEL_LI_TANH ? launch_model<RP_MODEL_LI_TANH>(P, B, st)
-                                                      : launch_model<RP_MODEL_LI_SIGMOID>(P, B, st);
-        if (rc != RP_OK) RP_FAIL(rc, "no batched kernel for batch %d", B);
+        if (mfma) {
+            const int blocks = (net->rows + 127) / 128;
+            if (net->model == RP_MODEL_LI_TANH)
+                hipLaunchKernelGGL(step_batched_mfma_kernel<RP_MODEL_LI_TANH>, dim3(blocks), dim3(kThreads), 0, st, P, B);
+            else
+                hipLaunchKernelGGL(step_batched_mfma_kernel<RP_MODEL_LI_SIGMOID>, dim3(blocks), dim3(kThreads), 0, st, P, B);
+        } else {
+            const int rc = net->model == RP_MODEL_LI_TANH ? launch_model<RP_MODEL_LI_TANH>(P, B, st)
+                                                          : launch_model<RP_MODEL_LI_SIGMOID>(P, B, st);
+            if (rc != RP_OK) RP_FAIL(rc, "no batched kernel for batch %d", B);
+        }
         if (t == 0) RP_HIP_CHECK(hipGetLastError());
         bt->cur ^= 1;
     }

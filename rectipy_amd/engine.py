@@ -577,27 +577,53 @@ class Population:
 class BatchedPopulation:
     """B independent trajectories of ONE rate population (same W, same per-neuron parameters; different states and
     inputs) advanced together: every Euler step streams W once for all of them (``rp_forward_batched``).  The reference
-    has no batch axis -- B trials of a network are B passes of its time loop, each streaming W again.  Trajectory b is
-    bit-identical to an unbatched :class:`Population` run on the same state.  Rate models, n % 4 == 0, B in {2, 4, 8, 16}.
+    has no batch axis -- B trials of a network are B passes of its time loop, each streaming W again.
+
+    Two forms.  B in {2, 4, 8}: vector ALUs, state batch-major ([B, n]); trajectory b is BIT-IDENTICAL to an unbatched
+    :class:`Population` run on the same state.  9 <= B <= 32 (or ``mfma=True``): the contraction runs on the matrix cores
+    (exact-fp32 MFMA) with up to 32 trajectories per pass over W; state neuron-major ([n, 32] internally); equal to the
+    unbatched run up to fp32 rounding (its own summation order, mirrored by the oracle).  ``v`` / ``source`` are
+    [B, rows] / [B, n] views in both forms.  Rate models, n % 4 == 0.
     """
 
-    BATCHES = (2, 4, 8, 16)
+    BATCHES = (2, 4, 8, 16)   # vector-ALU form
+    SLOTS = _abi.RP_BATCH_SLOTS
 
-    def __init__(self, pop: Population, batch: int, v0=None):
+    def __init__(self, pop: Population, batch: int, v0=None, mfma: Optional[bool] = None):
         if pop.spiking:
             raise NotImplementedError("batched trajectories cover the rate models (li_tanh, li_sigmoid)")
-        if batch not in self.BATCHES:
-            raise ValueError(f"batch must be one of {self.BATCHES}, got {batch}")
         if pop.n % 4 or pop.W.stride(0) % 4:
             raise ValueError("batched trajectories need n % 4 == 0")
+        self.mfma = (batch > 8) if mfma is None else bool(mfma)
+        if self.mfma and not 1 <= batch <= self.SLOTS:
+            raise ValueError(f"the matrix-core form holds 1..{self.SLOTS} trajectories, got {batch}")
+        if not self.mfma and batch not in self.BATCHES:
+            raise ValueError(f"batch must be one of {self.BATCHES} (vector-ALU form) or <= {self.SLOTS} (mfma=True), got {batch}")
+        if self.mfma and pop.row0 % 128:
+            raise ValueError("the matrix-core form needs a shard offset that is a multiple of 128")
         self.pop, self.batch = pop, int(batch)
         f32 = dict(dtype=torch.float32, device=pop.device)
-        self.v = torch.zeros(batch, pop.rows, **f32)
+        if self.mfma:
+            self._v = torch.zeros(pop.rows, self.SLOTS, **f32)
+            self._src = [torch.zeros(pop.n, self.SLOTS, **f32), torch.zeros(pop.n, self.SLOTS, **f32)]
+        else:
+            self._v = torch.zeros(batch, pop.rows, **f32)
+            self._src = [torch.zeros(batch, pop.n, **f32), torch.zeros(batch, pop.n, **f32)]
+        self.cur = 0
         if v0 is not None:
             self.v.copy_(torch.as_tensor(v0, dtype=torch.float32).to(pop.device).expand(batch, pop.rows))
-        self.src = [torch.zeros(batch, pop.n, **f32), torch.zeros(batch, pop.n, **f32)]
-        self.cur = 0
         self.refresh()
+
+    @property
+    def v(self) -> torch.Tensor:
+        """States [B, rows] (a view: writes go to the device state; call :meth:`refresh` afterwards)."""
+        return self._v.t()[:self.batch] if self.mfma else self._v
+
+    @property
+    def source(self) -> torch.Tensor:
+        """Current source vectors r_b = act(v_b), [B, n] (view)."""
+        s = self._src[self.cur]
+        return s.t()[:self.batch] if self.mfma else s
 
     def refresh(self):
         """r_b = act(v_b) after the states were set from the host (through the unbatched refresh kernel, row by row)."""
@@ -605,16 +631,15 @@ class BatchedPopulation:
         keep_v, keep_src, keep_cur = pop.v, pop.src, pop.cur
         try:
             for b in range(self.batch):
-                pop.v, pop.src, pop.cur = self.v[b], [self.src[self.cur][b], self.src[self.cur ^ 1][b]], 0
+                vb = self.v[b].contiguous()
+                sb = torch.zeros(pop.n, dtype=torch.float32, device=pop.device)
+                pop.v, pop.src, pop.cur = vb, [sb, sb.clone()], 0
                 pop._net_cache = None
                 pop.refresh()
+                self.source[b, pop.row0:pop.row0 + pop.rows] = sb[pop.row0:pop.row0 + pop.rows]
         finally:
             pop.v, pop.src, pop.cur = keep_v, keep_src, keep_cur
             pop._net_cache = None
-
-    @property
-    def source(self) -> torch.Tensor:
-        return self.src[self.cur]
 
     def forward(self, steps: int, x: Optional[torch.Tensor] = None, traj: Optional[torch.Tensor] = None,
                 out_var: int = _abi.RP_OUT_STATE0):
@@ -623,8 +648,9 @@ class BatchedPopulation:
         pop, B = self.pop, self.batch
         bt = _abi.RpBatch()
         bt.batch, bt.steps = B, int(steps)
-        bt.v, bt.ldv = self.v.data_ptr(), self.v.stride(0)
-        bt.src[0], bt.src[1], bt.ldsrc = self.src[0].data_ptr(), self.src[1].data_ptr(), self.src[0].stride(0)
+        bt.layout = _abi.RP_BATCH_MFMA if self.mfma else _abi.RP_BATCH_VALU
+        bt.v, bt.ldv = self._v.data_ptr(), self._v.stride(0)
+        bt.src[0], bt.src[1], bt.ldsrc = self._src[0].data_ptr(), self._src[1].data_ptr(), self._src[0].stride(0)
         bt.cur = self.cur
         keep = []
         if x is None:

@@ -352,8 +352,9 @@ class Network:
         initial state (``y0``: [B, N] initial states of the population; default: its current state for every b).
 
         Not part of the reference's API (it has no batch axis: B trials are B passes of its time loop, each streaming W
-        again).  Here every Euler step streams W ONCE for all B trajectories (``rp_forward_batched``), trajectory b being
-        bit-identical to an unbatched run.  Chain topologies around one RATE population; the network's own state is
+        again).  Here every Euler step streams W ONCE for all B trajectories (``rp_forward_batched``): up to 8 trajectories
+        on the vector ALUs, each bit-identical to an unbatched run; 9..32 per pass on the matrix cores (equal to unbatched
+        runs up to fp32 rounding); more in groups of 32.  Chain topologies around one RATE population; the network's own state is
         left untouched."""
         from .engine import BatchedPopulation
         self.compile()
@@ -379,10 +380,11 @@ class Network:
         self._fit_width(X.reshape(B * T, -1), N)
         per_step = torch.empty(B, T, N, dtype=torch.float32, device=pop.device)
         finals = torch.empty(B, N, dtype=torch.float32, device=pop.device)
-        chunk = max(1, min(T, _WINDOW_BYTES // (4 * N * 16)))
-        for b0 in range(0, B, 16):  # groups of at most 16 trajectories, padded to a supported batch size
-            nb = min(16, B - b0)
-            size = next(q for q in BatchedPopulation.BATCHES if q >= nb) if nb > 1 else 2
+        chunk = max(1, min(T, _WINDOW_BYTES // (4 * N * 32)))
+        for b0 in range(0, B, BatchedPopulation.SLOTS):  # groups of at most 32 trajectories
+            nb = min(BatchedPopulation.SLOTS, B - b0)
+            # up to 8: vector-ALU form (padded to 2 / 4 / 8; bit-identical to unbatched runs); more: matrix-core form
+            size = nb if nb > 8 else next(q for q in (2, 4, 8) if q >= nb)
             bp = BatchedPopulation(pop, size)
             bp.v.zero_()
             bp.v[:nb] = start[b0:b0 + nb]

@@ -41,7 +41,7 @@ def test_batched_equals_unbatched_runs(target, model, n, B, xw):
     v0 = torch.randn(B, n, generator=g)
     x = {"full": torch.randn(T, B, n, generator=g) * 0.5, "bcast": torch.randn(T, B, 1, generator=g), "none": None}[xw]
     pop = Population(model, W, params, 1e-2, dev, backend=backend)
-    bp = BatchedPopulation(pop, B)
+    bp = BatchedPopulation(pop, B, mfma=False)
     bp.v.copy_(v0.to(dev))
     bp.refresh()
     traj = torch.zeros(T, B, n, device=dev)
@@ -68,7 +68,7 @@ def test_batched_hip_equals_oracle(oracle_backend, hip_device):
     x = torch.randn(T, B, n, generator=g) * 0.5
     res = []
     for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
-        bp = BatchedPopulation(Population("li_tanh", W, params, 1e-2, dev, backend=backend), B)
+        bp = BatchedPopulation(Population("li_tanh", W, params, 1e-2, dev, backend=backend), B, mfma=False)
         bp.v.copy_(v0.to(dev))
         bp.refresh()
         traj = torch.zeros(T, B, n, device=dev)
@@ -82,7 +82,9 @@ def test_batched_argument_errors(oracle_backend):
     W, params = network(64, "li_tanh", seed=1)
     pop = Population("li_tanh", W, params, 1e-2, "cpu", backend=oracle_backend)
     with pytest.raises(ValueError):
-        BatchedPopulation(pop, 3)
+        BatchedPopulation(pop, 3, mfma=False)
+    with pytest.raises(ValueError):
+        BatchedPopulation(pop, 33)
     bp = BatchedPopulation(pop, 2)
     with pytest.raises(RuntimeError):
         bp.forward(5, x=torch.zeros(5, 3, 64))
@@ -125,3 +127,56 @@ def test_network_run_batch_equals_separate_runs(target):
         assert list(obs["steps"]) == list(batch[b]["steps"])
         assert np.allclose(obs.to_numpy("out"), batch[b].to_numpy("out"), atol=1e-6)
         assert torch.equal(single.state["rnn"], batch[b]["state"])
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("model,n,B,xw", [("li_tanh", 64, 32, "full"), ("li_tanh", 260, 20, "bcast"), ("li_sigmoid", 516, 9, "full"),
+                                         ("li_tanh", 1036, 32, "none"), ("li_tanh", 2048, 16, "full")])
+def test_matrix_core_form_matches_unbatched_runs(target, model, n, B, xw):
+    """Matrix-core form (up to 32 trajectories per pass over W, its own summation order): every trajectory equals an
+    unbatched run up to fp32 rounding -- 2e-5 absolute on O(1) trajectories of 25 steps."""
+    dev, backend = target["device"], target["backend"]
+    W, params = network(n, model, seed=n + B)
+    g = torch.Generator().manual_seed(17)
+    T = 25
+    v0 = torch.randn(B, n, generator=g)
+    x = {"full": torch.randn(T, B, n, generator=g) * 0.5, "bcast": torch.randn(T, B, 1, generator=g), "none": None}[xw]
+    pop = Population(model, W, params, 1e-2, dev, backend=backend)
+    bp = BatchedPopulation(pop, B)
+    assert bp.mfma
+    bp.v.copy_(v0.to(dev))
+    bp.refresh()
+    traj = torch.zeros(T, B, n, device=dev)
+    bp.forward(10, x=None if x is None else x[:10].to(dev), traj=traj[:10], out_var=_abi.RP_OUT_SOURCE)
+    bp.forward(T - 10, x=None if x is None else x[10:].to(dev), traj=traj[10:], out_var=_abi.RP_OUT_SOURCE)
+    for b in (0, 1, B // 2, B - 1):
+        single = Population(model, W, params, 1e-2, dev, backend=backend, v0=v0[b])
+        tr = torch.zeros(T, n, device=dev)
+        single.forward(T, x=None if x is None else x[:, b].to(dev), traj=tr, out_var=_abi.RP_OUT_SOURCE)
+        assert float((traj[:, b] - tr).abs().max()) <= 2e-5 and float((bp.v[b] - single.v).abs().max()) <= 2e-5
+        assert float((bp.source[b] - single.source).abs().max()) <= 2e-5
+    assert np.abs(np.diff(traj.cpu().numpy(), axis=0)).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,B,sigmoid", [(1036, 32, False), (640, 13, True), (2052, 32, False)])
+def test_matrix_core_form_hip_equals_oracle(oracle_backend, hip_device, n, B, sigmoid):
+    """The MFMA kernel against the oracle's mirror of its fmaf chain: bit for bit (ragged last tile, rows that are not a
+    multiple of the 128-row workgroup, unused slots)."""
+    model = "li_sigmoid" if sigmoid else "li_tanh"
+    W, params = network(n, model, seed=n)
+    g = torch.Generator().manual_seed(9)
+    T = 12
+    v0 = torch.randn(B, n, generator=g)
+    x = torch.randn(T, B, n, generator=g) * 0.5
+    res = []
+    for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+        bp = BatchedPopulation(Population(model, W, params, 1e-2, dev, backend=backend), B, mfma=True)
+        bp.v.copy_(v0.to(dev))
+        bp.refresh()
+        traj = torch.zeros(T, B, n, device=dev)
+        bp.forward(T, x=x.to(dev), traj=traj)
+        res.append((traj.cpu().numpy(), bp.v.cpu().numpy().copy(), bp.source.cpu().numpy().copy()))
+    for a, c, name in zip(res[0], res[1], ("traj", "v", "source")):
+        same = (a.view(np.uint32) == c.view(np.uint32)) | ((a == 0) & (c == 0))
+        assert same.all(), f"{name}: {np.count_nonzero(~same)} of {a.size} differ, max {np.abs(a - c).max()}"
