@@ -143,44 +143,45 @@ void launch(const BatchParams& P, hipStream_t st) {
 }
 
 // ---- matrix-core form: up to 32 trajectories per pass over W --------------------------------------------------------
-// C[128 rows x 32 slots] per workgroup = W[128 x n] @ R[n x 32] with v_mfma_f32_32x32x2_f32 (exact fp32: one fmaf chain
-// per output element).  Wave w owns rows 32 w .. 32 w + 31 of the block; the four waves walk the column tiles (64 columns)
-// in step, so one source tile R[64 x 32] per tile is shared through LDS.  W tiles are loaded coalesced (4 rows x 256 B per
-// wave instruction, non-temporal), parked in registers while the previous tile is multiplied, and written to the wave's
-// own LDS tile; MFMA operands are read back as one 16-byte LDS read (A: row l & 31, columns 8 q + 4 (l >> 5) .. +3) and
-// four 4-byte reads (B) per four MFMAs.  State is neuron-major ([n x 32]), so the C fragment (slot = lane & 31) reads
-// and writes it coalesced.  At 32 slots the MFMA pipe needs 0.7 of the time HBM needs to deliver the tile.
+// C[32 rows x 32 slots] per workgroup = W[32 x n] @ R[n x 32] with v_mfma_f32_32x32x2_f32 (exact fp32: fmaf chains).
+// The reduction over the columns is split over the workgroup's four waves (wave w takes the column tiles q = w, w + 4, ...
+// of the staggered tile sequence), so a 32768-neuron network gives 1024 workgroups x 4 waves of independent work and no
+// barrier inside the loop: every wave owns its W tile and its source tile in LDS.  W tiles are loaded coalesced (4 rows x
+// 256 B per wave instruction, non-temporal) and parked in registers while the previous tile is multiplied; MFMA operands
+// are read back as one 16-byte LDS read (A: row l & 31, columns 8 g + 4 (l >> 5) .. +3) and four 4-byte reads (B) per
+// four MFMAs.  The four partial tiles are added in wave order through LDS.  State is neuron-major ([n x 32]), so the C
+// fragment (slot = lane & 31) reads and writes it coalesced.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kMT = 64;        // columns per tile
 constexpr int kWs = 68;        // LDS row stride of a W tile (floats): rows 16-byte aligned, quarter-wave reads conflict-free
-constexpr int kRs = 40;        // LDS row stride of the source tile: the two half-waves of a B read hit disjoint banks
+constexpr int kRs = 40;        // LDS row stride of a source tile: the two half-waves of a B read hit disjoint banks
 constexpr int kSlots = RP_BATCH_SLOTS;
+constexpr int kWaveLds = 32 * kWs + kMT * kRs;  // floats per wave: its W tile and its source tile
 
 template <int MODEL>
 __global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const BatchParams P, int batch) {
-    __shared__ __attribute__((aligned(16))) float Ws[4 * 32 * kWs];
-    __shared__ __attribute__((aligned(16))) float Rs[kMT * kRs];
+    __shared__ __attribute__((aligned(16))) float lds[4 * kWaveLds];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
-    const int row_blk = blockIdx.x * 128;           // first local row of this workgroup
+    const int row_blk = blockIdx.x * 32;            // first local row of this workgroup
     const int tiles = (P.n + kMT - 1) / kMT;
-    const int t0 = (int)((3u * (unsigned)((P.row0 + row_blk) >> 7)) % (unsigned)tiles);
-    float* myW = Ws + wave * 32 * kWs;
+    const int t0 = (int)((3u * (unsigned)((P.row0 + row_blk) >> 5)) % (unsigned)tiles);
+    float* myW = lds + wave * kWaveLds;
+    float* myR = myW + 32 * kWs;
 
-    // global -> registers: the wave's 32 x 64 tile of W (8 loads of 4 rows x 256 B) and the block's 64 x 32 source tile
-    rp_f4 wreg[8], rreg[2];
-    auto load_tile = [&](int tile) {
+    rp_f4 wreg[8], rreg[8];
+    auto load_tile = [&](int tile) {  // global -> registers: 32 x 64 of W (4 rows x 256 B per instruction), 64 x 32 of R
         const int c = tile * kMT + 4 * (lane & 15);
 #pragma clang loop unroll(full)
         for (int q = 0; q < 8; ++q) {
-            int row = row_blk + 32 * wave + 4 * q + (lane >> 4);
+            int row = row_blk + 4 * q + (lane >> 4);
             row = row < P.rows ? row : P.rows - 1;  // clamp: rows past the end re-read a valid row, results discarded
             wreg[q] = c < P.n ? rp_ld4_stream(P.W + (int64_t)row * P.ldw + c) : rp_f4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma clang loop unroll(full)
-        for (int q = 0; q < 2; ++q) {  // 64 x 32 floats = 512 float4: thread t takes float4 t and t + 256
-            const int f = tid + 256 * q;
+        for (int q = 0; q < 8; ++q) {  // 512 float4: lane l takes float4 l, l + 64, ...
+            const int f = lane + 64 * q;
             const int k = tile * kMT + (f >> 3);
             rreg[q] = k < P.n ? rp_ld4(P.src_cur + (int64_t)k * kSlots + 4 * (f & 7)) : rp_f4{0.f, 0.f, 0.f, 0.f};
         }
@@ -190,23 +191,21 @@ __global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const Batch
         for (int q = 0; q < 8; ++q)
             *reinterpret_cast<rp_f4*>(myW + (4 * q + (lane >> 4)) * kWs + 4 * (lane & 15)) = wreg[q];
 #pragma clang loop unroll(full)
-        for (int q = 0; q < 2; ++q) {
-            const int f = tid + 256 * q;
-            *reinterpret_cast<rp_f4*>(Rs + (f >> 3) * kRs + 4 * (f & 7)) = rreg[q];
+        for (int q = 0; q < 8; ++q) {
+            const int f = lane + 64 * q;
+            *reinterpret_cast<rp_f4*>(myR + (f >> 3) * kRs + 4 * (f & 7)) = rreg[q];
         }
     };
 
     f32x16 acc;
 #pragma clang loop unroll(full)
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    load_tile(t0);
-    for (int q = 0; q < tiles; ++q) {
-        __syncthreads();  // every wave is done with the previous source tile
-        store_tile();
-        __syncthreads();
-        if (q + 1 < tiles) load_tile((t0 + q + 1) % tiles);  // next tile in flight behind the MFMAs
+    if (wave < tiles) load_tile((t0 + wave) % tiles);
+    for (int q = wave; q < tiles; q += 4) {
+        store_tile();  // (the wave's own LDS tiles: program order is all the synchronisation needed)
+        if (q + 4 < tiles) load_tile((t0 + q + 4) % tiles);  // next tile in flight behind the MFMAs
         const float* ap = myW + lr * kWs + 4 * lh;
-        const float* bp = Rs + (4 * lh) * kRs + lr;
+        const float* bp = myR + (4 * lh) * kRs + lr;
 #pragma clang loop unroll(full)
         for (int g = 0; g < kMT / 8; ++g) {
             const rp_f4 a = *reinterpret_cast<const rp_f4*>(ap + 8 * g);
@@ -218,11 +217,23 @@ __global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const Batch
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
         }
     }
+    // partial tiles of waves 1..3 -> LDS (their own regions are free now); wave 0 adds them in wave order
+    __syncthreads();
+    if (wave > 0) {
+#pragma clang loop unroll(full)
+        for (int r = 0; r < 16; ++r) myW[r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma clang loop unroll(full)
+    for (int r = 0; r < 16; ++r)
+        acc[r] = ((acc[r] + lds[1 * kWaveLds + r * 64 + lane]) + lds[2 * kWaveLds + r * 64 + lane]) +
+                 lds[3 * kWaveLds + r * 64 + lane];
     // C/D layout of the 32x32 MFMA: slot = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if (lr < batch) {
 #pragma clang loop unroll(full)
         for (int r = 0; r < 16; ++r) {
-            const int i = row_blk + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int i = row_blk + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (i < P.rows) {
                 const int gi = P.row0 + i, b = lr;
                 float I = 0.f;
@@ -303,7 +314,7 @@ int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
         RP_FAIL(RP_ERR_ARG, "W, v, src[0], src[1] must be non-null (and the two source buffers distinct)");
     if (!mfma && (bt->ldv < net->rows || bt->ldsrc < net->n || bt->ldsrc % 4 != 0))
         RP_FAIL(RP_ERR_SHAPE, "ldv >= rows, ldsrc >= n and ldsrc %% 4 == 0 required");
-    if (mfma && net->row0 % 128 != 0) RP_FAIL(RP_ERR_ARG, "row0=%d must be a multiple of 128 for the matrix-core form", net->row0);
+    if (mfma && net->row0 % 32 != 0) RP_FAIL(RP_ERR_ARG, "row0=%d must be a multiple of 32 for the matrix-core form", net->row0);
     if ((reinterpret_cast<uintptr_t>(net->W) & 15u) || (reinterpret_cast<uintptr_t>(bt->src[0]) & 15u) ||
         (reinterpret_cast<uintptr_t>(bt->src[1]) & 15u))
         RP_FAIL(RP_ERR_ARG, "W and the source buffers must be 16-byte aligned");
@@ -343,7 +354,7 @@ int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
         P.x_t = bt->x ? bt->x + (int64_t)t * B * bt->ldx : nullptr;
         P.traj_t = bt->traj ? bt->traj + (int64_t)t * B * bt->ldtraj : nullptr;
         if (mfma) {
-            const int blocks = (net->rows + 127) / 128;
+            const int blocks = (net->rows + 31) / 32;
             if (net->model == RP_MODEL_LI_TANH)
                 hipLaunchKernelGGL(step_batched_mfma_kernel<RP_MODEL_LI_TANH>, dim3(blocks), dim3(kThreads), 0, st, P, B);
             else

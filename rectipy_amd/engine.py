@@ -599,8 +599,8 @@ class BatchedPopulation:
             raise ValueError(f"the matrix-core form holds 1..{self.SLOTS} trajectories, got {batch}")
         if not self.mfma and batch not in self.BATCHES:
             raise ValueError(f"batch must be one of {self.BATCHES} (vector-ALU form) or <= {self.SLOTS} (mfma=True), got {batch}")
-        if self.mfma and pop.row0 % 128:
-            raise ValueError("the matrix-core form needs a shard offset that is a multiple of 128")
+        if self.mfma and pop.row0 % 32:
+            raise ValueError("the matrix-core form needs a shard offset that is a multiple of 32")
         self.pop, self.batch = pop, int(batch)
         f32 = dict(dtype=torch.float32, device=pop.device)
         if self.mfma:

@@ -33,8 +33,8 @@ for B, R, U in ((2, 0, 0), (4, 0, 0), (4, 8, 1), (4, 8, 2), (4, 4, 1), (8, 0, 0)
                       "fma_TFLOPs": round(2.0 * N * N * B / (ms * 1e-3) / 1e12, 1),
                       "finite": bool(torch.isfinite(bp.v).all().item())}), flush=True)
 
-lib.rp_set_batched_tuning(0, 0)
-for B in (16, 24, 32):
+for B, U in ((32, 0), (16, 0)):
+    lib.rp_set_batched_tuning(0, U)
     bp = BatchedPopulation(pop, B, mfma=True)
     bp.v.normal_()
     bp.refresh()
@@ -42,7 +42,7 @@ for B in (16, 24, 32):
     bp.forward(20, x=x[:20]); torch.cuda.synchronize()
     e0.record(); bp.forward(T, x=x); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / T
-    print(json.dumps({"form": "mfma", "B": B, "ms_per_step": round(ms, 4), "trajectory_steps_per_s": round(B * 1e3 / ms, 1),
+    print(json.dumps({"form": "mfma" + ("_single_buffer" if U == 9 else ""), "B": B, "ms_per_step": round(ms, 4), "trajectory_steps_per_s": round(B * 1e3 / ms, 1),
                       "speedup_vs_B_unbatched_runs": round(B * ms1 / ms, 2),
                       "W_stream_TBps": round(4.0 * N * N / (ms * 1e-3) / 1e12, 2),
                       "mfma_TFLOPs_32_slots": round(2.0 * N * N * 32 / (ms * 1e-3) / 1e12, 1),
