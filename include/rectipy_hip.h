@@ -364,9 +364,9 @@ typedef struct rp_batch {
     /* layout = RP_BATCH_MFMA: the contraction W @ [r_0 .. r_31] runs on the matrix cores (v_mfma_f32_32x32x2_f32, exact
        fp32) with up to 32 trajectories per pass over W.  State is NEURON-major then: v = [rows x 32], src[k] = [n x 32]
        (slot b of neuron i at i * 32 + b; ldv / ldsrc are ignored), batch <= 32 names the slots in use.  Summation order
-       per (row i, trajectory b): the column tiles of 64 are taken in the sequence t0, t0 + 1, ... (mod tiles) with
+       per (row i, trajectory b): the column tiles of 32 are taken in the sequence t0, t0 + 1, ... (mod tiles) with
        t0 = (3 * ((row0 + i) >> 5)) mod tiles; position q of that sequence goes to chain q mod 4 (the four waves of a
-       workgroup); inside a tile the columns 8 g + {0, 4, 1, 5, 2, 6, 3, 7} for g = 0..7; the four fmaf chains are added
+       workgroup); inside a tile the columns 8 g + {0, 4, 1, 5, 2, 6, 3, 7} for g = 0..3; the four fmaf chains are added
        as ((c0 + c1) + c2) + c3 (mirrored by the oracle).  Equal to the unbatched run up to fp32 rounding (different
        order), not bit for bit. */
     int32_t layout;           /* RP_BATCH_VALU (0) | RP_BATCH_MFMA (1)                               */

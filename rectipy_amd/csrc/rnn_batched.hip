@@ -146,17 +146,27 @@ void launch(const BatchParams& P, hipStream_t st) {
 // C[32 rows x 32 slots] per workgroup = W[32 x n] @ R[n x 32] with v_mfma_f32_32x32x2_f32 (exact fp32: fmaf chains).
 // The reduction over the columns is split over the workgroup's four waves (wave w takes the column tiles q = w, w + 4, ...
 // of the staggered tile sequence), so a 32768-neuron network gives 1024 workgroups x 4 waves of independent work and no
-// barrier inside the loop: every wave owns its W tile and its source tile in LDS.  W tiles are loaded coalesced (4 rows x
-// 256 B per wave instruction, non-temporal) and parked in registers while the previous tile is multiplied; MFMA operands
-// are read back as one 16-byte LDS read (A: row l & 31, columns 8 g + 4 (l >> 5) .. +3) and four 4-byte reads (B) per
-// four MFMAs.  The four partial tiles are added in wave order through LDS.  State is neuron-major ([n x 32]), so the C
-// fragment (slot = lane & 31) reads and writes it coalesced.
+// barrier inside the loop: every wave owns its W tile and its source tile in LDS.  W tiles (32 rows x 32 columns) are
+// loaded coalesced (8 rows x 128 B per wave instruction, non-temporal) and parked in registers while the previous tile
+// is multiplied; MFMA operands are read back as one 16-byte LDS read (A: row l & 31, columns 8 g + 4 (l >> 5) .. +3) and
+// four 4-byte reads (B) per four MFMAs.  The four partial tiles are added in wave order through LDS.  State is
+// neuron-major ([n x 32]), so the C fragment (slot = lane & 31) reads and writes it coalesced.
+// Measured split of the 0.89 ms step at N = 32768 (probe flags of this kernel, r02): loads + LDS stores alone 0.74 ms
+// (W at 5.8 TB/s: 128-byte pieces of 8 rows per instruction are a poorer DRAM pattern than the 1 KiB pieces of the
+// unbatched kernel), LDS reads + MFMA alone 0.58 ms (118 TFLOP/s); the two overlap only partly.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kMT = 64;        // columns per tile
-constexpr int kWs = 68;        // LDS row stride of a W tile (floats): rows 16-byte aligned, quarter-wave reads conflict-free
+constexpr int kMT = 32;        // columns per tile
+constexpr int kWs = kMT + 4;   // LDS row stride of a W tile (floats): rows 16-byte aligned, quarter-wave reads conflict-free
+constexpr int kLpr = kMT / 4;  // lanes per tile row of a W load (16 bytes each)
+constexpr int kRpi = 64 / kLpr;  // tile rows per W load instruction
+constexpr int kWld = 32 / kRpi;  // W load instructions per tile
+constexpr int kRld = kMT * 32 / 4 / 64;  // source load instructions per tile (float4 per lane)
 constexpr int kRs = 40;        // LDS row stride of a source tile: the two half-waves of a B read hit disjoint banks
 constexpr int kSlots = RP_BATCH_SLOTS;
-constexpr int kWaveLds = 32 * kWs + kMT * kRs;  // floats per wave: its W tile and its source tile
+constexpr int kRT = 1;         // 32-row MFMA tiles per wave (2: every source operand read feeds two MFMAs; +3 % at N = 32768,
+                               // but half the workgroups: slower below N = 16384)
+constexpr int kRows = 32 * kRT;  // rows per workgroup
+constexpr int kWaveLds = kRows * kWs + kMT * kRs;  // floats per wave: its W tile and its source tile
 
 template <int MODEL>
 __global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const BatchParams P, int batch) {
@@ -164,23 +174,23 @@ __global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const Batch
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
-    const int row_blk = blockIdx.x * 32;            // first local row of this workgroup
+    const int row_blk = blockIdx.x * kRows;         // first local row of this workgroup
     const int tiles = (P.n + kMT - 1) / kMT;
-    const int t0 = (int)((3u * (unsigned)((P.row0 + row_blk) >> 5)) % (unsigned)tiles);
+    const int t0 = (int)((3u * (unsigned)((P.row0 + row_blk) / kRows)) % (unsigned)tiles);
     float* myW = lds + wave * kWaveLds;
-    float* myR = myW + 32 * kWs;
+    float* myR = myW + kRows * kWs;
 
-    rp_f4 wreg[8], rreg[8];
-    auto load_tile = [&](int tile) {  // global -> registers: 32 x 64 of W (4 rows x 256 B per instruction), 64 x 32 of R
-        const int c = tile * kMT + 4 * (lane & 15);
+    rp_f4 wreg[kRT * kWld], rreg[kRld];
+    auto load_tile = [&](int tile) {  // global -> registers: kRows x kMT of W (kRpi rows per instruction), kMT x 32 of R
+        const int c = tile * kMT + 4 * (lane % kLpr);
 #pragma clang loop unroll(full)
-        for (int q = 0; q < 8; ++q) {
-            int row = row_blk + 4 * q + (lane >> 4);
+        for (int q = 0; q < kRT * kWld; ++q) {
+            int row = row_blk + kRpi * q + (lane / kLpr);
             row = row < P.rows ? row : P.rows - 1;  // clamp: rows past the end re-read a valid row, results discarded
             wreg[q] = c < P.n ? rp_ld4_stream(P.W + (int64_t)row * P.ldw + c) : rp_f4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma clang loop unroll(full)
-        for (int q = 0; q < 8; ++q) {  // 512 float4: lane l takes float4 l, l + 64, ...
+        for (int q = 0; q < kRld; ++q) {  // kMT * 8 float4: lane l takes float4 l, l + 64, ...
             const int f = lane + 64 * q;
             const int k = tile * kMT + (f >> 3);
             rreg[q] = k < P.n ? rp_ld4(P.src_cur + (int64_t)k * kSlots + 4 * (f & 7)) : rp_f4{0.f, 0.f, 0.f, 0.f};
@@ -188,18 +198,20 @@ __global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const Batch
     };
     auto store_tile = [&]() {
 #pragma clang loop unroll(full)
-        for (int q = 0; q < 8; ++q)
-            *reinterpret_cast<rp_f4*>(myW + (4 * q + (lane >> 4)) * kWs + 4 * (lane & 15)) = wreg[q];
+        for (int q = 0; q < kRT * kWld; ++q)
+            *reinterpret_cast<rp_f4*>(myW + (kRpi * q + (lane / kLpr)) * kWs + 4 * (lane % kLpr)) = wreg[q];
 #pragma clang loop unroll(full)
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < kRld; ++q) {
             const int f = lane + 64 * q;
             *reinterpret_cast<rp_f4*>(myR + (f >> 3) * kRs + 4 * (f & 7)) = rreg[q];
         }
     };
 
-    f32x16 acc;
+    f32x16 acc[kRT];
 #pragma clang loop unroll(full)
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int j = 0; j < kRT; ++j)
+#pragma clang loop unroll(full)
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     if (wave < tiles) load_tile((t0 + wave) % tiles);
     for (int q = wave; q < tiles; q += 4) {
         store_tile();  // (the wave's own LDS tiles: program order is all the synchronisation needed)
@@ -208,48 +220,61 @@ __global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const Batch
         const float* bp = myR + (4 * lh) * kRs + lr;
 #pragma clang loop unroll(full)
         for (int g = 0; g < kMT / 8; ++g) {
-            const rp_f4 a = *reinterpret_cast<const rp_f4*>(ap + 8 * g);
+            rp_f4 a[kRT];
+#pragma clang loop unroll(full)
+            for (int j = 0; j < kRT; ++j) a[j] = *reinterpret_cast<const rp_f4*>(ap + j * 32 * kWs + 8 * g);
             const float b0 = bp[(8 * g + 0) * kRs], b1 = bp[(8 * g + 1) * kRs];
             const float b2 = bp[(8 * g + 2) * kRs], b3 = bp[(8 * g + 3) * kRs];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
+#pragma clang loop unroll(full)
+            for (int j = 0; j < kRT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b0, acc[j], 0, 0, 0);
+#pragma clang loop unroll(full)
+            for (int j = 0; j < kRT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b1, acc[j], 0, 0, 0);
+#pragma clang loop unroll(full)
+            for (int j = 0; j < kRT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b2, acc[j], 0, 0, 0);
+#pragma clang loop unroll(full)
+            for (int j = 0; j < kRT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b3, acc[j], 0, 0, 0);
         }
     }
     // partial tiles of waves 1..3 -> LDS (their own regions are free now); wave 0 adds them in wave order
     __syncthreads();
     if (wave > 0) {
 #pragma clang loop unroll(full)
-        for (int r = 0; r < 16; ++r) myW[r * 64 + lane] = acc[r];
+        for (int j = 0; j < kRT; ++j)
+#pragma clang loop unroll(full)
+            for (int r = 0; r < 16; ++r) myW[(j * 16 + r) * 64 + lane] = acc[j][r];
     }
     __syncthreads();
     if (wave != 0) return;
 #pragma clang loop unroll(full)
-    for (int r = 0; r < 16; ++r)
-        acc[r] = ((acc[r] + lds[1 * kWaveLds + r * 64 + lane]) + lds[2 * kWaveLds + r * 64 + lane]) +
-                 lds[3 * kWaveLds + r * 64 + lane];
+    for (int j = 0; j < kRT; ++j)
+#pragma clang loop unroll(full)
+        for (int r = 0; r < 16; ++r) {
+            const int o = (j * 16 + r) * 64 + lane;
+            acc[j][r] = ((acc[j][r] + lds[1 * kWaveLds + o]) + lds[2 * kWaveLds + o]) + lds[3 * kWaveLds + o];
+        }
     // C/D layout of the 32x32 MFMA: slot = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     if (lr < batch) {
 #pragma clang loop unroll(full)
-        for (int r = 0; r < 16; ++r) {
-            const int i = row_blk + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (i < P.rows) {
-                const int gi = P.row0 + i, b = lr;
-                float I = 0.f;
-                if (P.x_mode == RP_X_FULL) I = P.x_t[(int64_t)b * P.ldx + i];
-                else if (P.x_mode == RP_X_BCAST) I = P.x_t[(int64_t)b * P.ldx];
-                float* vp = P.v + (int64_t)i * kSlots + b;
-                const float v = *vp;
-                const float dv = ((-v / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * acc[r]) + I) + P.p[RP_P_ETA][i];
-                const float v_new = v + P.dt * dv;
-                *vp = v_new;
-                P.src_next[(int64_t)gi * kSlots + b] = act<MODEL>(P, i, v_new);
-                if (P.traj_t)
-                    P.traj_t[(int64_t)b * P.ldtraj + i] =
-                        P.out_var == RP_OUT_STATE0 ? v : P.src_cur[(int64_t)gi * kSlots + b];
+        for (int j = 0; j < kRT; ++j)
+#pragma clang loop unroll(full)
+            for (int r = 0; r < 16; ++r) {
+                const int i = row_blk + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (i < P.rows) {
+                    const int gi = P.row0 + i, b = lr;
+                    float I = 0.f;
+                    if (P.x_mode == RP_X_FULL) I = P.x_t[(int64_t)b * P.ldx + i];
+                    else if (P.x_mode == RP_X_BCAST) I = P.x_t[(int64_t)b * P.ldx];
+                    float* vp = P.v + (int64_t)i * kSlots + b;
+                    const float v = *vp;
+                    const float dv = ((-v / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * acc[j][r]) + I) + P.p[RP_P_ETA][i];
+                    const float v_new = v + P.dt * dv;
+                    *vp = v_new;
+                    P.src_next[(int64_t)gi * kSlots + b] = act<MODEL>(P, i, v_new);
+                    if (P.traj_t)
+                        P.traj_t[(int64_t)b * P.ldtraj + i] =
+                            P.out_var == RP_OUT_STATE0 ? v : P.src_cur[(int64_t)gi * kSlots + b];
+                }
             }
-        }
     }
 }
 
@@ -314,7 +339,7 @@ int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
         RP_FAIL(RP_ERR_ARG, "W, v, src[0], src[1] must be non-null (and the two source buffers distinct)");
     if (!mfma && (bt->ldv < net->rows || bt->ldsrc < net->n || bt->ldsrc % 4 != 0))
         RP_FAIL(RP_ERR_SHAPE, "ldv >= rows, ldsrc >= n and ldsrc %% 4 == 0 required");
-    if (mfma && net->row0 % 32 != 0) RP_FAIL(RP_ERR_ARG, "row0=%d must be a multiple of 32 for the matrix-core form", net->row0);
+    if (mfma && net->row0 % kRows != 0) RP_FAIL(RP_ERR_ARG, "row0=%d must be a multiple of %d for the matrix-core form", net->row0, kRows);
     if ((reinterpret_cast<uintptr_t>(net->W) & 15u) || (reinterpret_cast<uintptr_t>(bt->src[0]) & 15u) ||
         (reinterpret_cast<uintptr_t>(bt->src[1]) & 15u))
         RP_FAIL(RP_ERR_ARG, "W and the source buffers must be 16-byte aligned");
@@ -354,7 +379,7 @@ int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
         P.x_t = bt->x ? bt->x + (int64_t)t * B * bt->ldx : nullptr;
         P.traj_t = bt->traj ? bt->traj + (int64_t)t * B * bt->ldtraj : nullptr;
         if (mfma) {
-            const int blocks = (net->rows + 31) / 32;
+            const int blocks = (net->rows + kRows - 1) / kRows;
             if (net->model == RP_MODEL_LI_TANH)
                 hipLaunchKernelGGL(step_batched_mfma_kernel<RP_MODEL_LI_TANH>, dim3(blocks), dim3(kThreads), 0, st, P, B);
             else

@@ -42,7 +42,7 @@ for B, U in ((32, 0), (16, 0)):
     bp.forward(20, x=x[:20]); torch.cuda.synchronize()
     e0.record(); bp.forward(T, x=x); e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / T
-    print(json.dumps({"form": "mfma" + ("_single_buffer" if U == 9 else ""), "B": B, "ms_per_step": round(ms, 4), "trajectory_steps_per_s": round(B * 1e3 / ms, 1),
+    print(json.dumps({"form": "mfma", "B": B, "ms_per_step": round(ms, 4), "trajectory_steps_per_s": round(B * 1e3 / ms, 1),
                       "speedup_vs_B_unbatched_runs": round(B * ms1 / ms, 2),
                       "W_stream_TBps": round(4.0 * N * N / (ms * 1e-3) / 1e12, 2),
                       "mfma_TFLOPs_32_slots": round(2.0 * N * N * 32 / (ms * 1e-3) / 1e12, 1),
