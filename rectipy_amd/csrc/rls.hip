@@ -15,6 +15,8 @@
 // Row mapping and summation order as in the step kernel (one wave per R rows, lane l owns columns 256 m + 4 l
 // .. +3, m ascending from 0, lane sum (a0+a1)+(a2+a3), fixed butterfly), mirrored by oracle/rls_oracle.c.
 
+#include <atomic>
+
 #include "rp_common.h"
 
 namespace {
@@ -285,17 +287,19 @@ __global__ void rls_zn_kernel(const RlsParams P) {
     P.zn[i] = P.beta_inv * s;
 }
 
-int g_rls_R = 0, g_rls_U = 0, g_rls_nts = -1;  // benchmark-only override (rp_set_rls_tuning)
+std::atomic<int> g_rls_R{0}, g_rls_U{0}, g_rls_nts{-1};  // benchmark-only override (rp_set_rls_tuning)
 
-int g_rls_blocks = 0;  // benchmark-only: grid cap override
+std::atomic<int> g_rls_blocks{0};  // benchmark-only: grid cap override
 
 template <int R, int U, bool NTS, bool UPDATE>
 void launch_cfg(const RlsParams& P, bool vec4, hipStream_t st) {
     int groups = (P.n_in + R - 1) / R;
     int blocks = (groups + 3) / 4;
-    const int cap = g_rls_blocks > 0 ? g_rls_blocks : 2048;
+    const int cap_req = g_rls_blocks;
+    const int cap = cap_req > 0 ? cap_req : 2048;
     if (blocks > cap) blocks = cap;
-    if (vec4 && g_rls_nts >= 0 && (g_rls_nts & 2))
+    const int policy = g_rls_nts;
+    if (vec4 && policy >= 0 && (policy & 2))
         hipLaunchKernelGGL((rls_pass_kernel<R, U, NTS, true, UPDATE, false>), dim3(blocks), dim3(kThreads), 0, st, P);
     else if (vec4)
         hipLaunchKernelGGL((rls_pass_kernel<R, U, NTS, true, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
@@ -305,8 +309,9 @@ void launch_cfg(const RlsParams& P, bool vec4, hipStream_t st) {
 
 template <bool UPDATE>
 void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
-    const int R = g_rls_R ? g_rls_R : 2, U = g_rls_U ? g_rls_U : 4;
-    const bool nts = g_rls_nts < 0 ? true : (g_rls_nts & 1) != 0;
+    const int tr = g_rls_R, tu = g_rls_U, tn = g_rls_nts;
+    const int R = tr ? tr : 2, U = tu ? tu : 4;
+    const bool nts = tn < 0 ? true : (tn & 1) != 0;
     if (vec4 && P.partials) {  // one-shot tiles in address order + the per-row sum of the tile partials
         const int tpr = (P.n_in + kTileCols - 1) / kTileCols;
         const unsigned blocks = (unsigned)P.n_in * (unsigned)tpr;

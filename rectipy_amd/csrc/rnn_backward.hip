@@ -20,6 +20,8 @@
 // also applies the adjoint update and prepares u for the next (earlier) step.  The
 // summation order is a function of n only (mirrored in oracle/rnn_oracle.c).
 
+#include <atomic>
+
 #include "rp_common.h"
 #include "rp_dot.h"
 
@@ -27,7 +29,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxChunks = 64;
-int g_bwd_chunks = 0;  // benchmark-only override of the chunk count (rp_set_bwd_chunks); changes the summation order
+std::atomic<int> g_bwd_chunks{0};  // benchmark-only override of the chunk count (rp_set_bwd_chunks); changes the summation order
 
 // RC(n, rows): rows per chunk (multiple of 8) for `rows` rows of an n-column matrix.  The chunk count aims at ~1024
 // waves of 512-column strips, Q = clamp(1024 / ceil(n / 512), 8, 64): long row streams per wave are worth more than
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void wt_partial_kernel(const BwdParams P)
 }
 
 // benchmark-only override of (U, SW); 0 = built-in choice (rp_set_bwd_tuning)
-int g_bwd_U = 0, g_bwd_SW = 0;
+std::atomic<int> g_bwd_U{0}, g_bwd_SW{0};
 
 void launch_wt_partial(const BwdParams& P, bool vec4, hipStream_t st) {
     if (!vec4) {
@@ -188,7 +190,8 @@ void launch_wt_partial(const BwdParams& P, bool vec4, hipStream_t st) {
     // shape from n = 8192 up (n = 32768: 6.7-6.8 TB/s vs 6.3 TB/s for 1-KiB strips); below that the narrow strips give
     // more waves.  2-KiB strips need >= 1024 waves.
     const bool wide = ((P.n + 511) / 512) * P.q >= 1024;
-    const int U = g_bwd_U ? g_bwd_U : (wide ? 4 : 8), SW = g_bwd_SW ? g_bwd_SW : (wide ? 2 : 1);
+    const int tu = g_bwd_U, tsw = g_bwd_SW;
+    const int U = tu ? tu : (wide ? 4 : 8), SW = tsw ? tsw : (wide ? 2 : 1);
     const int strips = (P.n + 256 * SW - 1) / (256 * SW);
     int blocks = (strips * P.q + 3) / 4;
     if (blocks > 4096) blocks = 4096;

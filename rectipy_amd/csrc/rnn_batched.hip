@@ -11,6 +11,8 @@
 // chunk last, lane sum (a0+a1)+(a2+a3), fixed butterfly -- so trajectory b of a batched call reproduces an unbatched
 // rp_forward on the same state bit for bit (tests/test_batched.py).
 
+#include <atomic>
+
 #include "rp_common.h"
 #include "rp_dot.h"
 
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const Batch
     }
 }
 
-int g_bt_R = 0, g_bt_U = 0;  // benchmark-only override (rp_set_batched_tuning)
+std::atomic<int> g_bt_R{0}, g_bt_U{0};  // benchmark-only override (rp_set_batched_tuning)
 
 template <int MODEL>
 int launch_model(const BatchParams& P, int B, hipStream_t st) {

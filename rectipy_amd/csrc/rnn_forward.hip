@@ -17,6 +17,8 @@
 // summation tree per row is therefore independent of grid size, R, unrolling
 // and row sharding; oracle/rnn_oracle.c mirrors it bit for bit.
 
+#include <atomic>
+
 #include "rp_common.h"
 #include "rp_dot.h"
 
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(WAVES * RP_WAVE) void step_sparse_blocked_kernel(co
 }
 
 // benchmark-only: waves per workgroup / groups in flight of the blocked sparse step (0 = built-in)
-int g_blocked_waves = 0, g_blocked_U = 0;
+std::atomic<int> g_blocked_waves{0}, g_blocked_U{0};
 
 template <int MODEL, int WAVES, int U>
 int launch_step_sparse_blocked_cfg(const StepParams& P, hipStream_t st, int n_cu, size_t lds) {
@@ -369,7 +371,7 @@ int launch_step_sparse_blocked(const StepParams& P, hipStream_t st, int n_cu) {
 }
 
 // benchmark-only: rows per wave / groups in flight per row of the sparse step (0 = built-in)
-int g_sparse_R = 0, g_sparse_U = 0;
+std::atomic<int> g_sparse_R{0}, g_sparse_U{0};
 
 template <int MODEL, int R, int U>
 int launch_step_sparse_cfg(const StepParams& P, hipStream_t st, int n_cu) {
@@ -563,7 +565,7 @@ void fill_static(StepParams& P, const rp_net* net) {
 }
 
 // Tuning override (rp_set_tuning): 0 = use the built-in choice.
-int g_tune_R = 0, g_tune_U = 0, g_tune_nt = -1, g_tune_blocks = 0;
+std::atomic<int> g_tune_R{0}, g_tune_U{0}, g_tune_nt{-1}, g_tune_blocks{0};
 
 template <int MODEL, int R, int U, bool VEC4, bool NT>
 void launch_cfg(const StepParams& P, hipStream_t st, int max_blocks) {
