@@ -5,6 +5,10 @@ the dense product, `rectipy_amd/sparse.py`).
 
     python examples/reservoir_ridge.py [N]          (needs the MI355X; default N = 16384)
 """
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from anywhere without PYTHONPATH
 import json
 import sys
 import time
