@@ -7,12 +7,12 @@ __version__ = "0.1.0"
 
 from .network import Network
 from .observer import Observer
-from .nodes import InstantNode, MultiSpikeResetNet, RateNet, Spike, SpikeResetNet
+from .nodes import InstantNode, MultiSpikeResetNet, RateNet, Spike, SpikeNet, SpikeResetNet
 from .edges import Linear
 from .feedback import FeedbackNetwork
 from .connectivity import (circular_connectivity, input_connections, line_connectivity, normalize,
                            random_connectivity, wta_score)
 
-__all__ = ["Network", "FeedbackNetwork", "Observer", "RateNet", "SpikeResetNet", "MultiSpikeResetNet", "Spike", "InstantNode", "Linear",
+__all__ = ["Network", "FeedbackNetwork", "Observer", "RateNet", "SpikeNet", "SpikeResetNet", "MultiSpikeResetNet", "Spike", "InstantNode", "Linear",
            "random_connectivity", "circular_connectivity", "line_connectivity", "input_connections", "normalize",
            "wta_score"]

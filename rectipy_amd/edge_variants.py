@@ -34,7 +34,7 @@ class LinearMasked(_Stateful):
     _extra = ("mask",)
 
     def __init__(self, n_in: int, n_out: int, mask: Union[np.ndarray, torch.Tensor], weights=None,
-                 dtype: torch.dtype = torch.float32, detach: bool = True, **kwargs):
+                 dtype: torch.dtype = torch.float64, detach: bool = True, **kwargs):
         mask = torch.as_tensor(np.asarray(mask) if not isinstance(mask, torch.Tensor) else mask, dtype=dtype)
         if mask.shape[0] == n_in and mask.shape[1] == n_out:  # square masks are transposed too (edges.py:161-162)
             mask = mask.T
@@ -54,7 +54,7 @@ class LinearMemory(_Stateful):
     _extra = ("buffer", "delays", "_cols", "_src")
 
     def __init__(self, n_in: int, n_out: int, delays: Union[np.ndarray, torch.Tensor], weights=None,
-                 dtype: torch.dtype = torch.float32, detach: bool = True, **kwargs):
+                 dtype: torch.dtype = torch.float64, detach: bool = True, **kwargs):
         delays = torch.as_tensor(np.asarray(delays) if not isinstance(delays, torch.Tensor) else delays).long()
         if len(delays) != n_in:
             raise ValueError("The number of delays must match the number of node inputs.")
@@ -100,7 +100,7 @@ class LinearMemoryFilter(LinearMemory):
     _extra = ("buffer", "delays", "_cols", "_src", "filter")
 
     def __init__(self, n_in: int, n_out: int, delays, filter_weights, weights=None,
-                 dtype: torch.dtype = torch.float32, detach: bool = True, **kwargs):
+                 dtype: torch.dtype = torch.float64, detach: bool = True, **kwargs):
         self.filter = _square(filter_weights, n_in, dtype)
         super().__init__(n_in, n_out, delays=delays, weights=weights, dtype=dtype, detach=detach)
 

@@ -16,7 +16,8 @@ class Linear:
     _tensors = ["weights"]
 
     def __init__(self, n_in: int, n_out: int, weights: Union[np.ndarray, torch.Tensor] = None,
-                 dtype: torch.dtype = torch.float32, detach: bool = True, **kwargs):
+                 dtype: torch.dtype = torch.float64, detach: bool = True, **kwargs):
+        # (dtype defaults to float64 as in the reference, edges.py:12; Network.add_edge passes the network's float32)
         if weights is None:
             weights = torch.randn(n_out, n_in, dtype=dtype)
         elif not isinstance(weights, torch.Tensor):

@@ -222,12 +222,17 @@ class Network:
                              f"{out_nodes}. Make sure that exactly one such node exists in the network.")
         self._in_node, self._out_node = in_nodes[0], out_nodes[0]
         self._order = list(topological_sort(self.graph))
+        # the reference's backward view of the graph (network.py:455-460, 953-960): node -> its source nodes, for every
+        # node on a path to the output node that has sources
+        self._bwd_graph = {n: list(self.graph.predecessors(n)) for n in self._order if self.graph.in_degree(n) > 0}
 
     # ---- per-step evaluation (drop-in for user loops) ----------------------------------------
     def forward(self, x) -> torch.Tensor:
         """One step through the whole graph (reference network.py:462-478)."""
         if not self._order:
             self.compile()
+        if isinstance(x, torch.Tensor) and x.dtype != self.dtype:
+            x = x.to(self.dtype)  # a float64 input to the float32 engine (Network(dtype=float64) warns once)
         for n in self._order:
             preds = list(self.graph.predecessors(n))
             if preds:

@@ -571,6 +571,17 @@ class Spike(torch.autograd.Function):
         return grad_output / (den * den)
 
 
+class SpikeNet(RateNet):
+    """The reference's in-equation-reset spiking node (rectipy/nodes.py:292-330).  Its ``forward`` reads an attribute it
+    never sets (``_y_spike``, nodes.py:324), i.e. it cannot run in the reference either; the name exists for imports
+    (rectipy_tests/test_network.py:5) and construction fails with a clear message."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("SpikeNet (reset=False: the reset written into the equations) is not supported; the "
+                                  "reference's own implementation of it is broken (rectipy/nodes.py:323-330). Use "
+                                  "SpikeResetNet (reset=True).")
+
+
 class SpikeResetNet(RateNet):
     """Spiking population with threshold + reset (reference ``SpikeResetNet``, rectipy/nodes.py:333-401).
 

@@ -60,6 +60,12 @@ class RLS(Linear):
             self._partials = torch.zeros(self.n_in * tiles, dtype=torch.float32, device=dev) \
                 if use and self.n_in % 4 == 0 else None
 
+    def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
+        """``weights @ x``.  The weights and P are float32 (the update runs in the gfx950 kernel); a float64 input -- the
+        reference's default edge dtype -- is answered in float64."""
+        w = self.weights if x.dtype == self.weights.dtype else self.weights.to(x.dtype)
+        return x @ w.T if x.dim() == 2 else w @ x
+
     def sweep(self, X: torch.Tensor, Y: torch.Tensor, stride: int = 1):
         """Train over T consecutive steps: X [T, n_in] edge inputs, Y [T, n_out] targets, an update every `stride`
         steps (at 0, stride, ...).  Returns (pred [T, n_out], loss [T]) as the reference's loop would record them:
