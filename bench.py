@@ -32,11 +32,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def step_kernel_label(rows, n):
-    """Launch shape the library picks for a rows x n shard (rnn_forward.hip: launch_step)."""
-    cache_sized = rows * n * 4 <= (320 << 20)
-    r, u = (4, 2) if rows >= 8192 and not cache_sized else (8, 1) if rows >= 8192 else (2, 2) if rows > 2048 else (1, 4)
-    return f"step_kernel<LI_TANH,R={r},U={u},vec4,nt>"
+def step_kernel_label(streaming):
+    """The step kernel instance the library launched: its streaming configuration comes from the library itself
+    (rp_forward_tuning: the static rule, or the one rp_tune_forward measured for this shape on this device)."""
+    return (f"step_kernel<LI_TANH,R={streaming['rows_per_wave']},U={streaming['chunks_in_flight']},vec4,nt> on "
+            f"{streaming['workgroups'] or 'rows/4R'} workgroups ({'measured' if streaming['measured'] else 'static rule'})")
 
 
 def gen_rows(n, row0, rows, device, g=1.5, block=1024):
@@ -148,6 +148,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax.item())
     finite = bool(torch.isfinite(pop.v).all().item())
+    streaming = pop.backend.forward_tuning(pop._net())
 
     config5 = None
     if use_dist and args.config5_neurons > 0:
@@ -184,7 +185,7 @@ def main():
                    if use_dist else "single GPU, driven through rectipy_amd.Network.run"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": step_kernel_label(rows, N), "algorithmic_bytes_per_launch": algo_bytes,
+                     "kernel": step_kernel_label(streaming), "algorithmic_bytes_per_launch": algo_bytes,
                      "avg_launch_ms": kernel_ms},
         "state_finite": finite,
     }

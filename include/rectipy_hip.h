@@ -406,6 +406,21 @@ typedef struct rp_rls {
 int rp_rls_sweep(const rp_rls* rls, int32_t steps, int32_t stride, const float* X, int64_t ldx, const float* Y,
                  int64_t ldy, float* pred, int64_t ldpred, float* loss, void* stream);
 
+/* Streaming configuration of the dense step kernel, measured on the current device.  How W is walked (rows per wave,
+   256-column chunks in flight, resident workgroups) never changes what is summed in which order, so every configuration
+   gives the same bits; which one is fastest depends on the shape (rows, n, ldw) in ways only a measurement shows
+   (DESIGN.md section 3).  rp_tune_forward times a few dozen configurations on a scratch tanh population over the
+   caller's W (read-only; nothing of `net` but W, n, rows, row0, ldw is used), on `stream`, synchronising the host, and
+   remembers the best per (device, rows, n, ldw) for every later rp_forward / rp_forward_sharded of that shape and any
+   model.  Shapes that do not stream from HBM (rows < 8192 or W <= 320 MiB), the 4-byte path, and a capturing stream
+   return RP_OK without measuring.  No reference counterpart.
+   rp_forward_tuning reports the configuration rp_forward would use now (`measured` = 1 if it came from rp_tune_forward,
+   with its time per step; 0: the static rule). */
+int rp_tune_forward(const rp_net* net, void* stream);
+int rp_forward_tuning(const rp_net* net, int32_t* rows_per_wave, int32_t* chunks_in_flight, int32_t* workgroups,
+                      float* us_per_step, int32_t* measured);
+int rp_clear_forward_tuning(void);
+
 /* Benchmark-only: override the streaming configuration of the tanh step kernel
    (rows per wave, unroll depth, non-temporal W loads, grid cap); rows_per_wave = 0 restores
    the built-in choice.  Results are bit-identical for every configuration. */

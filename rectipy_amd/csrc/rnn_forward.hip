@@ -17,7 +17,12 @@
 // summation tree per row is therefore independent of grid size, R, unrolling
 // and row sharding; oracle/rnn_oracle.c mirrors it bit for bit.
 
+#include <algorithm>
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
 
 #include "rp_common.h"
 #include "rp_dot.h"
@@ -575,11 +580,70 @@ void launch_cfg(const StepParams& P, hipStream_t st, int max_blocks) {
     hipLaunchKernelGGL((step_kernel<MODEL, R, U, VEC4, NT>), dim3(blocks), dim3(kThreads), 0, st, P);
 }
 
-// rows per wave / unroll: large networks stream 4 rows x 2 chunks per wave; small ones
-// use fewer rows per wave so that more waves share the (latency-bound) work.
+// ---- streaming configuration of the dense step kernel ---------------------------------------------------------------
+// Rows per wave R, chunks in flight U and the number of resident workgroups change how W is walked, never what is
+// summed in which order (rp_dot.h): every configuration gives the same bits.  The choice is (1) the benchmark override
+// rp_set_tuning, (2) a configuration measured on this device for this shape by rp_tune_forward, (3) a static rule.
+struct StreamCfg {
+    int R, U, blocks;  // blocks = 0: one workgroup per 4 row groups
+};
+
+struct TunedShape {
+    int device, rows, n;
+    int64_t ldw;
+    StreamCfg cfg;
+    float us;
+};
+std::mutex g_tuned_mu;
+std::vector<TunedShape> g_tuned;
+
+bool tuned_lookup(int rows, int n, int64_t ldw, StreamCfg* cfg, float* us) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_tuned_mu);
+    for (const TunedShape& t : g_tuned)
+        if (t.device == dev && t.rows == rows && t.n == n && t.ldw == ldw) {
+            if (cfg) *cfg = t.cfg;
+            if (us) *us = t.us;
+            return true;
+        }
+    return false;
+}
+
+bool streams_from_hbm(int rows, int n) { return rows >= 8192 && (int64_t)rows * n * 4 > (320ll << 20); }
+
+// measured with scripts/tune_forward.py / tune_shard_shapes.py / sweep_forward_shapes.py (us per step):
+//   n = 32768: (4,2) on 2048 workgroups 620, (2,1) on 683 604;  16384^2 (4,2) 166, (2,1) on 683 151;
+//   16384 x 32768 314 -> 303;  8192 x 32768 (4,2) 163, (2,1) on 1024 155;  4096 x 32768 (2,2) 79
+//   65536^2 and 32768 x 262144: (4,2) on 2048, 7.0 TB/s, nothing better found
+//   n = 12288: (4,2) 90 vs (8,1) 99;  n = 8192 (W ~ Infinity-Cache sized): (8,1) 43 vs (4,2) 51;
+//   n = 4096: (2,2) 11.8;  n = 2048: (1,4) 4.9 vs (2,2) 6.4
+// With rows of at most 128 KiB, two rows x one chunk per wave on about 683 resident workgroups that split the row
+// groups into whole passes is the fastest walk found; which grid is best depends on the shape in ways only a
+// measurement shows (e.g. 20000^2: (4,2) on 512 230 us, this rule 261), hence rp_tune_forward.
+StreamCfg static_cfg(int rows, int n) {
+    if (streams_from_hbm(rows, n)) {
+        if (n <= 32768 && n % 256 == 0) {
+            const int groups = (rows + 1) / 2;
+            const int passes = std::max(1, (groups + 683) / 2732);
+            return StreamCfg{2, 1, (groups + 4 * passes - 1) / (4 * passes)};
+        }
+        return StreamCfg{4, 2, 2048};
+    }
+    if (rows >= 8192) return StreamCfg{8, 1, 2048};
+    if (rows > 2048) return StreamCfg{2, 2, 0};
+    return StreamCfg{1, 4, 0};
+}
+
+StreamCfg choose_cfg(const rp_net* net) {
+    StreamCfg cfg;
+    if (use_vec4(net) && streams_from_hbm(net->rows, net->n) && tuned_lookup(net->rows, net->n, net->ldw, &cfg, nullptr))
+        return cfg;
+    return static_cfg(net->rows, net->n);
+}
+
 template <int MODEL, bool VEC4>
-void launch_step(const StepParams& P, hipStream_t st) {
-    const int rows = P.rows;
+void launch_step(const StepParams& P, hipStream_t st, const StreamCfg& cfg) {
     if constexpr (VEC4 && MODEL == RP_MODEL_LI_TANH) {
         if (g_tune_R > 0) {  // benchmark-only sweep of the streaming configuration
             const int key = g_tune_R * 100 + g_tune_U * 10 + (g_tune_nt != 0 ? 1 : 0);
@@ -588,7 +652,7 @@ void launch_step(const StepParams& P, hipStream_t st) {
 #define RP_CFG(R_, U_)                                                                  \
     case R_ * 100 + U_ * 10 + 1: launch_cfg<MODEL, R_, U_, true, true>(P, st, mb); return; \
     case R_ * 100 + U_ * 10 + 0: launch_cfg<MODEL, R_, U_, true, false>(P, st, mb); return;
-                RP_CFG(1, 2) RP_CFG(1, 4) RP_CFG(1, 8)
+                RP_CFG(1, 2) RP_CFG(1, 4) RP_CFG(1, 8) RP_CFG(1, 16) RP_CFG(2, 8)
                 RP_CFG(2, 1) RP_CFG(2, 2) RP_CFG(2, 4)
                 RP_CFG(4, 1) RP_CFG(4, 2) RP_CFG(4, 4)
                 RP_CFG(8, 1) RP_CFG(8, 2)
@@ -597,32 +661,36 @@ void launch_step(const StepParams& P, hipStream_t st) {
             }
         }
     }
-    // measured with scripts/tune_forward.py / tune_shard_shapes.py (us per step, best configuration):
-    //   n = 32768: (4,2) 625;  shards 16384/8192/4096 x 32768: (4,2) 312 / (4,2) 157 / (2,2) 79
-    //   n = 12288: (4,2) 90 vs (8,1) 99;  n = 8192 (W ~ Infinity-Cache sized): (8,1) 43 vs (4,2) 51;
-    //   n = 4096: (2,2) 11.8;  n = 2048: (1,4) 4.9 vs (2,2) 6.4
-    const bool cache_sized = (int64_t)rows * P.n * 4 <= (320ll << 20);
-    if (rows >= 8192 && !cache_sized)
-        launch_cfg<MODEL, 4, 2, VEC4, true>(P, st, 2048);
-    else if (rows >= 8192)
-        launch_cfg<MODEL, 8, 1, VEC4, true>(P, st, 2048);
-    else if (rows > 2048)
-        launch_cfg<MODEL, 2, 2, VEC4, true>(P, st, 0);
-    else
-        launch_cfg<MODEL, 1, 4, VEC4, true>(P, st, 0);
+    if constexpr (VEC4) {
+        switch (cfg.R * 10 + cfg.U) {  // the configurations rp_tune_forward may pick, for every model
+            case 14: launch_cfg<MODEL, 1, 4, true, true>(P, st, cfg.blocks); return;
+            case 21: launch_cfg<MODEL, 2, 1, true, true>(P, st, cfg.blocks); return;
+            case 22: launch_cfg<MODEL, 2, 2, true, true>(P, st, cfg.blocks); return;
+            case 41: launch_cfg<MODEL, 4, 1, true, true>(P, st, cfg.blocks); return;
+            case 81: launch_cfg<MODEL, 8, 1, true, true>(P, st, cfg.blocks); return;
+            default: launch_cfg<MODEL, 4, 2, true, true>(P, st, cfg.blocks); return;
+        }
+    } else {  // 4-byte path: no chunks in flight to choose
+        switch (cfg.R) {
+            case 1: launch_cfg<MODEL, 1, 1, false, true>(P, st, cfg.blocks); return;
+            case 2: launch_cfg<MODEL, 2, 1, false, true>(P, st, cfg.blocks); return;
+            case 8: launch_cfg<MODEL, 8, 1, false, true>(P, st, cfg.blocks); return;
+            default: launch_cfg<MODEL, 4, 1, false, true>(P, st, cfg.blocks); return;
+        }
+    }
 }
 
 template <bool VEC4>
-void launch_step_model(int model, const StepParams& P, hipStream_t st) {
+void launch_step_model(int model, const StepParams& P, hipStream_t st, const StreamCfg& cfg) {
     switch (model) {
-        case RP_MODEL_LI_TANH: launch_step<RP_MODEL_LI_TANH, VEC4>(P, st); break;
-        case RP_MODEL_LI_SIGMOID: launch_step<RP_MODEL_LI_SIGMOID, VEC4>(P, st); break;
-        case RP_MODEL_QIF: launch_step<RP_MODEL_QIF, VEC4>(P, st); break;
-        case RP_MODEL_QIF_SFA: launch_step<RP_MODEL_QIF_SFA, VEC4>(P, st); break;
-        case RP_MODEL_LIF: launch_step<RP_MODEL_LIF, VEC4>(P, st); break;
-        case RP_MODEL_IK: launch_step<RP_MODEL_IK, VEC4>(P, st); break;
-        case RP_MODEL_IKU: launch_step<RP_MODEL_IKU, VEC4>(P, st); break;
-        default: launch_step<RP_MODEL_IK_BIEXP, VEC4>(P, st); break;
+        case RP_MODEL_LI_TANH: launch_step<RP_MODEL_LI_TANH, VEC4>(P, st, cfg); break;
+        case RP_MODEL_LI_SIGMOID: launch_step<RP_MODEL_LI_SIGMOID, VEC4>(P, st, cfg); break;
+        case RP_MODEL_QIF: launch_step<RP_MODEL_QIF, VEC4>(P, st, cfg); break;
+        case RP_MODEL_QIF_SFA: launch_step<RP_MODEL_QIF_SFA, VEC4>(P, st, cfg); break;
+        case RP_MODEL_LIF: launch_step<RP_MODEL_LIF, VEC4>(P, st, cfg); break;
+        case RP_MODEL_IK: launch_step<RP_MODEL_IK, VEC4>(P, st, cfg); break;
+        case RP_MODEL_IKU: launch_step<RP_MODEL_IKU, VEC4>(P, st, cfg); break;
+        default: launch_step<RP_MODEL_IK_BIEXP, VEC4>(P, st, cfg); break;
     }
 }
 
@@ -752,6 +820,7 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     }
 
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const StreamCfg stream_cfg = choose_cfg(net);
     StepParams P = {};
     fill_static(P, net);
     P.x_mode = run->x_mode;
@@ -802,9 +871,9 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
             const int src_rc = launch_step_sparse_model(net->model, P, st);
             if (src_rc != RP_OK) RP_FAIL(src_rc, "sparse step launch failed (device properties / LDS attribute)");
         } else if (vec4) {
-            launch_step_model<true>(net->model, P, st);
+            launch_step_model<true>(net->model, P, st, stream_cfg);
         } else {
-            launch_step_model<false>(net->model, P, st);
+            launch_step_model<false>(net->model, P, st, stream_cfg);
         }
         if (t == 0) RP_HIP_CHECK(hipGetLastError());  // a rejected launch configuration shows on the first step
         if (comm) {  // every rank wrote rows [row0, row0 + rows) of src_next: exchange in place, same stream
@@ -840,6 +909,143 @@ int rp_set_blocked_tuning(int waves, int groups_in_flight) {
 int rp_set_sparse_tuning(int rows_per_wave, int groups_in_flight) {
     g_sparse_R = rows_per_wave;
     g_sparse_U = groups_in_flight;
+    return RP_OK;
+}
+
+int rp_tune_forward(const rp_net* net, void* stream) {
+    if (!net || !net->W) RP_FAIL(RP_ERR_ARG, "rp_tune_forward: net and net->W must be non-null");
+    if (net->n <= 0 || net->rows <= 0 || net->row0 < 0 || (int64_t)net->row0 + net->rows > net->n || net->ldw < net->n ||
+        net->row0 % 8 != 0)
+        RP_FAIL(RP_ERR_SHAPE, "rp_tune_forward: bad shard n=%d rows=%d row0=%d ldw=%lld", net->n, net->rows, net->row0,
+                (long long)net->ldw);
+    // only the HBM-streaming 16-byte path has anything to choose; smaller shapes keep the static rule
+    if (!use_vec4(net) || !aligned16(net->W) || !streams_from_hbm(net->rows, net->n)) return RP_OK;
+    if (tuned_lookup(net->rows, net->n, net->ldw, nullptr, nullptr)) return RP_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return RP_OK;  // timing needs host synchronisation: not inside a graph capture
+    }
+    int dev = 0;
+    RP_HIP_CHECK(hipGetDevice(&dev));
+
+    // a scratch tanh population on the caller's W (read-only): v = 0, tau = 1, k = eta = 0, source = 0
+    const size_t rows = (size_t)net->rows, n = (size_t)net->n;
+    float* buf = nullptr;
+    RP_HIP_CHECK(hipMalloc(&buf, sizeof(float) * (4 * rows + 2 * n)));
+    float *v = buf, *tau = buf + rows, *k = buf + 2 * rows, *eta = buf + 3 * rows, *src[2] = {buf + 4 * rows, buf + 4 * rows + n};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipFree(buf);
+    };
+    if (hipMemsetAsync(buf, 0, sizeof(float) * (4 * rows + 2 * n), st) != hipSuccess ||
+        hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(tau), 0x3f800000, rows, st) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        cleanup();
+        RP_FAIL(RP_ERR_HIP, "rp_tune_forward: scratch set-up failed (%s)", hipGetErrorString(hipGetLastError()));
+    }
+    StepParams P = {};
+    P.W = net->W;
+    P.ldw = net->ldw;
+    P.n = net->n;
+    P.rows = net->rows;
+    P.row0 = net->row0;
+    P.p[RP_P_TAU] = tau;
+    P.p[RP_P_K] = k;
+    P.p[RP_P_ETA] = eta;
+    P.y[RP_Y_V] = v;
+    P.dt = 1e-3f;
+    P.inv_dt = 1e3f;
+    P.x_mode = RP_X_NONE;
+    P.out_var = RP_OUT_STATE0;
+    int cur = 0;
+    bool failed = false;
+    auto time_cfg = [&](const StreamCfg& cfg, int steps) -> float {  // us per step
+        for (int t = -1; t < steps; ++t) {  // one untimed step first
+            if (t == 0) failed = failed || hipEventRecord(e0, st) != hipSuccess;
+            P.src_cur = src[cur];
+            P.src_next = src[cur ^ 1];
+            cur ^= 1;
+            launch_step<RP_MODEL_LI_TANH, true>(P, st, cfg);
+        }
+        float ms = 0.f;
+        failed = failed || hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                 hipEventElapsedTime(&ms, e0, e1) != hipSuccess;
+        return ms * 1e3f / (float)steps;
+    };
+
+    struct Timed {
+        StreamCfg cfg;
+        float us;
+    };
+    std::vector<Timed> cand;
+    const StreamCfg fallback = static_cfg(net->rows, net->n);
+    cand.push_back(Timed{fallback, 0.f});
+    const int shapes[][2] = {{2, 1}, {4, 2}, {8, 1}, {4, 1}, {2, 2}};
+    for (const auto& ru : shapes) {
+        const int groups = (net->rows + ru[0] - 1) / ru[0];
+        int grids[16];
+        int ng = 0;
+        for (int g : {256, 512, 683, 768, 1024, 2048}) grids[ng++] = g;
+        for (int passes : {2, 3, 4, 6}) grids[ng++] = (groups + 4 * passes - 1) / (4 * passes);  // whole passes
+        for (int q = 0; q < ng; ++q) {
+            const int g = grids[q];
+            if (g < 256 || (int64_t)g * 4 > groups) continue;
+            bool seen = false;
+            for (const Timed& c : cand) seen = seen || (c.cfg.R == ru[0] && c.cfg.U == ru[1] && c.cfg.blocks == g);
+            if (!seen) cand.push_back(Timed{StreamCfg{ru[0], ru[1], g}, 0.f});
+        }
+    }
+    for (Timed& c : cand) c.us = time_cfg(c.cfg, 3);
+    std::sort(cand.begin() + 1, cand.end(), [](const Timed& a, const Timed& b) { return a.us < b.us; });
+    // second look at the static rule (cand[0]) and the best few: three interleaved rounds of 8 steps, medians compared,
+    // so that a drifting clock or a slow stretch of the box hits every finalist alike
+    constexpr int kRounds = 3;
+    const size_t finalists = std::min<size_t>(cand.size(), 5);
+    float seen[5][kRounds];
+    for (int r = 0; r < kRounds && !failed; ++r)
+        for (size_t q = 0; q < finalists; ++q) seen[q][r] = time_cfg(cand[q].cfg, 8);
+    failed = failed || hipStreamSynchronize(st) != hipSuccess;
+    if (!failed)
+        for (size_t q = 0; q < finalists; ++q) {
+            std::sort(seen[q], seen[q] + kRounds);
+            cand[q].us = seen[q][kRounds / 2];
+        }
+    if (const char* log = getenv("RECTIPY_AMD_TUNE_LOG"); log && log[0] == '1')
+        for (size_t q = 0; q < cand.size(); ++q)
+            fprintf(stderr, "[rp_tune_forward %dx%d] %s R=%d U=%d workgroups=%d: %.2f us\n", net->rows, net->n,
+                    q < finalists ? "final" : "first", cand[q].cfg.R, cand[q].cfg.U, cand[q].cfg.blocks, cand[q].us);
+    cleanup();
+    if (failed) RP_FAIL(RP_ERR_HIP, "rp_tune_forward: timing failed (%s)", hipGetErrorString(hipGetLastError()));
+    size_t best = 0;
+    for (size_t q = 1; q < finalists; ++q)
+        if (cand[q].us < cand[best].us * (best == 0 ? 0.99f : 1.0f)) best = q;  // the static rule keeps near-ties
+    std::lock_guard<std::mutex> lock(g_tuned_mu);
+    g_tuned.push_back(TunedShape{dev, net->rows, net->n, net->ldw, cand[best].cfg, cand[best].us});
+    return RP_OK;
+}
+
+int rp_forward_tuning(const rp_net* net, int32_t* rows_per_wave, int32_t* chunks_in_flight, int32_t* workgroups,
+                      float* us_per_step, int32_t* measured) {
+    if (!net) RP_FAIL(RP_ERR_ARG, "net is null");
+    StreamCfg cfg = static_cfg(net->rows, net->n);
+    float us = 0.f;
+    const bool tuned = use_vec4(net) && streams_from_hbm(net->rows, net->n) &&
+                       tuned_lookup(net->rows, net->n, net->ldw, &cfg, &us);
+    if (rows_per_wave) *rows_per_wave = cfg.R;
+    if (chunks_in_flight) *chunks_in_flight = cfg.U;
+    if (workgroups) *workgroups = cfg.blocks;
+    if (us_per_step) *us_per_step = us;
+    if (measured) *measured = tuned ? 1 : 0;
+    return RP_OK;
+}
+
+int rp_clear_forward_tuning(void) {
+    std::lock_guard<std::mutex> lock(g_tuned_mu);
+    g_tuned.clear();
     return RP_OK;
 }
 

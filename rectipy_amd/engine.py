@@ -10,6 +10,7 @@ tensors); tests inject an oracle-backed object with the same four methods to exe
 host logic (sampling bookkeeping, sharding) without a GPU.
 """
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -88,6 +89,20 @@ class HipBackend:
     def forward(self, net: RpNet, run: RpRun, device):
         with self._on(device):
             self._lib_mod.check(self.lib.rp_forward(C.byref(net), C.byref(run), self._stream(device)))
+
+    def tune_forward(self, net: RpNet, device):
+        """Measure the streaming configuration of the dense step kernel for this shape once per process (a no-op for
+        shapes that do not stream from HBM); RECTIPY_AMD_NO_AUTOTUNE=1 keeps the static rule."""
+        if os.environ.get("RECTIPY_AMD_NO_AUTOTUNE", "0") == "1":
+            return
+        with self._on(device):
+            self._lib_mod.check(self.lib.rp_tune_forward(C.byref(net), self._stream(device)))
+
+    def forward_tuning(self, net: RpNet) -> dict:
+        R, U, G, m, us = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_float()
+        self._lib_mod.check(self.lib.rp_forward_tuning(C.byref(net), C.byref(R), C.byref(U), C.byref(G), C.byref(us), C.byref(m)))
+        return dict(rows_per_wave=R.value, chunks_in_flight=U.value, workgroups=G.value, measured=bool(m.value),
+                    us_per_step=us.value)
 
     def rate_backward(self, net: RpNet, bwd: RpBwd, device):
         with self._on(device):
@@ -202,6 +217,7 @@ class Population:
         self.aux2 = self._vec(0.0 if aux2_0 is None else aux2_0) if model in HAS_AUX2 else None
         self._scratch = torch.zeros(4, **f32) if model in NEEDS_MEANS else None
         self._net_cache = None           # (key, RpNet) reused across calls, see _net()
+        self._tuned = False              # rp_tune_forward ran for this population's shape (first forward)
         self.packed = None               # PackedRows of a fixed sparse W (sparse.py); the step kernel then streams it
         self._packed_version = -1        # W._version when `packed` was built (see _sync_packed)
         self.packed_t = None             # PackedRows of W^T (adjoint of a fixed sparse W), built on first use
@@ -462,6 +478,10 @@ class Population:
             run.spike_count = spike_count.data_ptr()
 
         net = self._net()
+        if not self._tuned:  # once per population; the library keeps one measurement per (device, shape)
+            self._tuned = True
+            if self.packed is None and hasattr(self.backend, "tune_forward"):
+                self.backend.tune_forward(net, self.device)
         if comm is None:
             self.backend.forward(net, run, self.device)
         else:

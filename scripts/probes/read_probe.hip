@@ -57,6 +57,41 @@ __global__ __launch_bounds__(256) void k_rows(const f4* buf, int n, float* out, 
     if (s == 123.456f) out[0] = s;
 }
 
+// one-shot tiles WITH the arithmetic of a mat-vec: a wave owns RW rows x (256*CQ) columns, keeps its slice of the source
+// vector in registers, and writes one partial sum per row; consecutive workgroups walk along the row (COLMAJOR false)
+// or down the rows (true)
+template <int RW, int CQ, bool NT, bool COLMAJOR>
+__global__ __launch_bounds__(256) void k_tile_dot(const f4* W, const f4* src, int n, float* partial) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n4 = n / 4, tiles_c = n4 / (64 * CQ), groups = n / (4 * RW);
+    const int tile = COLMAJOR ? blockIdx.x / groups : blockIdx.x % tiles_c;
+    const int grp = COLMAJOR ? blockIdx.x % groups : blockIdx.x / tiles_c;
+    const int row0 = (grp * 4 + wave) * RW;
+    const int c0 = tile * 64 * CQ + lane;
+    f4 s[CQ], a[RW][CQ];
+#pragma unroll
+    for (int q = 0; q < CQ; ++q) s[q] = src[c0 + 64 * q];
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+            const f4* p = W + (int64_t)(row0 + j) * n4 + c0 + 64 * q;
+            a[j][q] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+#pragma unroll
+    for (int j = 0; j < RW; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < CQ; ++q) {
+            const f4 w = a[j][q], r = s[q];
+            acc += (w.x * r.x + w.y * r.y) + (w.z * r.z + w.w * r.w);
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) partial[(int64_t)(row0 + j) * tiles_c + tile] = acc;
+    }
+}
+
 template <typename F> float timeit(F f) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     f(); hipDeviceSynchronize();
@@ -79,5 +114,12 @@ int main() {
     PERSIST(4, true, 2048); PERSIST(8, true, 2048); PERSIST(8, true, 4096); PERSIST(16, true, 2048); PERSIST(8, false, 2048);
 #define ROWS(R, U, L, G) rep("rows R=" #R " U=" #U " nt=" #L " grid=" #G, timeit([&] { hipLaunchKernelGGL((k_rows<R, U, L>), dim3(G), dim3(256), 0, 0, buf, n, out, n / R); }))
     ROWS(4, 2, true, 2048); ROWS(4, 2, false, 2048); ROWS(2, 4, true, 2048); ROWS(1, 8, true, 2048); ROWS(4, 4, true, 2048); ROWS(8, 1, true, 1024);
+    float* partial; f4* src;
+    if (hipMalloc(&partial, (size_t)n * 128 * 4) != hipSuccess || hipMalloc(&src, n * 4) != hipSuccess) return 1;
+    (void)hipMemset(src, 0, n * 4);
+#define TILE(RW, CQ, L, CM) rep("tile-dot RW=" #RW " CQ=" #CQ " nt=" #L " down-rows=" #CM, timeit([&] { hipLaunchKernelGGL((k_tile_dot<RW, CQ, L, CM>), dim3((unsigned)(n4 / (256 * RW * CQ))), dim3(256), 0, 0, buf, src, n, partial); }))
+    TILE(4, 4, true, false); TILE(4, 4, true, true); TILE(4, 4, false, false); TILE(2, 8, true, false); TILE(1, 16, true, false);
+    TILE(8, 2, true, false); TILE(4, 2, true, false); TILE(4, 8, true, false); TILE(2, 4, true, false); TILE(2, 8, true, true);
+    TILE(1, 8, true, false); TILE(8, 4, true, false);
     return 0;
 }

@@ -46,11 +46,11 @@ print(json.dumps({"probe_GBps": pop.W.numel() * 4 / ms / 1e6}), flush=True)
 results = []
 cfgs = [(0, 0, 1, 0)]
 for R in (1, 2, 4, 8):
-    for U in (1, 2, 4, 8):
+    for U in (1, 2, 4, 8, 16):
         for nt in (1, 0):
-            for mb in (0, 1024, 2048):
+            for mb in (0, 1024, 2048, 4096):
                 cfgs.append((R, U, nt, mb))
-valid = {(1, 2), (1, 4), (1, 8), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2)}
+valid = {(1, 2), (1, 4), (1, 8), (1, 16), (2, 8), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2)}
 for R, U, nt, mb in cfgs:
     if R and (R, U) not in valid:
         continue

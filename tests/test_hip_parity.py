@@ -1,5 +1,7 @@
 """HIP kernels vs the CPU oracle through the C ABI -- bit-exact (same summation tree, same
 roundings).  Sizes are small enough for the oracle to finish in seconds."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -607,3 +609,48 @@ def test_long_run_stays_bit_exact(oracle_backend, hip_device, model):
         assert len(res[0][3]) > 500, "expected an actively spiking network"
     else:
         assert float(res[0][0].abs().max()) > 0.1
+
+
+@pytest.mark.gpu
+def test_measured_streaming_configuration_keeps_the_bits():
+    """rp_tune_forward picks how W is walked (rows per wave, chunks in flight, resident workgroups) by timing; the
+    summation order does not depend on it, so a run before and after the measurement gives identical bits, for the model
+    that was timed (tanh) and for another one (QIF) that reuses the measurement."""
+    import ctypes as C
+
+    from rectipy_amd import _lib
+    from rectipy_amd.engine import Population
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    rows, n = 8192, 16384                                    # 512 MiB: streams from HBM
+    gen = torch.Generator(device=dev).manual_seed(5)
+    W = torch.randn(rows, n, device=dev, generator=gen) * (1.2 / n ** 0.5)
+    x = torch.sin(torch.arange(12, device=dev) * 0.1).reshape(-1, 1).contiguous()
+    os.environ["RECTIPY_AMD_NO_AUTOTUNE"] = "1"
+    try:
+        lib.rp_clear_forward_tuning()
+        outs = {}
+        for tuned in (False, True):
+            pop = Population("li_tanh", W, dict(tau=2.0, k=1.0, eta=0.1), 1e-2, dev, n=n, row0=4096)
+            pop.source.copy_(torch.tanh(torch.randn(n, device=dev, generator=torch.Generator(device=dev).manual_seed(6))))
+            if tuned:
+                w_before = W.clone()
+                _lib.check(lib.rp_tune_forward(C.byref(pop._net()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+                assert torch.equal(W, w_before)
+                info = pop.backend.forward_tuning(pop._net())
+                assert info["measured"] and info["us_per_step"] > 0
+                assert info["rows_per_wave"] in (1, 2, 4, 8) and info["workgroups"] >= 0
+            else:
+                assert not pop.backend.forward_tuning(pop._net())["measured"]
+            traj = torch.empty(12, rows, device=dev)
+            pop.forward(12, x=x, traj=traj)
+            qif = Population("qif", W, dict(tau=1.0, k=1.0, eta=-5.0, tau_s=1.0), 1e-3, dev, n=n, row0=4096,
+                             v0=torch.linspace(-2, 99, rows))
+            qtraj = torch.empty(6, rows, device=dev)
+            qif.forward(6, traj=qtraj)
+            outs[tuned] = (traj, pop.v.clone(), qtraj, qif.v.clone())
+        for a, b in zip(outs[False], outs[True]):
+            assert torch.equal(a, b)
+    finally:
+        os.environ.pop("RECTIPY_AMD_NO_AUTOTUNE", None)
+        lib.rp_clear_forward_tuning()
