@@ -434,6 +434,7 @@ int rp_set_blocked_tuning(int waves_per_workgroup, int groups_in_flight); /* blo
 /* Benchmark-only: rows in flight per wave (unroll) and 1-KiB column groups per lane of the adjoint's column-strip
    kernel; 0, 0 restores the built-in choice.  Results are bit-identical for every configuration. */
 int rp_set_bwd_tuning(int unroll, int strip_groups);
+int rp_set_bwd_grid(int max_workgroups); /* benchmark-only: cap on the strip kernel's resident workgroups; 0 = built-in */
 /* Benchmark-only: number of row chunks of the adjoint (0 = built-in RC(n)).  Unlike the two above this CHANGES the
    summation order, i.e. results then differ from the oracle in the last bits; never set in production. */
 int rp_set_bwd_chunks(int max_chunks);

@@ -31,11 +31,14 @@ constexpr int kThreads = 256;
 constexpr int kMaxChunks = 64;
 std::atomic<int> g_bwd_chunks{0};  // benchmark-only override of the chunk count (rp_set_bwd_chunks); changes the summation order
 
-// RC(n, rows): rows per chunk (multiple of 8) for `rows` rows of an n-column matrix.  The chunk count aims at ~1024
-// waves of 512-column strips, Q = clamp(1024 / ceil(n / 512), 8, 64): long row streams per wave are worth more than
-// extra waves once the chip is covered (n = 32768, scripts/tune_chunks.py: Q = 16 636 us, 32 644 us, 64 655 us per step).
+// RC(n, rows): rows per chunk (multiple of 8) for `rows` rows of an n-column matrix.  The chunk count is part of the
+// summation-order contract (oracle/rnn_oracle.c mirrors it): Q = clamp(3072 / ceil(n / 256), 8, 64), i.e. about 3072
+// (chunk, 256-column strip) items -- 12 waves per CU, each with 2 rows x 1 KiB in flight, which is where the chip's
+// HBM streams fastest (scripts/tune_chunks.py, us per adjoint step, r02): n = 32768: Q = 16 634 (r01 rule), 20 616,
+// 24 602, 28 638, 40 626 (599 with one row in flight), 64 655;  n = 65536: Q = 8 2508 (r01 rule), 12 2405, 24 2408;
+// n = 16384: Q = 32 167 (r01 rule), 40 156, 48 168.
 inline int chunk_rows(int n, int rows) {
-    int q = 1024 / ((n + 511) / 512);
+    int q = 3072 / ((n + 255) / 256);
     q = q < 8 ? 8 : (q > kMaxChunks ? kMaxChunks : q);
     if (g_bwd_chunks > 0) q = g_bwd_chunks;
     int rc = (rows + q - 1) / q;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(kThreads) void wt_partial_kernel(const BwdParams P)
 }
 
 // benchmark-only override of (U, SW); 0 = built-in choice (rp_set_bwd_tuning)
-std::atomic<int> g_bwd_U{0}, g_bwd_SW{0};
+std::atomic<int> g_bwd_U{0}, g_bwd_SW{0}, g_bwd_blocks{0};
 
 void launch_wt_partial(const BwdParams& P, bool vec4, hipStream_t st) {
     if (!vec4) {
@@ -189,18 +192,24 @@ void launch_wt_partial(const BwdParams& P, bool vec4, hipStream_t st) {
     // measured (scripts/size_sweep.py, scripts/tune_backward.py): 2-KiB strips with 4 rows in flight are the fastest
     // shape from n = 8192 up (n = 32768: 6.7-6.8 TB/s vs 6.3 TB/s for 1-KiB strips); below that the narrow strips give
     // more waves.  2-KiB strips need >= 1024 waves.
+    // r02: with >= 2560 items of 1-KiB strips, 2 rows in flight per wave on at most 768 workgroups (12 waves per CU,
+    // 24 KiB in flight per CU) is the fastest shape: n = 32768 602 us vs 634 for 2-KiB strips x 4 rows.
+    const bool many = ((P.n + 255) / 256) * P.q >= 2560;
     const bool wide = ((P.n + 511) / 512) * P.q >= 1024;
     const int tu = g_bwd_U, tsw = g_bwd_SW;
-    const int U = tu ? tu : (wide ? 4 : 8), SW = tsw ? tsw : (wide ? 2 : 1);
+    const int U = tu ? tu : (many ? 2 : wide ? 4 : 8), SW = tsw ? tsw : (many ? 1 : wide ? 2 : 1);
     const int strips = (P.n + 256 * SW - 1) / (256 * SW);
     int blocks = (strips * P.q + 3) / 4;
     if (blocks > 4096) blocks = 4096;
+    if (many && !tu && !tsw && blocks > 768) blocks = 768;
+    if (const int cap = g_bwd_blocks; cap > 0 && blocks > cap) blocks = cap;
 #define RP_BW(U_, SW_)                                                                                         \
     if (U == U_ && SW == SW_) {                                                                                \
         hipLaunchKernelGGL((wt_partial_kernel<true, U_, SW_>), dim3(blocks), dim3(kThreads), 0, st, P);        \
         return;                                                                                                \
     }
     RP_BW(8, 1) RP_BW(16, 1) RP_BW(4, 1) RP_BW(4, 2) RP_BW(8, 2) RP_BW(2, 2) RP_BW(6, 2) RP_BW(32, 1) RP_BW(12, 1) RP_BW(3, 2) RP_BW(5, 2)
+    RP_BW(2, 1) RP_BW(1, 1) RP_BW(3, 1) RP_BW(1, 2)
 #undef RP_BW
     hipLaunchKernelGGL((wt_partial_kernel<true, 8, 1>), dim3(blocks), dim3(kThreads), 0, st, P);
 }
@@ -961,6 +970,11 @@ int rp_backward_sharded(const rp_net* net, const rp_bwd* b, const rp_comm* comm,
 
 int rp_set_bwd_chunks(int max_chunks) {
     g_bwd_chunks = max_chunks;
+    return RP_OK;
+}
+
+int rp_set_bwd_grid(int max_workgroups) {
+    g_bwd_blocks = max_workgroups;
     return RP_OK;
 }
 

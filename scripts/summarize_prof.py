@@ -11,7 +11,7 @@ out = sys.argv[1]
 
 def find(sub, pattern):
     hits = glob.glob(os.path.join(out, sub, "**", pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None  # (gpurun merges into gpurun_out/: older runs' files stay)
 
 
 stats = find("stats", "*kernel_stats.csv")
@@ -28,6 +28,21 @@ if stats:
         print(f"{name:90s} {calls:7d} {avg:10.2f} {tot:10.2f} {float(r.get('Percentage', 0)):6.2f}")
         summary[name] = dict(calls=calls, avg_us=avg, total_ms=tot)
 
+# the same kernel instance runs on several grids (other shapes of the bench's extra legs, and the few hundred launches
+# of rp_tune_forward's measurement): per (kernel, grid) durations from the trace of the same run
+trace = find("stats", "*kernel_trace.csv")
+if trace:
+    per = defaultdict(list)
+    for r in csv.DictReader(open(trace)):
+        if "step_kernel<" in r.get("Kernel_Name", ""):
+            per[(r["Kernel_Name"][:60], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])))].append(
+                (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print("== step kernel per (instance, workgroups) from the kernel trace ==")
+    print(f"{'kernel':60s} {'workgroups':>10s} {'calls':>7s} {'avg_us':>10s} {'min_us':>10s}")
+    for (name, grid), v in sorted(per.items(), key=lambda kv: -len(kv[1]))[:6]:
+        print(f"{name:60s} {grid:10d} {len(v):7d} {sum(v) / len(v):10.2f} {min(v):10.2f}")
+        summary[f"{name} @ {grid} workgroups"] = dict(calls=len(v), avg_us=sum(v) / len(v), min_us=min(v))
+
 for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     f = find(sub, "*counter_collection.csv")
     if not f:
@@ -37,7 +52,8 @@ for sub, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         if r.get("Counter_Name") == counter:
             per_kernel[r.get("Kernel_Name", "")[:90]].append(float(r.get("Counter_Value", 0)))
     print(f"== {counter} per dispatch (raw counter units, KiB) ==")
-    for name, vals in sorted(per_kernel.items(), key=lambda kv: -sum(kv[1]))[:6]:
+    ranked = sorted(per_kernel.items(), key=lambda kv: -sum(kv[1]))
+    for name, vals in ranked[:6] + [kv for kv in ranked[6:] if "step_kernel<" in kv[0]]:
         avg = sum(vals) / len(vals)
         print(f"{name:90s} n={len(vals):5d} avg={avg:14.1f}")
         summary.setdefault(name, {})[counter + "_avg_KiB"] = avg

@@ -39,14 +39,22 @@ def timed(reps=5 if T <= 50 else 3):
     return ts[0], ts[len(ts) // 2]
 
 
-for rounds in range(2):
-    for Q in ((16, 32, 48, 64) if T <= 50 else (16, 32, 64)):
-        for U, SW in (((4, 2), (8, 1), (8, 2), (2, 2)) if T <= 50 else ((4, 2), (8, 1))):
-            lib.rp_set_bwd_chunks(Q)
-            lib.rp_set_bwd_tuning(U, SW)
-            run()
-            best, med = timed()
-            print(json.dumps(dict(N=N, Q=Q, U=U, SW=SW, best_us=round(best, 1), med_us=round(med, 1),
-                                  med_GBps=round(4.0 * N * N / med / 1e3, 1))), flush=True)
+# optional: argv[3] = "Q,Q,...", argv[4] = "U:SW,U:SW,...", argv[5] = "grid,grid,..." (0 = one workgroup per 4 items)
+QS = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else ((16, 32, 48, 64) if T <= 50 else (16, 32, 64))
+SHAPES = [tuple(int(w) for w in v.split(":")) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else \
+    (((4, 2), (8, 1), (8, 2), (2, 2)) if T <= 50 else ((4, 2), (8, 1)))
+GRIDS = [int(v) for v in sys.argv[5].split(",")] if len(sys.argv) > 5 else [0]
+for rounds in range(2 if len(sys.argv) <= 3 else 1):
+    for Q in QS:
+        for U, SW in SHAPES:
+            for grid in GRIDS:
+                lib.rp_set_bwd_chunks(Q)
+                lib.rp_set_bwd_tuning(U, SW)
+                lib.rp_set_bwd_grid(grid)
+                run()
+                best, med = timed()
+                print(json.dumps(dict(N=N, Q=Q, U=U, SW=SW, grid=grid, best_us=round(best, 1), med_us=round(med, 1),
+                                      med_GBps=round(4.0 * N * N / med / 1e3, 1))), flush=True)
 lib.rp_set_bwd_chunks(0)
 lib.rp_set_bwd_tuning(0, 0)
+lib.rp_set_bwd_grid(0)

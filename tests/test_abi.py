@@ -47,7 +47,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.rp_forward(C.byref(net), C.byref(run), None) == _abi.RP_ERR_ARG
     assert b"model" in lib.rp_last_error()
     assert lib.rp_outer_accum(0, 1, 1.0, None, 0, None, 0, None, 0, None) == _abi.RP_ERR_ARG
-    assert lib.rp_bwd_partial_rows(32768) == 16 and lib.rp_bwd_partial_rows(8192) == 64 and lib.rp_bwd_partial_rows(10) == 2
+    assert lib.rp_bwd_partial_rows(32768) == 24 and lib.rp_bwd_partial_rows(65536) == 12 and lib.rp_bwd_partial_rows(8192) == 64 and lib.rp_bwd_partial_rows(10) == 2
     with pytest.raises(ValueError):
         _lib.check(_abi.RP_ERR_ARG)
     with pytest.raises(RuntimeError):
