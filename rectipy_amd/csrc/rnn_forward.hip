@@ -664,7 +664,7 @@ void launch_step(const StepParams& P, hipStream_t st, const StreamCfg& cfg) {
 #define RP_CFG(R_, U_)                                                                  \
     case R_ * 100 + U_ * 10 + 1: launch_cfg<MODEL, R_, U_, true, true>(P, st, mb); return; \
     case R_ * 100 + U_ * 10 + 0: launch_cfg<MODEL, R_, U_, true, false>(P, st, mb); return;
-                RP_CFG(1, 2) RP_CFG(1, 4) RP_CFG(1, 8) RP_CFG(1, 16) RP_CFG(2, 8)
+                RP_CFG(1, 1) RP_CFG(1, 2) RP_CFG(1, 4) RP_CFG(1, 8) RP_CFG(2, 8) RP_CFG(3, 1)
                 RP_CFG(2, 1) RP_CFG(2, 2) RP_CFG(2, 4)
                 RP_CFG(4, 1) RP_CFG(4, 2) RP_CFG(4, 4)
                 RP_CFG(8, 1) RP_CFG(8, 2)

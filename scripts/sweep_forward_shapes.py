@@ -21,7 +21,7 @@ os.environ["RECTIPY_AMD_NO_AUTOTUNE"] = "1"  # the sweep itself runs on the stat
 if os.environ.get('CFGS'):
     valid = [tuple(int(v) for v in c.split(',')) for c in os.environ['CFGS'].split(';')]
 else:
-    valid = [(1, 2), (1, 4), (1, 8), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2)]
+    valid = [(1, 1), (1, 2), (1, 4), (1, 8), (3, 1), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2)]
 for rows, n in shapes:
     W = torch.empty(rows, n, device=dev).normal_(0.0, 1.5 / n ** 0.5)
     pop = Population("li_tanh", W, dict(tau=10.0, k=1.0, eta=0.0), 1e-2, dev, n=n, row0=0)
