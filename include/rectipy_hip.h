@@ -379,6 +379,7 @@ typedef struct rp_batch {
 int rp_sizeof_batch(void);
 int rp_forward_batched(const rp_net* net, rp_batch* batch, void* stream);
 int rp_set_batched_tuning(int rows_per_wave, int unroll); /* benchmark-only; 0 = built-in */
+int rp_set_batched_grid(int max_workgroups); /* benchmark-only: cap on the resident workgroups of the vector-ALU batched step; 0 = built-in */
 
 /*
  * Recursive-least-squares training of a readout edge (reference RLS.update, rectipy/edges.py:227-234, driven by

@@ -136,11 +136,14 @@ __global__ __launch_bounds__(kThreads) void step_batched_kernel(const BatchParam
     }
 }
 
+std::atomic<int> g_bt_R{0}, g_bt_U{0}, g_bt_blocks{0};  // benchmark-only override (rp_set_batched_tuning / _grid)
+
 template <int MODEL, int R, int B, int U>
-void launch(const BatchParams& P, hipStream_t st) {
+void launch(const BatchParams& P, hipStream_t st, int default_blocks = 2048) {
     const int groups = (P.rows + R - 1) / R;
     int blocks = (groups + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
+    const int cap = g_bt_blocks > 0 ? (int)g_bt_blocks : default_blocks;
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((step_batched_kernel<MODEL, R, B, U>), dim3(blocks), dim3(kThreads), 0, st, P);
 }
 
@@ -280,14 +283,22 @@ __global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const Batch
     }
 }
 
-std::atomic<int> g_bt_R{0}, g_bt_U{0};  // benchmark-only override (rp_set_batched_tuning)
-
 template <int MODEL>
 int launch_model(const BatchParams& P, int B, hipStream_t st) {
     // R * B accumulator sets of four floats per lane; W chunks in flight per wave: R * U KiB
     if constexpr (MODEL == RP_MODEL_LI_TANH) {  // benchmark-only sweep
         const int key = B * 100 + g_bt_R * 10 + g_bt_U;
         switch (key) {
+            case 221: launch<MODEL, 2, 2, 1>(P, st); return RP_OK;
+            case 222: launch<MODEL, 2, 2, 2>(P, st); return RP_OK;
+            case 241: launch<MODEL, 4, 2, 1>(P, st); return RP_OK;
+            case 242: launch<MODEL, 4, 2, 2>(P, st); return RP_OK;
+            case 421: launch<MODEL, 2, 4, 1>(P, st); return RP_OK;
+            case 422: launch<MODEL, 2, 4, 2>(P, st); return RP_OK;
+            case 821: launch<MODEL, 2, 8, 1>(P, st); return RP_OK;
+            case 841: launch<MODEL, 4, 8, 1>(P, st); return RP_OK;
+            case 811: launch<MODEL, 1, 8, 1>(P, st); return RP_OK;
+            case 812: launch<MODEL, 1, 8, 2>(P, st); return RP_OK;
             case 481: launch<MODEL, 8, 4, 1>(P, st); return RP_OK;
             case 482: launch<MODEL, 8, 4, 2>(P, st); return RP_OK;
             case 441: launch<MODEL, 4, 4, 1>(P, st); return RP_OK;
@@ -301,10 +312,12 @@ int launch_model(const BatchParams& P, int B, hipStream_t st) {
         }
     }
     switch (B) {
-        case 2: launch<MODEL, 4, 2, 2>(P, st); return RP_OK;
+        // r02 (scripts/sweep_batched.py, N = 32768, ms per step): fewer resident workgroups, as for the unbatched walk --
+        // B=2 (4,2) on 2048 0.627, (4,1) on 768 0.618;  B=4 (8,2) on 2048 0.639, on 512 0.629;  B=8 flat (0.86)
+        case 2: launch<MODEL, 4, 2, 1>(P, st, 768); return RP_OK;
         // measured at N = 32768 (scripts/bench_batched.py): B=2 1.98x, B=4 3.91x, B=8 5.74x, B=16 5.92x the throughput of
         // B unbatched runs; from B = 8 the L2 -> CU path (B source loads per R rows of W) and the register budget bind
-        case 4: launch<MODEL, 8, 4, 2>(P, st); return RP_OK;
+        case 4: launch<MODEL, 8, 4, 2>(P, st, 512); return RP_OK;
         case 8: launch<MODEL, 4, 8, 1>(P, st); return RP_OK;
         case 16: launch<MODEL, 2, 16, 1>(P, st); return RP_OK;
         default: return RP_ERR_ARG;
@@ -316,6 +329,11 @@ int launch_model(const BatchParams& P, int B, hipStream_t st) {
 extern "C" {
 
 int rp_sizeof_batch(void) { return (int)sizeof(rp_batch); }
+
+int rp_set_batched_grid(int max_workgroups) {
+    g_bt_blocks = max_workgroups;
+    return RP_OK;
+}
 
 int rp_set_batched_tuning(int rows_per_wave, int unroll) {
     g_bt_R = rows_per_wave;
