@@ -442,6 +442,7 @@ int rp_set_bwd_chunks(int max_chunks);
 
 /* Benchmark-only: rows per wave, column chunks in flight and store policy (-1 = default) of the RLS pass. */
 int rp_set_rls_tuning(int rows_per_wave, int unroll, int nontemporal_store);
+int rp_set_rls_tile(int kcols_per_tile, int workgroups_per_cu); /* benchmark-only: tile width (x 1024 columns; changes the summation order) and residency cap of the tiled RLS pass; 0, 0 = built-in */
 
 /* Bandwidth probe used by bench.py: sums `bytes` of HBM with the same load shape as the step kernel. */
 int rp_stream_probe(const float* buf, int64_t n_floats, float* out, void* stream);

@@ -57,24 +57,22 @@ static float pass_row(float* p, int n, int vec4, int update, float kz, const flo
     return butterfly64(s);
 }
 
-/* tiled pass (rp_rls.partials given, 16-byte path): row i is cut into tiles of 4096 columns; inside a tile, wave w owns
-   the columns 1024 u + 256 w + 4 l + c (u = 0..3): accumulators a[l][c] over u ascending, lane sum, butterfly -> s_w; the
-   tile partial is ((s_0 + s_1) + s_2) + s_3; the row's dot = tile partials added ascending (rls_tile_kernel) */
+/* tiled pass (rp_rls.partials given, 16-byte path): row i is cut into tiles of 1024 columns; inside a tile, wave w owns
+   the columns 256 w + 4 l + c: products a[l][c], lane sum, butterfly -> s_w; the tile partial is
+   ((s_0 + s_1) + s_2) + s_3; the row's dot = tile partials added ascending (rls_tile_kernel) */
 static float pass_row_tiled(float* p, int n, int update, float kz, const float* z, const float* x_next) {
     if (update)
         for (int j = 0; j < n; ++j) p[j] = p[j] - kz * z[j];
     if (!x_next) return 0.0f;
     float total = 0.0f;
-    for (int c0 = 0, c = 0; c0 < n; c0 += 4096, ++c) {
+    for (int c0 = 0, c = 0; c0 < n; c0 += 1024, ++c) {
         float sw[4];
         for (int w = 0; w < 4; ++w) {
             float a[256], s[64];
-            for (int q = 0; q < 256; ++q) a[q] = 0.0f;
-            for (int u = 0; u < 4; ++u)
-                for (int q = 0; q < 256; ++q) {
-                    const int j = c0 + 1024 * u + 256 * w + q;
-                    if (j < n) a[q] = fmaf(p[j], x_next[j], a[q]);
-                }
+            for (int q = 0; q < 256; ++q) {
+                const int j = c0 + 256 * w + q;
+                a[q] = j < n ? fmaf(p[j], x_next[j], 0.0f) : 0.0f;
+            }
             for (int l = 0; l < 64; ++l) s[l] = (a[4 * l] + a[4 * l + 1]) + (a[4 * l + 2] + a[4 * l + 3]);
             sw[w] = butterfly64(s);
         }

@@ -249,6 +249,7 @@ def declare(lib):
     sig("rp_set_bwd_grid", C.c_int, [C.c_int])
     sig("rp_set_bwd_tuning", C.c_int, [C.c_int, C.c_int])
     sig("rp_set_bwd_chunks", C.c_int, [C.c_int])
+    sig("rp_set_rls_tile", C.c_int, [C.c_int, C.c_int])
     sig("rp_set_rls_tuning", C.c_int, [C.c_int, C.c_int, C.c_int])
     return lib
 
@@ -258,5 +259,5 @@ EXPORTS = [
     "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum", "rp_outer_accum_rect",
     "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial", "rp_bwd_apply",
     "rp_sizeof_comm", "rp_forward_sharded", "rp_backward_sharded",
-    "rp_sizeof_batch", "rp_forward_batched", "rp_set_batched_tuning", "rp_set_batched_grid", "rp_rls_sweep", "rp_stream_probe", "rp_tune_forward", "rp_forward_tuning", "rp_clear_forward_tuning", "rp_set_tuning", "rp_set_sparse_tuning", "rp_set_blocked_tuning", "rp_set_bwd_tuning", "rp_set_bwd_grid", "rp_set_bwd_chunks", "rp_set_rls_tuning",
+    "rp_sizeof_batch", "rp_forward_batched", "rp_set_batched_tuning", "rp_set_batched_grid", "rp_rls_sweep", "rp_stream_probe", "rp_tune_forward", "rp_forward_tuning", "rp_clear_forward_tuning", "rp_set_tuning", "rp_set_sparse_tuning", "rp_set_blocked_tuning", "rp_set_bwd_tuning", "rp_set_bwd_grid", "rp_set_bwd_chunks", "rp_set_rls_tuning", "rp_set_rls_tile",
 ]

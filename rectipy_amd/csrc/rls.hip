@@ -215,31 +215,36 @@ __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
 
 // Tiled pass (rp_rls.partials given).  How the chip walks P decides the speed of an in-place update, not its arithmetic
 // (scripts/probes/rmw_probe.hip, 4 GiB read-modify-write on one MI355X): one wave per row keeps 8192 far-apart row
-// streams open -- 5.1 TB/s; ONE-SHOT workgroups that each take 16 KiB of contiguous memory in address order, all loads
-// first, then all stores -- 6.2 TB/s.  Here a workgroup (4 waves) takes the tile (row i, columns [4096 c, 4096 c + 4096)):
-// thread (wave w, lane l) owns columns 4096 c + 1024 u + 256 w + 4 l .. +3 for u = 0..3, i.e. every wave instruction
-// touches 1 KiB and the four waves 4 KiB of contiguous memory per u.  The tile's share of the mat-vec: per wave the
-// accumulators a[l][comp] over u ascending, lane sum (a0+a1)+(a2+a3), butterfly; the four wave sums are added in wave
-// order; rls_zn_kernel adds a row's tile partials in ascending order (mirrored by oracle/rls_oracle.c).
-constexpr int kTileCols = 4096;
+// streams open -- 5.1 TB/s; ONE-SHOT workgroups that each take a contiguous piece in address order, all loads first,
+// then all stores -- 6.2 TB/s with 16 KiB per workgroup, 6.7 TB/s with 4 KiB (one 16-byte access per lane: less in
+// flight per CU, as for the step kernel's walk).  Here a workgroup (4 waves) takes the tile (row i, columns
+// [1024 c, 1024 c + 1024)): thread (wave w, lane l) owns columns 1024 c + 256 w + 4 l .. +3.  The tile's share of the
+// mat-vec: the four products of a lane, lane sum (a0+a1)+(a2+a3), butterfly; the four wave sums are added in wave order;
+// rls_zn_kernel adds a row's tile partials in ascending order (mirrored by oracle/rls_oracle.c).  Measured at
+// n_in = 32768 (scripts/sweep_rls_tiles.py): 4096-column tiles 1.54 ms per update, 2048 1.56, 1024 1.41.
+// (TU = 2, 4: wider tiles, thread owns columns 1024 u + 256 w + 4 l of the tile, accumulated over u ascending --
+// benchmark-only, rp_set_rls_tile; a different summation order.)
+constexpr int kTileCols = 1024;
 
-template <bool NTS, bool UPDATE>
+template <bool NTS, bool UPDATE, int TU>
 __global__ __launch_bounds__(kThreads) void rls_tile_kernel(const RlsParams P) {
     __shared__ float wsum[kThreads / 64];
+    extern __shared__ float residency_pad[];  // (never touched: a dynamic allocation caps the workgroups per CU)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n = P.n_in;
-    const int tpr = (n + kTileCols - 1) / kTileCols;
+    constexpr int kCols = 1024 * TU;
+    const int tpr = (n + kCols - 1) / kCols;
     const int row = blockIdx.x / tpr;
     const int ct = blockIdx.x - row * tpr;
-    const int col0 = ct * kTileCols + 256 * wave + 4 * lane;
+    const int col0 = ct * kCols + 256 * wave + 4 * lane;
     float* prow = P.P + (int64_t)row * P.ldp;
     const bool dot = P.x_next != nullptr && !P.no_dot;
     const float kz = UPDATE ? P.scal[0] * P.z[row] : 0.f;
     const rp_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    rp_f4 p[4], zv[4], xv[4];
+    rp_f4 p[TU], zv[TU], xv[TU];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < TU; ++u) {
         const int col = col0 + 1024 * u;
         if (col < n) {
             p[u] = rp_ld4_stream(prow + col);
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void rls_tile_kernel(const RlsParams P) {
     }
     rp_f4 a = zero4;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < TU; ++u) {
         const int col = col0 + 1024 * u;
         if (col < n) {
             if constexpr (UPDATE) {
@@ -277,10 +282,10 @@ __global__ __launch_bounds__(kThreads) void rls_tile_kernel(const RlsParams P) {
 }
 
 // z'_i = beta_inv * (part[i][0] + part[i][1] + ...), ascending
-__global__ void rls_zn_kernel(const RlsParams P) {
+__global__ void rls_zn_kernel(const RlsParams P, int tile_cols) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P.n_in) return;
-    const int tpr = (P.n_in + kTileCols - 1) / kTileCols;
+    const int tpr = (P.n_in + tile_cols - 1) / tile_cols;
     const float* part = P.partials + (int64_t)i * tpr;
     float s = part[0];
     for (int c = 1; c < tpr; ++c) s = s + part[c];
@@ -290,6 +295,7 @@ __global__ void rls_zn_kernel(const RlsParams P) {
 std::atomic<int> g_rls_R{0}, g_rls_U{0}, g_rls_nts{-1};  // benchmark-only override (rp_set_rls_tuning)
 
 std::atomic<int> g_rls_blocks{0};  // benchmark-only: grid cap override
+std::atomic<int> g_rls_tile_u{0}, g_rls_tile_per_cu{0};  // benchmark-only (rp_set_rls_tile): KiB-columns per tile, residency cap
 
 template <int R, int U, bool NTS, bool UPDATE>
 void launch_cfg(const RlsParams& P, bool vec4, hipStream_t st) {
@@ -313,14 +319,26 @@ void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
     const int R = tr ? tr : 2, U = tu ? tu : 4;
     const bool nts = tn < 0 ? true : (tn & 1) != 0;
     if (vec4 && P.partials) {  // one-shot tiles in address order + the per-row sum of the tile partials
-        const int tpr = (P.n_in + kTileCols - 1) / kTileCols;
+        const int TU = g_rls_tile_u > 0 ? (int)g_rls_tile_u : kTileCols / 1024;
+        const int per_cu = g_rls_tile_per_cu;
+        const int tile_cols = 1024 * TU;
+        const int tpr = (P.n_in + tile_cols - 1) / tile_cols;
         const unsigned blocks = (unsigned)P.n_in * (unsigned)tpr;
-        if (nts)
-            hipLaunchKernelGGL((rls_tile_kernel<true, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
-        else
-            hipLaunchKernelGGL((rls_tile_kernel<false, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
+        const size_t lds = per_cu > 0 ? ((size_t)rp_lds_limit() - 1024) / per_cu - 64 : 0;  // (the kernel has 16 static bytes)
+#define RP_TILE(TU_)                                                                                                  \
+    if (TU == TU_) {                                                                                                  \
+        if (nts) {                                                                                                    \
+            if (lds) rp_allow_dynamic_lds<rls_tile_kernel<true, UPDATE, TU_>>(rp_lds_limit() - 1024);                        \
+            hipLaunchKernelGGL((rls_tile_kernel<true, UPDATE, TU_>), dim3(blocks), dim3(kThreads), lds, st, P);      \
+        } else {                                                                                                      \
+            if (lds) rp_allow_dynamic_lds<rls_tile_kernel<false, UPDATE, TU_>>(rp_lds_limit() - 1024);                       \
+            hipLaunchKernelGGL((rls_tile_kernel<false, UPDATE, TU_>), dim3(blocks), dim3(kThreads), lds, st, P);     \
+        }                                                                                                             \
+    }
+        RP_TILE(1) RP_TILE(2) RP_TILE(4)
+#undef RP_TILE
         if (P.x_next && !P.no_dot)
-            hipLaunchKernelGGL(rls_zn_kernel, dim3((P.n_in + 255) / 256), dim3(256), 0, st, P);
+            hipLaunchKernelGGL(rls_zn_kernel, dim3((P.n_in + 255) / 256), dim3(256), 0, st, P, tile_cols);
         return;
     }
 #define RP_RLS(R_, U_)                                            \
@@ -337,6 +355,14 @@ void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int rp_set_rls_tile(int kcols_per_tile, int workgroups_per_cu) {
+    if (kcols_per_tile != 0 && kcols_per_tile != 1 && kcols_per_tile != 2 && kcols_per_tile != 4)
+        RP_FAIL(RP_ERR_ARG, "rp_set_rls_tile: tile of %d x 1024 columns is not built", kcols_per_tile);
+    g_rls_tile_u = kcols_per_tile;
+    g_rls_tile_per_cu = workgroups_per_cu;
+    return RP_OK;
+}
 
 extern "C" int rp_set_rls_tuning(int rows_per_wave, int unroll, int nontemporal_store) {
     g_rls_R = rows_per_wave;

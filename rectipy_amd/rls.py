@@ -35,7 +35,7 @@ class RLS(Linear):
         self._partials = None
         self.tiled = None  # None: by size; True / False: force the tiled / row-per-wave pass (tests, measurements)
 
-    TILED_MIN_N = 24576  # measured (scripts/bench_rls.py): n_in = 32768: 1.54 vs 1.67 ms per update; 16384 and below: tie
+    TILED_MIN_N = 8192  # measured (scripts/bench_rls.py, ms per update tiled / row-per-wave): n_in = 8192 0.108 / 0.113, 16384 0.386 / 0.401, 32768 1.43 / 1.68
 
     def to(self, device: str, **kwargs):
         self.weights = self.weights.detach().to(device).contiguous()
@@ -55,7 +55,7 @@ class RLS(Linear):
                              torch.zeros(4 + self.n_out, dtype=torch.float32, device=dev))
             # tiled pass (P walked in address order by one-shot workgroups) once P is far beyond
             # the caches; below that the update is launch-bound and one wave per row is as fast
-            tiles = (self.n_in + 4095) // 4096
+            tiles = (self.n_in + 1023) // 1024  # one partial per (row, 1024-column tile): rls_tile_kernel
             use = self.tiled is True or (self.tiled is None and self.n_in >= self.TILED_MIN_N)
             self._partials = torch.zeros(self.n_in * tiles, dtype=torch.float32, device=dev) \
                 if use and self.n_in % 4 == 0 else None

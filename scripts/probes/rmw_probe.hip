@@ -93,5 +93,25 @@ int main() {
     PERSIST(4, false, false, 2048); PERSIST(4, true, true, 2048); PERSIST(4, true, true, 8192); PERSIST(8, true, true, 2048); PERSIST(8, false, false, 4096);
 #define ROWS(U, L, S, G) rep("rows R=2 U=" #U " ntl=" #L " nts=" #S " grid=" #G, timeit([&] { hipLaunchKernelGGL((k_rows<U, L, S>), dim3(G), dim3(256), 0, 0, buf, n, 1e-9f, n / 2); }))
     ROWS(4, true, true, 2048); ROWS(4, false, false, 2048); ROWS(4, true, true, 4096); ROWS(8, true, true, 2048); ROWS(2, true, true, 4096);
+    // r02: how much to keep in flight.  Persistent grids of k workgroups per CU, and one-shot grids whose residency is
+    // capped at k workgroups per CU by an (unused) dynamic LDS allocation of 160 KiB / k.
+#define PERSIST_G(U, G) rep("persist nt U=" #U " grid=" #G, timeit([&] { hipLaunchKernelGGL((k_persist<U, true, true>), dim3(G), dim3(256), 0, 0, buf, n4, 1e-9f); }))
+    PERSIST_G(1, 512); PERSIST_G(1, 768); PERSIST_G(1, 1024); PERSIST_G(1, 1536); PERSIST_G(1, 2048); PERSIST_G(1, 4096);
+    PERSIST_G(2, 256); PERSIST_G(2, 512); PERSIST_G(2, 768); PERSIST_G(2, 1024); PERSIST_G(2, 1536);
+    PERSIST_G(4, 256); PERSIST_G(4, 512); PERSIST_G(4, 768); PERSIST_G(4, 1024);
+    PERSIST_G(8, 256); PERSIST_G(8, 512); PERSIST_G(8, 768);
+    (void)hipFuncSetAttribute((const void*)k_oneshot<4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_oneshot<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_oneshot<2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int k : {1, 2, 3, 4, 6, 8, 12}) {
+        const size_t lds = (size_t)(160 * 1024) / k - 64;
+        char name[96];
+        snprintf(name, sizeof name, "oneshot nt U=4, <= %d workgroups per CU", k);
+        rep(name, timeit([&] { hipLaunchKernelGGL((k_oneshot<4, true, true>), dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), lds, 0, buf, n4, 1e-9f); }));
+        snprintf(name, sizeof name, "oneshot nt U=2, <= %d workgroups per CU", k);
+        rep(name, timeit([&] { hipLaunchKernelGGL((k_oneshot<2, true, true>), dim3((unsigned)((n4 + 511) / 512)), dim3(256), lds, 0, buf, n4, 1e-9f); }));
+        snprintf(name, sizeof name, "oneshot nt U=1, <= %d workgroups per CU", k);
+        rep(name, timeit([&] { hipLaunchKernelGGL((k_oneshot<1, true, true>), dim3((unsigned)((n4 + 255) / 256)), dim3(256), lds, 0, buf, n4, 1e-9f); }));
+    }
     return 0;
 }

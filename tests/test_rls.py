@@ -92,8 +92,8 @@ def test_fit_rls_epochs_recovers_readout(target):
                                                        (1030, 1, 9, 2, False), (256, 2, 25, 3, True), (1000, 4, 12, 1, True),
                                                        (4100, 2, 6, 1, True), (9000, 3, 4, 2, None)])
 def test_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride, tiled):
-    """Row-per-wave pass and the tiled pass (P walked in address order by one-shot workgroups, 4096-column tiles with
-    per-tile partial sums; chosen by size from n_in = 24576), ragged last tiles included."""
+    """Row-per-wave pass and the tiled pass (P walked in address order by one-shot workgroups, 1024-column tiles with
+    per-tile partial sums; chosen by size from n_in = 8192), ragged last tiles included."""
     gen = torch.Generator().manual_seed(n_in + T)
     X = torch.randn(T, n_in, generator=gen)
     Y = torch.randn(T, n_out, generator=gen)
