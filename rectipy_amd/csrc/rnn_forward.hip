@@ -382,8 +382,14 @@ int launch_step_sparse_blocked(const StepParams& P, hipStream_t st, int n_cu) {
                                                  : launch_step_sparse_blocked_cfg<MODEL, 8, 8>(P, st, n_cu, lds);
         if (g_blocked_U == 2) return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 2>(P, st, n_cu, lds)
                                                  : launch_step_sparse_blocked_cfg<MODEL, 8, 2>(P, st, n_cu, lds);
+        if (g_blocked_U == 1) return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 1>(P, st, n_cu, lds)
+                                                 : launch_step_sparse_blocked_cfg<MODEL, 8, 1>(P, st, n_cu, lds);
+        if (g_blocked_U == 3) return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 3>(P, st, n_cu, lds)
+                                                 : launch_step_sparse_blocked_cfg<MODEL, 8, 3>(P, st, n_cu, lds);
     }
-    return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 4>(P, st, n_cu, lds)
+    // groups in flight per lane (scripts/tune_blocked.py, us per step, 16 waves): n = 32768 (8-row blocks) U=4 121.1,
+    // U=2 117.7, U=1 133.9;  n = 16384 (4-row blocks) U=4 39.7, U=2 38.0
+    return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 2>(P, st, n_cu, lds)
                        : launch_step_sparse_blocked_cfg<MODEL, 8, 8>(P, st, n_cu, lds);
 }
 

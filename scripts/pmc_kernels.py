@@ -54,5 +54,5 @@ X = torch.randn(6, n_in, device=dev) * 0.1
 Y = torch.randn(6, 3, device=dev)
 edge.sweep(X, Y, 1)
 torch.cuda.synchronize()
-algo["rls_pass_kernel"] = 8.0 * n_in * n_in                      # P read + written once per update
+algo["rls_tile_kernel"] = 8.0 * n_in * n_in + 8.0 * n_in * (n_in // 1024)                      # P read + written once per update
 print(json.dumps({"algorithmic_bytes_per_launch": algo}), flush=True)

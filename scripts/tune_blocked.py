@@ -27,7 +27,7 @@ def timed(pop, x, T):
     return round((time.perf_counter() - t0) / T * 1e6, 1)
 
 
-for N, p, T in ((8192, 0.1, 2000), (16384, 0.1, 1000), (32768, 0.1, 600)):
+for N, p, T in ((8192, 0.1, 2000), (16384, 0.1, 1000), (32768, 0.1, 600)) if len(sys.argv) < 2 else ((int(sys.argv[1]), 0.1, 600),):
     gen = torch.Generator(device=dev).manual_seed(0)
     W = torch.randn(N, N, device=dev, generator=gen) * (1.5 / (p * N) ** 0.5)
     W *= torch.rand(N, N, device=dev, generator=gen) < p
@@ -41,10 +41,10 @@ for N, p, T in ((8192, 0.1, 2000), (16384, 0.1, 1000), (32768, 0.1, 600)):
     res["per_row_us"] = timed(pop, x, T)
     v_ref = pop.v.clone()
     pop.blocked_sparse = True
-    for rb in (4, 8, 16):
+    for rb in ((4, 8, 16) if len(sys.argv) < 3 else (int(sys.argv[2]),)):
         pop.sparse_block_rows = rb
         res[f"rb{rb}_MB"] = round(pop.pack_weights().stored_bytes / 1e6, 1)
-        for waves, U in ((16, 4), (16, 8), (8, 8)):
+        for waves, U in ((16, 4), (16, 8), (8, 8), (16, 3), (16, 2), (16, 1), (8, 4), (8, 2)):
             lib.rp_set_blocked_tuning(waves, U)
             try:
                 res[f"rb{rb}_w{waves}U{U}_us"] = timed(pop, x, T)
