@@ -108,3 +108,40 @@ def test_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride,
     for a, b, name in zip(res[0], res[1], ("pred", "loss", "weights", "P")):
         same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
         assert same.all(), f"{name}: {np.count_nonzero(~same)} of {a.size} differ, max abs {np.abs(a - b).max()}"
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("n,tiled", [(520, False), (520, True), (2060, False), (2060, True), (1030, False), (777, False)],
+                         ids=["n520-rows", "n520-tiled", "n2060-rows", "n2060-tiled", "n1030-4byte", "n777-4byte"])
+def test_g31_fit_rls_at_kernel_sizes_matches_reference(target, n, tiled):
+    """Golden G31 (tests/golden/make_golden_rls_large.py): the reference's fit_rls at sizes where the 16-byte row pass
+    (full 256-column chunks), the tiled pass (two full 1024-column tiles + a ragged one at n = 2060) and the 4-byte pass
+    (n % 4 != 0) are the code that runs.  Inputs are regenerated from tests/golden/recipes.py and checked against the
+    stored fingerprints first.  Tolerances: a few times the reference's own float32-vs-float64 deviation (printed by
+    the generator: W 7e-6 .. 1.1e-5, P 2e-7 relative, predictions 7e-5 .. 1.3e-4); measured here: W <= 1.3e-5, P <= 3.7e-7
+    relative, predictions <= 2.9e-5, sum of squares of P to 1e-8."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import recipes
+    g = dict(np.load(os.path.join(GOLD, f"g31_rls_n{n}.npz")))
+    T, stride, kout = int(g["T"]), int(g["stride"]), 3
+    P = recipes.li_network(n, seed=3100 + n, g=0.8, defaults=False)
+    x = (0.5 * recipes.normal((T, n), seed=3150 + n)).astype(np.float32)
+    tgt = recipes.normal((T, kout), seed=3160 + n)
+    W0 = (0.1 * recipes.normal((kout, n), seed=3170 + n)).astype(np.float32)
+    for name, arr in (("W", P["W"]), ("x", x), ("target", tgt), ("W0", W0)):
+        assert np.array_equal(recipes.fingerprint(arr), g["fp_" + name]), f"regenerated {name} differs from the generator's"
+    net, edge = build(dict(dt=g["dt"], W0=W0, beta=g["beta"], alpha=g["alpha"], **P), target)
+    edge.tiled = tiled
+    obs = net.fit_rls(x, tgt, update_steps=stride, sampling_steps=1, verbose=False)
+    W_ref, rows = g["W_after_f64"], g["rows"]
+    Pm = edge.P.cpu().numpy()
+    p_scale = np.abs(g["P_rows_f64"]).max()
+    assert np.abs(edge.weights.cpu().numpy() - W_ref).max() < 5e-5 * max(1.0, np.abs(W_ref).max())
+    assert np.abs(Pm[rows] - g["P_rows_f64"]).max() < 2e-6 * p_scale
+    assert np.abs(np.diag(Pm) - g["P_diag_f64"]).max() < 2e-6 * p_scale
+    fp, fp_ref = recipes.fingerprint(Pm), g["P_fp_f64"]
+    assert abs(fp[1] - fp_ref[1]) < 1e-6 * fp_ref[1]              # sum of squares of all n^2 entries
+    assert np.abs(obs.to_numpy("out") - g["pred_f64"]).max() < 1.5e-4
+    assert np.abs(obs.to_numpy("loss") - g["loss_f64"]).max() < 2e-5 * max(1.0, g["loss_f64"].max())
+    assert np.abs(net.state["rnn"].cpu().numpy() - g["state_f64"]).max() < 2e-5
