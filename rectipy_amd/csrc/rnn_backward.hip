@@ -628,7 +628,7 @@ int launch_adj_sparse(const BwdParams& P, const SpkGrad& G, hipStream_t st) {
         const size_t per_wave = sizeof(float) * RP_WAVE * (size_t)P.spt_block_rows;
         const size_t limit = rp_lds_limit();
         if (src_bytes + 16 * per_wave <= limit)
-            return launch_adj_sparse_blocked_cfg<SPIKING, 16, 4>(P, G, st, n_cu, src_bytes + 16 * per_wave);
+            return launch_adj_sparse_blocked_cfg<SPIKING, 16, 2>(P, G, st, n_cu, src_bytes + 16 * per_wave);  // (2 groups in flight: as the step kernel)
         if (src_bytes + 8 * per_wave <= limit)
             return launch_adj_sparse_blocked_cfg<SPIKING, 8, 8>(P, G, st, n_cu, src_bytes + 8 * per_wave);
         return RP_ERR_HIP;
