@@ -313,11 +313,34 @@ def facade_fit_bptt(pop, x, N, dev, teacher_net=None):
         obs = net.fit_bptt(inp, tgt, optimizer="sgd", lr=lr, update_steps=win, sampling_steps=1, verbose=False)
         torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    # sub-case of SURVEY 8d C3: only the read-out is trained (no gradient through the recurrence, so no adjoint sweep)
+    with contextlib.redirect_stdout(sys.stderr):
+        del net
+        torch.cuda.empty_cache()
+        net = Network(dt=pop.dt, device=str(dev))
+        net.add_diffeq_node("rnn", "neuron_model_templates.rate_neurons.leaky_integrator.tanh", input_var="li_op/I_ext",
+                            output_var="li_op/v", weights=pop.W, source_var="tanh_op/r", target_var="li_op/r_in",
+                            dtype=torch.float32)
+        net.add_func_node("out", 3, "identity")
+        net.add_edge("rnn", "out", weights=W_teach + 0.5 * torch.randn(3, N, generator=gen, device=dev) / N ** 0.5,
+                     train="gd")
+        net.fit_bptt(inp[:100], tgt[:100], optimizer="sgd", lr=0.0, update_steps=100, sampling_steps=100, verbose=False)
+        net.reset()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        obs_ro = net.fit_bptt(inp, tgt, optimizer="sgd", lr=lr, update_steps=win, sampling_steps=1, verbose=False)
+        torch.cuda.synchronize()
+        wall_ro = time.perf_counter() - t1
+        ro_losses = obs_ro["loss"]
+        ro_wl = [float(ro_losses[b - 1]) for b in range(win, T + 1, win)]
+        del net
     # the loss recorded at the LAST step of a window is that window's loss (reference network.py:1043-1046)
     losses = obs["loss"]
     wl = [float(losses[b - 1]) for b in range(win, T + 1, win)]
     tp = [float((tgt[b - win:b] ** 2).mean().item()) for b in range(win, T + 1, win)]
     return {"facade_fit_bptt_steps_per_s": T / wall, "facade_fit_bptt_lr": lr, "facade_fit_bptt_window_losses": wl,
+            "facade_fit_readout_only_steps_per_s": T / wall_ro,
+            "facade_fit_readout_only_window_relative_losses": [l / p for l, p in zip(ro_wl, [float((tgt[b - win:b] ** 2).mean().item()) for b in range(win, T + 1, win)])],
             # MSE of a window relative to the mean square of its targets (the trajectory's power grows from v0 = 0)
             "facade_fit_bptt_window_relative_losses": [l / p for l, p in zip(wl, tp)]}
 

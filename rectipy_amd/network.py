@@ -729,7 +729,12 @@ class Network:
                     preds = self._window_outputs(inp[a:b], a, True, {}, 0, 1)[self._out_node]
                 else:
                     X = self._apply_chain(pre, inp[a:b], None, label) if pre else inp[a:b]
-                    traj = rnn._grad_window(b - a, self._fit_width(X, N)) if self._wants_grad(plan, X) else \
+                    # the adjoint sweep runs only if a gradient has to pass INTO the population: its own trainable
+                    # parameters or something trainable upstream.  (The reference also tracks the state after
+                    # `detach(requires_grad=True)`, network.py:496; inside fit_bptt that leaf is unreachable for the
+                    # caller, so a read-out-only fit skips the sweep: same parameter updates at the forward's speed.)
+                    into_rnn = X.requires_grad or any(p.requires_grad for p in rnn.parameters())
+                    traj = rnn._grad_window(b - a, self._fit_width(X, N)) if into_rnn else \
                         self._nograd_traj(rnn, b - a, self._fit_width(X, N))
                     preds = self._apply_chain(post, traj, label, None) if post else traj
                 prev_error = error

@@ -383,3 +383,47 @@ def test_reference_style_constructor_recognises_the_field(where):
     named = RateNet("li_tanh", (torch.zeros(n), torch.zeros(n), torch.tensor(W), 2.0), {"out": [0, n]},
                     {"in": 0, "weights": 1, "li_op/tau": 2}, dtype=torch.float32, **where)
     assert float(named["li_op/tau"][0]) == 2.0
+
+
+def test_readout_only_fit_skips_the_adjoint_and_gives_the_same_updates(where):
+    """Only the read-out edge is trained: no gradient has to pass into the population, so fit_bptt integrates the
+    window without the autograd node (no adjoint sweep) -- the read-out updates are those of plain SGD on the collected
+    states (two windows; the second starts from the first one's end state)."""
+    dt, n, k, T, win, lr = 1e-2, 24, 3, 80, 40, 0.05
+    rng = np.random.default_rng(11)
+    W, W_out = rng.standard_normal((n, n)) * 0.3, rng.standard_normal((k, n)) * 0.2
+    x, target = rng.standard_normal((T, n)).astype(np.float32) * 0.5, rng.standard_normal((T, k)).astype(np.float32)
+
+    def build(train):
+        net = Network(dt, **where)
+        net.add_diffeq_node("rnn", TANH, input_var=IN, output_var="li_op/v", weights=W, source_var=SRC, target_var=TGT,
+                            dtype=torch.float32)
+        net.add_func_node("out", k, "identity")
+        net.add_edge("rnn", "out", weights=W_out.copy(), train=train)
+        return net
+
+    # states of the population over the run: re-run a bare population network whose output IS the state
+    bare = Network(dt, **where)
+    bare.add_diffeq_node("rnn", TANH, input_var=IN, output_var="li_op/v", weights=W, source_var=SRC, target_var=TGT,
+                         dtype=torch.float32)
+    V = torch.tensor(bare.run(x, sampling_steps=1, enable_grad=False, verbose=False).to_numpy("out"))
+    w = torch.tensor(W_out, dtype=torch.float32, requires_grad=True)
+    tgt = torch.tensor(target)
+    expected_losses = []
+    for a in range(0, T, win):
+        loss = torch.nn.functional.mse_loss(V[a:a + win] @ w.T, tgt[a:a + win])
+        (g,) = torch.autograd.grad(loss, w)
+        with torch.no_grad():
+            w -= lr * g
+        expected_losses.append(float(loss.detach()))
+
+    net = build("gd")
+    rnn = net.get_node("rnn")
+    calls = []
+    inner = rnn._grad_window
+    rnn._grad_window = lambda *a, **kw: (calls.append(1), inner(*a, **kw))[1]
+    obs = net.fit_bptt(x, target, optimizer="sgd", lr=lr, update_steps=win, sampling_steps=1, verbose=False)
+    assert not calls, "a read-out-only fit went through the population's autograd window"
+    fitted = net.get_edge("rnn", "out").weights.detach()
+    assert torch.allclose(fitted, w.detach(), atol=2e-6)
+    assert [float(obs["loss"][b - 1]) for b in (win, T)] == pytest.approx(expected_losses, rel=1e-5)
