@@ -47,6 +47,15 @@ def test_argument_validation_without_gpu(lib):
     assert lib.rp_forward(C.byref(net), C.byref(run), None) == _abi.RP_ERR_ARG
     assert b"model" in lib.rp_last_error()
     assert lib.rp_outer_accum(0, 1, 1.0, None, 0, None, 0, None, 0, None) == _abi.RP_ERR_ARG
+    # rp_tune_forward: arguments are checked, and shapes that do not stream from HBM return before any HIP call
+    assert lib.rp_tune_forward(None, None) == _abi.RP_ERR_ARG
+    small = _abi.RpNet()
+    small.n = small.rows = 512
+    small.ldw = 512
+    small.W = 16  # (never dereferenced: 512 x 512 has nothing to measure)
+    assert lib.rp_tune_forward(C.byref(small), None) == _abi.RP_OK
+    small.ldw = 100
+    assert lib.rp_tune_forward(C.byref(small), None) == _abi.RP_ERR_SHAPE
     assert lib.rp_bwd_partial_rows(32768) == 24 and lib.rp_bwd_partial_rows(65536) == 12 and lib.rp_bwd_partial_rows(8192) == 64 and lib.rp_bwd_partial_rows(10) == 2
     with pytest.raises(ValueError):
         _lib.check(_abi.RP_ERR_ARG)
