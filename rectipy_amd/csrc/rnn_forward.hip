@@ -1002,8 +1002,9 @@ int rp_tune_forward(const rp_net* net, void* stream) {
             launch_probe(cfg);
         }
         float ms = 0.f;
-        failed = failed || hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
-                 hipEventElapsedTime(&ms, e0, e1) != hipSuccess;
+        failed = failed || hipGetLastError() != hipSuccess ||  // (a rejected launch must not look like a fast one)
+                 hipEventRecord(e1, st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+                 hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f);
         return ms * 1e3f / (float)steps;
     };
 
