@@ -121,3 +121,46 @@ def test_qif_backward_bit_exact(oracle_backend, hip_device, N, T, grad_var, xw, 
         a, b = a.cpu().numpy(), b.cpu().numpy()
         same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
         assert same.all(), f"{name}: {np.count_nonzero(~same)} of {a.size} differ (max abs {np.abs(a - b).max()})"
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("transposed", [True, False], ids=["transposed-copy", "column-strips"])
+@pytest.mark.parametrize("n", [512, 1028])
+def test_g32_qif_gradients_at_kernel_sizes_match_reference_autograd(target, n, transposed):
+    """Golden G32 (tests/golden/make_golden_qif_bptt_large.py): one SGD window of the reference's fit_bptt through its
+    SpikeResetNet at N = 512 / 1028, all parameters trained.  Both adjoint forms of the spiking sweep run here with full
+    256-column chunks (and the ragged 4-column chunk at 1028).  Inputs are regenerated from tests/golden/recipes.py and
+    checked against the stored fingerprints first.  Tolerances: 4e-4 of each gradient's largest entry (measured: <= 9.3e-5,
+    which is also what the reference's own float32 run deviates from its float64 run); column sums of dW 1e-3."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import recipes
+    from make_golden_qif_bptt_large import network
+    g = dict(np.load(os.path.join(GOLD, f"g32_qif_bptt_n{n}.npz")))
+    T, kout, dev = int(g["T"]), 3, target["device"]
+    P = network(n, 3200 + n)
+    W_out0 = (recipes.normal((kout, n), 3250 + n) / np.float32(np.sqrt(n))).astype(np.float32)
+    x = (15.0 + recipes.normal((T, n), 3260 + n)).astype(np.float32)
+    tgt = (0.1 * recipes.normal((T, kout), 3270 + n)).astype(np.float32)
+    for name, arr in (("W", P["W"]), ("x", x), ("target", tgt), ("y0", P["y0"])):
+        assert np.array_equal(recipes.fingerprint(arr), g["fp_" + name]), f"regenerated {name} differs from the generator's"
+    node = qif_node(dict(theta=g["theta"], v_reset=g["v_reset"], dt=g["dt"], **P), target, TRAIN)
+    node._pop.transposed_adjoint = transposed
+    node.enable_spike_recording(1 << 16)
+    W_out = torch.tensor(W_out0, device=dev, requires_grad=True)
+    traj = node._grad_window(T, torch.tensor(x, device=dev))
+    assert len(node.spikes()) >= n // 4, "the window must contain many spikes for this test to mean anything"
+    pred = traj @ W_out.T
+    assert np.abs(pred.detach().cpu().numpy() - g["pred_f64"]).max() < 2e-5
+    loss = torch.nn.functional.mse_loss(pred, torch.tensor(tgt, device=dev))
+    assert abs(loss.item() - float(g["loss_f64"])) < 2e-6
+    loss.backward()
+    gW = node["weights"].grad.cpu().numpy().astype(np.float64)
+    scale = np.abs(g["gW_rows_f64"]).max()
+    assert np.abs(gW[g["rows"]] - g["gW_rows_f64"]).max() <= 4e-4 * scale
+    assert np.abs(gW.sum(axis=0) - g["gW_colsum_f64"]).max() <= 1e-3 * np.abs(g["gW_colsum_f64"]).max()
+    assert abs(recipes.fingerprint(gW)[1] - g["gW_fp_f64"][1]) <= 1e-4 * g["gW_fp_f64"][1]      # sum of squares of all of it
+    for name, key in (("tau", "qif_op/tau"), ("k", "qif_op/k"), ("eta", "qif_op/eta"), ("tau_s", "qif_op/tau_s")):
+        ref = g[f"g{name}_f64"]
+        assert np.abs(node[key].grad.cpu().numpy() - ref).max() <= 4e-4 * np.abs(ref).max(), name
+    assert np.abs(W_out.grad.cpu().numpy() - g["gW_out_f64"]).max() <= 1e-3 * np.abs(g["gW_out_f64"]).max()
