@@ -20,6 +20,8 @@ T = int(os.environ.get("T", 400))
 local_rank = int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(local_rank)
 dev = torch.device("cuda", local_rank)
+if "RANK" not in os.environ:  # started with plain `python`: one rank on this GPU
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
 dist.init_process_group("nccl", device_id=dev)
 row0, rows = shard_bounds(N, dist.get_world_size(), dist.get_rank())
 
