@@ -612,7 +612,8 @@ def test_long_run_stays_bit_exact(oracle_backend, hip_device, model):
 
 
 @pytest.mark.gpu
-def test_measured_streaming_configuration_keeps_the_bits():
+@pytest.mark.parametrize("rows,n,row0", [(8192, 16384, 4096), (8200, 12300, 0)], ids=["aligned", "ragged"])
+def test_measured_streaming_configuration_keeps_the_bits(rows, n, row0):
     """rp_tune_forward picks how W is walked (rows per wave, chunks in flight, resident workgroups) by timing; the
     summation order does not depend on it, so a run before and after the measurement gives identical bits, for the model
     that was timed (tanh) and for another one (QIF) that reuses the measurement."""
@@ -622,7 +623,7 @@ def test_measured_streaming_configuration_keeps_the_bits():
     from rectipy_amd.engine import Population
     lib = _lib.load()
     dev = torch.device("cuda:0")
-    rows, n = 8192, 16384                                    # 512 MiB: streams from HBM
+    assert rows * n * 4 > (320 << 20)                        # streams from HBM: the measurement runs
     gen = torch.Generator(device=dev).manual_seed(5)
     W = torch.randn(rows, n, device=dev, generator=gen) * (1.2 / n ** 0.5)
     x = torch.sin(torch.arange(12, device=dev) * 0.1).reshape(-1, 1).contiguous()
@@ -631,7 +632,7 @@ def test_measured_streaming_configuration_keeps_the_bits():
         lib.rp_clear_forward_tuning()
         outs = {}
         for tuned in (False, True):
-            pop = Population("li_tanh", W, dict(tau=2.0, k=1.0, eta=0.1), 1e-2, dev, n=n, row0=4096)
+            pop = Population("li_tanh", W, dict(tau=2.0, k=1.0, eta=0.1), 1e-2, dev, n=n, row0=row0)
             pop.source.copy_(torch.tanh(torch.randn(n, device=dev, generator=torch.Generator(device=dev).manual_seed(6))))
             if tuned:
                 w_before = W.clone()
@@ -644,7 +645,7 @@ def test_measured_streaming_configuration_keeps_the_bits():
                 assert not pop.backend.forward_tuning(pop._net())["measured"]
             traj = torch.empty(12, rows, device=dev)
             pop.forward(12, x=x, traj=traj)
-            qif = Population("qif", W, dict(tau=1.0, k=1.0, eta=-5.0, tau_s=1.0), 1e-3, dev, n=n, row0=4096,
+            qif = Population("qif", W, dict(tau=1.0, k=1.0, eta=-5.0, tau_s=1.0), 1e-3, dev, n=n, row0=row0,
                              v0=torch.linspace(-2, 99, rows))
             qtraj = torch.empty(6, rows, device=dev)
             qif.forward(6, traj=qtraj)
