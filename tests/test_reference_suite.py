@@ -131,14 +131,16 @@ def test_reference_test_passes_against_this_package(oracle_backend, fname, test)
 # ---- the reference's documentation scripts (its user-facing gallery), unmodified ---------------------------------------
 REF_DOCS = "/root/reference/documentation"
 # script -> seconds it takes on the CPU oracle here.  The long ones run only with RECTIPY_AMD_SLOW_DOCS=1.
-DOC_SCRIPTS = {"interfaces/simulation.py": 1, "interfaces/model_definition.py": 1,
+DOC_SCRIPTS = {"interfaces/simulation.py": 1, "interfaces/model_definition.py": 1, "models/leaky_integrator.py": 3,
+               "models/lif.py": 1, "models/qif.py": 1,
                "interfaces/torch_integration.py": 62, "ridge_example.py": 100}
 # Not run: scripts that the reference itself rejects today because they use an older API --
 #   qif_example.py, interfaces/observer.py: `spike_def=` without `reset_var` -> the ValueError of network.py:292-294 (this
 #     package raises the same message);  interfaces/train_test.py: integer class targets are cast to the network dtype
 #     (network.py:695) before `nll` -> torch's "expected scalar type Long";  bptt_rate_neurons.py: a 3-D ndarray of epochs is
 #     iterated as steps (network.py:693-701);  rls_example.py, rl_example.py: `Network.from_yaml` does not exist;
-#   bptt_spiking_neurons_*.py: `spike_def=`;  rnn_tryout.py: hard-wired to "cuda:0".
+#   bptt_spiking_neurons_ffwd.py: `spike_def=`;  bptt_spiking_neurons_recurrent.py: current API, but 1000 epochs x 20000
+#     Python-level steps (hours);  rnn_tryout.py: hard-wired to "cuda:0".
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_DOCS), reason="the reference is only present in the build container")
