@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 7
+#define RP_ABI_VERSION 8
 #define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0

@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 7
+RP_ABI_VERSION = 8
 RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_SLOTS = 0, 1, 32
 
 RP_OK = 0
