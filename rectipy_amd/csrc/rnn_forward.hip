@@ -951,7 +951,10 @@ int rp_tune_forward(const rp_net* net, void* stream) {
     // a scratch tanh population on the caller's W (read-only): v = 0, tau = 1, k = eta = 0, source = 0
     const size_t rows = (size_t)net->rows, n = (size_t)net->n;
     float* buf = nullptr;
-    RP_HIP_CHECK(hipMalloc(&buf, sizeof(float) * (4 * rows + 2 * n)));
+    if (hipMalloc(&buf, sizeof(float) * (4 * rows + 2 * n)) != hipSuccess) {
+        (void)hipGetLastError();
+        return RP_OK;  // no room for the scratch vectors: keep the static rule (the measurement is an optimisation)
+    }
     float *v = buf, *tau = buf + rows, *k = buf + 2 * rows, *eta = buf + 3 * rows, *src[2] = {buf + 4 * rows, buf + 4 * rows + n};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() {
