@@ -187,7 +187,8 @@ typedef struct rp_run {
     float* save_src;          /* optional [steps x ldsave]: pre-update source (local rows) */
     float* save_acc;          /* optional [steps x ldsave]: (W @ src)_i       */
     int64_t ldsave;
-    float* acc;               /* [rows] running sum of buffered outputs (in/out); required if samples */
+    float* acc;               /* [rows] running sum of buffered outputs (in/out); required if samples.  Read only
+                                 while acc_count > 0: with acc_count == 0 the first buffered output overwrites it */
     int32_t acc_count;        /* [host, in/out] buffered outputs in acc       */
     int32_t sample_idx;       /* [host, in/out] next sample row               */
     float* samples;           /* optional [max_samples x ldsamples]           */

@@ -36,6 +36,7 @@ constexpr int kThreads = kWavesPerBlock * RP_WAVE;
 
 constexpr int FLAG_BUFFER = 1;  // step >= cutoff: output joins the sampling buffer
 constexpr int FLAG_SAMPLE = 2;  // record mean of the buffer at this step
+constexpr int FLAG_FIRST = 4;   // first output of a buffer (acc_count was 0): the accumulator's old contents are not read
 
 struct StepParams {
     const float* W;
@@ -112,7 +113,7 @@ __device__ __forceinline__ float input_current(const StepParams& P, int i) {
 __device__ __forceinline__ void sample_output(const StepParams& P, int i, float out) {
     if (P.traj_t) P.traj_t[i] = out;
     if (P.flags & FLAG_BUFFER) {
-        float a = P.acc[i] + out;
+        float a = ((P.flags & FLAG_FIRST) ? 0.0f : P.acc[i]) + out;
         if (P.flags & FLAG_SAMPLE) {
             if (P.sample_row) P.sample_row[i] = a / P.count;
             a = 0.f;
@@ -869,6 +870,7 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
         for (int q = 0; q < RP_MAX_STATE; ++q) P.rec_row[q] = nullptr;
         if (run->acc && t_abs >= run->cutoff) {
             P.flags |= FLAG_BUFFER;
+            if (run->acc_count == 0) P.flags |= FLAG_FIRST;  // an empty buffer: no reset pass over acc is ever needed
             run->acc_count += 1;
             if (t_abs % run->sampling_steps == 0) {
                 P.flags |= FLAG_SAMPLE;

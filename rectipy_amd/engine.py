@@ -366,8 +366,7 @@ class Population:
         return self.packed_t
 
     def reset_sampling(self):
-        self.acc.zero_()
-        self.acc_count = 0
+        self.acc_count = 0  # an empty buffer: the library overwrites `acc` with the first buffered output (rp_run.acc)
 
     # -- forward -------------------------------------------------------------------------
     def forward(self, steps: int, x: Optional[torch.Tensor] = None, w_in: Optional[torch.Tensor] = None,

@@ -47,6 +47,8 @@ class Network:
         self._out_node = None
         self._order: List[str] = []
         self._train_edge = ()
+        self._compiled_shape = None  # (nodes, edges) of the graph at the last successful compile()
+        self._input_device = None
 
     # ---- container protocol -------------------------------------------------------------
     def __getitem__(self, item):
@@ -212,6 +214,10 @@ class Network:
 
     def compile(self):
         """Find the unique input / output node and an evaluation order (reference network.py:439-460)."""
+        shape = (tuple(self.graph.nodes), tuple(self.graph.edges))
+        if shape == self._compiled_shape:  # same nodes and edges as at the last successful compile: nothing to redo
+            return
+        self._compiled_shape = None
         in_nodes = [n for n in self.graph.nodes if self.graph.in_degree(n) == 0]
         if len(in_nodes) != 1:
             raise ValueError(f"Unable to identify the input node of the Network. Nodes that have no input edges: "
@@ -225,6 +231,7 @@ class Network:
         # the reference's backward view of the graph (network.py:455-460, 953-960): node -> its source nodes, for every
         # node on a path to the output node that has sources
         self._bwd_graph = {n: list(self.graph.predecessors(n)) for n in self._order if self.graph.in_degree(n) > 0}
+        self._compiled_shape = shape
 
     # ---- per-step evaluation (drop-in for user loops) ----------------------------------------
     def forward(self, x) -> torch.Tensor:
@@ -307,6 +314,11 @@ class Network:
 
     def _to_input(self, inputs) -> torch.Tensor:
         dev = self.device if self._backend is None else "cpu"
+        if isinstance(inputs, torch.Tensor) and inputs.dtype == torch.float32 and inputs.dim() == 2:
+            if self._input_device is None:
+                self._input_device = torch.empty(0, device=dev).device  # (with the index torch resolves `dev` to)
+            if inputs.device == self._input_device:
+                return inputs  # already what the engine takes: nothing to convert
         if isinstance(inputs, np.ndarray):
             inputs = torch.tensor(inputs, device=dev, dtype=torch.float32)
         inputs = inputs.to(device=dev, dtype=torch.float32)
