@@ -395,8 +395,8 @@ typedef struct rp_rls {
     float* z;        /* scratch [n_in], 16-byte aligned                                        */
     float* zn;       /* scratch [n_in], 16-byte aligned                                        */
     float* scratch;  /* scratch [4 + n_out]                                                    */
-    /* optional workspace [n_in x ceil(n_in / 4096)]: selects the TILED pass (16-byte path only).  One-shot workgroups
-       sweep P in address order, each takes one 16 KiB tile (row i, 4096 columns) and leaves the tile's partial dot
+    /* optional workspace [n_in x ceil(n_in / 1024)]: selects the TILED pass (16-byte path only).  One-shot workgroups
+       sweep P in address order, each takes one 4 KiB tile (row i, 1024 columns) and leaves the tile's partial dot
        product here; z'_i = beta_inv * (sum of row i's partials, ascending).  NULL: one wave per row (small n_in). */
     float* partials;
 } rp_rls;
