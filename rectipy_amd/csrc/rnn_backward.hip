@@ -36,7 +36,11 @@ std::atomic<int> g_bwd_chunks{0};  // benchmark-only override of the chunk count
 // (chunk, 256-column strip) items -- 12 waves per CU, each with 2 rows x 1 KiB in flight, which is where the chip's
 // HBM streams fastest (scripts/tune_chunks.py, us per adjoint step, r02): n = 32768: Q = 16 634 (r01 rule), 20 616,
 // 24 602, 28 638, 40 626 (599 with one row in flight), 64 655;  n = 65536: Q = 8 2508 (r01 rule), 12 2405, 24 2408;
-// n = 16384: Q = 32 167 (r01 rule), 40 156, 48 168.
+// n = 16384: Q = 32 167 (r01 rule), 40 156, 48 168.  Best chunk counts of a later sweep over other sizes (Q, rows in
+// flight x strip KiB, us): 8192: 40, 4x2, 47 (this rule: 64 -> 52);  12288: 40, 4x2, 94 (64 -> 96);  20480: 20, 4x2, 248
+// (38);  24576: 28, 2x1, 342 (32 -> 345);  40960: 10, 4x2, 948 (19; 16 -> 964);  49152: 16, 2x1, 1349 (16).  Either
+// ~3072 items of 2 rows x 1 KiB or ~768 items of 4 rows x 2 KiB -- 24 KiB in flight per CU both ways; the rule keeps
+// the first form, which is the best one at the benchmark sizes (32768, 65536) and within 7 % elsewhere.
 inline int chunk_rows(int n, int rows) {
     int q = 3072 / ((n + 255) / 256);
     q = q < 8 ? 8 : (q > kMaxChunks ? kMaxChunks : q);
