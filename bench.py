@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--neurons 32768]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` (N > 1) without a launcher starts the N ranks itself: the parent touches no GPU, spawns
+`python -m torch.distributed.run` on a free port as a CHILD process, relays rank 0's JSON line and returns the
+children's exit status (`self_launch`).
+
 Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): N = 32768 neurons,
 W = 1.5 * randn(N, N) / sqrt(N) (generated on device in 1024-row blocks seeded by block index, so
 every sharding sees the same matrix), tau = 10, k = 1, eta = 0, v(0) = 0, dt = 1e-2, a broadcast
@@ -55,6 +59,56 @@ def gen_rows(n, row0, rows, device, g=1.5, block=1024):
     return W
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n_ranks, argv, script=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes through torch.distributed.run (one
+    node, rendezvous on 127.0.0.1 at a free port) as CHILDREN of this process, which has not touched the GPU and never
+    replaces itself.  Rank 0's JSON line is relayed to stdout as the only stdout line; everything else the ranks print
+    goes to stderr.  Returns the children's exit status (non-zero when any rank failed or no JSON line appeared)."""
+    import subprocess
+    script = script or os.path.abspath(__file__)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(var, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *argv]
+    print("[bench] launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = []
+    try:
+        out, _ = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        out, _ = proc.communicate()
+        print(f"[bench] the {n_ranks}-rank job did not finish within {timeout} s and was killed", file=sys.stderr)
+        sys.stderr.write(out or "")
+        return 124
+    for ln in (out or "").splitlines():
+        try:
+            rec = json.loads(ln)
+        except ValueError:
+            rec = None
+        if isinstance(rec, dict) and "metric" in rec and "value" in rec:
+            lines.append(ln)
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print(f"[bench] torch.distributed.run exited with status {proc.returncode}", file=sys.stderr)
+        return proc.returncode
+    if len(lines) != 1:
+        print(f"[bench] expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,18 +123,21 @@ def main():
     ap.add_argument("--config5-steps", type=int, default=200)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become the launcher (nothing above this line has touched the GPU)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         import torch.distributed as dist
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        from rectipy_amd.sharded import one_rank_env
+        one_rank_env()  # --force-dist without a launcher: fills in only the missing variables, free port
         dist.init_process_group("nccl", device_id=dev)
 
     N, K, Wm = args.neurons, args.steps, args.warmup
@@ -114,12 +171,13 @@ def main():
         pop = sp.pop
         samples = torch.zeros(n_samples, rows, device=dev)
         exchange = "torch.distributed all_gather_into_tensor per step (host loop)"
-        if sp.comm is not None:
-            # the in-library RCCL exchange must reproduce the torch.distributed one bit for bit; otherwise it is dropped
-            if sp.check_inlib_exchange(3):
-                exchange = "RCCL all-gather enqueued in-library (rp_forward_sharded); checked == torch.distributed path"
-            else:
-                exchange += " [in-library exchange disagreed with it and was disabled]"
+        had_comm = sp.comm is not None
+        # collective (every rank calls it, whether or not it got a communicator): the in-library RCCL exchange must be
+        # available on ALL ranks and reproduce the torch.distributed one bit for bit; otherwise every rank drops it
+        if sp.check_inlib_exchange(3):
+            exchange = "RCCL all-gather enqueued in-library (rp_forward_sharded); checked == torch.distributed path"
+        elif had_comm:
+            exchange += " [in-library exchange unavailable on some rank or disagreed with it: disabled]"
 
         def run(steps, step0, idx):
             return sp.forward(steps, x=x[step0:step0 + steps], step0=step0, sampling_steps=sampling,
@@ -222,7 +280,9 @@ def main():
         "config": {"workload": f"tanh rate RNN N={N} dense W fp32, forward-only Euler, dt=1e-2, sampling_steps=100, "
                                f"broadcast sinusoid input (BASELINE.json configs[1])",
                    "neurons": N, "rows_per_gpu": rows, "parallelism": f"row-shard x{world}; " + exchange
-                   if use_dist else "single GPU, driven through rectipy_amd.Network.run"},
+                   if use_dist else "single GPU, driven through rectipy_amd.Network.run",
+                   "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                   "exchange": exchange if use_dist else "none (one GPU holds every row)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": step_kernel_label(streaming), "algorithmic_bytes_per_launch": algo_bytes,
@@ -556,7 +616,7 @@ def config5_leg(n5, steps, world, rank, dev, dt):
         return None if rank else {"skipped": f"a {rows} x {n5} shard does not fit one GPU"}
     sp = ShardedPopulation("li_tanh", gen_rows(n5, row0, rows, dev), dict(tau=10.0, k=1.0, eta=0.0), dt, dev, n=n5)
     exchange = "torch.distributed all_gather_into_tensor per step (host loop)"
-    if sp.comm is not None and sp.check_inlib_exchange(2):
+    if sp.check_inlib_exchange(2):  # collective: every rank calls it
         exchange = "RCCL all-gather enqueued in-library"
     warm = 20
     tt = torch.arange(warm + steps, device=dev, dtype=torch.float32) * dt

@@ -13,7 +13,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import gen_rows  # noqa: E402
-from rectipy_amd.sharded import ShardedNetwork, shard_bounds  # noqa: E402
+from rectipy_amd.sharded import ShardedNetwork, one_rank_env, shard_bounds  # noqa: E402
 
 N = int(os.environ.get("N", 8192))
 T = int(os.environ.get("T", 400))
@@ -21,7 +21,7 @@ local_rank = int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(local_rank)
 dev = torch.device("cuda", local_rank)
 if "RANK" not in os.environ:  # started with plain `python`: one rank on this GPU
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1")
+    one_rank_env()  # fills in only what is missing; free port
 dist.init_process_group("nccl", device_id=dev)
 row0, rows = shard_bounds(N, dist.get_world_size(), dist.get_rank())
 

@@ -53,6 +53,14 @@ def rccl_comm(group, device, backend) -> Optional[_abi.RpComm]:
 _warned_fallback = False
 
 
+def agreed_comm(comm, group, device):
+    """`comm` if EVERY rank of the group obtained one, else None on every rank (collective; `rccl_comm` can fail on a
+    single rank, and a rank in the host loop next to ranks that enqueue the in-library collective would hang the job)."""
+    have = torch.tensor([int(comm is not None)], device=device)
+    dist.all_reduce(have, op=dist.ReduceOp.MIN, group=group)
+    return comm if int(have.item()) == 1 else None
+
+
 def _loaded_rccl():
     """The RCCL instance that owns PyTorch's communicators: torch's bundled lib/librccl.so when it ships one (dlopen
     returns the already-loaded instance), else the symbols visible in the process (torch linked against a system
@@ -65,6 +73,23 @@ def _loaded_rccl():
     lib = ctypes.CDLL(None)
     lib.ncclAllGather, lib.ncclReduceScatter  # AttributeError when not visible -> host collectives
     return lib
+
+
+def one_rank_env(environ=None):
+    """Rendezvous variables for a process started WITHOUT a launcher (plain `python`): a one-rank group on 127.0.0.1
+    at a free port.  Only the variables that are missing are filled in -- a partially set environment (a launcher's
+    MASTER_ADDR / WORLD_SIZE) is never overwritten -- and no port is hard-coded, so two such runs on one host do not
+    collide."""
+    import os
+    import socket
+    env = os.environ if environ is None else environ
+    if "MASTER_PORT" not in env:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(s.getsockname()[1])
+    for key, val in (("MASTER_ADDR", "127.0.0.1"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+        env.setdefault(key, val)
+    return env
 
 
 def shard_bounds(n: int, world: int, rank: int):
@@ -87,7 +112,7 @@ class ShardedPopulation:
                               row0=self.row0, backend=backend, **kw)
         self.n = n
         self._gather_source()  # every rank needs the full initial source vector
-        self.comm = rccl_comm(group, self.pop.device, self.pop.backend)
+        self.comm = agreed_comm(rccl_comm(group, self.pop.device, self.pop.backend), group, self.pop.device)
 
     def _gather_source(self):
         full = self.pop.source
@@ -118,7 +143,14 @@ class ShardedPopulation:
 
 
 def check_inlib_exchange(pop: Population, holder, steps: int, group) -> bool:
-    """See ShardedPopulation.check_inlib_exchange; `holder.comm` is the rp_comm in use (set to None on failure)."""
+    """See ShardedPopulation.check_inlib_exchange; `holder.comm` is the rp_comm in use (set to None on failure).
+
+    Collective.  The ranks first agree -- through the process group's own all-reduce -- on whether EVERY rank holds a
+    communicator (`rccl_comm` can fail on one rank only), so that no rank ever enqueues the in-library all-gather while
+    another one has already left for the host loop.  A library error during the comparison is not survivable: some
+    ranks may have enqueued a collective the failing rank never will, so the error propagates (the launcher ends the
+    job) instead of continuing with collectives on that communicator."""
+    holder.comm = agreed_comm(holder.comm, group, pop.device)
     if holder.comm is None:
         return False
     saved = (pop.v.clone(), pop.src[0].clone(), pop.src[1].clone(), pop.cur,
@@ -143,13 +175,8 @@ def check_inlib_exchange(pop: Population, holder, steps: int, group) -> bool:
                 dist.all_gather_into_tensor(full, full[row0:row0 + rows], group=group)
         return pop.v.clone(), pop.source.clone()
 
-    try:
-        a, b = run(holder.comm), run(None)
-        agree = int(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]))
-    except RuntimeError as err:  # RP_ERR_COMM / RP_ERR_HIP from the library: keep the host loop
-        import warnings
-        warnings.warn(f"in-library RCCL exchange failed on rank {dist.get_rank(group)}: {err}")
-        agree = 0
+    a, b = run(holder.comm), run(None)
+    agree = int(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]))
     same = torch.tensor([agree], device=pop.device)
     dist.all_reduce(same, op=dist.ReduceOp.MIN, group=group)
     restore()
