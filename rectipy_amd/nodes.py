@@ -238,6 +238,7 @@ class RateNet:
         for name in self._train_names:
             self._tensor(name).requires_grad_(True)
         self._y_grad: Optional[torch.Tensor] = None  # autograd handle of the state (same values as pop.v)
+        self._y_handed = None  # (handle, its version when it was handed out): detects in-place writes by the holder
         self._v_exposed = False  # pop.v was handed out through `y`: the next step continues on a copy
         self._y_requires_grad = len(self._train_names) >= 1  # nodes.py:89-90
         self._out_slice = None
@@ -429,21 +430,39 @@ class RateNet:
         remembers that the live tensor was handed out and, at the next step, continues on a fresh copy
         (:meth:`_before_step`): the handed-out tensor then holds the state it showed when it was read, and writes made
         into it before the next step (``net.state[...][:] = ...``) are part of the state, as in the reference.
-        Fused windows never read ``y`` and stay zero-copy."""
+        Fused windows never read ``y`` and stay zero-copy.
+
+        While a gradient is being tracked the tensor handed out is the autograd handle (same values as the device
+        state, carrying the history of the window that produced it).  Its version counter is remembered: an in-place
+        write by the holder (``net.state["rnn"][:] = v`` -- allowed by torch once the handle is a non-leaf, or under
+        ``no_grad``, exactly as for the reference's ``y``) is copied into the device state before the next step, and the
+        next window continues from the written handle, so autograd sees the write the way it does in the reference
+        (network.py:88-98, nodes.py:166-170)."""
         if self._y_grad is None and self._y_requires_grad:
             self._y_grad = self._pop.v.detach().clone().requires_grad_(True)
         if self._y_grad is None:
             self._v_exposed = True
             return self._pop.v
+        self._y_handed = (self._y_grad, self._y_grad._version)
         return self._y_grad
 
-    def _before_step(self):
-        """Copy-on-step for a state tensor that was handed out (see :attr:`y`)."""
+    def _before_step(self) -> bool:
+        """Bring the device state up to date with what a holder of :attr:`y` did to it; True if the state changed
+        hands (the source vector r = act(v) was recomputed).  (i) Copy-on-step for the live tensor; (ii) a write into
+        the autograd handle of the state is copied into the device state."""
+        pop = self._pop
+        synced = False
         if self._v_exposed:
-            pop = self._pop
             pop.v = pop.v.clone()        # the old tensor stays with whoever holds it
             pop.refresh()                # the holder may have written into it: r = act(v) again (bit-identical otherwise)
             self._v_exposed = False
+            synced = True
+        handed, self._y_handed = self._y_handed, None
+        if handed is not None and handed[0] is self._y_grad and handed[0]._version != handed[1]:
+            pop.v = handed[0].detach().to(dtype=torch.float32).clone().contiguous()
+            pop.refresh()
+            synced = True
+        return synced
 
     def set_state(self, var: str, val):
         """Write a state variable (``Network.set_var`` on a state name): goes to the device state itself, also when
@@ -538,7 +557,7 @@ class RateNet:
             self._before_step()
             out = torch.empty(1, self._pop.rows, dtype=torch.float32, device=self._pop.device)
             self._pop.forward(1, x=x2, traj=out, out_var=self._out_code)
-            self._y_grad = None
+            self._ungraphed_step()
             out = out[0]
         return out if self._out_slice is None else out[self._out_slice[0]:self._out_slice[1]]
 
@@ -546,8 +565,16 @@ class RateNet:
                    **kw):
         """Fused multi-step integration without autograd (see Population.forward for kwargs)."""
         self._before_step()
-        self._y_grad = None
+        self._ungraphed_step()
         return self._pop.forward(steps, x=x, w_in=w_in, out_var=self._out_code, **kw)
+
+    def _ungraphed_step(self):
+        """The state after a step that recorded no graph has no history; computed under ``no_grad`` it does not
+        require grad either (the reference's ``y = y_old + dt * f(...)`` under ``Network.run(enable_grad=False)``), so
+        ``net.state[...][:] = v`` afterwards is a plain write."""
+        self._y_grad = None
+        if not torch.is_grad_enabled():
+            self._y_requires_grad = False
 
 
 class Spike(torch.autograd.Function):

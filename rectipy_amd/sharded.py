@@ -434,6 +434,15 @@ class ShardedNetwork(Network):
         """Per-step exchange after every step the node takes, whichever entry point is used."""
         net = self
         base_window, base_forward, base_reset = node.run_window, node.forward, node.reset
+        base_before = getattr(node, "_before_step", None)
+
+        def before_step(self_):
+            """A state write by the holder of `y` (every rank runs the same script, so every rank sees its own slice
+            written) changes this rank's slice of the source vector: the other ranks need it before the next step."""
+            synced = base_before()
+            if synced:
+                net._gather(self_, row0, rows, clone=True)
+            return synced
 
         def run_window(self_, steps, x=None, w_in=None, **kw):
             step0 = kw.pop("step0", 0)
@@ -471,6 +480,7 @@ class ShardedNetwork(Network):
                 tv, ts, ta, _ = self_._last_window
                 self_._y_prev = self_._pack(tv[-1], ts[-1], None if ta is None else ta[-1])
                 return traj
+            self_._before_step()
             v_in = self_._y_grad
             if v_in is None:
                 v_in = pop.v.detach().clone().requires_grad_(self_._y_requires_grad)
@@ -486,6 +496,8 @@ class ShardedNetwork(Network):
                 return grad_window(self_, 1, x2)[0]
             return forward(self_, x)
 
+        if base_before is not None and not node._pop.spiking:
+            node._before_step = types.MethodType(before_step, node)
         node.run_window = types.MethodType(run_window, node)
         node.forward = types.MethodType(forward_any, node)
         node.reset = types.MethodType(reset, node)

@@ -313,6 +313,82 @@ def test_state_writes_reach_the_device_state_of_a_trained_node(where):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("enable_grad", [True, False])
+@pytest.mark.parametrize("train", [None, ["weights"], ["weights", "li_op/tau"]])
+def test_in_place_write_into_net_state_is_part_of_the_state(where, train, enable_grad):
+    """`net.run(x[:5]); net.state["rnn"][:] = v; net.run(x[5:])`: the reference hands out the live `y`
+    (network.py:88-98) and its next step starts from whatever it holds (nodes.py:166-170) -- with or without trainable
+    parameters (where `y` is the autograd handle of the last window), with or without a graph being recorded."""
+    n = 40
+    r = np.random.default_rng(7)
+    W = r.standard_normal((n, n)) / n ** 0.5
+    v = torch.tensor(r.standard_normal(n), dtype=torch.float32)
+    x = torch.tensor(r.standard_normal((9, n)) * 0.3, dtype=torch.float32)
+    net = Network(1e-2, **where)
+    net.add_diffeq_node("rnn", TANH, input_var=IN, output_var="li_op/v", weights=W, source_var=SRC, target_var=TGT,
+                        train_params=train, dtype=torch.float32)
+    net.run(x[:5], verbose=False, enable_grad=enable_grad)
+    net.state["rnn"][:] = v      # plain write, no no_grad: legal on the reference's y after a step, and here
+    obs = net.run(x[5:], verbose=False, enable_grad=enable_grad)
+    assert np.array_equal(obs.to_numpy("out")[0], v.numpy()), "the write was dropped"
+    # the rest of the run continues from v: same numbers as a fresh network reset to v
+    net2 = Network(1e-2, **where)
+    net2.add_diffeq_node("rnn", TANH, input_var=IN, output_var="li_op/v", weights=W, source_var=SRC, target_var=TGT,
+                         dtype=torch.float32)
+    net2.reset({"rnn": v})
+    ref = net2.run(x[5:], verbose=False, enable_grad=False)
+    assert np.array_equal(obs.to_numpy("out"), ref.to_numpy("out"))
+    # a partial write through the variable view of the state keeps the other entries
+    before = net.state["rnn"].detach().clone()
+    with torch.no_grad():
+        net.get_node("rnn")["li_op/v"][:3] = 0.25
+    out = net.run(x[:1], verbose=False, enable_grad=enable_grad).to_numpy("out")[0]
+    assert np.array_equal(out[:3], np.full(3, 0.25, dtype=np.float32)) and np.array_equal(out[3:], before[3:].numpy())
+
+
+def test_gradient_flows_through_a_written_state_handle(where):
+    """Autograd sees the in-place write the way it does in the reference: entries overwritten lose their history,
+    the others keep it (CopySlices on the handle that the next window starts from)."""
+    n = 12
+    r = np.random.default_rng(11)
+    W = r.standard_normal((n, n)) / n ** 0.5
+    x = torch.tensor(r.standard_normal((6, n)) * 0.3, dtype=torch.float32)
+    net = Network(1e-2, **where)
+    node = net.add_diffeq_node("rnn", TANH, input_var=IN, output_var="li_op/v", weights=W, source_var=SRC,
+                               target_var=TGT, train_params=["weights"], dtype=torch.float32)
+    net.compile()
+    for t in range(3):
+        net.forward(x[t])
+    net.state["rnn"][: n // 2] = 0.5   # half of the state is replaced by constants
+    out = torch.stack([net.forward(x[t]) for t in range(3, 6)])
+    assert np.array_equal(out[0, : n // 2].detach().numpy(), np.full(n // 2, 0.5, dtype=np.float32))
+    out.sum().backward()
+    g = node["weights"].grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
+
+
+def test_state_write_on_a_spiking_node_lands_in_the_lagging_copy(where):
+    """SpikeResetNet.y is the PRE-update copy the reference rebuilds from _y_start/_y_spike/_y_stop at every step
+    (nodes.py:382-392): a write into `net.state[...]` does not reach the integration state there, and does not here
+    (reset() is the way to set it).  Pinned against the reference's own class in tests/test_reference_seam.py."""
+    n = 16
+    r = np.random.default_rng(5)
+    W = np.abs(r.standard_normal((n, n))) / n
+    x = torch.full((8, n), 15.0)
+    outs = []
+    for write in (False, True):
+        net = Network(1e-3, **where)
+        net.add_diffeq_node("qif", QIF, input_var="qif_op/I_ext", output_var="qif_op/s", weights=W,
+                            source_var="qif_op/s", target_var="qif_op/s_in", spike_var="qif_op/spike",
+                            reset_var="qif_op/v", dtype=torch.float32, node_vars={"all/qif_op/v": -2.0})
+        net.run(x[:4], verbose=False, enable_grad=False)
+        if write:
+            with torch.no_grad():
+                net.state["qif"][:] = 1.0
+        outs.append(net.run(x[4:], verbose=False, enable_grad=False, record_vars=[("qif", "qif_op/v", False)]))
+    assert np.array_equal(outs[0].to_numpy(("qif", "qif_op/v")), outs[1].to_numpy(("qif", "qif_op/v")))
+
+
 def test_recorded_state_rows_do_not_alias(where):
     """A per-step recorder that keeps the tensors it gets from `node[var]` / `net.state` (what the reference's Observer
     does, observer.py:100-101) sees one distinct state per step."""

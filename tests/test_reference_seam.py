@@ -125,6 +125,79 @@ def test_state_write_through_live_tensor(ref, oracle_backend):
     assert torch.equal(outs[0][0], torch.tensor(g["y0"] + 1.0, dtype=torch.float32))
 
 
+@pytest.mark.parametrize("enable_grad", [True, False])
+@pytest.mark.parametrize("train", [None, ["weights"]])
+def test_in_place_state_write_between_two_runs_matches_the_reference(ref, oracle_backend, train, enable_grad):
+    """`net.run(x[:5]); net.state["rnn"][:] = v; net.run(x[5:])` inside the reference's own rectipy.Network
+    (network.py:88-98 hands out the live y): once with the reference's RateNet around the hand-written field, once with
+    the rectipy_amd node -- with train_params the latter's `y` is the autograd handle of the last window, and the
+    write must still reach the device state."""
+    from make_golden import rate_node
+    sys.path.insert(0, "/root/reference")
+    from rectipy.nodes import RateNet as RefRateNet
+    g = gold("g1_rate_tanh_n16")
+    x = torch.tensor(g["x_full"][:10], dtype=torch.float32)
+    v = torch.tensor(g["y0"] * 0.5 + 0.3, dtype=torch.float32)
+    outs = []
+    for which in ("reference", "amd"):
+        net = ref(float(g["dt"]), dtype=torch.float32)
+        if which == "reference":
+            node = rate_node(RefRateNet, g["W"], g["tau"], g["k"], g["eta"], g["y0"], float(g["dt"]), torch.float32,
+                             train_params=train)
+        else:
+            node = amd_node(g, oracle_backend, train=train)
+        net.add_node("rnn", node, node_type="diff_eq", op="li_op")
+        net.run(x[:5], verbose=False, enable_grad=enable_grad)
+        net.state["rnn"][:] = v
+        obs = net.run(x[5:], verbose=False, enable_grad=enable_grad)
+        outs.append(obs.to_numpy("out"))
+    assert np.array_equal(outs[0][0], v.numpy()) and np.array_equal(outs[1][0], v.numpy())
+    close(outs[1], outs[0], 2e-6)
+
+
+def test_state_write_on_spiking_node_is_ignored_by_the_reference_too(ref, oracle_backend):
+    """The reference's SpikeResetNet rebuilds `y` from its private segments at every step (nodes.py:382-392), so a
+    write into net.state[...] never reaches the integration; rectipy_amd.SpikeResetNet keeps that behaviour."""
+    from make_golden import make_qif
+    sys.path.insert(0, "/root/reference")
+    from rectipy.nodes import SpikeResetNet as RefSpikeNet
+    import rectipy_amd
+    n, dt = 8, 1e-3
+    r = np.random.default_rng(2)
+    W = np.abs(r.standard_normal((n, n))) / n
+    x = torch.full((8, n), 15.0)
+    recs = {}
+    for which in ("reference", "amd"):
+        for write in (False, True):
+            net = ref(dt, dtype=torch.float32)
+            if which == "reference":
+                t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float32)
+                y0 = np.concatenate([np.full(n, -2.0), np.zeros(n)])
+                args = (t(y0), torch.zeros(n), torch.zeros(n), t(W), t(np.ones(n)), t(np.ones(n)), t(np.full(n, -5.0)),
+                        t(np.ones(n)))
+                node = RefSpikeNet(make_qif(n), args, {"out": (n, 2 * n), "reset_var": (0, n), "qif_op/v": (0, n)},
+                                   {"in": 0, "spike_var": 1, "weights": 2}, dt=dt, dtype=torch.float32)
+            else:
+                node = rectipy_amd.SpikeResetNet.from_pyrates(
+                    "neuron_model_templates.spiking_neurons.qif.qif", input_var="qif_op/I_ext", output_var="qif_op/s",
+                    weights=W, source_var="qif_op/s", target_var="qif_op/s_in", spike_var="qif_op/spike",
+                    reset_var="qif_op/v", node_vars={"all/qif_op/v": -2.0, "all/qif_op/eta": -5.0}, dt=dt,
+                    dtype=torch.float32, device="cpu", backend=oracle_backend)
+            net.add_node("qif", node, node_type="diff_eq", op="qif_op")
+            net.compile()
+            for t_ in range(4):
+                net.forward(x[t_])
+            if write:
+                with torch.no_grad():
+                    net.state["qif"][:] = 1.0
+            for t_ in range(4, 8):
+                net.forward(x[t_])
+            recs[which, write] = net.state["qif"].detach().numpy().copy()
+    assert np.array_equal(recs["reference", False], recs["reference", True])
+    assert np.array_equal(recs["amd", False], recs["amd", True])
+    close(recs["amd", False], recs["reference", False], 1e-5)
+
+
 def test_reference_fit_bptt_with_amd_node(ref, oracle_backend):
     """G5 through rectipy.Network.fit_bptt (the reference's window loop, loss, optimizer and detach calls) with the
     compiled node doing forward AND backward one step at a time."""

@@ -151,6 +151,51 @@ def test_sharded_network_front_end(tmp_path, oracle_backend):
     assert np.array_equal(np.concatenate([p["state"] for p in parts]), net.state["rnn"].numpy())
 
 
+def _write_build(cls, where, train):
+    W, params, v0, x = _data()
+    net = cls(1e-2, **where)
+    net.add_diffeq_node("rnn", TANH, weights=W.numpy(), source_var="tanh_op/r", target_var="li_op/r_in",
+                        input_var="li_op/I_ext", output_var="li_op/v", dtype=torch.float32, train_params=train,
+                        node_vars={"all/li_op/tau": params["tau"].numpy(), "all/li_op/k": params["k"].numpy(),
+                                   "all/li_op/eta": params["eta"].numpy(), "all/li_op/v": v0.numpy()})
+    return net, x[:, :1].numpy().copy(), (v0 * 0.5 + 0.25)
+
+
+def _write_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from oracle.backend import OracleBackend
+        from rectipy_amd.sharded import ShardedNetwork, shard_bounds
+        row0, rows = shard_bounds(N, WORLD, rank)
+        for train in (None, ["weights"]):
+            net, x, v = _write_build(ShardedNetwork, dict(device="cpu", backend=OracleBackend()), train)
+            net.run(x[:5], verbose=False)
+            net.state["rnn"][:] = v[row0:row0 + rows]     # every rank writes its slice of the state
+            obs = net.run(x[5:12], verbose=False)
+            np.save(os.path.join(out_dir, f"write_{'t' if train else 'n'}_{rank}.npy"), obs.to_numpy("out"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_state_write_on_a_sharded_population_reaches_every_rank(tmp_path, oracle_backend):
+    """`net.state[...][:] = v` between two runs of a ShardedNetwork: the rank's slice of the source vector r = tanh(v)
+    changes with the write and the other ranks need it before the next step (one extra all-gather)."""
+    from rectipy_amd import Network
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_write_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    for train, tag in ((None, "n"), (["weights"], "t")):
+        net, x, v = _write_build(Network, dict(device="cpu", backend=oracle_backend), train)
+        net.run(x[:5], verbose=False)
+        net.state["rnn"][:] = v
+        want = net.run(x[5:12], verbose=False).to_numpy("out")
+        got = np.concatenate([np.load(tmp_path / f"write_{tag}_{r}.npy") for r in range(WORLD)], axis=1)
+        assert np.array_equal(got[0], v.numpy())
+        assert np.array_equal(got, want)
+
+
 def _bptt_worker(rank, port, out_dir, WORLD=WORLD):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
