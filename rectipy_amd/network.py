@@ -368,6 +368,10 @@ class Network:
         :class:`Observer` per trajectory, each as :meth:`run` would have produced it for ``inputs[b]`` from the same
         initial state (``y0``: [B, N] initial states of the population; default: its current state for every b).
 
+        The observers' samples are computed the way `run` computes them (running fp32 sum in step order / count behind
+        identity read-out nodes; per-step read-out + torch mean behind a non-linear one), so for B <= 8 they equal `run`'s
+        bit for bit for every ``sampling_steps`` / ``cutoff`` (tests/test_batched.py).
+
         Not part of the reference's API (it has no batch axis: B trials are B passes of its time loop, each streaming W
         again).  Here every Euler step streams W ONCE for all B trajectories (``rp_forward_batched``): up to 8 trajectories
         on the vector ALUs, each bit-identical to an unbatched run; 9..32 per pass on the matrix cores (equal to unbatched
@@ -416,15 +420,33 @@ class Network:
                 if verbose:
                     print(f"Progress: trajectories {b0}..{b0 + nb - 1}, {e}/{T} integration steps finished.")
             finals[b0:b0 + nb] = bp.v[:nb]
-        out = per_step if not post else self._apply_chain(post, per_step.reshape(B * T, N), label, None).reshape(B, T, -1)
+        # sampling as `run` does it for this topology (_run_fused): behind identity read-out nodes the buffer mean is the
+        # step kernel's -- a running fp32 sum in step order divided by the count -- taken on the
+        # population's output and read out afterwards; a non-linear read-out is applied per step and averaged by torch
+        linear_post = all(self.get_node(n).name == "identity" for n in post)
+        S = len(sample_at)
+        if linear_post:
+            sampled = torch.empty(B, S, N, dtype=torch.float32, device=pop.device)
+            begin = cutoff
+            for j, t in enumerate(sample_at):
+                acc = per_step[:, begin].clone()
+                for u in range(begin + 1, t + 1):
+                    acc += per_step[:, u]
+                sampled[:, j] = acc / float(t + 1 - begin)
+                begin = t + 1
+            # read out per trajectory: the same [S, N] product `run` computes (a [B*S, N] product may round differently)
+            out = sampled if not post else torch.stack([self._apply_chain(post, sampled[b], label, None) for b in range(B)])
+        else:
+            full = torch.stack([self._apply_chain(post, per_step[b], label, None) for b in range(B)])
+            out = torch.empty(B, S, full.shape[2], dtype=torch.float32, device=pop.device)
+            begin = cutoff
+            for j, t in enumerate(sample_at):
+                out[:, j] = torch.stack([full[b, begin:t + 1].mean(dim=0) for b in range(B)])
+                begin = t + 1
         observers = []
         for b in range(B):
-            rows, begin = [], cutoff
-            for t in sample_at:  # mean over the steps buffered since the previous sample (network.py:595)
-                rows.append(out[b, begin:t + 1].mean(dim=0))
-                begin = t + 1
             obs = Observer(dt=self.dt, record_loss=False)
-            obs.record_block(sample_at, torch.stack(rows) if rows else out[b, :0], 0.0, [])
+            obs.record_block(sample_at, out[b], 0.0, [])
             obs.save("state", finals[b].clone())
             observers.append(obs)
         return observers

@@ -107,26 +107,28 @@ def test_network_run_batch_equals_separate_runs(target):
     x = rng.standard_normal((B, T, m)).astype(np.float32)
     y0 = rng.standard_normal(n).astype(np.float32)
 
-    def build():
-        net = Network(1e-2, **target)
-        net.add_func_node("inp", m, "identity")
-        net.add_diffeq_node("rnn", "neuron_model_templates.rate_neurons.leaky_integrator.tanh", weights=W,
-                            source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext", output_var="tanh_op/r",
-                            node_vars={"all/li_op/v": y0}, dtype=torch.float32)
-        net.add_func_node("out", k, "identity")
-        net.add_edge("inp", "rnn", weights=W_in)
-        net.add_edge("rnn", "out", weights=W_out)
-        return net
+    for out_fn, s, cutoff in (("identity", 3, 4), ("identity", 1, 0), ("identity", 7, 5), ("tanh", 3, 4)):
+        def build():
+            net = Network(1e-2, **target)
+            net.add_func_node("inp", m, "identity")
+            net.add_diffeq_node("rnn", "neuron_model_templates.rate_neurons.leaky_integrator.tanh", weights=W,
+                                source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                                output_var="tanh_op/r", node_vars={"all/li_op/v": y0}, dtype=torch.float32)
+            net.add_func_node("out", k, out_fn)
+            net.add_edge("inp", "rnn", weights=W_in)
+            net.add_edge("rnn", "out", weights=W_out)
+            return net
 
-    net = build()
-    batch = net.run_batch(x, sampling_steps=3, cutoff=4)
-    assert len(batch) == B and np.array_equal(net.state["rnn"].cpu().numpy(), y0)  # the network's own state is untouched
-    for b in range(B):
-        single = build()
-        obs = single.run(x[b], sampling_steps=3, cutoff=4, verbose=False, enable_grad=False)
-        assert list(obs["steps"]) == list(batch[b]["steps"])
-        assert np.allclose(obs.to_numpy("out"), batch[b].to_numpy("out"), atol=1e-6)
-        assert torch.equal(single.state["rnn"], batch[b]["state"])
+        net = build()
+        batch = net.run_batch(x, sampling_steps=s, cutoff=cutoff)
+        assert len(batch) == B and np.array_equal(net.state["rnn"].cpu().numpy(), y0)  # the network's own state is untouched
+        for b in range(B):
+            single = build()
+            obs = single.run(x[b], sampling_steps=s, cutoff=cutoff, verbose=False, enable_grad=False)
+            assert list(obs["steps"]) == list(batch[b]["steps"])
+            # buffer means included: the same running sum in step order / count as the step kernel's
+            assert np.array_equal(obs.to_numpy("out"), batch[b].to_numpy("out")), (out_fn, s, cutoff, b)
+            assert torch.equal(single.state["rnn"], batch[b]["state"])
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
