@@ -217,12 +217,15 @@ def main():
         stamps.append(time.perf_counter())
 
     setattr(backend, entry, bracketed)
+    torch.cuda.synchronize()
+    t_first = time.perf_counter()
     try:
-        idx = run(Wm, 0, 0)
+        idx = run(Wm, 0, 0)  # the process's FIRST call of the path: its wall time is reported as first_call.cold_ms
     except BaseException:
         delattr(backend, entry)
         raise
     torch.cuda.synchronize()
+    first_call_ms = (time.perf_counter() - t_first) * 1e3
     barrier()
     torch.cuda.synchronize()
     timing[0] = True
@@ -305,6 +308,14 @@ def main():
         out["cpu_baseline"], cpu_threads = cpu_baseline(pop, x, dt, N)
     if world == 1 and not use_dist and not args.no_extra:
         out["extra"] = fwd_bwd_extra(pop, x, N, dev)
+        from rectipy_amd import tuning
+        # cold vs warm cost of one call through the front end: the W-step warm-up call was this process's first call of
+        # the path (library load, code-object load, first launches; NO walk measurement under the default policy), the
+        # timed call a warm one; "overhead" = wall time minus steps x the measured launch duration
+        out["extra"]["first_call"] = {
+            "steps": Wm, "cold_ms": first_call_ms, "cold_overhead_ms": first_call_ms - Wm * kernel_ms,
+            "warm_steps": K, "warm_ms": wall * 1e3, "warm_overhead_ms": wall * 1e3 - K * kernel_ms,
+            "autotune_policy": tuning.mode(), "walk_measured_in_this_process": bool(streaming["measured"])}
         if cpu_threads is not None:
             out["extra"]["cpu_fwd_bwd"] = cpu_fwd_bwd(pop, x, dt, N, cpu_threads)
         out["extra"]["batched_trajectories"] = batched_extra(pop, N, dev, out["ms_per_step"])

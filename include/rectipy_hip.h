@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 8
+#define RP_ABI_VERSION 9
 #define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0
@@ -416,11 +416,18 @@ int rp_rls_sweep(const rp_rls* rls, int32_t steps, int32_t stride, const float* 
    remembers the best per (device, rows, n, ldw) for every later rp_forward / rp_forward_sharded of that shape and any
    model.  Shapes that do not stream from HBM (rows < 8192 or W <= 320 MiB), the 4-byte path, and a capturing stream
    return RP_OK without measuring.  No reference counterpart.
-   rp_forward_tuning reports the configuration rp_forward would use now (`measured` = 1 if it came from rp_tune_forward,
-   with its time per step; 0: the static rule). */
+   rp_forward_tuning reports the configuration rp_forward would use now (`measured` = 1 if it came from rp_tune_forward
+   or rp_install_forward_tuning, with its time per step; 0: the static rule).
+   rp_install_forward_tuning records a configuration measured EARLIER for this shape on this device model (the host
+   side persists winners per (device name, rows, n, ldw), so that a second process pays nothing); (R, U) must be one of
+   the compiled instances (1,4) (2,1) (2,2) (4,1) (4,2) (8,1).  A measurement is an optimisation, never a
+   requirement: the host side measures only on request or when a run is long enough to repay it, and treats any error
+   of rp_tune_forward as "keep the static rule". */
 int rp_tune_forward(const rp_net* net, void* stream);
 int rp_forward_tuning(const rp_net* net, int32_t* rows_per_wave, int32_t* chunks_in_flight, int32_t* workgroups,
                       float* us_per_step, int32_t* measured);
+int rp_install_forward_tuning(const rp_net* net, int32_t rows_per_wave, int32_t chunks_in_flight, int32_t workgroups,
+                               float us_per_step);
 int rp_clear_forward_tuning(void);
 
 /* Benchmark-only: override the streaming configuration of the tanh step kernel

@@ -1079,6 +1079,32 @@ int rp_forward_tuning(const rp_net* net, int32_t* rows_per_wave, int32_t* chunks
     return RP_OK;
 }
 
+int rp_install_forward_tuning(const rp_net* net, int32_t rows_per_wave, int32_t chunks_in_flight, int32_t workgroups,
+                               float us_per_step) {
+    if (!net) RP_FAIL(RP_ERR_ARG, "net is null");
+    if (net->n <= 0 || net->rows <= 0 || net->ldw < net->n)
+        RP_FAIL(RP_ERR_SHAPE, "rp_install_forward_tuning: bad shape n=%d rows=%d ldw=%lld", net->n, net->rows,
+                (long long)net->ldw);
+    bool known = false;  // the (R, U) instances launch_step dispatches on
+    for (int ru : {14, 21, 22, 41, 42, 81}) known = known || rows_per_wave * 10 + chunks_in_flight == ru;
+    if (!known || workgroups < 0 || workgroups > (1 << 20))
+        RP_FAIL(RP_ERR_ARG, "rp_install_forward_tuning: no step kernel instance for R=%d U=%d workgroups=%d",
+                rows_per_wave, chunks_in_flight, workgroups);
+    if (!use_vec4(net) || !streams_from_hbm(net->rows, net->n)) return RP_OK;  // such shapes keep the static rule
+    int dev = 0;
+    RP_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_tuned_mu);
+    for (TunedShape& t : g_tuned)
+        if (t.device == dev && t.rows == net->rows && t.n == net->n && t.ldw == net->ldw) {
+            t.cfg = StreamCfg{rows_per_wave, chunks_in_flight, workgroups};
+            t.us = us_per_step;
+            return RP_OK;
+        }
+    g_tuned.push_back(TunedShape{dev, net->rows, net->n, net->ldw, StreamCfg{rows_per_wave, chunks_in_flight, workgroups},
+                                 us_per_step});
+    return RP_OK;
+}
+
 int rp_clear_forward_tuning(void) {
     std::lock_guard<std::mutex> lock(g_tuned_mu);
     g_tuned.clear();

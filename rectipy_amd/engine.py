@@ -16,7 +16,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from . import _abi
+from . import _abi, tuning
 from ._abi import RpBwd, RpNet, RpRun
 
 MODEL_IDS = {"li_tanh": _abi.RP_MODEL_LI_TANH, "li_sigmoid": _abi.RP_MODEL_LI_SIGMOID, "qif": _abi.RP_MODEL_QIF,
@@ -91,12 +91,23 @@ class HipBackend:
             self._lib_mod.check(self.lib.rp_forward(C.byref(net), C.byref(run), self._stream(device)))
 
     def tune_forward(self, net: RpNet, device):
-        """Measure the streaming configuration of the dense step kernel for this shape once per process (a no-op for
-        shapes that do not stream from HBM); RECTIPY_AMD_NO_AUTOTUNE=1 keeps the static rule."""
-        if os.environ.get("RECTIPY_AMD_NO_AUTOTUNE", "0") == "1":
-            return
+        """Measure the streaming configuration of the dense step kernel for this shape (a no-op for shapes that do not
+        stream from HBM, and for a shape already measured or installed in this process).  WHEN this is called is the
+        policy of :mod:`rectipy_amd.tuning` (on request, or for runs long enough to repay it -- not by default)."""
         with self._on(device):
             self._lib_mod.check(self.lib.rp_tune_forward(C.byref(net), self._stream(device)))
+
+    def install_forward_tuning(self, net: RpNet, R: int, U: int, workgroups: int, us: float, device):
+        """Install a configuration measured by an earlier process for this shape (tuning.py keeps them on disk)."""
+        with self._on(device):
+            self._lib_mod.check(self.lib.rp_install_forward_tuning(C.byref(net), R, U, workgroups, us))
+
+    def abi_version(self) -> int:
+        return int(self.lib.rp_abi_version())
+
+    @staticmethod
+    def device_name(device) -> str:
+        return torch.cuda.get_device_name(device)
 
     def forward_tuning(self, net: RpNet) -> dict:
         R, U, G, m, us = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_float()
@@ -179,7 +190,8 @@ class Population:
 
     def __init__(self, model: str, weights, params: Dict[str, object], dt: float, device,
                  v0=None, s0=None, theta: float = 100.0, v_reset: float = -100.0,
-                 n: Optional[int] = None, row0: int = 0, backend=None, aux0=None, aux2_0=None):
+                 n: Optional[int] = None, row0: int = 0, backend=None, aux0=None, aux2_0=None,
+                 tune: Optional[bool] = None):
         if model not in MODEL_IDS:
             raise ValueError(f"unknown model '{model}'; available: {sorted(MODEL_IDS)}")
         self.model = model
@@ -217,7 +229,10 @@ class Population:
         self.aux2 = self._vec(0.0 if aux2_0 is None else aux2_0) if model in HAS_AUX2 else None
         self._scratch = torch.zeros(4, **f32) if model in NEEDS_MEANS else None
         self._net_cache = None           # (key, RpNet) reused across calls, see _net()
-        self._tuned = False              # rp_tune_forward ran for this population's shape (first forward)
+        self.tune = tune                 # True: measure the step kernel's walk at the first step; False: never; None:
+        #                                  the RECTIPY_AMD_AUTOTUNE policy (tuning.py: only runs long enough to repay it)
+        self._tuned = False              # nothing left to decide: measured, installed from the cache, or ruled out
+        self._cache_checked = False      # the persisted winners were looked up for this population's shape
         self.packed = None               # PackedRows of a fixed sparse W (sparse.py); the step kernel then streams it
         self._packed_version = -1        # W._version when `packed` was built (see _sync_packed)
         self.packed_t = None             # PackedRows of W^T (adjoint of a fixed sparse W), built on first use
@@ -477,10 +492,8 @@ class Population:
             run.spike_count = spike_count.data_ptr()
 
         net = self._net()
-        if not self._tuned:  # once per population; the library keeps one measurement per (device, shape)
-            self._tuned = True
-            if self.packed is None and hasattr(self.backend, "tune_forward"):
-                self.backend.tune_forward(net, self.device)
+        if not self._tuned:  # static rule unless a measurement was asked for or this call is long enough to repay one
+            tuning.prepare(self, net, steps)
         if comm is None:
             self.backend.forward(net, run, self.device)
         else:

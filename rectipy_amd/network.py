@@ -33,7 +33,8 @@ _WINDOW_BYTES = 2 << 30  # cap for [T, N] staging buffers of one fused call
 class Network:
     """Graph of diff-eq populations, activation nodes and linear edges (reference network.py:16-44)."""
 
-    def __init__(self, dt: float, device: str = "cuda:0", dtype: torch.dtype = torch.float32, backend=None):
+    def __init__(self, dt: float, device: str = "cuda:0", dtype: torch.dtype = torch.float32, backend=None,
+                 tune: Optional[bool] = None):
         self.graph = DiGraph()
         self.device = device
         if dtype is not torch.float32:
@@ -42,6 +43,7 @@ class Network:
         self.dtype = torch.float32
         self.dt = dt
         self._backend = backend  # test seam, see rectipy_amd.engine
+        self._tune = tune        # True: populations measure their step kernel's walk at the first step (tuning.py)
         self._var_map = {}
         self._in_node = None
         self._out_node = None
@@ -148,6 +150,8 @@ class Network:
         kwargs.setdefault("dt", self.dt)
         if self._backend is not None:
             kwargs.setdefault("backend", self._backend)
+        if self._tune is not None:
+            kwargs.setdefault("tune", self._tune)
         common = dict(weights=weights, source_var=names["svar"], target_var=names["tvar"], train_params=train_params)
         if spike_var is None:
             new = RateNet.from_pyrates(node, names["in_ext"], names["out"], **common, **kwargs)

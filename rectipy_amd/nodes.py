@@ -190,6 +190,8 @@ class RateNet:
         shard = kwargs.pop("shard", None)  # (row0, n): this node holds rows [row0, row0+rows) of an n x n matrix
         if shard is not None:
             kw.update(row0=int(shard[0]), n=int(shard[1]))
+        if "tune" in kwargs:  # True: measure the step kernel's walk for this shape at the first step (tuning.py)
+            kw["tune"] = kwargs.pop("tune")
         self._pop = Population(template.model, weights, eng_params, dt, device, backend=backend, **kw)
         N = self._pop.rows
         self.n_in = N

@@ -56,6 +56,14 @@ def test_argument_validation_without_gpu(lib):
     assert lib.rp_tune_forward(C.byref(small), None) == _abi.RP_OK
     small.ldw = 100
     assert lib.rp_tune_forward(C.byref(small), None) == _abi.RP_ERR_SHAPE
+    # rp_install_forward_tuning: the configuration must name a compiled kernel instance; small shapes return before any HIP call
+    assert lib.rp_install_forward_tuning(None, 2, 1, 683, 600.0) == _abi.RP_ERR_ARG
+    assert lib.rp_install_forward_tuning(C.byref(small), 2, 1, 683, 600.0) == _abi.RP_ERR_SHAPE  # ldw < n
+    small.ldw = 512
+    assert lib.rp_install_forward_tuning(C.byref(small), 3, 1, 683, 600.0) == _abi.RP_ERR_ARG
+    assert b"no step kernel instance" in lib.rp_last_error()
+    assert lib.rp_install_forward_tuning(C.byref(small), 2, 1, -1, 600.0) == _abi.RP_ERR_ARG
+    assert lib.rp_install_forward_tuning(C.byref(small), 2, 1, 683, 600.0) == _abi.RP_OK
     assert lib.rp_bwd_partial_rows(32768) == 24 and lib.rp_bwd_partial_rows(65536) == 12 and lib.rp_bwd_partial_rows(8192) == 64 and lib.rp_bwd_partial_rows(10) == 2
     with pytest.raises(ValueError):
         _lib.check(_abi.RP_ERR_ARG)

@@ -655,3 +655,49 @@ def test_measured_streaming_configuration_keeps_the_bits(rows, n, row0):
     finally:
         os.environ.pop("RECTIPY_AMD_NO_AUTOTUNE", None)
         lib.rp_clear_forward_tuning()
+
+
+@pytest.mark.gpu
+def test_measurement_policy_default_static_request_measures_cache_installs(tmp_path, monkeypatch):
+    """rectipy_amd/tuning.py on the device: by default a population's first (short) forward runs on the static rule -- no
+    probe launches; `tune=True` measures and persists the winner; the next population of that shape (a "second
+    process": library table cleared) installs it from the cache file without measuring; every variant gives the same bits."""
+    import time
+
+    from rectipy_amd import _lib
+    from rectipy_amd.engine import Population
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    rows, n = 8192, 16384
+    monkeypatch.setenv("RECTIPY_AMD_TUNE_CACHE", str(tmp_path / "forward_tuning.json"))
+    monkeypatch.delenv("RECTIPY_AMD_AUTOTUNE", raising=False)
+    monkeypatch.delenv("RECTIPY_AMD_NO_AUTOTUNE", raising=False)
+    lib.rp_clear_forward_tuning()
+    gen = torch.Generator(device=dev).manual_seed(5)
+    W = torch.randn(rows, n, device=dev, generator=gen) * (1.2 / n ** 0.5)
+    x = torch.sin(torch.arange(12, device=dev) * 0.1).reshape(-1, 1).contiguous()
+
+    def run(**kw):
+        pop = Population("li_tanh", W, dict(tau=2.0, k=1.0, eta=0.1), 1e-2, dev, n=n, row0=4096, **kw)
+        traj = torch.empty(12, rows, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pop.forward(12, x=x, traj=traj)
+        torch.cuda.synchronize()
+        return traj, pop.backend.forward_tuning(pop._net()), time.perf_counter() - t0
+
+    try:
+        run()                                                    # (first launch of the process: module load etc.)
+        base, info, t_static = run()
+        assert not info["measured"] and not (tmp_path / "forward_tuning.json").exists()
+        tuned, info, t_tuned = run(tune=True)
+        assert info["measured"] and (tmp_path / "forward_tuning.json").exists()
+        assert t_tuned > 5 * t_static                            # the measurement is what a default run no longer pays
+        lib.rp_clear_forward_tuning()                            # "second process"
+        cached, info2, t_cached = run()
+        assert info2["measured"] and (info2["rows_per_wave"], info2["chunks_in_flight"], info2["workgroups"]) == \
+            (info["rows_per_wave"], info["chunks_in_flight"], info["workgroups"])
+        assert t_cached < 0.2 * t_tuned
+        assert torch.equal(base, tuned) and torch.equal(base, cached)
+    finally:
+        lib.rp_clear_forward_tuning()
