@@ -370,16 +370,26 @@ typedef struct rp_batch {
        workgroup); inside a tile the columns 8 g + {0, 4, 1, 5, 2, 6, 3, 7} for g = 0..3; the four fmaf chains are added
        as ((c0 + c1) + c2) + c3 (mirrored by the oracle).  Equal to the unbatched run up to fp32 rounding (different
        order), not bit for bit. */
-    int32_t layout;           /* RP_BATCH_VALU (0) | RP_BATCH_MFMA (1)                               */
+    /* layout = RP_BATCH_MFMA16: the contraction runs on v_mfma_f32_16x16x4_f32 (exact fp32) with 1..32 trajectories per
+       pass over W (one or two blocks of 16 slots: a batch <= 16 fills whole matrix tiles).  State is BATCH-major exactly
+       as for RP_BATCH_VALU (v [B x ldv], src[k] [B x ldsrc]); row0 must be a multiple of 128.  W and the source tiles reach
+       the LDS by LDS-DMA (global_load_lds_dwordx4) in a ring of stages shared by the four (eight) waves of a 64-row (128-row) workgroup.
+       Summation order per (row i, trajectory b): ONE fmaf chain from 0 over the 16-column groups g0, g0 + 1, ..., G - 1,
+       0, ..., g0 - 1 with G = ceil(n / 16), g0 = 16 * ((3 * ((row0 + i) >> 7)) mod ceil(n / 256)); inside a group the
+       columns 16 g + 4 kq + c for c = 0..3 (outer) and kq = 0..3 (inner); columns >= n contribute fmaf(0, 0, acc)
+       (mirrored by the oracle).  Equal to the unbatched run up to fp32 rounding, not bit for bit. */
+    int32_t layout;           /* RP_BATCH_VALU (0) | RP_BATCH_MFMA (1) | RP_BATCH_MFMA16 (2)          */
 } rp_batch;
 
 #define RP_BATCH_VALU 0
 #define RP_BATCH_MFMA 1
+#define RP_BATCH_MFMA16 2
 #define RP_BATCH_SLOTS 32
 
 int rp_sizeof_batch(void);
 int rp_forward_batched(const rp_net* net, rp_batch* batch, void* stream);
 int rp_set_batched_tuning(int rows_per_wave, int unroll); /* benchmark-only; 0 = built-in */
+int rp_set_batched_mfma_tuning(int tile_columns, int stages, int waves); /* benchmark-only: tile width (64, 128, 256), LDS ring depth and waves per workgroup (4, 8) of the RP_BATCH_MFMA16 step; 0 = built-in.  Never changes the bits. */
 int rp_set_batched_grid(int max_workgroups); /* benchmark-only: cap on the resident workgroups of the vector-ALU batched step; 0 = built-in */
 
 /*

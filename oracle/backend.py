@@ -61,6 +61,7 @@ def _declare(lib):
     sig("oracle_bwd_partial", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp])
     sig("oracle_bwd_apply", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp])
     sig("oracle_forward_batched_mfma", C.c_int, [P(RpNet), P(_abi.RpBatch)])
+    sig("oracle_forward_batched_mfma16", C.c_int, [P(RpNet), P(_abi.RpBatch)])
     sig("oracle_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp])
     sig("oracle_expf", C.c_float, [C.c_float])
     sig("oracle_tanhf", C.c_float, [C.c_float])
@@ -117,6 +118,9 @@ class OracleBackend:
         B = int(bt.batch)
         if bt.layout == _abi.RP_BATCH_MFMA:  # its own summation order: mirrored in C (oracle_forward_batched_mfma)
             assert self.lib.oracle_forward_batched_mfma(C.byref(net), C.byref(bt)) == 0
+            return
+        if bt.layout == _abi.RP_BATCH_MFMA16:  # the 16x16x4 form: one chain per element (oracle_forward_batched_mfma16)
+            assert self.lib.oracle_forward_batched_mfma16(C.byref(net), C.byref(bt)) == 0
             return
         for b in range(B):
             nb = _abi.RpNet()

@@ -283,6 +283,220 @@ __global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const Batch
     }
 }
 
+// ---- matrix-core form on v_mfma_f32_16x16x4_f32 (RP_BATCH_MFMA16): 1..32 trajectories, batch-major state ------------
+// C[16 rows x 16 slots] per MFMA, K = 4 per instruction at 32 cycles: the same FLOP rate as the 32x32x2 form, but a batch
+// of <= 16 fills whole tiles (no padded half) and the state keeps the vector-ALU form's [B x n] layout.  A workgroup of
+// WAVES (four or eight) waves owns 16 rows per wave and walks the column tiles of TC columns TOGETHER: the 16 NB x TC
+// source tile is loaded once per workgroup (each wave brings its share) and shared, each wave brings its own 16 x TC block
+// of W.  All
+// loads are LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, W non-temporal, no VGPR staging, no ds_write)
+// into a ring of S stages, with a counted s_waitcnt vmcnt + ONE raw s_barrier per tile:
+//     wait own DMAs of tile i -> barrier (everyone's landed; everyone is done reading tile i-1) -> issue tile i+S-1 into
+//     the stage tile i-1 used -> MFMAs of tile i.
+// LDS image: row-major rows of TC floats, the 16-byte quads of a row XOR-swizzled with (row & 15) -- applied on the DMA's
+// per-lane SOURCE address (the LDS side of a DMA is lane-linear) and on the read address: lane (r = l & 15, kq = l >> 4)
+// reads quad (4 j + kq) ^ r of row r for A and of slot-row r for B with ds_read_b128, conflict-free, and feeds component c
+// to MFMA c of the group (k index kq <-> column 16 j + 4 kq + c for both operands).
+// Summation order per (row, slot): ONE fmaf chain from 0 over the 16-column groups g0, g0 + 1, ..., G - 1, 0, ..., g0 - 1
+// (G = ceil(n / 16), g0 = 16 * ((3 * (global row >> 7)) mod ceil(n / 256))); inside a group the columns
+// 16 g + 4 kq + c for c = 0..3 (outer), kq = 0..3 (inner: the k order of one MFMA); columns >= n contribute
+// fmaf(0, 0, acc).  Independent of TC and S.  Mirrored by oracle_forward_batched_mfma16.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) void* rp_gptr;
+typedef __attribute__((address_space(3))) void* rp_lptr;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit count");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int MODEL, int NB, int TC, int S, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void step_batched_mfma16_kernel(const BatchParams P, int batch) {
+    extern __shared__ __attribute__((aligned(16))) float lds16[];
+    constexpr int ROWS = 16 * WAVES;         // rows per workgroup (16 per wave)
+    constexpr int QPR = TC / 4;              // 16-byte quads per tile row
+    constexpr int W_INSTR = TC / 16;         // DMA instructions (1 KiB) for a wave's 16 x TC block of W
+    constexpr int R_INSTR = NB * TC / (16 * WAVES);  // ... for this wave's share of the 16 NB x TC source tile
+    constexpr int DPT = W_INSTR + R_INSTR;   // DMA instructions per tile and wave
+    constexpr int STAGE = ROWS * TC + 16 * NB * TC;  // floats per stage: the workgroup's rows of W, 16 NB slot-rows of the source
+    static_assert((NB * TC) % (16 * WAVES) == 0, "every wave brings the same number of source pieces");
+    static_assert(DPT * (S - 2) < 64 && S >= 2 && S <= 4, "ring depth");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row_blk = blockIdx.x * ROWS;
+    const int tiles = (P.n + TC - 1) / TC;
+    const int supers = (P.n + 255) / 256;
+    const int t0 = (int)((3u * (unsigned)((P.row0 + row_blk) >> 7)) % (unsigned)supers) * (256 / TC);
+    const bool ragged = (P.n % TC) != 0;     // the last tile has columns >= n: filled through registers, zeros past n
+
+    // this lane's part of every DMA instruction: LDS quad Q = 64 i + lane of the block -> (row, swizzled quad)
+    const float* wsrc[W_INSTR];
+    int wq[W_INSTR];
+#pragma clang loop unroll(full)
+    for (int i = 0; i < W_INSTR; ++i) {
+        const int Q = 64 * i + lane, row = Q / QPR, qp = Q % QPR;
+        int grow = row_blk + 16 * wave + row;
+        grow = grow < P.rows ? grow : P.rows - 1;  // clamp: rows past the end re-read a valid row, results discarded
+        wq[i] = 4 * (qp ^ (row & 15));
+        wsrc[i] = P.W + (int64_t)grow * P.ldw + wq[i];
+    }
+    const float* rsrc[R_INSTR];
+    int rq[R_INSTR];
+#pragma clang loop unroll(full)
+    for (int i = 0; i < R_INSTR; ++i) {
+        const int Q = 64 * (wave * R_INSTR + i) + lane, srow = Q / QPR, qp = Q % QPR;
+        const int slot = srow < batch ? srow : batch - 1;  // unused slots re-read the last trajectory (never stored)
+        rq[i] = 4 * (qp ^ (srow & 15));
+        rsrc[i] = P.src_cur + (int64_t)slot * P.ldsrc + rq[i];
+    }
+
+    auto issue = [&](int tile, int slot) {
+        float* stage = lds16 + slot * STAGE;
+        float* myW = stage + wave * (16 * TC);
+        float* myR = stage + ROWS * TC + wave * (R_INSTR * 256);
+        const int c0 = tile * TC;
+        if (ragged && tile == tiles - 1) {
+#pragma clang loop unroll(full)
+            for (int i = 0; i < W_INSTR; ++i) {
+                const rp_f4 w = c0 + wq[i] < P.n ? rp_ld4_stream(wsrc[i] + c0) : rp_f4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<rp_f4*>(myW + 256 * i + 4 * lane) = w;
+            }
+#pragma clang loop unroll(full)
+            for (int i = 0; i < R_INSTR; ++i) {
+                const rp_f4 r = c0 + rq[i] < P.n ? rp_ld4(rsrc[i] + c0) : rp_f4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<rp_f4*>(myR + 256 * i + 4 * lane) = r;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the raw barrier below does not wait for LDS stores
+            return;
+        }
+#pragma clang loop unroll(full)
+        for (int i = 0; i < W_INSTR; ++i)
+            __builtin_amdgcn_global_load_lds((rp_gptr)(wsrc[i] + c0), (rp_lptr)(myW + 256 * i), 16, 0, 2 /* nt */);
+#pragma clang loop unroll(full)
+        for (int i = 0; i < R_INSTR; ++i)
+            __builtin_amdgcn_global_load_lds((rp_gptr)(rsrc[i] + c0), (rp_lptr)(myR + 256 * i), 16, 0, 0);
+    };
+
+    f32x4 acc[NB];
+#pragma clang loop unroll(full)
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, kq = lane >> 4;
+
+    int next = 0;  // position in the tile sequence of the next tile to issue
+    int tile_issue = t0, slot_issue = 0;
+    for (; next < S - 1 && next < tiles; ++next) {
+        issue(tile_issue, slot_issue);
+        tile_issue = tile_issue + 1 == tiles ? 0 : tile_issue + 1;
+        slot_issue = slot_issue + 1 == S ? 0 : slot_issue + 1;
+    }
+    int tile = t0, slot = 0;
+    for (int i = 0; i < tiles; ++i) {
+        // tile i has landed once at most the DMAs of the tiles issued after it are outstanding
+        const int later = next - 1 - i;  // 0 .. S-2
+        if (later >= 2) wait_vmcnt<(S >= 4 ? 2 * DPT : 0)>();
+        else if (later == 1) wait_vmcnt<(S >= 3 ? DPT : 0)>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (next < tiles) {
+            issue(tile_issue, slot_issue);
+            tile_issue = tile_issue + 1 == tiles ? 0 : tile_issue + 1;
+            slot_issue = slot_issue + 1 == S ? 0 : slot_issue + 1;
+            ++next;
+        }
+        const float* stage = lds16 + slot * STAGE;
+        const float* ap = stage + wave * (16 * TC) + r * TC;
+        const float* bp = stage + ROWS * TC + r * TC;
+        const int groups_here = (P.n - tile * TC + 15) >> 4;  // 16-column groups of this tile that start below n
+        if (groups_here >= TC / 16) {
+#pragma clang loop unroll(full)
+            for (int j = 0; j < TC / 16; ++j) {
+                const int off = 4 * ((4 * j + kq) ^ r);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ap + off);
+                f32x4 b[NB];
+#pragma clang loop unroll(full)
+                for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const f32x4*>(bp + nb * 16 * TC + off);
+#pragma clang loop unroll(full)
+                for (int c = 0; c < 4; ++c)
+#pragma clang loop unroll(full)
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[nb][c], acc[nb], 0, 0, 0);
+            }
+        } else {
+            for (int j = 0; j < groups_here; ++j) {
+                const int off = 4 * ((4 * j + kq) ^ r);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(ap + off);
+#pragma clang loop unroll(full)
+                for (int nb = 0; nb < NB; ++nb) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(bp + nb * 16 * TC + off);
+#pragma clang loop unroll(full)
+                    for (int c = 0; c < 4; ++c) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], acc[nb], 0, 0, 0);
+                }
+            }
+        }
+        tile = tile + 1 == tiles ? 0 : tile + 1;
+        slot = slot + 1 == S ? 0 : slot + 1;
+    }
+
+    // C/D layout of the 16x16 MFMA: slot = lane & 15, row = 4 * (lane >> 4) + reg
+    const int i0 = row_blk + 16 * wave + 4 * kq;
+#pragma clang loop unroll(full)
+    for (int nb = 0; nb < NB; ++nb) {
+        const int b = 16 * nb + r;
+        if (b >= batch) continue;
+#pragma clang loop unroll(full)
+        for (int e = 0; e < 4; ++e)
+            if (i0 + e < P.rows) epilogue<MODEL>(P, i0 + e, b, acc[nb][e]);
+    }
+}
+
+template <int MODEL, int NB, int TC, int S, int WAVES>
+int launch_mfma16(const BatchParams& P, int B, hipStream_t st) {
+    constexpr size_t lds = sizeof(float) * S * (16 * WAVES * TC + 16 * NB * TC);
+    if constexpr (lds > 160 * 1024) {
+        return RP_ERR_SHAPE;  // this instance does not fit the 160 KiB of LDS
+    } else {
+        if (rp_allow_dynamic_lds<&step_batched_mfma16_kernel<MODEL, NB, TC, S, WAVES>>(lds) != RP_OK) {
+            (void)hipGetLastError();
+            return RP_ERR_HIP;
+        }
+        const int blocks = (P.rows + 16 * WAVES - 1) / (16 * WAVES);
+        hipLaunchKernelGGL((step_batched_mfma16_kernel<MODEL, NB, TC, S, WAVES>), dim3(blocks), dim3(64 * WAVES), lds, st, P, B);
+        return RP_OK;
+    }
+}
+
+// benchmark-only override (rp_set_batched_mfma_tuning): tile columns, ring stages, waves per workgroup
+std::atomic<int> g_m16_tc{0}, g_m16_stages{0}, g_m16_waves{0};
+
+template <int MODEL, int NB>
+int launch_mfma16_cfg(const BatchParams& P, int B, hipStream_t st) {
+    // defaults measured at N = 32768 (scripts/sweep_mfma16.py, r03)
+    int tc = 64, stages = 2, waves = 4;
+    if (g_m16_tc > 0) tc = g_m16_tc;
+    if (g_m16_stages > 0) stages = g_m16_stages;
+    if (g_m16_waves > 0) waves = g_m16_waves;
+    switch (waves * 10000 + tc * 10 + stages) {
+        case 40642: return launch_mfma16<MODEL, NB, 64, 2, 4>(P, B, st);
+        case 40643: return launch_mfma16<MODEL, NB, 64, 3, 4>(P, B, st);
+        case 40644: return launch_mfma16<MODEL, NB, 64, 4, 4>(P, B, st);
+        case 41282: return launch_mfma16<MODEL, NB, 128, 2, 4>(P, B, st);
+        case 41283: return launch_mfma16<MODEL, NB, 128, 3, 4>(P, B, st);
+        case 42562: return launch_mfma16<MODEL, NB, 256, 2, 4>(P, B, st);
+        default: break;
+    }
+    if constexpr (NB == 2) {  // eight waves share one source tile: every wave brings one 1 KiB piece of it per 64 columns
+        switch (waves * 10000 + tc * 10 + stages) {
+            case 80642: return launch_mfma16<MODEL, NB, 64, 2, 8>(P, B, st);
+            case 80643: return launch_mfma16<MODEL, NB, 64, 3, 8>(P, B, st);
+            case 81282: return launch_mfma16<MODEL, NB, 128, 2, 8>(P, B, st);
+            default: break;
+        }
+    }
+    return RP_ERR_ARG;
+}
+
 template <int MODEL>
 int launch_model(const BatchParams& P, int B, hipStream_t st) {
     // R * B accumulator sets of four floats per lane; W chunks in flight per wave: R * U KiB
@@ -335,6 +549,13 @@ int rp_set_batched_grid(int max_workgroups) {
     return RP_OK;
 }
 
+int rp_set_batched_mfma_tuning(int tile_columns, int stages, int waves) {
+    g_m16_tc = tile_columns;
+    g_m16_stages = stages;
+    g_m16_waves = waves;
+    return RP_OK;
+}
+
 int rp_set_batched_tuning(int rows_per_wave, int unroll) {
     g_bt_R = rows_per_wave;
     g_bt_U = unroll;
@@ -347,9 +568,12 @@ int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
         RP_FAIL(RP_ERR_ARG, "rp_forward_batched covers the rate models (LI_TANH, LI_SIGMOID), got model %d", net->model);
     const int B = bt->batch;
     const bool mfma = bt->layout == RP_BATCH_MFMA;
-    if (bt->layout != RP_BATCH_VALU && !mfma) RP_FAIL(RP_ERR_ARG, "unknown batch layout %d", bt->layout);
-    if (mfma && (B < 1 || B > RP_BATCH_SLOTS)) RP_FAIL(RP_ERR_ARG, "the matrix-core form holds 1..%d trajectories, got %d", RP_BATCH_SLOTS, B);
-    if (!mfma && B != 2 && B != 4 && B != 8 && B != 16) RP_FAIL(RP_ERR_ARG, "batch must be 2, 4, 8 or 16, got %d", B);
+    const bool mfma16 = bt->layout == RP_BATCH_MFMA16;
+    if (bt->layout != RP_BATCH_VALU && !mfma && !mfma16) RP_FAIL(RP_ERR_ARG, "unknown batch layout %d", bt->layout);
+    if ((mfma || mfma16) && (B < 1 || B > RP_BATCH_SLOTS))
+        RP_FAIL(RP_ERR_ARG, "the matrix-core forms hold 1..%d trajectories, got %d", RP_BATCH_SLOTS, B);
+    if (!mfma && !mfma16 && B != 2 && B != 4 && B != 8 && B != 16) RP_FAIL(RP_ERR_ARG, "batch must be 2, 4, 8 or 16, got %d", B);
+    if (mfma16 && net->row0 % 128 != 0) RP_FAIL(RP_ERR_ARG, "row0=%d must be a multiple of 128 for the 16x16x4 matrix-core form", net->row0);
     if (net->n <= 0 || net->rows <= 0 || net->row0 < 0 || net->row0 + net->rows > net->n)
         RP_FAIL(RP_ERR_SHAPE, "bad shard geometry n=%d rows=%d row0=%d", net->n, net->rows, net->row0);
     if (net->row0 % 8 != 0) RP_FAIL(RP_ERR_ARG, "row0=%d must be a multiple of 8", net->row0);
@@ -398,7 +622,15 @@ int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
         P.src_next = bt->src[bt->cur ^ 1];
         P.x_t = bt->x ? bt->x + (int64_t)t * B * bt->ldx : nullptr;
         P.traj_t = bt->traj ? bt->traj + (int64_t)t * B * bt->ldtraj : nullptr;
-        if (mfma) {
+        if (mfma16) {
+            int rc;
+            if (net->model == RP_MODEL_LI_TANH)
+                rc = B <= 16 ? launch_mfma16_cfg<RP_MODEL_LI_TANH, 1>(P, B, st) : launch_mfma16_cfg<RP_MODEL_LI_TANH, 2>(P, B, st);
+            else
+                rc = B <= 16 ? launch_mfma16_cfg<RP_MODEL_LI_SIGMOID, 1>(P, B, st)
+                             : launch_mfma16_cfg<RP_MODEL_LI_SIGMOID, 2>(P, B, st);
+            if (rc != RP_OK) RP_FAIL(rc, "no 16x16x4 batched kernel for this configuration (batch %d)", B);
+        } else if (mfma) {
             const int blocks = (net->rows + kRows - 1) / kRows;
             if (net->model == RP_MODEL_LI_TANH)
                 hipLaunchKernelGGL(step_batched_mfma_kernel<RP_MODEL_LI_TANH>, dim3(blocks), dim3(kThreads), 0, st, P, B);

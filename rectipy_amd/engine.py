@@ -611,31 +611,45 @@ class BatchedPopulation:
     inputs) advanced together: every Euler step streams W once for all of them (``rp_forward_batched``).  The reference
     has no batch axis -- B trials of a network are B passes of its time loop, each streaming W again.
 
-    Two forms.  B in {2, 4, 8}: vector ALUs, state batch-major ([B, n]); trajectory b is BIT-IDENTICAL to an unbatched
+    B in {2, 4, 8}: vector ALUs, state batch-major ([B, n]); trajectory b is BIT-IDENTICAL to an unbatched
     :class:`Population` run on the same state.  9 <= B <= 32 (or ``mfma=True``): the contraction runs on the matrix cores
-    (exact-fp32 MFMA) with up to 32 trajectories per pass over W; state neuron-major ([n, 32] internally); equal to the
-    unbatched run up to fp32 rounding (its own summation order, mirrored by the oracle).  ``v`` / ``source`` are
-    [B, rows] / [B, n] views in both forms.  Rate models, n % 4 == 0.
+    (exact-fp32 MFMA) with up to 32 trajectories per pass over W; equal to the unbatched run up to fp32 rounding (its own
+    summation order, mirrored by the oracle).  Two matrix-core forms: "mfma16" (v_mfma_f32_16x16x4_f32, W and source
+    tiles by LDS-DMA, batch-major state) and the r02 form "mfma32" (v_mfma_f32_32x32x2_f32, neuron-major [n, 32] state).
+    ``v`` / ``source`` are [B, rows] / [B, n] views in every form.  Rate models, n % 4 == 0.
     """
 
     BATCHES = (2, 4, 8, 16)   # vector-ALU form
     SLOTS = _abi.RP_BATCH_SLOTS
+    FORMS = {"valu": _abi.RP_BATCH_VALU, "mfma32": _abi.RP_BATCH_MFMA, "mfma16": _abi.RP_BATCH_MFMA16}
+    DEFAULT_MFMA = "mfma16"   # which matrix-core form `mfma=True` / batch > 8 selects
 
-    def __init__(self, pop: Population, batch: int, v0=None, mfma: Optional[bool] = None):
+    def __init__(self, pop: Population, batch: int, v0=None, mfma: Optional[bool] = None, form: Optional[str] = None):
+        """``form``: "valu" | "mfma16" (v_mfma_f32_16x16x4_f32, LDS-DMA ring, batch-major state) | "mfma32" (the r02
+        v_mfma_f32_32x32x2_f32 form, neuron-major state); default: "valu" up to 8 trajectories, else ``DEFAULT_MFMA``
+        (``mfma=True`` asks for the matrix cores at any batch)."""
         if pop.spiking:
             raise NotImplementedError("batched trajectories cover the rate models (li_tanh, li_sigmoid)")
         if pop.n % 4 or pop.W.stride(0) % 4:
             raise ValueError("batched trajectories need n % 4 == 0")
-        self.mfma = (batch > 8) if mfma is None else bool(mfma)
+        if form is None:
+            use_mfma = (batch > 8) if mfma is None else bool(mfma)
+            form = self.DEFAULT_MFMA if use_mfma else "valu"
+        if form not in self.FORMS:
+            raise ValueError(f"form must be one of {sorted(self.FORMS)}, got {form!r}")
+        self.form = form
+        self.mfma = form != "valu"
+        self.neuron_major = form == "mfma32"
         if self.mfma and not 1 <= batch <= self.SLOTS:
-            raise ValueError(f"the matrix-core form holds 1..{self.SLOTS} trajectories, got {batch}")
+            raise ValueError(f"the matrix-core forms hold 1..{self.SLOTS} trajectories, got {batch}")
         if not self.mfma and batch not in self.BATCHES:
             raise ValueError(f"batch must be one of {self.BATCHES} (vector-ALU form) or <= {self.SLOTS} (mfma=True), got {batch}")
-        if self.mfma and pop.row0 % 32:
-            raise ValueError("the matrix-core form needs a shard offset that is a multiple of 32")
+        align = {"mfma32": 32, "mfma16": 128}.get(form, 8)
+        if pop.row0 % align:
+            raise ValueError(f"the '{form}' form needs a shard offset that is a multiple of {align}")
         self.pop, self.batch = pop, int(batch)
         f32 = dict(dtype=torch.float32, device=pop.device)
-        if self.mfma:
+        if self.neuron_major:
             self._v = torch.zeros(pop.rows, self.SLOTS, **f32)
             self._src = [torch.zeros(pop.n, self.SLOTS, **f32), torch.zeros(pop.n, self.SLOTS, **f32)]
         else:
@@ -649,13 +663,13 @@ class BatchedPopulation:
     @property
     def v(self) -> torch.Tensor:
         """States [B, rows] (a view: writes go to the device state; call :meth:`refresh` afterwards)."""
-        return self._v.t()[:self.batch] if self.mfma else self._v
+        return self._v.t()[:self.batch] if self.neuron_major else self._v
 
     @property
     def source(self) -> torch.Tensor:
         """Current source vectors r_b = act(v_b), [B, n] (view)."""
         s = self._src[self.cur]
-        return s.t()[:self.batch] if self.mfma else s
+        return s.t()[:self.batch] if self.neuron_major else s
 
     def refresh(self):
         """r_b = act(v_b) after the states were set from the host (through the unbatched refresh kernel, row by row)."""
@@ -680,7 +694,7 @@ class BatchedPopulation:
         pop, B = self.pop, self.batch
         bt = _abi.RpBatch()
         bt.batch, bt.steps = B, int(steps)
-        bt.layout = _abi.RP_BATCH_MFMA if self.mfma else _abi.RP_BATCH_VALU
+        bt.layout = self.FORMS[self.form]
         bt.v, bt.ldv = self._v.data_ptr(), self._v.stride(0)
         bt.src[0], bt.src[1], bt.ldsrc = self._src[0].data_ptr(), self._src[1].data_ptr(), self._src[0].stride(0)
         bt.cur = self.cur

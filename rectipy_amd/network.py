@@ -436,7 +436,9 @@ class Network:
                 acc = per_step[:, begin].clone()
                 for u in range(begin + 1, t + 1):
                     acc += per_step[:, u]
-                sampled[:, j] = acc / float(t + 1 - begin)
+                # true division as in the kernel (`acc / count`): a python-scalar divisor would become a multiplication by
+                # the rounded reciprocal on the GPU, which differs in the last bit for counts like 3
+                sampled[:, j] = torch.div(acc, torch.full((), float(t + 1 - begin), dtype=torch.float32, device=acc.device))
                 begin = t + 1
             # read out per trajectory: the same [S, N] product `run` computes (a [B*S, N] product may round differently)
             out = sampled if not post else torch.stack([self._apply_chain(post, sampled[b], label, None) for b in range(B)])

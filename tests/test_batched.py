@@ -132,10 +132,12 @@ def test_network_run_batch_equals_separate_runs(target):
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("form", ["mfma16", "mfma32"])
 @pytest.mark.parametrize("model,n,B,xw", [("li_tanh", 64, 32, "full"), ("li_tanh", 260, 20, "bcast"), ("li_sigmoid", 516, 9, "full"),
-                                         ("li_tanh", 1036, 32, "none"), ("li_tanh", 2048, 16, "full")])
-def test_matrix_core_form_matches_unbatched_runs(target, model, n, B, xw):
-    """Matrix-core form (up to 32 trajectories per pass over W, its own summation order): every trajectory equals an
+                                         ("li_tanh", 1036, 32, "none"), ("li_tanh", 2048, 16, "full"),
+                                         ("li_tanh", 40, 3, "full"), ("li_tanh", 1300, 1, "bcast")])
+def test_matrix_core_form_matches_unbatched_runs(target, form, model, n, B, xw):
+    """Matrix-core forms (up to 32 trajectories per pass over W, their own summation orders): every trajectory equals an
     unbatched run up to fp32 rounding -- 2e-5 absolute on O(1) trajectories of 25 steps."""
     dev, backend = target["device"], target["backend"]
     W, params = network(n, model, seed=n + B)
@@ -144,14 +146,16 @@ def test_matrix_core_form_matches_unbatched_runs(target, model, n, B, xw):
     v0 = torch.randn(B, n, generator=g)
     x = {"full": torch.randn(T, B, n, generator=g) * 0.5, "bcast": torch.randn(T, B, 1, generator=g), "none": None}[xw]
     pop = Population(model, W, params, 1e-2, dev, backend=backend)
-    bp = BatchedPopulation(pop, B)
-    assert bp.mfma
+    bp = BatchedPopulation(pop, B, form=form)
+    assert bp.mfma and bp.form == form
+    if form == BatchedPopulation.DEFAULT_MFMA and B > 8:
+        assert BatchedPopulation(pop, B).form == form
     bp.v.copy_(v0.to(dev))
     bp.refresh()
     traj = torch.zeros(T, B, n, device=dev)
     bp.forward(10, x=None if x is None else x[:10].to(dev), traj=traj[:10], out_var=_abi.RP_OUT_SOURCE)
     bp.forward(T - 10, x=None if x is None else x[10:].to(dev), traj=traj[10:], out_var=_abi.RP_OUT_SOURCE)
-    for b in (0, 1, B // 2, B - 1):
+    for b in sorted({0, min(1, B - 1), B // 2, B - 1}):
         single = Population(model, W, params, 1e-2, dev, backend=backend, v0=v0[b])
         tr = torch.zeros(T, n, device=dev)
         single.forward(T, x=None if x is None else x[:, b].to(dev), traj=tr, out_var=_abi.RP_OUT_SOURCE)
@@ -161,10 +165,12 @@ def test_matrix_core_form_matches_unbatched_runs(target, model, n, B, xw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,B,sigmoid", [(1036, 32, False), (640, 13, True), (2052, 32, False)])
-def test_matrix_core_form_hip_equals_oracle(oracle_backend, hip_device, n, B, sigmoid):
-    """The MFMA kernel against the oracle's mirror of its fmaf chain: bit for bit (ragged last tile, rows that are not a
-    multiple of the 128-row workgroup, unused slots)."""
+@pytest.mark.parametrize("form", ["mfma16", "mfma32"])
+@pytest.mark.parametrize("n,B,sigmoid", [(1036, 32, False), (640, 13, True), (2052, 32, False), (64, 16, False), (60, 5, False),
+                                         (1280, 17, False), (4100, 8, True)])
+def test_matrix_core_form_hip_equals_oracle(oracle_backend, hip_device, form, n, B, sigmoid):
+    """The MFMA kernels against the oracle's mirrors of their fmaf chains: bit for bit (ragged last tile, rows that are
+    not a multiple of the workgroup's row block, unused slots, a single tile, more tiles than ring stages)."""
     model = "li_sigmoid" if sigmoid else "li_tanh"
     W, params = network(n, model, seed=n)
     g = torch.Generator().manual_seed(9)
@@ -173,7 +179,7 @@ def test_matrix_core_form_hip_equals_oracle(oracle_backend, hip_device, n, B, si
     x = torch.randn(T, B, n, generator=g) * 0.5
     res = []
     for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
-        bp = BatchedPopulation(Population(model, W, params, 1e-2, dev, backend=backend), B, mfma=True)
+        bp = BatchedPopulation(Population(model, W, params, 1e-2, dev, backend=backend), B, form=form)
         bp.v.copy_(v0.to(dev))
         bp.refresh()
         traj = torch.zeros(T, B, n, device=dev)
@@ -182,3 +188,33 @@ def test_matrix_core_form_hip_equals_oracle(oracle_backend, hip_device, n, B, si
     for a, c, name in zip(res[0], res[1], ("traj", "v", "source")):
         same = (a.view(np.uint32) == c.view(np.uint32)) | ((a == 0) & (c == 0))
         assert same.all(), f"{name}: {np.count_nonzero(~same)} of {a.size} differ, max {np.abs(a - c).max()}"
+
+
+@pytest.mark.gpu
+def test_mfma16_tile_width_and_ring_depth_keep_the_bits(hip_device):
+    """The 16x16x4 form's summation order is defined on 16-column groups, not on the kernel's tile width or LDS ring
+    depth: every (tile columns, stages) instance gives the same bits (n with a ragged tail, both slot-block counts)."""
+    from rectipy_amd import _lib
+    lib = _lib.load()
+    n, T = 2308, 6
+    W, params = network(n, "li_tanh", seed=3)
+    g = torch.Generator().manual_seed(4)
+    try:
+        for B in (11, 27):
+            v0 = torch.randn(B, n, generator=g)
+            x = torch.randn(T, B, 1, generator=g)
+            outs = []
+            # (256-column tiles with two slot blocks need 192 KiB of LDS: that instance does not exist on this chip)
+            for tc, stages, waves in ((0, 0, 0), (64, 2, 4), (64, 3, 4), (64, 4, 4), (128, 2, 4), (128, 3, 4)) + \
+                    (((256, 2, 4),) if B <= 16 else ((64, 2, 8), (64, 3, 8), (128, 2, 8))):
+                lib.rp_set_batched_mfma_tuning(tc, stages, waves)
+                bp = BatchedPopulation(Population("li_tanh", W, params, 1e-2, hip_device), B, form="mfma16")
+                bp.v.copy_(v0.to(hip_device))
+                bp.refresh()
+                traj = torch.zeros(T, B, n, device=hip_device)
+                bp.forward(T, x=x.to(hip_device), traj=traj)
+                outs.append((traj.clone(), bp.v.clone()))
+            for tr, v in outs[1:]:
+                assert torch.equal(tr, outs[0][0]) and torch.equal(v, outs[0][1])
+    finally:
+        lib.rp_set_batched_mfma_tuning(0, 0, 0)
