@@ -12,6 +12,7 @@
 // rp_forward on the same state bit for bit (tests/test_batched.py).
 
 #include <atomic>
+#include <type_traits>
 
 #include "rp_common.h"
 #include "rp_dot.h"
@@ -290,9 +291,10 @@ __global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const Batch
 // source tile is loaded once per workgroup (each wave brings its share) and shared, each wave brings its own 16 x TC block
 // of W.  All
 // loads are LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, W non-temporal, no VGPR staging, no ds_write)
-// into a ring of S stages, with a counted s_waitcnt vmcnt + ONE raw s_barrier per tile:
-//     wait own DMAs of tile i -> barrier (everyone's landed; everyone is done reading tile i-1) -> issue tile i+S-1 into
-//     the stage tile i-1 used -> MFMAs of tile i.
+// into a ring of S stages, with a counted s_waitcnt vmcnt + ONE raw s_barrier per tile, software-pipelined:
+//     [fragments of tile i in registers] wait own DMAs of tile i+1 -> barrier (everyone's landed; everyone holds tile i's
+//     fragments, so its stage is free) -> between the MFMAs of tile i: LDS reads of tile i+1's fragments into the other
+//     register set and the DMA pieces of tile i+S into the freed stage.
 // LDS image: row-major rows of TC floats, the 16-byte quads of a row XOR-swizzled with (row & 15) -- applied on the DMA's
 // per-lane SOURCE address (the LDS side of a DMA is lane-linear) and on the read address: lane (r = l & 15, kq = l >> 4)
 // reads quad (4 j + kq) ^ r of row r for A and of slot-row r for B with ds_read_b128, conflict-free, and feeds component c
@@ -311,7 +313,8 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int MODEL, int NB, int TC, int S, int WAVES>
+// PROBE (measurement builds only, results meaningless): 1 = no MFMAs, 2 = no DMA in the steady state
+template <int MODEL, int NB, int TC, int S, int WAVES, int PROBE = 0>
 __global__ __launch_bounds__(64 * WAVES) void step_batched_mfma16_kernel(const BatchParams P, int batch) {
     extern __shared__ __attribute__((aligned(16))) float lds16[];
     constexpr int ROWS = 16 * WAVES;         // rows per workgroup (16 per wave)
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(64 * WAVES) void step_batched_mfma16_kernel(const B
     constexpr int DPT = W_INSTR + R_INSTR;   // DMA instructions per tile and wave
     constexpr int STAGE = ROWS * TC + 16 * NB * TC;  // floats per stage: the workgroup's rows of W, 16 NB slot-rows of the source
     static_assert((NB * TC) % (16 * WAVES) == 0, "every wave brings the same number of source pieces");
-    static_assert(DPT * (S - 2) < 64 && S >= 2 && S <= 4, "ring depth");
+    static_assert(DPT * (S - 1) < 64 && S >= 2 && S <= 4, "ring depth");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row_blk = blockIdx.x * ROWS;
@@ -351,12 +354,15 @@ __global__ __launch_bounds__(64 * WAVES) void step_batched_mfma16_kernel(const B
         rsrc[i] = P.src_cur + (int64_t)slot * P.ldsrc + rq[i];
     }
 
-    auto issue = [&](int tile, int slot) {
+    // One piece (k = 0 .. DPT-1: the wave's W pieces first, then its source pieces) of a tile's DMA; a ragged tile (columns
+    // >= n) goes through registers instead, zeros past n, all pieces at once with k == 0.
+    auto issue_piece = [&](int tile, int slot, int k) {
         float* stage = lds16 + slot * STAGE;
         float* myW = stage + wave * (16 * TC);
         float* myR = stage + ROWS * TC + wave * (R_INSTR * 256);
         const int c0 = tile * TC;
         if (ragged && tile == tiles - 1) {
+            if (k != 0) return;
 #pragma clang loop unroll(full)
             for (int i = 0; i < W_INSTR; ++i) {
                 const rp_f4 w = c0 + wq[i] < P.n ? rp_ld4_stream(wsrc[i] + c0) : rp_f4{0.f, 0.f, 0.f, 0.f};
@@ -364,79 +370,138 @@ __global__ __launch_bounds__(64 * WAVES) void step_batched_mfma16_kernel(const B
             }
 #pragma clang loop unroll(full)
             for (int i = 0; i < R_INSTR; ++i) {
-                const rp_f4 r = c0 + rq[i] < P.n ? rp_ld4(rsrc[i] + c0) : rp_f4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<rp_f4*>(myR + 256 * i + 4 * lane) = r;
+                const rp_f4 rr = c0 + rq[i] < P.n ? rp_ld4(rsrc[i] + c0) : rp_f4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<rp_f4*>(myR + 256 * i + 4 * lane) = rr;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the raw barrier below does not wait for LDS stores
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // a raw barrier does not wait for LDS stores
             return;
         }
 #pragma clang loop unroll(full)
         for (int i = 0; i < W_INSTR; ++i)
-            __builtin_amdgcn_global_load_lds((rp_gptr)(wsrc[i] + c0), (rp_lptr)(myW + 256 * i), 16, 0, 2 /* nt */);
+            if (i == k) __builtin_amdgcn_global_load_lds((rp_gptr)(wsrc[i] + c0), (rp_lptr)(myW + 256 * i), 16, 0, 2 /* nt */);
 #pragma clang loop unroll(full)
         for (int i = 0; i < R_INSTR; ++i)
-            __builtin_amdgcn_global_load_lds((rp_gptr)(rsrc[i] + c0), (rp_lptr)(myR + 256 * i), 16, 0, 0);
+            if (W_INSTR + i == k) __builtin_amdgcn_global_load_lds((rp_gptr)(rsrc[i] + c0), (rp_lptr)(myR + 256 * i), 16, 0, 0);
     };
 
+    constexpr int G = TC / 16;  // 16-column groups per tile
+    struct Frags {
+        f32x4 a[G], b[NB][G];
+    };
     f32x4 acc[NB];
 #pragma clang loop unroll(full)
     for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int r = lane & 15, kq = lane >> 4;
+    auto read_group = [&](Frags& f, int slot, int j) {
+        const float* stage = lds16 + slot * STAGE;
+        const int off = r * TC + 4 * ((4 * j + kq) ^ r);
+        f.a[j] = *reinterpret_cast<const f32x4*>(stage + wave * (16 * TC) + off);
+#pragma clang loop unroll(full)
+        for (int nb = 0; nb < NB; ++nb) f.b[nb][j] = *reinterpret_cast<const f32x4*>(stage + ROWS * TC + nb * 16 * TC + off);
+    };
 
-    int next = 0;  // position in the tile sequence of the next tile to issue
+    // Software pipeline over the tile sequence (position i, tile (t0 + i) mod tiles, stage i mod S).  At the top of
+    // iteration i the fragments of tile i are in registers; the iteration waits for tile i+1's DMAs, passes the barrier,
+    // and then issues, BETWEEN the MFMAs of tile i, the LDS reads of tile i+1's fragments (other register set) and the DMA
+    // pieces of tile i+S (into the stage tile i occupied): the matrix pipe never waits for an LDS read or a DMA issue.
+    int issued = 0;  // tiles issued so far (positions 0 .. issued-1)
     int tile_issue = t0, slot_issue = 0;
-    for (; next < S - 1 && next < tiles; ++next) {
-        issue(tile_issue, slot_issue);
+    for (; issued < S && issued < tiles; ++issued) {
+#pragma clang loop unroll(full)
+        for (int k = 0; k < DPT; ++k) issue_piece(tile_issue, slot_issue, k);
         tile_issue = tile_issue + 1 == tiles ? 0 : tile_issue + 1;
         slot_issue = slot_issue + 1 == S ? 0 : slot_issue + 1;
     }
-    int tile = t0, slot = 0;
-    for (int i = 0; i < tiles; ++i) {
-        // tile i has landed once at most the DMAs of the tiles issued after it are outstanding
-        const int later = next - 1 - i;  // 0 .. S-2
-        if (later >= 2) wait_vmcnt<(S >= 4 ? 2 * DPT : 0)>();
-        else if (later == 1) wait_vmcnt<(S >= 3 ? DPT : 0)>();
+    {   // tile 0 has landed once at most the tiles issued after it are outstanding
+        const int later = issued - 1;
+        if (later >= 3) wait_vmcnt<(S >= 4 ? 3 * DPT : 0)>();
+        else if (later == 2) wait_vmcnt<(S >= 3 ? 2 * DPT : 0)>();
+        else if (later == 1) wait_vmcnt<DPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (next < tiles) {
-            issue(tile_issue, slot_issue);
-            tile_issue = tile_issue + 1 == tiles ? 0 : tile_issue + 1;
-            slot_issue = slot_issue + 1 == S ? 0 : slot_issue + 1;
-            ++next;
+    }
+    Frags f0, f1;
+#pragma clang loop unroll(full)
+    for (int j = 0; j < G; ++j) read_group(f0, 0, j);
+
+    int tile = t0, slot = 0;  // tile and stage of position i
+    // FAST: the steady state -- a next tile exists, a tile is issued, neither this tile nor the issued one is the ragged
+    // one: no conditionals between the barrier and the last MFMA.
+    auto iteration = [&](auto fast_tag, int i, Frags& cur, Frags& nxt) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const bool more = FAST || i + 1 < tiles;
+        const int slot1 = slot + 1 == S ? 0 : slot + 1;
+        // this tile's fragments must be in registers before the barrier (its stage is overwritten after it): naming them
+        // as inputs makes the compiler wait for exactly their LDS reads here, and know below that they have arrived
+#pragma clang loop unroll(full)
+        for (int j = 0; j < G; ++j) {
+            asm volatile("" ::"v"(cur.a[j]));
+#pragma clang loop unroll(full)
+            for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(cur.b[nb][j]));
         }
-        const float* stage = lds16 + slot * STAGE;
-        const float* ap = stage + wave * (16 * TC) + r * TC;
-        const float* bp = stage + ROWS * TC + r * TC;
-        const int groups_here = (P.n - tile * TC + 15) >> 4;  // 16-column groups of this tile that start below n
-        if (groups_here >= TC / 16) {
+        if (more) {
+            const int later = issued - 2 - i;  // tiles issued after tile i+1: 0 .. S-2
+            if (FAST) wait_vmcnt<(S - 2) * (PROBE == 3 ? W_INSTR : DPT)>();
+            else if (later >= 2) wait_vmcnt<(S >= 4 ? 2 * DPT : 0)>();
+            else if (later == 1) wait_vmcnt<(S >= 3 ? DPT : 0)>();
+            else wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const bool issue_now = FAST || issued < tiles;
+        const int groups_here = FAST ? G : (P.n - tile * TC + 15) >> 4;  // 16-column groups of this tile that start below n
 #pragma clang loop unroll(full)
-            for (int j = 0; j < TC / 16; ++j) {
-                const int off = 4 * ((4 * j + kq) ^ r);
-                const f32x4 a = *reinterpret_cast<const f32x4*>(ap + off);
-                f32x4 b[NB];
+        for (int j = 0; j < G; ++j) {
+            if (more) read_group(nxt, slot1, j);
+            if (issue_now) {
 #pragma clang loop unroll(full)
-                for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const f32x4*>(bp + nb * 16 * TC + off);
+                for (int k = j; k < DPT; k += G) {
+                    if constexpr (FAST && PROBE == 2) {
+                    } else if constexpr (FAST) {
+                        float* stage = lds16 + slot * STAGE;
+                        const int c0 = tile_issue * TC;
+                        if (k < W_INSTR)
+                            __builtin_amdgcn_global_load_lds((rp_gptr)(wsrc[k < W_INSTR ? k : 0] + c0),
+                                                             (rp_lptr)(stage + wave * (16 * TC) + 256 * k), 16, 0, 2 /* nt */);
+                        else if (PROBE != 3)
+                            __builtin_amdgcn_global_load_lds(
+                                (rp_gptr)(rsrc[k >= W_INSTR ? k - W_INSTR : 0] + c0),
+                                (rp_lptr)(stage + ROWS * TC + wave * (R_INSTR * 256) + 256 * (k - W_INSTR)), 16, 0, 0);
+                    } else {
+                        issue_piece(tile_issue, slot, k);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (PROBE == 1 || PROBE == 3) {
+                asm volatile("" ::"v"(cur.a[j]));
+#pragma clang loop unroll(full)
+                for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(cur.b[nb][j]));
+            } else if (j < groups_here) {
 #pragma clang loop unroll(full)
                 for (int c = 0; c < 4; ++c)
 #pragma clang loop unroll(full)
                     for (int nb = 0; nb < NB; ++nb)
-                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[nb][c], acc[nb], 0, 0, 0);
+                        acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[j][c], cur.b[nb][j][c], acc[nb], 0, 0, 0);
             }
-        } else {
-            for (int j = 0; j < groups_here; ++j) {
-                const int off = 4 * ((4 * j + kq) ^ r);
-                const f32x4 a = *reinterpret_cast<const f32x4*>(ap + off);
-#pragma clang loop unroll(full)
-                for (int nb = 0; nb < NB; ++nb) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(bp + nb * 16 * TC + off);
-#pragma clang loop unroll(full)
-                    for (int c = 0; c < 4; ++c) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[c], acc[nb], 0, 0, 0);
-                }
-            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (issue_now) {
+            tile_issue = tile_issue + 1 == tiles ? 0 : tile_issue + 1;
+            ++issued;
         }
         tile = tile + 1 == tiles ? 0 : tile + 1;
-        slot = slot + 1 == S ? 0 : slot + 1;
+        slot = slot1;
+    };
+    auto step = [&](int i, Frags& cur, Frags& nxt) {
+        const bool fast = issued < tiles && !(ragged && (tile == tiles - 1 || tile_issue == tiles - 1));
+        if (fast) iteration(std::true_type{}, i, cur, nxt);
+        else iteration(std::false_type{}, i, cur, nxt);
+    };
+    for (int i = 0; i < tiles; i += 2) {
+        step(i, f0, f1);
+        if (i + 1 < tiles) step(i + 1, f1, f0);
     }
 
     // C/D layout of the 16x16 MFMA: slot = lane & 15, row = 4 * (lane >> 4) + reg
@@ -451,18 +516,233 @@ __global__ __launch_bounds__(64 * WAVES) void step_batched_mfma16_kernel(const B
     }
 }
 
-template <int MODEL, int NB, int TC, int S, int WAVES>
+// ---- the same contraction with the waves of a workgroup split into roles (17..32 trajectories) -------------------------
+// With two slot blocks the matrix pipe is as long a pole as the HBM stream (N = 32768: 0.58 ms of MFMAs, 0.62 ms of DMA),
+// and a wave that issues its own DMA pieces (60-180 cycles each, in order) stops feeding the pipe meanwhile.  Here a
+// 512-thread workgroup owns 128 rows: waves 0..3 only multiply (32 rows x 32 slots each: 2 x 2 accumulators, every A and
+// every B fragment feeds two MFMAs, 64 MFMAs per 64-column tile = all of the SIMD's matrix cycles), waves 4..7 -- their
+// SIMD partners -- only load (each a quarter of the 128 x TC block of W and of the 32 x TC source tile per tile).  Same
+// ring, same ONE barrier per tile, same LDS image, and the SAME summation order as step_batched_mfma16_kernel.
+template <int MODEL, int TC, int S, int PROBE = 0>
+__global__ __launch_bounds__(512) void step_batched_mfma16_split_kernel(const BatchParams P, int batch) {
+    extern __shared__ __attribute__((aligned(16))) float lds16[];
+    constexpr int ROWS = 128, NB = 2, RB = 2;
+    constexpr int QPR = TC / 4;
+    constexpr int G = TC / 16;
+    constexpr int W_PIECES = ROWS * TC / 256 / 4;     // 1 KiB DMA pieces of W per loader wave and tile
+    constexpr int R_PIECES = 16 * NB * TC / 256 / 4;  // ... of the source tile
+    constexpr int DPT = W_PIECES + R_PIECES;
+    constexpr int STAGE = ROWS * TC + 16 * NB * TC;
+    static_assert(DPT * (S - 1) < 64 && S >= 2 && S <= 4, "ring depth");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row_blk = blockIdx.x * ROWS;
+    const int tiles = (P.n + TC - 1) / TC;
+    const int supers = (P.n + 255) / 256;
+    const int t0 = (int)((3u * (unsigned)((P.row0 + row_blk) >> 7)) % (unsigned)supers) * (256 / TC);
+    const bool ragged = (P.n % TC) != 0;
+
+    // shared bookkeeping of the tile sequence (identical in both roles)
+    int issued = 0, tile_issue = t0, tile = t0, slot = 0;
+    auto advance_issue = [&]() {
+        tile_issue = tile_issue + 1 == tiles ? 0 : tile_issue + 1;
+        ++issued;
+    };
+    auto is_fast = [&]() { return issued < tiles && !(ragged && (tile == tiles - 1 || tile_issue == tiles - 1)); };
+
+    if (wave >= 4) {
+        // ---------------- loader ----------------
+        const int lw = wave - 4;
+        if (PROBE >= 10) __builtin_amdgcn_s_setprio(3);  // (measured: see DESIGN.md)
+        const float* src[DPT];  // per-lane source of piece k (W pieces first), without the tile's column offset
+        int quad[DPT];
+#pragma clang loop unroll(full)
+        for (int k = 0; k < W_PIECES; ++k) {
+            const int Q = 64 * (lw * W_PIECES + k) + lane, row = Q / QPR, qp = Q % QPR;
+            int grow = row_blk + row;
+            grow = grow < P.rows ? grow : P.rows - 1;
+            quad[k] = 4 * (qp ^ (row & 15));
+            src[k] = P.W + (int64_t)grow * P.ldw + quad[k];
+        }
+#pragma clang loop unroll(full)
+        for (int k = 0; k < R_PIECES; ++k) {
+            const int Q = 64 * (lw * R_PIECES + k) + lane, srow = Q / QPR, qp = Q % QPR;
+            const int sl = srow < batch ? srow : batch - 1;
+            quad[W_PIECES + k] = 4 * (qp ^ (srow & 15));
+            src[W_PIECES + k] = P.src_cur + (int64_t)sl * P.ldsrc + quad[W_PIECES + k];
+        }
+        auto piece_lds = [&](int st, int k) -> float* {
+            float* stage = lds16 + st * STAGE;
+            return k < W_PIECES ? stage + 256 * (lw * W_PIECES + k) : stage + ROWS * TC + 256 * (lw * R_PIECES + (k - W_PIECES));
+        };
+        auto issue_tile = [&](auto fast_tag, int tl, int st) {
+            const int c0 = tl * TC;
+            if (!decltype(fast_tag)::value && ragged && tl == tiles - 1) {
+#pragma clang loop unroll(full)
+                for (int k = 0; k < DPT; ++k) {
+                    rp_f4 w = rp_f4{0.f, 0.f, 0.f, 0.f};
+                    if (c0 + quad[k] < P.n) w = k < W_PIECES ? rp_ld4_stream(src[k] + c0) : rp_ld4(src[k] + c0);
+                    *reinterpret_cast<rp_f4*>(piece_lds(st, k) + 4 * lane) = w;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                return;
+            }
+#pragma clang loop unroll(full)
+            for (int k = 0; k < DPT; ++k) {
+                if (k < W_PIECES)
+                    __builtin_amdgcn_global_load_lds((rp_gptr)(src[k] + c0), (rp_lptr)piece_lds(st, k), 16, 0, 2 /* nt */);
+                else
+                    __builtin_amdgcn_global_load_lds((rp_gptr)(src[k] + c0), (rp_lptr)piece_lds(st, k), 16, 0, 0);
+            }
+        };
+        int slot_issue = 0;
+        for (; issued < S && issued < tiles; advance_issue()) {
+            issue_tile(std::false_type{}, tile_issue, slot_issue);
+            slot_issue = slot_issue + 1 == S ? 0 : slot_issue + 1;
+        }
+        {
+            const int later = issued - 1;
+            if (later >= 3) wait_vmcnt<(S >= 4 ? 3 * DPT : 0)>();
+            else if (later == 2) wait_vmcnt<(S >= 3 ? 2 * DPT : 0)>();
+            else if (later == 1) wait_vmcnt<DPT>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        }
+        for (int i = 0; i < tiles; ++i) {
+            const bool fast = is_fast();
+            if (fast) {
+                wait_vmcnt<(S - 2) * DPT>();  // tile i+1 has landed; the S-2 tiles issued after it may be in flight
+                __builtin_amdgcn_s_barrier();
+                if (PROBE != 2) issue_tile(std::true_type{}, tile_issue, slot);
+                advance_issue();
+            } else {
+                if (i + 1 < tiles) {
+                    const int later = issued - 2 - i;
+                    if (later >= 2) wait_vmcnt<(S >= 4 ? 2 * DPT : 0)>();
+                    else if (later == 1) wait_vmcnt<(S >= 3 ? DPT : 0)>();
+                    else wait_vmcnt<0>();
+                }
+                __builtin_amdgcn_s_barrier();
+                if (issued < tiles) {
+                    issue_tile(std::false_type{}, tile_issue, slot);
+                    advance_issue();
+                }
+            }
+            tile = tile + 1 == tiles ? 0 : tile + 1;
+            slot = slot + 1 == S ? 0 : slot + 1;
+        }
+        return;
+    }
+
+    // ---------------- multiplier ----------------
+    struct Frags {
+        f32x4 a[RB][G], b[NB][G];
+    };
+    f32x4 acc[RB][NB];
+#pragma clang loop unroll(full)
+    for (int rb = 0; rb < RB; ++rb)
+#pragma clang loop unroll(full)
+        for (int nb = 0; nb < NB; ++nb) acc[rb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r = lane & 15, kq = lane >> 4;
+    auto read_group = [&](Frags& f, int st, int j) {
+        const float* stage = lds16 + st * STAGE;
+        const int off = r * TC + 4 * ((4 * j + kq) ^ r);
+#pragma clang loop unroll(full)
+        for (int rb = 0; rb < RB; ++rb) f.a[rb][j] = *reinterpret_cast<const f32x4*>(stage + (32 * wave + 16 * rb) * TC + off);
+#pragma clang loop unroll(full)
+        for (int nb = 0; nb < NB; ++nb) f.b[nb][j] = *reinterpret_cast<const f32x4*>(stage + ROWS * TC + nb * 16 * TC + off);
+    };
+    for (; issued < S && issued < tiles;) advance_issue();  // (mirror of the loaders' prologue)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    Frags f0, f1;
+#pragma clang loop unroll(full)
+    for (int j = 0; j < G; ++j) read_group(f0, 0, j);
+
+    auto iteration = [&](auto fast_tag, int i, Frags& cur, Frags& nxt) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        const bool more = FAST || i + 1 < tiles;
+        const int slot1 = slot + 1 == S ? 0 : slot + 1;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < G; ++j) {  // this tile's fragments have arrived (their stage is overwritten after the barrier)
+#pragma clang loop unroll(full)
+            for (int rb = 0; rb < RB; ++rb) asm volatile("" ::"v"(cur.a[rb][j]));
+#pragma clang loop unroll(full)
+            for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(cur.b[nb][j]));
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int groups_here = FAST ? G : (P.n - tile * TC + 15) >> 4;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < G; ++j) {
+            if (more) read_group(nxt, slot1, j);
+            __builtin_amdgcn_sched_barrier(0);
+            if (PROBE == 1) {
+#pragma clang loop unroll(full)
+                for (int rb = 0; rb < RB; ++rb) asm volatile("" ::"v"(cur.a[rb][j]));
+#pragma clang loop unroll(full)
+                for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(cur.b[nb][j]));
+            } else if (j < groups_here) {
+#pragma clang loop unroll(full)
+                for (int c = 0; c < 4; ++c)
+#pragma clang loop unroll(full)
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma clang loop unroll(full)
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[rb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.a[rb][j][c], cur.b[nb][j][c], acc[rb][nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (FAST || issued < tiles) advance_issue();
+        tile = tile + 1 == tiles ? 0 : tile + 1;
+        slot = slot1;
+    };
+    auto step = [&](int i, Frags& cur, Frags& nxt) {
+        if (is_fast()) iteration(std::true_type{}, i, cur, nxt);
+        else iteration(std::false_type{}, i, cur, nxt);
+    };
+    for (int i = 0; i < tiles; i += 2) {
+        step(i, f0, f1);
+        if (i + 1 < tiles) step(i + 1, f1, f0);
+    }
+#pragma clang loop unroll(full)
+    for (int rb = 0; rb < RB; ++rb)
+#pragma clang loop unroll(full)
+        for (int nb = 0; nb < NB; ++nb) {
+            const int b = 16 * nb + r;
+            if (b >= batch) continue;
+            const int i0 = row_blk + 32 * wave + 16 * rb + 4 * kq;
+#pragma clang loop unroll(full)
+            for (int e = 0; e < 4; ++e)
+                if (i0 + e < P.rows) epilogue<MODEL>(P, i0 + e, b, acc[rb][nb][e]);
+        }
+}
+
+template <int MODEL, int TC, int S, int PROBE = 0>
+int launch_mfma16_split(const BatchParams& P, int B, hipStream_t st) {
+    constexpr size_t lds = sizeof(float) * S * (128 * TC + 32 * TC);
+    static_assert(lds <= 160 * 1024, "LDS");
+    if (rp_allow_dynamic_lds<&step_batched_mfma16_split_kernel<MODEL, TC, S, PROBE>>(lds) != RP_OK) {
+        (void)hipGetLastError();
+        return RP_ERR_HIP;
+    }
+    const int blocks = (P.rows + 127) / 128;
+    hipLaunchKernelGGL((step_batched_mfma16_split_kernel<MODEL, TC, S, PROBE>), dim3(blocks), dim3(512), lds, st, P, B);
+    return RP_OK;
+}
+
+template <int MODEL, int NB, int TC, int S, int WAVES, int PROBE = 0>
 int launch_mfma16(const BatchParams& P, int B, hipStream_t st) {
     constexpr size_t lds = sizeof(float) * S * (16 * WAVES * TC + 16 * NB * TC);
     if constexpr (lds > 160 * 1024) {
         return RP_ERR_SHAPE;  // this instance does not fit the 160 KiB of LDS
     } else {
-        if (rp_allow_dynamic_lds<&step_batched_mfma16_kernel<MODEL, NB, TC, S, WAVES>>(lds) != RP_OK) {
+        if (rp_allow_dynamic_lds<&step_batched_mfma16_kernel<MODEL, NB, TC, S, WAVES, PROBE>>(lds) != RP_OK) {
             (void)hipGetLastError();
             return RP_ERR_HIP;
         }
         const int blocks = (P.rows + 16 * WAVES - 1) / (16 * WAVES);
-        hipLaunchKernelGGL((step_batched_mfma16_kernel<MODEL, NB, TC, S, WAVES>), dim3(blocks), dim3(64 * WAVES), lds, st, P, B);
+        hipLaunchKernelGGL((step_batched_mfma16_kernel<MODEL, NB, TC, S, WAVES, PROBE>), dim3(blocks), dim3(64 * WAVES), lds, st, P, B);
         return RP_OK;
     }
 }
@@ -485,6 +765,35 @@ int launch_mfma16_cfg(const BatchParams& P, int B, hipStream_t st) {
         case 41283: return launch_mfma16<MODEL, NB, 128, 3, 4>(P, B, st);
         case 42562: return launch_mfma16<MODEL, NB, 256, 2, 4>(P, B, st);
         default: break;
+    }
+    if constexpr (NB == 2 && MODEL == RP_MODEL_LI_TANH) {  // measurement builds: halves of the kernel switched off
+        switch (waves * 10000 + tc * 10 + stages) {
+            case 140643: return launch_mfma16<MODEL, NB, 64, 3, 4, 1>(P, B, st);
+            case 240643: return launch_mfma16<MODEL, NB, 64, 3, 4, 2>(P, B, st);
+            case 180643: return launch_mfma16<MODEL, NB, 64, 3, 8, 1>(P, B, st);
+            case 280643: return launch_mfma16<MODEL, NB, 64, 3, 8, 2>(P, B, st);
+            case 340643: return launch_mfma16<MODEL, NB, 64, 3, 4, 3>(P, B, st);
+            case 380643: return launch_mfma16<MODEL, NB, 64, 3, 8, 3>(P, B, st);
+            default: break;
+        }
+    }
+    if constexpr (NB == 2) {  // waves = 16: the role-split kernel (4 multiplier + 4 loader waves, 128 rows)
+        switch (waves * 10000 + tc * 10 + stages) {
+            case 160643: return launch_mfma16_split<MODEL, 64, 3>(P, B, st);
+            case 160644: return launch_mfma16_split<MODEL, 64, 4>(P, B, st);
+            case 160642: return launch_mfma16_split<MODEL, 64, 2>(P, B, st);
+            default: break;
+        }
+        if constexpr (MODEL == RP_MODEL_LI_TANH) {
+            switch (waves * 10000 + tc * 10 + stages) {  // measurement builds
+                case 1160643: return launch_mfma16_split<MODEL, 64, 3, 1>(P, B, st);
+                case 2160643: return launch_mfma16_split<MODEL, 64, 3, 2>(P, B, st);
+                case 1160644: return launch_mfma16_split<MODEL, 64, 4, 1>(P, B, st);
+                case 2160644: return launch_mfma16_split<MODEL, 64, 4, 2>(P, B, st);
+                case 10160643: return launch_mfma16_split<MODEL, 64, 3, 10>(P, B, st);
+                default: break;
+            }
+        }
     }
     if constexpr (NB == 2) {  // eight waves share one source tile: every wave brings one 1 KiB piece of it per 64 columns
         switch (waves * 10000 + tc * 10 + stages) {

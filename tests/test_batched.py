@@ -206,7 +206,7 @@ def test_mfma16_tile_width_and_ring_depth_keep_the_bits(hip_device):
             outs = []
             # (256-column tiles with two slot blocks need 192 KiB of LDS: that instance does not exist on this chip)
             for tc, stages, waves in ((0, 0, 0), (64, 2, 4), (64, 3, 4), (64, 4, 4), (128, 2, 4), (128, 3, 4)) + \
-                    (((256, 2, 4),) if B <= 16 else ((64, 2, 8), (64, 3, 8), (128, 2, 8))):
+                    (((256, 2, 4),) if B <= 16 else ((64, 2, 8), (64, 3, 8), (128, 2, 8), (64, 2, 16), (64, 3, 16), (64, 4, 16))):
                 lib.rp_set_batched_mfma_tuning(tc, stages, waves)
                 bp = BatchedPopulation(Population("li_tanh", W, params, 1e-2, hip_device), B, form="mfma16")
                 bp.v.copy_(v0.to(hip_device))
