@@ -570,15 +570,19 @@ def cpu_fwd_bwd(pop, x, dt, N, threads, T=20):
 def batched_extra(pop, N, dev, ms_single, T=200):
     """B independent trajectories of the same network in one pass over W per step (rp_forward_batched; the "batched-input
     dense W @ state contraction" of the brief -- the reference has no batch axis and would run them one after the other).
-    Every trajectory is bit-identical to an unbatched run (tests/test_batched.py)."""
+    Up to 8 trajectories on the vector ALUs are bit-identical to unbatched runs; the matrix-core forms have their own
+    summation order, mirrored bit for bit by the oracle (tests/test_batched.py)."""
     from rectipy_amd.engine import BatchedPopulation
     if N % 4:
         return {"skipped": "n % 4 != 0"}
     res = {"workload": f"tanh rate RNN N={N}, B trajectories per pass over W, {T} timed steps each, broadcast input",
            "unit": "trajectory-steps/s"}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for B in (2, 4, 8, 16, 32):  # 2..8: vector ALUs (bit-identical to unbatched runs); 16, 32: exact-fp32 MFMA
-        bp = BatchedPopulation(pop, B)
+    # 2..8: vector ALUs (bit-identical to unbatched runs); ("mfma", 8), 16, 32: exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32,
+    # W and source tiles by LDS-DMA; 17..32 trajectories: role-split workgroups).  Binding roof of a step: the slower of W
+    # once from HBM (4 N^2 B / 8 TB/s) and the contraction on the fp32 matrix cores (2 N^2 B flop / 157.3 TFLOP/s).
+    for B, mfma in ((2, False), (4, False), (8, False), (8, True), (16, True), (32, True)):
+        bp = BatchedPopulation(pop, B, mfma=mfma)
         bp.v.normal_(generator=torch.Generator(device=dev).manual_seed(B))
         bp.refresh()
         xb = torch.randn(T + 10, B, 1, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + B))
@@ -589,10 +593,15 @@ def batched_extra(pop, N, dev, ms_single, T=200):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / T
-        res[f"B{B}"] = {"form": "mfma_f32_32x32x2" if bp.mfma else "valu", "trajectory_steps_per_s": B * 1e3 / ms, "ms_per_step": ms,
-                        "vs_unbatched": B * ms_single / ms, "W_stream_GBps": 4.0 * N * N / (ms * 1e-3) / 1e9,
-                        "fma_TFLOPs": 2.0 * N * N * B / (ms * 1e-3) / 1e12,
-                        "state_finite": bool(torch.isfinite(bp.v).all().item())}
+        roof_ms = max(4.0 * N * N / (HBM_PEAK_GBPS * 1e9), 2.0 * N * N * B / 157.3e12) * 1e3
+        forms = {"valu": "valu", "mfma16": "mfma_f32_16x16x4 + LDS-DMA ring", "mfma32": "mfma_f32_32x32x2"}
+        res[f"B{B}" + ("_mfma" if mfma and B <= 8 else "")] = {
+            "form": forms[bp.form], "trajectory_steps_per_s": B * 1e3 / ms, "ms_per_step": ms,
+            "vs_unbatched": B * ms_single / ms, "W_stream_GBps": 4.0 * N * N / (ms * 1e-3) / 1e9,
+            "fma_TFLOPs": 2.0 * N * N * B / (ms * 1e-3) / 1e12,
+            "roof": {"bound": "hbm" if 4.0 * N * N / (HBM_PEAK_GBPS * 1e9) >= 2.0 * N * N * B / 157.3e12 else "mfma",
+                     "ms_at_roof": roof_ms, "frac": roof_ms / ms},
+            "state_finite": bool(torch.isfinite(bp.v).all().item())}
         del bp, xb
     torch.cuda.empty_cache()
     return res

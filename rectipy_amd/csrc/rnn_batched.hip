@@ -539,7 +539,9 @@ __global__ __launch_bounds__(512) void step_batched_mfma16_split_kernel(const Ba
     const int row_blk = blockIdx.x * ROWS;
     const int tiles = (P.n + TC - 1) / TC;
     const int supers = (P.n + 255) / 256;
-    const int t0 = (int)((3u * (unsigned)((P.row0 + row_blk) >> 7)) % (unsigned)supers) * (256 / TC);
+    int t0 = (int)((3u * (unsigned)((P.row0 + row_blk) >> 7)) % (unsigned)supers) * (256 / TC);
+    if (PROBE == 20) t0 = 0;
+    if (PROBE == 21) t0 = (int)((((unsigned)((P.row0 + row_blk) >> 7)) & 7u) * (unsigned)(supers / 8)) * (256 / TC);
     const bool ragged = (P.n % TC) != 0;
 
     // shared bookkeeping of the tile sequence (identical in both roles)
@@ -752,8 +754,13 @@ std::atomic<int> g_m16_tc{0}, g_m16_stages{0}, g_m16_waves{0};
 
 template <int MODEL, int NB>
 int launch_mfma16_cfg(const BatchParams& P, int B, hipStream_t st) {
-    // defaults measured at N = 32768 (scripts/sweep_mfma16.py, r03)
-    int tc = 64, stages = 2, waves = 4;
+    // defaults (scripts/sweep_mfma16.py, r03; ms per step, (tile columns, stages, waves), waves = 16: the role-split kernel):
+    //   one slot block (B <= 16)   N = 8192: (64,3,4) 0.067, (64,2,4) 0.107;  16384: 0.156 / 0.231;  32768: 0.621 / 0.618;
+    //                              65536: 2.69 / 2.69  -> three stages everywhere (small N has one workgroup per CU)
+    //   two slot blocks (B <= 32)  N = 16384: (64,3,4) 0.206, (64,3,8) 0.357, split 0.307;  24576: 0.524 / 0.531 / 0.464;
+    //                              32768: 0.82 / 0.81 / 0.745;  65536: 3.28 / 3.21 / 2.99  -> the split kernel from 192 workgroups
+    int tc = 64, stages = 3, waves = 4;
+    if (NB == 2 && P.rows >= 128 * 192) waves = 16;
     if (g_m16_tc > 0) tc = g_m16_tc;
     if (g_m16_stages > 0) stages = g_m16_stages;
     if (g_m16_waves > 0) waves = g_m16_waves;
@@ -791,6 +798,8 @@ int launch_mfma16_cfg(const BatchParams& P, int B, hipStream_t st) {
                 case 1160644: return launch_mfma16_split<MODEL, 64, 4, 1>(P, B, st);
                 case 2160644: return launch_mfma16_split<MODEL, 64, 4, 2>(P, B, st);
                 case 10160643: return launch_mfma16_split<MODEL, 64, 3, 10>(P, B, st);
+                case 20160643: return launch_mfma16_split<MODEL, 64, 3, 20>(P, B, st);
+                case 21160643: return launch_mfma16_split<MODEL, 64, 3, 21>(P, B, st);
                 default: break;
             }
         }

@@ -635,6 +635,11 @@ class BatchedPopulation:
         if form is None:
             use_mfma = (batch > 8) if mfma is None else bool(mfma)
             form = self.DEFAULT_MFMA if use_mfma else "valu"
+            # more than 16 trajectories on a SMALL population: the r02 form's 32-row workgroups fill the chip where the
+            # 64-row workgroups of "mfma16" cannot (scripts/sweep_mfma16.py: N = 8192, B = 32: 0.075 vs 0.096 ms per step;
+            # N = 16384: 0.227 vs 0.206)
+            if use_mfma and batch > 16 and pop.rows < 12288 and pop.row0 % 32 == 0:
+                form = "mfma32"
         if form not in self.FORMS:
             raise ValueError(f"form must be one of {sorted(self.FORMS)}, got {form!r}")
         self.form = form

@@ -19,10 +19,13 @@ for B in (8, 16, 32):
     cases.append(("mfma32", B, 0, 0, 0))
     for tc, st, wv in ((64, 2, 4), (64, 3, 4), (128, 2, 4)) + (((64, 2, 8), (64, 3, 8), (128, 2, 8)) if B > 16 else ()):
         cases.append(("mfma16", B, tc, st, wv))
-if os.environ.get("SPLIT"):  # the role-split kernel (waves = 16), whole and with halves switched off (116 / 216)
+if os.environ.get("SIZES"):  # the candidates for the dispatch rule, at another N
+    cases = [("valu", 8, 0, 0, 0), ("mfma16", 8, 64, 2, 4), ("mfma32", 16, 0, 0, 0), ("mfma16", 16, 64, 2, 4), ("mfma16", 16, 64, 3, 4),
+             ("mfma32", 32, 0, 0, 0), ("mfma16", 32, 64, 3, 4), ("mfma16", 32, 64, 3, 8), ("mfma16", 32, 64, 3, 16)]
+elif os.environ.get("SPLIT"):  # the role-split kernel (waves = 16), whole and with halves switched off (116 / 216)
     cases = [("mfma16", 32, 64, 3, 8), ("mfma16", 32, 64, 3, 16), ("mfma16", 32, 64, 4, 16), ("mfma16", 32, 64, 2, 16),
              ("mfma16", 32, 64, 3, 116), ("mfma16", 32, 64, 3, 216), ("mfma16", 32, 64, 4, 116), ("mfma16", 17, 64, 3, 16),
-             ("mfma16", 32, 64, 3, 1016)]
+             ("mfma16", 32, 64, 3, 1016), ("mfma16", 32, 64, 3, 2016), ("mfma16", 32, 64, 3, 2116)]
 elif os.environ.get("PROBE_HALVES"):  # waves + 10 / 20: the kernel without its MFMAs / without its steady-state DMA
     cases = [("mfma16", 32, 64, 3, 4), ("mfma16", 32, 64, 3, 14), ("mfma16", 32, 64, 3, 24),
              ("mfma16", 32, 64, 3, 8), ("mfma16", 32, 64, 3, 18), ("mfma16", 32, 64, 3, 28), ("mfma16", 32, 64, 3, 34), ("mfma16", 32, 64, 3, 38)]

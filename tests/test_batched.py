@@ -148,8 +148,10 @@ def test_matrix_core_form_matches_unbatched_runs(target, form, model, n, B, xw):
     pop = Population(model, W, params, 1e-2, dev, backend=backend)
     bp = BatchedPopulation(pop, B, form=form)
     assert bp.mfma and bp.form == form
-    if form == BatchedPopulation.DEFAULT_MFMA and B > 8:
-        assert BatchedPopulation(pop, B).form == form
+    if 8 < B <= 16:
+        assert BatchedPopulation(pop, B).form == BatchedPopulation.DEFAULT_MFMA == "mfma16"
+    if B > 16:  # small populations keep the r02 form for more than 16 trajectories (32-row workgroups fill the chip)
+        assert BatchedPopulation(pop, B).form == ("mfma32" if n < 12288 else "mfma16")
     bp.v.copy_(v0.to(dev))
     bp.refresh()
     traj = torch.zeros(T, B, n, device=dev)
