@@ -15,8 +15,8 @@ N, T = 32768, 40
 lib = _lib.load()
 W = bench.gen_rows(N, 0, N, dev)
 pop = Population("li_tanh", W, dict(tau=10.0, k=1.0, eta=0.0), 1e-2, dev)
-cases = [("mfma32", 32, 0, 0, 0), ("mfma16", 8, 64, 2, 4), ("mfma16", 16, 64, 2, 4), ("mfma16", 32, 64, 2, 4),
-         ("mfma16", 32, 64, 3, 4), ("mfma16", 32, 64, 3, 8)]
+cases = [("mfma32", 32, 0, 0, 0), ("mfma16", 8, 64, 3, 4), ("mfma16", 16, 64, 3, 4), ("mfma16", 32, 64, 3, 4),
+         ("mfma16", 32, 64, 3, 16)]
 cases += [tuple([c[0], int(c[1]), int(c[2]), int(c[3]), int(c[4])]) for c in (a.split(",") for a in sys.argv[1:])]
 for form, B, tc, st, wv in cases:
     lib.rp_set_batched_mfma_tuning(tc, st, wv)

@@ -17,6 +17,9 @@ for pas in ("pmc", "wait"):
         m = re.search(r"step_batched_mfma16_kernel<([^>]*)>", name)
         if m:
             return "mfma16<" + m.group(1).replace(" ", "") + ">"
+        m = re.search(r"step_batched_mfma16_split_kernel<([^>]*)>", name)
+        if m:
+            return "mfma16_split<" + m.group(1).replace(" ", "") + ">"
         if "step_batched_mfma_kernel" in name:
             return "mfma32"
         return None
