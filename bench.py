@@ -323,6 +323,7 @@ def main():
         out["extra"].update(facade_fit_bptt(pop, x, N, dev, teacher_net=net))  # it trains (modifies) the shared weight matrix
         pop = net = sp = None  # release the 4.3 GB network before the two larger side workloads
         torch.cuda.empty_cache()
+        out["extra"]["stepwise"] = stepwise_extra(dev)
         out["extra"]["qif_n65536"] = qif_extra(dev, cpu_threads=cpu_threads)
         out["extra"]["sparse_p0.1_n32768"] = sparse_extra(dev)
     print(json.dumps(out), flush=True)
@@ -604,6 +605,81 @@ def batched_extra(pop, N, dev, ms_single, T=200):
             "state_finite": bool(torch.isfinite(bp.v).all().item())}
         del bp, xb
     torch.cuda.empty_cache()
+    return res
+
+
+def stepwise_extra(dev):
+    """What the paths cost that advance ONE Euler step per call (us per step, wall clock incl. the Python graph walk), at
+    N = 4096 and N = 32768: (i) a user loop over net.forward(x) (reference rectipy_tests/test_network.py:327-333);
+    (ii) inp -> LinearMemoryFilter -> rnn through Network.run -- r03: the edge is evaluated per window, so the population
+    takes the fused-window plan; the same graph forced onto the step-by-step walk is what r02 paid; (iii) a
+    FeedbackNetwork of two populations of N/2 neurons (a -> b, feedback b -> a; dense N/2 x N/2 edges), which stays
+    step by step by construction (a feedback edge needs the source's state of the same step)."""
+    import contextlib
+    from rectipy_amd import FeedbackNetwork, Network
+    tanh = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
+    res = {"unit": "us per Euler step (wall clock)", "sizes": {}}
+
+    def node_kw(W):
+        return dict(input_var="li_op/I_ext", output_var="li_op/v", weights=W, source_var="tanh_op/r",
+                    target_var="li_op/r_in", dtype=torch.float32)
+
+    def timed(fn, steps):
+        fn(max(2, steps // 10))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn(steps)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e6
+
+    with contextlib.redirect_stdout(sys.stderr):
+        for N, T in ((4096, 1000), (32768, 200)):
+            m = 8
+            gen = torch.Generator(device=dev).manual_seed(N)
+            W = gen_rows(N, 0, N, dev)
+            W_in = torch.randn(N, m, device=dev, generator=gen)
+            x_full = torch.randn(T, N, device=dev, generator=gen) * 0.1
+            x_m = torch.randn(T, m, device=dev, generator=gen)
+            rec = {}
+            # (i) user loop over net.forward
+            net = Network(dt=1e-2, device=str(dev))
+            net.add_diffeq_node("rnn", tanh, **node_kw(W))
+            net.compile()
+
+            def user_loop(steps):
+                with torch.no_grad():
+                    for t in range(steps):
+                        net.forward(x_full[t])
+            rec["user_loop_net_forward"] = timed(user_loop, T)
+            rec["fused_Network_run_same_graph"] = timed(
+                lambda steps: net.run(x_full[:steps], sampling_steps=steps, verbose=False, enable_grad=False), T)
+            del net
+            # (ii) a delay + filter edge in front of the population
+            for forced in (False, True):
+                net = Network(dt=1e-2, device=str(dev))
+                net.add_func_node("inp", m, "identity")
+                net.add_diffeq_node("rnn", tanh, **node_kw(W))
+                net.add_edge("inp", "rnn", weights=W_in, delays=torch.arange(m) % 3,
+                             filter_weights=torch.eye(m) * 0.5)
+                net._force_stepwise = forced
+                key = "memory_filter_edge_" + ("step_by_step_walk" if forced else "windowed_edge_fused_population")
+                rec[key] = timed(lambda steps: net.run(x_m[:steps], sampling_steps=steps, verbose=False, enable_grad=False), T)
+                del net
+            del W, W_in, x_full
+            torch.cuda.empty_cache()
+            # (iii) two populations with a feedback edge
+            h = N // 2
+            fb = FeedbackNetwork(dt=1e-2, device=str(dev))
+            fb.add_diffeq_node("a", tanh, **node_kw(gen_rows(h, 0, h, dev)))
+            fb.add_diffeq_node("b", tanh, **node_kw(gen_rows(h, 0, h, dev)))
+            fb.add_edge("a", "b", weights=gen_rows(h, 0, h, dev, g=0.5))
+            fb.add_edge("b", "a", weights=gen_rows(h, 0, h, dev, g=0.5), feedback=True)
+            x_h = torch.randn(T, h, device=dev, generator=gen) * 0.1
+            rec["feedback_two_populations_of_N_over_2"] = timed(
+                lambda steps: fb.run(x_h[:steps], sampling_steps=steps, verbose=False, enable_grad=False), T)
+            del fb, x_h
+            torch.cuda.empty_cache()
+            res["sizes"][f"N{N}"] = {k_: round(v_, 2) for k_, v_ in rec.items()}
     return res
 
 

@@ -1,7 +1,12 @@
 """Stateful / masked variants of the linear edge (reference rectipy/edges.py:68-174).  They carry per-step state
-(delay buffers, recursive filters), so a network that uses one is evaluated step by step (every diff-eq node still
-steps through the HIP kernels); they are k x n host-side projections, not part of the HBM-bound path.  Behaviour
-follows the reference's ``forward`` methods, including the delay-buffer indexing of edges.py:91-94."""
+(delay buffers, recursive filters); they are k x n host-side projections, not part of the HBM-bound path.  Behaviour
+follows the reference's ``forward`` methods, including the delay-buffer indexing of edges.py:91-94.
+
+On an ACYCLIC edge such a map is a causal function of the source's window: ``forward_window(X[T, n_in])`` evaluates it
+for all T steps of a window (state carried across windows exactly as the per-step ``forward`` carries it), so the
+populations on either side still integrate as ONE fused window each (Network._edge_window).  The delay buffer has a
+closed form over the window; the recursive filters are T small matrix-vector products in step order -- the reference's
+own arithmetic, decoupled from the populations' kernel launches."""
 from typing import Union
 
 import numpy as np
@@ -28,6 +33,13 @@ class _Stateful(Linear):
             setattr(self, name, getattr(self, name).to(device))
         return self
 
+    def forward_window(self, X: torch.Tensor) -> torch.Tensor:
+        """The edge's outputs for the T consecutive inputs X[t] ([T, n_in] -> [T, n_out]); the edge's state afterwards
+        is what T calls of ``forward`` leave behind.  Default: exactly those T calls."""
+        if X.shape[0] == 0:
+            return X.new_zeros((0, self.weights.shape[0]))
+        return torch.stack([self.forward(X[t]) for t in range(X.shape[0])])
+
 
 class LinearMasked(_Stateful):
     """``(weights * mask) @ x`` (reference edges.py:150-174)."""
@@ -47,6 +59,9 @@ class LinearMasked(_Stateful):
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         w = self.weights * self.mask
         return x @ w.T if x.dim() == 2 else w @ x
+
+    def forward_window(self, X: torch.Tensor) -> torch.Tensor:
+        return self.forward(X)  # stateless: one product for the whole window
 
 
 class LinearMemory(_Stateful):
@@ -76,6 +91,38 @@ class LinearMemory(_Stateful):
         self.buffer = self._shift()
         self.buffer[:, self._cols] = x[self._src]  # == buffer[:, delays] = x, the reference's indexing (edges.py:93)
         return self.weights @ self.buffer[:, 0]
+
+    def forward_window(self, X: torch.Tensor) -> torch.Tensor:
+        """Closed form of T steps of the plain delay buffer.  ``buffer[:, delays] = x`` writes the SAME row into every
+        buffer row (edges.py:93), so one row b[0..D] describes the buffer: a step shifts it left (b[c] <- b[c+1]) and
+        sets b[d] = x[src(d)] for every distinct delay d.  Hence column c at the end of step t holds
+        x_{t-(d-c)}[src(d)] with d the smallest delay >= c, or the initial b[c+t+1] while t < d - c; the output is
+        column 0.  Pure selection -- no arithmetic besides the projection, which runs once for the window."""
+        if type(self)._shift is not LinearMemory._shift or X.shape[0] == 0 or X.requires_grad or \
+                not bool((self.buffer == self.buffer[:1]).all()):
+            return super().forward_window(X)  # filtered buffers, rows that differ, autograd: the T-step loop
+        T, D1 = X.shape[0], self.buffer.shape[1]
+        dev = self.buffer.device
+        cols = self._cols.to(dev)
+        c = torch.arange(D1, device=dev)
+        nxt = torch.searchsorted(cols, c)                  # index of the smallest delay >= c (the largest delay is D)
+        d, src = cols[nxt], self._src.to(dev)[nxt]
+        lag = d - c                                        # steps a value needs from its write column d to column c
+        b0 = self.buffer[0]
+
+        def column(cc, t):  # value of column cc (index tensor) at the end of step t (tensor of the same shape)
+            back = t - lag[cc]
+            from_x = back >= 0
+            xv = X[back.clamp(min=0), src[cc]]
+            init = b0[(cc + t + 1).clamp(max=D1 - 1)]
+            return torch.where(from_x, xv, init.to(X.dtype))
+
+        t_all = torch.arange(T, device=dev)
+        out0 = column(torch.zeros(T, dtype=torch.long, device=dev), t_all)          # buffer[:, 0] after every step
+        last = column(c, torch.full((D1,), T - 1, dtype=torch.long, device=dev))    # the whole buffer after the last step
+        self.buffer = last.to(self.buffer.dtype).reshape(1, D1).expand(self.buffer.shape[0], D1).contiguous()
+        # every row of the buffer is the same, so buffer[:, 0] is out0[t] repeated n_in times
+        return out0.reshape(T, 1).expand(T, self.weights.shape[1]).to(self.weights.dtype) @ self.weights.T
 
 
 class LinearFilter(_Stateful):

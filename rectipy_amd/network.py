@@ -297,11 +297,39 @@ class Network:
             if n != diffeq[0] and not (isinstance(node, InstantNode) and node.name in InstantNode.batched):
                 return None
         for s, t in self.graph.edges:
-            from .rls import RLS
-            if type(self.get_edge(s, t)) not in (Linear, RLS):  # stateful / masked variants are stepped one by one
+            if not self._windowable(self.get_edge(s, t)):
                 return None
         i = order.index(diffeq[0])
         return order[:i], diffeq[0], order[i + 1:]
+
+    @staticmethod
+    def _windowable(edge) -> bool:
+        """Edges that can be evaluated for a whole window of their source's outputs: plain / RLS projections, and the
+        masked, delay and filter variants (causal maps of the source's window on an acyclic edge,
+        edge_variants.forward_window).  Foreign edge classes are walked step by step."""
+        from .edge_variants import _Stateful
+        from .rls import RLS
+        return type(edge) in (Linear, RLS) or isinstance(edge, _Stateful)
+
+    def _memoryless_linear(self, labels: List[str], entry: Optional[str]) -> bool:
+        """True when the chain `entry -> labels...` is a LINEAR, MEMORYLESS map: identity nodes joined by plain / RLS /
+        masked projections.  Only then does it commute with the buffer mean of `run` (so that it may be applied to the
+        sampled means instead of every step); an edge with memory must see every step."""
+        from .edge_variants import LinearMasked
+        from .rls import RLS
+        prev = entry
+        for lab in labels:
+            if self.get_node(lab).name != "identity":
+                return False
+            if prev is not None and type(self.get_edge(prev, lab)) not in (Linear, RLS, LinearMasked):
+                return False
+            prev = lab
+        return True
+
+    def _edge_window(self, edge, X: torch.Tensor) -> torch.Tensor:
+        """Outputs of `edge` for the window X [T, n_in] of its source's per-step outputs."""
+        fw = getattr(edge, "forward_window", None)
+        return edge.forward(X) if fw is None else fw(X)
 
     def _apply_chain(self, labels: List[str], X: Optional[torch.Tensor], entry: Optional[str], exit_to: Optional[str]):
         """Apply activation nodes + the edges between them to a whole [T, m] batch.  `entry` is the node
@@ -309,11 +337,11 @@ class Network:
         prev = entry
         for lab in labels:
             if prev is not None:
-                X = self.get_edge(prev, lab).forward(X)
+                X = self._edge_window(self.get_edge(prev, lab), X)
             X = self.get_node(lab).forward(X)
             prev = lab
         if exit_to is not None and prev is not None:
-            X = self.get_edge(prev, exit_to).forward(X)
+            X = self._edge_window(self.get_edge(prev, exit_to), X)
         return X
 
     def _to_input(self, inputs) -> torch.Tensor:
@@ -391,6 +419,10 @@ class Network:
         pop = rnn._pop
         if isinstance(rnn, SpikeResetNet):
             raise NotImplementedError("run_batch covers the rate templates")
+        from .edge_variants import LinearMasked, _Stateful
+        if any(isinstance(self.get_edge(s_, t_), _Stateful) and not isinstance(self.get_edge(s_, t_), LinearMasked)
+               for s_, t_ in self.graph.edges):
+            raise NotImplementedError("run_batch: edges with memory (delay / filter) hold ONE state, not one per trajectory")
         dev = self.device if self._backend is None else "cpu"
         X = torch.as_tensor(inputs).to(device=dev, dtype=torch.float32)
         if X.dim() != 3:
@@ -427,7 +459,7 @@ class Network:
         # sampling as `run` does it for this topology (_run_fused): behind identity read-out nodes the buffer mean is the
         # step kernel's -- a running fp32 sum in step order divided by the count -- taken on the
         # population's output and read out afterwards; a non-linear read-out is applied per step and averaged by torch
-        linear_post = all(self.get_node(n).name == "identity" for n in post)
+        linear_post = self._memoryless_linear(post, label)
         S = len(sample_at)
         if linear_post:
             sampled = torch.empty(B, S, N, dtype=torch.float32, device=pop.device)
@@ -475,7 +507,7 @@ class Network:
             if not getattr(node, "_fusable", True):
                 return None
         for s_, t_ in self.graph.edges:
-            if type(self.get_edge(s_, t_)) not in (Linear, RLS):
+            if not self._windowable(self.get_edge(s_, t_)):
                 return None
         slots = []
         for label, var in rec_vars:
@@ -497,7 +529,7 @@ class Network:
             if preds:
                 X = None
                 for p_ in preds:
-                    contrib = self.get_edge(p_, n).forward(outs[p_])
+                    contrib = self._edge_window(self.get_edge(p_, n), outs[p_])
                     X = contrib if X is None else X + contrib
             else:
                 X = inputs_ab
@@ -604,7 +636,7 @@ class Network:
         sample_at = self._sample_steps(T, cutoff, sampling_steps)
         S = len(sample_at)
         exit_to = post[0] if post else None
-        linear_post = all(self.get_node(n).name == "identity" for n in post)
+        linear_post = self._memoryless_linear(post, label)
         grad = self._wants_grad(plan, inputs)
         spiking = isinstance(rnn, SpikeResetNet)
 
@@ -640,7 +672,8 @@ class Network:
         # no-grad path: sampling happens inside the step kernel
         w_in, X, x_chunked = None, None, False
         if pre:
-            if len(pre) == 1 and self.get_node(pre[0]).name == "identity" and inputs.shape[1] <= 64:
+            if len(pre) == 1 and self.get_node(pre[0]).name == "identity" and inputs.shape[1] <= 64 \
+                    and type(self.get_edge(pre[0], label)) is Linear:
                 w_in, X = self.get_edge(pre[0], label).weights, inputs  # projection folded into the kernel
             else:
                 x_chunked = True

@@ -1,6 +1,7 @@
 """Edge variants and FeedbackNetwork against fixtures captured from the REFERENCE's own classes
 (tests/golden/make_golden_topologies.py; reference rectipy/edges.py:68-174, rectipy/network.py:1196-1357).
-Networks with such edges are evaluated step by step, every diff-eq node on the engine (oracle / HIP)."""
+On acyclic edges the masked / delay / filter variants are causal maps of the source's window, so such networks take the
+fused-window plan (one library call per population and window); feedback graphs are walked step by step."""
 import os
 
 import numpy as np
@@ -81,16 +82,88 @@ def test_g27b_edge_variants_inside_network_run(target):
     e1 = net.add_edge("inp", "rnn", weights=g["W_in"], mask=g["mask"])
     e2 = net.add_edge("rnn", "out", weights=g["W_out"], filter_weights=g["F"])
     assert isinstance(e1, LinearMasked) and isinstance(e2, LinearFilter)
+    calls = count_window_calls(net)
     obs = net.run(g["x_m"], sampling_steps=1, verbose=False, enable_grad=False)
     assert err(obs.to_numpy("out"), g["masked_filter_f64"]) <= 2e-5
+    assert net._chain_plan() is not None and calls == [len(g["x_m"])], "the fused plan: ONE window call for the run"
     for name, kw, cls in (("memory", dict(delays=g["delays"]), LinearMemory),
                           ("memfilter", dict(delays=g["delays"], filter_weights=g["F"]), LinearMemoryFilter)):
         net = Network(float(g["dt"]), **target)
         net.add_diffeq_node("rnn", TANH, **li_node_kwargs(g))
         net.add_func_node("out", k, "identity")
         assert type(net.add_edge("rnn", "out", weights=g["W_out"], **kw)) is cls
+        calls = count_window_calls(net)
         obs = net.run(g["x_n"], sampling_steps=1, verbose=False, enable_grad=False)
         assert err(obs.to_numpy("out"), g[name + "_f64"]) <= 2e-5, name
+        assert net._chain_plan() is not None and calls == [len(g["x_n"])], name
+
+
+def count_window_calls(net):
+    """Records the `steps` of every fused-window call the population receives (a step-by-step walk calls forward())."""
+    node = net.get_node("rnn")
+    calls, inner, step = [], node.run_window, node.forward
+
+    def run_window(steps, *a, **kw):
+        calls.append(steps)
+        return inner(steps, *a, **kw)
+
+    def forward(x):
+        calls.append("step")
+        return step(x)
+
+    node.run_window, node.forward = run_window, forward
+    return calls
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("sampling_steps,cutoff", [(1, 0), (3, 2)])
+def test_windowed_edges_equal_the_step_by_step_walk(target, sampling_steps, cutoff):
+    """inp -> [LinearMemoryFilter] -> rnn -> [LinearFilter] -> out, and a two-population chain joined by a delay edge:
+    the fused-window plan (edges evaluated per window, state carried across the windows of two consecutive runs) gives
+    what the reference's step-by-step graph walk gives, including the buffer-mean sampling (an edge with memory must see
+    every step, so the read-out is applied per step and averaged afterwards)."""
+    g = gold("g27b_edge_variants_in_network")
+    n, m, k = g["W"].shape[0], g["W_in"].shape[1], g["W_out"].shape[0]
+    rng = np.random.default_rng(3)
+    delays_in = rng.integers(0, 4, m)
+    F_in = rng.standard_normal((m, m)) * 0.3
+    x = g["x_m"]
+
+    def build(stepwise):
+        net = Network(float(g["dt"]), **target)
+        net.add_func_node("inp", m, "identity")
+        net.add_diffeq_node("rnn", TANH, **li_node_kwargs(g))
+        net.add_func_node("out", k, "identity")
+        net.add_edge("inp", "rnn", weights=g["W_in"], delays=delays_in, filter_weights=F_in)
+        net.add_edge("rnn", "out", weights=g["W_out"], filter_weights=g["F"])
+        net._force_stepwise = stepwise
+        return net
+
+    outs = {}
+    for stepwise in (False, True):
+        net = build(stepwise)
+        calls = count_window_calls(net)
+        a = net.run(x[:17], sampling_steps=sampling_steps, cutoff=cutoff, verbose=False, enable_grad=False)
+        b = net.run(x[17:], sampling_steps=sampling_steps, cutoff=cutoff, verbose=False, enable_grad=False)
+        outs[stepwise] = (a.to_numpy("out"), b.to_numpy("out"), net.state["rnn"].cpu().numpy().copy())
+        assert ("step" in calls) == stepwise
+    for got, want in zip(outs[False], outs[True]):
+        assert got.shape == want.shape and err(got, want) <= 2e-6
+
+    # two populations joined by a delay edge (the multi-population plan)
+    outs = {}
+    W12 = rng.standard_normal((n, n)) * 0.2
+    for stepwise in (False, True):
+        net = Network(float(g["dt"]), **target)
+        net.add_diffeq_node("rnn", TANH, **li_node_kwargs(g))
+        kw2 = li_node_kwargs(g)
+        kw2["output_var"] = "tanh_op/r"
+        net.add_diffeq_node("rnn2", TANH, **kw2)
+        net.add_edge("rnn", "rnn2", weights=W12, delays=np.arange(n) % 5)
+        net._force_stepwise = stepwise
+        obs = net.run(g["x_n"], sampling_steps=sampling_steps, cutoff=cutoff, verbose=False, enable_grad=False)
+        outs[stepwise] = obs.to_numpy("out")
+    assert err(outs[False], outs[True]) <= 2e-6
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
