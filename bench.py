@@ -479,8 +479,8 @@ def qif_extra(dev, N=65536, T=400, cpu_threads=None):
            "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS},
            "state_finite": bool(torch.isfinite(pop.v).all().item())}
     if cpu_threads is not None:
-        from oracle.torch_eager import time_eager_qif
-        Wc = pop.W.cpu()
+        from oracle.torch_eager import host_copy_spread, time_eager_qif
+        Wc = host_copy_spread(pop.W)
         one = torch.ones(N)
         torch.set_num_threads(cpu_threads)
         warm, timed = 1, 8
@@ -533,21 +533,28 @@ def cpu_baseline(pop, x, dt, N):
     """Torch-eager port of the reference's per-step CPU loop on this box's host cores.  The mat-vec is DRAM-bound, so
     the default thread count (all hardware threads) is not the fastest: a short sweep picks the thread count, then 5
     warm-up + 60 timed steps at the winner (per-step cost is stationary; about 15-25 s of CPU work in total)."""
-    from oracle.torch_eager import sweep_threads, time_eager
-    W = pop.W.cpu()
+    from oracle.torch_eager import cpu_share, host_copy_spread, numa_nodes, sweep_threads, time_eager
+    W = host_copy_spread(pop.W)  # pages first-touched by all hardware threads: spread over every NUMA node
     tau, k, eta = (pop.params[n].cpu() for n in ("tau", "k", "eta"))
     v = pop.v.cpu()
     warm, timed = 5, 60
     xs = x[:warm + timed].cpu().expand(warm + timed, N).contiguous()
     hw = os.cpu_count() or torch.get_num_threads()
-    cands = sorted({t for t in (8, 16, 32, 64, hw // 2, hw) if 1 <= t <= hw})
+    share = cpu_share()
+    cands = sorted({t for t in (8, 16, int(round(share)), 32, 64, hw // 2, hw) if 1 <= t <= hw})
     best, _, table = sweep_threads(lambda: time_eager(W, tau, k, eta, v, xs, dt, 2, 10), cands)
     torch.set_num_threads(best)
     sps = time_eager(W, tau, k, eta, v, xs, dt, warm, timed)
     res = {"value": sps, "unit": "steps/s", "cores": best, "kind": "port",
            "sample": f"{warm} warm-up + {timed} timed Euler steps of the same N={N} network, torch {torch.__version__} "
                      f"CPU eager loop (oracle/torch_eager.py), fp32, no_grad; thread count = best of a sweep "
-                     f"(2 warm-up + 10 timed steps each) over {cands} on {hw} hardware threads",
+                     f"(2 warm-up + 10 timed steps each) over {cands} on {hw} hardware threads; W first-touched by all "
+                     f"hardware threads (pages spread over the host's {numa_nodes()} NUMA node(s))",
+           "hardware_threads": hw, "numa_nodes": numa_nodes(), "cpu_share_of_this_job": share,
+           # the survey container (8 vCPUs, SURVEY.md section 6) ran this loop at 17.4 steps/s = 75 GB/s: quote GPU/CPU
+           # ratios against the better of the two hosts, not against a throttled share of this one
+           "survey_container_probe_steps_per_s": 17.4,
+           "achieved_GBps": 4.0 * N * N * sps / 1e9,  # the mat-vec's stream of W: what bounds the CPU loop
            "thread_sweep_steps_per_s": {str(t): round(v_, 2) for t, v_ in table.items()}}
     return res, best
 
@@ -562,7 +569,8 @@ def cpu_fwd_bwd(pop, x, dt, N, threads, T=20):
     target = torch.randn(T, 3, generator=gen) * 0.1
     xs = x[:T].cpu().expand(T, N).contiguous()
     tau, k, eta = (pop.params[n].cpu() for n in ("tau", "k", "eta"))
-    sps = time_eager_bptt(pop.W.cpu(), tau, k, eta, pop.v.cpu(), xs, W_out, target, dt, T)
+    from oracle.torch_eager import host_copy_spread
+    sps = time_eager_bptt(host_copy_spread(pop.W), tau, k, eta, pop.v.cpu(), xs, W_out, target, dt, T)
     return {"value": sps, "unit": "steps/s (fwd+bwd)", "cores": threads, "kind": "port",
             "sample": f"one autograd window of T={T} steps, N={N}, trainable W, MSE read-out k=3 "
                       f"(oracle/torch_eager.py: time_eager_bptt)"}

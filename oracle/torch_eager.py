@@ -11,6 +11,54 @@ import time
 import torch
 
 
+def numa_nodes() -> int:
+    """NUMA nodes of the host (1 when the sysfs tree is absent)."""
+    import glob
+    return max(1, len(glob.glob("/sys/devices/system/node/node[0-9]*")))
+
+
+def cpu_share() -> float:
+    """CPUs this process may use at once: the cgroup quota (cpu.max, v2; cfs_quota_us / cfs_period_us, v1) when one is
+    set, else the affinity mask's size.  A GPU box hands a one-GPU job a SHARE of a 256-thread host; more threads than
+    that only time-slice."""
+    import os
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            return float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0:
+            return quota / period
+    except (OSError, ValueError):
+        pass
+    try:
+        return float(len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return float(os.cpu_count() or 1)
+
+
+def host_copy_spread(t: torch.Tensor) -> torch.Tensor:
+    """Host copy of `t` whose pages are FIRST TOUCHED by all hardware threads in parallel, so that a large matrix is
+    spread over the memory of every NUMA node instead of sitting on the node of the thread that called ``.cpu()``
+    (a 4.3 GB coupling matrix on one node caps the DRAM-bound mat-vec at that node's bandwidth, whatever the thread
+    count).  torch's fill and copy kernels split their range statically over the intra-op pool, as the BLAS mat-vec
+    splits its rows."""
+    import os
+    default = torch.get_num_threads()
+    try:
+        torch.set_num_threads(os.cpu_count() or default)
+        out = torch.empty(t.shape, dtype=t.dtype)
+        out.fill_(0)                      # parallel first touch
+        out.copy_(t.detach().cpu())       # parallel copy from the staging tensor
+    finally:
+        torch.set_num_threads(default)
+    return out
+
+
 def li_tanh_field(t, y, I_ext, weights, tau, k, eta):
     return -y / tau + k * (weights @ torch.tanh(y)) + I_ext + eta
 
