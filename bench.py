@@ -118,6 +118,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded (RCCL) path even with one rank")
+    ap.add_argument("--exchange", choices=("rccl", "direct"), default=os.environ.get("RECTIPY_AMD_EXCHANGE", "rccl"),
+                    help="per-step exchange of the row-sharded run: the RCCL all-gather enqueued in-library (default), or the "
+                         "stream-ordered direct push exchange (RP_COMM_DIRECT; opt-in: rehearsed with two processes on one "
+                         "GPU only, never over xGMI)")
     ap.add_argument("--config5-neurons", type=int, default=262144,
                     help="N of the row-sharded BASELINE configs[4] leg that runs with --gpus > 1 (0: skip)")
     ap.add_argument("--config5-steps", type=int, default=200)
@@ -167,15 +171,17 @@ def main():
     else:
         from rectipy_amd.sharded import ShardedPopulation, shard_bounds
         row0, rows = shard_bounds(N, world, rank)
-        sp = ShardedPopulation("li_tanh", gen_rows(N, row0, rows, dev), params, dt, dev, n=N)
+        sp = ShardedPopulation("li_tanh", gen_rows(N, row0, rows, dev), params, dt, dev, n=N, exchange=args.exchange)
         pop = sp.pop
         samples = torch.zeros(n_samples, rows, device=dev)
         exchange = "torch.distributed all_gather_into_tensor per step (host loop)"
         had_comm = sp.comm is not None
-        # collective (every rank calls it, whether or not it got a communicator): the in-library RCCL exchange must be
+        # collective (every rank calls it, whether or not it got a communicator): the in-library exchange must be
         # available on ALL ranks and reproduce the torch.distributed one bit for bit; otherwise every rank drops it
         if sp.check_inlib_exchange(3):
-            exchange = "RCCL all-gather enqueued in-library (rp_forward_sharded); checked == torch.distributed path"
+            exchange = ("stream-ordered direct push exchange (RP_COMM_DIRECT: peer stores + hipStreamWrite/WaitValue32)"
+                        if sp.direct is not None else "RCCL all-gather enqueued in-library (rp_forward_sharded)") + \
+                "; checked == torch.distributed path"
         elif had_comm:
             exchange += " [in-library exchange unavailable on some rank or disagreed with it: disabled]"
 

@@ -327,8 +327,33 @@ typedef struct rp_comm {
     void* reduce_scatter;  /* ncclResult_t (*)(const void*, void*, size_t, int dtype, int op, ncclComm_t, hipStream_t) */
     int32_t rank, world;
     float* work;           /* sharded adjoint only: n + rows floats (full-length partial, reduced slice)     */
+    /* mode = RP_COMM_DIRECT (forward only; opt-in): no collective launch.  After its step kernel a rank PUSHES its slice of
+       the next source vector straight into every peer's source buffer (peer memory mapped through hipIpc, written over
+       xGMI by one small copy kernel) and then its STREAM writes the step's sequence number into its slot of every peer's
+       flag array (hipStreamWriteValue32); before a step kernel the stream waits until every peer's slot holds the previous
+       sequence number (hipStreamWaitValue32, >=).  No CU-resident spin loop anywhere: a rank that is late only delays
+       the command processors of its peers.  The wait covers both hazards of the two ping-pong buffers: a peer's slices of
+       step s-1 have landed in this rank's current buffer, and the peer is done reading the buffer this rank is about to
+       push into.  Summation order untouched: results equal the RCCL / host-loop exchange bit for bit.  `seq` is the
+       number of steps exchanged so far on these buffers (in/out; flags must be zero while seq is 0).
+       comm / all_gather may be NULL in this mode; rp_backward_sharded still needs them. */
+    int32_t mode;                 /* RP_COMM_RCCL (0) | RP_COMM_DIRECT (1)                                          */
+    uint32_t seq;                 /* [host, in/out]                                                                 */
+    float* const* peer_src;       /* [2 * world] (host array): peer p's source buffer k at [2 p + k]; own entries = net->src[k] */
+    uint32_t* const* peer_flags;  /* [world] (host array): peer p's flag array (world words), mapped here; own entry = flags */
+    uint32_t* flags;              /* this rank's flag array [world], slot q written by rank q                       */
 } rp_comm;
+#define RP_COMM_RCCL 0
+#define RP_COMM_DIRECT 1
 int rp_sizeof_comm(void);
+
+/* Device memory that other PROCESSES can map (hipMalloc + hipIpcGetMemHandle; 64-byte handle), for the buffers of
+   RP_COMM_DIRECT: rp_ipc_alloc zero-fills; rp_ipc_open maps a peer's allocation into this process; rp_ipc_close unmaps;
+   rp_ipc_free releases an allocation of this process.  The caller exchanges the handles (torch.distributed). */
+int rp_ipc_alloc(int64_t bytes, void** ptr, unsigned char handle[64]);
+int rp_ipc_open(const unsigned char handle[64], void** ptr);
+int rp_ipc_close(void* ptr);
+int rp_ipc_free(void* ptr);
 
 /* rp_forward on a row shard (net->rows = n / world, net->row0 = rank * rows) followed, every step, by the in-place
    all-gather of the ranks' slices of the next source vector.  Same arguments and results as rp_forward. */

@@ -7,6 +7,7 @@ import ctypes as C
 
 RP_ABI_VERSION = 9
 RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_MFMA16, RP_BATCH_SLOTS = 0, 1, 2, 32
+RP_COMM_RCCL, RP_COMM_DIRECT = 0, 1
 
 RP_OK = 0
 RP_ERR_ARG = -1
@@ -196,6 +197,11 @@ class RpComm(C.Structure):
         ("rank", C.c_int32),
         ("world", C.c_int32),
         ("work", fp),
+        ("mode", C.c_int32),
+        ("seq", C.c_uint32),
+        ("peer_src", C.POINTER(C.c_void_p)),
+        ("peer_flags", C.POINTER(C.c_void_p)),
+        ("flags", C.c_void_p),
     ]
 
 
@@ -232,6 +238,10 @@ def declare(lib):
     sig("rp_sizeof_comm", C.c_int, [])
     sig("rp_forward_sharded", C.c_int, [P(RpNet), P(RpRun), P(RpComm), C.c_void_p])
     sig("rp_backward_sharded", C.c_int, [P(RpNet), P(RpBwd), P(RpComm), C.c_void_p])
+    sig("rp_ipc_alloc", C.c_int, [C.c_int64, C.POINTER(C.c_void_p), C.c_char_p])
+    sig("rp_ipc_open", C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)])
+    sig("rp_ipc_close", C.c_int, [C.c_void_p])
+    sig("rp_ipc_free", C.c_int, [C.c_void_p])
     sig("rp_sizeof_batch", C.c_int, [])
     sig("rp_forward_batched", C.c_int, [P(RpNet), P(RpBatch), C.c_void_p])
     sig("rp_set_batched_grid", C.c_int, [C.c_int])
@@ -261,5 +271,5 @@ EXPORTS = [
     "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum", "rp_outer_accum_rect",
     "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial", "rp_bwd_apply",
     "rp_sizeof_comm", "rp_forward_sharded", "rp_backward_sharded",
-    "rp_sizeof_batch", "rp_forward_batched", "rp_set_batched_tuning", "rp_set_batched_mfma_tuning", "rp_set_batched_grid", "rp_rls_sweep", "rp_stream_probe", "rp_tune_forward", "rp_forward_tuning", "rp_install_forward_tuning", "rp_clear_forward_tuning", "rp_set_tuning", "rp_set_sparse_tuning", "rp_set_blocked_tuning", "rp_set_bwd_tuning", "rp_set_bwd_grid", "rp_set_bwd_chunks", "rp_set_rls_tuning", "rp_set_rls_tile",
+    "rp_ipc_alloc", "rp_ipc_open", "rp_ipc_close", "rp_ipc_free", "rp_sizeof_batch", "rp_forward_batched", "rp_set_batched_tuning", "rp_set_batched_mfma_tuning", "rp_set_batched_grid", "rp_rls_sweep", "rp_stream_probe", "rp_tune_forward", "rp_forward_tuning", "rp_install_forward_tuning", "rp_clear_forward_tuning", "rp_set_tuning", "rp_set_sparse_tuning", "rp_set_blocked_tuning", "rp_set_bwd_tuning", "rp_set_bwd_grid", "rp_set_bwd_chunks", "rp_set_rls_tuning", "rp_set_rls_tile",
 ]

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -761,13 +762,39 @@ namespace {
 typedef int (*all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
 constexpr int kNcclFloat = 7;  // ncclFloat32 (rccl.h)
 
+// RP_COMM_DIRECT: copy this rank's slice of the next source vector into the same rows of every peer's buffer (peer
+// memory mapped through hipIpc; blockIdx.y = peer), 16 bytes per lane.
+struct PushParams {
+    const float* src;
+    float* dst[63];
+    int quads, peers;
+};
+__global__ __launch_bounds__(256) void push_slice_kernel(const PushParams Q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < Q.quads) reinterpret_cast<rp_f4*>(Q.dst[blockIdx.y])[i] = reinterpret_cast<const rp_f4*>(Q.src)[i];
+}
+
 // rp_forward / rp_forward_sharded: `comm` != nullptr adds the per-step all-gather of the source slices.
 int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     int rc = validate_net(net);
     if (rc != RP_OK) return rc;
     if (!run) RP_FAIL(RP_ERR_ARG, "run is null");
+    const bool direct = comm && comm->mode == RP_COMM_DIRECT;
     if (comm) {
-        if (!comm->comm || !comm->all_gather) RP_FAIL(RP_ERR_ARG, "rp_comm needs comm and all_gather");
+        if (comm->mode != RP_COMM_RCCL && comm->mode != RP_COMM_DIRECT) RP_FAIL(RP_ERR_ARG, "bad rp_comm.mode %d", comm->mode);
+        if (!direct && (!comm->comm || !comm->all_gather)) RP_FAIL(RP_ERR_ARG, "rp_comm needs comm and all_gather");
+        if (direct) {
+            if (!comm->peer_src || !comm->peer_flags || !comm->flags) RP_FAIL(RP_ERR_ARG, "RP_COMM_DIRECT needs peer_src, peer_flags and flags");
+            if (comm->world > 64) RP_FAIL(RP_ERR_ARG, "RP_COMM_DIRECT: at most 64 ranks");
+            for (int p = 0; p < comm->world; ++p) {
+                if (!comm->peer_flags[p] || !comm->peer_src[2 * p] || !comm->peer_src[2 * p + 1])
+                    RP_FAIL(RP_ERR_ARG, "RP_COMM_DIRECT: peer %d has a null buffer", p);
+            }
+            if (comm->peer_src[2 * comm->rank] != net->src[0] || comm->peer_src[2 * comm->rank + 1] != net->src[1] ||
+                comm->peer_flags[comm->rank] != comm->flags)
+                RP_FAIL(RP_ERR_ARG, "RP_COMM_DIRECT: this rank's entries of peer_src / peer_flags must be its own buffers");
+            if (net->rows % 4 != 0) RP_FAIL(RP_ERR_SHAPE, "RP_COMM_DIRECT pushes 16-byte pieces: rows %% 4 == 0 required");
+        }
         if (comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world)
             RP_FAIL(RP_ERR_ARG, "bad rank %d / world %d", comm->rank, comm->world);
         if ((int64_t)net->rows * comm->world != net->n || net->row0 != comm->rank * net->rows)
@@ -882,6 +909,10 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
                 run->acc_count = 0;
             }
         }
+        if (direct)  // every peer has pushed step seq (and is done with the buffer this step pushes into)
+            for (int p = 0; p < comm->world; ++p)
+                if (p != comm->rank)
+                    RP_HIP_CHECK(hipStreamWaitValue32(st, comm->flags + p, comm->seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
         if (run->save_src_full)
             RP_HIP_CHECK(hipMemcpyAsync(run->save_src_full + (int64_t)t * run->ldfull, P.src_cur,
                                         sizeof(float) * (size_t)net->n, hipMemcpyDeviceToDevice, st));
@@ -896,7 +927,25 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
             launch_step_model<false>(net->model, P, st, stream_cfg);
         }
         if (t == 0) RP_HIP_CHECK(hipGetLastError());  // a rejected launch configuration shows on the first step
-        if (comm) {  // every rank wrote rows [row0, row0 + rows) of src_next: exchange in place, same stream
+        if (direct) {
+            // push this rank's slice into every peer's next buffer, then tell them from the stream; the wait for the
+            // peers' previous step sits in front of the step kernel (below, for the next step; here for this one)
+            rp_comm* c = const_cast<rp_comm*>(comm);
+            PushParams Q = {};
+            Q.src = P.src_next + net->row0;
+            Q.quads = net->rows / 4;
+            Q.peers = 0;
+            for (int p = 0; p < comm->world; ++p)
+                if (p != comm->rank) Q.dst[Q.peers++] = comm->peer_src[2 * p + (net->cur ^ 1)] + net->row0;
+            if (Q.peers > 0) {
+                const int per = (Q.quads + 255) / 256;
+                hipLaunchKernelGGL(push_slice_kernel, dim3(per, Q.peers), dim3(256), 0, st, Q);
+            }
+            c->seq += 1;
+            for (int p = 0; p < comm->world; ++p)
+                if (p != comm->rank)
+                    RP_HIP_CHECK(hipStreamWriteValue32(st, comm->peer_flags[p] + comm->rank, c->seq, 0));
+        } else if (comm) {  // every rank wrote rows [row0, row0 + rows) of src_next: exchange in place, same stream
             const int nrc = reinterpret_cast<all_gather_fn>(comm->all_gather)(
                 P.src_next + net->row0, P.src_next, (size_t)net->rows, kNcclFloat, comm->comm, st);
             if (nrc != 0) RP_FAIL(RP_ERR_COMM, "ncclAllGather returned %d at step %lld", nrc, (long long)t_abs);
@@ -919,6 +968,41 @@ int rp_forward_sharded(rp_net* net, rp_run* run, const rp_comm* comm, void* stre
 }
 
 int rp_sizeof_comm(void) { return (int)sizeof(rp_comm); }
+
+int rp_ipc_alloc(int64_t bytes, void** ptr, unsigned char handle[64]) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (!ptr || !handle || bytes <= 0) RP_FAIL(RP_ERR_ARG, "rp_ipc_alloc: bad arguments");
+    void* p = nullptr;
+    RP_HIP_CHECK(hipMalloc(&p, (size_t)bytes));
+    hipIpcMemHandle_t h;
+    if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        hipIpcGetMemHandle(&h, p) != hipSuccess) {
+        const hipError_t e = hipGetLastError();
+        (void)hipFree(p);
+        RP_FAIL(RP_ERR_HIP, "rp_ipc_alloc: %s", hipGetErrorString(e));
+    }
+    memcpy(handle, &h, 64);
+    *ptr = p;
+    return RP_OK;
+}
+
+int rp_ipc_open(const unsigned char handle[64], void** ptr) {
+    if (!ptr || !handle) RP_FAIL(RP_ERR_ARG, "rp_ipc_open: bad arguments");
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, 64);
+    RP_HIP_CHECK(hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return RP_OK;
+}
+
+int rp_ipc_close(void* ptr) {
+    if (ptr) RP_HIP_CHECK(hipIpcCloseMemHandle(ptr));
+    return RP_OK;
+}
+
+int rp_ipc_free(void* ptr) {
+    if (ptr) RP_HIP_CHECK(hipFree(ptr));
+    return RP_OK;
+}
 
 int rp_set_blocked_tuning(int waves, int groups_in_flight) {
     g_blocked_waves = waves;

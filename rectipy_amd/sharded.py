@@ -75,6 +75,82 @@ def _loaded_rccl():
     return lib
 
 
+class DirectExchange:
+    """``rp_comm`` for the stream-ordered DIRECT exchange (``RP_COMM_DIRECT``, include/rectipy_hip.h): the population's
+    two source buffers and a flag array live in device memory that the other rank processes map through hipIpc; every
+    step a rank pushes its slice into its peers' buffers and the STREAMS signal / wait on per-step sequence numbers
+    (hipStreamWriteValue32 / hipStreamWaitValue32) -- no collective launch and no spinning kernel.  Opt-in
+    (``ShardedPopulation(..., exchange="direct")`` or RECTIPY_AMD_EXCHANGE=direct): it has been run with two processes
+    on ONE MI355X (tests/test_direct_exchange.py: bit-equal to the host-loop exchange), never over xGMI.  Forward only;
+    the sharded adjoint keeps the RCCL reduce-scatter.  Collective constructor: every rank of `group` calls it."""
+
+    def __init__(self, pop: Population, group=None):
+        import ctypes as C
+        from . import _lib
+        self.lib = _lib.load()
+        self.group = group
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if pop.rows % 4 or pop.rows * world != pop.n:
+            raise ValueError("the direct exchange needs n = world * rows and rows % 4 == 0")
+        n, dev = pop.n, pop.device
+        self._own, self._mapped = [], []
+        handles = []
+        with torch.cuda.device(dev):
+            for nbytes in (4 * n, 4 * n, 4 * max(world, 1)):
+                ptr, h = C.c_void_p(), C.create_string_buffer(64)
+                _lib.check(self.lib.rp_ipc_alloc(nbytes, C.byref(ptr), h))
+                self._own.append(ptr.value)
+                handles.append(h.raw)
+        # the population's source buffers move into the exportable allocations (same values)
+        new_src = [_wrap_device_floats(self._own[k], n, dev, self) for k in range(2)]
+        for k in range(2):
+            new_src[k].copy_(pop.src[k])
+        pop.src = new_src
+        pop._net_cache = None
+        everyone = [None] * world
+        dist.all_gather_object(everyone, handles, group=group)
+        self.peer_src = (C.c_void_p * (2 * world))()
+        self.peer_flags = (C.c_void_p * world)()
+        with torch.cuda.device(dev):
+            for p in range(world):
+                if p == rank:
+                    ptrs = self._own
+                else:
+                    ptrs = []
+                    for h in everyone[p]:
+                        q = C.c_void_p()
+                        _lib.check(self.lib.rp_ipc_open(h, C.byref(q)))
+                        ptrs.append(q.value)
+                        self._mapped.append(q.value)
+                self.peer_src[2 * p], self.peer_src[2 * p + 1], self.peer_flags[p] = ptrs[0], ptrs[1], ptrs[2]
+        comm = _abi.RpComm()
+        comm.rank, comm.world, comm.mode, comm.seq = rank, world, _abi.RP_COMM_DIRECT, 0
+        comm.peer_src = C.cast(self.peer_src, C.POINTER(C.c_void_p))
+        comm.peer_flags = C.cast(self.peer_flags, C.POINTER(C.c_void_p))
+        comm.flags = self._own[2]
+        self.comm = comm
+        dist.barrier(group=group)  # nobody pushes before everybody has mapped
+
+    def close(self):
+        """Unmap the peers' buffers (the own allocations stay alive with the tensors that wrap them)."""
+        torch.cuda.synchronize()
+        for q in self._mapped:
+            self.lib.rp_ipc_close(q)
+        self._mapped = []
+
+
+def _wrap_device_floats(ptr: int, count: int, device, owner) -> torch.Tensor:
+    """A float32 torch tensor over `count` floats of device memory at `ptr` (not owned by torch; `owner` is kept alive by
+    the tensor through the array-interface object)."""
+    class _Mem:
+        pass
+
+    mem = _Mem()
+    mem.owner = owner
+    mem.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(mem, device=device)
+
+
 def one_rank_env(environ=None):
     """Rendezvous variables for a process started WITHOUT a launcher (plain `python`): a one-rank group on 127.0.0.1
     at a free port.  Only the variables that are missing are filled in -- a partially set environment (a launcher's
@@ -103,7 +179,10 @@ class ShardedPopulation:
     """One rank's shard plus the per-step exchange."""
 
     def __init__(self, model: str, weights_local, params_local: Dict[str, object], dt: float, device, n: int,
-                 v0_local=None, s0_local=None, group=None, backend=None, **kw):
+                 v0_local=None, s0_local=None, group=None, backend=None, exchange: Optional[str] = None, **kw):
+        """``exchange``: None / "rccl" -- the per-step RCCL all-gather enqueued in-library (host loop for gloo groups);
+        "direct" -- the stream-ordered push exchange (:class:`DirectExchange`; opt-in, also RECTIPY_AMD_EXCHANGE=direct)."""
+        import os
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -112,11 +191,28 @@ class ShardedPopulation:
                               row0=self.row0, backend=backend, **kw)
         self.n = n
         self._gather_source()  # every rank needs the full initial source vector
-        self.comm = agreed_comm(rccl_comm(group, self.pop.device, self.pop.backend), group, self.pop.device)
+        exchange = exchange or os.environ.get("RECTIPY_AMD_EXCHANGE", "rccl")
+        self.direct = None
+        if exchange == "direct":
+            if not hasattr(self.pop.backend, "forward_sharded") or self.pop.device.type != "cuda":
+                raise RuntimeError("the direct exchange runs on the HIP backend only")
+            self.direct = DirectExchange(self.pop, group)
+            self.comm = self.direct.comm
+        elif exchange == "rccl":
+            self.comm = agreed_comm(rccl_comm(group, self.pop.device, self.pop.backend), group, self.pop.device)
+        else:
+            raise ValueError(f"exchange must be 'rccl' or 'direct', got {exchange!r}")
 
     def _gather_source(self):
         full = self.pop.source
-        dist.all_gather_into_tensor(full, full[self.row0:self.row0 + self.rows].clone(), group=self.group)
+        mine = full[self.row0:self.row0 + self.rows].clone()
+        if full.is_cuda and dist.get_backend(self.group) != "nccl":
+            # a CPU-only process group around GPU ranks (the two-processes-on-one-GPU test of the direct exchange)
+            parts = [None] * self.world
+            dist.all_gather_object(parts, mine.cpu(), group=self.group)
+            full.copy_(torch.cat(parts).to(full.device))
+            return
+        dist.all_gather_into_tensor(full, mine, group=self.group)
 
     def check_inlib_exchange(self, steps: int = 3) -> bool:
         """One-time guard for the in-library RCCL exchange (it runs on the compute stream with ProcessGroupNCCL's
