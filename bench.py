@@ -326,10 +326,12 @@ def main():
             out["extra"]["cpu_fwd_bwd"] = cpu_fwd_bwd(pop, x, dt, N, cpu_threads)
         out["extra"]["batched_trajectories"] = batched_extra(pop, N, dev, out["ms_per_step"])
         out["extra"]["fit_ridge"] = ridge_extra(net, x, N, dev)
+        out["extra"]["fit_ridge"]["phases_ms"]["step_kernels_alone_at_the_measured_launch_time"] = 2000 * kernel_ms
         out["extra"].update(facade_fit_bptt(pop, x, N, dev, teacher_net=net))  # it trains (modifies) the shared weight matrix
         pop = net = sp = None  # release the 4.3 GB network before the two larger side workloads
         torch.cuda.empty_cache()
         out["extra"]["stepwise"] = stepwise_extra(dev)
+        out["extra"]["rls_n32768"] = rls_extra(dev, cpu_threads=cpu_threads)
         out["extra"]["qif_n65536"] = qif_extra(dev, cpu_threads=cpu_threads)
         out["extra"]["sparse_p0.1_n32768"] = sparse_extra(dev)
     print(json.dumps(out), flush=True)
@@ -622,6 +624,42 @@ def batched_extra(pop, N, dev, ms_single, T=200):
     return res
 
 
+def rls_extra(dev, n_in=32768, k=3, T=20, cpu_threads=None):
+    """recursive-least-squares read-out training (reference RLS.update, rectipy/edges.py:227-234) at
+    n_in = 32768: P is 4.3 GB, one update = ONE fused read-modify-write pass over it (rank-1 update of step t + the
+    mat-vec of step t+1; 8 n_in^2 algorithmic bytes; the reference makes three passes: 12 n_in^2 + an n_in^2 temporary)."""
+    from rectipy_amd.rls import RLS
+    edge = RLS(n_in, k, beta=0.99, alpha=1.0).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(5)
+    X = torch.randn(T, n_in, device=dev, generator=gen) * 0.1
+    Y = torch.randn(T, k, device=dev, generator=gen)
+    edge.sweep(X[:3], Y[:3], 1)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    edge.sweep(X, Y, 1)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / (T + 1)  # T fused passes + the initial mat-vec pass
+    gbps = 8.0 * n_in * n_in / (ms * 1e-3) / 1e9
+    res = {"workload": f"RLS read-out training, n_in={n_in}, n_out={k}, {T} consecutive updates (rp_rls_sweep)",
+           "updates_per_s": 1e3 / ms, "ms_per_update": ms,
+           "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                        "algorithmic_bytes_per_update": 8.0 * n_in * n_in,
+                        "note": "an in-place read-modify-write of 4 GiB reaches 6.7-6.8 TB/s on this chip (DESIGN.md section 8)"},
+           "state_finite": bool(torch.isfinite(edge.P).all().item())}
+    del edge, X, Y
+    torch.cuda.empty_cache()
+    if cpu_threads is not None:
+        from oracle.torch_eager import time_eager_rls
+        torch.set_num_threads(cpu_threads)
+        ups = time_eager_rls(n_in, k, 3)
+        res["cpu"] = {"value": ups, "unit": "updates/s", "cores": cpu_threads, "kind": "port",
+                      "sample": "1 warm-up + 3 timed updates of the reference's RLS.update, op for op, torch CPU eager "
+                                "(oracle/torch_eager.py: time_eager_rls), fp32"}
+    return res
+
+
 def stepwise_extra(dev):
     """What the paths cost that advance ONE Euler step per call (us per step, wall clock incl. the Python graph walk), at
     N = 4096 and N = 32768: (i) a user loop over net.forward(x) (reference rectipy_tests/test_network.py:327-333);
@@ -699,8 +737,10 @@ def stepwise_extra(dev):
 
 def ridge_extra(net, x, N, dev, T=2000, sampling=10, k=3):
     """Network.fit_ridge -- state collection over T steps on the fused window (sampled every
-    `sampling` steps) + the closed-form read-out solve (float64 Gram matrix and solve in torch, dual form S x S)."""
+    `sampling` steps) + the closed-form read-out solve (float64 Gram matrix and solve in torch, dual form S x S).  The
+    phases are timed separately as well (each followed by a synchronize): what the call spends outside the step kernels."""
     import contextlib
+    from rectipy_amd import Network
     gen = torch.Generator(device=dev).manual_seed(4)
     targets = torch.randn(T, k, generator=gen, device=dev)
     with contextlib.redirect_stdout(sys.stderr):
@@ -709,10 +749,30 @@ def ridge_extra(net, x, N, dev, T=2000, sampling=10, k=3):
         obs = net.fit_ridge(x[:T], targets, sampling_steps=sampling, alpha=1e-2, verbose=False, add_readout_node=False)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
+        # the same phases one by one
+        net.reset()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_obs = net.run(x[:T], sampling_steps=sampling, verbose=False, enable_grad=False)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        X = run_obs.stacked("out")
+        Y = targets[run_obs["steps"]]
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        w2 = Network._ridge_solve(X, Y, 1e-2)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        y = X @ w2
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
     w = obs["w_out"]
     return {"workload": f"Network.fit_ridge, N={N}, {T} steps, sampling_steps={sampling}, k={k}",
             "steps_per_s": T / wall, "wall_s": wall, "w_out_shape": list(w.shape),
-            "w_out_finite": bool(torch.isfinite(w).all().item())}
+            "phases_ms": {"state_collection_Network_run": (t2 - t1) * 1e3, "stack_samples_and_targets": (t3 - t2) * 1e3,
+                          "float64_gram_and_solve": (t4 - t3) * 1e3, "predictions": (t5 - t4) * 1e3,
+                          "step_kernels_alone_at_the_measured_launch_time": None},
+            "w_out_finite": bool(torch.isfinite(w).all().item()) and bool(torch.isfinite(y).all().item())}
 
 
 def config5_leg(n5, steps, world, rank, dev, dt):

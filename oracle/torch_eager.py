@@ -145,3 +145,35 @@ def time_eager_qif(W, tau, k, eta, tau_s, v, s, x_const, dt, theta, v_reset, war
             v = y_new[:n] * (1.0 - reset) + reset * v_reset
             s = y_new[n:]
     return steps / (time.perf_counter() - t0)
+
+
+def time_eager_rls(n_in, n_out, updates, beta=0.99, alpha=1.0, seed=0):
+    """updates/s of the reference's RLS.update on the CPU, op for op (rectipy/edges.py:227-234): z = beta^-1 P x,
+    k = 1 / (1 + x.z), the weight update through two outer products, P -= k outer(z, z) (an n_in x n_in temporary),
+    loss.  float32, P spread over the NUMA nodes by a parallel first touch."""
+    import os
+    g = torch.Generator().manual_seed(seed)
+    default = torch.get_num_threads()
+    torch.set_num_threads(os.cpu_count() or default)
+    P = torch.empty(n_in, n_in)
+    P.fill_(0)
+    torch.set_num_threads(default)
+    P.diagonal().fill_(alpha)
+    W = torch.zeros(n_out, n_in)
+    beta_inv = 1.0 / beta
+    X = torch.randn(updates + 1, n_in, generator=g) * 0.1
+    Y = torch.randn(updates + 1, n_out, generator=g)
+    t0 = None
+    with torch.no_grad():
+        for t in range(updates + 1):
+            if t == 1:
+                t0 = time.perf_counter()
+            x, y = X[t], Y[t]
+            y_hat = W @ x
+            z = beta_inv * P @ x
+            k = (1.0 + x @ z) ** (-1)
+            error = y - y_hat
+            W += torch.outer((y - k * x @ (W + torch.outer(y, z)).T), z)
+            P -= k * torch.outer(z, z)
+            _ = torch.inner(error, error)
+    return updates / (time.perf_counter() - t0)
