@@ -274,7 +274,7 @@ def main():
     # HBM bytes per launch from the PMC counters need their own rocprofv3 passes (scripts/profile_kernels.sh); the
     # figure is read from the committed summary of that run and labelled as such -- it is NOT measured by this run
     traffic, traffic_source = None, None
-    for name in ("r02_step_kernel_traffic.json", "r01_step_kernel_traffic.json"):
+    for name in ("r03_step_kernel_traffic.json", "r02_step_kernel_traffic.json", "r01_step_kernel_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if world == 1 and N == 32768 and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
