@@ -771,7 +771,10 @@ def ridge_extra(net, x, N, dev, T=2000, sampling=10, k=3):
             "steps_per_s": T / wall, "wall_s": wall, "w_out_shape": list(w.shape),
             "phases_ms": {"state_collection_Network_run": (t2 - t1) * 1e3, "stack_samples_and_targets": (t3 - t2) * 1e3,
                           "float64_gram_and_solve": (t4 - t3) * 1e3, "predictions": (t5 - t4) * 1e3,
-                          "step_kernels_alone_at_the_measured_launch_time": None},
+                          "step_kernels_alone_at_the_measured_launch_time": None,
+                          # wall of the first call minus the phases of the second: one-time library set-up (the first
+                          # torch.linalg.solve of a process creates its rocSOLVER / hipBLAS handles)
+                          "one_time_setup_in_the_first_call": wall * 1e3 - (t5 - t1) * 1e3},
             "w_out_finite": bool(torch.isfinite(w).all().item()) and bool(torch.isfinite(y).all().item())}
 
 
