@@ -629,26 +629,43 @@ def rls_extra(dev, n_in=32768, k=3, T=20, cpu_threads=None):
     n_in = 32768: P is 4.3 GB, one update = ONE fused read-modify-write pass over it (rank-1 update of step t + the
     mat-vec of step t+1; 8 n_in^2 algorithmic bytes; the reference makes three passes: 12 n_in^2 + an n_in^2 temporary)."""
     from rectipy_amd.rls import RLS
-    edge = RLS(n_in, k, beta=0.99, alpha=1.0).to(dev)
     gen = torch.Generator(device=dev).manual_seed(5)
     X = torch.randn(T, n_in, device=dev, generator=gen) * 0.1
     Y = torch.randn(T, k, device=dev, generator=gen)
-    edge.sweep(X[:3], Y[:3], 1)
-    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    edge.sweep(X, Y, 1)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / (T + 1)  # T fused passes + the initial mat-vec pass
-    gbps = 8.0 * n_in * n_in / (ms * 1e-3) / 1e9
+    ms, finite = {}, True
+    for form in ("symmetric", "dense"):  # symmetric: the default from 4 updates per call at this size
+        edge = RLS(n_in, k, beta=0.99, alpha=1.0).to(dev)
+        edge.symmetric = form == "symmetric"
+        edge.sweep(X[:5], Y[:5], 1)
+        torch.cuda.synchronize()
+        e0.record()
+        edge.sweep(X, Y, 1)
+        e1.record()
+        torch.cuda.synchronize()
+        ms[form] = e0.elapsed_time(e1) / (T + 1)  # T fused passes + the initial mat-vec pass (+ the mirror, symmetric form)
+        finite = finite and bool(torch.isfinite(edge.P).all().item())
+        del edge
+        torch.cuda.empty_cache()
+    nb = (n_in + 1023) // 1024
+    dense_bytes = 8.0 * n_in * n_in
+    sym_bytes = 8.0 * 1024.0 * 1024.0 * nb * (nb + 1) / 2 if n_in % 1024 == 0 else dense_bytes * (nb + 1) / (2.0 * nb)
+    gb_sym, gb_dense = sym_bytes / (ms["symmetric"] * 1e-3) / 1e9, dense_bytes / (ms["dense"] * 1e-3) / 1e9
     res = {"workload": f"RLS read-out training, n_in={n_in}, n_out={k}, {T} consecutive updates (rp_rls_sweep)",
-           "updates_per_s": 1e3 / ms, "ms_per_update": ms,
-           "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                        "algorithmic_bytes_per_update": 8.0 * n_in * n_in,
-                        "note": "an in-place read-modify-write of 4 GiB reaches 6.7-6.8 TB/s on this chip (DESIGN.md section 8)"},
-           "state_finite": bool(torch.isfinite(edge.P).all().item())}
-    del edge, X, Y
+           "updates_per_s": 1e3 / ms["symmetric"], "ms_per_update": ms["symmetric"],
+           "form": "symmetric pass: only the 1024 x 1024 blocks of P on and above the diagonal are streamed (P -= k z z^T "
+                   "keeps P symmetric), mirrored once per call",
+           "roofline": {"bound": "hbm", "achieved": gb_sym, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb_sym / HBM_PEAK_GBPS,
+                        "algorithmic_bytes_per_update": sym_bytes,
+                        "note": "bytes of the blocks on and above the diagonal, read + written once; the dense pass's "
+                                "8 n_in^2 bytes in this time would be " + f"{dense_bytes / (ms['symmetric'] * 1e-3) / 1e9:.0f} GB/s"},
+           "dense_pass": {"ms_per_update": ms["dense"], "updates_per_s": 1e3 / ms["dense"],
+                          "roofline": {"bound": "hbm", "achieved": gb_dense, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                       "frac": gb_dense / HBM_PEAK_GBPS, "algorithmic_bytes_per_update": dense_bytes,
+                                       "note": "an in-place read-modify-write of 4 GiB reaches 6.7-6.8 TB/s on this chip"}},
+           "speedup_over_dense_pass": ms["dense"] / ms["symmetric"],
+           "state_finite": finite}
+    del X, Y
     torch.cuda.empty_cache()
     if cpu_threads is not None:
         from oracle.torch_eager import time_eager_rls

@@ -434,6 +434,18 @@ typedef struct rp_rls {
        sweep P in address order, each takes one 4 KiB tile (row i, 1024 columns) and leaves the tile's partial dot
        product here; z'_i = beta_inv * (sum of row i's partials, ascending).  NULL: one wave per row (small n_in). */
     float* partials;
+    /* optional workspace [(ceil(n_in / sym_rows) + ceil(n_in / 1024)) x ldc] (ldc >= n_in, ldc % 4 == 0; needs `partials`
+       too): selects the SYMMETRIC pass.  P -= k z z^T keeps P symmetric (the reference's k * outer(z, z) does so exactly),
+       so only the 1024 x 1024 blocks on and above the diagonal are streamed -- 4 n_in^2 instead of 8 n_in^2 bytes per
+       update -- and every off-diagonal element serves both P_ij x_j (row partials, as in the tiled pass) and P_ij x_i
+       (column partials per chunk of sym_rows rows: an i-ascending fmaf chain from 0; the chunks of a block row are added
+       in ascending order to the block's column sum).  z'_i = beta_inv * (the column sums of the block rows above i's,
+       ascending, then the row's tile partials from its diagonal block on, ascending).  On entry the blocks on and above
+       the diagonal are authoritative (whatever the lower ones hold); on return the off-diagonal blocks have been
+       mirrored, so P is full again.  Worth it from a few updates per call (the mirror costs about one dense pass). */
+    float* colparts;
+    int64_t ldc;
+    int32_t sym_rows;  /* rows per chunk of the symmetric pass: 16, 32 or 64 (0: 64); part of its summation order */
 } rp_rls;
 
 /* `steps` consecutive rows of X [steps x ldx] (edge inputs) and Y [steps x ldy] (targets); an update happens at
@@ -485,6 +497,7 @@ int rp_set_bwd_chunks(int max_chunks);
 
 /* Benchmark-only: rows per wave, column chunks in flight and store policy (-1 = default) of the RLS pass. */
 int rp_set_rls_tuning(int rows_per_wave, int unroll, int nontemporal_store);
+int rp_set_rls_sym(int rows_in_flight); /* benchmark-only: rows in flight per wave of the symmetric pass (1, 2, 4, 8; 0 = built-in); never the bits */
 int rp_set_rls_tile(int kcols_per_tile, int workgroups_per_cu); /* benchmark-only: tile width (x 1024 columns; changes the summation order) and residency cap of the tiled RLS pass; 0, 0 = built-in */
 
 /* Bandwidth probe used by bench.py: sums `bytes` of HBM with the same load shape as the step kernel. */

@@ -82,18 +82,96 @@ static float pass_row_tiled(float* p, int n, int update, float kz, const float* 
     return total;
 }
 
+/* symmetric pass (rp_rls.colparts given; rls_sym_kernel / rls_sym_colsum_kernel / rls_sym_zn_kernel / rls_mirror_kernel
+   of rls.hip): only the 1024 x 1024 blocks on and above the diagonal are visited, as tiles of R = sym_rows rows x 1024
+   columns.  Per tile and row: the optional rank-1 update, the row's tile partial (the tiled pass's tree) and, above the
+   diagonal, the column partial chain over the tile's rows.  colsum[I][j] = the chunks of block row I, ascending;
+   zn_i = beta_inv * (colsum[0][i] + ... + colsum[I_i - 1][i], then the row partials from the diagonal block on). */
+static void sym_pass(const rp_rls* r, int update, float k, const float* z, const float* x_next, float* zn) {
+    const int R = r->sym_rows > 0 ? r->sym_rows : 64;
+    const int n = r->n_in, nb = (n + 1023) / 1024, chunks = (n + R - 1) / R, per_block = 1024 / R;
+#pragma omp parallel for schedule(dynamic)
+    for (int chunk = 0; chunk < chunks; ++chunk) {
+        const int row0 = chunk * R, I = row0 >> 10;
+        for (int ct = I; ct < nb; ++ct) {
+            const int c0 = ct * 1024;
+            float cp[1024];
+            for (int q = 0; q < 1024; ++q) cp[q] = 0.0f;
+            for (int rr = 0; rr < R && row0 + rr < n; ++rr) {
+                const int i = row0 + rr;
+                float* p = r->P + (int64_t)i * r->ldp;
+                if (update) {
+                    const float kz = k * z[i];
+                    for (int q = 0; q < 1024 && c0 + q < n; ++q) p[c0 + q] = p[c0 + q] - kz * z[c0 + q];
+                }
+                if (!x_next) continue;
+                float sw[4];
+                for (int w = 0; w < 4; ++w) {
+                    float a[256], s[64];
+                    for (int q = 0; q < 256; ++q) {
+                        const int j = c0 + 256 * w + q;
+                        a[q] = j < n ? fmaf(p[j], x_next[j], 0.0f) : 0.0f;
+                    }
+                    for (int l = 0; l < 64; ++l) s[l] = (a[4 * l] + a[4 * l + 1]) + (a[4 * l + 2] + a[4 * l + 3]);
+                    sw[w] = butterfly64(s);
+                }
+                r->partials[(int64_t)i * nb + ct] = ((sw[0] + sw[1]) + sw[2]) + sw[3];
+                if (ct > I)
+                    for (int q = 0; q < 1024 && c0 + q < n; ++q) cp[q] = fmaf(p[c0 + q], x_next[i], cp[q]);
+            }
+            if (x_next && ct > I)
+                for (int q = 0; q < 1024 && c0 + q < n; ++q) r->colparts[(int64_t)chunk * r->ldc + c0 + q] = cp[q];
+        }
+    }
+    if (!x_next) return;
+    for (int I = 0; I + 1 < nb; ++I) {
+        const int c0 = I * per_block, c1 = c0 + per_block < chunks ? c0 + per_block : chunks;
+        for (int j = (I + 1) << 10; j < n; ++j) {
+            float s = r->colparts[(int64_t)c0 * r->ldc + j];
+            for (int c = c0 + 1; c < c1; ++c) s = s + r->colparts[(int64_t)c * r->ldc + j];
+            r->colparts[(int64_t)(chunks + I) * r->ldc + j] = s;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const int I = i >> 10;
+        float s = 0.0f;
+        int first = 1;
+        for (int b = 0; b < I; ++b) {
+            const float v = r->colparts[(int64_t)(chunks + b) * r->ldc + i];
+            s = first ? v : s + v;
+            first = 0;
+        }
+        for (int ct = I; ct < nb; ++ct) {
+            const float v = r->partials[(int64_t)i * nb + ct];
+            s = first ? v : s + v;
+            first = 0;
+        }
+        zn[i] = r->beta_inv * s;
+    }
+}
+
+static void sym_mirror(const rp_rls* r) {
+    const int n = r->n_in;
+    for (int i = 0; i < n; ++i)
+        for (int j = ((i >> 10) + 1) << 10; j < n; ++j) r->P[(int64_t)j * r->ldp + i] = r->P[(int64_t)i * r->ldp + j];
+}
+
 int oracle_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, const float* X, int64_t ldx, const float* Y,
                      int64_t ldy, float* pred, int64_t ldpred, float* loss) {
     const int n = r->n_in, m = r->n_out;
     if (steps == 0) return RP_OK;
     const int vec4 = (n % 4 == 0) && (r->ldp % 4 == 0) && (ldx % 4 == 0);
     const int tiled = vec4 && r->partials != 0;
+    const int sym = tiled && r->colparts != 0;
     float* za = r->z;
     float* zb = r->zn;
     float* err = r->scratch + 4;
-    for (int i = 0; i < n; ++i)
-        za[i] = r->beta_inv * (tiled ? pass_row_tiled(r->P + (int64_t)i * r->ldp, n, 0, 0.0f, 0, X)
-                                     : pass_row(r->P + (int64_t)i * r->ldp, n, vec4, 0, 0.0f, 0, X));
+    if (sym)
+        sym_pass(r, 0, 0.0f, 0, X, za);
+    else
+        for (int i = 0; i < n; ++i)
+            za[i] = r->beta_inv * (tiled ? pass_row_tiled(r->P + (int64_t)i * r->ldp, n, 0, 0.0f, 0, X)
+                                         : pass_row(r->P + (int64_t)i * r->ldp, n, vec4, 0, 0.0f, 0, X));
     for (int t = 0; t < steps; t += stride) {
         const float* x = X + (int64_t)t * ldx;
         const float* y = Y + (int64_t)t * ldy;
@@ -116,8 +194,9 @@ int oracle_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, const float
             }
         const int next = t + stride;
         const float* x_next = next < steps ? X + (int64_t)next * ldx : 0;
+        if (sym) sym_pass(r, 1, k, za, x_next, zb);
 #pragma omp parallel for schedule(static)
-        for (int i = 0; i < n; ++i) {
+        for (int i = 0; i < (sym ? 0 : n); ++i) {
             const float v = tiled ? pass_row_tiled(r->P + (int64_t)i * r->ldp, n, 1, k * za[i], za, x_next)
                                   : pass_row(r->P + (int64_t)i * r->ldp, n, vec4, 1, k * za[i], za, x_next);
             if (x_next) zb[i] = r->beta_inv * v;
@@ -130,5 +209,6 @@ int oracle_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, const float
         za = zb;
         zb = tmp;
     }
+    if (sym) sym_mirror(r);
     return RP_OK;
 }

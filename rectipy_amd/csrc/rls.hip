@@ -42,6 +42,8 @@ struct RlsParams {
     int loss_count;
     int no_dot;  // benchmark-only: skip the mat-vec half of the pass
     float* partials;  // tiled pass: [n_in x tiles_per_row] partial dot products
+    float* colparts;  // symmetric pass: [ceil(n_in / 64) x ldc] column partials of the off-diagonal blocks
+    int64_t ldc;
 };
 
 // One block: d = x.z (fixed tree), k = 1/(1+d), y_hat = W x, err = y - y_hat, loss = err.err
@@ -292,6 +294,235 @@ __global__ void rls_zn_kernel(const RlsParams P, int tile_cols) {
     P.zn[i] = P.beta_inv * s;
 }
 
+// ---- symmetric pass (rp_rls.colparts given) -----------------------------------------------------------------------------
+// P -= k z z^T keeps P symmetric, so only the blocks on and above the diagonal of a 1024 x 1024 block grid are streamed:
+// 4 n^2 instead of 8 n^2 bytes per update (plus the diagonal blocks, 1 / nb of P, which are kept whole).  A ONE-SHOT
+// workgroup takes the tile (rows [R c, R c + R), columns [1024 ct, 1024 ct + 1024)) with ct >= I = (R c) >> 10 -- all its
+// loads first, as the tiled pass (the walk that reaches the chip's read-modify-write rate); thread (wave w, lane l) owns
+// columns 1024 ct + 256 w + 4 l .. +3 of all R rows.  Per row: P_ij -= (k z_i) z_j, store, and the tile's share of the
+// mat-vec z' = beta^-1 P x in BOTH roles of the element:
+//   row role     rowpart[i][ct] = tile partial of sum_j P_ij x_j: products, lane sum (a0+a1)+(a2+a3), the butterfly over
+//                the 64 lanes (done for the R rows together by a transposed butterfly: R - 1 + log2(64 / R) shuffles
+//                instead of 6 R, the same additions), the four wave sums added in wave order -- the tiled pass's partial
+//   column role  (ct > I only) colpart[c][j] = fmaf chain over the tile's rows i ascending of P_ij x_i, from 0
+// rls_sym_colsum_kernel: colsum[I][j] = colpart chain over the chunks c of block row I, ascending.
+// rls_sym_zn_kernel: z'_i = beta^-1 (colsum[0][i] + ... + colsum[I_i - 1][i], then rowpart[i][I_i] + ... ascending).
+// After the last update of a sweep rls_mirror_kernel copies the off-diagonal blocks to their transposed positions, so the
+// caller always sees a full P.  Mirrored by oracle/rls_oracle.c.
+template <int R>
+__device__ __forceinline__ float rows_allreduce(float (&v)[R], int lane) {
+    // sums over the 64 lanes of R per-lane values at once; afterwards lane l holds the total of value
+    // (bits of l selected level by level); same pairings (l, l ^ 32), (l, l ^ 16), ... as rp_wave_allreduce
+    int width = R;
+    int off = 32;
+#pragma unroll
+    for (; width > 1; width >>= 1, off >>= 1) {
+        const bool hi = (lane & off) != 0;
+#pragma unroll
+        for (int q = 0; q < width / 2; ++q) {
+            const float send = hi ? v[q] : v[q + width / 2];
+            const float keep = hi ? v[q + width / 2] : v[q];
+            v[q] = keep + __shfl_xor(send, off, 64);
+        }
+    }
+    float s = v[0];
+#pragma unroll
+    for (; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+    return s;
+}
+
+// C = rows per tile (the chunk of the column partials: part of the summation order), R = rows in flight per wave (how the
+// tile is walked: groups of R rows, the next group's loads issued before the current one is processed; never the order).
+template <bool UPDATE, int C, int R>
+__global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
+    __shared__ float wsum[C][4];
+    __shared__ float zrow[C], xrow[C];
+    static_assert(C % R == 0 && (R & (R - 1)) == 0 && R <= 64, "groups of R rows");
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = P.n_in;
+    const int nb = (n + 1023) >> 10;
+    // blockIdx.x enumerates the block pairs (I, ct >= I) row by row -- only tiles that exist are launched --, blockIdx.y
+    // the chunk inside block row I
+    int b = blockIdx.x, I = 0;
+    while (b >= nb - I) {
+        b -= nb - I;
+        ++I;
+    }
+    const int ct = I + b;
+    const int chunk = I * (1024 / C) + blockIdx.y;
+    const int row0 = chunk * C;
+    if (row0 >= n) return;
+    const bool upper = ct > I;
+    const int col = ct * 1024 + 256 * wave + 4 * lane;
+    const bool valid = col < n;
+    const bool dot = P.x_next != nullptr;
+    const rp_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float* base = P.P + (int64_t)row0 * P.ldp + col;
+    rp_f4 cur[R], nxt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) cur[r] = (valid && row0 + r < n) ? rp_ld4_stream(base + (int64_t)r * P.ldp) : zero4;
+    const rp_f4 zv = (UPDATE && valid) ? rp_ld4(P.z + col) : zero4;
+    const rp_f4 xv = (dot && valid) ? rp_ld4(P.x_next + col) : zero4;
+    if (threadIdx.x < C) {
+        const int i = row0 + threadIdx.x;
+        zrow[threadIdx.x] = (UPDATE && i < n) ? P.z[i] : 0.f;
+        xrow[threadIdx.x] = (dot && i < n) ? P.x_next[i] : 0.f;
+    }
+    const float k = UPDATE ? P.scal[0] : 0.f;
+    __syncthreads();
+    rp_f4 cp = zero4;
+    constexpr int kGroup = 64 / R;  // lanes that hold the same row's total after the transposed butterfly
+#pragma unroll 1
+    for (int g = 0; g < C; g += R) {
+        if (g + R < C) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                nxt[r] = (valid && row0 + g + R + r < n) ? rp_ld4_stream(base + (int64_t)(g + R + r) * P.ldp) : zero4;
+        }
+        float rs[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = row0 + g + r;
+            rp_f4 p = cur[r];
+            if constexpr (UPDATE) {
+                const float kz = k * zrow[g + r];
+                p.x = p.x - kz * zv.x;
+                p.y = p.y - kz * zv.y;
+                p.z = p.z - kz * zv.z;
+                p.w = p.w - kz * zv.w;
+                if (valid && i < n) __builtin_nontemporal_store(p, reinterpret_cast<rp_f4*>(base + (int64_t)(g + r) * P.ldp));
+            }
+            rp_f4 a;
+            a.x = fmaf(p.x, xv.x, 0.f);
+            a.y = fmaf(p.y, xv.y, 0.f);
+            a.z = fmaf(p.z, xv.z, 0.f);
+            a.w = fmaf(p.w, xv.w, 0.f);
+            rs[r] = rp_lane_sum4(a);
+            if (upper && i < n) {  // (rows past the end must not touch the chain: the oracle stops at n)
+                const float xi = xrow[g + r];
+                cp.x = fmaf(p.x, xi, cp.x);
+                cp.y = fmaf(p.y, xi, cp.y);
+                cp.z = fmaf(p.z, xi, cp.z);
+                cp.w = fmaf(p.w, xi, cp.w);
+            }
+        }
+        if (dot) {
+            const float total = rows_allreduce<R>(rs, lane);
+            if ((lane & (kGroup - 1)) == 0) {  // the row index of a lane's total is spelled by its lane bits, high bit first
+                int r = 0;
+                int width = R, off = 32;
+                for (; width > 1; width >>= 1, off >>= 1) r += (lane & off) ? width / 2 : 0;
+                wsum[g + r][wave] = total;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+    }
+    if (!dot) return;
+    __syncthreads();
+    if (threadIdx.x < C && row0 + (int)threadIdx.x < n) {
+        const int r = threadIdx.x;
+        P.partials[(int64_t)(row0 + r) * nb + ct] = ((wsum[r][0] + wsum[r][1]) + wsum[r][2]) + wsum[r][3];
+    }
+    if (upper && valid) *reinterpret_cast<rp_f4*>(P.colparts + (int64_t)chunk * P.ldc + col) = cp;
+}
+
+// colsum[I][j] (stored behind the chunk rows of the workspace) = colpart[c][j] over the chunks c of block row I, ascending
+__global__ void rls_sym_colsum_kernel(const RlsParams P, int rows_per_chunk) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int I = blockIdx.y;
+    if (j >= P.n_in || (j >> 10) <= I) return;
+    const int chunks = (P.n_in + rows_per_chunk - 1) / rows_per_chunk;
+    const int per_block = 1024 / rows_per_chunk;
+    const int c0 = I * per_block;
+    const int c1 = (c0 + per_block < chunks) ? c0 + per_block : chunks;
+    float s = P.colparts[(int64_t)c0 * P.ldc + j];
+    int c = c0 + 1;
+    for (; c + 8 <= c1; c += 8) {  // eight independent loads in flight, added in ascending order
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = P.colparts[(int64_t)(c + q) * P.ldc + j];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s = s + v[q];
+    }
+    for (; c < c1; ++c) s = s + P.colparts[(int64_t)c * P.ldc + j];
+    P.colparts[(int64_t)(chunks + I) * P.ldc + j] = s;
+}
+
+__global__ void rls_sym_zn_kernel(const RlsParams P, int rows_per_chunk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_in) return;
+    const int nb = (P.n_in + 1023) >> 10;
+    const int chunks = (P.n_in + rows_per_chunk - 1) / rows_per_chunk;
+    const int I = i >> 10;
+    float s = 0.f;
+    bool first = true;
+    for (int b = 0; b < I; ++b) {
+        const float v = P.colparts[(int64_t)(chunks + b) * P.ldc + i];
+        s = first ? v : s + v;
+        first = false;
+    }
+    const float* part = P.partials + (int64_t)i * nb;
+    for (int ct = I; ct < nb; ++ct) {
+        s = first ? part[ct] : s + part[ct];
+        first = false;
+    }
+    P.zn[i] = P.beta_inv * s;
+}
+
+// P[j][i] = P[i][j] for the 32 x 32 tile (ti, tj) of an off-diagonal block (ti >> 5 < tj >> 5), through LDS
+__global__ __launch_bounds__(kThreads) void rls_mirror_kernel(float* Pm, int64_t ldp, int n) {
+    __shared__ float tile[32][33];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if ((ti >> 5) >= (tj >> 5)) return;
+    const int r = threadIdx.x >> 3, q = threadIdx.x & 7;  // 32 rows x 8 quads
+    const int i = ti * 32 + r, j = tj * 32 + 4 * q;
+    if (i < n && j < n) {  // (n % 4 == 0)
+        const rp_f4 v = rp_ld4_stream(Pm + (int64_t)i * ldp + j);
+        tile[r][4 * q + 0] = v.x;
+        tile[r][4 * q + 1] = v.y;
+        tile[r][4 * q + 2] = v.z;
+        tile[r][4 * q + 3] = v.w;
+    }
+    __syncthreads();
+    const int jj = tj * 32 + r, ii = ti * 32 + 4 * q;  // row jj of the mirrored tile, columns ii .. ii+3
+    if (jj < n && ii < n) {
+        rp_f4 v;
+        v.x = tile[4 * q + 0][r];
+        v.y = tile[4 * q + 1][r];
+        v.z = tile[4 * q + 2][r];
+        v.w = tile[4 * q + 3][r];
+        __builtin_nontemporal_store(v, reinterpret_cast<rp_f4*>(Pm + (int64_t)jj * ldp + ii));
+    }
+}
+
+constexpr int kSymRowsDefault = 64;
+std::atomic<int> g_sym_inflight{0};  // benchmark-only (rp_set_rls_sym): rows in flight per wave; 0 = built-in
+
+template <bool UPDATE, int C, int R>
+void launch_sym_rows(const RlsParams& P, hipStream_t st) {
+    const int nb = (P.n_in + 1023) >> 10;
+    hipLaunchKernelGGL((rls_sym_kernel<UPDATE, C, R>), dim3(nb * (nb + 1) / 2, 1024 / C), dim3(kThreads), 0, st, P);
+    if (P.x_next) {
+        if (nb > 1) hipLaunchKernelGGL(rls_sym_colsum_kernel, dim3((P.n_in + 255) / 256, nb - 1), dim3(256), 0, st, P, C);
+        hipLaunchKernelGGL(rls_sym_zn_kernel, dim3((P.n_in + 255) / 256), dim3(256), 0, st, P, C);
+    }
+}
+
+template <bool UPDATE>
+int launch_sym(const RlsParams& P, int rows, hipStream_t st) {
+    const int inflight = g_sym_inflight > 0 ? (int)g_sym_inflight : 4;
+    switch (rows * 100 + inflight) {
+#define RP_SYM(C_, R_) case C_ * 100 + R_: launch_sym_rows<UPDATE, C_, R_>(P, st); return RP_OK;
+        RP_SYM(16, 2) RP_SYM(16, 4) RP_SYM(16, 8) RP_SYM(16, 16)
+        RP_SYM(32, 2) RP_SYM(32, 4) RP_SYM(32, 8)
+        RP_SYM(64, 1) RP_SYM(64, 2) RP_SYM(64, 4) RP_SYM(64, 8)
+#undef RP_SYM
+        default: return RP_ERR_ARG;
+    }
+}
+
 std::atomic<int> g_rls_R{0}, g_rls_U{0}, g_rls_nts{-1};  // benchmark-only override (rp_set_rls_tuning)
 
 std::atomic<int> g_rls_blocks{0};  // benchmark-only: grid cap override
@@ -356,6 +587,11 @@ void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int rp_set_rls_sym(int rows_in_flight) {
+    g_sym_inflight = rows_in_flight;
+    return RP_OK;
+}
+
 extern "C" int rp_set_rls_tile(int kcols_per_tile, int workgroups_per_cu) {
     if (kcols_per_tile != 0 && kcols_per_tile != 1 && kcols_per_tile != 2 && kcols_per_tile != 4)
         RP_FAIL(RP_ERR_ARG, "rp_set_rls_tile: tile of %d x 1024 columns is not built", kcols_per_tile);
@@ -399,6 +635,14 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
     P.scal = r->scratch;
     P.err = r->scratch + 4;
     P.partials = vec4 ? r->partials : nullptr;
+    const bool sym = vec4 && r->partials && r->colparts;
+    if (r->colparts && !sym) RP_FAIL(RP_ERR_ARG, "the symmetric pass (colparts) needs partials and the 16-byte path");
+    if (sym && (r->ldc < r->n_in || r->ldc % 4 != 0 || (reinterpret_cast<uintptr_t>(r->colparts) & 15u)))
+        RP_FAIL(RP_ERR_SHAPE, "colparts: ldc >= n_in, ldc %% 4 == 0 and 16-byte alignment required");
+    P.colparts = sym ? r->colparts : nullptr;
+    P.ldc = r->ldc;
+    const int sym_rows = r->sym_rows > 0 ? r->sym_rows : kSymRowsDefault;
+    if (sym && sym_rows != 16 && sym_rows != 32 && sym_rows != 64) RP_FAIL(RP_ERR_ARG, "sym_rows must be 16, 32 or 64, got %d", sym_rows);
     float* za = r->z;
     float* zb = r->zn;
 
@@ -406,7 +650,8 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
     P.z = za;
     P.zn = za;
     P.x_next = X;
-    launch_pass<false>(P, vec4, st);
+    if (sym && launch_sym<false>(P, sym_rows, st) != RP_OK) RP_FAIL(RP_ERR_ARG, "no symmetric RLS kernel for %d rows per tile with this tuning", sym_rows);
+    if (!sym) launch_pass<false>(P, vec4, st);
 
     const int eblocks = (r->n_in + 255) / 256;
     for (int t = 0; t < steps; t += stride) {
@@ -421,7 +666,8 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
         hipLaunchKernelGGL(rls_weights_kernel, dim3(eblocks), dim3(256), 0, st, P);
         const int next = t + stride;
         P.x_next = next < steps ? X + (int64_t)next * ldx : nullptr;
-        launch_pass<true>(P, vec4, st);
+        if (sym) (void)launch_sym<true>(P, sym_rows, st);
+        else launch_pass<true>(P, vec4, st);
         if (pred && stride > 1) {  // steps between updates are predicted with the updated weights
             const int count = (next <= steps ? stride : steps - t) - 1;
             if (count > 0) {
@@ -434,6 +680,10 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
         float* tmp = za;
         za = zb;
         zb = tmp;
+    }
+    if (sym) {  // the caller sees a full P again: off-diagonal blocks copied to their transposed positions
+        const int t32 = (r->n_in + 31) / 32;
+        hipLaunchKernelGGL(rls_mirror_kernel, dim3(t32, t32), dim3(kThreads), 0, st, r->P, r->ldp, r->n_in);
     }
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;

@@ -33,8 +33,15 @@ class RLS(Linear):
         self._backend = backend
         self._scratch = None
         self._partials = None
+        self._colparts = None
         self.tiled = None  # None: by size; True / False: force the tiled / row-per-wave pass (tests, measurements)
+        self.symmetric = None  # None: by size and updates per call; True / False: force / forbid the symmetric pass
 
+    # The symmetric pass streams only the blocks of P on and above the diagonal (4 n^2 instead of 8 n^2 bytes per update)
+    # and mirrors them once per call: from a few updates per call on, on matrices far beyond the caches
+    SYMMETRIC_ROWS = 64  # rows per tile of the symmetric pass (part of its summation order: rp_rls.sym_rows)
+    SYMMETRIC_MIN_N = 8192
+    SYMMETRIC_MIN_UPDATES = 4
     TILED_MIN_N = 8192  # measured (scripts/bench_rls.py, ms per update tiled / row-per-wave): n_in = 8192 0.108 / 0.113, 16384 0.386 / 0.401, 32768 1.43 / 1.68
 
     def to(self, device: str, **kwargs):
@@ -91,6 +98,17 @@ class RLS(Linear):
         r.beta_inv = float(self.beta)
         r.z, r.zn, r.scratch = z.data_ptr(), zn.data_ptr(), scratch.data_ptr()
         r.partials = None if self._partials is None else self._partials.data_ptr()
+        updates = (T + int(stride) - 1) // int(stride)
+        use_sym = self._partials is not None and (
+            self.symmetric is True or (self.symmetric is None and self.n_in >= self.SYMMETRIC_MIN_N
+                                       and updates >= self.SYMMETRIC_MIN_UPDATES))
+        if use_sym:
+            rows = self.SYMMETRIC_ROWS
+            if self._colparts is None or self._colparts.shape[0] != (self.n_in + rows - 1) // rows + (self.n_in + 1023) // 1024:
+                # column partials per chunk of `rows` rows, then one column sum per 1024-row block row
+                self._colparts = torch.zeros((self.n_in + rows - 1) // rows + (self.n_in + 1023) // 1024, self.n_in,
+                                             dtype=torch.float32, device=dev)
+            r.colparts, r.ldc, r.sym_rows = self._colparts.data_ptr(), self._colparts.stride(0), rows
         self._backend.rls_sweep(r, T, int(stride), X.data_ptr(), X.stride(0) if T > 1 else self.n_in, Y.data_ptr(),
                                 Y.stride(0) if T > 1 else self.n_out, pred.data_ptr(), self.n_out, loss.data_ptr(), dev)
         self.loss = loss[-1]

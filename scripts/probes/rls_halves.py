@@ -24,3 +24,15 @@ for label, (R, U, nts), (tile, per_cu) in (("default", (0, 0, -1), (0, 0)), ("no
     print(json.dumps({"variant": label, "ms_per_update": round(ms, 4), "TBps": round(8.0 * n * n / ms / 1e9, 3)}), flush=True)
 lib.rp_set_rls_tuning(0, 0, -1)
 lib.rp_set_rls_tile(0, 0)
+
+for sym in (False, True, None):
+    edge2 = RLS(n, k, beta=0.99, alpha=1.0).to(dev)
+    edge2.symmetric = sym
+    edge2.sweep(X[:5], Y[:5], 1)
+    torch.cuda.synchronize()
+    e0.record(); edge2.sweep(X, Y, 1); e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / (T + 1)
+    print(json.dumps({"variant": f"symmetric={sym}", "ms_per_update_incl_mirror": round(ms, 4),
+                      "TBps_of_8n2": round(8.0 * n * n / ms / 1e9, 3), "finite": bool(torch.isfinite(edge2.P).all().item())}), flush=True)
+    del edge2
+    torch.cuda.empty_cache()

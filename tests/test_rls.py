@@ -36,11 +36,12 @@ def build(g, target):
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
 @pytest.mark.parametrize("stride", [1, 4])
-@pytest.mark.parametrize("tiled", [False, True], ids=["row-per-wave", "tiled"])
+@pytest.mark.parametrize("tiled", [False, True, "symmetric"], ids=["row-per-wave", "tiled", "symmetric"])
 def test_g14_fit_rls_matches_reference(target, stride, tiled):
     g = dict(np.load(os.path.join(GOLD, "g14_rls.npz")))
     net, edge = build(g, target)
-    edge.tiled = tiled and g["W"].shape[0] % 4 == 0
+    edge.symmetric = tiled == "symmetric" and g["W"].shape[0] % 4 == 0
+    edge.tiled = bool(tiled) and g["W"].shape[0] % 4 == 0
     assert isinstance(edge, RLS) and abs(edge.beta - 1 / 0.95) < 1e-12
     obs = net.fit_rls(g["x"], g["target"], update_steps=stride, sampling_steps=1, verbose=False)
     key = f"s{stride}_f64"
@@ -90,10 +91,14 @@ def test_fit_rls_epochs_recovers_readout(target):
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_in,n_out,T,stride,tiled", [(40, 3, 30, 1, False), (256, 2, 25, 3, False), (1000, 4, 12, 1, False),
                                                        (1030, 1, 9, 2, False), (256, 2, 25, 3, True), (1000, 4, 12, 1, True),
-                                                       (4100, 2, 6, 1, True), (9000, 3, 4, 2, None)])
+                                                       (4100, 2, 6, 1, True), (9000, 3, 4, 2, None),
+                                                       (256, 2, 25, 3, "sym"), (1000, 4, 12, 1, "sym"), (2048, 2, 8, 1, "sym"),
+                                                       (4100, 2, 6, 1, "sym"), (3140, 3, 7, 2, "sym"), (9000, 3, 9, 2, None)])
 def test_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride, tiled):
-    """Row-per-wave pass and the tiled pass (P walked in address order by one-shot workgroups, 1024-column tiles with
-    per-tile partial sums; chosen by size from n_in = 8192), ragged last tiles included."""
+    """Row-per-wave pass, the tiled pass (P walked in address order by one-shot workgroups, 1024-column tiles with
+    per-tile partial sums; chosen by size from n_in = 8192) and the symmetric pass (only the blocks on and above the
+    diagonal are streamed; row and column partials; mirror at the end: "sym", and by size from 4 updates per call),
+    ragged last tiles / chunks / blocks included."""
     gen = torch.Generator().manual_seed(n_in + T)
     X = torch.randn(T, n_in, generator=gen)
     Y = torch.randn(T, n_out, generator=gen)
@@ -101,9 +106,18 @@ def test_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride,
     res = []
     for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
         edge = RLS(n_in, n_out, weights=W0.clone(), beta=0.97, alpha=1.5, backend=backend).to(dev)
-        edge.tiled = tiled
+        edge.tiled = True if tiled == "sym" else tiled
+        edge.symmetric = True if tiled == "sym" else None
         pred, loss = edge.sweep(X.to(dev), Y.to(dev), stride)
-        assert (edge._partials is not None) == (tiled is True or (tiled is None and n_in >= RLS.TILED_MIN_N))
+        assert (edge._partials is not None) == (bool(tiled) or (tiled is None and n_in >= RLS.TILED_MIN_N))
+        updates = (T + stride - 1) // stride
+        assert (edge._colparts is not None) == (tiled == "sym" or (tiled is None and n_in >= RLS.SYMMETRIC_MIN_N
+                                                                   and updates >= RLS.SYMMETRIC_MIN_UPDATES))
+        if edge._colparts is not None:  # the caller sees a full P again: mirrored between the blocks
+            Pm = edge.P.cpu()
+            blk = torch.arange(n_in) // 1024
+            off = blk[:, None] != blk[None, :]
+            assert torch.equal(Pm[off], Pm.T[off])
         res.append([t.cpu().numpy() for t in (pred, loss, edge.weights, edge.P)])
     for a, b, name in zip(res[0], res[1], ("pred", "loss", "weights", "P")):
         same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
@@ -111,8 +125,10 @@ def test_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride,
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
-@pytest.mark.parametrize("n,tiled", [(520, False), (520, True), (2060, False), (2060, True), (1030, False), (777, False)],
-                         ids=["n520-rows", "n520-tiled", "n2060-rows", "n2060-tiled", "n1030-4byte", "n777-4byte"])
+@pytest.mark.parametrize("n,tiled", [(520, False), (520, True), (2060, False), (2060, True), (1030, False), (777, False),
+                                     (2060, "symmetric"), (520, "symmetric")],
+                         ids=["n520-rows", "n520-tiled", "n2060-rows", "n2060-tiled", "n1030-4byte", "n777-4byte",
+                              "n2060-symmetric", "n520-symmetric"])
 def test_g31_fit_rls_at_kernel_sizes_matches_reference(target, n, tiled):
     """Golden G31 (tests/golden/make_golden_rls_large.py): the reference's fit_rls at sizes where the 16-byte row pass
     (full 256-column chunks), the tiled pass (two full 1024-column tiles + a ragged one at n = 2060) and the 4-byte pass
@@ -132,7 +148,8 @@ def test_g31_fit_rls_at_kernel_sizes_matches_reference(target, n, tiled):
     for name, arr in (("W", P["W"]), ("x", x), ("target", tgt), ("W0", W0)):
         assert np.array_equal(recipes.fingerprint(arr), g["fp_" + name]), f"regenerated {name} differs from the generator's"
     net, edge = build(dict(dt=g["dt"], W0=W0, beta=g["beta"], alpha=g["alpha"], **P), target)
-    edge.tiled = tiled
+    edge.symmetric = tiled == "symmetric"
+    edge.tiled = bool(tiled)
     obs = net.fit_rls(x, tgt, update_steps=stride, sampling_steps=1, verbose=False)
     W_ref, rows = g["W_after_f64"], g["rows"]
     Pm = edge.P.cpu().numpy()
