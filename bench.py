@@ -130,6 +130,16 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher around us: become the launcher (nothing above this line has touched the GPU)
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    # stdout carries the ONE JSON line and nothing else: libraries that print to the C-level stdout (RCCL's version banner
+    # at communicator creation, hipBLASLt notices) are sent to stderr for the whole run; the line is written to the saved
+    # descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line: str):
+        os.write(json_fd, (line + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -334,7 +344,7 @@ def main():
         out["extra"]["rls_n32768"] = rls_extra(dev, cpu_threads=cpu_threads)
         out["extra"]["qif_n65536"] = qif_extra(dev, cpu_threads=cpu_threads)
         out["extra"]["sparse_p0.1_n32768"] = sparse_extra(dev)
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
 
