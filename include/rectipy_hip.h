@@ -497,6 +497,7 @@ int rp_set_bwd_chunks(int max_chunks);
 
 /* Benchmark-only: rows per wave, column chunks in flight and store policy (-1 = default) of the RLS pass. */
 int rp_set_rls_tuning(int rows_per_wave, int unroll, int nontemporal_store);
+int rp_set_gemm_dma(int on); /* benchmark-only: 0 = rp_outer_accum always uses the register-staged kernel (1: LDS-DMA ring on full tiles); identical bits */
 int rp_set_rls_sym(int rows_in_flight); /* benchmark-only: rows in flight per wave of the symmetric pass (1, 2, 4, 8; 0 = built-in); never the bits */
 int rp_set_rls_tile(int kcols_per_tile, int workgroups_per_cu); /* benchmark-only: tile width (x 1024 columns; changes the summation order) and residency cap of the tiled RLS pass; 0, 0 = built-in */
 
