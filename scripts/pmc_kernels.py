@@ -50,9 +50,36 @@ del sp, packed
 
 n_in = 16384
 edge = RLS(n_in, 3, beta=0.99).to(dev)
+edge.symmetric = False
 X = torch.randn(6, n_in, device=dev) * 0.1
 Y = torch.randn(6, 3, device=dev)
 edge.sweep(X, Y, 1)
 torch.cuda.synchronize()
 algo["rls_tile_kernel"] = 8.0 * n_in * n_in + 8.0 * n_in * (n_in // 1024)                      # P read + written once per update
+# r03: the symmetric pass streams the 1024 x 1024 blocks on and above the diagonal (read + written once per update) and
+# writes one column partial per 64-row tile above the diagonal
+edge2 = RLS(n_in, 3, beta=0.99).to(dev)
+edge2.symmetric = True
+edge2.sweep(X, Y, 1)
+torch.cuda.synchronize()
+nb = n_in // 1024
+algo["rls_sym_kernel<true"] = 8.0 * 1024 * 1024 * nb * (nb + 1) / 2 + 4.0 * (n_in // 64) * n_in / 2
+del edge, edge2
+
+# r03: the batched matrix-core steps (W once per step for all trajectories; the source tiles come from L2)
+import bench  # noqa: E402
+from rectipy_amd.engine import BatchedPopulation  # noqa: E402
+Wb = bench.gen_rows(N, 0, N, dev)
+popb = Population("li_tanh", Wb, dict(tau=10.0, k=1.0, eta=0.0), 1e-2, dev)
+for B in (16, 32):
+    bp = BatchedPopulation(popb, B, mfma=True)
+    bp.v.normal_()
+    bp.refresh()
+    bp.forward(T, x=torch.zeros(T, B, 1, device=dev))
+    torch.cuda.synchronize()
+    del bp
+# W + per trajectory: v read/written, source read once per workgroup from L2 (not HBM) and written, parameters
+algo["step_batched_mfma16_kernel<0, 1"] = 4.0 * N * N + 4.0 * 16 * (3 * N) + 12.0 * N
+algo["step_batched_mfma16_split_kernel"] = 4.0 * N * N + 4.0 * 32 * (3 * N) + 12.0 * N
+del popb, Wb
 print(json.dumps({"algorithmic_bytes_per_launch": algo}), flush=True)
