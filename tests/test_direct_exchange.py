@@ -1,5 +1,5 @@
-"""The stream-ordered direct exchange (RP_COMM_DIRECT) with TWO rank processes on the one GPU of the
-box: each integrates its row shard, pushes its slice of the source vector into the other's buffer through a hipIpc
+"""The stream-ordered direct exchange (RP_COMM_DIRECT) with TWO and with FOUR rank processes on the
+one GPU of the box: each integrates its row shard, pushes its slice of the source vector into the other's buffer through a hipIpc
 mapping, and the streams hand over with hipStreamWriteValue32 / hipStreamWaitValue32.  The assembled result must equal
 the single-process run bit for bit (tanh and QIF; two library calls, so the sequence numbers carry over)."""
 import os
@@ -16,11 +16,13 @@ sys.path.insert(0, HERE)
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_one_gpu_match_the_single_process_run(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_on_one_gpu_match_the_single_process_run(tmp_path, world):
+    """world = 4: every rank pushes to three peers and waits on three flag slots per step -- the many-peer form of the
+    protocol that an 8-GPU node runs with seven (the box admits at most 6 GPU processes: 4 ranks + this one)."""
     from _direct_exchange_rank import data
     from rectipy_amd import _abi
     from rectipy_amd.engine import Population
-    world = 2
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
