@@ -33,12 +33,43 @@ class _Stateful(Linear):
             setattr(self, name, getattr(self, name).to(device))
         return self
 
+    HOST_RECURRENCE_MAX_N_IN = 64  # narrow edges (an input node's few channels): the T-step recurrence runs on the host
+    _state = ()  # the tensors `_advance` reads and replaces (besides its constants in `_extra`)
+
+    def _advance(self, x: torch.Tensor) -> torch.Tensor:
+        """One step of the edge's memory: takes the source's output x, returns the vector the projection is applied to."""
+        raise NotImplementedError
+
     def forward_window(self, X: torch.Tensor) -> torch.Tensor:
         """The edge's outputs for the T consecutive inputs X[t] ([T, n_in] -> [T, n_out]); the edge's state afterwards
-        is what T calls of ``forward`` leave behind.  Default: exactly those T calls."""
-        if X.shape[0] == 0:
+        is what T calls of ``forward`` leave behind.  Default: exactly those T calls.
+
+        On a GPU every call is a handful of tiny launches (~10 us each, whatever the size).  For a NARROW edge without a
+        gradient the T steps of the edge's MEMORY (delay buffer, recursive filter: a few KB) therefore run on host copies
+        of its tensors (microseconds per step), and the projection of the whole window is ONE product on the device.
+        Same formulas in float32; equal to the device loop up to the rounding order of the small matrix products."""
+        T = X.shape[0]
+        if T == 0:
             return X.new_zeros((0, self.weights.shape[0]))
-        return torch.stack([self.forward(X[t]) for t in range(X.shape[0])])
+        narrow = X.is_cuda and X.shape[1] <= self.HOST_RECURRENCE_MAX_N_IN and T > 1 and not X.requires_grad and \
+            not self.weights.requires_grad and not any(getattr(self, n).requires_grad for n in self._extra
+                                                       if isinstance(getattr(self, n), torch.Tensor))
+        if not narrow:
+            return torch.stack([self.forward(X[t]) for t in range(T)])
+        dev = X.device
+        names = tuple(self._extra)
+        on_dev = {n: getattr(self, n) for n in names}
+        host = {n: t.detach().cpu() for n, t in on_dev.items()}
+        try:
+            for n, t in host.items():
+                setattr(self, n, t)
+            Xh = X.detach().cpu()
+            U = torch.stack([self._advance(Xh[t]) for t in range(T)])
+        finally:
+            for n in names:  # state the steps REPLACED (buffer, y) goes back to the device; everything else is the original object
+                cur = getattr(self, n)
+                setattr(self, n, on_dev[n] if cur is host[n] else cur.to(dev))
+        return U.to(device=dev, dtype=self.weights.dtype) @ self.weights.T
 
 
 class LinearMasked(_Stateful):
@@ -85,12 +116,15 @@ class LinearMemory(_Stateful):
     def _shift(self):
         return self.buffer.roll(-1, 1)
 
+    def _advance(self, x: torch.Tensor) -> torch.Tensor:
+        self.buffer = self._shift()
+        self.buffer[:, self._cols] = x[self._src]  # == buffer[:, delays] = x, the reference's indexing (edges.py:93)
+        return self.buffer[:, 0]
+
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         if x.dim() != 1:
             raise RuntimeError("delay edges are evaluated one step at a time")
-        self.buffer = self._shift()
-        self.buffer[:, self._cols] = x[self._src]  # == buffer[:, delays] = x, the reference's indexing (edges.py:93)
-        return self.weights @ self.buffer[:, 0]
+        return self.weights @ self._advance(x)
 
     def forward_window(self, X: torch.Tensor) -> torch.Tensor:
         """Closed form of T steps of the plain delay buffer.  ``buffer[:, delays] = x`` writes the SAME row into every
@@ -135,11 +169,14 @@ class LinearFilter(_Stateful):
         self.y = torch.zeros(n_in, dtype=dtype)
         super().__init__(n_in, n_out, weights=weights, dtype=dtype, detach=detach)
 
+    def _advance(self, x: torch.Tensor) -> torch.Tensor:
+        self.y = self.filter @ self.y + x
+        return self.y
+
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         if x.dim() != 1:
             raise RuntimeError("filter edges are evaluated one step at a time")
-        self.y = self.filter @ self.y + x
-        return self.weights @ self.y
+        return self.weights @ self._advance(x)
 
 
 class LinearMemoryFilter(LinearMemory):
