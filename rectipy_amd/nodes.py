@@ -445,7 +445,10 @@ class RateNet:
         if self._y_grad is None:
             self._v_exposed = True
             return self._pop.v
-        self._y_handed = (self._y_grad, self._y_grad._version)
+        if self._y_handed is None or self._y_handed[0] is not self._y_grad:
+            # the version at the FIRST hand-out of this handle (the engine never writes into it, so that is its version
+            # since it was bound): a later read of `y` must not forget a write made after an earlier one
+            self._y_handed = (self._y_grad, self._y_grad._version)
         return self._y_grad
 
     def _before_step(self) -> bool:
@@ -471,6 +474,7 @@ class RateNet:
         ``y`` currently is the autograd handle of a window (whose history the write cuts, as an in-place write to the
         reference's ``y`` under no_grad would)."""
         lo, hi = self._var_map[var]
+        self._before_step()  # a write the holder made into the autograd handle comes first (it may cover other entries)
         with torch.no_grad():
             self._pop.v[lo:hi] = torch.as_tensor(val, dtype=torch.float32).to(self._pop.device)
         self._y_grad = None
@@ -478,6 +482,7 @@ class RateNet:
 
     def detach(self, requires_grad: bool = False, detach_params: bool = False):
         """Cut the autograd history of the state (reference nodes.py:176-196)."""
+        self._before_step()  # values the holder wrote into the handle stay (the reference detaches the SAME tensor's data)
         self._y_grad = None
         self._y_requires_grad = requires_grad
         if detach_params:
@@ -487,6 +492,8 @@ class RateNet:
     def reset(self, y: Union[np.ndarray, torch.Tensor] = None, idx: np.ndarray = None):
         """Set the state (cloned, reference nodes.py:198-211); ``idx`` resets a subset."""
         pop = self._pop
+        if idx is not None:
+            self._before_step()  # a subset reset keeps the other entries: including what the holder wrote into the handle
         with torch.no_grad():
             if y is None:
                 new = torch.zeros_like(pop.v)

@@ -346,6 +346,33 @@ def test_in_place_write_into_net_state_is_part_of_the_state(where, train, enable
     assert np.array_equal(out[:3], np.full(3, 0.25, dtype=np.float32)) and np.array_equal(out[3:], before[3:].numpy())
 
 
+def test_a_written_state_handle_survives_a_second_read_detach_and_a_subset_reset(where):
+    """Found by scripts/fuzz_vs_reference.py: (i) reading `net.state[...]` AGAIN after writing into it must not make the
+    node forget the write (the version it compares with is the one of the first hand-out); (ii) `detach()` and (iii) a
+    subset `reset(idx=...)` keep the written values -- the reference detaches / clones the very tensor that was written."""
+    n = 20
+    r = np.random.default_rng(21)
+    W = r.standard_normal((n, n)) / n ** 0.5
+    x = torch.tensor(r.standard_normal((6, n)) * 0.3, dtype=torch.float32)
+    v = torch.tensor(r.standard_normal(n), dtype=torch.float32)
+    for how in ("read_again", "detach", "reset_subset"):
+        net = Network(1e-2, **where)
+        node = net.add_diffeq_node("rnn", TANH, input_var=IN, output_var="li_op/v", weights=W, source_var=SRC,
+                                   target_var=TGT, train_params=["weights"], dtype=torch.float32)
+        net.run(x[:3], verbose=False)
+        net.state["rnn"][:] = v
+        want = v.clone()
+        if how == "read_again":
+            assert torch.equal(net.state["rnn"].detach(), v) and torch.equal(net.state["rnn"].detach(), v)
+        elif how == "detach":
+            net.detach()
+        else:
+            node.reset(y=np.array([7.0, -7.0]), idx=np.array([0, 3]))
+            want[0], want[3] = 7.0, -7.0
+        out = net.run(x[3:], verbose=False).to_numpy("out")
+        assert np.array_equal(out[0], want.numpy()), how
+
+
 def test_gradient_flows_through_a_written_state_handle(where):
     """Autograd sees the in-place write the way it does in the reference: entries overwritten lose their history,
     the others keep it (CopySlices on the handle that the next window starts from)."""
