@@ -132,7 +132,7 @@ class LinearMemory(_Stateful):
         sets b[d] = x[src(d)] for every distinct delay d.  Hence column c at the end of step t holds
         x_{t-(d-c)}[src(d)] with d the smallest delay >= c, or the initial b[c+t+1] while t < d - c; the output is
         column 0.  Pure selection -- no arithmetic besides the projection, which runs once for the window."""
-        if type(self)._shift is not LinearMemory._shift or X.shape[0] == 0 or X.requires_grad or \
+        if type(self) is not LinearMemory or X.shape[0] == 0 or X.requires_grad or \
                 not bool((self.buffer == self.buffer[:1]).all()):
             return super().forward_window(X)  # filtered buffers, rows that differ, autograd: the T-step loop
         T, D1 = X.shape[0], self.buffer.shape[1]
@@ -188,5 +188,12 @@ class LinearMemoryFilter(LinearMemory):
         self.filter = _square(filter_weights, n_in, dtype)
         super().__init__(n_in, n_out, delays=delays, weights=weights, dtype=dtype, detach=detach)
 
-    def _shift(self):
-        return self.filter @ self.buffer.roll(-1, 1)
+    def _advance(self, x: torch.Tensor) -> torch.Tensor:
+        """The reference's step, as its classes execute it (edges.py:143-146): the filtered buffer is shifted and x is
+        written at the delays -- and then ``super().forward(self.buffer[:, 0])`` is ``LinearMemory.forward``, which shifts
+        the buffer AGAIN and writes that column-0 vector at the delays before projecting column 0.  With a zero delay the
+        second phase returns the same column 0 (fixture G27 only has such delays); without one it does not -- found by
+        scripts/fuzz_edges_vs_reference.py against the reference's own class."""
+        self.buffer = self.filter @ self.buffer.roll(-1, 1)
+        self.buffer[:, self._cols] = x[self._src]
+        return super()._advance(self.buffer[:, 0].clone())

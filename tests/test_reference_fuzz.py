@@ -18,3 +18,46 @@ def test_random_call_sequences_match_the_reference(seed, capsys):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import fuzz_vs_reference
     assert fuzz_vs_reference.main(30, seed) == 0, capsys.readouterr().out[-2000:]
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_random_chains_with_edge_variants_match_the_reference(seed, capsys):
+    """inp --edge--> rnn --edge--> out with random plain / masked / delay / filter / delay + filter edges, two consecutive
+    runs: the reference walks the graph step by step, this package evaluates the edges per window (fused plan)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_edges_vs_reference
+    assert fuzz_edges_vs_reference.main(25, seed) == 0, capsys.readouterr().out[-2000:]
+
+
+def test_edge_classes_match_the_reference_classes_step_by_step_and_per_window():
+    """The four stateful / masked edge classes against the reference's own classes on random small cases -- delays
+    with and WITHOUT a zero delay (LinearMemoryFilter steps its buffer twice per call in the reference, edges.py:143-146 ->
+    LinearMemory.forward; fixture G27 only had delay sets containing 0), repeated delays, a window split in two."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import import_reference
+    import_reference()
+    from rectipy import edges as ref
+    from rectipy_amd import edge_variants as amd
+    rng = np.random.default_rng(0)
+    for trial in range(150):
+        n_in, n_out = int(rng.integers(1, 7)), int(rng.integers(1, 5))
+        delays = rng.integers(0, int(rng.integers(1, 5)), n_in)
+        F = rng.standard_normal((n_in, n_in)) * 0.3
+        W = rng.standard_normal((n_out, n_in))
+        mask = (rng.uniform(size=(n_out, n_in)) > 0.5).astype(np.float64)
+        T = int(rng.integers(2, 12))
+        X = torch.tensor(rng.standard_normal((T, n_in)))
+        for name, kw in (("LinearMemoryFilter", dict(delays=delays, filter_weights=F)), ("LinearMemory", dict(delays=delays)),
+                         ("LinearFilter", dict(filter_weights=F)), ("LinearMasked", dict(mask=mask))):
+            mk = lambda mod: getattr(mod, name)(n_in, n_out, weights=W.copy(), dtype=torch.float64,
+                                                **{k: np.array(v) for k, v in kw.items()})
+            r, a, a2 = mk(ref), mk(amd), mk(amd)
+            with torch.no_grad():
+                want = torch.stack([r.forward(X[t]) for t in range(T)])
+                step = torch.stack([a.forward(X[t]) for t in range(T)])
+                win = torch.cat([a2.forward_window(X[:T // 2]), a2.forward_window(X[T // 2:])])
+            assert float((want - step).abs().max()) < 1e-12 and float((want - win).abs().max()) < 1e-12, (name, delays)
+            if hasattr(r, "buffer"):
+                assert float((r.buffer - a.buffer).abs().max()) < 1e-12 and float((r.buffer - a2.buffer).abs().max()) < 1e-12
