@@ -70,3 +70,21 @@ def test_random_qif_call_sequences_match_the_reference(seed, capsys):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import fuzz_qif_vs_reference
     assert fuzz_qif_vs_reference.main(15, seed) == 0, capsys.readouterr().out[-2000:]
+
+
+@pytest.mark.parametrize("seed", [0, 2])
+def test_random_readout_training_sequences_match_the_reference(seed, capsys):
+    """fit_rls (array and epochs, random strides) / run / reset / test() sequences and a closing fit_ridge, on
+    inp -> rnn -(rls)-> out; relative tolerance 2e-3 on weights, P, outputs, losses (measured worst 2.2e-4 over 150)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_training_vs_reference
+    assert fuzz_training_vs_reference.main(20, seed) == 0, capsys.readouterr().out[-2000:]
+
+
+@pytest.mark.parametrize("seed", [0, 2])
+def test_random_population_chains_match_the_reference(seed, capsys):
+    """Two or three rate populations of different sizes in a chain, with and without feedback edges (FeedbackNetwork):
+    run / reset (all, one node) / forward() sequences; tolerance 5e-5 (measured worst 3.6e-7 over 220)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_chains_vs_reference
+    assert fuzz_chains_vs_reference.main(30, seed) == 0, capsys.readouterr().out[-2000:]
