@@ -59,6 +59,11 @@ class FeedbackNetwork(Network):
             return None  # a feedback edge needs the source's output of the previous step: step by step
         return super()._dag_plan(rec_vars)
 
+    def _unreached_parameters(self, steps: int) -> list:
+        if any(d.get("feedback") for _, _, d in self.graph.edges(data=True)):
+            return []  # feedback edges open further paths to the output; the delay count of the base class does not hold
+        return super()._unreached_parameters(steps)
+
     def forward(self, x) -> torch.Tensor:
         if not self._order:
             self.compile()

@@ -771,15 +771,52 @@ class Network:
         return obs
 
     @staticmethod
-    def _bptt_step(predictions, targets, optimizer, loss, error_kwargs, step_kwargs, lazy: bool = False):
+    def _bptt_step(predictions, targets, optimizer, loss, error_kwargs, step_kwargs, lazy: bool = False, unreached=()):
         """One optimisation step (reference network.py:1123-1130).  ``lazy``: return the loss as a 0-dim device tensor
         instead of a float, so that the window loop does not synchronise with the GPU once per window (the Observer
-        converts on read)."""
+        converts on read).  ``unreached``: parameters no prediction of this window depends on (_unreached_parameters):
+        their gradient is None, as the reference's step-by-step graph leaves it, not the zeros a fused window returns."""
         error = loss(predictions, targets)
         optimizer.zero_grad()
         error.backward(**error_kwargs)
+        for p in unreached:
+            p.grad = None
         optimizer.step(**step_kwargs)
         return error.detach() if lazy else error.item()
+
+    def _unreached_parameters(self, steps: int) -> list:
+        """Trainable parameters that cannot influence any prediction of a window of `steps` steps that starts from
+        states without an older graph.  A population hands on its state from BEFORE the step (nodes.py:166-170), so every
+        population between a quantity and the output node delays its influence by one step: a population's own
+        parameters and the weights of an edge into it first show in the output `c` steps later, c = the populations on
+        the shortest path from it (inclusive) to the output.  The reference's autograd graph simply has no path to such a
+        parameter and leaves ``grad`` None, which a stateful optimiser (Adam's moments, momentum, weight decay) treats
+        differently from a zero gradient; the fused window's adjoint returns zeros, so the step sets them back to None.
+        Edges with memory delay further and are left alone (zeros), as are windows whose start state carries a graph."""
+        from .edge_variants import LinearMasked, _Stateful
+        if any(isinstance(self.get_edge(s, t), _Stateful) and not isinstance(self.get_edge(s, t), LinearMasked)
+               for s, t in self.graph.edges):
+            return []
+        for n in self.graph.nodes:
+            node = self.get_node(n)
+            handle = getattr(node, "_y_grad", None)
+            if handle is not None and handle.grad_fn is not None:
+                return []
+        count = {}
+        for n in reversed(self._order):
+            nxt = [count[m] for m in self.graph.successors(n) if m in count]
+            if n != self._out_node and not nxt:
+                continue  # not on a path to the output node
+            count[n] = int(self[n]["node_type"] == "diff_eq") + (min(nxt) if nxt and n != self._out_node else 0)
+        out = []
+        for n, c in count.items():
+            if steps >= c + 1:
+                continue
+            if self[n]["node_type"] == "diff_eq":
+                out.extend(p for p in self.get_node(n).parameters() if p.requires_grad)
+            for m in self.graph.predecessors(n):
+                out.extend(p for p in self.get_edge(m, n).parameters() if p.requires_grad)
+        return out
 
     def _bptt(self, inp, target, loss, optimizer, obs: Observer, error_kwargs, step_kwargs, sampling_steps,
               optim_steps, verbose) -> Observer:
@@ -797,6 +834,14 @@ class Network:
         error = 0.0
         for a in range(0, steps, optim_steps):
             b = min(a + optim_steps, steps)
+            unreached = self._unreached_parameters(b - a)
+            if unreached and b - a == optim_steps and len(unreached) == sum(p.requires_grad for p in self.parameters()) \
+                    and not any(getattr(self.get_node(n), "_y_requires_grad", False) or
+                                getattr(getattr(self.get_node(n), "_y_grad", None), "requires_grad", False)
+                                for n in self.graph.nodes):
+                # the window's loss depends on nothing trainable and on no tracked state: the reference's backward()
+                # fails with exactly this message (network.py:1128)
+                raise RuntimeError("element 0 of tensors does not require grad and does not have a grad_fn")
             with torch.enable_grad():
                 if windows:
                     preds = self._window_outputs(inp[a:b], a, True, {}, 0, 1)[self._out_node]
@@ -813,7 +858,7 @@ class Network:
                 prev_error = error
                 if b - a == optim_steps:  # only complete windows trigger an update (network.py:1035)
                     error = self._bptt_step(preds, target[a:b], optimizer, loss, error_kwargs, step_kwargs,
-                                            lazy=not verbose)
+                                            lazy=not verbose, unreached=unreached)
                     self.detach()
             sample_at = [t for t in range(a, b) if t % sampling_steps == 0]
             if sample_at:
@@ -835,11 +880,13 @@ class Network:
         rec_vars = list(obs.recorded_state_variables)
         steps, error, predictions, old_step = inp.shape[0], 0.0, [], 0
         for step in range(steps):
+            if not predictions:
+                unreached = self._unreached_parameters(optim_steps)  # (a one-step node returns zeros too)
             pred = self.forward(inp[step, :])
             predictions.append(pred)
             if step % optim_steps == optim_steps - 1:
                 error = self._bptt_step(torch.stack(predictions), target[old_step:step + 1], optimizer, loss,
-                                        error_kwargs, step_kwargs)
+                                        error_kwargs, step_kwargs, unreached=unreached)
                 self.detach()
                 old_step = step + 1
                 predictions.clear()

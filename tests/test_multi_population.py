@@ -96,6 +96,36 @@ def test_fit_bptt_window_by_window_equals_step_by_step(target, spiking_second):
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("window", [1, 2, 3])
+def test_short_windows_leave_unreached_gradients_none(target, window):
+    """Every population delays by one step, so in a window of 1 or 2 steps the upstream parameters cannot reach any
+    prediction: the step-by-step autograd graph (the reference's) has no path to them and leaves ``grad`` None -- Adam
+    then skips them -- while the fused windows' adjoints return zeros.  Network._unreached_parameters restores None.
+    A gradient-tracking run first gives Adam non-zero moments in the first window (through the older graph), which is
+    what makes zeros and None differ afterwards."""
+    rng = np.random.default_rng(6)
+    x0 = rng.standard_normal((5, 3)).astype(np.float32)
+    x = rng.standard_normal((4 * window, 3)).astype(np.float32)
+    tgt = (rng.standard_normal((4 * window, 2)) * 0.2).astype(np.float32)
+    res = []
+    for stepwise in (False, True):
+        net = build(target, train=True, stepwise=stepwise)
+        net.run(x0, sampling_steps=1, verbose=False, enable_grad=True)
+        net.fit_bptt(x, tgt, optimizer="adam", lr=0.01, update_steps=window, sampling_steps=1, verbose=False)
+        params = {"W1": net.get_node("p1")["weights"], "tau1": net.get_node("p1")["li_op/tau"],
+                  "W2": net.get_node("p2")["weights"], "W_in": net.get_edge("inp", "p1").weights,
+                  "W_12": net.get_edge("p1", "p2").weights, "W_out": net.get_edge("p2", "out").weights}
+        res.append(({k: v.detach().cpu().numpy().copy() for k, v in params.items()},
+                    {k for k, v in params.items() if v.grad is None}))
+    # (the step-by-step arm walks the graph node by node as the reference does, with the same rule applied to it)
+    expected = {1: {"W1", "tau1", "W_in", "W2", "W_12"}, 2: {"W1", "tau1", "W_in"}, 3: set()}[window]
+    assert res[0][1] == expected and res[1][1] == expected
+    for key in res[0][0]:
+        a, b = res[0][0][key], res[1][0][key]
+        assert np.abs(a - b).max() <= 2e-4 * max(1.0, np.abs(b).max()), key
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
 def test_fit_rls_behind_two_populations(target):
     """RLS read-out behind inp -> p1 -> p2: the populations' windows first, then one RLS sweep; same weights, P matrix
     and predictions as the step-by-step loop."""

@@ -88,3 +88,14 @@ def test_random_population_chains_match_the_reference(seed, capsys):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import fuzz_chains_vs_reference
     assert fuzz_chains_vs_reference.main(30, seed) == 0, capsys.readouterr().out[-2000:]
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_trainable_chains_match_the_reference(seed, capsys):
+    """The chains above with trainable populations / edges and fit_bptt windows (sgd, adam) mixed into the call
+    sequences.  Seeds 1 and 2 hold the cases that found the None-vs-zero gradient difference: a window too short for an
+    upstream population's parameters to reach its predictions leaves their grad None in the reference (Adam skips
+    them), where a fused window's adjoint returned zeros (Adam's moments kept moving them)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_chains_vs_reference
+    assert fuzz_chains_vs_reference.main(40, seed, tol=2e-3, trainable=True) == 0, capsys.readouterr().out[-2000:]
