@@ -39,6 +39,9 @@ def build(rng, n, k, train, dt):
     return ref, amd
 
 
+TOL = 2e-4  # (adam / rmsprop divide by the root of a squared gradient: float32 gradients near zero move a step by O(lr))
+
+
 def main(cases=40, seed=0):
     rng = np.random.default_rng(seed)
     worst, worst_at = 0.0, None
@@ -49,7 +52,7 @@ def main(cases=40, seed=0):
         ref, amd = build(rng, n, k, train, dt)
         log = []
         for op_i in range(int(rng.integers(3, 8))):
-            op = ["run", "run_nograd", "write", "set_var", "reset", "fit", "detach"][int(rng.integers(0, 7))]
+            op = ["run", "run_nograd", "write", "set_var", "reset", "fit", "detach", "fit_epochs"][int(rng.integers(0, 8))]
             log.append(op)
             if op in ("run", "run_nograd"):
                 T = int(rng.integers(2, 14))
@@ -78,8 +81,11 @@ def main(cases=40, seed=0):
                 dev = 0.0
             elif op == "set_var":
                 v = rng.standard_normal(n) * 0.5
-                with torch.no_grad():
-                    ref.state["rnn"][:] = torch.tensor(v, dtype=torch.float64)  # (the reference's set_var does not relabel)
+                try:  # the reference's own set_var: a TRACKED in-place write into a slice of y (network.py:152-176), which
+                    ref.set_var("rnn", "li_op/v", torch.tensor(v, dtype=torch.float64))  # cuts the older graph off
+                except RuntimeError:  # y is a leaf that requires grad: torch refuses; this package's set_var does not
+                    with torch.no_grad():
+                        ref.state["rnn"][:] = torch.tensor(v, dtype=torch.float64)
                 amd.set_var("rnn", "li_op/v", v)
                 dev = 0.0
             elif op == "reset":
@@ -92,16 +98,28 @@ def main(cases=40, seed=0):
                 amd.detach()
                 dev = 0.0
             else:
-                w = int(rng.integers(2, 6))
-                T = w * int(rng.integers(1, 3))
-                x, tgt = rng.standard_normal((T, n)) * 0.3, rng.standard_normal((T, k)) * 0.1
-                kw = dict(optimizer="sgd", lr=1e-2, update_steps=w, sampling_steps=1, verbose=False)
                 import contextlib
                 import io
-                with contextlib.redirect_stdout(io.StringIO()):
-                    a = ref.fit_bptt(x, tgt, **kw).to_numpy("out")
-                    b = amd.fit_bptt(x.astype(np.float32), tgt.astype(np.float32), **kw).to_numpy("out")
-                dev = float(np.abs(a - b).max())
+                opt = ["sgd", "adam", "rmsprop", "adamw"][int(rng.integers(0, 4))]
+                if op == "fit_epochs":
+                    E, T = int(rng.integers(1, 4)), int(rng.integers(2, 9))
+                    xs = [rng.standard_normal((T, n)) * 0.3 for _ in range(E)]
+                    ts = [rng.standard_normal((T, k)) * 0.1 for _ in range(E)]
+                    kw = dict(optimizer=opt, lr=1e-2, sampling_steps=1, verbose=False,
+                              loss=["mse", "l1"][int(rng.integers(0, 2))])
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        a = ref.fit_bptt(xs, ts, **kw).to_numpy("out")
+                        b = amd.fit_bptt([v.astype(np.float32) for v in xs], [v.astype(np.float32) for v in ts],
+                                         **kw).to_numpy("out")
+                else:
+                    w = int(rng.integers(1, 6))
+                    T = w * int(rng.integers(1, 3)) + int(rng.integers(0, 2)) * int(rng.integers(0, w))
+                    x, tgt = rng.standard_normal((T, n)) * 0.3, rng.standard_normal((T, k)) * 0.1
+                    kw = dict(optimizer=opt, lr=1e-2, update_steps=w, sampling_steps=int(rng.integers(1, 3)), verbose=False)
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        a = ref.fit_bptt(x, tgt, **kw).to_numpy("out")
+                        b = amd.fit_bptt(x.astype(np.float32), tgt.astype(np.float32), **kw).to_numpy("out")
+                dev = float(np.abs(a - b).max()) if a.shape == b.shape else float("inf")
                 dev = max(dev, float(np.abs(ref.get_edge("rnn", "out").weights.detach().numpy()
                                             - amd.get_edge("rnn", "out").weights.detach().numpy()).max()))
                 if train and "weights" in train:
@@ -111,7 +129,7 @@ def main(cases=40, seed=0):
             dev = max(dev, sdev)
             if dev > worst:
                 worst, worst_at = dev, (case, list(log), train, n)
-            if dev > 5e-5:
+            if not dev <= TOL:
                 print("MISMATCH", dev, case, log, train, n)
                 return 1
     print(f"{cases} random call sequences: worst deviation {worst:.3e} at {worst_at}")
