@@ -359,7 +359,7 @@ def fwd_bwd_extra(pop, x, N, dev):
     gen = torch.Generator(device=dev).manual_seed(2)
     W_out = torch.randn(3, N, generator=gen, **f32) / N ** 0.5
     target = torch.randn(T, 3, generator=gen, **f32) * 0.1
-    gW = torch.zeros(N, N, **f32)
+    grad = {}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 
     def window(Tw):
@@ -372,7 +372,8 @@ def fwd_bwd_extra(pop, x, N, dev):
         lam = torch.zeros(N, **f32)
         keep = pop.backward(v_, r_, g_out, _abi.RP_OUT_STATE0, lam, u_)
         ev[2].record()
-        pop.outer_accum(pop.dt, u_, r_, gW)
+        grad.clear()  # (the previous window's gradient goes back to the allocator first, as autograd's does)
+        grad["W"] = pop.outer_product(pop.dt, u_, r_)  # what _RateWindow.backward calls: the GEMM's store form
         ev[3].record()
         torch.cuda.synchronize()
         del keep
@@ -390,7 +391,7 @@ def fwd_bwd_extra(pop, x, N, dev):
                          "unit": "GB/s", "frac": bytes_step / (bwd / T * 1e-3) / 1e9 / HBM_PEAK_GBPS},
         "dw_gemm_roofline": {"bound": "mfma", "achieved": 2.0 * N * N * T / (gemm * 1e-3) / 1e12, "peak": 157.3,
                              "unit": "TFLOP/s", "frac": 2.0 * N * N * T / (gemm * 1e-3) / 1e12 / 157.3},
-        "grad_finite": bool(torch.isfinite(gW).all().item()),
+        "grad_finite": bool(torch.isfinite(grad["W"]).all().item()),
     }
 
 

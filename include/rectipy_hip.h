@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 9
+#define RP_ABI_VERSION 10
 #define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0
@@ -312,6 +312,10 @@ int rp_outer_accum(int32_t n, int32_t T, float alpha, const float* A, int64_t ld
                    int64_t ldb, float* C, int64_t ldc, void* stream);
 /* Rectangular form for a row shard: C[m x n] += alpha * A^T B with A = [T x m], B = [T x n]. */
 int rp_outer_accum_rect(int32_t m, int32_t n, int32_t T, float alpha, const float* A, int64_t lda, const float* B,
+                        int64_t ldb, float* C, int64_t ldc, void* stream);
+/* Store form: C[m x n] = alpha * A^T B -- C is written, never read (no zero-fill pass before the GEMM, no read of C in
+   its epilogue).  Bits of rp_outer_accum_rect into a zeroed C (each element is stored as 0 + alpha * sum). */
+int rp_outer_store_rect(int32_t m, int32_t n, int32_t T, float alpha, const float* A, int64_t lda, const float* B,
                         int64_t ldb, float* C, int64_t ldc, void* stream);
 
 /*

@@ -100,6 +100,10 @@ class OracleBackend:
     def outer_accum_rect(self, m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
         assert self.lib.oracle_outer_accum_rect(m, n, T, alpha, A, lda, B, ldb, Cmat, ldc) == 0
 
+    def outer_store_rect(self, m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
+        C.memset(Cmat, 0, 4 * ((m - 1) * ldc + n))  # the store form has the bits of accumulating into zeros
+        assert self.lib.oracle_outer_accum_rect(m, n, T, alpha, A, lda, B, ldb, Cmat, ldc) == 0
+
     def bwd_prepare(self, net, bwd, device):
         assert self.lib.oracle_bwd_prepare(C.byref(net), C.byref(bwd)) == 0
 

@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 9
+RP_ABI_VERSION = 10
 RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_MFMA16, RP_BATCH_SLOTS = 0, 1, 2, 32
 RP_COMM_RCCL, RP_COMM_DIRECT = 0, 1
 
@@ -234,6 +234,8 @@ def declare(lib):
         [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
     sig("rp_outer_accum_rect", C.c_int,
         [C.c_int32, C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
+    sig("rp_outer_store_rect", C.c_int,
+        [C.c_int32, C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
     sig("rp_bwd_shard_partial_rows", C.c_int32, [C.c_int32, C.c_int32])
     sig("rp_bwd_prepare", C.c_int, [P(RpNet), P(RpBwd), C.c_void_p])
     sig("rp_bwd_partial", C.c_int, [P(RpNet), P(RpBwd), C.c_int32, fp, C.c_void_p])
@@ -273,7 +275,7 @@ def declare(lib):
 
 EXPORTS = [
     "rp_abi_version", "rp_last_error", "rp_device_check", "rp_sizeof_net", "rp_sizeof_run", "rp_sizeof_bwd",
-    "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum", "rp_outer_accum_rect",
+    "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum", "rp_outer_accum_rect", "rp_outer_store_rect",
     "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial", "rp_bwd_apply",
     "rp_sizeof_comm", "rp_forward_sharded", "rp_backward_sharded",
     "rp_ipc_alloc", "rp_ipc_open", "rp_ipc_close", "rp_ipc_free", "rp_sizeof_batch", "rp_forward_batched", "rp_set_batched_tuning", "rp_set_batched_mfma_tuning", "rp_set_batched_grid", "rp_rls_sweep", "rp_stream_probe", "rp_tune_forward", "rp_forward_tuning", "rp_install_forward_tuning", "rp_clear_forward_tuning", "rp_set_tuning", "rp_set_sparse_tuning", "rp_set_blocked_tuning", "rp_set_bwd_tuning", "rp_set_bwd_grid", "rp_set_bwd_chunks", "rp_set_rls_tuning", "rp_set_rls_sym", "rp_set_gemm_dma", "rp_set_rls_tile",

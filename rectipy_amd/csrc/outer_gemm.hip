@@ -62,7 +62,7 @@ template <bool VEC4>
 __global__ __launch_bounds__(kThreads) void outer_accum_kernel(int m, int n, int T, float alpha,
                                                                const float* __restrict__ A, int64_t lda,
                                                                const float* __restrict__ B, int64_t ldb,
-                                                               float* __restrict__ C, int64_t ldc) {
+                                                               float* __restrict__ C, int64_t ldc, int accumulate) {
     __shared__ __attribute__((aligned(16))) float As[BK * BM];
     __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
 
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kThreads) void outer_accum_kernel(int m, int n, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                old[r] = (row < m && col < n) ? C[(int64_t)row * ldc + col] : 0.f;
+                old[r] = (accumulate && row < m && col < n) ? C[(int64_t)row * ldc + col] : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -171,7 +171,7 @@ constexpr int kStages = 3;
 __global__ __launch_bounds__(kThreads) void outer_accum_dma_kernel(int m, int n, int T, float alpha,
                                                                    const float* __restrict__ A, int64_t lda,
                                                                    const float* __restrict__ B, int64_t ldb,
-                                                                   float* __restrict__ C, int64_t ldc) {
+                                                                   float* __restrict__ C, int64_t ldc, int accumulate) {
     __shared__ __attribute__((aligned(16))) float S[kStages * 2 * BK * BM];  // stage: A slice, then B slice
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void outer_accum_dma_kernel(int m, int n,
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = i0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                old[r] = C[(int64_t)row * ldc + col];
+                old[r] = accumulate ? C[(int64_t)row * ldc + col] : 0.f;  // (store form: 0 + x, the bits of accumulating into zeros)
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -282,27 +282,45 @@ std::atomic<int> g_gemm_dma{1};  // benchmark-only (rp_set_gemm_dma): 0 = always
 
 }  // namespace
 
-extern "C" int rp_outer_accum_rect(int32_t m, int32_t n, int32_t T, float alpha, const float* A, int64_t lda,
-                                   const float* B, int64_t ldb, float* C, int64_t ldc, void* stream) {
+namespace {
+
+int outer_launch(int32_t m, int32_t n, int32_t T, float alpha, const float* A, int64_t lda, const float* B, int64_t ldb,
+                 float* C, int64_t ldc, int accumulate, void* stream) {
     if (!A || !B || !C) RP_FAIL(RP_ERR_ARG, "A, B, C must be non-null");
     if (m <= 0 || n <= 0 || T < 0) RP_FAIL(RP_ERR_ARG, "m, n must be > 0 and T >= 0");
     if (lda < m || ldb < n || ldc < n) RP_FAIL(RP_ERR_SHAPE, "leading dimensions too small");
-    if (T == 0) return RP_OK;
+    if (T == 0) {
+        if (!accumulate) RP_HIP_CHECK(hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)n * sizeof(float), (size_t)m,
+                                                       static_cast<hipStream_t>(stream)));
+        return RP_OK;
+    }
     const int tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
     const bool vec4 = (m % 4 == 0) && (n % 4 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) &&
                       !(reinterpret_cast<uintptr_t>(A) & 15u) && !(reinterpret_cast<uintptr_t>(B) & 15u);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (vec4 && g_gemm_dma && m % BM == 0 && n % BN == 0 && T >= 1)
         hipLaunchKernelGGL(outer_accum_dma_kernel, dim3(tiles_m * tiles_n), dim3(kThreads), 0, st, m, n, T, alpha, A, lda, B,
-                           ldb, C, ldc);
+                           ldb, C, ldc, accumulate);
     else if (vec4)
         hipLaunchKernelGGL(outer_accum_kernel<true>, dim3(tiles_m * tiles_n), dim3(kThreads), 0, st, m, n, T, alpha, A,
-                           lda, B, ldb, C, ldc);
+                           lda, B, ldb, C, ldc, accumulate);
     else
         hipLaunchKernelGGL(outer_accum_kernel<false>, dim3(tiles_m * tiles_n), dim3(kThreads), 0, st, m, n, T, alpha, A,
-                           lda, B, ldb, C, ldc);
+                           lda, B, ldb, C, ldc, accumulate);
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;
+}
+
+}  // namespace
+
+extern "C" int rp_outer_accum_rect(int32_t m, int32_t n, int32_t T, float alpha, const float* A, int64_t lda,
+                                   const float* B, int64_t ldb, float* C, int64_t ldc, void* stream) {
+    return outer_launch(m, n, T, alpha, A, lda, B, ldb, C, ldc, 1, stream);
+}
+
+extern "C" int rp_outer_store_rect(int32_t m, int32_t n, int32_t T, float alpha, const float* A, int64_t lda,
+                                   const float* B, int64_t ldb, float* C, int64_t ldc, void* stream) {
+    return outer_launch(m, n, T, alpha, A, lda, B, ldb, C, ldc, 0, stream);
 }
 
 extern "C" int rp_set_gemm_dma(int on) {

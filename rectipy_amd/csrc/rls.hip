@@ -46,45 +46,62 @@ struct RlsParams {
     int64_t ldc;
 };
 
-// One block: d = x.z (fixed tree), k = 1/(1+d), y_hat = W x, err = y - y_hat, loss = err.err
+// d = x.z, k = 1/(1+d), y_hat = W x, err = y - y_hat, loss = err.err.  One block per dot product (block 0: x.z, block
+// o + 1: W_o.x), each in the fixed order "per-thread fmaf chain over j = tid + 1024 m, then a 1024-leaf tree"; the block that
+// finishes last (a counter in scal[3]) turns the 1 + n_out sums into k, err, loss in output order.  A thread's operands are
+// loaded eight chain links ahead of the chain itself (the chain is serial, its loads need not be).
 __global__ __launch_bounds__(1024) void rls_scalars_kernel(const RlsParams P) {
     __shared__ float red[1024];
+    __shared__ int is_last;
     const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const float* u = b == 0 ? P.z : P.W + (int64_t)(b - 1) * P.ldw;
     float a = 0.f;
-    for (int j = tid; j < P.n_in; j += 1024) a = fmaf(P.x[j], P.z[j], a);
+    for (int j0 = tid; j0 < P.n_in; j0 += 8 * 1024) {
+        float uv[8], xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = j0 + q * 1024;
+            uv[q] = j < P.n_in ? u[j] : 0.f;
+            xv[q] = j < P.n_in ? P.x[j] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (j0 + q * 1024 < P.n_in) a = fmaf(uv[q], xv[q], a);
+    }
     red[tid] = a;
     __syncthreads();
     for (int off = 512; off >= 1; off >>= 1) {
         if (tid < off) red[tid] = red[tid] + red[tid + off];
         __syncthreads();
     }
-    const float k = 1.0f / (1.0f + red[0]);
+    if (tid == 0) {
+        if (b == 0) P.scal[2] = red[0];
+        else P.err[b - 1] = red[0];  // y_hat for now
+        __threadfence();
+        is_last = atomicAdd(reinterpret_cast<unsigned*>(P.scal + 3), 1u) == gridDim.x - 1;
+    }
     __syncthreads();
-    float loss = 0.f;
-    for (int o = 0; o < P.n_out; ++o) {  // outputs are few: one block-wide dot each, same tree
-        float b = 0.f;
-        const float* w = P.W + (int64_t)o * P.ldw;
-        for (int j = tid; j < P.n_in; j += 1024) b = fmaf(w[j], P.x[j], b);
-        red[tid] = b;
-        __syncthreads();
-        for (int off = 512; off >= 1; off >>= 1) {
-            if (tid < off) red[tid] = red[tid] + red[tid + off];
-            __syncthreads();
-        }
-        const float yhat = red[0];
-        __syncthreads();
-        const float e = P.y[o] - yhat;
-        loss = fmaf(e, e, loss);
-        if (tid == 0) {
+    if (!is_last) return;
+    if (tid == 0) {
+        __threadfence();
+        const float d = __hip_atomic_load(P.scal + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float k = 1.0f / (1.0f + d);
+        float loss = 0.f;
+        for (int o = 0; o < P.n_out; ++o) {
+            const float yhat = __hip_atomic_load(P.err + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float e = P.y[o] - yhat;
+            loss = fmaf(e, e, loss);
             P.err[o] = e;
             if (P.pred) P.pred[o] = yhat;
         }
-    }
-    if (tid == 0) {
         P.scal[0] = k;
         P.scal[1] = loss;
+        *reinterpret_cast<unsigned*>(P.scal + 3) = 0u;  // ready for the next update
+        red[0] = loss;
     }
-    if (P.loss_out && tid < P.loss_count) P.loss_out[tid] = loss;
+    __syncthreads();
+    if (P.loss_out && tid < P.loss_count) P.loss_out[tid] = red[0];
 }
 
 // W[o][j] += (k * err[o]) * z[j]
@@ -333,11 +350,14 @@ __device__ __forceinline__ float rows_allreduce(float (&v)[R], int lane) {
 
 // C = rows per tile (the chunk of the column partials: part of the summation order), R = rows in flight per wave (how the
 // tile is walked: groups of R rows, the next group's loads issued before the current one is processed; never the order).
-template <bool UPDATE, int C, int R>
+// FULL: n_in is a multiple of 1024, so every tile is complete and no access is predicated -- the loads of the next group
+// are then plain straight-line code and the compiler waits with a counted vmcnt for the current group only (behind the
+// per-access bounds branches it waits for vmcnt(0), i.e. for the prefetch it has just issued).
+template <bool UPDATE, int C, int R, bool FULL>
 __global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
     __shared__ float wsum[C][4];
     __shared__ float zrow[C], xrow[C];
-    static_assert(C % R == 0 && (R & (R - 1)) == 0 && R <= 64, "groups of R rows");
+    static_assert(C % R == 0 && (R & (R - 1)) == 0 && R <= 32, "groups of R rows");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int n = P.n_in;
@@ -352,46 +372,48 @@ __global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
     const int ct = I + b;
     const int chunk = I * (1024 / C) + blockIdx.y;
     const int row0 = chunk * C;
-    if (row0 >= n) return;
+    if (!FULL && row0 >= n) return;
     const bool upper = ct > I;
     const int col = ct * 1024 + 256 * wave + 4 * lane;
-    const bool valid = col < n;
+    const bool valid = FULL || col < n;
     const bool dot = P.x_next != nullptr;
     const rp_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float* base = P.P + (int64_t)row0 * P.ldp + col;
-    rp_f4 cur[R], nxt[R];
+    rp_f4 bufA[R], bufB[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) cur[r] = (valid && row0 + r < n) ? rp_ld4_stream(base + (int64_t)r * P.ldp) : zero4;
+    for (int r = 0; r < R; ++r)
+        bufA[r] = (FULL || (valid && row0 + r < n)) ? rp_ld4_stream(base + (int64_t)r * P.ldp) : zero4;
     const rp_f4 zv = (UPDATE && valid) ? rp_ld4(P.z + col) : zero4;
     const rp_f4 xv = (dot && valid) ? rp_ld4(P.x_next + col) : zero4;
     if (threadIdx.x < C) {
         const int i = row0 + threadIdx.x;
-        zrow[threadIdx.x] = (UPDATE && i < n) ? P.z[i] : 0.f;
-        xrow[threadIdx.x] = (dot && i < n) ? P.x_next[i] : 0.f;
+        zrow[threadIdx.x] = (UPDATE && (FULL || i < n)) ? P.z[i] : 0.f;
+        xrow[threadIdx.x] = (dot && (FULL || i < n)) ? P.x_next[i] : 0.f;
     }
     const float k = UPDATE ? P.scal[0] : 0.f;
     __syncthreads();
     rp_f4 cp = zero4;
     constexpr int kGroup = 64 / R;  // lanes that hold the same row's total after the transposed butterfly
-#pragma unroll 1
-    for (int g = 0; g < C; g += R) {
-        if (g + R < C) {
+    // one group of R rows: update + store, the lane sums of the row partials, the column chains
+    auto group = [&](const int g, const rp_f4 (&cur)[R]) {
+        float rs[R], zr[R], xr[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                nxt[r] = (valid && row0 + g + R + r < n) ? rp_ld4_stream(base + (int64_t)(g + R + r) * P.ldp) : zero4;
+        for (int r = 0; r < R; ++r) {  // (adjacent LDS words: the compiler merges them into wide reads, one wait per group)
+            zr[r] = UPDATE ? zrow[g + r] : 0.f;
+            xr[r] = xrow[g + r];
         }
-        float rs[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = row0 + g + r;
             rp_f4 p = cur[r];
             if constexpr (UPDATE) {
-                const float kz = k * zrow[g + r];
+                const float kz = k * zr[r];
                 p.x = p.x - kz * zv.x;
                 p.y = p.y - kz * zv.y;
                 p.z = p.z - kz * zv.z;
                 p.w = p.w - kz * zv.w;
-                if (valid && i < n) __builtin_nontemporal_store(p, reinterpret_cast<rp_f4*>(base + (int64_t)(g + r) * P.ldp));
+                if (FULL || (valid && i < n))
+                    __builtin_nontemporal_store(p, reinterpret_cast<rp_f4*>(base + (int64_t)(g + r) * P.ldp));
             }
             rp_f4 a;
             a.x = fmaf(p.x, xv.x, 0.f);
@@ -399,8 +421,10 @@ __global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
             a.z = fmaf(p.z, xv.z, 0.f);
             a.w = fmaf(p.w, xv.w, 0.f);
             rs[r] = rp_lane_sum4(a);
-            if (upper && i < n) {  // (rows past the end must not touch the chain: the oracle stops at n)
-                const float xi = xrow[g + r];
+            // (rows past the end must not touch the chain: the oracle stops at n.  On a diagonal block the chain is
+            // computed and dropped -- 32 of 528 blocks -- rather than branched around: no divergent path in the loop)
+            if (FULL || (upper && i < n)) {
+                const float xi = xr[r];
                 cp.x = fmaf(p.x, xi, cp.x);
                 cp.y = fmaf(p.y, xi, cp.y);
                 cp.z = fmaf(p.z, xi, cp.z);
@@ -416,12 +440,30 @@ __global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
                 wsum[g + r][wave] = total;
             }
         }
+    };
+    // Two register buffers A / B used in turn, the loop unrolled by two groups so that neither is ever copied: the loads
+    // of group g + 1 are issued, unconditionally, before group g is processed, and the wait in front of a group is a
+    // counted one (the R loads just issued -- and the stores of the group before -- may stay in flight).  The last pair
+    // is peeled (nothing to prefetch behind it).
+    auto fetch = [&](const int g, rp_f4 (&buf)[R]) {
 #pragma unroll
-        for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+        for (int r = 0; r < R; ++r)
+            buf[r] = (FULL || (valid && row0 + g + r < n)) ? rp_ld4_stream(base + (int64_t)(g + r) * P.ldp) : zero4;
+    };
+    static_assert(C % (2 * R) == 0, "pairs of groups");
+#pragma unroll 1
+    for (int g = 0; g + 2 * R < C; g += 2 * R) {
+        fetch(g + R, bufB);
+        group(g, bufA);
+        fetch(g + 2 * R, bufA);
+        group(g + R, bufB);
     }
+    fetch(C - R, bufB);
+    group(C - 2 * R, bufA);
+    group(C - R, bufB);
     if (!dot) return;
     __syncthreads();
-    if (threadIdx.x < C && row0 + (int)threadIdx.x < n) {
+    if (threadIdx.x < C && (FULL || row0 + (int)threadIdx.x < n)) {
         const int r = threadIdx.x;
         P.partials[(int64_t)(row0 + r) * nb + ct] = ((wsum[r][0] + wsum[r][1]) + wsum[r][2]) + wsum[r][3];
     }
@@ -503,7 +545,10 @@ std::atomic<int> g_sym_inflight{0};  // benchmark-only (rp_set_rls_sym): rows in
 template <bool UPDATE, int C, int R>
 void launch_sym_rows(const RlsParams& P, hipStream_t st) {
     const int nb = (P.n_in + 1023) >> 10;
-    hipLaunchKernelGGL((rls_sym_kernel<UPDATE, C, R>), dim3(nb * (nb + 1) / 2, 1024 / C), dim3(kThreads), 0, st, P);
+    if (P.n_in % 1024 == 0)
+        hipLaunchKernelGGL((rls_sym_kernel<UPDATE, C, R, true>), dim3(nb * (nb + 1) / 2, 1024 / C), dim3(kThreads), 0, st, P);
+    else
+        hipLaunchKernelGGL((rls_sym_kernel<UPDATE, C, R, false>), dim3(nb * (nb + 1) / 2, 1024 / C), dim3(kThreads), 0, st, P);
     if (P.x_next) {
         if (nb > 1) hipLaunchKernelGGL(rls_sym_colsum_kernel, dim3((P.n_in + 255) / 256, nb - 1), dim3(256), 0, st, P, C);
         hipLaunchKernelGGL(rls_sym_zn_kernel, dim3((P.n_in + 255) / 256), dim3(256), 0, st, P, C);
@@ -512,10 +557,10 @@ void launch_sym_rows(const RlsParams& P, hipStream_t st) {
 
 template <bool UPDATE>
 int launch_sym(const RlsParams& P, int rows, hipStream_t st) {
-    const int inflight = g_sym_inflight > 0 ? (int)g_sym_inflight : 4;
+    const int inflight = g_sym_inflight > 0 ? (int)g_sym_inflight : 8;
     switch (rows * 100 + inflight) {
 #define RP_SYM(C_, R_) case C_ * 100 + R_: launch_sym_rows<UPDATE, C_, R_>(P, st); return RP_OK;
-        RP_SYM(16, 2) RP_SYM(16, 4) RP_SYM(16, 8) RP_SYM(16, 16)
+        RP_SYM(16, 2) RP_SYM(16, 4) RP_SYM(16, 8)
         RP_SYM(32, 2) RP_SYM(32, 4) RP_SYM(32, 8)
         RP_SYM(64, 1) RP_SYM(64, 2) RP_SYM(64, 4) RP_SYM(64, 8)
 #undef RP_SYM
@@ -654,6 +699,7 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
     if (!sym) launch_pass<false>(P, vec4, st);
 
     const int eblocks = (r->n_in + 255) / 256;
+    RP_HIP_CHECK(hipMemsetAsync(r->scratch + 3, 0, sizeof(float), st));  // the scalar kernel's arrival counter
     for (int t = 0; t < steps; t += stride) {
         P.z = za;
         P.zn = zb;
@@ -662,7 +708,7 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
         P.pred = pred ? pred + (int64_t)t * ldpred : nullptr;
         P.loss_out = loss ? loss + t : nullptr;  // the loss of this update holds until the next one
         P.loss_count = t + stride <= steps ? stride : steps - t;
-        hipLaunchKernelGGL(rls_scalars_kernel, dim3(1), dim3(1024), 0, st, P);
+        hipLaunchKernelGGL(rls_scalars_kernel, dim3(1 + r->n_out), dim3(1024), 0, st, P);
         hipLaunchKernelGGL(rls_weights_kernel, dim3(eblocks), dim3(256), 0, st, P);
         const int next = t + stride;
         P.x_next = next < steps ? X + (int64_t)next * ldx : nullptr;

@@ -131,6 +131,10 @@ class HipBackend:
         with self._on(device):
             self._lib_mod.check(self.lib.rp_outer_accum_rect(m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
 
+    def outer_store_rect(self, m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
+        with self._on(device):
+            self._lib_mod.check(self.lib.rp_outer_store_rect(m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
+
     def bwd_prepare(self, net, bwd, device):
         with self._on(device):
             self._lib_mod.check(self.lib.rp_bwd_prepare(C.byref(net), C.byref(bwd), self._stream(device)))
@@ -604,6 +608,17 @@ class Population:
         self.backend.outer_accum(self.n, T, float(alpha), A.data_ptr(), A.stride(0) if T > 1 else A.shape[1],
                                  B.data_ptr(), B.stride(0) if T > 1 else B.shape[1], Cmat.data_ptr(),
                                  Cmat.stride(0), self.device)
+
+
+    def outer_product(self, alpha: float, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+        """alpha * A^T @ B as a NEW [n, n] matrix (A, B: [T, n]): the GEMM's store form -- no zero-fill pass over the
+        result and no read of it in the epilogue; the bits of ``outer_accum`` into zeros."""
+        T = int(A.shape[0])
+        out = torch.empty(self.n, self.n, dtype=torch.float32, device=self.device)
+        self.backend.outer_store_rect(self.n, self.n, T, float(alpha), A.data_ptr(), A.stride(0) if T > 1 else A.shape[1],
+                                      B.data_ptr(), B.stride(0) if T > 1 else B.shape[1], out.data_ptr(), out.stride(0),
+                                      self.device)
+        return out
 
 
 class BatchedPopulation:

@@ -118,8 +118,7 @@ class _RateWindow(torch.autograd.Function):
                             grad_tau=g_tau, grad_k=g_k, grad_eta=g_eta, grad_x=g_x, grad_params=g_act)
         g_W = None
         if need[4]:
-            g_W = torch.zeros(N, N, **f32)
-            pop.outer_accum(pop.dt, u_traj, traj_r, g_W)
+            g_W = pop.outer_product(pop.dt, u_traj, traj_r)
         if g_x is not None and ctx.x_width == 1:
             g_x = g_x.sum(dim=1, keepdim=True)
         del keep

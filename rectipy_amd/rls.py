@@ -39,7 +39,7 @@ class RLS(Linear):
 
     # The symmetric pass streams only the blocks of P on and above the diagonal (4 n^2 instead of 8 n^2 bytes per update)
     # and mirrors them once per call: from a few updates per call on, on matrices far beyond the caches
-    SYMMETRIC_ROWS = 64  # rows per tile of the symmetric pass (part of its summation order: rp_rls.sym_rows)
+    SYMMETRIC_ROWS = 32  # rows per tile of the symmetric pass (part of its summation order: rp_rls.sym_rows)
     SYMMETRIC_MIN_N = 8192
     SYMMETRIC_MIN_UPDATES = 4
     TILED_MIN_N = 8192  # measured (scripts/bench_rls.py, ms per update tiled / row-per-wave): n_in = 8192 0.108 / 0.113, 16384 0.386 / 0.401, 32768 1.43 / 1.68

@@ -372,8 +372,8 @@ class _ShardedRateWindow(torch.autograd.Function):
                             grad_k=g_k, grad_eta=g_eta, grad_x=g_x, grad_params=g_act, exchange=_Exchange(net))
         g_W = None
         if need[5]:
-            g_W = torch.zeros(rows, n, **f32)
-            pop.backend.outer_accum_rect(rows, n, T, float(pop.dt), u_traj.data_ptr(), rows, traj_r_full.data_ptr(), n,
+            g_W = torch.empty(rows, n, **f32)
+            pop.backend.outer_store_rect(rows, n, T, float(pop.dt), u_traj.data_ptr(), rows, traj_r_full.data_ptr(), n,
                                          g_W.data_ptr(), n, dev)
         if g_x is not None and ctx.x_width == 1:
             g_x = g_x.sum(dim=1, keepdim=True)
@@ -465,8 +465,8 @@ class _ShardedSpikeWindow(torch.autograd.Function):
                             lam_x=lam_x, grad_params=grads, exchange=_Exchange(net))
         g_W = None
         if need[5]:
-            g_W = torch.zeros(rows, n, **f32)
-            pop.backend.outer_accum_rect(rows, n, T, float(pop.dt), u_traj.data_ptr(), rows, traj_s_full.data_ptr(), n,
+            g_W = torch.empty(rows, n, **f32)
+            pop.backend.outer_store_rect(rows, n, T, float(pop.dt), u_traj.data_ptr(), rows, traj_s_full.data_ptr(), n,
                                          g_W.data_ptr(), n, dev)
         if g_x is not None and ctx.x is not None and ctx.x.shape[1] == 1:
             g_x = g_x.sum(dim=1, keepdim=True)

@@ -71,8 +71,7 @@ class SpikeWindow(torch.autograd.Function):
                             traj_aux=traj_aux, lam_x=lam_x, grad_params=grads, traj_aux2=traj_aux2, lam_x2=lam_x2)
         g_W = None
         if need[4]:
-            g_W = torch.zeros(N, N, **f32)
-            pop.outer_accum(pop.dt, u_traj, traj_s, g_W)
+            g_W = pop.outer_product(pop.dt, u_traj, traj_s)
         if g_x is not None and ctx.x is not None and ctx.x.shape[1] == 1:
             g_x = g_x.sum(dim=1, keepdim=True)
         del keep

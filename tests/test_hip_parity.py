@@ -190,6 +190,29 @@ def test_outer_accum_bit_exact(oracle_backend, hip_device, N, T):
     assert (res[1].cpu().double() - ref).abs().max() < 1e-4
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,T", [(256, 37), (130, 9), (384, 16), (77, 5)])
+def test_outer_product_store_form_never_reads_its_result(oracle_backend, hip_device, N, T):
+    """rp_outer_store_rect (what the autograd windows call for dW): C = alpha A^T B written into memory full of NaN -- a
+    read of C anywhere would poison the result -- with the bits of rp_outer_accum into zeros, on both GEMM kernels."""
+    from rectipy_amd.engine import HipBackend
+    gen = torch.Generator().manual_seed(N * T)
+    A = torch.randn(T, N, generator=gen)
+    B = torch.randn(T, N, generator=gen)
+    A[:, 0] += 3.0
+    pop = Population("li_tanh", torch.zeros(N, N), dict(tau=1.0, k=1.0, eta=0.0), 1e-2, hip_device)
+    a, b = A.to(hip_device), B.to(hip_device)
+    acc = torch.zeros(N, N, device=hip_device)
+    pop.outer_accum(0.37, a, b, acc)
+    out = torch.full((N, N), float("nan"), device=hip_device)
+    HipBackend().outer_store_rect(N, N, T, 0.37, a.data_ptr(), N, b.data_ptr(), N, out.data_ptr(), N, torch.device(hip_device))
+    torch.cuda.synchronize()
+    assert_same(acc, out, f"store form vs accumulate into zeros N={N} T={T}")
+    assert_same(acc, pop.outer_product(0.37, a, b), "Population.outer_product")
+    cpu = Population("li_tanh", torch.zeros(N, N), dict(tau=1.0, k=1.0, eta=0.0), 1e-2, "cpu", backend=oracle_backend)
+    assert_same(cpu.outer_product(0.37, A, B), out, "oracle mirror of the store form")
+
+
 def test_full_size_properties(hip_device):
     """BASELINE size (N = 32768): properties that do not need the oracle to run at that size.
     (1) sampled rows of the fused step agree with a float64 dot product;  (2) the transposed product of the
