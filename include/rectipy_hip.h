@@ -433,7 +433,7 @@ typedef struct rp_rls {
     float beta_inv;  /* 1 / forgetting rate (edges.py:220)                                     */
     float* z;        /* scratch [n_in], 16-byte aligned                                        */
     float* zn;       /* scratch [n_in], 16-byte aligned                                        */
-    float* scratch;  /* scratch [4 + n_out]                                                    */
+    float* scratch;  /* scratch [4 + n_out] ([2], [3]: the scalar kernel's x.z and its arrival counter)  */
     /* optional workspace [n_in x ceil(n_in / 1024)]: selects the TILED pass (16-byte path only).  One-shot workgroups
        sweep P in address order, each takes one 4 KiB tile (row i, 1024 columns) and leaves the tile's partial dot
        product here; z'_i = beta_inv * (sum of row i's partials, ascending).  NULL: one wave per row (small n_in). */
@@ -456,6 +456,7 @@ typedef struct rp_rls {
    rows 0, stride, 2*stride, ...  pred[t] = W x_t with the weights in force at step t (before the update at an update
    step); loss[t] = squared error of the most recent update.  The rank-1 update of P is fused with the mat-vec of
    the next update step (8 n_in^2 bytes of HBM traffic per update). */
+int rp_sizeof_rls(void);
 int rp_rls_sweep(const rp_rls* rls, int32_t steps, int32_t stride, const float* X, int64_t ldx, const float* Y,
                  int64_t ldy, float* pred, int64_t ldpred, float* loss, void* stream);
 
@@ -502,7 +503,7 @@ int rp_set_bwd_chunks(int max_chunks);
 /* Benchmark-only: rows per wave, column chunks in flight and store policy (-1 = default) of the RLS pass. */
 int rp_set_rls_tuning(int rows_per_wave, int unroll, int nontemporal_store);
 int rp_set_gemm_dma(int on); /* benchmark-only: 0 = rp_outer_accum always uses the register-staged kernel (1: LDS-DMA ring on full tiles); identical bits */
-int rp_set_rls_sym(int rows_in_flight); /* benchmark-only: rows in flight per wave of the symmetric pass (1, 2, 4, 8; 0 = built-in); never the bits */
+int rp_set_rls_sym(int rows_in_flight); /* benchmark-only: bits 0-7 rows in flight per wave of the symmetric pass (1, 2, 4, 8; 0 = built-in), bits 8-11 resident workgroups per CU (an LDS allocation; 0 = built-in, 15 = no cap); never the bits */
 int rp_set_rls_tile(int kcols_per_tile, int workgroups_per_cu); /* benchmark-only: tile width (x 1024 columns; changes the summation order) and residency cap of the tiled RLS pass; 0, 0 = built-in */
 
 /* Bandwidth probe used by bench.py: sums `bytes` of HBM with the same load shape as the step kernel. */

@@ -248,6 +248,7 @@ def declare(lib):
     sig("rp_ipc_close", C.c_int, [C.c_void_p])
     sig("rp_ipc_free", C.c_int, [C.c_void_p])
     sig("rp_sizeof_batch", C.c_int, [])
+    sig("rp_sizeof_rls", C.c_int, [])
     sig("rp_forward_batched", C.c_int, [P(RpNet), P(RpBatch), C.c_void_p])
     sig("rp_set_batched_grid", C.c_int, [C.c_int])
     sig("rp_set_batched_tuning", C.c_int, [C.c_int, C.c_int])
@@ -278,5 +279,5 @@ EXPORTS = [
     "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum", "rp_outer_accum_rect", "rp_outer_store_rect",
     "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial", "rp_bwd_apply",
     "rp_sizeof_comm", "rp_forward_sharded", "rp_backward_sharded",
-    "rp_ipc_alloc", "rp_ipc_open", "rp_ipc_close", "rp_ipc_free", "rp_sizeof_batch", "rp_forward_batched", "rp_set_batched_tuning", "rp_set_batched_mfma_tuning", "rp_set_batched_grid", "rp_rls_sweep", "rp_stream_probe", "rp_tune_forward", "rp_forward_tuning", "rp_install_forward_tuning", "rp_clear_forward_tuning", "rp_set_tuning", "rp_set_sparse_tuning", "rp_set_blocked_tuning", "rp_set_bwd_tuning", "rp_set_bwd_grid", "rp_set_bwd_chunks", "rp_set_rls_tuning", "rp_set_rls_sym", "rp_set_gemm_dma", "rp_set_rls_tile",
+    "rp_ipc_alloc", "rp_ipc_open", "rp_ipc_close", "rp_ipc_free", "rp_sizeof_batch", "rp_sizeof_rls", "rp_forward_batched", "rp_set_batched_tuning", "rp_set_batched_mfma_tuning", "rp_set_batched_grid", "rp_rls_sweep", "rp_stream_probe", "rp_tune_forward", "rp_forward_tuning", "rp_install_forward_tuning", "rp_clear_forward_tuning", "rp_set_tuning", "rp_set_sparse_tuning", "rp_set_blocked_tuning", "rp_set_bwd_tuning", "rp_set_bwd_grid", "rp_set_bwd_chunks", "rp_set_rls_tuning", "rp_set_rls_sym", "rp_set_gemm_dma", "rp_set_rls_tile",
 ]

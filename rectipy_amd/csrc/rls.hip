@@ -353,7 +353,8 @@ __device__ __forceinline__ float rows_allreduce(float (&v)[R], int lane) {
 // FULL: n_in is a multiple of 1024, so every tile is complete and no access is predicated -- the loads of the next group
 // are then plain straight-line code and the compiler waits with a counted vmcnt for the current group only (behind the
 // per-access bounds branches it waits for vmcnt(0), i.e. for the prefetch it has just issued).
-template <bool UPDATE, int C, int R, bool FULL>
+// PROBE (measurements only, wrong results): 1 = no column chains, 2 = no row sums, 3 = neither (the bare walk)
+template <bool UPDATE, int C, int R, bool FULL, int PROBE = 0>
 __global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
     __shared__ float wsum[C][4];
     __shared__ float zrow[C], xrow[C];
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
             rs[r] = rp_lane_sum4(a);
             // (rows past the end must not touch the chain: the oracle stops at n.  On a diagonal block the chain is
             // computed and dropped -- 32 of 528 blocks -- rather than branched around: no divergent path in the loop)
-            if (FULL || (upper && i < n)) {
+            if (!(PROBE & 1) && (FULL || (upper && i < n))) {
                 const float xi = xr[r];
                 cp.x = fmaf(p.x, xi, cp.x);
                 cp.y = fmaf(p.y, xi, cp.y);
@@ -431,7 +432,12 @@ __global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
                 cp.w = fmaf(p.w, xi, cp.w);
             }
         }
-        if (dot) {
+        if (PROBE & 2) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) t += rs[r];
+            if (t == 12345.f) wsum[g][wave] = t;  // (keeps the loads alive)
+        } else if (dot) {
             const float total = rows_allreduce<R>(rs, lane);
             if ((lane & (kGroup - 1)) == 0) {  // the row index of a lane's total is spelled by its lane bits, high bit first
                 int r = 0;
@@ -513,42 +519,86 @@ __global__ void rls_sym_zn_kernel(const RlsParams P, int rows_per_chunk) {
     P.zn[i] = P.beta_inv * s;
 }
 
-// P[j][i] = P[i][j] for the 32 x 32 tile (ti, tj) of an off-diagonal block (ti >> 5 < tj >> 5), through LDS
+// P[j][i] = P[i][j] for one 64 x 64 tile of an off-diagonal block (I < J), through LDS: 256-byte row pieces on both
+// sides (16 lanes x 16 bytes), four of them per thread in flight.  blockIdx.x = the block pair (only pairs that exist
+// are launched, enumerated row by row), blockIdx.y = the tile inside the 1024 x 1024 block.
 __global__ __launch_bounds__(kThreads) void rls_mirror_kernel(float* Pm, int64_t ldp, int n) {
-    __shared__ float tile[32][33];
-    const int ti = blockIdx.y, tj = blockIdx.x;
-    if ((ti >> 5) >= (tj >> 5)) return;
-    const int r = threadIdx.x >> 3, q = threadIdx.x & 7;  // 32 rows x 8 quads
-    const int i = ti * 32 + r, j = tj * 32 + 4 * q;
-    if (i < n && j < n) {  // (n % 4 == 0)
-        const rp_f4 v = rp_ld4_stream(Pm + (int64_t)i * ldp + j);
-        tile[r][4 * q + 0] = v.x;
-        tile[r][4 * q + 1] = v.y;
-        tile[r][4 * q + 2] = v.z;
-        tile[r][4 * q + 3] = v.w;
+    __shared__ float tile[64][65];
+    const int nb = (n + 1023) >> 10;
+    int b = blockIdx.x, I = 0;
+    while (b >= nb - 1 - I) {
+        b -= nb - 1 - I;
+        ++I;
+    }
+    const int J = I + 1 + b;
+    const int i0 = I * 1024 + (blockIdx.y >> 4) * 64, j0 = J * 1024 + (blockIdx.y & 15) * 64;
+    if (j0 >= n) return;  // (i0 < j0: a source row always exists where its column does)
+    const int r = threadIdx.x >> 4, q = threadIdx.x & 15;  // 16 rows x 16 quads per pass, four passes
+    rp_f4 v[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int j = j0 + 4 * q;
+        v[p] = j < n ? rp_ld4_stream(Pm + (int64_t)(i0 + 16 * p + r) * ldp + j) : rp_f4{0.f, 0.f, 0.f, 0.f};  // (n % 4 == 0)
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        tile[16 * p + r][4 * q + 0] = v[p].x;
+        tile[16 * p + r][4 * q + 1] = v[p].y;
+        tile[16 * p + r][4 * q + 2] = v[p].z;
+        tile[16 * p + r][4 * q + 3] = v[p].w;
     }
     __syncthreads();
-    const int jj = tj * 32 + r, ii = ti * 32 + 4 * q;  // row jj of the mirrored tile, columns ii .. ii+3
-    if (jj < n && ii < n) {
-        rp_f4 v;
-        v.x = tile[4 * q + 0][r];
-        v.y = tile[4 * q + 1][r];
-        v.z = tile[4 * q + 2][r];
-        v.w = tile[4 * q + 3][r];
-        __builtin_nontemporal_store(v, reinterpret_cast<rp_f4*>(Pm + (int64_t)jj * ldp + ii));
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int jj = j0 + 16 * p + r;  // row jj of the mirrored tile, columns i0 + 4 q .. + 3
+        if (jj < n) {
+            rp_f4 w;
+            w.x = tile[4 * q + 0][16 * p + r];
+            w.y = tile[4 * q + 1][16 * p + r];
+            w.z = tile[4 * q + 2][16 * p + r];
+            w.w = tile[4 * q + 3][16 * p + r];
+            __builtin_nontemporal_store(w, reinterpret_cast<rp_f4*>(Pm + (int64_t)jj * ldp + i0 + 4 * q));
+        }
     }
 }
 
 constexpr int kSymRowsDefault = 64;
 std::atomic<int> g_sym_inflight{0};  // benchmark-only (rp_set_rls_sym): rows in flight per wave; 0 = built-in
+std::atomic<int> g_sym_per_cu{0}, g_sym_probe{0};  // benchmark-only: residency cap (through an LDS allocation), ablation
 
 template <bool UPDATE, int C, int R>
 void launch_sym_rows(const RlsParams& P, hipStream_t st) {
     const int nb = (P.n_in + 1023) >> 10;
-    if (P.n_in % 1024 == 0)
-        hipLaunchKernelGGL((rls_sym_kernel<UPDATE, C, R, true>), dim3(nb * (nb + 1) / 2, 1024 / C), dim3(kThreads), 0, st, P);
-    else
-        hipLaunchKernelGGL((rls_sym_kernel<UPDATE, C, R, false>), dim3(nb * (nb + 1) / 2, 1024 / C), dim3(kThreads), 0, st, P);
+    const dim3 grid(nb * (nb + 1) / 2, 1024 / C);
+    // An in-place read-modify-write walk is fastest with LITTLE in flight: ONE resident workgroup per CU (four waves, two
+    // groups of rows each) -- 0.816 ms per update at n_in = 32768 against 0.858-0.866 with the chip filled (3-4 workgroups
+    // per CU), scripts/probes/rls_sym_cap.py; presumably because a tile's stores then reach DRAM pages its loads have
+    // just opened.  The cap is an LDS allocation nobody uses.  Small matrices (fewer than four tiles per CU) are not
+    // HBM-bound and run uncapped.
+    const int req = g_sym_per_cu, probe = g_sym_probe;
+    // (the read-only first pass of a sweep, UPDATE = false, is a plain stream and likes the chip full: 0.39 against 0.47 ms)
+    const int per_cu = req == 15 ? 0 : req > 0 ? req
+                       : (UPDATE && (int64_t)grid.x * grid.y >= 4 * (int64_t)rp_cu_count() ? 1 : 0);
+    const size_t lds = per_cu > 0 ? ((size_t)rp_lds_limit() - 4096) / per_cu - 4096 : 0;  // (static: up to 1.6 KiB)
+    if constexpr (C == 32 && R == 8) {
+        if (P.n_in % 1024 == 0 && probe) {
+#define RP_SYM_PROBE(Q_)                                                                                              \
+    if (probe == Q_) {                                                                                                \
+        if (lds) rp_allow_dynamic_lds<rls_sym_kernel<UPDATE, C, R, true, Q_>>(rp_lds_limit() - 8192);                 \
+        hipLaunchKernelGGL((rls_sym_kernel<UPDATE, C, R, true, Q_>), grid, dim3(kThreads), lds, st, P);               \
+    }
+            RP_SYM_PROBE(0) RP_SYM_PROBE(1) RP_SYM_PROBE(2) RP_SYM_PROBE(3)
+#undef RP_SYM_PROBE
+            return;  // (measurements only: no column sums, no z')
+        }
+    }
+    if (P.n_in % 1024 == 0) {
+        if (lds) rp_allow_dynamic_lds<rls_sym_kernel<UPDATE, C, R, true>>(rp_lds_limit() - 8192);
+        hipLaunchKernelGGL((rls_sym_kernel<UPDATE, C, R, true>), grid, dim3(kThreads), lds, st, P);
+    } else {
+        if (lds) rp_allow_dynamic_lds<rls_sym_kernel<UPDATE, C, R, false>>(rp_lds_limit() - 8192);
+        hipLaunchKernelGGL((rls_sym_kernel<UPDATE, C, R, false>), grid, dim3(kThreads), lds, st, P);
+    }
     if (P.x_next) {
         if (nb > 1) hipLaunchKernelGGL(rls_sym_colsum_kernel, dim3((P.n_in + 255) / 256, nb - 1), dim3(256), 0, st, P, C);
         hipLaunchKernelGGL(rls_sym_zn_kernel, dim3((P.n_in + 255) / 256), dim3(256), 0, st, P, C);
@@ -557,7 +607,7 @@ void launch_sym_rows(const RlsParams& P, hipStream_t st) {
 
 template <bool UPDATE>
 int launch_sym(const RlsParams& P, int rows, hipStream_t st) {
-    const int inflight = g_sym_inflight > 0 ? (int)g_sym_inflight : 8;
+    const int inflight = g_sym_inflight > 0 ? (int)g_sym_inflight : 4;
     switch (rows * 100 + inflight) {
 #define RP_SYM(C_, R_) case C_ * 100 + R_: launch_sym_rows<UPDATE, C_, R_>(P, st); return RP_OK;
         RP_SYM(16, 2) RP_SYM(16, 4) RP_SYM(16, 8)
@@ -632,8 +682,12 @@ void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int rp_sizeof_rls(void) { return (int)sizeof(rp_rls); }
+
 extern "C" int rp_set_rls_sym(int rows_in_flight) {
-    g_sym_inflight = rows_in_flight;
+    g_sym_inflight = rows_in_flight & 0xff;
+    g_sym_per_cu = (rows_in_flight >> 8) & 0xf;   // measurements only: workgroups per CU (0 = no cap)
+    g_sym_probe = (rows_in_flight >> 12) & 0xf;   // measurements only: ablation of the (32, 8) kernel, see PROBE
     return RP_OK;
 }
 
@@ -728,8 +782,9 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
         zb = tmp;
     }
     if (sym) {  // the caller sees a full P again: off-diagonal blocks copied to their transposed positions
-        const int t32 = (r->n_in + 31) / 32;
-        hipLaunchKernelGGL(rls_mirror_kernel, dim3(t32, t32), dim3(kThreads), 0, st, r->P, r->ldp, r->n_in);
+        const int nbm = (r->n_in + 1023) / 1024;
+        if (nbm > 1)
+            hipLaunchKernelGGL(rls_mirror_kernel, dim3(nbm * (nbm - 1) / 2, 256), dim3(kThreads), 0, st, r->P, r->ldp, r->n_in);
     }
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;
