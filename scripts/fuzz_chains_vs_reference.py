@@ -15,15 +15,40 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-from make_golden import import_reference, rate_node  # noqa: E402
+from make_golden import import_reference, make_qif, rate_node  # noqa: E402
 
-RefNetwork, RefRateNet, _, _ = import_reference()
+RefNetwork, RefRateNet, RefSpikeResetNet, _ = import_reference()
 from rectipy.network import FeedbackNetwork as RefFeedbackNetwork  # noqa: E402
 from oracle.backend import OracleBackend  # noqa: E402
 import rectipy_amd  # noqa: E402
 from rectipy_amd.feedback import FeedbackNetwork  # noqa: E402
 
 TANH = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
+QIF = "neuron_model_templates.spiking_neurons.qif.qif"
+QIF_PM = {"in": 0, "spike_var": 1, "weights": 2, "qif_op/tau": 3, "qif_op/k": 4, "qif_op/eta": 5, "qif_op/tau_s": 6}
+THETA, V_RESET = 1.0, -1.0
+
+
+def qif_pop(rng, n):
+    return dict(W=np.abs(rng.standard_normal((n, n))) * 2.0 / n, tau=rng.uniform(0.8, 1.2, n), k=rng.uniform(0.5, 1.5, n),
+                eta=rng.uniform(0.5, 3.0, n), tau_s=rng.uniform(0.5, 2.0, n),
+                y0=np.concatenate([rng.uniform(-0.9, 0.9, n), rng.uniform(0, 0.2, n)]))
+
+
+def add_qif(ref, amd, lab, P, dt):
+    n = P["W"].shape[0]
+    t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+    args = (t(P["y0"]), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64), t(P["W"]), t(P["tau"]),
+            t(P["k"]), t(P["eta"]), t(P["tau_s"]))
+    vm = {"out": (n, 2 * n), "reset_var": (0, n), "qif_op/v": (0, n), "qif_op/s": (n, 2 * n)}
+    node = RefSpikeResetNet(make_qif(n), args, vm, dict(QIF_PM), spike_threshold=THETA, spike_reset=V_RESET, dt=dt,
+                            dtype=torch.float64, device="cpu")
+    ref.add_node(lab, node, node_type="diff_eq", op="qif_op")
+    amd.add_diffeq_node(lab, QIF, input_var="qif_op/I_ext", output_var="qif_op/s", weights=P["W"], source_var="qif_op/s",
+                        target_var="qif_op/s_in", spike_var="qif_op/spike", reset_var="qif_op/v", dtype=torch.float32,
+                        spike_threshold=THETA, spike_reset=V_RESET,
+                        node_vars={"all/qif_op/tau": P["tau"], "all/qif_op/k": P["k"], "all/qif_op/eta": P["eta"],
+                                   "all/qif_op/tau_s": P["tau_s"], "all/qif_op/v": P["y0"][:n], "all/qif_op/s": P["y0"][n:]})
 
 
 def pop(rng, n):
@@ -31,9 +56,12 @@ def pop(rng, n):
                 eta=rng.standard_normal(n) * 0.1, y0=rng.standard_normal(n) * 0.5)
 
 
-def build(rng, sizes, m, k, feedback, dt, trainable=False):
+def build(rng, sizes, m, k, feedback, dt, trainable=False, spiking=False):
     labels = ["a", "b", "c"][:len(sizes)]
-    pops = [pop(rng, n) for n in sizes]
+    kinds = ["qif" if spiking and rng.integers(0, 2) else "rate" for _ in sizes]
+    if spiking and "qif" not in kinds:
+        kinds[int(rng.integers(0, len(sizes)))] = "qif"
+    pops = [pop(rng, n) if kind == "rate" else qif_pop(rng, n) for n, kind in zip(sizes, kinds)]
     choices = [None, ["weights"], ["li_op/tau", "li_op/eta"], ["weights", "li_op/k"]]
     trains = [choices[int(rng.integers(0, 4))] if trainable else None for _ in sizes]
     if feedback:
@@ -46,7 +74,10 @@ def build(rng, sizes, m, k, feedback, dt, trainable=False):
     if m:
         ref.add_func_node("inp", m, "identity")
         amd.add_func_node("inp", m, "identity")
-    for lab, P, train in zip(labels, pops, trains):
+    for lab, P, train, kind in zip(labels, pops, trains, kinds):
+        if kind == "qif":
+            add_qif(ref, amd, lab, P, dt)
+            continue
         ref.add_node(lab, rate_node(RefRateNet, P["W"], P["tau"], P["k"], P["eta"], P["y0"], dt, torch.float64,
                                     train_params=train), node_type="diff_eq", op="li_op")
         amd.add_diffeq_node(lab, TANH, input_var="li_op/I_ext", output_var="li_op/v", weights=P["W"], source_var="tanh_op/r",
@@ -91,7 +122,7 @@ def params_dev(ref, amd, labels, edges, trains):
     return dev
 
 
-def main(cases=30, seed=0, tol=5e-5, trainable=False):
+def main(cases=30, seed=0, tol=5e-5, trainable=False, spiking=False):
     rng = np.random.default_rng(seed)
     worst, worst_at = 0.0, None
     for case in range(cases):
@@ -100,7 +131,9 @@ def main(cases=30, seed=0, tol=5e-5, trainable=False):
         feedback = bool(rng.integers(0, 2))
         dt = 5e-2
         feedback = feedback and not trainable
-        ref, amd, labels, width, fb, edges, trains = build(rng, sizes, m, k, feedback, dt, trainable)
+        dt = 5e-3 if spiking else dt
+        ref, amd, labels, width, fb, edges, trains = build(rng, sizes, m, k, feedback, dt, trainable, spiking)
+        state_len = {lab: ref.state[lab].shape[0] for lab in labels}  # (a QIF population's state is [v, s])
         n_out = k or sizes[-1]
         log = []
         for _ in range(int(rng.integers(2, 6))):
@@ -108,20 +141,20 @@ def main(cases=30, seed=0, tol=5e-5, trainable=False):
             log.append(op)
             dev = 0.0
             if op in ("run", "run_nograd"):
-                T = int(rng.integers(2, 25))
-                x = rng.standard_normal((T, width)) * 0.5
+                T = int(rng.integers(40, 160)) if spiking else int(rng.integers(2, 25))
+                x = rng.standard_normal((T, width)) * 0.5 + (2.0 if spiking else 0.0)
                 kw = dict(sampling_steps=int(rng.integers(1, 4)), cutoff=int(rng.integers(0, 3)), verbose=False,
                           enable_grad=op == "run")
                 a = ref.run(torch.tensor(x), **kw).to_numpy("out")
                 b = amd.run(x.astype(np.float32), **kw).to_numpy("out")
                 dev = float(np.abs(a - b).max()) if a.size and a.shape == b.shape else (0.0 if a.shape == b.shape else np.inf)
             elif op == "reset":
-                ys = {lab: rng.standard_normal(n) * 0.5 for lab, n in zip(labels, sizes)}
+                ys = {lab: rng.uniform(-0.9, 0.9, state_len[lab]) for lab in labels}
                 ref.reset(ys)
                 amd.reset(ys)
             elif op == "reset_one":
                 i = int(rng.integers(0, len(labels)))
-                ys = {labels[i]: rng.standard_normal(sizes[i]) * 0.5}
+                ys = {labels[i]: rng.uniform(-0.9, 0.9, state_len[labels[i]])}
                 ref.reset(ys)
                 amd.reset(ys)
             elif op == "fit":
@@ -148,13 +181,16 @@ def main(cases=30, seed=0, tol=5e-5, trainable=False):
                 ref.compile()
                 amd.compile()
                 for _ in range(int(rng.integers(1, 4))):
-                    x = rng.standard_normal(width) * 0.5
+                    x = rng.standard_normal(width) * 0.5 + (2.0 if spiking else 0.0)
                     with torch.no_grad():
                         a = ref.forward(torch.tensor(x)).detach().numpy()
                         b = amd.forward(torch.tensor(x, dtype=torch.float32)).detach().numpy()
                     dev = max(dev, float(np.abs(a - b).max()))
             for lab in labels:
-                dev = max(dev, float(np.abs(ref.state[lab].detach().numpy() - amd.state[lab].detach().numpy()).max()))
+                a, b = ref.state[lab].detach().numpy(), amd.state[lab].detach().numpy()
+                if a.shape[0] != dict(zip(labels, sizes))[lab]:
+                    a, b = a[a.shape[0] // 2:], b[b.shape[0] // 2:]  # QIF: compare s (v jumps by the reset when a spike lands a step apart)
+                dev = max(dev, float(np.abs(a - b).max()))
             if dev > worst:
                 worst, worst_at = dev, (case, list(log), sizes, m, k, fb)
             if not dev <= tol:
@@ -166,4 +202,5 @@ def main(cases=30, seed=0, tol=5e-5, trainable=False):
 
 if __name__ == "__main__":
     sys.exit(main(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 0,
-                  trainable=len(sys.argv) > 3 and sys.argv[3] == "train", tol=2e-3 if len(sys.argv) > 3 else 5e-5))
+                  trainable=len(sys.argv) > 3 and sys.argv[3] == "train", spiking=len(sys.argv) > 3 and sys.argv[3] == "spiking",
+                  tol=2e-3 if len(sys.argv) > 3 else 5e-5))

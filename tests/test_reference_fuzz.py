@@ -99,3 +99,12 @@ def test_random_trainable_chains_match_the_reference(seed, capsys):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import fuzz_chains_vs_reference
     assert fuzz_chains_vs_reference.main(40, seed, tol=2e-3, trainable=True) == 0, capsys.readouterr().out[-2000:]
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_chains_with_spiking_populations_match_the_reference(seed, capsys):
+    """Chains mixing tanh rate populations and QIF SpikeResetNet populations (thresholds low enough to spike inside every
+    run), with and without feedback edges; s-trajectories and states to 2e-3 (measured worst 1.8e-6 over 150)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_chains_vs_reference
+    assert fuzz_chains_vs_reference.main(20, seed, tol=2e-3, spiking=True) == 0, capsys.readouterr().out[-2000:]
