@@ -423,3 +423,13 @@ def test_sharded_fit_bptt_trains_the_sigmoid_parameters(tmp_path, oracle_backend
         got = np.concatenate([p[q] for p in parts])
         assert np.abs(got - node[f"sigmoid_op/{q}"].detach().numpy()).max() < 2e-6, q
         assert np.abs(got - before[q]).max() > 1e-7, f"{q} was not trained"
+
+
+def test_random_sharded_call_sequences_match_single_process():
+    """scripts/fuzz_sharded.py: ShardedNetwork against the unsharded Network through random run / reset / state write /
+    forward() / fit_bptt (sgd, adam) sequences on tanh and QIF populations, two gloo ranks (measured worst 9.5e-7 over 130
+    sequences on 2 and 4 ranks)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import fuzz_sharded
+    assert fuzz_sharded.main(12, 1, 2) == 0
