@@ -362,6 +362,32 @@ class Network:
     def _sample_steps(steps: int, cutoff: int, sampling_steps: int, start: int = 0) -> List[int]:
         return [t for t in range(start, start + steps) if t >= cutoff and t % sampling_steps == 0]
 
+    @staticmethod
+    def _seq_mean(block: torch.Tensor) -> torch.Tensor:
+        """Mean over dim -2 of [..., m, width] the way the step kernel forms a sample (`acc += out` in step order, then
+        `acc / count`): sequential float32 additions and a TRUE division.  ``torch.mean`` reduces in a device-dependent
+        order and divides through a rounded reciprocal on the GPU, so sampled outputs would differ in the last bit between
+        a gradient-tracking run and the fused no-grad run, and between devices."""
+        m = block.shape[-2]
+        acc = block[..., 0, :]
+        for u in range(1, m):
+            acc = acc + block[..., u, :]
+        return acc if m == 1 else torch.div(acc, torch.full((), float(m), dtype=acc.dtype, device=acc.device))
+
+    @staticmethod
+    def _buffer_means(per_step: torch.Tensor, sample_at: List[int], cutoff: int, offset: int = 0) -> torch.Tensor:
+        """Row j = mean of the outputs buffered since the previous sample (reference network.py:590-597): per_step[t - offset]
+        for t from the previous sample + 1 (`cutoff` for the first one) to sample_at[j].  All windows but the first have
+        the same length, so they are averaged together: `sampling_steps` element-wise additions in all."""
+        if not sample_at:
+            return per_step[:0]
+        first = Network._seq_mean(per_step[cutoff - offset:sample_at[0] + 1 - offset]).unsqueeze(0)
+        if len(sample_at) == 1:
+            return first
+        m = sample_at[1] - sample_at[0]
+        rest = per_step[sample_at[0] + 1 - offset:sample_at[-1] + 1 - offset]
+        return torch.cat((first, Network._seq_mean(rest.reshape(len(sample_at) - 1, m, *per_step.shape[1:]))))
+
     # ---- simulation ---------------------------------------------------------------------------
     def run(self, inputs: Union[np.ndarray, torch.Tensor], sampling_steps: int = 1, cutoff: int = 0,
             verbose: bool = True, enable_grad: bool = True, **kwargs) -> Observer:
@@ -478,9 +504,8 @@ class Network:
             full = torch.stack([self._apply_chain(post, per_step[b], label, None) for b in range(B)])
             out = torch.empty(B, S, full.shape[2], dtype=torch.float32, device=pop.device)
             begin = cutoff
-            for j, t in enumerate(sample_at):
-                out[:, j] = torch.stack([full[b, begin:t + 1].mean(dim=0) for b in range(B)])
-                begin = t + 1
+            for b in range(B):
+                out[b] = self._buffer_means(full[b], sample_at, cutoff)
         observers = []
         for b in range(B):
             obs = Observer(dt=self.dt, record_loss=False)
@@ -591,11 +616,7 @@ class Network:
             if verbose:
                 print(f"Progress: {b}/{T} integration steps finished.")
         per_step = torch.cat(pending)
-        rows, start = [], cutoff
-        for t in sample_at:  # mean over the steps buffered since the previous sample (network.py:595)
-            rows.append(per_step[start:t + 1].mean(dim=0))
-            start = t + 1
-        outputs = torch.stack(rows) if rows else per_step[:0]
+        outputs = self._buffer_means(per_step, sample_at, cutoff)  # mean over the steps buffered since the previous sample
         rec_out = []
         for (label, _), slot in zip(rec_vars, rec_slots):
             rec_out.append(torch.cat(rec[label][slot])[sample_at] if grad else rec[label][slot])
@@ -660,11 +681,7 @@ class Network:
                 if truncate_steps < T and b - a == truncate_steps:
                     self.detach()
             per_step = torch.cat(outs)
-            rows, start = [], cutoff
-            for t in sample_at:  # mean over the steps buffered since the previous sample (network.py:595)
-                rows.append(per_step[start:t + 1].mean(dim=0))
-                start = t + 1
-            outputs = torch.stack(rows) if rows else per_step[:0]
+            outputs = self._buffer_means(per_step, sample_at, cutoff)  # (network.py:595)
             rec_out = [torch.cat(r)[sample_at] for r in recs]
             obs.record_block(sample_at, outputs, 0.0, rec_out)
             return
@@ -707,10 +724,7 @@ class Network:
                                      traj=traj, rec=rec_bufs, sample_idx=idx)
                 pending.append(self._apply_chain(post, traj, label, None))
             per_step = torch.cat(pending)
-            for t in sample_at:
-                rows.append(per_step[start:t + 1].mean(dim=0))
-                start = t + 1
-            outputs = torch.stack(rows) if rows else per_step[:0]
+            outputs = self._buffer_means(per_step, sample_at, cutoff)
         obs.record_block(sample_at, outputs, 0.0, [rec_bufs[s] for s in slots])
 
     @staticmethod
@@ -731,7 +745,7 @@ class Network:
                     if step % sampling_steps == 0:
                         if verbose:
                             print(f"Progress: {step}/{steps} integration steps finished.")
-                        obs.record(step, torch.mean(torch.stack(buffer, dim=0), dim=0), 0.0,
+                        obs.record(step, self._seq_mean(torch.stack(buffer, dim=0)), 0.0,
                                    [self.get_var(v[0], v[1]) for v in rec_vars])
                         buffer = []
                 if truncate_steps < steps and step % truncate_steps == truncate_steps - 1:

@@ -530,3 +530,39 @@ def test_readout_only_fit_skips_the_adjoint_and_gives_the_same_updates(where):
     fitted = net.get_edge("rnn", "out").weights.detach()
     assert torch.allclose(fitted, w.detach(), atol=2e-6)
     assert [float(obs["loss"][b - 1]) for b in (win, T)] == pytest.approx(expected_losses, rel=1e-5)
+
+
+@pytest.mark.parametrize("readout", [False, True])
+def test_sampled_outputs_have_the_same_bits_with_and_without_gradient_tracking(where, readout):
+    """A sample is the mean of the outputs buffered since the previous one (network.py:590-597).  The fused no-grad run
+    forms it in the step kernel (sequential float32 sum, true division); the gradient-tracking run, the read-out path and
+    the step-by-step walk form it with torch ops -- in the same order and with a true division (Network._seq_mean), not
+    with torch.mean, whose order and reciprocal multiplication are the device's: found by the HIP-vs-oracle fuzz as a
+    last-bit difference between the CPU and the GPU at sampling_steps = 3."""
+    rng = np.random.default_rng(3)
+    n, T = 37, 29
+    W = rng.standard_normal((n, n)) / 4
+    x = rng.standard_normal((T, n)).astype(np.float32)
+    outs = []
+    for grad, stepwise in ((False, False), (True, False), (False, True)):
+        net = Network(1e-2, **where)
+        net._force_stepwise = stepwise
+        net.add_diffeq_node("rnn", TANH, weights=W, source_var=SRC, target_var=TGT, input_var=IN, output_var="li_op/v",
+                            train_params=["weights"] if grad else None, dtype=torch.float32)
+        if readout:
+            net.add_func_node("out", 3, "tanh")
+            net.add_edge("rnn", "out", weights=np.random.default_rng(4).standard_normal((3, n)))
+        outs.append(net.run(x, sampling_steps=3, cutoff=2, verbose=False, enable_grad=grad).to_numpy("out"))
+    assert outs[0].shape[0] == len([t for t in range(T) if t >= 2 and t % 3 == 0])
+    assert np.array_equal(outs[0], outs[1])
+    # (the walk applies the read-out per step as a matrix-vector product, the windows as one matrix-matrix product: BLAS rounding)
+    assert np.array_equal(outs[0], outs[2]) if not readout else np.abs(outs[0] - outs[2]).max() < 1e-6
+    # and they are the sequential sums: three consecutive per-step outputs, added in order, divided by three
+    net = Network(1e-2, **where)
+    net.add_diffeq_node("rnn", TANH, weights=W, source_var=SRC, target_var=TGT, input_var=IN, output_var="li_op/v", dtype=torch.float32)
+    if readout:
+        net.add_func_node("out", 3, "tanh")
+        net.add_edge("rnn", "out", weights=np.random.default_rng(4).standard_normal((3, n)))
+    per_step = net.run(x, sampling_steps=1, verbose=False, enable_grad=False).to_numpy("out")
+    want = ((per_step[4] + per_step[5]) + per_step[6]) / np.float32(3.0)
+    assert np.array_equal(outs[0][1], want) and np.array_equal(outs[0][0], (per_step[2] + per_step[3]) / np.float32(2.0))
