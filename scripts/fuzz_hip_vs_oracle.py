@@ -39,10 +39,14 @@ MODELS = {
                 vars={"tau": (0.4, 0.8), "k": (0.5, 1.5), "eta": (2.0, 5.0), "tau_s": (0.2, 0.6)}, wscale=1.0),
     "ik": dict(path=P + "spiking_neurons.ik.ik", op="ik_op", src="ik_op/s", tgt="ik_op/s_in", out=["ik_op/s"], spike=True,
                train=[None], dt=5e-2, drive=80.0, theta=40.0, reset=-60.0, vars={}, wscale=5.0),
+    "iku": dict(path=P + "spiking_neurons.ik.iku", op="iku_op", src="iku_op/s", tgt="iku_op/s_in", out=["iku_op/s"], spike=True,
+                train=[None], dt=5e-2, drive=80.0, theta=40.0, reset=-60.0, vars={}, wscale=5.0),
+    "ik_biexp": dict(path=P + "spiking_neurons.ik.ik_biexp", op="ik_biexp_op", src="ik_biexp_op/s", tgt="ik_biexp_op/s_in",
+                     out=["ik_biexp_op/s"], spike=True, train=[None], dt=5e-2, drive=80.0, theta=40.0, reset=-60.0, vars={}, wscale=5.0),
 }
 
 
-def build(where, seed, name, n, m, k, train, out_var, readout):
+def build(where, seed, name, n, m, k, train, out_var, readout, sparse=0.0):
     M = MODELS[name]
     rng = np.random.default_rng(seed)
     net = Network(M["dt"], **where)
@@ -59,6 +63,9 @@ def build(where, seed, name, n, m, k, train, out_var, readout):
         op = M["op"]
         node_vars = {f"all/{op}/{q}": rng.uniform(lo, hi, n) for q, (lo, hi) in M["vars"].items()}
         kw = dict(spike_var=f"{op}/spike", reset_var=f"{op}/v", spike_threshold=M["theta"], spike_reset=M["reset"])
+    if sparse:  # a fixed sparse W is stored packed ("auto": when W is not trained) -- the packed step kernels
+        W = W * (rng.uniform(size=W.shape) < sparse) / sparse
+        kw["sparse_weights"] = "auto"
     net.add_diffeq_node("rnn", M["path"], weights=W, source_var=M["src"], target_var=M["tgt"], input_var=f"{M['op']}/I_ext",
                         output_var=out_var, dtype=torch.float32, train_params=train, node_vars=node_vars, **kw)
     if k:
@@ -96,7 +103,10 @@ def main(cases=50, seed=0, max_n=2100):
         readout = {"gd": dict(train="gd"), "rls": dict(train="rls", beta=0.98, alpha=1.5)}.get(mode, {})
         if mode == "rls":
             train = None
-        args = (int(rng.integers(0, 1 << 30)), name, n, m, k, train, out_var, readout)
+        sparse = float(rng.uniform(0.03, 0.3)) if (rng.integers(0, 3) == 0 and not (train and "weights" in train)) else 0.0
+        if sparse:
+            n = max(8, n - n % 4)  # (the packed layout needs n % 4 == 0)
+        args = (int(rng.integers(0, 1 << 30)), name, n, m, k, train, out_var, readout, sparse)
         cpu = build(dict(device="cpu", backend=OracleBackend()), *args)
         gpu = build(dict(device=DEV) if DEV != "cpu" else dict(device="cpu", backend=OracleBackend()), *args)
         width = m or n
@@ -114,6 +124,8 @@ def main(cases=50, seed=0, max_n=2100):
                 ops.append("fit_rls")
             if k == 0 and not M.get("spike"):
                 ops.append("fit_ridge")
+            if not M.get("spike") and n % 4 == 0 and not sparse:
+                ops.append("run_batch")
             op = ops[int(rng.integers(0, len(ops)))]
             log.append(op)
             ok = True
@@ -134,9 +146,20 @@ def main(cases=50, seed=0, max_n=2100):
                     if rec:
                         va, vb = a.to_numpy(("rnn", f"{M['op']}/v")), b.to_numpy(("rnn", f"{M['op']}/v"))
                         ok = ok and (bits_equal(va, vb) if not trained else close(va, vb, loose if not M.get("spike") else 1.0))
+                elif op == "run_batch":
+                    B = int([2, 3, 5, 8, 9, 16, 17, 32, 33][int(rng.integers(0, 9))])
+                    Tb = int(rng.integers(2, 12))
+                    xb = (rng.standard_normal((B, Tb, width)) * 0.5).astype(np.float32)
+                    y0 = (rng.standard_normal((B, n)) * 0.5).astype(np.float32)
+                    kw = dict(sampling_steps=int(rng.integers(1, 4)), cutoff=int(rng.integers(0, 2)), y0=y0)
+                    oa, ob = cpu.run_batch(xb, **kw), gpu.run_batch(xb, **kw)
+                    for a, b in zip(oa, ob):
+                        same = bits_equal if (k == 0 and m == 0 and not trained) else (lambda u, v: close(u, v, loose))
+                        ok = ok and same(a.to_numpy("out"), b.to_numpy("out")) and \
+                            (bits_equal if m == 0 and not trained else (lambda u, v: close(u, v, loose)))(a["state"].cpu().numpy(), b["state"].cpu().numpy())
                 elif op == "reset":
                     y = rng.uniform(-0.5, 0.5, cpu.state["rnn"].shape[0]).astype(np.float32)
-                    if name == "ik":
+                    if name.startswith("ik"):
                         y = None
                     cpu.reset(None if y is None else {"rnn": y})
                     gpu.reset(None if y is None else {"rnn": y})
@@ -177,13 +200,13 @@ def main(cases=50, seed=0, max_n=2100):
                     ok = close(a["w_out"].detach().numpy(), b["w_out"].detach().cpu().numpy(), 2e-4)
             sa, sb = cpu.state["rnn"].detach().numpy(), gpu.state["rnn"].detach().cpu().numpy()
             if M.get("spike") and trained:
-                lo = 2 * n if name == "ik" else n  # compare s: v (and IK's u) jump at a spike, which may land a step apart
+                lo = 2 * n if name.startswith("ik") else n  # compare s: v (and IK's u) jump at a spike, which may land a step apart
                 sa, sb = sa[lo:lo + n], sb[lo:lo + n]
             ok = ok and (bits_equal(sa, sb) if not trained else close(sa, sb, loose))
             if not ok:
                 fails += 1
                 print(json.dumps({"fail": True, "case": case, "model": name, "n": n, "m": m, "k": k, "train": train, "out": out_var,
-                                  "readout": mode, "log": log}), flush=True)
+                                  "readout": mode, "sparse": round(sparse, 3), "log": log}), flush=True)
                 break
             if op == "fit_ridge":
                 break
