@@ -8,6 +8,7 @@ exist above N = 256 meet numbers produced by the REFERENCE's classes, not only t
 | G24 n512 | fit_bptt window T=100 | adjoint: transposed-copy sweep (n <= 4096) AND column-strip kernels (`transposed_adjoint=False`: Q chunks x 256-column strips); dW GEMM 4x4 tiles of 128x128 |
 | G24 n1028 | fit_bptt window T=100 | 4 full chunks + ragged 4-column chunk; strips with a ragged last strip; dW GEMM 9x9 tiles with ragged edge tiles |
 | G25 | QIF N=512, T=3000 | spiking epilogue + event append at 2 full chunks; 2047 spike events, exact |
+| G33 | N=4100: Network.run T=60, fit_bptt window T=40 | above RP_BWD_TRANSPOSE_MAX_N = 4096: the production adjoint (column strips over row chunks) by default; 16 full chunks + ragged 4-column chunk; dW GEMM 33x33 tiles with ragged edges |
 
 Tolerances (fp32 engine vs the reference's float64 run on identical float32 inputs) are stated per test next to the
 reference's own float32-vs-float64 deviation stored in the fixture.
@@ -176,3 +177,48 @@ def test_g25_qif_n512_spike_events_exact(target):
     cur = node.current_state
     assert maxerr(cur[n:], g["s_final_f64"]) <= 5e-4
     assert maxerr(cur[:n], g["v_final_f64"]) <= 2e-2  # v reaches +-100: 2e-4 relative
+
+
+# G33 (tests/golden/make_golden_n4100.py): N = 4100 -- past the 4096 below which the adjoint works on a transposed copy of
+# W, so the PRODUCTION adjoint (column strips over row chunks, what N = 32768 runs), a 33 x 33-tile dW GEMM with ragged
+# edge tiles and 16 full 256-column chunks + a ragged 4-column one in the forward row dot meet the reference's numbers.
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_g33_n4100_run_and_bptt_vs_reference(target):
+    g = gold("g33_n4100")
+    n, T, Tb = int(g["n"]), int(g["T"]), int(g["Tb"])
+    P = recipes.li_network(n, seed=int(g["seed"]), g=1.5, defaults=False)
+    x = (0.5 * recipes.normal((T, n), seed=3310)).astype(np.float32)
+    W_out_np = (recipes.normal((3, n), seed=3320) / np.float32(np.sqrt(n))).astype(np.float32)
+    xb = (0.5 * recipes.normal((Tb, n), seed=3330)).astype(np.float32)
+    tgt_np = (0.1 * recipes.normal((Tb, 3), seed=3340)).astype(np.float32)
+    check_recipe(g, W=P["W"], x=x, xb=xb, W_out=W_out_np, target=tgt_np)
+    # -- Network.run: 4x the reference's own float32-vs-float64 deviation (1.1e-6), as for G23
+    atol = 4 * float(g["run_ref_f32_dev"])
+    net = Network(float(g["dt"]), **target)
+    net.add_diffeq_node("rnn", TANH, output_var="li_op/v", **li_kwargs(P))
+    obs = net.run(x, sampling_steps=1, verbose=False, enable_grad=False)
+    for ref in ("f64", "f32"):
+        assert maxerr(obs.to_numpy("out")[:, g["cols8"]], g["run_out_" + ref]) <= atol
+        assert maxerr(net.state["rnn"], g["run_state_" + ref]) <= atol
+    # -- one BPTT window against the reference's float64 autograd: 2e-4 of each gradient's max magnitude, as for G24
+    dev = target["device"]
+    node = RateNet.from_pyrates(TANH, output_var="li_op/v", dt=float(g["dt"]),
+                                train_params=["weights", "li_op/tau", "li_op/k", "li_op/eta"], **li_kwargs(P), **target)
+    W_out = torch.tensor(W_out_np, device=dev, requires_grad=True)
+    xt, tgt = torch.tensor(xb, device=dev), torch.tensor(tgt_np, device=dev)
+    traj = node._grad_window(Tb, xt)
+    pred = traj @ W_out.T
+    assert maxerr(pred, g["pred_f64"]) <= 2e-5
+    loss = torch.nn.functional.mse_loss(pred, tgt)
+    assert abs(loss.item() - g["loss_f64"][-1]) <= 1e-6 * max(1.0, abs(g["loss_f64"][-1]))
+    loss.backward()
+    gW = node["weights"].grad.cpu().numpy().astype(np.float64)
+    scale = float(g["gW_absmax"])
+    assert np.abs(gW[np.ix_(g["rows"], g["cols"])] - g["gW_sub"]).max() <= 2e-4 * scale, "dW sample"
+    for key, got in (("gW_rowsum", gW.sum(1)), ("gW_colsum", gW.sum(0))):  # every tile of the GEMM contributes
+        assert np.abs(got - g[key]).max() <= 2e-4 * max(np.abs(g[key]).max(), scale), key
+    for key, got in (("g_tau", node["li_op/tau"].grad), ("g_k", node["li_op/k"].grad), ("g_eta", node["li_op/eta"].grad),
+                     ("g_W_out", W_out.grad)):
+        ref = g[key]
+        assert maxerr(got, ref) <= 2e-4 * np.abs(ref).max(), f"{key}: {maxerr(got, ref)} vs scale {np.abs(ref).max()}"
+    assert maxerr(node._pop.v, g["state_f64"]) <= 2e-5
