@@ -173,3 +173,41 @@ def test_g31_fit_rls_at_kernel_sizes_matches_reference(target, n, tiled):
     assert np.abs(obs.to_numpy("out") - g["pred_f64"]).max() < 1.5e-4
     assert np.abs(obs.to_numpy("loss") - g["loss_f64"]).max() < 2e-5 * max(1.0, g["loss_f64"].max())
     assert np.abs(net.state["rnn"].cpu().numpy() - g["state_f64"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_g34_fit_rls_n8200_default_symmetric_pass_matches_reference(target):
+    """Golden G34 (tests/golden/make_golden_rls_n8200.py): the reference's fit_rls at n_in = 8200, where this package's
+    DEFAULTS select the symmetric pass (n_in >= 8192, >= 4 updates per call) -- blocks on and above the diagonal only,
+    row + column partials, the mirror, on the GPU the one-workgroup-per-CU residency cap; 8 full blocks + a ragged one.
+    Tolerances as for G31 (float32 engine vs the reference's float64 run)."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import recipes
+    g = dict(np.load(os.path.join(GOLD, "g34_rls_n8200.npz")))
+    n, T, stride, kout = int(g["n"]), int(g["T"]), int(g["stride"]), 3
+    P = recipes.li_network(n, seed=3400 + n, g=0.8, defaults=False)
+    x = (0.5 * recipes.normal((T, n), seed=3450 + n)).astype(np.float32)
+    tgt = recipes.normal((T, kout), seed=3460 + n)
+    W0 = (0.1 * recipes.normal((kout, n), seed=3470 + n)).astype(np.float32)
+    for name, arr in (("W", P["W"]), ("x", x), ("target", tgt), ("W0", W0)):
+        assert np.array_equal(recipes.fingerprint(arr), g["fp_" + name]), f"regenerated {name} differs from the generator's"
+    net, edge = build(dict(dt=g["dt"], W0=W0, beta=g["beta"], alpha=g["alpha"], **P), target)
+    obs = net.fit_rls(x, tgt, update_steps=stride, sampling_steps=1, verbose=False)
+    assert edge._colparts is not None, "the defaults must have taken the symmetric pass at this size"
+    Pm = edge.P.cpu().numpy()
+    rows, p_scale = g["rows"], np.abs(g["P_rows_f64"]).max()
+    W_ref = g["W_after_f64"]
+    assert np.abs(edge.weights.cpu().numpy() - W_ref).max() < 5e-5 * max(1.0, np.abs(W_ref).max())
+    assert np.abs(Pm[rows] - g["P_rows_f64"]).max() < 2e-6 * p_scale
+    assert np.abs(np.diag(Pm) - g["P_diag_f64"]).max() < 2e-6 * p_scale
+    blk = np.arange(n) // 1024
+    off = blk[:, None] != blk[None, :]
+    assert np.array_equal(Pm[off], Pm.T[off]), "mirrored: the off-diagonal blocks are exact transposes"
+    # (inside a diagonal block both halves are updated, as (k z_i) z_j and (k z_j) z_i: symmetric to rounding)
+    assert np.abs(Pm - Pm.T).max() < 1e-6 * p_scale
+    fp, fp_ref = recipes.fingerprint(Pm), g["P_fp_f64"]
+    assert abs(fp[1] - fp_ref[1]) < 1e-6 * fp_ref[1]              # sum of squares of all n^2 entries
+    assert np.abs(obs.to_numpy("out") - g["pred_f64"]).max() < 1.5e-4
+    assert np.abs(obs.to_numpy("loss") - g["loss_f64"]).max() < 2e-5 * max(1.0, g["loss_f64"].max())
+    assert np.abs(net.state["rnn"].cpu().numpy() - g["state_f64"]).max() < 2e-5
