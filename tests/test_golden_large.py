@@ -8,6 +8,7 @@ exist above N = 256 meet numbers produced by the REFERENCE's classes, not only t
 | G24 n512 | fit_bptt window T=100 | adjoint: transposed-copy sweep (n <= 4096) AND column-strip kernels (`transposed_adjoint=False`: Q chunks x 256-column strips); dW GEMM 4x4 tiles of 128x128 |
 | G24 n1028 | fit_bptt window T=100 | 4 full chunks + ragged 4-column chunk; strips with a ragged last strip; dW GEMM 9x9 tiles with ragged edge tiles |
 | G25 | QIF N=512, T=3000 | spiking epilogue + event append at 2 full chunks; 2047 spike events, exact |
+| G35 | QIF N=2052, T=2500 | spiking epilogue at 8 full chunks + a ragged one; 6175 spike events (the reference's f32 / f64 runs differ on one) |
 | G33 | N=4100: Network.run T=60, fit_bptt window T=40 | above RP_BWD_TRANSPOSE_MAX_N = 4096: the production adjoint (column strips over row chunks) by default; 16 full chunks + ragged 4-column chunk; dW GEMM 33x33 tiles with ragged edges |
 
 Tolerances (fp32 engine vs the reference's float64 run on identical float32 inputs) are stated per test next to the
@@ -222,3 +223,42 @@ def test_g33_n4100_run_and_bptt_vs_reference(target):
         ref = g[key]
         assert maxerr(got, ref) <= 2e-4 * np.abs(ref).max(), f"{key}: {maxerr(got, ref)} vs scale {np.abs(ref).max()}"
     assert maxerr(node._pop.v, g["state_f64"]) <= 2e-5
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_g35_qif_n2052_spike_events(target):
+    """SpikeResetNet + QIF at N = 2052 (8 full chunks + a ragged one), 2500 steps of the configs[3] recipe, 6175 spikes
+    (tests/golden/make_golden_qif_n2052.py).  At this size the reference's OWN float32 and float64 runs disagree on one
+    spike by one step (stored in the fixture), so the events are held to: the same spike count for every neuron, every
+    spike within one step of the float64 run's, and at most 4 neurons with any shifted spike; s of the neurons whose
+    events agree within 5e-4 (nodes.py:382-392)."""
+    g = gold("g35_qif_n2052")
+    n, T, stride = int(g["n"]), int(g["T"]), int(g["stride"])
+    P = recipes.qif_network(n, seed=int(g["seed"]))
+    check_recipe(g, W=P["W"], eta=P["eta"])
+    node = SpikeResetNet.from_pyrates(
+        QIF, input_var="qif_op/I_ext", output_var="qif_op/s", weights=P["W"], source_var="qif_op/s",
+        target_var="qif_op/s_in", spike_var="qif_op/spike", reset_var="qif_op/v",
+        node_vars={"all/qif_op/eta": P["eta"], "all/qif_op/v": P["y0"][:n], "all/qif_op/s": P["y0"][n:]},
+        spike_threshold=float(g["theta"]), spike_reset=float(g["v_reset"]), dt=float(g["dt"]), dtype=torch.float32,
+        **target)
+    node.enable_spike_recording(16384)
+    dev = target["device"]
+    x = torch.full((T, 1), float(g["x_const"]), device=dev)
+    traj = torch.empty(T, n, device=dev)
+    node.run_window(T, x=x, traj=traj)
+    ev, ref = node.spikes(), g["events_f64"]
+
+    def per_neuron(events):
+        out = [[] for _ in range(n)]
+        for step, idx in events:
+            out[int(idx)].append(int(step))
+        return [sorted(v) for v in out]
+
+    mine, want = per_neuron(ev), per_neuron(ref)
+    assert [len(v) for v in mine] == [len(v) for v in want] and len(ev) == len(ref) == 6175
+    shifted = [i for i in range(n) if mine[i] != want[i]]
+    assert len(shifted) <= 4, shifted
+    assert all(abs(a - b) <= 1 for i in shifted for a, b in zip(mine[i], want[i]))
+    keep = np.array([j for j, c in enumerate(g["cols"]) if int(c) not in shifted])
+    assert maxerr(traj[::stride][:, g["cols"]][:, keep], g["s_f64"][:, keep]) <= 5e-4
