@@ -104,7 +104,8 @@ __global__ __launch_bounds__(1024) void rls_scalars_kernel(const RlsParams P) {
     if (P.loss_out && tid < P.loss_count) P.loss_out[tid] = red[0];
 }
 
-// W[o][j] += (k * err[o]) * z[j]
+// W[o][j] += (k * err[o]) * z[j]  (its own launch: folded into the last block of the kernel above it costs 30 us -- one
+// block's worth of memory parallelism -- instead of 5)
 __global__ void rls_weights_kernel(const RlsParams P) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= P.n_in) return;
@@ -476,38 +477,39 @@ __global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
     if (upper && valid) *reinterpret_cast<rp_f4*>(P.colparts + (int64_t)chunk * P.ldc + col) = cp;
 }
 
-// colsum[I][j] (stored behind the chunk rows of the workspace) = colpart[c][j] over the chunks c of block row I, ascending
-__global__ void rls_sym_colsum_kernel(const RlsParams P, int rows_per_chunk) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    const int I = blockIdx.y;
-    if (j >= P.n_in || (j >> 10) <= I) return;
-    const int chunks = (P.n_in + rows_per_chunk - 1) / rows_per_chunk;
-    const int per_block = 1024 / rows_per_chunk;
-    const int c0 = I * per_block;
-    const int c1 = (c0 + per_block < chunks) ? c0 + per_block : chunks;
-    float s = P.colparts[(int64_t)c0 * P.ldc + j];
-    int c = c0 + 1;
-    for (; c + 8 <= c1; c += 8) {  // eight independent loads in flight, added in ascending order
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = P.colparts[(int64_t)(c + q) * P.ldc + j];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) s = s + v[q];
-    }
-    for (; c < c1; ++c) s = s + P.colparts[(int64_t)c * P.ldc + j];
-    P.colparts[(int64_t)(chunks + I) * P.ldc + j] = s;
-}
-
-__global__ void rls_sym_zn_kernel(const RlsParams P, int rows_per_chunk) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n_in) return;
+// z'_i = beta^-1 (colsum[0][i] + ... + colsum[I_i - 1][i], then rowpart[i][I_i] + ... ascending), colsum[b][i] = the
+// column partials colpart[c][i] of the chunks c of block row b added in ascending order from the first one.  One
+// workgroup per 32 columns: thread (c, s) adds up the block rows b = s, s + 32, ... of column c (their sums are
+// independent), thread (c, 0) chains them and the row partials in the order above.
+__global__ __launch_bounds__(1024) void rls_sym_zn_kernel(const RlsParams P, int rows_per_chunk) {
+    extern __shared__ float colsum[];  // [nb][32]
+    const int c = threadIdx.x & 31, slot = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + c;
     const int nb = (P.n_in + 1023) >> 10;
-    const int chunks = (P.n_in + rows_per_chunk - 1) / rows_per_chunk;
-    const int I = i >> 10;
+    const int I = (blockIdx.x * 32) >> 10;  // (32 divides 1024: one block row per workgroup)
+    const int per_block = 1024 / rows_per_chunk;
+    if (i < P.n_in) {
+        for (int b = slot; b < I; b += 32) {
+            const float* col = P.colparts + (int64_t)b * per_block * P.ldc + i;
+            float s = col[0];
+            int q = 1;
+            for (; q + 8 <= per_block; q += 8) {  // eight independent loads in flight, added in ascending order
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(q + u) * P.ldc];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s = s + v[u];
+            }
+            for (; q < per_block; ++q) s = s + col[(int64_t)q * P.ldc];
+            colsum[b * 32 + c] = s;
+        }
+    }
+    __syncthreads();
+    if (slot != 0 || i >= P.n_in) return;
     float s = 0.f;
     bool first = true;
     for (int b = 0; b < I; ++b) {
-        const float v = P.colparts[(int64_t)(chunks + b) * P.ldc + i];
+        const float v = colsum[b * 32 + c];
         s = first ? v : s + v;
         first = false;
     }
@@ -599,10 +601,8 @@ void launch_sym_rows(const RlsParams& P, hipStream_t st) {
         if (lds) rp_allow_dynamic_lds<rls_sym_kernel<UPDATE, C, R, false>>(rp_lds_limit() - 8192);
         hipLaunchKernelGGL((rls_sym_kernel<UPDATE, C, R, false>), grid, dim3(kThreads), lds, st, P);
     }
-    if (P.x_next) {
-        if (nb > 1) hipLaunchKernelGGL(rls_sym_colsum_kernel, dim3((P.n_in + 255) / 256, nb - 1), dim3(256), 0, st, P, C);
-        hipLaunchKernelGGL(rls_sym_zn_kernel, dim3((P.n_in + 255) / 256), dim3(256), 0, st, P, C);
-    }
+    if (P.x_next)
+        hipLaunchKernelGGL(rls_sym_zn_kernel, dim3((P.n_in + 31) / 32), dim3(1024), (size_t)nb * 32 * sizeof(float), st, P, C);
 }
 
 template <bool UPDATE>
@@ -752,7 +752,6 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
     if (sym && launch_sym<false>(P, sym_rows, st) != RP_OK) RP_FAIL(RP_ERR_ARG, "no symmetric RLS kernel for %d rows per tile with this tuning", sym_rows);
     if (!sym) launch_pass<false>(P, vec4, st);
 
-    const int eblocks = (r->n_in + 255) / 256;
     RP_HIP_CHECK(hipMemsetAsync(r->scratch + 3, 0, sizeof(float), st));  // the scalar kernel's arrival counter
     for (int t = 0; t < steps; t += stride) {
         P.z = za;
@@ -763,7 +762,7 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
         P.loss_out = loss ? loss + t : nullptr;  // the loss of this update holds until the next one
         P.loss_count = t + stride <= steps ? stride : steps - t;
         hipLaunchKernelGGL(rls_scalars_kernel, dim3(1 + r->n_out), dim3(1024), 0, st, P);
-        hipLaunchKernelGGL(rls_weights_kernel, dim3(eblocks), dim3(256), 0, st, P);
+        hipLaunchKernelGGL(rls_weights_kernel, dim3((r->n_in + 255) / 256), dim3(256), 0, st, P);
         const int next = t + stride;
         P.x_next = next < steps ? X + (int64_t)next * ldx : nullptr;
         if (sym) (void)launch_sym<true>(P, sym_rows, st);
