@@ -1,0 +1,7 @@
+set -o pipefail
+mkdir -p gpurun_out/r03p
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r03p/gputests.log 2>&1; echo "gpu tests rc=$?" | tee gpurun_out/r03p/status.txt
+tail -3 gpurun_out/r03p/gputests.log
+python bench.py > gpurun_out/r03p/bench_default.json 2> gpurun_out/r03p/bench_default.err; echo "bench default rc=$?" | tee -a gpurun_out/r03p/status.txt
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r03p/smoke.log 2>&1; echo "smoke rc=$?" | tee -a gpurun_out/r03p/status.txt
+python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03p/bench_driver_cmd.json 2> gpurun_out/r03p/bench_driver_cmd.err; echo "bench20 rc=$?" | tee -a gpurun_out/r03p/status.txt
