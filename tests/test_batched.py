@@ -129,6 +129,12 @@ def test_network_run_batch_equals_separate_runs(target):
             # buffer means included: the same running sum in step order / count as the step kernel's
             assert np.array_equal(obs.to_numpy("out"), batch[b].to_numpy("out")), (out_fn, s, cutoff, b)
             assert torch.equal(single.state["rnn"], batch[b]["state"])
+    # mfma=True: the same three trajectories on the matrix cores (3 of 16 slots) -- equal to rounding, not bit for bit
+    net = build()
+    fast = net.run_batch(x, sampling_steps=3, cutoff=4, mfma=True)
+    for b in range(B):
+        assert np.abs(fast[b].to_numpy("out") - batch[b].to_numpy("out")).max() < 2e-5
+        assert np.abs((fast[b]["state"] - batch[b]["state"]).cpu().numpy()).max() < 2e-5
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
