@@ -59,9 +59,19 @@ def main(cases=40, seed=0):
                 x = rng.standard_normal((T, n)) * 0.3
                 kw = dict(sampling_steps=int(rng.integers(1, 4)), cutoff=int(rng.integers(0, 3)), verbose=False,
                           enable_grad=op == "run")
-                a = ref.run(x, **kw).to_numpy("out")
-                b = amd.run(x.astype(np.float32), **kw).to_numpy("out")
+                if rng.integers(0, 3) == 0:
+                    kw["truncate_steps"] = int(rng.integers(1, 6))
+                rec = rng.integers(0, 3) == 0
+                if rec:  # (the reference relabels nothing for a hand-built node: its var_map holds "li_op/v")
+                    kw["record_vars"] = [("rnn", "li_op/v", bool(rng.integers(0, 2)))]
+                oa, ob = ref.run(x, **kw), amd.run(x.astype(np.float32), **kw)
+                a, b = oa.to_numpy("out"), ob.to_numpy("out")
                 dev = float(np.abs(a - b).max()) if a.size else 0.0
+                if a.shape != b.shape or list(oa["steps"]) != list(ob["steps"]):
+                    dev = float("inf")
+                if rec and a.size:
+                    ra, rb = oa.to_numpy(("rnn", "li_op/v")), ob.to_numpy(("rnn", "li_op/v"))
+                    dev = max(dev, float(np.abs(ra - rb).max()) if ra.shape == rb.shape else float("inf"))
             elif op == "write":
                 v = rng.standard_normal(n) * 0.5
                 try:
