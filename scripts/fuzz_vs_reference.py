@@ -52,7 +52,8 @@ def main(cases=40, seed=0):
         ref, amd = build(rng, n, k, train, dt)
         log = []
         for op_i in range(int(rng.integers(3, 8))):
-            op = ["run", "run_nograd", "write", "set_var", "reset", "fit", "detach", "fit_epochs"][int(rng.integers(0, 8))]
+            op = ["run", "run_nograd", "write", "set_var", "reset", "fit", "detach", "fit_epochs", "set_param",
+                  "swap_readout"][int(rng.integers(0, 10))]
             log.append(op)
             if op in ("run", "run_nograd"):
                 T = int(rng.integers(2, 14))
@@ -97,6 +98,21 @@ def main(cases=40, seed=0):
                     with torch.no_grad():
                         ref.state["rnn"][:] = torch.tensor(v, dtype=torch.float64)
                 amd.set_var("rnn", "li_op/v", v)
+                dev = 0.0
+            elif op == "set_param":  # a parameter that is not trained gets a new value (reference nodes.py:213-230)
+                name = "li_op/eta" if not (train and "li_op/eta" in train) else "li_op/tau"
+                if train and name in train:
+                    continue
+                val = rng.uniform(5, 10, n) if name == "li_op/tau" else rng.standard_normal(n) * 0.1
+                ref.set_var("rnn", name, torch.tensor(val, dtype=torch.float64))
+                amd.set_var("rnn", name, val)
+                dev = 0.0
+            elif op == "swap_readout":  # pop_edge + add_edge: the graph is recompiled on the next call
+                W_new = rng.standard_normal((k, n)) / np.sqrt(n)
+                ref.pop_edge("rnn", "out")
+                amd.pop_edge("rnn", "out")
+                ref.add_edge("rnn", "out", weights=W_new.copy(), train="gd", dtype=torch.float64)
+                amd.add_edge("rnn", "out", weights=W_new.copy(), train="gd")
                 dev = 0.0
             elif op == "reset":
                 v = rng.standard_normal(n) * 0.5
