@@ -693,8 +693,9 @@ def stepwise_extra(dev):
     N = 4096 and N = 32768: (i) a user loop over net.forward(x) (reference rectipy_tests/test_network.py:327-333);
     (ii) inp -> LinearMemoryFilter -> rnn through Network.run -- r03: the edge is evaluated per window, so the population
     takes the fused-window plan; the same graph forced onto the step-by-step walk is what r02 paid; (iii) a
-    FeedbackNetwork of two populations of N/2 neurons (a -> b, feedback b -> a; dense N/2 x N/2 edges), which stays
-    step by step by construction (a feedback edge needs the source's state of the same step)."""
+    FeedbackNetwork of two populations of N/2 neurons (a -> b, feedback b -> a; dense N/2 x N/2 edges) -- r04: one
+    rp_forward_coupled call per window, both edge matrices streamed by the targets' step kernels (r03: a Python walk per
+    step with the edge products in rocBLAS); the same graph forced onto the per-step walk is reported next to it."""
     import contextlib
     from rectipy_amd import FeedbackNetwork, Network
     tanh = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
@@ -756,6 +757,9 @@ def stepwise_extra(dev):
             fb.add_edge("b", "a", weights=gen_rows(h, 0, h, dev, g=0.5), feedback=True)
             x_h = torch.randn(T, h, device=dev, generator=gen) * 0.1
             rec["feedback_two_populations_of_N_over_2"] = timed(
+                lambda steps: fb.run(x_h[:steps], sampling_steps=steps, verbose=False, enable_grad=False), T)
+            fb._force_stepwise = True
+            rec["feedback_two_populations_step_by_step_walk"] = timed(
                 lambda steps: fb.run(x_h[:steps], sampling_steps=steps, verbose=False, enable_grad=False), T)
             del fb, x_h
             torch.cuda.empty_cache()

@@ -17,6 +17,9 @@
  *                          spiking_neurons/qif.yaml:11-12
  *                        the time loop + sampling   rectipy/network.py:588-599
  *                        the input edge             rectipy/edges.py:48-49
+ *   rp_forward_coupled <- the per-step graph walk over several populations joined by dense edges, feedback edges
+ *                        included                   rectipy/network.py:962-981, 1322-1357 (FeedbackNetwork._backward,
+ *                                                   _edge_bwd), rectipy/edges.py:48-49
  *   rp_refresh_source <- (state re-initialisation)  rectipy/nodes.py:198-211,398-401
  *   rp_rate_backward, rp_qif_backward
  *                     <- torch.autograd over the unrolled loop (incl. Spike.backward, nodes.py:479-481),
@@ -47,7 +50,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 10
+#define RP_ABI_VERSION 11
 #define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0
@@ -70,6 +73,7 @@ extern "C" {
 
 #define RP_MAX_PARAMS 12
 #define RP_MAX_STATE 4
+#define RP_MAX_EDGES 4 /* dense edges from other vectors into one population (rp_run.edge_*) */
 
 /* parameter slots p[] (each a per-neuron vector of length `rows`) */
 #define RP_P_TAU 0
@@ -207,7 +211,48 @@ typedef struct rp_run {
        starts at zero and is not refreshed by reset() (rectipy/nodes.py:428-431, 451-456).  Later steps of the call
        use v.  Not available for the population-mean models (IKU, IK_BIEXP). */
     const float* spike_src;
+    /* Dense edges INTO this population evaluated inside its step (the reference's `edge.forward(source output)` summed
+       into the node input, rectipy/network.py:962-977, 1322-1357, rectipy/edges.py:48-49): at step t edge e adds
+       E_e[i] = sum_j edge_w[e][i * edge_ld[e] + j] * s_e[j], j < edge_n[e], with s_e = edge_src[e] + t * edge_src_ld[e]
+       (edge_src_ld = 0: the same vector every step; rp_forward_coupled sets the vector of every step itself).  Each
+       E_e[i] is a row dot product with the summation tree of the recurrent one (16-byte path iff edge_n % 4 == 0 and
+       edge_ld % 4 == 0 -- then edge_w, edge_src and edge_src_ld must be 16-byte aligned --, start chunk from the global
+       row index row0 + i and edge_n).  The node input of the step then is
+           I[i] = x-input[i] + ((E_0[i] + E_1[i]) + ...)      (just the edge sum when x_mode == RP_X_NONE),
+       the order in which the front end adds a node's edge inputs.  The matrices are streamed from HBM next to W by the
+       same wave that owns the row: one launch per population and step, whatever the number of edges.  Dense W only
+       (rp_net.sp_vals is ignored when n_edges > 0; the packed form gives the same bits as the dense one anyway). */
+    int32_t n_edges;                       /* 0..RP_MAX_EDGES                                                   */
+    const float* edge_w[RP_MAX_EDGES];     /* [rows x edge_ld]                                                  */
+    int64_t edge_ld[RP_MAX_EDGES];
+    int32_t edge_n[RP_MAX_EDGES];          /* columns of the edge = length of its source vector                 */
+    const float* edge_src[RP_MAX_EDGES];   /* source vector of the call's first step (rp_forward only)          */
+    int64_t edge_src_ld[RP_MAX_EDGES];     /* added per step (rp_forward only)                                  */
+    /* optional [rows] each: the step with absolute index a stores its pre-update output in hist[a & 1] -- the vector the
+       RP_EDGE_OUT / RP_EDGE_LAG edges of rp_forward_coupled read.  Both or neither. */
+    float* hist[2];
 } rp_run;
+
+/* what an edge of rp_forward_coupled reads from its source population q (q's output variable, rp_run.out_var) */
+#define RP_EDGE_LIVE 0 /* as it stands when the target is stepped: y[0] or src[cur] of q.  A feedback edge from a rate
+                          population (rectipy/network.py:1354-1357 reads `source["out"]`): the state before q's step of
+                          this Euler step if q comes later in the order, after it if q comes earlier */
+#define RP_EDGE_OUT 1  /* what q's step of THIS Euler step returned (its pre-update output): a feed-forward edge, or a
+                          feedback edge from a spiking population stepped earlier.  q must come earlier in the order;
+                          reads q's src buffer of the step (RP_OUT_SOURCE) or q's hist[a & 1] (RP_OUT_STATE0: required) */
+#define RP_EDGE_LAG 2  /* q's pre-update output of the PREVIOUS Euler step, hist[(a - 1) & 1] of q (required): a feedback
+                          edge from a spiking population that has not been stepped yet -- its exposed state lags one step
+                          (rectipy/nodes.py:387-392).  Before the first step of a call the caller stores there what the
+                          edge shall read at that step */
+
+/* One population of a coupled circuit: its rp_net, its rp_run (inputs, sampling, trajectories, edge matrices) and, per
+   edge of the run, which member the edge reads and how. */
+typedef struct rp_member {
+    rp_net* net;
+    rp_run* run;
+    int32_t edge_source[RP_MAX_EDGES]; /* index of the source member                                           */
+    int32_t edge_mode[RP_MAX_EDGES];   /* RP_EDGE_*                                                            */
+} rp_member;
 
 /* Arguments of the adjoint sweep over a stored window (LI models). */
 typedef struct rp_bwd {
@@ -275,6 +320,7 @@ const char* rp_last_error(void);
 int rp_sizeof_net(void);
 int rp_sizeof_run(void);
 int rp_sizeof_bwd(void);
+int rp_sizeof_member(void);
 
 /* RP_OK iff HIP device `device` exists and is gfx950. */
 int rp_device_check(int device);
@@ -284,6 +330,17 @@ int rp_refresh_source(const rp_net* net, void* stream);
 
 /* `run->steps` fused Euler steps; asynchronous on `stream`. */
 int rp_forward(rp_net* net, rp_run* run, void* stream);
+
+/*
+ * `count` unsharded populations joined by dense edges, cycles allowed: every Euler step steps the members in array order
+ * (the front end's topological order of the feed-forward edges), one launch per member, inside ONE host call for the
+ * whole window -- what the reference does with one Python graph walk per step (rectipy/network.py:588-599, 962-981,
+ * 1322-1357).  All runs must agree on steps and step0; each member samples / records / stores trajectories through its
+ * own rp_run exactly as under rp_forward.  Edge e of member m reads member edge_source[e] in mode edge_mode[e];
+ * edge_n[e] must be that member's n.  A member may read itself only in RP_EDGE_LAG, or in RP_EDGE_LIVE when its output
+ * variable is the source vector.  Row shards, spike_src and save_src_full are not available here.
+ */
+int rp_forward_coupled(rp_member* members, int32_t count, void* stream);
 
 /* Rows of the partial-sum workspace needed by rp_rate_backward for n neurons. */
 int32_t rp_bwd_partial_rows(int32_t n);
@@ -385,7 +442,7 @@ typedef struct rp_batch {
     float* src[2];            /* [B x ldsrc] ping-pong source vectors r_b = act(v_b), global length n (in/out) */
     int64_t ldsrc;
     int32_t cur;              /* [host, in/out] index of the current source buffer               */
-    int32_t x_mode;           /* RP_X_NONE / RP_X_FULL / RP_X_BCAST                              */
+    int32_t x_mode;           /* RP_X_NONE / RP_X_FULL / RP_X_BCAST / RP_X_PROJ (m, w_in below)   */
     const float* x;           /* inputs: row (t, b) at x + (t * B + b) * ldx                     */
     int64_t ldx;
     int32_t out_var;          /* RP_OUT_*                                                        */
@@ -408,6 +465,26 @@ typedef struct rp_batch {
        columns 16 g + 4 kq + c for c = 0..3 (outer) and kq = 0..3 (inner); columns >= n contribute fmaf(0, 0, acc)
        (mirrored by the oracle).  Equal to the unbatched run up to fp32 rounding, not bit for bit. */
     int32_t layout;           /* RP_BATCH_VALU (0) | RP_BATCH_MFMA (1) | RP_BATCH_MFMA16 (2)          */
+    /* Sampling per trajectory, exactly as rp_run does it for one (rectipy/network.py:588-599): the step with absolute
+       index step0 + t is buffered iff >= cutoff and recorded iff also a multiple of sampling_steps, as the running fp32
+       sum of the buffered outputs divided by their count.  All optional (samples == NULL and rec == NULL: none of it).
+       Every form keeps these buffers BATCH-major, whatever the layout of its state. */
+    int64_t step0;            /* absolute index of the call's first step                           */
+    int32_t cutoff;
+    int32_t sampling_steps;   /* >= 1 when sampling                                                */
+    int32_t max_samples;      /* sample rows per trajectory in samples / rec[]                     */
+    float* acc;               /* [B x ldacc] running sums (in/out); required when sampling.  Read only while acc_count > 0 */
+    int64_t ldacc;
+    int32_t acc_count;        /* [host, in/out] buffered outputs in acc (the same for every trajectory) */
+    int32_t sample_idx;       /* [host, in/out] next sample row                                    */
+    float* samples;           /* optional: sample j of trajectory b at samples + (b * max_samples + j) * ldsamples */
+    int64_t ldsamples;
+    float* rec[2];            /* optional, same layout: post-update v (RP_REC_V) / r (RP_REC_SOURCE) at the sample steps */
+    /* RP_X_PROJ (the input edge inside the step, rectipy/edges.py:48-49): x row (t, b) holds m inputs,
+       I[i] = sum_j w_in[i * ldwin + j] * x[j] as a j-ascending fmaf chain from 0 (as rp_run) */
+    int32_t m;
+    const float* w_in;        /* [rows x ldwin]                                                    */
+    int64_t ldwin;
 } rp_batch;
 
 #define RP_BATCH_VALU 0
@@ -417,9 +494,6 @@ typedef struct rp_batch {
 
 int rp_sizeof_batch(void);
 int rp_forward_batched(const rp_net* net, rp_batch* batch, void* stream);
-int rp_set_batched_tuning(int rows_per_wave, int unroll); /* benchmark-only; 0 = built-in */
-int rp_set_batched_mfma_tuning(int tile_columns, int stages, int waves); /* benchmark-only: tile width (64, 128, 256), LDS ring depth and waves per workgroup (4, 8) of the RP_BATCH_MFMA16 step; 0 = built-in.  Never changes the bits. */
-int rp_set_batched_grid(int max_workgroups); /* benchmark-only: cap on the resident workgroups of the vector-ALU batched step; 0 = built-in */
 
 /*
  * Recursive-least-squares training of a readout edge (reference RLS.update, rectipy/edges.py:227-234, driven by
@@ -482,29 +556,42 @@ int rp_install_forward_tuning(const rp_net* net, int32_t rows_per_wave, int32_t 
                                float us_per_step);
 int rp_clear_forward_tuning(void);
 
-/* Benchmark-only: override the streaming configuration of the tanh step kernel
+/*
+ * MEASUREMENT BUILD ONLY (-DRP_MEASUREMENT: rectipy_amd/_C/librectipy_hip_measure.so, `python -m rectipy_amd.build
+ * --measurement`).  The product library exports none of these and contains none of the kernel instances they select:
+ * process-wide knobs that override how a kernel walks its operands (the scripts under scripts/ sweep them), and the
+ * ablation instances of two kernels ("probe": halves of the kernel switched off, results meaningless).  Unless a
+ * comment says otherwise a knob changes the walk, never the summation order.  0 restores the built-in choice.
+ */
+#ifdef RP_MEASUREMENT
+int rp_set_batched_tuning(int rows_per_wave, int unroll); /* measurement; 0 = built-in */
+int rp_set_batched_mfma_tuning(int tile_columns, int stages, int waves); /* measurement: tile width (64, 128, 256), LDS ring depth and waves per workgroup (4, 8) of the RP_BATCH_MFMA16 step; 0 = built-in.  Tile width, ring depth and waves never change the bits; waves >= 100 select the ablation instances. */
+int rp_set_batched_grid(int max_workgroups); /* measurement: cap on the resident workgroups of the vector-ALU batched step; 0 = built-in */
+/* Measurement: override the streaming configuration of the tanh step kernel
    (rows per wave, unroll depth, non-temporal W loads, grid cap); rows_per_wave = 0 restores
    the built-in choice.  Results are bit-identical for every configuration. */
 int rp_set_tuning(int rows_per_wave, int unroll, int nontemporal, int max_blocks);
 
-/* Benchmark-only: rows per wave and groups in flight per row of the sparse step kernel (tanh model); 0, 0 restores the
+/* Measurement: rows per wave and groups in flight per row of the sparse step kernel (tanh model); 0, 0 restores the
    built-in choice.  Results are bit-identical for every configuration. */
 int rp_set_sparse_tuning(int rows_per_wave, int groups_in_flight);
 int rp_set_blocked_tuning(int waves_per_workgroup, int groups_in_flight); /* blocked sparse step; 0 = built-in */
 
-/* Benchmark-only: rows in flight per wave (unroll) and 1-KiB column groups per lane of the adjoint's column-strip
+/* Measurement: rows in flight per wave (unroll) and 1-KiB column groups per lane of the adjoint's column-strip
    kernel; 0, 0 restores the built-in choice.  Results are bit-identical for every configuration. */
 int rp_set_bwd_tuning(int unroll, int strip_groups);
-int rp_set_bwd_grid(int max_workgroups); /* benchmark-only: cap on the strip kernel's resident workgroups; 0 = built-in */
-/* Benchmark-only: number of row chunks of the adjoint (0 = built-in RC(n)).  Unlike the two above this CHANGES the
+int rp_set_bwd_grid(int max_workgroups); /* measurement: cap on the strip kernel's resident workgroups; 0 = built-in */
+/* Measurement: number of row chunks of the adjoint (0 = built-in RC(n)).  Unlike the two above this CHANGES the
    summation order, i.e. results then differ from the oracle in the last bits; never set in production. */
 int rp_set_bwd_chunks(int max_chunks);
 
-/* Benchmark-only: rows per wave, column chunks in flight and store policy (-1 = default) of the RLS pass. */
+/* Measurement: rows per wave, column chunks in flight and store policy (-1 = default) of the RLS pass. */
 int rp_set_rls_tuning(int rows_per_wave, int unroll, int nontemporal_store);
-int rp_set_gemm_dma(int on); /* benchmark-only: 0 = rp_outer_accum always uses the register-staged kernel (1: LDS-DMA ring on full tiles); identical bits */
-int rp_set_rls_sym(int rows_in_flight); /* benchmark-only: bits 0-7 rows in flight per wave of the symmetric pass (1, 2, 4, 8; 0 = built-in), bits 8-11 resident workgroups per CU (an LDS allocation; 0 = built-in, 15 = no cap); never the bits */
-int rp_set_rls_tile(int kcols_per_tile, int workgroups_per_cu); /* benchmark-only: tile width (x 1024 columns; changes the summation order) and residency cap of the tiled RLS pass; 0, 0 = built-in */
+int rp_set_gemm_dma(int on); /* measurement: 0 = rp_outer_accum always uses the register-staged kernel (1: LDS-DMA ring on full tiles); identical bits */
+int rp_set_rls_sym(int rows_in_flight); /* measurement: bits 0-7 rows in flight per wave of the symmetric pass (1, 2, 4, 8; 0 = built-in), bits 8-11 resident workgroups per CU (an LDS allocation; 0 = built-in, 15 = no cap); never the bits */
+int rp_set_rls_tile(int kcols_per_tile, int workgroups_per_cu); /* measurement: tile width (x 1024 columns; changes the summation order) and residency cap of the tiled RLS pass; 0, 0 = built-in */
+
+#endif /* RP_MEASUREMENT */
 
 /* Bandwidth probe used by bench.py: sums `bytes` of HBM with the same load shape as the step kernel. */
 int rp_stream_probe(const float* buf, int64_t n_floats, float* out, void* stream);

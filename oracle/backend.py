@@ -52,6 +52,7 @@ def _declare(lib):
 
     sig("oracle_refresh_source", C.c_int, [P(RpNet)])
     sig("oracle_forward", C.c_int, [P(RpNet), P(RpRun)])
+    sig("oracle_forward_coupled", C.c_int, [P(_abi.RpMember), C.c_int32])
     sig("oracle_rate_backward", C.c_int, [P(RpNet), P(RpBwd)])
     sig("oracle_qif_backward", C.c_int, [P(RpNet), P(RpBwd)])
     sig("oracle_outer_accum", C.c_int, [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64])
@@ -87,6 +88,9 @@ class OracleBackend:
 
     def forward(self, net, run, device):
         assert self.lib.oracle_forward(C.byref(net), C.byref(run)) == 0
+
+    def forward_coupled(self, members, count, device):
+        assert self.lib.oracle_forward_coupled(members, count) == 0
 
     def rate_backward(self, net, bwd, device):
         assert self.lib.oracle_rate_backward(C.byref(net), C.byref(bwd)) == 0
@@ -126,6 +130,8 @@ class OracleBackend:
         if bt.layout == _abi.RP_BATCH_MFMA16:  # the 16x16x4 form: one chain per element (oracle_forward_batched_mfma16)
             assert self.lib.oracle_forward_batched_mfma16(C.byref(net), C.byref(bt)) == 0
             return
+        sampling = bool(bt.samples or bt.rec[0] or bt.rec[1])
+        counts = None
         for b in range(B):
             nb = _abi.RpNet()
             C.memmove(C.byref(nb), C.byref(net), C.sizeof(_abi.RpNet))
@@ -137,9 +143,24 @@ class OracleBackend:
             run.steps, run.x_mode, run.out_var, run.sampling_steps = bt.steps, bt.x_mode, bt.out_var, 1
             if bt.x:
                 run.x, run.ldx = bt.x + 4 * b * bt.ldx, B * bt.ldx
+            if bt.x_mode == _abi.RP_X_PROJ:
+                run.m, run.w_in, run.ldwin = bt.m, bt.w_in, bt.ldwin
             if bt.traj:
                 run.traj, run.ldtraj = bt.traj + 4 * b * bt.ldtraj, B * bt.ldtraj
+            if sampling:  # trajectory b's rows of the batch-major buffers
+                stride = 4 * b * bt.max_samples * bt.ldsamples
+                run.step0, run.cutoff, run.sampling_steps, run.max_samples = bt.step0, bt.cutoff, bt.sampling_steps, bt.max_samples
+                run.acc, run.acc_count, run.sample_idx = bt.acc + 4 * b * bt.ldacc, bt.acc_count, bt.sample_idx
+                run.ldsamples = bt.ldsamples
+                if bt.samples:
+                    run.samples = bt.samples + stride
+                for q in (0, 1):
+                    if bt.rec[q]:
+                        run.rec[q] = bt.rec[q] + stride
             assert self.lib.oracle_forward(C.byref(nb), C.byref(run)) == 0
+            counts = (run.acc_count, run.sample_idx)
+        if sampling:
+            bt.acc_count, bt.sample_idx = counts
         bt.cur = (bt.cur + bt.steps) % 2
 
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):

@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 10
+RP_ABI_VERSION = 11
 RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_MFMA16, RP_BATCH_SLOTS = 0, 1, 2, 32
 RP_COMM_RCCL, RP_COMM_DIRECT = 0, 1
 
@@ -28,6 +28,8 @@ RP_MODEL_IK_BIEXP = 7
 
 RP_MAX_PARAMS = 12
 RP_MAX_STATE = 4
+RP_MAX_EDGES = 4
+RP_EDGE_LIVE, RP_EDGE_OUT, RP_EDGE_LAG = 0, 1, 2
 
 RP_P_TAU, RP_P_K, RP_P_ETA = 0, 1, 2
 RP_P_RMAX, RP_P_SLOPE, RP_P_V0 = 3, 4, 5
@@ -106,6 +108,22 @@ class RpRun(C.Structure):
         ("save_src_full", fp),
         ("ldfull", C.c_int64),
         ("spike_src", fp),
+        ("n_edges", C.c_int32),
+        ("edge_w", fp * RP_MAX_EDGES),
+        ("edge_ld", C.c_int64 * RP_MAX_EDGES),
+        ("edge_n", C.c_int32 * RP_MAX_EDGES),
+        ("edge_src", fp * RP_MAX_EDGES),
+        ("edge_src_ld", C.c_int64 * RP_MAX_EDGES),
+        ("hist", fp * 2),
+    ]
+
+
+class RpMember(C.Structure):
+    _fields_ = [
+        ("net", C.POINTER(RpNet)),
+        ("run", C.POINTER(RpRun)),
+        ("edge_source", C.c_int32 * RP_MAX_EDGES),
+        ("edge_mode", C.c_int32 * RP_MAX_EDGES),
     ]
 
 
@@ -170,6 +188,20 @@ class RpBatch(C.Structure):
         ("traj", fp),
         ("ldtraj", C.c_int64),
         ("layout", C.c_int32),
+        ("step0", C.c_int64),
+        ("cutoff", C.c_int32),
+        ("sampling_steps", C.c_int32),
+        ("max_samples", C.c_int32),
+        ("acc", fp),
+        ("ldacc", C.c_int64),
+        ("acc_count", C.c_int32),
+        ("sample_idx", C.c_int32),
+        ("samples", fp),
+        ("ldsamples", C.c_int64),
+        ("rec", fp * 2),
+        ("m", C.c_int32),
+        ("w_in", fp),
+        ("ldwin", C.c_int64),
     ]
 
 
@@ -225,6 +257,8 @@ def declare(lib):
     sig("rp_sizeof_net", C.c_int, [])
     sig("rp_sizeof_run", C.c_int, [])
     sig("rp_sizeof_bwd", C.c_int, [])
+    sig("rp_sizeof_member", C.c_int, [])
+    sig("rp_forward_coupled", C.c_int, [P(RpMember), C.c_int32, C.c_void_p])
     sig("rp_refresh_source", C.c_int, [P(RpNet), C.c_void_p])
     sig("rp_forward", C.c_int, [P(RpNet), P(RpRun), C.c_void_p])
     sig("rp_bwd_partial_rows", C.c_int32, [C.c_int32])
@@ -276,8 +310,16 @@ def declare(lib):
 
 EXPORTS = [
     "rp_abi_version", "rp_last_error", "rp_device_check", "rp_sizeof_net", "rp_sizeof_run", "rp_sizeof_bwd",
-    "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum", "rp_outer_accum_rect", "rp_outer_store_rect",
-    "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial", "rp_bwd_apply",
-    "rp_sizeof_comm", "rp_forward_sharded", "rp_backward_sharded",
-    "rp_ipc_alloc", "rp_ipc_open", "rp_ipc_close", "rp_ipc_free", "rp_sizeof_batch", "rp_sizeof_rls", "rp_forward_batched", "rp_set_batched_tuning", "rp_set_batched_mfma_tuning", "rp_set_batched_grid", "rp_rls_sweep", "rp_stream_probe", "rp_tune_forward", "rp_forward_tuning", "rp_install_forward_tuning", "rp_clear_forward_tuning", "rp_set_tuning", "rp_set_sparse_tuning", "rp_set_blocked_tuning", "rp_set_bwd_tuning", "rp_set_bwd_grid", "rp_set_bwd_chunks", "rp_set_rls_tuning", "rp_set_rls_sym", "rp_set_gemm_dma", "rp_set_rls_tile",
+    "rp_sizeof_member", "rp_forward_coupled",
+    "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum",
+    "rp_outer_accum_rect", "rp_outer_store_rect", "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial",
+    "rp_bwd_apply", "rp_sizeof_comm", "rp_forward_sharded", "rp_backward_sharded", "rp_ipc_alloc", "rp_ipc_open",
+    "rp_ipc_close", "rp_ipc_free", "rp_sizeof_batch", "rp_sizeof_rls", "rp_forward_batched", "rp_rls_sweep",
+    "rp_stream_probe", "rp_tune_forward", "rp_forward_tuning", "rp_install_forward_tuning", "rp_clear_forward_tuning",
+]
+# the measurement build (-DRP_MEASUREMENT) adds the knobs of include/rectipy_hip.h's RP_MEASUREMENT section
+MEASUREMENT_EXPORTS = [
+    "rp_set_batched_tuning", "rp_set_batched_mfma_tuning", "rp_set_batched_grid", "rp_set_tuning", "rp_set_sparse_tuning",
+    "rp_set_blocked_tuning", "rp_set_bwd_tuning", "rp_set_bwd_grid", "rp_set_bwd_chunks", "rp_set_rls_tuning",
+    "rp_set_rls_sym", "rp_set_gemm_dma", "rp_set_rls_tile",
 ]

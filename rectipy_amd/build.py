@@ -14,6 +14,10 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "_C")
 LIB_PATH = os.path.join(OUT_DIR, "librectipy_hip.so")
+# The measurement build (-DRP_MEASUREMENT): the same library plus the benchmark-only knobs (rp_set_*), the sweep-only
+# kernel instantiations and the ablation kernels the scripts under scripts/ drive.  Never loaded by the product unless
+# RECTIPY_AMD_MEASUREMENT=1 is set (rectipy_amd/_lib.py); built on demand: python -m rectipy_amd.build --measurement
+MEASURE_LIB_PATH = os.path.join(OUT_DIR, "librectipy_hip_measure.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: every fma in the sources is explicit; the oracle is built the same
@@ -28,34 +32,56 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _deps():
-    deps = sources()
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+def _headers():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     inc = os.path.join(ROOT, "include")
     deps += [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
     deps.append(os.path.abspath(__file__))
     return deps
 
 
-def is_stale():
-    if not os.path.exists(LIB_PATH):
+def _deps():
+    return sources() + _headers()
+
+
+def is_stale(measurement=False):
+    lib = MEASURE_LIB_PATH if measurement else LIB_PATH
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force=False, verbose=True):
-    """Compile every HIP source into one shared library; returns its path."""
-    if not force and not is_stale():
-        return LIB_PATH
-    os.makedirs(OUT_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB_PATH] + sources()
+def build(force=False, verbose=True, measurement=False):
+    """Compile every HIP source (one object per source, the stale ones in parallel) and link them into one shared
+    library; returns its path.  ``measurement``: the -DRP_MEASUREMENT build (see MEASURE_LIB_PATH)."""
+    lib = MEASURE_LIB_PATH if measurement else LIB_PATH
+    if not force and not is_stale(measurement):
+        return lib
+    obj_dir = os.path.join(OUT_DIR, "obj_measure" if measurement else "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    newest_header = max(os.path.getmtime(h) for h in _headers())
+    compile_flags = [f for f in FLAGS if f != "-shared"] + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    if measurement:
+        compile_flags.append("-DRP_MEASUREMENT")
+    jobs, objects = [], []
+    for src in sources():
+        obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
+        objects.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            cmd = [HIPCC] + compile_flags + ["-c", src, "-o", obj]
+            if verbose:
+                print("[rectipy_amd.build]", " ".join(cmd), flush=True)
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, proc in jobs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objects
     if verbose:
-        print("[rectipy_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
-    return LIB_PATH
+        print("[rectipy_amd.build]", " ".join(link), flush=True)
+    subprocess.run(link, check=True)
+    return lib
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB_PATH)
+    print(build(force="--force" in sys.argv, measurement="--measurement" in sys.argv))

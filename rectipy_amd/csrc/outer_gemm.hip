@@ -278,7 +278,11 @@ __global__ __launch_bounds__(kThreads) void outer_accum_dma_kernel(int m, int n,
         }
 }
 
-std::atomic<int> g_gemm_dma{1};  // benchmark-only (rp_set_gemm_dma): 0 = always the register-staged kernel
+#ifdef RP_MEASUREMENT
+std::atomic<int> g_gemm_dma{1};  // measurement build only (rp_set_gemm_dma): 0 = always the register-staged kernel
+#else
+constexpr int g_gemm_dma = 1;
+#endif
 
 }  // namespace
 
@@ -323,10 +327,12 @@ extern "C" int rp_outer_store_rect(int32_t m, int32_t n, int32_t T, float alpha,
     return outer_launch(m, n, T, alpha, A, lda, B, ldb, C, ldc, 0, stream);
 }
 
+#ifdef RP_MEASUREMENT
 extern "C" int rp_set_gemm_dma(int on) {
     g_gemm_dma = on;
     return RP_OK;
 }
+#endif
 
 extern "C" int rp_outer_accum(int32_t n, int32_t T, float alpha, const float* A, int64_t lda, const float* B,
                               int64_t ldb, float* C, int64_t ldc, void* stream) {

@@ -565,8 +565,10 @@ __global__ __launch_bounds__(kThreads) void rls_mirror_kernel(float* Pm, int64_t
 }
 
 constexpr int kSymRowsDefault = 64;
-std::atomic<int> g_sym_inflight{0};  // benchmark-only (rp_set_rls_sym): rows in flight per wave; 0 = built-in
-std::atomic<int> g_sym_per_cu{0}, g_sym_probe{0};  // benchmark-only: residency cap (through an LDS allocation), ablation
+#ifdef RP_MEASUREMENT
+std::atomic<int> g_sym_inflight{0};  // measurement build only (rp_set_rls_sym): rows in flight per wave; 0 = built-in
+std::atomic<int> g_sym_per_cu{0}, g_sym_probe{0};  // measurement build only: residency cap (through an LDS allocation), ablation
+#endif
 
 template <bool UPDATE, int C, int R>
 void launch_sym_rows(const RlsParams& P, hipStream_t st) {
@@ -577,11 +579,16 @@ void launch_sym_rows(const RlsParams& P, hipStream_t st) {
     // per CU), scripts/probes/rls_sym_cap.py; presumably because a tile's stores then reach DRAM pages its loads have
     // just opened.  The cap is an LDS allocation nobody uses.  Small matrices (fewer than four tiles per CU) are not
     // HBM-bound and run uncapped.
+#ifdef RP_MEASUREMENT
     const int req = g_sym_per_cu, probe = g_sym_probe;
+#else
+    constexpr int req = 0;
+#endif
     // (the read-only first pass of a sweep, UPDATE = false, is a plain stream and likes the chip full: 0.39 against 0.47 ms)
     const int per_cu = req == 15 ? 0 : req > 0 ? req
                        : (UPDATE && (int64_t)grid.x * grid.y >= 4 * (int64_t)rp_cu_count() ? 1 : 0);
     const size_t lds = per_cu > 0 ? ((size_t)rp_lds_limit() - 4096) / per_cu - 4096 : 0;  // (static: up to 1.6 KiB)
+#ifdef RP_MEASUREMENT
     if constexpr (C == 32 && R == 8) {
         if (P.n_in % 1024 == 0 && probe) {
 #define RP_SYM_PROBE(Q_)                                                                                              \
@@ -594,6 +601,7 @@ void launch_sym_rows(const RlsParams& P, hipStream_t st) {
             return;  // (measurements only: no column sums, no z')
         }
     }
+#endif
     if (P.n_in % 1024 == 0) {
         if (lds) rp_allow_dynamic_lds<rls_sym_kernel<UPDATE, C, R, true>>(rp_lds_limit() - 8192);
         hipLaunchKernelGGL((rls_sym_kernel<UPDATE, C, R, true>), grid, dim3(kThreads), lds, st, P);
@@ -607,21 +615,29 @@ void launch_sym_rows(const RlsParams& P, hipStream_t st) {
 
 template <bool UPDATE>
 int launch_sym(const RlsParams& P, int rows, hipStream_t st) {
+#ifdef RP_MEASUREMENT
     const int inflight = g_sym_inflight > 0 ? (int)g_sym_inflight : 4;
+#else
+    constexpr int inflight = 4;
+#endif
     switch (rows * 100 + inflight) {
 #define RP_SYM(C_, R_) case C_ * 100 + R_: launch_sym_rows<UPDATE, C_, R_>(P, st); return RP_OK;
-        RP_SYM(16, 2) RP_SYM(16, 4) RP_SYM(16, 8)
-        RP_SYM(32, 2) RP_SYM(32, 4) RP_SYM(32, 8)
-        RP_SYM(64, 1) RP_SYM(64, 2) RP_SYM(64, 4) RP_SYM(64, 8)
+        RP_SYM(16, 4) RP_SYM(32, 4) RP_SYM(64, 4)
+#ifdef RP_MEASUREMENT
+        RP_SYM(16, 2) RP_SYM(16, 8) RP_SYM(32, 2) RP_SYM(32, 8) RP_SYM(64, 1) RP_SYM(64, 2) RP_SYM(64, 8)
+#endif
 #undef RP_SYM
         default: return RP_ERR_ARG;
     }
 }
 
-std::atomic<int> g_rls_R{0}, g_rls_U{0}, g_rls_nts{-1};  // benchmark-only override (rp_set_rls_tuning)
-
-std::atomic<int> g_rls_blocks{0};  // benchmark-only: grid cap override
-std::atomic<int> g_rls_tile_u{0}, g_rls_tile_per_cu{0};  // benchmark-only (rp_set_rls_tile): KiB-columns per tile, residency cap
+#ifdef RP_MEASUREMENT
+std::atomic<int> g_rls_R{0}, g_rls_U{0}, g_rls_nts{-1};  // measurement build only (rp_set_rls_tuning)
+std::atomic<int> g_rls_blocks{0};  // measurement build only: grid cap override
+std::atomic<int> g_rls_tile_u{0}, g_rls_tile_per_cu{0};  // measurement build only (rp_set_rls_tile): KiB-columns per tile, residency cap
+#else
+constexpr int g_rls_R = 0, g_rls_U = 0, g_rls_nts = -1, g_rls_blocks = 0, g_rls_tile_u = 0, g_rls_tile_per_cu = 0;
+#endif
 
 template <int R, int U, bool NTS, bool UPDATE>
 void launch_cfg(const RlsParams& P, bool vec4, hipStream_t st) {
@@ -631,9 +647,14 @@ void launch_cfg(const RlsParams& P, bool vec4, hipStream_t st) {
     const int cap = cap_req > 0 ? cap_req : 2048;
     if (blocks > cap) blocks = cap;
     const int policy = g_rls_nts;
-    if (vec4 && policy >= 0 && (policy & 2))
+#ifdef RP_MEASUREMENT
+    if (vec4 && policy >= 0 && (policy & 2)) {
         hipLaunchKernelGGL((rls_pass_kernel<R, U, NTS, true, UPDATE, false>), dim3(blocks), dim3(kThreads), 0, st, P);
-    else if (vec4)
+        return;
+    }
+#endif
+    (void)policy;
+    if (vec4)
         hipLaunchKernelGGL((rls_pass_kernel<R, U, NTS, true, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
     else
         hipLaunchKernelGGL((rls_pass_kernel<R, 1, NTS, false, UPDATE>), dim3(blocks), dim3(kThreads), 0, st, P);
@@ -650,7 +671,8 @@ void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
         const int tile_cols = 1024 * TU;
         const int tpr = (P.n_in + tile_cols - 1) / tile_cols;
         const unsigned blocks = (unsigned)P.n_in * (unsigned)tpr;
-        const size_t lds = per_cu > 0 ? ((size_t)rp_lds_limit() - 1024) / per_cu - 64 : 0;  // (the kernel has 16 static bytes)
+        const size_t lds = per_cu > 0 ? ((size_t)rp_lds_limit() - 1024) / (per_cu > 0 ? per_cu : 1) - 64 : 0;  // (the kernel has 16 static bytes)
+#ifdef RP_MEASUREMENT
 #define RP_TILE(TU_)                                                                                                  \
     if (TU == TU_) {                                                                                                  \
         if (nts) {                                                                                                    \
@@ -661,7 +683,17 @@ void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
             hipLaunchKernelGGL((rls_tile_kernel<false, UPDATE, TU_>), dim3(blocks), dim3(kThreads), lds, st, P);     \
         }                                                                                                             \
     }
-        RP_TILE(1) RP_TILE(2) RP_TILE(4)
+#else
+#define RP_TILE(TU_)                                                                                                  \
+    if (TU == TU_) {                                                                                                  \
+        if (lds) rp_allow_dynamic_lds<rls_tile_kernel<true, UPDATE, TU_>>(rp_lds_limit() - 1024);                     \
+        hipLaunchKernelGGL((rls_tile_kernel<true, UPDATE, TU_>), dim3(blocks), dim3(kThreads), lds, st, P);           \
+    }
+#endif
+        RP_TILE(kTileCols / 1024)
+#ifdef RP_MEASUREMENT
+        RP_TILE(2) RP_TILE(4)
+#endif
 #undef RP_TILE
         if (P.x_next && !P.no_dot)
             hipLaunchKernelGGL(rls_zn_kernel, dim3((P.n_in + 255) / 256), dim3(256), 0, st, P, tile_cols);
@@ -675,8 +707,13 @@ void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
             launch_cfg<R_, U_, false, UPDATE>(P, vec4, st);       \
         return;                                                   \
     }
+#ifdef RP_MEASUREMENT
     RP_RLS(2, 4) RP_RLS(1, 4) RP_RLS(1, 8) RP_RLS(2, 2) RP_RLS(4, 2) RP_RLS(4, 1) RP_RLS(2, 8) RP_RLS(1, 16) RP_RLS(4, 4)
+#endif
 #undef RP_RLS
+    (void)R;
+    (void)U;
+    (void)nts;
     launch_cfg<2, 4, true, UPDATE>(P, vec4, st);
 }
 
@@ -684,6 +721,7 @@ void launch_pass(const RlsParams& P, bool vec4, hipStream_t st) {
 
 extern "C" int rp_sizeof_rls(void) { return (int)sizeof(rp_rls); }
 
+#ifdef RP_MEASUREMENT
 extern "C" int rp_set_rls_sym(int rows_in_flight) {
     g_sym_inflight = rows_in_flight & 0xff;
     g_sym_per_cu = (rows_in_flight >> 8) & 0xf;   // measurements only: workgroups per CU (0 = no cap)
@@ -706,6 +744,7 @@ extern "C" int rp_set_rls_tuning(int rows_per_wave, int unroll, int nontemporal_
     g_rls_nts = nontemporal_store;    // -1 default; bit 0: non-temporal stores, bit 1: cached (not streaming) loads
     return RP_OK;
 }
+#endif
 
 extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, const float* X, int64_t ldx,
                             const float* Y, int64_t ldy, float* pred, int64_t ldpred, float* loss, void* stream) {

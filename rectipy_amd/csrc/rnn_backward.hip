@@ -29,7 +29,9 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kMaxChunks = 64;
-std::atomic<int> g_bwd_chunks{0};  // benchmark-only override of the chunk count (rp_set_bwd_chunks); changes the summation order
+#ifdef RP_MEASUREMENT
+std::atomic<int> g_bwd_chunks{0};  // measurement build only (rp_set_bwd_chunks): overrides the chunk count, i.e. the summation order
+#endif
 
 // RC(n, rows): rows per chunk (multiple of 8) for `rows` rows of an n-column matrix.  The chunk count is part of the
 // summation-order contract (oracle/rnn_oracle.c mirrors it): Q = clamp(3072 / ceil(n / 256), 8, 64), i.e. about 3072
@@ -44,7 +46,9 @@ std::atomic<int> g_bwd_chunks{0};  // benchmark-only override of the chunk count
 inline int chunk_rows(int n, int rows) {
     int q = 3072 / ((n + 255) / 256);
     q = q < 8 ? 8 : (q > kMaxChunks ? kMaxChunks : q);
+#ifdef RP_MEASUREMENT
     if (g_bwd_chunks > 0) q = g_bwd_chunks;
+#endif
     int rc = (rows + q - 1) / q;
     rc = (rc + 7) & ~7;
     return rc < 8 ? 8 : rc;
@@ -183,8 +187,10 @@ __global__ __launch_bounds__(kThreads) void wt_partial_kernel(const BwdParams P)
     }
 }
 
-// benchmark-only override of (U, SW); 0 = built-in choice (rp_set_bwd_tuning)
+#ifdef RP_MEASUREMENT
+// measurement build only: override of (U, SW) and of the grid cap; 0 = built-in choice (rp_set_bwd_tuning, rp_set_bwd_grid)
 std::atomic<int> g_bwd_U{0}, g_bwd_SW{0}, g_bwd_blocks{0};
+#endif
 
 void launch_wt_partial(const BwdParams& P, bool vec4, hipStream_t st) {
     if (!vec4) {
@@ -200,20 +206,29 @@ void launch_wt_partial(const BwdParams& P, bool vec4, hipStream_t st) {
     // 24 KiB in flight per CU) is the fastest shape: n = 32768 602 us vs 634 for 2-KiB strips x 4 rows.
     const bool many = ((P.n + 255) / 256) * P.q >= 2560;
     const bool wide = ((P.n + 511) / 512) * P.q >= 1024;
+#ifdef RP_MEASUREMENT
     const int tu = g_bwd_U, tsw = g_bwd_SW;
+#else
+    constexpr int tu = 0, tsw = 0;
+#endif
     const int U = tu ? tu : (many ? 2 : wide ? 4 : 8), SW = tsw ? tsw : (many ? 1 : wide ? 2 : 1);
     const int strips = (P.n + 256 * SW - 1) / (256 * SW);
     int blocks = (strips * P.q + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     if (many && !tu && !tsw && blocks > 768) blocks = 768;
+#ifdef RP_MEASUREMENT
     if (const int cap = g_bwd_blocks; cap > 0 && blocks > cap) blocks = cap;
+#endif
 #define RP_BW(U_, SW_)                                                                                         \
     if (U == U_ && SW == SW_) {                                                                                \
         hipLaunchKernelGGL((wt_partial_kernel<true, U_, SW_>), dim3(blocks), dim3(kThreads), 0, st, P);        \
         return;                                                                                                \
     }
-    RP_BW(8, 1) RP_BW(16, 1) RP_BW(4, 1) RP_BW(4, 2) RP_BW(8, 2) RP_BW(2, 2) RP_BW(6, 2) RP_BW(32, 1) RP_BW(12, 1) RP_BW(3, 2) RP_BW(5, 2)
-    RP_BW(2, 1) RP_BW(1, 1) RP_BW(3, 1) RP_BW(1, 2)
+    RP_BW(2, 1) RP_BW(4, 2)  // (and (8, 1) below): the shapes the rule above picks
+#ifdef RP_MEASUREMENT
+    RP_BW(16, 1) RP_BW(4, 1) RP_BW(8, 2) RP_BW(2, 2) RP_BW(6, 2) RP_BW(32, 1) RP_BW(12, 1) RP_BW(3, 2) RP_BW(5, 2)
+    RP_BW(1, 1) RP_BW(3, 1) RP_BW(1, 2)
+#endif
 #undef RP_BW
     hipLaunchKernelGGL((wt_partial_kernel<true, 8, 1>), dim3(blocks), dim3(kThreads), 0, st, P);
 }
@@ -972,6 +987,7 @@ int rp_backward_sharded(const rp_net* net, const rp_bwd* b, const rp_comm* comm,
     return RP_OK;
 }
 
+#ifdef RP_MEASUREMENT
 int rp_set_bwd_chunks(int max_chunks) {
     g_bwd_chunks = max_chunks;
     return RP_OK;
@@ -987,6 +1003,7 @@ int rp_set_bwd_tuning(int unroll, int strip_groups) {
     g_bwd_SW = strip_groups;
     return RP_OK;
 }
+#endif
 
 // Validation and parameter block of a spiking sweep over the `net->rows` local neurons (rows == n: whole population;
 // rows < n: a row shard, all per-neuron vectors of rp_bwd local).

@@ -38,7 +38,55 @@ struct BatchParams {
     int out_var;
     float* traj_t;     // row (t, 0)
     int64_t ldtraj;
+    // RP_X_PROJ: the input edge inside the step (x row (t, b) holds m inputs)
+    int m;
+    const float* w_in;
+    int64_t ldwin;
+    // sampling of this step (rp_batch: per trajectory what rp_run does for one; all buffers batch-major)
+    int flags;          // FLAG_BUFFER | FLAG_SAMPLE | FLAG_FIRST
+    float count;
+    float* acc;
+    int64_t ldacc;
+    float* sample_row;  // row (sample, trajectory 0); trajectory b at + b * sample_stride
+    float* rec_row[2];
+    int64_t sample_stride;
 };
+
+constexpr int FLAG_BUFFER = 1;  // step >= cutoff: output joins the sampling buffer
+constexpr int FLAG_SAMPLE = 2;  // record the mean of the buffer at this step
+constexpr int FLAG_FIRST = 4;   // first output of a buffer: the accumulator's old contents are not read
+
+__device__ __forceinline__ float batched_input(const BatchParams& P, int i, int b) {
+    if (P.x_mode == RP_X_FULL) return P.x_t[(int64_t)b * P.ldx + i];
+    if (P.x_mode == RP_X_BCAST) return P.x_t[(int64_t)b * P.ldx];
+    if (P.x_mode == RP_X_PROJ) {  // weights @ x (edges.py:48-49), sequential in j as in rp_forward
+        float s = 0.f;
+        const float* wr = P.w_in + (int64_t)i * P.ldwin;
+        const float* xb = P.x_t + (int64_t)b * P.ldx;
+        for (int j = 0; j < P.m; ++j) s = fmaf(wr[j], xb[j], s);
+        return s;
+    }
+    return 0.f;
+}
+
+// trajectory output, running-buffer mean (network.py:590-597) and post-update recordings (network.py:147-148) of
+// neuron i, trajectory b -- the unbatched kernel's sample_output per trajectory
+__device__ __forceinline__ void batched_outputs(const BatchParams& P, int i, int b, float out, float v_new, float r_new) {
+    if (P.traj_t) P.traj_t[(int64_t)b * P.ldtraj + i] = out;
+    if (P.flags & FLAG_BUFFER) {
+        float* ap = P.acc + (int64_t)b * P.ldacc + i;
+        float a = ((P.flags & FLAG_FIRST) ? 0.0f : *ap) + out;
+        if (P.flags & FLAG_SAMPLE) {
+            if (P.sample_row) P.sample_row[(int64_t)b * P.sample_stride + i] = a / P.count;
+            a = 0.f;
+        }
+        *ap = a;
+    }
+    if (P.flags & FLAG_SAMPLE) {
+        if (P.rec_row[0]) P.rec_row[0][(int64_t)b * P.sample_stride + i] = v_new;
+        if (P.rec_row[1]) P.rec_row[1][(int64_t)b * P.sample_stride + i] = r_new;
+    }
+}
 
 template <int MODEL>
 __device__ __forceinline__ float act(const BatchParams& P, int i, float v) {
@@ -54,17 +102,16 @@ __device__ __forceinline__ float act(const BatchParams& P, int i, float v) {
 template <int MODEL>
 __device__ __forceinline__ void epilogue(const BatchParams& P, int i, int b, float wsum) {
     const int gi = P.row0 + i;
-    float I = 0.f;
-    if (P.x_mode == RP_X_FULL) I = P.x_t[(int64_t)b * P.ldx + i];
-    else if (P.x_mode == RP_X_BCAST) I = P.x_t[(int64_t)b * P.ldx];
+    const float I = batched_input(P, i, b);
     float* vb = P.v + (int64_t)b * P.ldv;
     const float v = vb[i];
     const float dv = ((-v / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * wsum) + I) + P.p[RP_P_ETA][i];
     const float v_new = v + P.dt * dv;
+    const float r_new = act<MODEL>(P, i, v_new);
     vb[i] = v_new;
-    P.src_next[(int64_t)b * P.ldsrc + gi] = act<MODEL>(P, i, v_new);
-    if (P.traj_t)
-        P.traj_t[(int64_t)b * P.ldtraj + i] = P.out_var == RP_OUT_STATE0 ? v : P.src_cur[(int64_t)b * P.ldsrc + gi];
+    P.src_next[(int64_t)b * P.ldsrc + gi] = r_new;
+    if (P.traj_t || P.flags)
+        batched_outputs(P, i, b, P.out_var == RP_OUT_STATE0 ? v : P.src_cur[(int64_t)b * P.ldsrc + gi], v_new, r_new);
 }
 
 // one 256-column chunk: R loads of W, B loads of the sources, R * B * 4 fmaf (fully unrolled: the accumulators must
@@ -137,13 +184,19 @@ __global__ __launch_bounds__(kThreads) void step_batched_kernel(const BatchParam
     }
 }
 
-std::atomic<int> g_bt_R{0}, g_bt_U{0}, g_bt_blocks{0};  // benchmark-only override (rp_set_batched_tuning / _grid)
+#ifdef RP_MEASUREMENT
+std::atomic<int> g_bt_R{0}, g_bt_U{0}, g_bt_blocks{0};  // measurement build only (rp_set_batched_tuning / _grid)
+#endif
 
 template <int MODEL, int R, int B, int U>
 void launch(const BatchParams& P, hipStream_t st, int default_blocks = 2048) {
     const int groups = (P.rows + R - 1) / R;
     int blocks = (groups + 3) / 4;
+#ifdef RP_MEASUREMENT
     const int cap = g_bt_blocks > 0 ? (int)g_bt_blocks : default_blocks;
+#else
+    const int cap = default_blocks;
+#endif
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((step_batched_kernel<MODEL, R, B, U>), dim3(blocks), dim3(kThreads), 0, st, P);
 }
@@ -267,18 +320,16 @@ __global__ __launch_bounds__(kThreads) void step_batched_mfma_kernel(const Batch
                 const int i = row_blk + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (i < P.rows) {
                     const int gi = P.row0 + i, b = lr;
-                    float I = 0.f;
-                    if (P.x_mode == RP_X_FULL) I = P.x_t[(int64_t)b * P.ldx + i];
-                    else if (P.x_mode == RP_X_BCAST) I = P.x_t[(int64_t)b * P.ldx];
+                    const float I = batched_input(P, i, b);
                     float* vp = P.v + (int64_t)i * kSlots + b;
                     const float v = *vp;
                     const float dv = ((-v / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * acc[j][r]) + I) + P.p[RP_P_ETA][i];
                     const float v_new = v + P.dt * dv;
+                    const float r_new = act<MODEL>(P, i, v_new);
                     *vp = v_new;
-                    P.src_next[(int64_t)gi * kSlots + b] = act<MODEL>(P, i, v_new);
-                    if (P.traj_t)
-                        P.traj_t[(int64_t)b * P.ldtraj + i] =
-                            P.out_var == RP_OUT_STATE0 ? v : P.src_cur[(int64_t)gi * kSlots + b];
+                    P.src_next[(int64_t)gi * kSlots + b] = r_new;
+                    if (P.traj_t || P.flags)
+                        batched_outputs(P, i, b, P.out_var == RP_OUT_STATE0 ? v : P.src_cur[(int64_t)gi * kSlots + b], v_new, r_new);
                 }
             }
     }
@@ -749,8 +800,10 @@ int launch_mfma16(const BatchParams& P, int B, hipStream_t st) {
     }
 }
 
-// benchmark-only override (rp_set_batched_mfma_tuning): tile columns, ring stages, waves per workgroup
+#ifdef RP_MEASUREMENT
+// measurement build only (rp_set_batched_mfma_tuning): tile columns, ring stages, waves per workgroup
 std::atomic<int> g_m16_tc{0}, g_m16_stages{0}, g_m16_waves{0};
+#endif
 
 template <int MODEL, int NB>
 int launch_mfma16_cfg(const BatchParams& P, int B, hipStream_t st) {
@@ -761,6 +814,13 @@ int launch_mfma16_cfg(const BatchParams& P, int B, hipStream_t st) {
     //                              32768: 0.82 / 0.81 / 0.745;  65536: 3.28 / 3.21 / 2.99  -> the split kernel from 192 workgroups
     int tc = 64, stages = 3, waves = 4;
     if (NB == 2 && P.rows >= 128 * 192) waves = 16;
+#ifndef RP_MEASUREMENT
+    (void)tc;
+    (void)stages;
+    if constexpr (NB == 2)
+        if (waves == 16) return launch_mfma16_split<MODEL, 64, 3>(P, B, st);
+    return launch_mfma16<MODEL, NB, 64, 3, 4>(P, B, st);
+#else
     if (g_m16_tc > 0) tc = g_m16_tc;
     if (g_m16_stages > 0) stages = g_m16_stages;
     if (g_m16_waves > 0) waves = g_m16_waves;
@@ -813,12 +873,14 @@ int launch_mfma16_cfg(const BatchParams& P, int B, hipStream_t st) {
         }
     }
     return RP_ERR_ARG;
+#endif
 }
 
 template <int MODEL>
 int launch_model(const BatchParams& P, int B, hipStream_t st) {
     // R * B accumulator sets of four floats per lane; W chunks in flight per wave: R * U KiB
-    if constexpr (MODEL == RP_MODEL_LI_TANH) {  // benchmark-only sweep
+#ifdef RP_MEASUREMENT
+    if constexpr (MODEL == RP_MODEL_LI_TANH) {  // sweep (rp_set_batched_tuning)
         const int key = B * 100 + g_bt_R * 10 + g_bt_U;
         switch (key) {
             case 221: launch<MODEL, 2, 2, 1>(P, st); return RP_OK;
@@ -843,6 +905,7 @@ int launch_model(const BatchParams& P, int B, hipStream_t st) {
             default: break;
         }
     }
+#endif
     switch (B) {
         // r02 (scripts/sweep_batched.py, N = 32768, ms per step): fewer resident workgroups, as for the unbatched walk --
         // B=2 (4,2) on 2048 0.627, (4,1) on 768 0.618;  B=4 (8,2) on 2048 0.639, on 512 0.629;  B=8 flat (0.86)
@@ -862,6 +925,7 @@ extern "C" {
 
 int rp_sizeof_batch(void) { return (int)sizeof(rp_batch); }
 
+#ifdef RP_MEASUREMENT
 int rp_set_batched_grid(int max_workgroups) {
     g_bt_blocks = max_workgroups;
     return RP_OK;
@@ -879,6 +943,7 @@ int rp_set_batched_tuning(int rows_per_wave, int unroll) {
     g_bt_U = unroll;
     return RP_OK;
 }
+#endif
 
 int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
     if (!net || !bt) RP_FAIL(RP_ERR_ARG, "net / batch is null");
@@ -907,10 +972,26 @@ int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
         RP_FAIL(RP_ERR_ARG, "W and the source buffers must be 16-byte aligned");
     if (bt->cur != 0 && bt->cur != 1) RP_FAIL(RP_ERR_ARG, "cur must be 0 or 1");
     if (bt->steps < 0) RP_FAIL(RP_ERR_ARG, "steps < 0");
-    if (bt->x_mode != RP_X_NONE && bt->x_mode != RP_X_FULL && bt->x_mode != RP_X_BCAST)
-        RP_FAIL(RP_ERR_ARG, "x_mode must be RP_X_NONE, RP_X_FULL or RP_X_BCAST");
-    if (bt->x_mode != RP_X_NONE && (!bt->x || bt->ldx < (bt->x_mode == RP_X_FULL ? net->rows : 1)))
+    if (bt->x_mode != RP_X_NONE && bt->x_mode != RP_X_FULL && bt->x_mode != RP_X_BCAST && bt->x_mode != RP_X_PROJ)
+        RP_FAIL(RP_ERR_ARG, "x_mode must be RP_X_NONE, RP_X_FULL, RP_X_BCAST or RP_X_PROJ");
+    if (bt->x_mode == RP_X_PROJ) {
+        if (!bt->x || !bt->w_in || bt->m < 1 || bt->ldx < bt->m || bt->ldwin < bt->m)
+            RP_FAIL(RP_ERR_SHAPE, "RP_X_PROJ needs x (ldx >= m), w_in (ldwin >= m), m >= 1");
+    } else if (bt->x_mode != RP_X_NONE && (!bt->x || bt->ldx < (bt->x_mode == RP_X_FULL ? net->rows : 1)))
         RP_FAIL(RP_ERR_SHAPE, "inputs missing or rows too short");
+    const bool sampling = bt->samples || bt->rec[0] || bt->rec[1];
+    if (sampling) {
+        if (!bt->acc || bt->ldacc < net->rows) RP_FAIL(RP_ERR_ARG, "sampling needs the acc buffer with ldacc >= rows");
+        if (bt->ldsamples < net->rows) RP_FAIL(RP_ERR_SHAPE, "ldsamples < rows");
+        if (bt->sampling_steps < 1 || bt->cutoff < 0 || bt->step0 < 0 || bt->acc_count < 0 || bt->sample_idx < 0)
+            RP_FAIL(RP_ERR_ARG, "sampling_steps >= 1 and cutoff, step0, acc_count, sample_idx >= 0 required");
+        int64_t produced = 0;
+        for (int64_t t = bt->step0; t < bt->step0 + bt->steps; ++t)
+            if (t >= bt->cutoff && t % bt->sampling_steps == 0) ++produced;
+        if (bt->sample_idx + produced > bt->max_samples)
+            RP_FAIL(RP_ERR_SHAPE, "sample buffers hold %d rows per trajectory, call needs %lld", bt->max_samples,
+                    (long long)(bt->sample_idx + produced));
+    }
     if (bt->traj && bt->ldtraj < net->rows) RP_FAIL(RP_ERR_SHAPE, "ldtraj < rows");
     const int need[] = {RP_P_TAU, RP_P_K, RP_P_ETA};
     for (int q = 0; q < 3; ++q)
@@ -935,11 +1016,33 @@ int rp_forward_batched(const rp_net* net, rp_batch* bt, void* stream) {
     P.ldx = bt->ldx;
     P.out_var = bt->out_var;
     P.ldtraj = bt->ldtraj;
+    P.m = bt->m;
+    P.w_in = bt->w_in;
+    P.ldwin = bt->ldwin;
+    P.acc = bt->acc;
+    P.ldacc = bt->ldacc;
+    P.sample_stride = (int64_t)bt->max_samples * bt->ldsamples;
     for (int t = 0; t < bt->steps; ++t) {
         P.src_cur = bt->src[bt->cur];
         P.src_next = bt->src[bt->cur ^ 1];
         P.x_t = bt->x ? bt->x + (int64_t)t * B * bt->ldx : nullptr;
         P.traj_t = bt->traj ? bt->traj + (int64_t)t * B * bt->ldtraj : nullptr;
+        P.flags = 0;
+        P.sample_row = P.rec_row[0] = P.rec_row[1] = nullptr;
+        if (const int64_t t_abs = bt->step0 + t; sampling && t_abs >= bt->cutoff) {  // (network.py:590-597, as rp_forward)
+            P.flags |= FLAG_BUFFER;
+            if (bt->acc_count == 0) P.flags |= FLAG_FIRST;
+            bt->acc_count += 1;
+            if (t_abs % bt->sampling_steps == 0) {
+                P.flags |= FLAG_SAMPLE;
+                P.count = (float)bt->acc_count;
+                const int64_t off = (int64_t)bt->sample_idx * bt->ldsamples;
+                P.sample_row = bt->samples ? bt->samples + off : nullptr;
+                for (int q = 0; q < 2; ++q) P.rec_row[q] = bt->rec[q] ? bt->rec[q] + off : nullptr;
+                bt->sample_idx += 1;
+                bt->acc_count = 0;
+            }
+        }
         if (mfma16) {
             int rc;
             if (net->model == RP_MODEL_LI_TANH)

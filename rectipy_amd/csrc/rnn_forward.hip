@@ -39,6 +39,13 @@ constexpr int FLAG_BUFFER = 1;  // step >= cutoff: output joins the sampling buf
 constexpr int FLAG_SAMPLE = 2;  // record mean of the buffer at this step
 constexpr int FLAG_FIRST = 4;   // first output of a buffer (acc_count was 0): the accumulator's old contents are not read
 
+struct EdgeArg {  // one dense edge into the population (rp_run.edge_*): the source vector of THIS step
+    const float* W;
+    int64_t ld;
+    const float* src;
+    int n, vec4;
+};
+
 struct StepParams {
     const float* W;
     int64_t ldw;
@@ -76,6 +83,10 @@ struct StepParams {
     const int32_t* sp_batch_class;
     const int32_t* sp_phase_window;
     int sp_phases, sp_batches, sp_block_rows;
+    // dense edges from other vectors into this population (rp_run.edge_*): the source vector of THIS step
+    int n_edges;
+    EdgeArg edge[RP_MAX_EDGES];
+    float* hist_t;  // optional: this step's pre-update output (rp_run.hist[t_abs & 1])
 };
 
 // ---- row dot products (rp_dot.h) ---------------------------------------------
@@ -113,6 +124,7 @@ __device__ __forceinline__ float input_current(const StepParams& P, int i) {
 // running-buffer mean of the node output (network.py:590-597)
 __device__ __forceinline__ void sample_output(const StepParams& P, int i, float out) {
     if (P.traj_t) P.traj_t[i] = out;
+    if (P.hist_t) P.hist_t[i] = out;
     if (P.flags & FLAG_BUFFER) {
         float a = ((P.flags & FLAG_FIRST) ? 0.0f : P.acc[i]) + out;
         if (P.flags & FLAG_SAMPLE) {
@@ -133,10 +145,12 @@ __device__ __forceinline__ float activation(const StepParams& P, int i, float v)
     }
 }
 
-template <int MODEL>
-__device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum) {
+// EDGES: `esum` = ((E_0 + E_1) + ...) of the population's dense edges joins the node input (rp_run.edge_*)
+template <int MODEL, bool EDGES = false>
+__device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum, float esum = 0.f) {
     const int gi = P.row0 + i;
-    const float I = input_current(P, i);
+    float I = input_current(P, i);
+    if constexpr (EDGES) I = P.x_mode != RP_X_NONE ? I + esum : esum;
     if constexpr (MODEL >= RP_MODEL_QIF) {
         // SpikeResetNet.forward (nodes.py:382-392) with the field of the spiking template:
         //   QIF      qif.yaml:11-12     v' = (v^2 + eta + I)/tau + k s_in;          s' = -s/tau_s + spike
@@ -254,6 +268,50 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepParams P) {
     step_body<MODEL, R, U, VEC4, NT>(P);
 }
 
+// Step of a population with dense edges from other vectors (rp_run.edge_*, rp_forward_coupled): the wave that owns a
+// row group streams its rows of W and then its rows of every edge matrix -- each a row dot product with the recurrent
+// one's summation tree (rp_dot.h) on the edge's own width --, adds the edge sums in edge order and hands them to the
+// epilogue as part of the node input.  One launch per population and Euler step whatever the number of edges.
+template <int MODEL, int R, int U, bool VEC4>
+__global__ __launch_bounds__(kThreads) void step_edges_kernel(const StepParams P) {
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int groups = (P.rows + R - 1) / R;
+    for (int g = blockIdx.x * kWavesPerBlock + wave; g < groups; g += gridDim.x * kWavesPerBlock) {
+        const int row_base = g * R;
+        float sum[R], esum[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) esum[j] = 0.f;
+        if constexpr (VEC4)
+            dot_rows_v4<R, U, true>(P, row_base, lane, sum);
+        else
+            dot_rows_s1<R>(P, row_base, lane, sum);
+        for (int e = 0; e < P.n_edges; ++e) {
+            // Edge e's descriptor straight from the kernel-argument segment (a scalar load at a runtime offset): indexing the
+            // by-value block `P` with a runtime e would copy it to scratch, selecting among four copies holds 32 more SGPRs.
+            typedef const __attribute__((address_space(4))) char* karg_ptr;
+            typedef const __attribute__((address_space(4))) EdgeArg* edge_ptr;
+            const edge_ptr Ep = (edge_ptr)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(StepParams, edge)) + e;
+            const EdgeArg E{Ep->W, Ep->ld, Ep->src, Ep->n, Ep->vec4};
+            float es[R];
+            if (E.vec4)
+                rp_dot_rows_v4<R, U, true>(RowDotArgs{E.W, E.ld, E.n, P.rows, P.row0, E.src}, row_base, lane, es);
+            else
+                rp_dot_rows_s1<R>(RowDotArgs{E.W, E.ld, E.n, P.rows, P.row0, E.src}, row_base, lane, es);
+#pragma unroll
+            for (int j = 0; j < R; ++j) esum[j] = e == 0 ? es[j] : esum[j] + es[j];
+        }
+        float mine = 0.f, mine_e = 0.f;
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (lane == j) {
+                mine = sum[j];
+                mine_e = esum[j];
+            }
+        if (lane < R && row_base + lane < P.rows) epilogue<MODEL, true>(P, row_base + lane, mine, mine_e);
+    }
+}
+
 // The same code under its own name: the launches rp_tune_forward times on its scratch population, so that a kernel
 // trace keeps them apart from the steps of a run.
 template <int R, int U>
@@ -354,8 +412,10 @@ __global__ __launch_bounds__(WAVES * RP_WAVE) void step_sparse_blocked_kernel(co
                                      [&](int row, float sum) { epilogue<MODEL>(P, row, sum); });
 }
 
-// benchmark-only: waves per workgroup / groups in flight of the blocked sparse step (0 = built-in)
+#ifdef RP_MEASUREMENT
+// measurement build only: waves per workgroup / groups in flight of the blocked sparse step (0 = built-in)
 std::atomic<int> g_blocked_waves{0}, g_blocked_U{0};
+#endif
 
 template <int MODEL, int WAVES, int U>
 int launch_step_sparse_blocked_cfg(const StepParams& P, hipStream_t st, int n_cu, size_t lds) {
@@ -374,10 +434,13 @@ int launch_step_sparse_blocked(const StepParams& P, hipStream_t st, int n_cu) {
     const size_t limit = rp_lds_limit();
     // 16 waves per workgroup when source + parked sums fit the LDS, else 8 (n = 32768 with 16-row blocks: 128 + 32 KiB)
     int waves = src_bytes + 16 * per_wave <= limit ? 16 : 8;
+#ifdef RP_MEASUREMENT
     if (g_blocked_waves == 8 || g_blocked_waves == 16) waves = g_blocked_waves;
+#endif
     const size_t lds = src_bytes + waves * per_wave;
     if (lds > limit) return RP_ERR_SHAPE;
-    if constexpr (MODEL == RP_MODEL_LI_TANH) {  // benchmark-only sweep (rp_set_blocked_tuning)
+#ifdef RP_MEASUREMENT
+    if constexpr (MODEL == RP_MODEL_LI_TANH) {  // sweep (rp_set_blocked_tuning)
         if (g_blocked_U == 4) return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 4>(P, st, n_cu, lds)
                                                  : launch_step_sparse_blocked_cfg<MODEL, 8, 4>(P, st, n_cu, lds);
         if (g_blocked_U == 8) return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 8>(P, st, n_cu, lds)
@@ -389,14 +452,17 @@ int launch_step_sparse_blocked(const StepParams& P, hipStream_t st, int n_cu) {
         if (g_blocked_U == 3) return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 3>(P, st, n_cu, lds)
                                                  : launch_step_sparse_blocked_cfg<MODEL, 8, 3>(P, st, n_cu, lds);
     }
+#endif
     // groups in flight per lane (scripts/tune_blocked.py, us per step, 16 waves): n = 32768 (8-row blocks) U=4 121.1,
     // U=2 117.7, U=1 133.9;  n = 16384 (4-row blocks) U=4 39.7, U=2 38.0
     return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 2>(P, st, n_cu, lds)
                        : launch_step_sparse_blocked_cfg<MODEL, 8, 8>(P, st, n_cu, lds);
 }
 
-// benchmark-only: rows per wave / groups in flight per row of the sparse step (0 = built-in)
+#ifdef RP_MEASUREMENT
+// measurement build only: rows per wave / groups in flight per row of the sparse step (0 = built-in)
 std::atomic<int> g_sparse_R{0}, g_sparse_U{0};
+#endif
 
 template <int MODEL, int R, int U>
 int launch_step_sparse_cfg(const StepParams& P, hipStream_t st, int n_cu) {
@@ -429,7 +495,8 @@ int launch_step_sparse(const StepParams& P, hipStream_t st) {
                                sizeof(float) * kWindowChunks * 256, st, P);
         return RP_OK;
     }
-    if constexpr (MODEL == RP_MODEL_LI_TANH) {  // benchmark-only sweep (rp_set_sparse_tuning)
+#ifdef RP_MEASUREMENT
+    if constexpr (MODEL == RP_MODEL_LI_TANH) {  // sweep (rp_set_sparse_tuning)
         const int key = g_sparse_R * 10 + g_sparse_U;
         switch (key) {
             case 14: return launch_step_sparse_cfg<MODEL, 1, 4>(P, st, n_cu);
@@ -444,6 +511,7 @@ int launch_step_sparse(const StepParams& P, hipStream_t st) {
             default: break;
         }
     }
+#endif
     // measured (scripts/tune_sparse.py): one row per wave with 4 groups in flight is the fastest or tied at every size
     return launch_step_sparse_cfg<MODEL, 1, 4>(P, st, n_cu);
 }
@@ -589,8 +657,10 @@ void fill_static(StepParams& P, const rp_net* net) {
     P.sp_batches = net->sp_batches;
 }
 
-// Tuning override (rp_set_tuning): 0 = use the built-in choice.
+#ifdef RP_MEASUREMENT
+// measurement build only (rp_set_tuning): 0 = use the built-in choice.
 std::atomic<int> g_tune_R{0}, g_tune_U{0}, g_tune_nt{-1}, g_tune_blocks{0};
+#endif
 
 template <int MODEL, int R, int U, bool VEC4, bool NT>
 void launch_cfg(const StepParams& P, hipStream_t st, int max_blocks) {
@@ -664,8 +734,9 @@ StreamCfg choose_cfg(const rp_net* net) {
 
 template <int MODEL, bool VEC4>
 void launch_step(const StepParams& P, hipStream_t st, const StreamCfg& cfg) {
+#ifdef RP_MEASUREMENT
     if constexpr (VEC4 && MODEL == RP_MODEL_LI_TANH) {
-        if (g_tune_R > 0) {  // benchmark-only sweep of the streaming configuration
+        if (g_tune_R > 0) {  // sweep of the streaming configuration
             const int key = g_tune_R * 100 + g_tune_U * 10 + (g_tune_nt != 0 ? 1 : 0);
             const int mb = g_tune_blocks;
             switch (key) {
@@ -681,6 +752,7 @@ void launch_step(const StepParams& P, hipStream_t st, const StreamCfg& cfg) {
             }
         }
     }
+#endif
     if constexpr (VEC4) {
         switch (cfg.R * 10 + cfg.U) {  // the configurations rp_tune_forward may pick, for every model
             case 14: launch_cfg<MODEL, 1, 4, true, true>(P, st, cfg.blocks); return;
@@ -711,6 +783,51 @@ void launch_step_model(int model, const StepParams& P, hipStream_t st, const Str
         case RP_MODEL_IK: launch_step<RP_MODEL_IK, VEC4>(P, st, cfg); break;
         case RP_MODEL_IKU: launch_step<RP_MODEL_IKU, VEC4>(P, st, cfg); break;
         default: launch_step<RP_MODEL_IK_BIEXP, VEC4>(P, st, cfg); break;
+    }
+}
+
+// ---- populations with dense edges (rp_run.edge_*) ------------------------------------------------------------------
+// The walk follows the static rule for the bytes a row group streams: the columns of W plus those of every edge.
+template <int MODEL, int R, int U, bool VEC4>
+void launch_edges_cfg(const StepParams& P, hipStream_t st, int max_blocks) {
+    int groups = (P.rows + R - 1) / R;
+    int blocks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (max_blocks > 0 && blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL((step_edges_kernel<MODEL, R, U, VEC4>), dim3(blocks), dim3(kThreads), 0, st, P);
+}
+
+template <int MODEL>
+void launch_step_edges(const StepParams& P, hipStream_t st, bool vec4) {
+    int64_t cols = P.n;
+    for (int e = 0; e < P.n_edges; ++e) cols += P.edge[e].n;
+    StreamCfg cfg = static_cfg(P.rows, (int)std::min<int64_t>(cols, 1 << 30));
+#ifdef RP_MEASUREMENT
+    if (g_tune_R > 0) cfg = StreamCfg{g_tune_R, g_tune_U, g_tune_blocks};  // sweep (rp_set_tuning)
+#endif
+    if (!vec4) {  // 4-byte recurrent path (small test networks): one instance
+        launch_edges_cfg<MODEL, 4, 1, false>(P, st, cfg.blocks);
+        return;
+    }
+    switch (cfg.R * 10 + cfg.U) {
+        case 14: launch_edges_cfg<MODEL, 1, 4, true>(P, st, cfg.blocks); return;
+        case 18: launch_edges_cfg<MODEL, 1, 8, true>(P, st, cfg.blocks); return;
+        case 21: launch_edges_cfg<MODEL, 2, 1, true>(P, st, cfg.blocks); return;
+        case 22: launch_edges_cfg<MODEL, 2, 2, true>(P, st, cfg.blocks); return;
+        case 81: launch_edges_cfg<MODEL, 8, 1, true>(P, st, cfg.blocks); return;
+        default: launch_edges_cfg<MODEL, 4, 2, true>(P, st, cfg.blocks); return;
+    }
+}
+
+void launch_step_edges_model(int model, const StepParams& P, hipStream_t st, bool vec4) {
+    switch (model) {
+        case RP_MODEL_LI_TANH: launch_step_edges<RP_MODEL_LI_TANH>(P, st, vec4); break;
+        case RP_MODEL_LI_SIGMOID: launch_step_edges<RP_MODEL_LI_SIGMOID>(P, st, vec4); break;
+        case RP_MODEL_QIF: launch_step_edges<RP_MODEL_QIF>(P, st, vec4); break;
+        case RP_MODEL_QIF_SFA: launch_step_edges<RP_MODEL_QIF_SFA>(P, st, vec4); break;
+        case RP_MODEL_LIF: launch_step_edges<RP_MODEL_LIF>(P, st, vec4); break;
+        case RP_MODEL_IK: launch_step_edges<RP_MODEL_IK>(P, st, vec4); break;
+        case RP_MODEL_IKU: launch_step_edges<RP_MODEL_IKU>(P, st, vec4); break;
+        default: launch_step_edges<RP_MODEL_IK_BIEXP>(P, st, vec4); break;
     }
 }
 
@@ -774,35 +891,11 @@ __global__ __launch_bounds__(256) void push_slice_kernel(const PushParams Q) {
     if (i < Q.quads) reinterpret_cast<rp_f4*>(Q.dst[blockIdx.y])[i] = reinterpret_cast<const rp_f4*>(Q.src)[i];
 }
 
-// rp_forward / rp_forward_sharded: `comm` != nullptr adds the per-step all-gather of the source slices.
-int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
-    int rc = validate_net(net);
-    if (rc != RP_OK) return rc;
+// ---- one window = a host loop over the steps ------------------------------------------------------------------------
+// Argument checks of one (net, run) pair; `coupled`: the pair is a member of rp_forward_coupled (edge sources come from
+// the other members, not from run->edge_src).
+int check_run(const rp_net* net, const rp_run* run, bool coupled) {
     if (!run) RP_FAIL(RP_ERR_ARG, "run is null");
-    const bool direct = comm && comm->mode == RP_COMM_DIRECT;
-    if (comm) {
-        if (comm->mode != RP_COMM_RCCL && comm->mode != RP_COMM_DIRECT) RP_FAIL(RP_ERR_ARG, "bad rp_comm.mode %d", comm->mode);
-        if (!direct && (!comm->comm || !comm->all_gather)) RP_FAIL(RP_ERR_ARG, "rp_comm needs comm and all_gather");
-        if (direct) {
-            if (!comm->peer_src || !comm->peer_flags || !comm->flags) RP_FAIL(RP_ERR_ARG, "RP_COMM_DIRECT needs peer_src, peer_flags and flags");
-            if (comm->world > 64) RP_FAIL(RP_ERR_ARG, "RP_COMM_DIRECT: at most 64 ranks");
-            for (int p = 0; p < comm->world; ++p) {
-                if (!comm->peer_flags[p] || !comm->peer_src[2 * p] || !comm->peer_src[2 * p + 1])
-                    RP_FAIL(RP_ERR_ARG, "RP_COMM_DIRECT: peer %d has a null buffer", p);
-            }
-            if (comm->peer_src[2 * comm->rank] != net->src[0] || comm->peer_src[2 * comm->rank + 1] != net->src[1] ||
-                comm->peer_flags[comm->rank] != comm->flags)
-                RP_FAIL(RP_ERR_ARG, "RP_COMM_DIRECT: this rank's entries of peer_src / peer_flags must be its own buffers");
-            if (net->rows % 4 != 0) RP_FAIL(RP_ERR_SHAPE, "RP_COMM_DIRECT pushes 16-byte pieces: rows %% 4 == 0 required");
-        }
-        if (comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world)
-            RP_FAIL(RP_ERR_ARG, "bad rank %d / world %d", comm->rank, comm->world);
-        if ((int64_t)net->rows * comm->world != net->n || net->row0 != comm->rank * net->rows)
-            RP_FAIL(RP_ERR_SHAPE, "shard rows=%d row0=%d does not match rank %d of %d over n=%d", net->rows, net->row0,
-                    comm->rank, comm->world, net->n);
-        if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP)
-            RP_FAIL(RP_ERR_ARG, "population-mean models cannot be row-sharded");
-    }
     if (run->spike_src && (net->model < RP_MODEL_QIF || net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP))
         RP_FAIL(RP_ERR_ARG, "spike_src is for the spiking models without population means (model %d)", net->model);
     if (run->steps < 0) RP_FAIL(RP_ERR_ARG, "steps < 0");
@@ -839,8 +932,7 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     if (run->save_src_full && run->ldfull < net->n) RP_FAIL(RP_ERR_SHAPE, "ldfull < n");
     if (run->spike_count && (!run->spike_events || run->spike_capacity < 0))
         RP_FAIL(RP_ERR_ARG, "spike_count given without spike_events");
-    const bool vec4 = use_vec4(net);
-    if (vec4 && (!aligned16(net->W) || !aligned16(net->src[0]) || !aligned16(net->src[1])))
+    if (use_vec4(net) && (!aligned16(net->W) || !aligned16(net->src[0]) || !aligned16(net->src[1])))
         RP_FAIL(RP_ERR_ARG, "W and src buffers must be 16-byte aligned when n and ldw are multiples of 4");
     if (net->sp_vals) {
         if (!net->sp_cidx || !net->sp_rowoff) RP_FAIL(RP_ERR_ARG, "sp_vals given without sp_cidx / sp_rowoff");
@@ -854,20 +946,33 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
             (net->sp_block_rows > 0 && (net->sp_row_ids || net->n > kSparseLdsMaxN)))
             RP_FAIL(RP_ERR_ARG, "sp_block_rows must be in [0, 64], without the windowed form and with n <= %d", kSparseLdsMaxN);
     }
+    if (run->n_edges < 0 || run->n_edges > RP_MAX_EDGES) RP_FAIL(RP_ERR_ARG, "n_edges must be in [0, %d]", RP_MAX_EDGES);
+    for (int e = 0; e < run->n_edges; ++e) {
+        if (!run->edge_w[e] || run->edge_n[e] < 1 || run->edge_ld[e] < run->edge_n[e])
+            RP_FAIL(RP_ERR_SHAPE, "edge %d needs edge_w, edge_n >= 1 and edge_ld >= edge_n", e);
+        const bool v4 = run->edge_n[e] % 4 == 0 && run->edge_ld[e] % 4 == 0;
+        if (v4 && !aligned16(run->edge_w[e])) RP_FAIL(RP_ERR_ARG, "edge %d: edge_w must be 16-byte aligned", e);
+        if (!coupled) {
+            if (!run->edge_src[e]) RP_FAIL(RP_ERR_ARG, "edge %d has no source vector", e);
+            if (v4 && (!aligned16(run->edge_src[e]) || run->edge_src_ld[e] % 4 != 0))
+                RP_FAIL(RP_ERR_ARG, "edge %d: edge_src / edge_src_ld must be 16-byte aligned", e);
+        }
+    }
+    if ((run->hist[0] == nullptr) != (run->hist[1] == nullptr)) RP_FAIL(RP_ERR_ARG, "hist: both buffers or neither");
+    if (run->hist[0] && run->hist[0] == run->hist[1]) RP_FAIL(RP_ERR_ARG, "hist[0] and hist[1] must be distinct buffers");
 
     // count the samples this call produces before touching anything
-    {
-        int64_t produced = 0;
-        for (int64_t t = run->step0; t < run->step0 + run->steps; ++t)
-            if (t >= run->cutoff && t % run->sampling_steps == 0) ++produced;
-        if ((run->samples || any_rec) && run->sample_idx + produced > run->max_samples)
-            RP_FAIL(RP_ERR_SHAPE, "sample buffers hold %d rows, call needs %lld", run->max_samples,
-                    (long long)(run->sample_idx + produced));
-    }
+    int64_t produced = 0;
+    for (int64_t t = run->step0; t < run->step0 + run->steps; ++t)
+        if (t >= run->cutoff && t % run->sampling_steps == 0) ++produced;
+    if ((run->samples || any_rec) && run->sample_idx + produced > run->max_samples)
+        RP_FAIL(RP_ERR_SHAPE, "sample buffers hold %d rows, call needs %lld", run->max_samples,
+                (long long)(run->sample_idx + produced));
+    return RP_OK;
+}
 
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const StreamCfg stream_cfg = choose_cfg(net);
-    StepParams P = {};
+// the parts of the kernel arguments that stay the same for the whole call
+void init_params(StepParams& P, const rp_net* net, const rp_run* run) {
     fill_static(P, net);
     P.x_mode = run->x_mode;
     P.m = run->m;
@@ -879,36 +984,108 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     P.spike_events = run->spike_events;
     P.spike_capacity = run->spike_capacity;
     P.spike_count = run->spike_count;
+    P.n_edges = run->n_edges;
+    for (int e = 0; e < run->n_edges; ++e) {
+        P.edge[e].W = run->edge_w[e];
+        P.edge[e].ld = run->edge_ld[e];
+        P.edge[e].n = run->edge_n[e];
+        P.edge[e].vec4 = (run->edge_n[e] % 4 == 0 && run->edge_ld[e] % 4 == 0) ? 1 : 0;
+        P.edge[e].src = nullptr;
+    }
+}
+
+// the arguments of step t of the call (row pointers, sampling flags); advances the run's sampling bookkeeping
+void set_step(StepParams& P, const rp_net* net, rp_run* run, int t) {
+    const int64_t t_abs = run->step0 + t;
+    P.src_cur = net->src[net->cur];
+    P.src_next = net->src[net->cur ^ 1];
+    P.x_t = run->x ? run->x + (int64_t)t * run->ldx : nullptr;
+    P.traj_t = run->traj ? run->traj + (int64_t)t * run->ldtraj : nullptr;
+    P.hist_t = run->hist[0] ? run->hist[t_abs & 1] : nullptr;
+    for (int q = 0; q < RP_MAX_STATE; ++q)
+        P.save_state_t[q] = run->save_state[q] ? run->save_state[q] + (int64_t)t * run->ldsave : nullptr;
+    P.save_src_t = run->save_src ? run->save_src + (int64_t)t * run->ldsave : nullptr;
+    P.save_acc_t = run->save_acc ? run->save_acc + (int64_t)t * run->ldsave : nullptr;
+    P.t_abs = (int)t_abs;
+    P.spike_src = t == 0 ? run->spike_src : nullptr;
+    P.flags = 0;
+    P.sample_row = nullptr;
+    for (int q = 0; q < RP_MAX_STATE; ++q) P.rec_row[q] = nullptr;
+    if (run->acc && t_abs >= run->cutoff) {
+        P.flags |= FLAG_BUFFER;
+        if (run->acc_count == 0) P.flags |= FLAG_FIRST;  // an empty buffer: no reset pass over acc is ever needed
+        run->acc_count += 1;
+        if (t_abs % run->sampling_steps == 0) {
+            P.flags |= FLAG_SAMPLE;
+            P.count = (float)run->acc_count;
+            const int64_t off = (int64_t)run->sample_idx * run->ldsamples;
+            P.sample_row = run->samples ? run->samples + off : nullptr;
+            for (int q = 0; q < RP_MAX_STATE; ++q) P.rec_row[q] = run->rec[q] ? run->rec[q] + off : nullptr;
+            run->sample_idx += 1;
+            run->acc_count = 0;
+        }
+    }
+}
+
+// the launches of one step of one population (P complete)
+int launch_population_step(const rp_net* net, const StepParams& P, hipStream_t st, const StreamCfg& cfg, bool vec4) {
+    if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP)
+        hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, st, P);
+    if (P.n_edges > 0) {
+        launch_step_edges_model(net->model, P, st, vec4);
+    } else if (net->sp_vals) {
+        const int src_rc = launch_step_sparse_model(net->model, P, st);
+        if (src_rc != RP_OK) RP_FAIL(src_rc, "sparse step launch failed (device properties / LDS attribute)");
+    } else if (vec4) {
+        launch_step_model<true>(net->model, P, st, cfg);
+    } else {
+        launch_step_model<false>(net->model, P, st, cfg);
+    }
+    return RP_OK;
+}
+
+// rp_forward / rp_forward_sharded: `comm` != nullptr adds the per-step all-gather of the source slices.
+int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
+    int rc = validate_net(net);
+    if (rc != RP_OK) return rc;
+    if (!run) RP_FAIL(RP_ERR_ARG, "run is null");
+    const bool direct = comm && comm->mode == RP_COMM_DIRECT;
+    if (comm) {
+        if (comm->mode != RP_COMM_RCCL && comm->mode != RP_COMM_DIRECT) RP_FAIL(RP_ERR_ARG, "bad rp_comm.mode %d", comm->mode);
+        if (!direct && (!comm->comm || !comm->all_gather)) RP_FAIL(RP_ERR_ARG, "rp_comm needs comm and all_gather");
+        if (direct) {
+            if (!comm->peer_src || !comm->peer_flags || !comm->flags) RP_FAIL(RP_ERR_ARG, "RP_COMM_DIRECT needs peer_src, peer_flags and flags");
+            if (comm->world > 64) RP_FAIL(RP_ERR_ARG, "RP_COMM_DIRECT: at most 64 ranks");
+            for (int p = 0; p < comm->world; ++p) {
+                if (!comm->peer_flags[p] || !comm->peer_src[2 * p] || !comm->peer_src[2 * p + 1])
+                    RP_FAIL(RP_ERR_ARG, "RP_COMM_DIRECT: peer %d has a null buffer", p);
+            }
+            if (comm->peer_src[2 * comm->rank] != net->src[0] || comm->peer_src[2 * comm->rank + 1] != net->src[1] ||
+                comm->peer_flags[comm->rank] != comm->flags)
+                RP_FAIL(RP_ERR_ARG, "RP_COMM_DIRECT: this rank's entries of peer_src / peer_flags must be its own buffers");
+            if (net->rows % 4 != 0) RP_FAIL(RP_ERR_SHAPE, "RP_COMM_DIRECT pushes 16-byte pieces: rows %% 4 == 0 required");
+        }
+        if (comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world)
+            RP_FAIL(RP_ERR_ARG, "bad rank %d / world %d", comm->rank, comm->world);
+        if ((int64_t)net->rows * comm->world != net->n || net->row0 != comm->rank * net->rows)
+            RP_FAIL(RP_ERR_SHAPE, "shard rows=%d row0=%d does not match rank %d of %d over n=%d", net->rows, net->row0,
+                    comm->rank, comm->world, net->n);
+        if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP)
+            RP_FAIL(RP_ERR_ARG, "population-mean models cannot be row-sharded");
+    }
+    rc = check_run(net, run, false);
+    if (rc != RP_OK) return rc;
+
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec4 = use_vec4(net);
+    const StreamCfg stream_cfg = choose_cfg(net);
+    StepParams P = {};
+    init_params(P, net, run);
 
     for (int t = 0; t < run->steps; ++t) {
         const int64_t t_abs = run->step0 + t;
-        P.src_cur = net->src[net->cur];
-        P.src_next = net->src[net->cur ^ 1];
-        P.x_t = run->x ? run->x + (int64_t)t * run->ldx : nullptr;
-        P.traj_t = run->traj ? run->traj + (int64_t)t * run->ldtraj : nullptr;
-        for (int q = 0; q < RP_MAX_STATE; ++q)
-            P.save_state_t[q] = run->save_state[q] ? run->save_state[q] + (int64_t)t * run->ldsave : nullptr;
-        P.save_src_t = run->save_src ? run->save_src + (int64_t)t * run->ldsave : nullptr;
-        P.save_acc_t = run->save_acc ? run->save_acc + (int64_t)t * run->ldsave : nullptr;
-        P.t_abs = (int)t_abs;
-        P.spike_src = t == 0 ? run->spike_src : nullptr;
-        P.flags = 0;
-        P.sample_row = nullptr;
-        for (int q = 0; q < RP_MAX_STATE; ++q) P.rec_row[q] = nullptr;
-        if (run->acc && t_abs >= run->cutoff) {
-            P.flags |= FLAG_BUFFER;
-            if (run->acc_count == 0) P.flags |= FLAG_FIRST;  // an empty buffer: no reset pass over acc is ever needed
-            run->acc_count += 1;
-            if (t_abs % run->sampling_steps == 0) {
-                P.flags |= FLAG_SAMPLE;
-                P.count = (float)run->acc_count;
-                const int64_t off = (int64_t)run->sample_idx * run->ldsamples;
-                P.sample_row = run->samples ? run->samples + off : nullptr;
-                for (int q = 0; q < RP_MAX_STATE; ++q) P.rec_row[q] = run->rec[q] ? run->rec[q] + off : nullptr;
-                run->sample_idx += 1;
-                run->acc_count = 0;
-            }
-        }
+        set_step(P, net, run, t);
+        for (int e = 0; e < run->n_edges; ++e) P.edge[e].src = run->edge_src[e] + (int64_t)t * run->edge_src_ld[e];
         if (direct)  // every peer has pushed step seq (and is done with the buffer this step pushes into)
             for (int p = 0; p < comm->world; ++p)
                 if (p != comm->rank)
@@ -916,16 +1093,8 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
         if (run->save_src_full)
             RP_HIP_CHECK(hipMemcpyAsync(run->save_src_full + (int64_t)t * run->ldfull, P.src_cur,
                                         sizeof(float) * (size_t)net->n, hipMemcpyDeviceToDevice, st));
-        if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP)
-            hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, st, P);
-        if (net->sp_vals) {
-            const int src_rc = launch_step_sparse_model(net->model, P, st);
-            if (src_rc != RP_OK) RP_FAIL(src_rc, "sparse step launch failed (device properties / LDS attribute)");
-        } else if (vec4) {
-            launch_step_model<true>(net->model, P, st, stream_cfg);
-        } else {
-            launch_step_model<false>(net->model, P, st, stream_cfg);
-        }
+        rc = launch_population_step(net, P, st, stream_cfg, vec4);
+        if (rc != RP_OK) return rc;
         if (t == 0) RP_HIP_CHECK(hipGetLastError());  // a rejected launch configuration shows on the first step
         if (direct) {
             // push this rank's slice into every peer's next buffer, then tell them from the stream; the wait for the
@@ -952,6 +1121,107 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
         }
         net->cur ^= 1;
     }
+    if (direct && run->steps > 0)
+        // Later work on this stream (a copy or clone of the source buffers, a restore into them, the host's read after a
+        // synchronize) must come after the peers' LAST pushes into this rank's buffers: wait for their final sequence number.
+        for (int p = 0; p < comm->world; ++p)
+            if (p != comm->rank)
+                RP_HIP_CHECK(hipStreamWaitValue32(st, comm->flags + p, comm->seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
+// rp_forward_coupled: the members' steps interleaved, one launch per member and Euler step
+int coupled_impl(rp_member* mem, int32_t count, void* stream) {
+    constexpr int kMaxMembers = 16;
+    if (!mem || count < 1 || count > kMaxMembers) RP_FAIL(RP_ERR_ARG, "rp_forward_coupled: 1..%d members", kMaxMembers);
+    for (int m = 0; m < count; ++m) {
+        if (!mem[m].net || !mem[m].run) RP_FAIL(RP_ERR_ARG, "member %d: net / run is null", m);
+        int rc = validate_net(mem[m].net);
+        if (rc != RP_OK) return rc;
+        rc = check_run(mem[m].net, mem[m].run, true);
+        if (rc != RP_OK) return rc;
+        const rp_net* net = mem[m].net;
+        const rp_run* run = mem[m].run;
+        if (net->rows != net->n || net->row0 != 0) RP_FAIL(RP_ERR_ARG, "member %d: row shards cannot be coupled", m);
+        if (run->spike_src || run->save_src_full) RP_FAIL(RP_ERR_ARG, "member %d: spike_src / save_src_full are not available here", m);
+        if (run->steps != mem[0].run->steps || run->step0 != mem[0].run->step0)
+            RP_FAIL(RP_ERR_ARG, "member %d: steps / step0 differ from member 0", m);
+        for (int q = 0; q < m; ++q)
+            if (mem[q].net == net || mem[q].run == run) RP_FAIL(RP_ERR_ARG, "members %d and %d share a net / run", q, m);
+    }
+    for (int m = 0; m < count; ++m) {
+        const rp_run* run = mem[m].run;
+        for (int e = 0; e < run->n_edges; ++e) {
+            const int q = mem[m].edge_source[e], mode = mem[m].edge_mode[e];
+            if (q < 0 || q >= count) RP_FAIL(RP_ERR_ARG, "member %d edge %d: source %d out of range", m, e, q);
+            if (mode != RP_EDGE_LIVE && mode != RP_EDGE_OUT && mode != RP_EDGE_LAG)
+                RP_FAIL(RP_ERR_ARG, "member %d edge %d: bad mode %d", m, e, mode);
+            const rp_run* qrun = mem[q].run;
+            if (run->edge_n[e] != mem[q].net->n)
+                RP_FAIL(RP_ERR_SHAPE, "member %d edge %d has %d columns, its source holds %d neurons", m, e, run->edge_n[e], mem[q].net->n);
+            if (mode == RP_EDGE_OUT && q >= m)
+                RP_FAIL(RP_ERR_ARG, "member %d edge %d: RP_EDGE_OUT needs a source stepped earlier (source %d)", m, e, q);
+            if (mode == RP_EDGE_LIVE && q == m && qrun->out_var == RP_OUT_STATE0)
+                RP_FAIL(RP_ERR_ARG, "member %d edge %d: a population cannot read its own state while it is stepped", m, e);
+            if ((mode == RP_EDGE_LAG || (mode == RP_EDGE_OUT && qrun->out_var == RP_OUT_STATE0)) && !qrun->hist[0])
+                RP_FAIL(RP_ERR_ARG, "member %d edge %d: source %d needs rp_run.hist", m, e, q);
+            // every vector this edge can be pointed at
+            const bool state_out = qrun->out_var == RP_OUT_STATE0;
+            const float* cand[2];
+            if (mode == RP_EDGE_LAG || (mode == RP_EDGE_OUT && state_out)) {
+                cand[0] = qrun->hist[0];
+                cand[1] = qrun->hist[1];
+            } else if (state_out) {
+                cand[0] = cand[1] = mem[q].net->y[RP_Y_V];
+            } else {
+                cand[0] = mem[q].net->src[0];
+                cand[1] = mem[q].net->src[1];
+            }
+            if (run->edge_n[e] % 4 == 0 && run->edge_ld[e] % 4 == 0 && (!aligned16(cand[0]) || !aligned16(cand[1])))
+                RP_FAIL(RP_ERR_ARG, "member %d edge %d: the source vectors must be 16-byte aligned", m, e);
+        }
+    }
+
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    StepParams P[kMaxMembers];
+    StreamCfg cfg[kMaxMembers];
+    bool vec4[kMaxMembers];
+    for (int m = 0; m < count; ++m) {
+        P[m] = StepParams{};
+        init_params(P[m], mem[m].net, mem[m].run);
+        cfg[m] = choose_cfg(mem[m].net);
+        vec4[m] = use_vec4(mem[m].net);
+    }
+    const int steps = mem[0].run->steps;
+    for (int t = 0; t < steps; ++t) {
+        const int64_t t_abs = mem[0].run->step0 + t;
+        for (int m = 0; m < count; ++m) {
+            rp_net* net = mem[m].net;
+            rp_run* run = mem[m].run;
+            set_step(P[m], net, run, t);
+            for (int e = 0; e < run->n_edges; ++e) {
+                const int q = mem[m].edge_source[e];
+                const rp_net* qn = mem[q].net;
+                const rp_run* qr = mem[q].run;
+                switch (mem[m].edge_mode[e]) {
+                    case RP_EDGE_LIVE:  // qn->cur names q's CURRENT source buffer: flipped already if q < m
+                        P[m].edge[e].src = qr->out_var == RP_OUT_STATE0 ? qn->y[RP_Y_V] : qn->src[qn->cur];
+                        break;
+                    case RP_EDGE_OUT:   // q < m: its buffer of this step is the one it flipped away from
+                        P[m].edge[e].src = qr->out_var == RP_OUT_STATE0 ? qr->hist[t_abs & 1] : qn->src[qn->cur ^ 1];
+                        break;
+                    default:            // RP_EDGE_LAG
+                        P[m].edge[e].src = qr->hist[(t_abs + 1) & 1];
+                        break;
+                }
+            }
+            const int rc = launch_population_step(net, P[m], st, cfg[m], vec4[m]);
+            if (rc != RP_OK) return rc;
+            if (t == 0) RP_HIP_CHECK(hipGetLastError());
+            net->cur ^= 1;
+        }
+    }
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;
 }
@@ -966,6 +1236,10 @@ int rp_forward_sharded(rp_net* net, rp_run* run, const rp_comm* comm, void* stre
     if (!comm) RP_FAIL(RP_ERR_ARG, "comm is null");
     return forward_impl(net, run, comm, stream);
 }
+
+int rp_forward_coupled(rp_member* members, int32_t count, void* stream) { return coupled_impl(members, count, stream); }
+
+int rp_sizeof_member(void) { return (int)sizeof(rp_member); }
 
 int rp_sizeof_comm(void) { return (int)sizeof(rp_comm); }
 
@@ -1004,6 +1278,7 @@ int rp_ipc_free(void* ptr) {
     return RP_OK;
 }
 
+#ifdef RP_MEASUREMENT
 int rp_set_blocked_tuning(int waves, int groups_in_flight) {
     g_blocked_waves = waves;
     g_blocked_U = groups_in_flight;
@@ -1015,6 +1290,7 @@ int rp_set_sparse_tuning(int rows_per_wave, int groups_in_flight) {
     g_sparse_U = groups_in_flight;
     return RP_OK;
 }
+#endif
 
 int rp_tune_forward(const rp_net* net, void* stream) {
     if (!net || !net->W) RP_FAIL(RP_ERR_ARG, "rp_tune_forward: net and net->W must be non-null");
@@ -1195,6 +1471,7 @@ int rp_clear_forward_tuning(void) {
     return RP_OK;
 }
 
+#ifdef RP_MEASUREMENT
 int rp_set_tuning(int rows_per_wave, int unroll, int nontemporal, int max_blocks) {
     g_tune_R = rows_per_wave;
     g_tune_U = unroll;
@@ -1202,6 +1479,7 @@ int rp_set_tuning(int rows_per_wave, int unroll, int nontemporal, int max_blocks
     g_tune_blocks = max_blocks;
     return RP_OK;
 }
+#endif
 
 int rp_stream_probe(const float* buf, int64_t n_floats, float* out, void* stream) {
     if (!buf || !out || n_floats < 4 || !aligned16(buf)) RP_FAIL(RP_ERR_ARG, "bad probe arguments");

@@ -58,17 +58,21 @@ class HipBackend:
     """Calls into librectipy_hip.so on the current HIP stream of the tensors' device."""
     name = "hip"
 
-    def __init__(self):
+    def __init__(self, measurement: Optional[bool] = None):
+        """``measurement=True``: bound to the measurement build of the library (its own handle and knobs; tests, scripts)."""
         from . import _lib
         self._lib_mod = _lib
-        self.lib = _lib.load()
+        self.lib = _lib.load(measurement)
+
+    def _check(self, rc):
+        self._lib_mod.check(rc, self.lib)
 
     def check_device(self, device: torch.device):
         if device.type != "cuda":
             raise self._lib_mod.HipLibraryError(
                 f"rectipy_amd integrates on MI355X only; got device '{device}'. There is no CPU fallback.")
         idx = device.index if device.index is not None else torch.cuda.current_device()
-        self._lib_mod.check(self.lib.rp_device_check(idx))
+        self._check(self.lib.rp_device_check(idx))
 
     @staticmethod
     def _stream(device):
@@ -84,23 +88,27 @@ class HipBackend:
 
     def refresh_source(self, net: RpNet, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_refresh_source(C.byref(net), self._stream(device)))
+            self._check(self.lib.rp_refresh_source(C.byref(net), self._stream(device)))
 
     def forward(self, net: RpNet, run: RpRun, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_forward(C.byref(net), C.byref(run), self._stream(device)))
+            self._check(self.lib.rp_forward(C.byref(net), C.byref(run), self._stream(device)))
+
+    def forward_coupled(self, members, count: int, device):
+        with self._on(device):
+            self._check(self.lib.rp_forward_coupled(members, count, self._stream(device)))
 
     def tune_forward(self, net: RpNet, device):
         """Measure the streaming configuration of the dense step kernel for this shape (a no-op for shapes that do not
         stream from HBM, and for a shape already measured or installed in this process).  WHEN this is called is the
         policy of :mod:`rectipy_amd.tuning` (on request, or for runs long enough to repay it -- not by default)."""
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_tune_forward(C.byref(net), self._stream(device)))
+            self._check(self.lib.rp_tune_forward(C.byref(net), self._stream(device)))
 
     def install_forward_tuning(self, net: RpNet, R: int, U: int, workgroups: int, us: float, device):
         """Install a configuration measured by an earlier process for this shape (tuning.py keeps them on disk)."""
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_install_forward_tuning(C.byref(net), R, U, workgroups, us))
+            self._check(self.lib.rp_install_forward_tuning(C.byref(net), R, U, workgroups, us))
 
     def abi_version(self) -> int:
         return int(self.lib.rp_abi_version())
@@ -111,62 +119,62 @@ class HipBackend:
 
     def forward_tuning(self, net: RpNet) -> dict:
         R, U, G, m, us = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_float()
-        self._lib_mod.check(self.lib.rp_forward_tuning(C.byref(net), C.byref(R), C.byref(U), C.byref(G), C.byref(us), C.byref(m)))
+        self._check(self.lib.rp_forward_tuning(C.byref(net), C.byref(R), C.byref(U), C.byref(G), C.byref(us), C.byref(m)))
         return dict(rows_per_wave=R.value, chunks_in_flight=U.value, workgroups=G.value, measured=bool(m.value),
                     us_per_step=us.value)
 
     def rate_backward(self, net: RpNet, bwd: RpBwd, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_rate_backward(C.byref(net), C.byref(bwd), self._stream(device)))
+            self._check(self.lib.rp_rate_backward(C.byref(net), C.byref(bwd), self._stream(device)))
 
     def qif_backward(self, net: RpNet, bwd: RpBwd, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_qif_backward(C.byref(net), C.byref(bwd), self._stream(device)))
+            self._check(self.lib.rp_qif_backward(C.byref(net), C.byref(bwd), self._stream(device)))
 
     def outer_accum(self, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_outer_accum(n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
+            self._check(self.lib.rp_outer_accum(n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
 
     def outer_accum_rect(self, m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_outer_accum_rect(m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
+            self._check(self.lib.rp_outer_accum_rect(m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
 
     def outer_store_rect(self, m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_outer_store_rect(m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
+            self._check(self.lib.rp_outer_store_rect(m, n, T, alpha, A, lda, B, ldb, Cmat, ldc, self._stream(device)))
 
     def bwd_prepare(self, net, bwd, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_bwd_prepare(C.byref(net), C.byref(bwd), self._stream(device)))
+            self._check(self.lib.rp_bwd_prepare(C.byref(net), C.byref(bwd), self._stream(device)))
 
     def bwd_partial(self, net, bwd, t, z_full, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_bwd_partial(C.byref(net), C.byref(bwd), t, z_full, self._stream(device)))
+            self._check(self.lib.rp_bwd_partial(C.byref(net), C.byref(bwd), t, z_full, self._stream(device)))
 
     def bwd_apply(self, net, bwd, t, z_local, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_bwd_apply(C.byref(net), C.byref(bwd), t, z_local, self._stream(device)))
+            self._check(self.lib.rp_bwd_apply(C.byref(net), C.byref(bwd), t, z_local, self._stream(device)))
 
     def shard_partial_rows(self, n, rows):
         return int(self.lib.rp_bwd_shard_partial_rows(n, rows))
 
     def forward_sharded(self, net, run, comm, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_forward_sharded(C.byref(net), C.byref(run), C.byref(comm),
+            self._check(self.lib.rp_forward_sharded(C.byref(net), C.byref(run), C.byref(comm),
                                                             self._stream(device)))
 
     def backward_sharded(self, net, bwd, comm, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_backward_sharded(C.byref(net), C.byref(bwd), C.byref(comm),
+            self._check(self.lib.rp_backward_sharded(C.byref(net), C.byref(bwd), C.byref(comm),
                                                                   self._stream(device)))
 
     def forward_batched(self, net, batch, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_forward_batched(C.byref(net), C.byref(batch), self._stream(device)))
+            self._check(self.lib.rp_forward_batched(C.byref(net), C.byref(batch), self._stream(device)))
 
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
         with self._on(device):
-            self._lib_mod.check(self.lib.rp_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss,
+            self._check(self.lib.rp_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss,
                                                       self._stream(device)))
 
     def partial_rows(self, n):
@@ -396,13 +404,41 @@ class Population:
                 spike_events: Optional[torch.Tensor] = None, spike_count: Optional[torch.Tensor] = None,
                 x_target: int = _abi.RP_XT_MEMBRANE, save_aux: Optional[torch.Tensor] = None,
                 save_aux2: Optional[torch.Tensor] = None, comm=None,
-                save_src_full: Optional[torch.Tensor] = None, spike_src: Optional[torch.Tensor] = None) -> int:
+                save_src_full: Optional[torch.Tensor] = None, spike_src: Optional[torch.Tensor] = None,
+                edges: Optional[list] = None, hist: Optional[list] = None) -> int:
         """Integrate ``steps`` Euler steps in one library call.  Returns the next sample index.
         ``comm`` (an ``RpComm``): this population is a row shard and every step ends with the in-library RCCL
         all-gather of the source vector (rp_forward_sharded).
 
         x: None | [steps, rows] | [steps, 1] | [steps, m] together with ``w_in`` [rows, m].
+        edges: dense edges into the population evaluated inside its step kernel, ``[(W_e [rows, n_e], s_e)]`` with
+        ``s_e`` the edge's source vector -- ``[n_e]`` (the same vector every step) or ``[steps, n_e]``.
         """
+        run, keep, sampling = self._make_run(steps, x, w_in, out_var, step0, cutoff, sampling_steps, samples, sample_idx,
+                                             rec, traj, save_v, save_src, save_acc, spike_events, spike_count, x_target,
+                                             save_aux, save_aux2, save_src_full, spike_src, edges, hist)
+        net = self._net()
+        if not self._tuned:  # static rule unless a measurement was asked for or this call is long enough to repay one
+            tuning.prepare(self, net, steps)
+        if comm is None:
+            self.backend.forward(net, run, self.device)
+        else:
+            self.backend.forward_sharded(net, run, comm, self.device)
+        return self._finish_run(net, run, sampling, keep)
+
+    def _finish_run(self, net: RpNet, run: RpRun, sampling: bool, keep) -> int:
+        self.cur = net.cur
+        if sampling:
+            self.acc_count = run.acc_count
+        del keep
+        return int(run.sample_idx)
+
+    def _make_run(self, steps, x=None, w_in=None, out_var=_abi.RP_OUT_STATE0, step0=0, cutoff=0, sampling_steps=1,
+                  samples=None, sample_idx=0, rec=None, traj=None, save_v=None, save_src=None, save_acc=None,
+                  spike_events=None, spike_count=None, x_target=_abi.RP_XT_MEMBRANE, save_aux=None, save_aux2=None,
+                  save_src_full=None, spike_src=None, edges=None, hist=None):
+        """The rp_run of one call (see :meth:`forward`): (run, tensors to keep alive until the call returned, sampling?).
+        Edge sources given as ``None`` are left for rp_forward_coupled to fill in."""
         run = RpRun()
         run.steps = int(steps)
         run.step0 = int(step0)
@@ -495,18 +531,33 @@ class Population:
             run.spike_capacity = spike_events.shape[0]
             run.spike_count = spike_count.data_ptr()
 
-        net = self._net()
-        if not self._tuned:  # static rule unless a measurement was asked for or this call is long enough to repay one
-            tuning.prepare(self, net, steps)
-        if comm is None:
-            self.backend.forward(net, run, self.device)
-        else:
-            self.backend.forward_sharded(net, run, comm, self.device)
-        self.cur = net.cur
-        if sampling:
-            self.acc_count = run.acc_count
-        del keep
-        return int(run.sample_idx)
+        if edges:
+            if len(edges) > _abi.RP_MAX_EDGES:
+                raise RuntimeError(f"at most {_abi.RP_MAX_EDGES} dense edges per population, got {len(edges)}")
+            run.n_edges = len(edges)
+            for e, (We, se) in enumerate(edges):
+                if We.dtype != torch.float32 or We.device != self.device or We.dim() != 2 or We.shape[0] != self.rows \
+                        or We.stride(1) != 1:
+                    raise RuntimeError(f"edge {e}: weights must be a float32 [{self.rows}, n_e] row-major tensor on {self.device}")
+                keep.append(We)
+                run.edge_w[e], run.edge_ld[e], run.edge_n[e] = We.data_ptr(), We.stride(0), We.shape[1]
+                if se is None:
+                    continue
+                se = se.detach()
+                if se.dtype != torch.float32 or se.device != self.device or se.shape[-1] != We.shape[1] or se.stride(-1) != 1 \
+                        or se.dim() not in (1, 2) or (se.dim() == 2 and se.shape[0] < steps):
+                    raise RuntimeError(f"edge {e}: the source must be a float32 [{We.shape[1]}] or [steps, {We.shape[1]}] tensor")
+                keep.append(se)
+                run.edge_src[e] = se.data_ptr()
+                run.edge_src_ld[e] = 0 if se.dim() == 1 else (se.stride(0) if se.shape[0] > 1 else se.shape[1])
+        if hist is not None:
+            for q in (0, 1):
+                h = hist[q]
+                if h.dtype != torch.float32 or h.device != self.device or h.numel() != self.rows or not h.is_contiguous():
+                    raise RuntimeError(f"hist[{q}] must be a contiguous float32 [{self.rows}] tensor on {self.device}")
+                run.hist[q] = h.data_ptr()
+            keep.extend(hist)
+        return run, keep, sampling
 
     # -- adjoint -------------------------------------------------------------------------
     def backward(self, traj_v, traj_r, grad_out, grad_var, lam, u_traj, traj_acc=None,
@@ -621,6 +672,30 @@ class Population:
         return out
 
 
+def forward_coupled(members: list) -> list:
+    """One library call for a whole window of SEVERAL populations joined by dense edges (rp_forward_coupled): every
+    Euler step steps the populations in list order, one launch each, the edge products inside the step kernels.
+
+    ``members``: dicts with ``pop`` (:class:`Population`), ``run`` (keyword arguments of :meth:`Population.forward`
+    without ``edges`` / ``comm``) and ``edges``: ``[(W_e [rows, n_source], source member index, RP_EDGE_* mode)]``.
+    Returns the next sample index of every member."""
+    count = len(members)
+    arr = (_abi.RpMember * count)()
+    built = []
+    for m, spec in enumerate(members):
+        pop: Population = spec["pop"]
+        edges = spec.get("edges") or []
+        run, keep, sampling = pop._make_run(edges=[(We, None) for We, _, _ in edges], **spec["run"])
+        net = pop._net()
+        for e, (_, source, mode) in enumerate(edges):
+            arr[m].edge_source[e], arr[m].edge_mode[e] = int(source), int(mode)
+        arr[m].net, arr[m].run = C.pointer(net), C.pointer(run)
+        built.append((pop, net, run, sampling, keep))
+    first = members[0]["pop"]
+    first.backend.forward_coupled(arr, count, first.device)
+    return [pop._finish_run(net, run, sampling, keep) for pop, net, run, sampling, keep in built]
+
+
 class BatchedPopulation:
     """B independent trajectories of ONE rate population (same W, same per-neuron parameters; different states and
     inputs) advanced together: every Euler step streams W once for all of them (``rp_forward_batched``).  The reference
@@ -654,6 +729,9 @@ class BatchedPopulation:
             # 64-row workgroups of "mfma16" cannot (scripts/sweep_mfma16.py: N = 8192, B = 32: 0.075 vs 0.096 ms per step;
             # N = 16384: 0.227 vs 0.206)
             if use_mfma and batch > 16 and pop.rows < 12288 and pop.row0 % 32 == 0:
+                form = "mfma32"
+            # a shard offset that is a multiple of 32 but not of 128: only the r02 form can take it
+            if use_mfma and form == "mfma16" and pop.row0 % 128 and pop.row0 % 32 == 0:
                 form = "mfma32"
         if form not in self.FORMS:
             raise ValueError(f"form must be one of {sorted(self.FORMS)}, got {form!r}")
@@ -707,10 +785,18 @@ class BatchedPopulation:
             pop.v, pop.src, pop.cur = keep_v, keep_src, keep_cur
             pop._net_cache = None
 
+    def reset_sampling(self):
+        self.acc_count = 0  # an empty buffer: the library overwrites `acc` with the first buffered output
+
     def forward(self, steps: int, x: Optional[torch.Tensor] = None, traj: Optional[torch.Tensor] = None,
-                out_var: int = _abi.RP_OUT_STATE0):
-        """`steps` Euler steps of all trajectories.  x: None | [steps, B, rows] | [steps, B, 1];
-        traj: optional [steps, B, rows] receiving the pre-update outputs."""
+                out_var: int = _abi.RP_OUT_STATE0, w_in: Optional[torch.Tensor] = None, step0: int = 0, cutoff: int = 0,
+                sampling_steps: int = 1, samples: Optional[torch.Tensor] = None, rec: Optional[dict] = None,
+                sample_idx: int = 0) -> int:
+        """`steps` Euler steps of all trajectories; returns the next sample index.
+        x: None | [steps, B, rows] | [steps, B, 1] | [steps, B, m] together with ``w_in`` [rows, m] (the input edge inside
+        the step); traj: optional [steps, B, rows] receiving the pre-update outputs; samples / rec[0 | 1]: optional
+        [B, S, rows] buffers receiving, per trajectory, what :meth:`Population.forward` samples for one (buffer means of the
+        output, post-update v / r at the sample steps; ``step0`` / ``cutoff`` / ``sampling_steps`` / ``sample_idx`` as there)."""
         pop, B = self.pop, self.batch
         bt = _abi.RpBatch()
         bt.batch, bt.steps = B, int(steps)
@@ -722,18 +808,52 @@ class BatchedPopulation:
         if x is None:
             bt.x_mode = _abi.RP_X_NONE
         else:
-            if x.dim() != 3 or x.shape[0] < steps or x.shape[1] != B or x.shape[2] not in (1, pop.rows):
-                raise RuntimeError(f"inputs must be [>= {steps}, {B}, {pop.rows} or 1], got {tuple(x.shape)}")
+            if x.dim() != 3 or x.shape[0] < steps or x.shape[1] != B:
+                raise RuntimeError(f"inputs must be [>= {steps}, {B}, width], got {tuple(x.shape)}")
             x = x.detach().to(dtype=torch.float32, device=pop.device).contiguous()
             keep.append(x)
             bt.x, bt.ldx = x.data_ptr(), x.shape[2]
-            bt.x_mode = _abi.RP_X_FULL if x.shape[2] == pop.rows and pop.rows != 1 else _abi.RP_X_BCAST
+            if w_in is not None:
+                w_in = w_in.detach().to(dtype=torch.float32, device=pop.device).contiguous()
+                if tuple(w_in.shape) != (pop.rows, x.shape[2]):
+                    raise RuntimeError(f"input weights {tuple(w_in.shape)} do not map {x.shape[2]} inputs to {pop.rows} neurons")
+                keep.append(w_in)
+                bt.x_mode, bt.m, bt.w_in, bt.ldwin = _abi.RP_X_PROJ, x.shape[2], w_in.data_ptr(), w_in.stride(0)
+            elif x.shape[2] == pop.rows and pop.rows != 1:
+                bt.x_mode = _abi.RP_X_FULL
+            elif x.shape[2] == 1:
+                bt.x_mode = _abi.RP_X_BCAST
+            else:
+                raise RuntimeError(f"inputs must be [>= {steps}, {B}, {pop.rows} or 1], got {tuple(x.shape)}")
         bt.out_var = int(out_var)
         if traj is not None:
             if traj.dtype != torch.float32 or traj.device != pop.device or traj.dim() != 3 or not traj.is_contiguous() \
                     or traj.shape[0] < steps or traj.shape[1] != B or traj.shape[2] < pop.rows:
                 raise RuntimeError(f"traj must be a contiguous float32 [>= {steps}, {B}, >= {pop.rows}] tensor on {pop.device}")
             bt.traj, bt.ldtraj = traj.data_ptr(), traj.shape[2]
+        bufs = [("samples", samples)] + [(f"rec[{k}]", v) for k, v in (rec or {}).items()]
+        bufs = [(name, t) for name, t in bufs if t is not None]
+        if bufs:
+            shape = None
+            for name, t in bufs:
+                if t.dtype != torch.float32 or t.device != pop.device or t.dim() != 3 or not t.is_contiguous() \
+                        or t.shape[0] != B or t.shape[2] < pop.rows or (shape is not None and tuple(t.shape) != shape):
+                    raise RuntimeError(f"{name} must be a contiguous float32 [{B}, S, >= {pop.rows}] tensor on {pop.device} "
+                                       "(all sample / record buffers of one shape)")
+                shape = tuple(t.shape)
+            if getattr(self, "_acc", None) is None:
+                self._acc = torch.empty(B, pop.rows, dtype=torch.float32, device=pop.device)
+                self.acc_count = 0
+            bt.step0, bt.cutoff, bt.sampling_steps, bt.max_samples = int(step0), int(cutoff), int(sampling_steps), shape[1]
+            bt.acc, bt.ldacc, bt.acc_count, bt.sample_idx = self._acc.data_ptr(), self._acc.stride(0), self.acc_count, int(sample_idx)
+            bt.samples, bt.ldsamples = _ptr(samples), shape[2]
+            for k, t in (rec or {}).items():
+                if int(k) not in (0, 1):
+                    raise RuntimeError("the batched step records v (0) and r (1)")
+                bt.rec[int(k)] = _ptr(t)
         pop.backend.forward_batched(pop._net(), bt, pop.device)
         self.cur = bt.cur
+        if bufs:
+            self.acc_count = bt.acc_count
         del keep
+        return int(bt.sample_idx)

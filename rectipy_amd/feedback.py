@@ -10,14 +10,25 @@ spiking population `y` lags one step (nodes.py:387-392), so it is the previous s
 stepped in this step delivers its post-update state.  Pinned by fixture G28 (tests/golden/make_golden_topologies.py).
 The reference cannot feed back from an activation node (``InstantNode["out"]`` is None -> TypeError); here such an edge
 delivers the node's output of the previous step (zero before the first step) -- an extension.
-Such networks are evaluated step by step; every diff-eq node still advances through the HIP step kernel."""
-from typing import Optional
+
+How such a network is evaluated (r04): populations joined DIRECTLY by plain dense edges -- feed-forward or feedback, cycles
+included -- are integrated as ONE library call per window (``rp_forward_coupled``, include/rectipy_hip.h): every Euler step
+steps the populations in evaluation order, one launch each, and every edge matrix is streamed by the target's step kernel
+next to its recurrent matrix (`_coupled_plan` / `_run_coupled`).  Activation nodes upstream of every population (input
+layers) are evaluated for the whole window in advance, those downstream of every population (read-outs) afterwards.
+Everything else -- an activation node BETWEEN populations, edges with memory inside the cycle, gradient-tracking runs --
+is walked step by step (`forward`), where a plain dense edge into a population is still evaluated inside that
+population's step kernel whenever no gradient has to pass through it."""
+from typing import List, Optional
 
 import torch
-from networkx import DiGraph, topological_sort
+from networkx import DiGraph, ancestors, descendants, topological_sort
 
+from . import _abi
 from .edges import Linear
-from .network import Network
+from .network import _WINDOW_BYTES, Network
+from .nodes import InstantNode, RateNet, SpikeResetNet
+from .observer import Observer
 
 
 class FeedbackNetwork(Network):
@@ -67,10 +78,13 @@ class FeedbackNetwork(Network):
     def forward(self, x) -> torch.Tensor:
         if not self._order:
             self.compile()
+        if isinstance(x, torch.Tensor) and x.dtype != self.dtype:
+            x = x.to(self.dtype)
         new_out = {}
         for n in self._order:
-            inp = None
+            node = self.get_node(n)
             has_ffwd = False
+            feeds = []  # (edge, what it reads) in predecessor order
             for p in self.graph.predecessors(n):
                 fb = self.graph[p][n].get("feedback")
                 if fb:
@@ -84,14 +98,275 @@ class FeedbackNetwork(Network):
                 else:
                     has_ffwd = True
                     src = new_out[p]
-                contrib = self.get_edge(p, n).forward(src)
+                feeds.append((self.get_edge(p, n), src))
+            # plain dense edges into a population are evaluated by its step kernel -- unless a gradient has to pass
+            # through the node's input (then every product is a torch op, as before)
+            tracked = torch.is_grad_enabled() and (
+                (not has_ffwd and isinstance(x, torch.Tensor) and x.requires_grad) or
+                any(src.requires_grad or any(q.requires_grad for q in edge.parameters()) for edge, src in feeds) or
+                (isinstance(node, RateNet) and node._wants_grad(None)))
+            inp, in_kernel = None, []
+            for edge, src in feeds:
+                if not tracked and len(in_kernel) < _abi.RP_MAX_EDGES and self._edge_in_kernel(edge, node, src):
+                    in_kernel.append((edge.weights, src.detach()))
+                    continue
+                contrib = edge.forward(src)
                 inp = contrib if inp is None else inp + contrib
             if not has_ffwd:
                 inp = x if inp is None else x + inp
-            new_out[n] = self.get_node(n).forward(inp)
+            new_out[n] = node.forward(inp, edges=in_kernel) if in_kernel else node.forward(inp)
             self[n]["out"] = new_out[n]
         self._prev_out = {k: v.detach() for k, v in new_out.items()}
         return new_out[self._out_node]
+
+    @staticmethod
+    def _edge_in_kernel(edge, node, src) -> bool:
+        """A plain dense edge into a compiled population is evaluated by the population's step kernel (rp_run.edge_*)
+        whenever no gradient has to pass through it: no product launch, no [n] temporary, W_e streamed next to W."""
+        if type(edge) is not Linear or not isinstance(node, RateNet) or not getattr(node, "_fusable", True):
+            return False
+        W = edge.weights
+        pop = node._pop
+        return (W.dtype == torch.float32 and W.device == pop.device and W.stride(1) == 1 and W.shape[0] == pop.rows
+                and src.dtype == torch.float32 and src.device == pop.device and src.dim() == 1 and src.is_contiguous()
+                and src.shape[0] == W.shape[1] and (W.shape[1] % 4 or W.stride(0) % 4 or src.data_ptr() % 16 == 0))
+
+    # ---- populations joined by dense edges: one library call per window ----------------------------------------------
+    def _coupled_plan(self, rec_vars) -> Optional[dict]:
+        """How to evaluate the graph with rp_forward_coupled, or None.  Populations (compiled, fusable) may be joined by
+        plain dense edges in any pattern, feedback edges included; activation nodes must sit entirely upstream of the
+        populations ("pre": evaluated for the whole window in advance) or entirely downstream ("post": afterwards)."""
+        if getattr(self, "_force_stepwise", False) or not self._order:
+            return None
+        g = self.graph
+        pops = [n for n in self._order if isinstance(self.get_node(n), RateNet)]
+        if not pops or len(pops) > 16:
+            return None
+        for n in self._order:
+            node = self.get_node(n)
+            if isinstance(node, RateNet):
+                if not getattr(node, "_fusable", True) or node._pop.rows != node._pop.n:
+                    return None
+            elif not (isinstance(node, InstantNode) and node.name in InstantNode.batched):
+                return None
+        below = set(pops).union(*(descendants(g, p) for p in pops))   # a population or downstream of one
+        above = set(pops).union(*(ancestors(g, p) for p in pops))     # a population or upstream of one
+        pre = [n for n in self._order if n not in below]
+        post = [n for n in self._order if n in below and n not in above]
+        if len(pre) + len(post) + len(pops) != len(self._order):
+            return None  # an activation node between populations
+        edges = {p: [] for p in pops}
+        for s_, t_, d in g.edges(data=True):
+            edge, fb = self.get_edge(s_, t_), bool(d.get("feedback"))
+            if s_ in edges and t_ in edges:
+                if type(edge) is not Linear or edge.weights.stride(1) != 1 or edge.weights.dtype != torch.float32:
+                    return None
+                src_node = self.get_node(s_)
+                if s_ == t_ and not isinstance(src_node, SpikeResetNet) and src_node._out_code == _abi.RP_OUT_STATE0:
+                    return None  # a population cannot read its own state while it is stepped
+                earlier = self._order.index(s_) < self._order.index(t_)
+                if not fb:
+                    mode = _abi.RP_EDGE_OUT            # what the source's step of this Euler step returned
+                elif isinstance(src_node, SpikeResetNet):
+                    mode = _abi.RP_EDGE_OUT if earlier else _abi.RP_EDGE_LAG  # its exposed state lags (nodes.py:387-392)
+                else:
+                    mode = _abi.RP_EDGE_LIVE           # `source["out"]` as it stands (network.py:1354-1357)
+                edges[t_].append((s_, mode))
+            elif fb or not self._windowable(edge):
+                return None  # feedback from / into an activation node; foreign edge classes
+        if any(len(v) > _abi.RP_MAX_EDGES for v in edges.values()):
+            return None
+        slots = []
+        for label, var in rec_vars:
+            node = self.get_node(label)
+            one = self._record_slots(node, [(label, var)]) if isinstance(node, RateNet) else None
+            if one is None:
+                return None
+            slots.append(one[0])
+        return dict(pre=pre, pops=pops, post=post, edges=edges, slots=slots)
+
+    def _coupled_wants_grad(self, inputs) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        return bool(inputs.requires_grad or any(p.requires_grad for p in self.parameters()) or
+                    any(self.get_node(n)._wants_grad(None) for n in self._order if isinstance(self.get_node(n), RateNet)))
+
+    def _coupled_window(self, plan: dict, inputs_ab: torch.Tensor, a: int, want_traj: set, rec: dict, sampler: Optional[dict],
+                        cutoff: int, sampling_steps: int) -> dict:
+        """Steps [a, a + len) of every population in one (spiking members: two) library calls.  `want_traj`: populations
+        whose per-step output is needed afterwards; `rec`: label -> {slot: buffer, "idx": next row}; `sampler`: the
+        population whose output is sampled in-kernel ({"label", "samples", "idx"}).  Returns label -> [steps, N] trajectory."""
+        from .engine import forward_coupled
+        steps = inputs_ab.shape[0]
+        pops: List[str] = plan["pops"]
+        index = {p: i for i, p in enumerate(pops)}
+        # activation nodes upstream of the populations: the whole window at once
+        outs = {}
+        for n in plan["pre"]:
+            preds = list(self.graph.predecessors(n))
+            X = inputs_ab if not preds else None
+            for p_ in preds:
+                contrib = self._edge_window(self.get_edge(p_, n), outs[p_])
+                X = contrib if X is None else X + contrib
+            outs[n] = self.get_node(n).forward(X)
+        spiking = any(isinstance(self.get_node(p), SpikeResetNet) for p in pops)
+        lag_read = {s_ for p in pops for s_, mode in plan["edges"][p] if mode == _abi.RP_EDGE_LAG}
+        hist_read = lag_read | {s_ for p in pops for s_, mode in plan["edges"][p]
+                                if mode == _abi.RP_EDGE_OUT and self.get_node(s_)._out_code == _abi.RP_OUT_STATE0}
+        trajs, xin = {}, {}
+        for p in pops:
+            node: RateNet = self.get_node(p)
+            pop = node._pop
+            node._coupled_begin()
+            X = inputs_ab if p == self._in_node else None
+            for p_ in self.graph.predecessors(p):
+                if p_ in outs and not self.graph[p_][p].get("feedback"):
+                    contrib = self._edge_window(self.get_edge(p_, p), outs[p_])
+                    X = contrib if X is None else X + contrib
+            xin[p] = None if X is None else self._fit_width(X.detach(), pop.rows)
+            if p in want_traj:
+                trajs[p] = torch.empty(steps, pop.rows, dtype=torch.float32, device=pop.device)
+            if p in hist_read:
+                if getattr(node, "_hist", None) is None:
+                    node._hist = [torch.zeros(pop.rows, dtype=torch.float32, device=pop.device) for _ in (0, 1)]
+                if p in lag_read:  # what a feedback edge reads at the window's first step: the node's exposed output
+                    node._hist[(a + 1) & 1].copy_(node["out"].detach())
+
+        def call(t0: int, t1: int, last: bool):
+            members, saves = [], {}
+            for p in pops:
+                node = self.get_node(p)
+                pop = node._pop
+                kw = node._coupled_kwargs()
+                kw.update(steps=t1 - t0, step0=a + t0, x=None if xin[p] is None else xin[p][t0:t1])
+                if p in trajs:
+                    kw["traj"] = trajs[p][t0:t1]
+                r = rec.get(p)
+                if r or (sampler and sampler["label"] == p):
+                    kw.update(cutoff=cutoff, sampling_steps=sampling_steps)
+                    if r:
+                        kw.update(rec={k_: v_ for k_, v_ in r.items() if k_ != "idx"}, sample_idx=r["idx"])
+                    if sampler and sampler["label"] == p:
+                        kw.update(samples=sampler["samples"], sample_idx=sampler["idx"])
+                if p in hist_read:
+                    kw["hist"] = node._hist
+                if last and isinstance(node, SpikeResetNet):
+                    saves[p] = node._state_bufs()
+                    kw.update(save_v=saves[p][0], save_src=saves[p][1], save_aux=saves[p][2], save_aux2=saves[p][3])
+                members.append(dict(pop=pop, run=kw, edges=[(self.get_edge(s_, p).weights, index[s_], mode)
+                                                            for s_, mode in plan["edges"][p]]))
+            idx = forward_coupled(members)
+            for p, i in zip(pops, idx):
+                if p in rec:
+                    rec[p]["idx"] = i
+                if sampler and sampler["label"] == p:
+                    sampler["idx"] = i
+            for p, bufs in saves.items():
+                self.get_node(p)._coupled_end(bufs)
+
+        if spiking and steps > 1:  # the last step on its own: it leaves the pre-update state a spiking node exposes as `y`
+            call(0, steps - 1, False)
+            call(steps - 1, steps, True)
+        else:
+            call(0, steps, spiking)
+        return trajs
+
+    ARENA_MIN_BYTES = 256 << 20
+
+    def _consolidate(self, plan: dict):
+        """Move the matrices a coupled step streams -- every population's W and every edge matrix between populations --
+        into ONE device allocation (the tensors the nodes / edges hold become views of it; same values, still live).
+        Measured on MI355X (scripts/probes/coupled_alloc2.py; two populations of 16384 neurons, four 1 GiB matrices): out
+        of one allocation the step takes 603-619 us on every box and trial -- the single-population kernel's time for the
+        same bytes -- while four separate 1 GiB allocations give 611-619 us or 653-667 us depending on where the driver
+        happened to place them (same kernel, same data; which matrices share a launch does not matter).  Trained matrices
+        stay where they are (an optimiser holds on to its parameter tensors)."""
+        mats = []
+        for p in plan["pops"]:
+            pop = self.get_node(p)._pop
+            mats.append((pop, "W"))
+            for s_, _ in plan["edges"][p]:
+                mats.append((self.get_edge(s_, p), "weights"))
+        tensors = [getattr(o, a) for o, a in mats]
+        if not tensors or tensors[0].device.type != "cuda" or any(t.requires_grad or not t.is_contiguous() for t in tensors):
+            return
+        total = sum(t.numel() for t in tensors)
+        if 4 * total < self.ARENA_MIN_BYTES:
+            return
+        arena = getattr(self, "_arena", None)
+        if arena is not None and all(t.untyped_storage().data_ptr() == arena.untyped_storage().data_ptr() for t in tensors):
+            return
+        pad = 64  # floats: every matrix starts on a 256-byte boundary
+        offs, off = [], 0
+        for t in tensors:
+            offs.append(off)
+            off += (t.numel() + pad - 1) // pad * pad
+        arena = torch.empty(off, dtype=torch.float32, device=tensors[0].device)
+        for (obj, attr), t, o in zip(mats, tensors, offs):
+            view = arena[o:o + t.numel()].view(t.shape)
+            view.copy_(t)
+            setattr(obj, attr, view)
+            if attr == "W":
+                obj._net_cache = None
+                if obj.packed is not None:
+                    obj._packed_version = view._version  # same values: the packed form stays valid
+        self._arena = arena
+
+    def _run_coupled(self, plan: dict, inputs, sampling_steps, cutoff, obs: Observer, rec_vars, verbose):
+        self._consolidate(plan)
+        T = inputs.shape[0]
+        sample_at = self._sample_steps(T, cutoff, sampling_steps)
+        S = len(sample_at)
+        pops, post = plan["pops"], plan["post"]
+        out_node = self._out_node
+        rec = {}
+        for (label, _), slot in zip(rec_vars, plan["slots"]):
+            pop = self.get_node(label)._pop
+            entry = rec.setdefault(label, {"idx": 0})
+            if slot not in entry:
+                entry[slot] = torch.empty(S, pop.rows, dtype=torch.float32, device=pop.device)
+        for p in pops:
+            self.get_node(p)._pop.reset_sampling()
+        # the output: sampled in-kernel when the output node is a population, or a linear memory-less read-out of ONE
+        # population (it commutes with the buffer mean); otherwise per-step trajectories -> read-out -> buffer means
+        feeders = [p for p in pops if any(t_ in post for t_ in self.graph.successors(p))]
+        sampler = None
+        if out_node in pops:
+            src_pop, chain = out_node, []
+        elif len(feeders) == 1 and all(self.graph.in_degree(n) == 1 for n in post) and \
+                self._memoryless_linear(post, feeders[0]) and list(topological_sort(self.graph.subgraph(post))) == post:
+            src_pop, chain = feeders[0], post
+        else:
+            src_pop, chain = None, None
+        if src_pop is not None:
+            pop = self.get_node(src_pop)._pop
+            sampler = dict(label=src_pop, samples=torch.empty(S, pop.rows, dtype=torch.float32, device=pop.device), idx=0)
+        want_traj = set() if sampler else set(feeders)
+        widest = max(self.get_node(p)._pop.rows for p in pops)
+        chunk = max(1, min(T, _WINDOW_BYTES // (4 * widest * max(1, len(want_traj) + len(plan["pre"]) + 1))))
+        pending = []
+        for a in range(0, T, chunk):
+            b = min(a + chunk, T)
+            trajs = self._coupled_window(plan, inputs[a:b], a, want_traj, rec, sampler, cutoff, sampling_steps)
+            if sampler is None:
+                outs = dict(trajs)
+                for n in post:
+                    X = None
+                    for p_ in self.graph.predecessors(n):
+                        contrib = self._edge_window(self.get_edge(p_, n), outs[p_])
+                        X = contrib if X is None else X + contrib
+                    outs[n] = self.get_node(n).forward(X)
+                pending.append(outs[out_node])
+            if verbose:
+                print(f"Progress: {b}/{T} integration steps finished.")
+        if sampler is not None:
+            outputs = self._apply_chain(chain, sampler["samples"], src_pop, None) if chain else sampler["samples"]
+        else:
+            outputs = self._buffer_means(torch.cat(pending), sample_at, cutoff)
+        obs.record_block(sample_at, outputs, 0.0, [rec[label][slot] for (label, _), slot in zip(rec_vars, plan["slots"])])
+        for n in self._order:  # what the per-step walk leaves in `net[n]["out"]`: not kept for windows
+            self[n]["out"] = None
+        self._prev_out = {}
 
     def reset(self, state: dict = None):
         super().reset(state)

@@ -417,26 +417,39 @@ class Network:
             with (torch.enable_grad() if enable_grad else torch.no_grad()):
                 self._run_windows(inputs, sampling_steps, cutoff, truncate_steps, obs, rec_vars, rec_slots, verbose)
             return obs
+        coupled = self._coupled_plan(rec_vars) if plan is None else None
+        if coupled is not None:
+            with (torch.enable_grad() if enable_grad else torch.no_grad()):
+                if not self._coupled_wants_grad(inputs):  # populations joined by dense edges: one library call per window
+                    with torch.no_grad():
+                        self._run_coupled(coupled, inputs, sampling_steps, cutoff, obs, rec_vars, verbose)
+                    return obs
         self._run_stepwise(inputs, sampling_steps, cutoff, truncate_steps, obs, rec_vars, enable_grad, verbose)
         return obs
 
+    def _coupled_plan(self, rec_vars):
+        """Graphs with cycles (feedback edges) exist in :class:`rectipy_amd.feedback.FeedbackNetwork` only."""
+        return None
+
     # ---- B trajectories through one pass over W -------------------------------------------------------
     def run_batch(self, inputs, sampling_steps: int = 1, cutoff: int = 0, y0=None, verbose: bool = False,
-                  mfma: Optional[bool] = None) -> List[Observer]:
+                  mfma: Optional[bool] = None, exact: bool = False) -> List[Observer]:
         """Integrate B independent trajectories of the SAME network -- ``inputs``: [B, T, m] -- and return one
         :class:`Observer` per trajectory, each as :meth:`run` would have produced it for ``inputs[b]`` from the same
         initial state (``y0``: [B, N] initial states of the population; default: its current state for every b).
 
-        The observers' samples are computed the way `run` computes them (running fp32 sum in step order / count behind
-        identity read-out nodes; per-step read-out + torch mean behind a non-linear one), so for B <= 8 they equal `run`'s
-        bit for bit for every ``sampling_steps`` / ``cutoff`` (tests/test_batched.py).
-
         Not part of the reference's API (it has no batch axis: B trials are B passes of its time loop, each streaming W
-        again).  Here every Euler step streams W ONCE for all B trajectories (``rp_forward_batched``): up to 8 trajectories
-        on the vector ALUs, each bit-identical to an unbatched run; 9..32 per pass on the matrix cores (equal to unbatched
-        runs up to fp32 rounding); more in groups of 32.  ``mfma=True`` puts groups of up to 8 on the matrix cores too
-        (N = 32768, 8 trajectories: 0.63 instead of 0.86 ms per step, at the price of the bit-identity with `run`).  Chain topologies around one RATE population; the network's own state is
-        left untouched."""
+        again).  Here every Euler step streams W ONCE for all B trajectories (``rp_forward_batched``), in groups of at most
+        32: up to 4 trajectories on the vector ALUs (each BIT-IDENTICAL to an unbatched `run`), 5..32 on the matrix cores
+        (equal to unbatched runs up to fp32 rounding: their own summation order).  ``exact=True`` keeps
+        groups of up to 8 on the vector ALUs, i.e. bit-identical to `run`, at 0.86 instead of 0.63 ms per step for 8
+        trajectories at N = 32768; ``mfma=True`` puts smaller groups on the matrix cores as well.
+
+        Sampling happens inside the step kernels exactly as in `run` (running fp32 sum of the buffered outputs in step
+        order / count, per trajectory): memory is O(B x samples x N), never O(B x T x N).  Only behind a read-out that does
+        not commute with the buffer mean (a non-linear activation, an edge with memory) are the per-step outputs staged,
+        one window of steps at a time.  Chain topologies around one RATE population; the network's own state is left
+        untouched."""
         from .engine import BatchedPopulation
         self.compile()
         plan = self._chain_plan()
@@ -457,61 +470,63 @@ class Network:
             raise RuntimeError(f"inputs must be [B, T, m], got {tuple(X.shape)}")
         B, T = int(X.shape[0]), int(X.shape[1])
         sample_at = self._sample_steps(T, cutoff, sampling_steps)
+        S = len(sample_at)
         N = pop.rows
+        f32 = dict(dtype=torch.float32, device=pop.device)
         start = pop.v.detach().clone().expand(B, N) if y0 is None else \
             torch.as_tensor(y0).to(device=dev, dtype=torch.float32).reshape(B, N)
+        w_in = None
         if pre:  # input nodes / edges act on every (b, t) row alike
-            X = self._apply_chain(pre, X.reshape(B * T, -1), None, label).reshape(B, T, -1)
-        self._fit_width(X.reshape(B * T, -1), N)
-        per_step = torch.empty(B, T, N, dtype=torch.float32, device=pop.device)
-        finals = torch.empty(B, N, dtype=torch.float32, device=pop.device)
-        chunk = max(1, min(T, _WINDOW_BYTES // (4 * N * 32)))
+            if len(pre) == 1 and self.get_node(pre[0]).name == "identity" and X.shape[2] <= 64 \
+                    and type(self.get_edge(pre[0], label)) is Linear:
+                w_in = self.get_edge(pre[0], label).weights  # the projection is folded into the step kernel (RP_X_PROJ)
+            else:
+                X = self._apply_chain(pre, X.reshape(B * T, -1), None, label).reshape(B, T, -1)
+        if w_in is None:
+            self._fit_width(X.reshape(B * T, -1), N)
+        # sampling as `run` does it for this topology (_run_fused): behind identity read-out nodes the buffer mean is the
+        # step kernel's, taken on the population's output and read out afterwards; a non-linear read-out is applied to
+        # every step and averaged afterwards
+        linear_post = self._memoryless_linear(post, label)
+        width = X.shape[2]
+        outputs, finals = [None] * B, torch.empty(B, N, **f32)
         for b0 in range(0, B, BatchedPopulation.SLOTS):  # groups of at most 32 trajectories
             nb = min(BatchedPopulation.SLOTS, B - b0)
-            # up to 8: vector-ALU form (padded to 2 / 4 / 8; bit-identical to unbatched runs); more: matrix-core form
-            size = nb if (nb > 8 or mfma) else next(q for q in (2, 4, 8) if q >= nb)
-            bp = BatchedPopulation(pop, size, mfma=True if (mfma and nb <= 8) else None)
+            on_valu = nb <= (8 if exact else 4) and not mfma
+            size = next(q for q in (2, 4, 8) if q >= nb) if on_valu else nb
+            bp = BatchedPopulation(pop, size, mfma=None if on_valu else True)
             bp.v.zero_()
             bp.v[:nb] = start[b0:b0 + nb]
             bp.refresh()
-            xb = torch.zeros(T, size, X.shape[2], dtype=torch.float32, device=pop.device)
-            xb[:, :nb] = X[b0:b0 + nb].transpose(0, 1)
+            bp.reset_sampling()
+            chunk = max(1, min(T, _WINDOW_BYTES // (4 * size * max(width, N if not linear_post else 1))))
+            samples = torch.empty(size, S, N, **f32) if linear_post else None
+            per_step = None if linear_post else [[] for _ in range(nb)]
+            idx = 0
             for a in range(0, T, chunk):
                 e = min(a + chunk, T)
-                traj = torch.empty(e - a, size, N, dtype=torch.float32, device=pop.device)
-                bp.forward(e - a, x=xb[a:e], traj=traj, out_var=rnn._out_code)
-                per_step[b0:b0 + nb, a:e] = traj[:, :nb].transpose(0, 1)
+                xb = torch.zeros(e - a, size, width, **f32)
+                xb[:, :nb] = X[b0:b0 + nb, a:e].transpose(0, 1)
+                if linear_post:
+                    idx = bp.forward(e - a, x=xb, w_in=w_in, out_var=rnn._out_code, step0=a, cutoff=cutoff,
+                                     sampling_steps=sampling_steps, samples=samples, sample_idx=idx)
+                else:
+                    traj = torch.empty(e - a, size, N, **f32)
+                    bp.forward(e - a, x=xb, w_in=w_in, traj=traj, out_var=rnn._out_code)
+                    for b in range(nb):
+                        per_step[b].append(self._apply_chain(post, traj[:, b], label, None))
                 if verbose:
                     print(f"Progress: trajectories {b0}..{b0 + nb - 1}, {e}/{T} integration steps finished.")
             finals[b0:b0 + nb] = bp.v[:nb]
-        # sampling as `run` does it for this topology (_run_fused): behind identity read-out nodes the buffer mean is the
-        # step kernel's -- a running fp32 sum in step order divided by the count -- taken on the
-        # population's output and read out afterwards; a non-linear read-out is applied per step and averaged by torch
-        linear_post = self._memoryless_linear(post, label)
-        S = len(sample_at)
-        if linear_post:
-            sampled = torch.empty(B, S, N, dtype=torch.float32, device=pop.device)
-            begin = cutoff
-            for j, t in enumerate(sample_at):
-                acc = per_step[:, begin].clone()
-                for u in range(begin + 1, t + 1):
-                    acc += per_step[:, u]
-                # true division as in the kernel (`acc / count`): a python-scalar divisor would become a multiplication by
-                # the rounded reciprocal on the GPU, which differs in the last bit for counts like 3
-                sampled[:, j] = torch.div(acc, torch.full((), float(t + 1 - begin), dtype=torch.float32, device=acc.device))
-                begin = t + 1
-            # read out per trajectory: the same [S, N] product `run` computes (a [B*S, N] product may round differently)
-            out = sampled if not post else torch.stack([self._apply_chain(post, sampled[b], label, None) for b in range(B)])
-        else:
-            full = torch.stack([self._apply_chain(post, per_step[b], label, None) for b in range(B)])
-            out = torch.empty(B, S, full.shape[2], dtype=torch.float32, device=pop.device)
-            begin = cutoff
-            for b in range(B):
-                out[b] = self._buffer_means(full[b], sample_at, cutoff)
+            for b in range(nb):
+                if linear_post:  # read out per trajectory: the same [S, N] product `run` computes
+                    outputs[b0 + b] = self._apply_chain(post, samples[b], label, None) if post else samples[b]
+                else:
+                    outputs[b0 + b] = self._buffer_means(torch.cat(per_step[b]), sample_at, cutoff)
         observers = []
         for b in range(B):
             obs = Observer(dt=self.dt, record_loss=False)
-            obs.record_block(sample_at, out[b], 0.0, [])
+            obs.record_block(sample_at, outputs[b], 0.0, [])
             obs.save("state", finals[b].clone())
             observers.append(obs)
         return observers

@@ -556,18 +556,33 @@ class RateNet:
         self._y_grad = v_end
         return traj
 
-    def forward(self, x) -> torch.Tensor:
-        """One Euler step; returns the PRE-update output slice (reference nodes.py:166-170)."""
+    def forward(self, x, edges: Optional[list] = None) -> torch.Tensor:
+        """One Euler step; returns the PRE-update output slice (reference nodes.py:166-170).  ``edges``: dense edges
+        ``[(W_e [N, n_e], source vector [n_e])]`` whose products join the input inside the step kernel (no gradient
+        passes through them; Population.forward)."""
         x2 = self._as_input(x)
         if self._wants_grad(x2):
+            if edges:
+                raise RuntimeError("in-kernel edges carry no gradient; add their products to the input instead")
             out = self._grad_window(1, x2)[0]
         else:
             self._before_step()
             out = torch.empty(1, self._pop.rows, dtype=torch.float32, device=self._pop.device)
-            self._pop.forward(1, x=x2, traj=out, out_var=self._out_code)
+            self._pop.forward(1, x=x2, traj=out, out_var=self._out_code, edges=edges)
             self._ungraphed_step()
             out = out[0]
         return out if self._out_slice is None else out[self._out_slice[0]:self._out_slice[1]]
+
+    # ---- member of a coupled window (FeedbackNetwork._coupled_window, rp_forward_coupled) -------------------------------
+    def _coupled_begin(self):
+        self._before_step()
+        self._ungraphed_step()
+
+    def _coupled_kwargs(self) -> dict:
+        return dict(out_var=self._out_code)
+
+    def _coupled_end(self, bufs):
+        pass
 
     def run_window(self, steps: int, x: Optional[torch.Tensor] = None, w_in: Optional[torch.Tensor] = None,
                    **kw):
@@ -778,9 +793,11 @@ class SpikeResetNet(RateNet):
         self._y_prev = self._pack(tv[-1], ts[-1], None if ta is None else ta[-1], None if tb is None else tb[-1])
         return traj
 
-    def forward(self, x) -> torch.Tensor:
+    def forward(self, x, edges: Optional[list] = None) -> torch.Tensor:
         x2 = self._as_input(x)
         if self._wants_grad(x2):
+            if edges:
+                raise RuntimeError("in-kernel edges carry no gradient; add their products to the input instead")
             return self._grad_window(1, x2)[0]
         self._y_grad = None
         pop = self._pop
@@ -788,9 +805,21 @@ class SpikeResetNet(RateNet):
         out = torch.empty(1, N, dtype=torch.float32, device=pop.device)
         sv, ss, sa, sb = self._state_bufs()
         pop.forward(1, x=x2, traj=out, save_v=sv, save_src=ss, save_aux=sa, save_aux2=sb, out_var=self._out_code,
-                    x_target=self._x_target, spike_events=self.spike_events, spike_count=self._spike_count)
+                    x_target=self._x_target, spike_events=self.spike_events, spike_count=self._spike_count, edges=edges)
         self._y_prev = self._pack(sv[0], ss[0], None if sa is None else sa[0], None if sb is None else sb[0])
         return out[0]
+
+    def _coupled_begin(self):
+        self._y_grad = None
+
+    def _coupled_kwargs(self) -> dict:
+        return dict(out_var=self._out_code, x_target=self._x_target, spike_events=self.spike_events,
+                    spike_count=self._spike_count)
+
+    def _coupled_end(self, bufs):
+        """`bufs`: the pre-update (v, s, aux, aux2) rows of the window's last step -- what `y` exposes from now on."""
+        sv, ss, sa, sb = bufs
+        self._y_prev = self._pack(sv[0], ss[0], None if sa is None else sa[0], None if sb is None else sb[0])
 
     def run_window(self, steps: int, x=None, w_in=None, **kw):
         """Fused window; the last step is issued separately so that ``y`` can expose its pre-update state."""

@@ -25,3 +25,14 @@ def hip_device():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no HIP device is visible")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session")
+def measure_backend(hip_device):
+    """HIP backend bound to the MEASUREMENT build of the library (-DRP_MEASUREMENT: the rp_set_* knobs and the kernel
+    instances they select; its own handle next to the product library).  Tests use it to show that a knob changes how a
+    kernel walks its operands, never the bits."""
+    from rectipy_amd import build
+    from rectipy_amd.engine import HipBackend
+    build.build(measurement=True)
+    return HipBackend(measurement=True)

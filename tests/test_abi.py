@@ -18,17 +18,43 @@ def lib():
 
 
 def declared_symbols():
+    """(product, measurement-only) entry points of include/rectipy_hip.h: the latter sit in its RP_MEASUREMENT section."""
     text = open(os.path.join(ROOT, "include", "rectipy_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rp_[a-z0-9_]+)\s*\(", text)))
+    head, rest = text.split("#ifdef RP_MEASUREMENT", 1)
+    measure, tail = rest.split("#endif", 1)
+    names = lambda t: sorted(set(re.findall(r"\b(rp_[a-z0-9_]+)\s*\(", t)))
+    return names(head + tail), names(measure)
+
+
+def exported(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+    # (functions only: the thread-local error text rp_err_buf is a data symbol shared by the library's translation units)
+    return sorted(line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("rp_") and line.split()[-2] == "T")
 
 
 def test_every_declared_symbol_is_exported(lib):
-    syms = declared_symbols()
-    assert len(syms) >= 12
+    syms, measure = declared_symbols()
+    assert len(syms) >= 30 and len(measure) >= 10
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/rectipy_hip.h but not exported"
     assert sorted(_abi.EXPORTS) == syms, "python EXPORTS list is out of sync with the header"
+    assert sorted(_abi.MEASUREMENT_EXPORTS) == measure, "python MEASUREMENT_EXPORTS list is out of sync with the header"
+    # the product library exports exactly the product entry points: no knob, no sweep hook
+    assert exported(_lib.lib_path(False)) == syms
+
+
+def test_measurement_build_adds_the_knobs_and_nothing_to_the_product():
+    """-DRP_MEASUREMENT: the product entry points plus the rp_set_* knobs; a second handle next to the product library."""
+    syms, measure = declared_symbols()
+    path = build.build(measurement=True)
+    assert exported(path) == sorted(syms + measure)
+    m = _lib.load(True)
+    assert m is not _lib.load(False) and m.rp_abi_version() == _abi.RP_ABI_VERSION
+    assert m.rp_set_tuning(2, 1, 1, 0) == _abi.RP_OK and m.rp_set_tuning(0, 0, 1, 0) == _abi.RP_OK
+    assert not hasattr(_lib.load(False), "rp_set_tuning")
+    assert os.path.getsize(path) > os.path.getsize(_lib.lib_path(False))  # (the sweep-only kernel instances)
 
 
 def test_struct_layouts_and_version(lib):
@@ -36,6 +62,7 @@ def test_struct_layouts_and_version(lib):
     assert lib.rp_sizeof_net() == C.sizeof(_abi.RpNet)
     assert lib.rp_sizeof_run() == C.sizeof(_abi.RpRun)
     assert lib.rp_sizeof_bwd() == C.sizeof(_abi.RpBwd)
+    assert lib.rp_sizeof_member() == C.sizeof(_abi.RpMember)
 
 
 def test_argument_validation_without_gpu(lib):

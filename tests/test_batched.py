@@ -138,6 +138,118 @@ def test_network_run_batch_equals_separate_runs(target):
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("with_edge", [True, False])
+def test_run_batch_samples_in_kernel(target, with_edge, monkeypatch):
+    """`run_batch` never stages [B, T, N]: the buffer means are formed inside the batched step kernels (all three forms)
+    and the largest buffer it allocates is O(B x samples x N).  sampling_steps 1 / 3 / 100, cutoff > 0, with an input edge
+    (folded into the kernel, RP_X_PROJ) and without; 7 trajectories: `exact=True` (vector ALUs, padded to 8) equals `run`
+    bit for bit, the default (matrix cores) to fp32 rounding; 35 trajectories: two groups (32 + 3)."""
+    from rectipy_amd import Network
+    n, m, k, T = 64, 3, 2, 230
+    rng = np.random.default_rng(5)
+    W, W_in, W_out = rng.standard_normal((n, n)) / n ** 0.5, rng.standard_normal((n, m)), rng.standard_normal((k, n))
+    y0 = rng.standard_normal(n).astype(np.float32)
+
+    def build():
+        net = Network(1e-2, **target)
+        if with_edge:
+            net.add_func_node("inp", m, "identity")
+        net.add_diffeq_node("rnn", "neuron_model_templates.rate_neurons.leaky_integrator.tanh", weights=W,
+                            source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                            output_var="li_op/v", node_vars={"all/li_op/v": y0}, dtype=torch.float32)
+        net.add_func_node("out", k, "identity")
+        if with_edge:
+            net.add_edge("inp", "rnn", weights=W_in)
+        net.add_edge("rnn", "out", weights=W_out)
+        return net
+
+    biggest = [0]
+    real_empty = torch.empty
+
+    def counting_empty(*a, **kw):
+        t = real_empty(*a, **kw)
+        biggest[0] = max(biggest[0], t.numel())
+        return t
+
+    for B in (7, 35):
+        x = rng.standard_normal((B, T, m if with_edge else 1)).astype(np.float32)
+        for s, cutoff in ((1, 0), (3, 4), (100, 30)):
+            S = len([t for t in range(T) if t >= cutoff and t % s == 0])
+            singles = [build().run(x[b], sampling_steps=s, cutoff=cutoff, verbose=False, enable_grad=False) for b in range(B)]
+            for exact in (True, False):
+                biggest[0] = 0
+                monkeypatch.setattr(torch, "empty", counting_empty)
+                batch = build().run_batch(x, sampling_steps=s, cutoff=cutoff, exact=exact)
+                monkeypatch.setattr(torch, "empty", real_empty)
+                assert biggest[0] <= max(32 * max(S, 1) * n, T * 32 * max(m, 1)), (B, s, exact, biggest[0])
+                for b in range(B):
+                    assert list(singles[b]["steps"]) == list(batch[b]["steps"])
+                    a, c = singles[b].to_numpy("out"), batch[b].to_numpy("out")
+                    if exact and B <= 8:
+                        assert np.array_equal(a, c), (B, s, cutoff, b)
+                    else:
+                        assert a.shape == c.shape and np.abs(a - c).max() < 5e-5, (B, s, cutoff, b, np.abs(a - c).max())
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("form,B", [("valu", 4), ("mfma16", 11), ("mfma16", 27), ("mfma32", 20)])
+def test_batched_sampling_matches_unbatched_sampling(target, form, B):
+    """BatchedPopulation.forward with in-kernel sampling (buffer means, post-update recordings, cutoff, two calls, the input
+    edge as RP_X_PROJ): per trajectory what Population.forward samples for one -- bit for bit on the vector ALUs, to fp32
+    rounding on the matrix cores."""
+    dev, backend = target["device"], target["backend"]
+    n, m, T, s, cutoff = 260, 5, 47, 4, 6
+    W, params = network(n, "li_tanh", seed=B)
+    g = torch.Generator().manual_seed(3)
+    v0 = torch.randn(B, n, generator=g)
+    x = torch.randn(T, B, m, generator=g)
+    w_in = torch.randn(n, m, generator=g).to(dev)
+    S = len([t for t in range(T) if t >= cutoff and t % s == 0])
+    bp = BatchedPopulation(Population("li_tanh", W, params, 1e-2, dev, backend=backend), B, form=form)
+    bp.v.copy_(v0.to(dev))
+    bp.refresh()
+    samples, rv, rr = (torch.zeros(B, S, n, device=dev) for _ in range(3))
+    idx = bp.forward(20, x=x[:20].to(dev), w_in=w_in, cutoff=cutoff, sampling_steps=s, samples=samples, rec={0: rv, 1: rr})
+    idx = bp.forward(T - 20, x=x[20:].to(dev), w_in=w_in, step0=20, cutoff=cutoff, sampling_steps=s, samples=samples,
+                     rec={0: rv, 1: rr}, sample_idx=idx)
+    assert idx == S
+    for b in sorted({0, B // 2, B - 1}):
+        single = Population("li_tanh", W, params, 1e-2, dev, backend=backend, v0=v0[b])
+        one, r0, r1 = (torch.zeros(S, n, device=dev) for _ in range(3))
+        assert single.forward(T, x=x[:, b].to(dev), w_in=w_in, cutoff=cutoff, sampling_steps=s, samples=one, rec={0: r0, 1: r1}) == S
+        for a, c, name in ((samples[b], one, "samples"), (rv[b], r0, "rec v"), (rr[b], r1, "rec r")):
+            if form == "valu":
+                assert torch.equal(a, c), (b, name)
+            else:
+                assert float((a - c).abs().max()) < 2e-5, (b, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form,B,n", [("valu", 8, 516), ("mfma16", 13, 1036), ("mfma16", 32, 2052), ("mfma32", 32, 1036)])
+def test_batched_sampling_hip_equals_oracle(oracle_backend, hip_device, form, B, n):
+    """In-kernel sampling of the batched forms against the oracle's mirrors: bit for bit (samples, recordings, state)."""
+    m, T, s, cutoff = 3, 21, 3, 2
+    W, params = network(n, "li_tanh", seed=n)
+    g = torch.Generator().manual_seed(5)
+    v0 = torch.randn(B, n, generator=g)
+    x = torch.randn(T, B, m, generator=g)
+    w_in = torch.randn(n, m, generator=g)
+    S = len([t for t in range(T) if t >= cutoff and t % s == 0])
+    res = []
+    for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+        bp = BatchedPopulation(Population("li_tanh", W, params, 1e-2, dev, backend=backend), B, form=form)
+        bp.v.copy_(v0.to(dev))
+        bp.refresh()
+        samples, rv, rr = (torch.zeros(B, S, n, device=dev) for _ in range(3))
+        idx = bp.forward(9, x=x[:9].to(dev), w_in=w_in.to(dev), cutoff=cutoff, sampling_steps=s, samples=samples, rec={0: rv, 1: rr})
+        bp.forward(T - 9, x=x[9:].to(dev), w_in=w_in.to(dev), step0=9, cutoff=cutoff, sampling_steps=s, samples=samples,
+                   rec={0: rv, 1: rr}, sample_idx=idx)
+        res.append([t.cpu().numpy() for t in (samples, rv, rr, bp.v)])
+    for a, c, name in zip(res[0], res[1], ("samples", "rec v", "rec r", "v")):
+        assert np.array_equal(a.view(np.uint32), c.view(np.uint32)), name
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
 @pytest.mark.parametrize("form", ["mfma16", "mfma32"])
 @pytest.mark.parametrize("model,n,B,xw", [("li_tanh", 64, 32, "full"), ("li_tanh", 260, 20, "bcast"), ("li_sigmoid", 516, 9, "full"),
                                          ("li_tanh", 1036, 32, "none"), ("li_tanh", 2048, 16, "full"),
@@ -199,11 +311,11 @@ def test_matrix_core_form_hip_equals_oracle(oracle_backend, hip_device, form, n,
 
 
 @pytest.mark.gpu
-def test_mfma16_tile_width_and_ring_depth_keep_the_bits(hip_device):
+def test_mfma16_tile_width_and_ring_depth_keep_the_bits(hip_device, measure_backend):
     """The 16x16x4 form's summation order is defined on 16-column groups, not on the kernel's tile width or LDS ring
-    depth: every (tile columns, stages) instance gives the same bits (n with a ragged tail, both slot-block counts)."""
-    from rectipy_amd import _lib
-    lib = _lib.load()
+    depth: every (tile columns, stages) instance of the measurement build gives the bits of the product library's
+    kernel (n with a ragged tail, both slot-block counts)."""
+    lib = measure_backend.lib
     n, T = 2308, 6
     W, params = network(n, "li_tanh", seed=3)
     g = torch.Generator().manual_seed(4)
@@ -213,10 +325,14 @@ def test_mfma16_tile_width_and_ring_depth_keep_the_bits(hip_device):
             x = torch.randn(T, B, 1, generator=g)
             outs = []
             # (256-column tiles with two slot blocks need 192 KiB of LDS: that instance does not exist on this chip)
-            for tc, stages, waves in ((0, 0, 0), (64, 2, 4), (64, 3, 4), (64, 4, 4), (128, 2, 4), (128, 3, 4)) + \
+            for tc, stages, waves in ((None, 0, 0), (0, 0, 0), (64, 2, 4), (64, 3, 4), (64, 4, 4), (128, 2, 4), (128, 3, 4)) + \
                     (((256, 2, 4),) if B <= 16 else ((64, 2, 8), (64, 3, 8), (128, 2, 8), (64, 2, 16), (64, 3, 16), (64, 4, 16))):
-                lib.rp_set_batched_mfma_tuning(tc, stages, waves)
-                bp = BatchedPopulation(Population("li_tanh", W, params, 1e-2, hip_device), B, form="mfma16")
+                if tc is None:  # the product library
+                    backend = None
+                else:
+                    lib.rp_set_batched_mfma_tuning(tc, stages, waves)
+                    backend = measure_backend
+                bp = BatchedPopulation(Population("li_tanh", W, params, 1e-2, hip_device, backend=backend), B, form="mfma16")
                 bp.v.copy_(v0.to(hip_device))
                 bp.refresh()
                 traj = torch.zeros(T, B, n, device=hip_device)

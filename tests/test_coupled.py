@@ -1,0 +1,400 @@
+"""Populations joined by dense edges, cycles included, as ONE library call per window (rp_forward_coupled,
+include/rectipy_hip.h; the reference's per-step graph walk with feedback edges, rectipy/network.py:962-981, 1322-1357).
+
+CPU (oracle backend): the coupled call against an independent numpy float64 restatement of the reference's walk; the front
+end's plan against the step-by-step walk of the same graph; the reference-derived fixture G28 runs through this path in
+tests/test_topologies.py.  GPU: the HIP library against the oracle, bit for bit, and at the benchmark's shard shape
+against a float64 recomputation on the device."""
+import numpy as np
+import pytest
+import torch
+
+import rectipy_amd.engine as engine
+from rectipy_amd import FeedbackNetwork, SpikeResetNet, _abi
+from rectipy_amd.engine import Population, forward_coupled
+
+TANH = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
+QIF = "neuron_model_templates.spiking_neurons.qif.qif"
+TARGETS = [pytest.param("oracle", id="oracle"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture
+def target(request, oracle_backend):
+    if request.param == "oracle":
+        return dict(device="cpu", backend=oracle_backend)
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    return dict(device="cuda:0", backend=None)
+
+
+def assert_same(a, b, what):
+    a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+    assert a.shape == b.shape, what
+    same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
+    assert same.all(), f"{what}: {np.count_nonzero(~same)} of {a.size} differ, max abs {np.abs(a - b).max()}"
+
+
+# ---- engine level -----------------------------------------------------------------------------------------------------
+def circuit(sizes, models, seed, dev, backend, dt=1e-2):
+    """Populations of the given sizes / models with an edge between EVERY ordered pair (incl. feedback directions)."""
+    gen = torch.Generator().manual_seed(seed)
+    pops, edges = [], {}
+    for n, model in zip(sizes, models):
+        if model == "qif":
+            W = torch.rand(n, n, generator=gen) * 8.0 / n
+            params = dict(tau=1.0, k=1.0, eta=torch.randn(n, generator=gen) + 2.0, tau_s=torch.rand(n, generator=gen) + 0.5)
+            pops.append(Population("qif", W, params, dt, dev, v0=torch.randn(n, generator=gen), s0=torch.rand(n, generator=gen) * 0.1,
+                                   theta=5.0, v_reset=-5.0, backend=backend))
+        else:
+            W = torch.randn(n, n, generator=gen) * 1.2 / n ** 0.5
+            params = dict(tau=torch.rand(n, generator=gen) * 2 + 0.5, k=torch.rand(n, generator=gen) + 0.5,
+                          eta=torch.randn(n, generator=gen) * 0.1)
+            pops.append(Population("li_tanh", W, params, dt, dev, v0=torch.randn(n, generator=gen) * 0.5, backend=backend))
+    for t_, nt in enumerate(sizes):
+        for s_, ns in enumerate(sizes):
+            if s_ != t_:
+                edges[(s_, t_)] = (torch.randn(nt, ns, generator=gen) * 0.7 / ns ** 0.5).to(dev)
+    return pops, edges
+
+
+def modes_for(models, s_, t_):
+    """The mode the front end gives an edge s_ -> t_ when edges towards later members are feed-forward and edges towards
+    earlier members feedback edges (FeedbackNetwork._coupled_plan)."""
+    if s_ < t_:
+        return _abi.RP_EDGE_OUT
+    return _abi.RP_EDGE_LAG if models[s_] == "qif" else _abi.RP_EDGE_LIVE
+
+
+def run_circuit(pops, edges, models, out_vars, x, T, split, dev, S_every=3, cutoff=2):
+    """The window in `split` library calls; returns per member (traj, samples, final v, final source)."""
+    n_m = len(pops)
+    trajs = [torch.zeros(T, p.rows, device=dev) for p in pops]
+    samples = [torch.zeros(T, p.rows, device=dev) for p in pops]
+    hist = [[torch.zeros(p.rows, device=dev), torch.zeros(p.rows, device=dev)] for p in pops]
+    for m, p in enumerate(pops):  # what a LAG edge reads at step 0: the member's current output
+        hist[m][1].copy_(p.v if out_vars[m] == _abi.RP_OUT_STATE0 else p.source)
+        p.reset_sampling()
+    idx = [0] * n_m
+    bounds = np.linspace(0, T, split + 1).astype(int)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        members = []
+        for m, p in enumerate(pops):
+            run = dict(steps=int(b - a), step0=int(a), out_var=out_vars[m], traj=trajs[m][a:b], cutoff=cutoff, sampling_steps=S_every,
+                       samples=samples[m], sample_idx=idx[m], hist=hist[m])
+            if m == 0:
+                run["x"] = x[a:b]
+            members.append(dict(pop=p, run=run, edges=[(edges[(s_, m)], s_, modes_for(models, s_, m)) for s_ in range(n_m) if s_ != m]))
+        idx = forward_coupled(members)
+    return [(trajs[m], samples[m][:idx[m]], pops[m].v, pops[m].source) for m in range(n_m)]
+
+
+def numpy_walk(pops, edges, models, out_vars, x, T):
+    """float64 restatement of FeedbackNetwork's walk for these members (feedback.py: forward): members in order; an edge
+    from an earlier member delivers what that member returned this step, an edge from a later rate member its current
+    state, an edge from a later spiking member its output of the previous step."""
+    f = lambda t: t.detach().cpu().numpy().astype(np.float64)
+    st = []
+    for p in pops:
+        st.append(dict(v=f(p.v), s=f(p.source), W=f(p.W), par={k: f(v) for k, v in p.params.items()}))
+    outs = [[] for _ in pops]
+    lag = [None] * len(pops)
+    for t in range(T):
+        ret = {}
+        for m, p in enumerate(pops):
+            S = st[m]
+            E = 0.0
+            for s_ in range(len(pops)):
+                if s_ == m:
+                    continue
+                Q = st[s_]
+                if s_ < m:
+                    vec = ret[s_]
+                elif models[s_] == "qif":
+                    vec = lag[s_] if lag[s_] is not None else (Q["v"] if out_vars[s_] == _abi.RP_OUT_STATE0 else Q["s"])
+                else:
+                    vec = Q["v"] if out_vars[s_] == _abi.RP_OUT_STATE0 else np.tanh(Q["v"])
+                E = E + f(edges[(s_, m)]) @ vec
+            I = (f(x[t]) if m == 0 else 0.0) + E
+            par, v = S["par"], S["v"]
+            if models[m] == "qif":
+                s = S["s"]
+                spike = (v - p.theta >= 0).astype(np.float64)
+                dv = (v * v + par["eta"] + I) / par["tau"] + par["k"] * (S["W"] @ s)
+                ds = -s / par["tau_s"] + spike / p.dt
+                ret[m] = v.copy() if out_vars[m] == _abi.RP_OUT_STATE0 else s.copy()
+                S["v"] = (v + p.dt * dv) * (1 - spike) + spike * p.v_reset
+                S["s"] = s + p.dt * ds
+            else:
+                r = np.tanh(v)
+                ret[m] = v.copy() if out_vars[m] == _abi.RP_OUT_STATE0 else r
+                S["v"] = v + p.dt * (-v / par["tau"] + par["k"] * (S["W"] @ r) + I + par["eta"])
+            outs[m].append(ret[m])
+        for m in range(len(pops)):
+            lag[m] = ret[m]
+    return [np.asarray(o) for o in outs]
+
+
+CASES = [((24, 40, 16), ("li_tanh", "li_tanh", "li_tanh"), (0, 0, 1)),
+         ((32, 20), ("qif", "li_tanh"), (1, 0)),
+         ((17, 30, 12), ("li_tanh", "qif", "qif"), (1, 1, 0)),   # widths off the 16-byte path
+         ((256, 520), ("li_tanh", "qif"), (0, 1))]
+
+
+@pytest.mark.parametrize("sizes,models,out_vars", CASES)
+def test_coupled_call_follows_the_walk(oracle_backend, sizes, models, out_vars):
+    """Oracle: the coupled call == float64 restatement of the front end's walk (fp32 tolerance), and splitting the window
+    into several calls changes nothing (sampling state, history buffers and ping-pong indices carry over)."""
+    T = 60
+    x = torch.randn(T, sizes[0], generator=torch.Generator().manual_seed(9)) * 0.5
+    ref = None
+    for split in (1, 3):
+        pops, edges = circuit(sizes, models, seed=sum(sizes), dev="cpu", backend=oracle_backend)
+        if ref is None:
+            ref = numpy_walk(pops, edges, models, out_vars, x, T)
+        res = run_circuit(pops, edges, models, out_vars, x, T, split, "cpu")
+        for m, (traj, samples, v, s) in enumerate(res):
+            assert np.abs(traj.numpy() - ref[m]).max() < 5e-4 * max(1.0, np.abs(ref[m]).max()), f"member {m}"
+        if split == 1:
+            one = res
+        else:
+            for m in range(len(pops)):
+                for a, b, name in zip(one[m], res[m], ("traj", "samples", "v", "source")):
+                    assert_same(a, b, f"split member {m} {name}")
+
+
+def test_single_steps_with_edges_equal_the_coupled_window(oracle_backend):
+    """rp_forward with rp_run.edge_* (one step per call, the sources handed over as plain vectors -- the stepwise walk)
+    == rp_forward_coupled for the same graph, bit for bit."""
+    sizes, models, out_vars = (24, 40), ("li_tanh", "li_tanh"), (0, 0)
+    T = 25
+    x = torch.randn(T, sizes[0], generator=torch.Generator().manual_seed(3))
+    pops, edges = circuit(sizes, models, seed=5, dev="cpu", backend=oracle_backend)
+    win = run_circuit(pops, edges, models, out_vars, x, T, 1, "cpu")
+    pops, edges = circuit(sizes, models, seed=5, dev="cpu", backend=oracle_backend)
+    traj = [torch.zeros(T, n) for n in sizes]
+    for t in range(T):
+        v_b = pops[1].v.clone()                       # b's current state: what the feedback edge b -> a reads
+        pops[0].forward(1, x=x[t:t + 1], traj=traj[0][t:t + 1], edges=[(edges[(1, 0)], v_b)])
+        pops[1].forward(1, traj=traj[1][t:t + 1], edges=[(edges[(0, 1)], traj[0][t].clone())])
+    for m in range(2):
+        assert_same(win[m][0], traj[m], f"member {m}")
+        assert_same(win[m][2], pops[m].v, f"member {m} state")
+
+
+def test_argument_checks(oracle_backend):
+    """The library rejects inconsistent circuits before any launch (no GPU needed: validation precedes every HIP call)."""
+    import ctypes as C
+    from rectipy_amd import _lib
+    lib = _lib.load()
+    pops, edges = circuit((8, 16), ("li_tanh", "li_tanh"), seed=1, dev="cpu", backend=oracle_backend)
+    arr = (_abi.RpMember * 2)()
+    runs = []
+    for m, p in enumerate(pops):
+        run, keep, _ = p._make_run(steps=2, edges=[(edges[(1 - m, m)], None)])
+        runs.append((run, keep))
+        arr[m].net, arr[m].run = C.pointer(p._net()), C.pointer(run)
+        arr[m].edge_source[0], arr[m].edge_mode[0] = 1 - m, _abi.RP_EDGE_LIVE
+    arr[0].edge_mode[0] = _abi.RP_EDGE_OUT           # member 0 cannot read what member 1 returns later in the same step
+    assert lib.rp_forward_coupled(arr, 2, None) == _abi.RP_ERR_ARG and b"stepped earlier" in lib.rp_last_error()
+    arr[0].edge_mode[0] = _abi.RP_EDGE_LAG            # needs the source's history buffers
+    assert lib.rp_forward_coupled(arr, 2, None) == _abi.RP_ERR_ARG and b"hist" in lib.rp_last_error()
+    arr[0].edge_mode[0] = _abi.RP_EDGE_LIVE
+    arr[0].edge_source[0] = 0                         # its own state while it is stepped
+    assert lib.rp_forward_coupled(arr, 2, None) == _abi.RP_ERR_SHAPE  # (and the width no longer matches)
+    arr[0].edge_source[0] = 5
+    assert lib.rp_forward_coupled(arr, 2, None) == _abi.RP_ERR_ARG
+    arr[0].edge_source[0] = 1
+    runs[1][0].steps = 3
+    assert lib.rp_forward_coupled(arr, 2, None) == _abi.RP_ERR_ARG and b"steps" in lib.rp_last_error()
+    assert lib.rp_forward_coupled(None, 2, None) == _abi.RP_ERR_ARG
+
+
+# ---- HIP vs oracle ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes,models,out_vars", CASES + [((1024, 2052, 512), ("li_tanh", "qif", "li_tanh"), (0, 1, 1))])
+def test_hip_coupled_bit_exact(oracle_backend, hip_device, sizes, models, out_vars):
+    T = 40
+    x = torch.randn(T, sizes[0], generator=torch.Generator().manual_seed(9)) * 0.5
+    res = []
+    for dev, backend in (("cpu", oracle_backend), (hip_device, None)):
+        pops, edges = circuit(sizes, models, seed=sum(sizes), dev=dev, backend=backend)
+        res.append(run_circuit(pops, edges, models, out_vars, x.to(dev), T, 2, dev))
+    for m in range(len(sizes)):
+        for a, b, name in zip(res[0][m], res[1][m], ("traj", "samples", "v", "source")):
+            assert_same(a, b, f"member {m} {name}")
+
+
+@pytest.mark.gpu
+def test_hip_single_step_edges_bit_exact(oracle_backend, hip_device):
+    """rp_forward with edges whose sources are a constant vector and a [T, n] window of vectors."""
+    N, n1, n2, T = 520, 260, 77, 12
+    gen = torch.Generator().manual_seed(2)
+    W = torch.randn(N, N, generator=gen) / N ** 0.5
+    params = dict(tau=2.0, k=1.0, eta=0.0)
+    E1, E2 = torch.randn(N, n1, generator=gen) / n1 ** 0.5, torch.randn(N, n2, generator=gen) / n2 ** 0.5
+    s1, s2 = torch.randn(n1, generator=gen), torch.randn(T, n2, generator=gen)
+    x = torch.randn(T, 1, generator=gen)
+    res = []
+    for dev, backend in (("cpu", oracle_backend), (hip_device, None)):
+        pop = Population("li_tanh", W, params, 1e-2, dev, backend=backend)
+        traj = torch.zeros(T, N, device=dev)
+        pop.forward(T, x=x.to(dev), traj=traj, edges=[(E1.to(dev), s1.to(dev)), (E2.to(dev), s2.to(dev))])
+        res.append((traj, pop.v))
+    assert_same(res[0][0], res[1][0], "traj")
+    assert_same(res[0][1], res[1][1], "v")
+
+
+@pytest.mark.gpu
+def test_full_size_coupled_step_against_float64(hip_device):
+    """The benchmark's shape -- two populations of 16384 neurons, a -> b and feedback b -> a, 4 x 1 GiB of matrices per
+    Euler step -- for 3 steps against a float64 recomputation on the device."""
+    n, T = 16384, 3
+    gen = torch.Generator(device=hip_device).manual_seed(7)
+    mk = lambda r, c, g: torch.randn(r, c, device=hip_device, generator=gen) * g / c ** 0.5
+    W = [mk(n, n, 1.2), mk(n, n, 1.2)]
+    E_ab, E_ba = mk(n, n, 0.6), mk(n, n, 0.6)
+    x = torch.randn(T, n, device=hip_device, generator=gen) * 0.3
+    v0 = [torch.randn(n, device=hip_device, generator=gen) * 0.5 for _ in range(2)]
+    pops = [Population("li_tanh", W[m], dict(tau=2.0, k=1.0, eta=0.05), 1e-2, hip_device, v0=v0[m]) for m in range(2)]
+    traj = [torch.zeros(T, n, device=hip_device) for _ in range(2)]
+    hist = [torch.zeros(n, device=hip_device), torch.zeros(n, device=hip_device)]
+    forward_coupled([
+        dict(pop=pops[0], run=dict(steps=T, x=x, traj=traj[0], hist=hist), edges=[(E_ba, 1, _abi.RP_EDGE_LIVE)]),
+        dict(pop=pops[1], run=dict(steps=T, traj=traj[1]), edges=[(E_ab, 0, _abi.RP_EDGE_OUT)])])
+    v = [t.double() for t in v0]
+    for t in range(T):
+        va, vb = v
+        out_a = va.clone()
+        assert (traj[0][t].double() - va).abs().max() < 2e-5 and (traj[1][t].double() - vb).abs().max() < 2e-5, t
+        va_new = va + 1e-2 * (-va / 2.0 + W[0].double() @ torch.tanh(va) + (x[t].double() + E_ba.double() @ vb) + 0.05)
+        vb_new = vb + 1e-2 * (-vb / 2.0 + W[1].double() @ torch.tanh(vb) + E_ab.double() @ out_a + 0.05)
+        v = [va_new, vb_new]
+    assert (pops[0].v.double() - v[0]).abs().max() < 2e-5 and (pops[1].v.double() - v[1]).abs().max() < 2e-5
+
+
+# ---- front end --------------------------------------------------------------------------------------------------------
+def build_net(target, force, sizes=(12, 20, 8), spiking=(False, False, False), m=3, k=2, out_r=False, out_act="tanh"):
+    net = FeedbackNetwork(1e-2, **target)
+    r = np.random.default_rng(1)
+    if m:
+        net.add_func_node("inp", m, "identity")
+    labs = "abc"[:len(sizes)]
+    for lab, n, sp in zip(labs, sizes, spiking):
+        W = r.standard_normal((n, n)) / np.sqrt(n)
+        if sp:
+            node = SpikeResetNet.from_pyrates(
+                QIF, input_var="qif_op/I_ext", output_var="qif_op/s", weights=W * 5, source_var="qif_op/s",
+                target_var="qif_op/s_in", spike_var="qif_op/spike", reset_var="qif_op/v",
+                node_vars={"all/qif_op/eta": r.standard_normal(n) + 3, "all/qif_op/v": r.standard_normal(n)},
+                spike_threshold=10.0, spike_reset=-10.0, dt=1e-2, dtype=torch.float32, **target)
+            net.add_node(lab, node, node_type="diff_eq")
+        else:
+            net.add_diffeq_node(lab, TANH, weights=W, source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                                output_var="tanh_op/r" if out_r else "li_op/v", dtype=torch.float32,
+                                node_vars={"all/li_op/v": r.standard_normal(n) * 0.5, "all/li_op/tau": r.uniform(0.5, 2, n)})
+    if k:
+        net.add_func_node("out", k, out_act)
+    order = (["inp"] if m else []) + list(labs) + (["out"] if k else [])
+    width = dict(zip(labs, sizes), inp=m, out=k)
+    for s_, t_ in zip(order[:-1], order[1:]):
+        net.add_edge(s_, t_, weights=r.standard_normal((width[t_], width[s_])) * 0.5)
+    net.add_edge(labs[-1], labs[0], weights=r.standard_normal((sizes[0], sizes[-1])) * 0.5, feedback=True)
+    if len(labs) > 2:
+        net.add_edge(labs[0], labs[2], weights=r.standard_normal((sizes[2], sizes[0])) * 0.5, feedback=True)
+    net._force_stepwise = force
+    return net
+
+
+CONFIGS = [dict(), dict(spiking=(True, False, True)), dict(sizes=(16, 8), spiking=(True, True), m=0, k=0),
+           dict(out_r=True, m=0), dict(sizes=(16, 24), spiking=(False, True), out_act="identity"),
+           dict(sizes=(16, 24), k=3, out_act="softmax")]
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[str(i) for i in range(len(CONFIGS))])
+def test_run_takes_one_call_per_window_and_matches_the_walk(target, cfg, monkeypatch):
+    """`FeedbackNetwork.run` on graphs with cycles: ONE coupled library call per window (two with spiking members: the last
+    step exposes `y`), same outputs, recordings and final state as the step-by-step walk; state, sampling phase and the
+    lagging `y` of spiking members carry from one run to the next."""
+    calls = []
+    real = engine.forward_coupled
+    monkeypatch.setattr(engine, "forward_coupled", lambda members: calls.append(len(members)) or real(members))
+    T = 57
+    m = cfg.get("m", 3)
+    sizes = cfg.get("sizes", (12, 20, 8))
+    spiking = cfg.get("spiking", (False,) * len(sizes))
+    x = np.random.default_rng(0).standard_normal((T, m if m else sizes[0])).astype(np.float32)
+    var = "qif_op/v" if spiking[0] else "li_op/v"
+    res = []
+    for force in (True, False):
+        calls.clear()
+        net = build_net(target, force, **cfg)
+        o1 = net.run(x[:30], sampling_steps=3, cutoff=4, verbose=False, enable_grad=False, record_vars=[("a", var, False)])
+        o2 = net.run(x[30:], sampling_steps=2, verbose=False, enable_grad=False)
+        res.append((o1.to_numpy("out"), o2.to_numpy("out"), o1.to_numpy(("a", var)),
+                    {k_: v_.detach().cpu().numpy().copy() for k_, v_ in net.state.items()}))
+        per_run = 2 if any(spiking) else 1
+        assert calls == ([] if force else [len(sizes)] * (2 * per_run)), calls
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert a.shape == b.shape and np.abs(a - b).max() < 5e-6
+    for k_ in res[0][3]:
+        assert np.abs(res[0][3][k_] - res[1][3][k_]).max() < 5e-6, k_
+
+
+def test_what_stays_on_the_walk(oracle_backend):
+    """An activation node between populations, an edge with memory inside the cycle, a trained edge in a gradient run and
+    more than RP_MAX_EDGES edges into one population keep the step-by-step walk (and still run)."""
+    target = dict(device="cpu", backend=oracle_backend)
+    x = np.random.default_rng(0).standard_normal((10, 3)).astype(np.float32)
+    net = build_net(target, False)
+    assert net.compile() is None and net._coupled_plan([]) is not None
+    # activation node between two populations
+    net = build_net(target, False, sizes=(12, 20), k=0)
+    net.pop_edge("a", "b")
+    net.add_func_node("mid", 12, "tanh")
+    net.add_edge("a", "mid", weights=np.eye(12))
+    net.add_edge("mid", "b", weights=np.ones((20, 12)) * 0.1)
+    net.compile()
+    assert net._coupled_plan([]) is None
+    assert net.run(x, verbose=False, enable_grad=False).to_numpy("out").shape == (10, 20)
+    # an edge with memory between populations
+    net = build_net(target, False, sizes=(12, 20), k=0)
+    net.pop_edge("a", "b")
+    net.add_edge("a", "b", weights=np.ones((20, 12)) * 0.1, delays=np.arange(12) % 2)
+    net.compile()
+    assert net._coupled_plan([]) is None
+    # a trained edge: no gradient passes through the in-kernel product, so a gradient-tracking run walks
+    net = build_net(target, False, sizes=(12, 20), k=0)
+    net.pop_edge("a", "b")
+    net.add_edge("a", "b", weights=np.ones((20, 12)) * 0.1, train="gd")
+    net.compile()
+    assert net._coupled_plan([]) is not None and net._coupled_wants_grad(torch.zeros(1))
+    with torch.no_grad():
+        assert not net._coupled_wants_grad(torch.zeros(1))
+    obs = net.run(x, verbose=False)   # enable_grad defaults to True: the walk, with an autograd graph
+    assert obs.stacked("out").requires_grad
+
+
+@pytest.mark.gpu
+def test_matrices_move_into_one_allocation_and_stay_live(hip_device, monkeypatch):
+    """The matrices of a coupled plan are consolidated into one device allocation (placement decides 5-8 % of the step
+    time at HBM-bound sizes, FeedbackNetwork._consolidate); the tensors nodes and edges hand out stay live views: the
+    results do not change, and an in-place edit of `node["weights"]` / `edge.weights` afterwards is seen by the next run."""
+    monkeypatch.setattr(FeedbackNetwork, "ARENA_MIN_BYTES", 0)
+    target = dict(device="cuda:0", backend=None)
+    x = np.random.default_rng(0).standard_normal((20, 16)).astype(np.float32)
+    net = build_net(target, False, sizes=(16, 24), m=0, k=0)
+    ref = build_net(target, True, sizes=(16, 24), m=0, k=0)
+    a = net.run(x, verbose=False, enable_grad=False).to_numpy("out")
+    b = ref.run(x, verbose=False, enable_grad=False).to_numpy("out")
+    assert np.array_equal(a, b)
+    held = [net.get_node("a")["weights"], net.get_node("b")["weights"], net.get_edge("a", "b").weights, net.get_edge("b", "a").weights]
+    assert len({t.untyped_storage().data_ptr() for t in held}) == 1 and all(t.data_ptr() % 256 == 0 for t in held)
+    arena = net._arena
+    with torch.no_grad():
+        for n_ in (net, ref):
+            n_.get_node("a")["weights"].mul_(0.5)
+            n_.get_edge("b", "a").weights.add_(0.1)
+    a = net.run(x, verbose=False, enable_grad=False).to_numpy("out")
+    b = ref.run(x, verbose=False, enable_grad=False).to_numpy("out")
+    assert np.array_equal(a, b) and net._arena is arena  # (nothing to consolidate the second time)

@@ -444,18 +444,17 @@ def test_qif_full_size_dense_step_properties(hip_device):
     assert (s_new.double() - s_ref).abs().max() < 1e-5
 
 
-def test_run_to_run_determinism(hip_device):
+def test_run_to_run_determinism(hip_device, measure_backend):
     """No atomics on the numerical path and a fixed summation tree: two runs of the same window are bit-identical
-    (forward trajectory, adjoint state, weight gradient), and so is a different launch configuration."""
-    from rectipy_amd import _lib
+    (forward trajectory, adjoint state, weight gradient), and so is a different launch configuration (measurement build)."""
     N, T = 4096, 300
     W, params, v0 = make_li(N, seed=5)
     x = torch.randn(T, 1, generator=torch.Generator().manual_seed(6)).to(hip_device)
     g_out = (torch.randn(T, N, generator=torch.Generator().manual_seed(7)) * 0.01).to(hip_device)
     runs = []
     for tune in ((0, 0), (0, 0), (2, 4)):
-        _lib.load().rp_set_tuning(tune[0], tune[1], 1, 0)
-        pop = Population("li_tanh", W, params, 1e-2, hip_device, v0=v0)
+        measure_backend.lib.rp_set_tuning(tune[0], tune[1], 1, 0)
+        pop = Population("li_tanh", W, params, 1e-2, hip_device, v0=v0, backend=measure_backend if tune[0] else None)
         tv, tr, ut = (torch.zeros(T, N, device=hip_device) for _ in range(3))
         pop.forward(T, x=x, save_v=tv, save_src=tr)
         lam = torch.zeros(N, device=hip_device)
@@ -465,7 +464,7 @@ def test_run_to_run_determinism(hip_device):
         torch.cuda.synchronize()
         runs.append((tv.clone(), lam.clone(), gW))
         del keep
-    _lib.load().rp_set_tuning(0, 0, 1, 0)
+    measure_backend.lib.rp_set_tuning(0, 0, 1, 0)
     for other in runs[1:]:
         for a, b in zip(runs[0], other):
             assert torch.equal(a, b)

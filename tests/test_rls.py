@@ -98,12 +98,11 @@ def test_fit_rls_epochs_recovers_readout(target):
                                                        # tiles for the residency cap (one workgroup per CU); "sym-wide":
                                                        # the cap lifted, eight rows in flight
                                                        (4096, 2, 6, 1, "sym"), (8192, 1, 5, 2, "sym"), (4096, 1, 4, 1, "sym-wide")])
-def test_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride, tiled):
+def test_rls_sweep_bit_exact(oracle_backend, hip_device, measure_backend, n_in, n_out, T, stride, tiled):
     """Row-per-wave pass, the tiled pass (P walked in address order by one-shot workgroups, 1024-column tiles with
     per-tile partial sums; chosen by size from n_in = 8192) and the symmetric pass (only the blocks on and above the
     diagonal are streamed; row and column partials; mirror at the end: "sym", and by size from 4 updates per call),
     ragged last tiles / chunks / blocks included."""
-    from rectipy_amd import _lib
     gen = torch.Generator().manual_seed(n_in + T)
     X = torch.randn(T, n_in, generator=gen)
     Y = torch.randn(T, n_out, generator=gen)
@@ -111,15 +110,17 @@ def test_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride,
     res = []
     knob = {"sym-wide": 8 | (15 << 8)}.get(tiled, 0)
     tiled = "sym" if knob else tiled
-    for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
+    # "sym-wide" runs on the measurement build with its knob set; everything else on the product library
+    for backend, dev in ((oracle_backend, "cpu"), (measure_backend if knob else None, hip_device)):
         edge = RLS(n_in, n_out, weights=W0.clone(), beta=0.97, alpha=1.5, backend=backend).to(dev)
         edge.tiled = True if tiled == "sym" else tiled
         edge.symmetric = True if tiled == "sym" else None
-        _lib.load().rp_set_rls_sym(knob if backend is None else 0)
+        if backend is measure_backend:
+            measure_backend.lib.rp_set_rls_sym(knob)
         try:
             pred, loss = edge.sweep(X.to(dev), Y.to(dev), stride)
         finally:
-            _lib.load().rp_set_rls_sym(0)
+            measure_backend.lib.rp_set_rls_sym(0)
         assert (edge._partials is not None) == (bool(tiled) or (tiled is None and n_in >= RLS.TILED_MIN_N))
         updates = (T + stride - 1) // stride
         assert (edge._colparts is not None) == (tiled == "sym" or (tiled is None and n_in >= RLS.SYMMETRIC_MIN_N
