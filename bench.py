@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--config5-neurons", type=int, default=262144,
                     help="N of the row-sharded BASELINE configs[4] leg that runs with --gpus > 1 (0: skip)")
     ap.add_argument("--config5-steps", type=int, default=200)
+    ap.add_argument("--qif-steps", type=int, default=20000,
+                    help="Euler steps of the QIF leg (BASELINE configs[3] states 20000: about 49 s on one MI355X)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -284,7 +286,8 @@ def main():
     # HBM bytes per launch from the PMC counters need their own rocprofv3 passes (scripts/profile_kernels.sh); the
     # figure is read from the committed summary of that run and labelled as such -- it is NOT measured by this run
     traffic, traffic_source = None, None
-    for name in ("r03_step_kernel_traffic.json", "r02_step_kernel_traffic.json", "r01_step_kernel_traffic.json"):
+    for name in ("r04_step_kernel_traffic.json", "r03_step_kernel_traffic.json", "r02_step_kernel_traffic.json",
+                 "r01_step_kernel_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if world == 1 and N == 32768 and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
@@ -334,15 +337,16 @@ def main():
             "autotune_policy": tuning.mode(), "walk_measured_in_this_process": bool(streaming["measured"])}
         if cpu_threads is not None:
             out["extra"]["cpu_fwd_bwd"] = cpu_fwd_bwd(pop, x, dt, N, cpu_threads)
-        out["extra"]["batched_trajectories"] = batched_extra(pop, N, dev, out["ms_per_step"])
+        out["extra"]["batched_trajectories"] = batched_extra(pop, N, dev, out["ms_per_step"], net=net)
         out["extra"]["fit_ridge"] = ridge_extra(net, x, N, dev)
         out["extra"]["fit_ridge"]["phases_ms"]["step_kernels_alone_at_the_measured_launch_time"] = 2000 * kernel_ms
         out["extra"].update(facade_fit_bptt(pop, x, N, dev, teacher_net=net))  # it trains (modifies) the shared weight matrix
         pop = net = sp = None  # release the 4.3 GB network before the two larger side workloads
         torch.cuda.empty_cache()
         out["extra"]["stepwise"] = stepwise_extra(dev)
+        out["extra"]["small_n"] = small_n_extra(dev)
         out["extra"]["rls_n32768"] = rls_extra(dev, cpu_threads=cpu_threads)
-        out["extra"]["qif_n65536"] = qif_extra(dev, cpu_threads=cpu_threads)
+        out["extra"]["qif_n65536"] = qif_extra(dev, T=args.qif_steps, cpu_threads=cpu_threads)
         out["extra"]["sparse_p0.1_n32768"] = sparse_extra(dev)
     emit(json.dumps(out))
     if use_dist:
@@ -463,54 +467,119 @@ def facade_fit_bptt(pop, x, N, dev, teacher_net=None):
             "facade_fit_bptt_window_relative_losses": [l / p for l, p in zip(wl, tp)]}
 
 
-def qif_extra(dev, N=65536, T=400, cpu_threads=None):
-    """BASELINE.json configs[3] at a reduced step count (the per-step cost is stationary): QIF population, dense
-    W = rand * 20 / N, spike + reset path, through the engine."""
-    from rectipy_amd import _abi
-    from rectipy_amd.engine import Population
+def qif_extra(dev, N=65536, T=20000, cpu_threads=None):
+    """BASELINE.json configs[3] AS STATED, through the front end: QIF population, N = 65536, dense
+    W = rand * 20 / N, tau = k = tau_s = 1, eta = -5, v0 = -2, s0 = 0, theta = 100, v_reset = -100, dt = 1e-3, constant
+    input 15, 20000 Euler steps, spike + reset path, Network.run with sampling_steps = 100 (about 49 s of GPU time)."""
+    import contextlib
+    from rectipy_amd import Network
     gen = torch.Generator(device=dev).manual_seed(0)
     W = torch.empty(N, N, device=dev)
     for r in range(0, N, 4096):
         W[r:r + 4096] = torch.rand(4096, N, device=dev, generator=gen)
     W.mul_(20.0 / N)
-    # membrane potentials spread over the whole range, so that threshold crossings and resets occur in every step of the
-    # short timed window (from v = -2 the first spike of this configuration needs ~700 steps)
-    pop = Population("qif", W, dict(tau=1.0, k=1.0, eta=-5.0, tau_s=1.0), 1e-3, dev,
-                     v0=torch.linspace(-2.0, 99.0, N), s0=0.0, theta=100.0, v_reset=-100.0)
+    net = Network(dt=1e-3, device=str(dev))
+    with contextlib.redirect_stdout(sys.stderr):
+        net.add_diffeq_node("qif", "neuron_model_templates.spiking_neurons.qif.qif", input_var="qif_op/I_ext",
+                            output_var="qif_op/s", weights=W, source_var="qif_op/s", target_var="qif_op/s_in",
+                            spike_var="qif_op/spike", reset_var="qif_op/v", spike_threshold=100.0, spike_reset=-100.0,
+                            dtype=torch.float32,
+                            node_vars={"all/qif_op/eta": -5.0, "all/qif_op/tau": 1.0, "all/qif_op/k": 1.0,
+                                       "all/qif_op/tau_s": 1.0, "all/qif_op/v": -2.0, "all/qif_op/s": 0.0})
     del W
-    x = torch.full((T + 50, 1), 15.0, device=dev)
-    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-    ev = torch.zeros(1 << 20, 2, dtype=torch.int32, device=dev)
-    pop.forward(50, x=x[:50])
+    node = net.get_node("qif")
+    x = torch.full((T, 1), 15.0, device=dev)
+    y0 = {k_: v_.detach().clone() for k_, v_ in net.state.items()}
+    net.run(x[:50], sampling_steps=50, verbose=False, enable_grad=False)  # warm-up
+    net.reset(y0)  # back to v0 = -2, s0 = 0
+    node.enable_spike_recording(1 << 23)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    pop.forward(T, x=x[50:], step0=50, out_var=_abi.RP_OUT_SOURCE, spike_events=ev, spike_count=cnt)
-    e1.record()
+    t0 = time.perf_counter()
+    obs = net.run(x, sampling_steps=100, verbose=False, enable_grad=False)
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / T
+    wall = time.perf_counter() - t0
+    ev = node.spikes()
+    ms = wall / T * 1e3
     gbps = (4.0 * N * N + 48.0 * N) / (ms * 1e-3) / 1e9
-    res = {"workload": f"QIF N={N} dense W = rand*20/N, eta=-5, constant input 15, dt=1e-3, spike/reset path; {T} timed "
-                       f"steps after 50 warm-up steps from v0 = linspace(-2, 99) (BASELINE.json configs[3] shape; the "
-                       f"stated recipe starts at v0=-2 and runs 20000 steps -- per-step cost is stationary and the spread "
-                       f"start puts threshold crossings into every timed step)",
-           "steps_per_s": 1e3 / ms, "ms_per_step": ms, "spikes": int(cnt.item()),
-           "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS},
-           "state_finite": bool(torch.isfinite(pop.v).all().item())}
+    s_mean = obs.to_numpy("out").mean(axis=1)
+    res = {"workload": f"QIF N={N} dense W = rand*20/N, eta=-5, v0=-2, s0=0, theta=100, v_reset=-100, constant input 15, "
+                       f"dt=1e-3, {T} Euler steps through Network.run (sampling_steps=100), spike/reset path: "
+                       f"BASELINE.json configs[3] as stated",
+           "steps_per_s": T / wall, "ms_per_step": ms, "wall_s": wall, "spikes": int(ev.shape[0]),
+           "first_spike_step": int(ev[:, 0].min()) if ev.shape[0] else None,
+           "spikes_per_neuron_per_unit_time": ev.shape[0] / N / (T * 1e-3),
+           "mean_s_first_last_sample": [float(s_mean[0]), float(s_mean[-1])], "samples": len(obs["steps"]),
+           "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                        "note": "wall clock of the whole run (front end included) over the algorithmic bytes 4 N^2 + 48 N per step"},
+           "state_finite": bool(torch.isfinite(node.current_state).all().item())}
     if cpu_threads is not None:
         from oracle.torch_eager import host_copy_spread, time_eager_qif
-        Wc = host_copy_spread(pop.W)
+        Wc = host_copy_spread(node._pop.W)
         one = torch.ones(N)
         torch.set_num_threads(cpu_threads)
         warm, timed = 1, 8
         sps = time_eager_qif(Wc, one, one, torch.full((N,), -5.0), one, torch.linspace(-2.0, 99.0, N), torch.zeros(N), 15.0,
                              1e-3, 100.0, -100.0, warm, timed)
         res["cpu"] = {"value": sps, "unit": "steps/s", "cores": cpu_threads, "kind": "port",
-                      "sample": f"{warm} warm-up + {timed} timed steps of the same QIF network, torch CPU eager loop "
-                                f"(oracle/torch_eager.py: time_eager_qif), fp32, no_grad"}
+                      "sample": f"{warm} warm-up + {timed} timed steps of the same QIF network from a spread start (threshold "
+                                f"crossings in every step), torch CPU eager loop (oracle/torch_eager.py: time_eager_qif), "
+                                f"fp32, no_grad"}
         del Wc
-    del pop
+    del net, node
     torch.cuda.empty_cache()
+    return res
+
+
+def small_n_extra(dev, N=512, T=2000):
+    """BASELINE.json configs[0] shape on the GPU (the reference's own scale: launch-bound, not HBM-bound): tanh population,
+    N = 512, g = 1.5, full-width input, 2000 Euler steps through Network.run (sampling_steps = 1) and through
+    Network.fit_bptt (SGD, 100-step windows, all of W trained, k = 3 read-out).  us per step, wall clock of whole calls;
+    `launch_floor_us` is the duration of an empty-grid launch pair on this box (what a step cannot go below while it is
+    one kernel launch per Euler step)."""
+    import contextlib
+    from rectipy_amd import Network
+    tanh = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
+    gen = torch.Generator(device=dev).manual_seed(0)
+    W = torch.randn(N, N, device=dev, generator=gen) * 1.5 / N ** 0.5
+    x = torch.randn(T, N, device=dev, generator=torch.Generator(device=dev).manual_seed(1)) * 0.5
+    target = torch.randn(T, 3, device=dev, generator=gen) * 0.1
+    res = {"workload": f"tanh rate RNN N={N} (BASELINE.json configs[0] shape), {T} Euler steps", "unit": "us per Euler step (wall clock)"}
+    with contextlib.redirect_stdout(sys.stderr):
+        net = Network(dt=1e-2, device=str(dev))
+        net.add_diffeq_node("rnn", tanh, input_var="li_op/I_ext", output_var="li_op/v", weights=W, source_var="tanh_op/r",
+                            target_var="li_op/r_in", dtype=torch.float32)
+        net.run(x[:200], sampling_steps=1, verbose=False, enable_grad=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        net.run(x, sampling_steps=1, verbose=False, enable_grad=False)
+        torch.cuda.synchronize()
+        res["Network_run"] = (time.perf_counter() - t0) / T * 1e6
+        res["Network_run_steps_per_s"] = 1e6 / res["Network_run"]
+        fit = Network(dt=1e-2, device=str(dev))
+        fit.add_diffeq_node("rnn", tanh, input_var="li_op/I_ext", output_var="li_op/v", weights=W * 0.5, source_var="tanh_op/r",
+                            target_var="li_op/r_in", dtype=torch.float32, train_params=["weights"])
+        fit.add_func_node("out", 3, "identity")
+        fit.add_edge("rnn", "out", weights=torch.randn(3, N, device=dev, generator=gen) / N ** 0.5, train="gd")
+        fit.fit_bptt(x[:200], target[:200], optimizer="sgd", lr=1e-3, update_steps=100, sampling_steps=100, verbose=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fit.fit_bptt(x, target, optimizer="sgd", lr=1e-3, update_steps=100, sampling_steps=100, verbose=False)
+        torch.cuda.synchronize()
+        res["Network_fit_bptt_sgd_100_step_windows"] = (time.perf_counter() - t0) / T * 1e6
+    # launch floor: dependent tiny kernels back to back on the stream
+    z = torch.zeros(64, device=dev)
+    for _ in range(200):
+        z.add_(1.0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(2000):
+        z.add_(1.0)
+    e1.record()
+    torch.cuda.synchronize()
+    res["launch_floor_us"] = e0.elapsed_time(e1) / 2000 * 1e3
+    res["note"] = ("one kernel launch per Euler step (two per adjoint step): the step is bounded by the dependent-launch "
+                   "interval of the stream, not by HBM (W is 1 MiB)")
     return res
 
 
@@ -595,7 +664,7 @@ def cpu_fwd_bwd(pop, x, dt, N, threads, T=20):
                       f"(oracle/torch_eager.py: time_eager_bptt)"}
 
 
-def batched_extra(pop, N, dev, ms_single, T=200):
+def batched_extra(pop, N, dev, ms_single, T=200, net=None):
     """B independent trajectories of the same network in one pass over W per step (rp_forward_batched; the "batched-input
     dense W @ state contraction" of the brief -- the reference has no batch axis and would run them one after the other).
     Up to 8 trajectories on the vector ALUs are bit-identical to unbatched runs; the matrix-core forms have their own
@@ -632,6 +701,30 @@ def batched_extra(pop, N, dev, ms_single, T=200):
             "state_finite": bool(torch.isfinite(bp.v).all().item())}
         del bp, xb
     torch.cuda.empty_cache()
+    if net is not None:
+        # the front-end path: Network.run_batch, 32 trajectories x 2000 steps, sampled every 100 steps inside the kernels.
+        # Wall clock of the whole call and the peak of device memory it allocated on top of the network (r03 staged
+        # [B, T, N] = 8.4 GB here; now O(B x samples x N))
+        B, Tb = 32, 2000
+        xb = torch.randn(B, Tb, 1, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+        net.run_batch(xb[:, :100], sampling_steps=100)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats(dev)
+        base = torch.cuda.memory_allocated(dev)
+        t0 = time.perf_counter()
+        obs = net.run_batch(xb, sampling_steps=100)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ms = wall / Tb * 1e3
+        roof_ms = max(4.0 * N * N / (HBM_PEAK_GBPS * 1e9), 2.0 * N * N * B / 157.3e12) * 1e3
+        res["Network_run_batch_B32"] = {
+            "workload": f"Network.run_batch: {B} trajectories x {Tb} steps, sampling_steps=100, broadcast input",
+            "wall_s": wall, "ms_per_step": ms, "trajectory_steps_per_s": B * Tb / wall, "roof_frac": roof_ms / ms,
+            "samples_per_trajectory": len(obs[0]["steps"]),
+            "peak_device_memory_above_the_network_MB": (torch.cuda.max_memory_allocated(dev) - base) / 1e6,
+            "staging_all_steps_would_take_MB": 4.0 * B * Tb * N / 1e6}
+        del xb, obs
+        torch.cuda.empty_cache()
     return res
 
 

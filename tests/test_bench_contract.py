@@ -14,7 +14,7 @@ def test_bench_json_contract():
     env = dict(os.environ)
     env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
     proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "20",
-                           "--neurons", "8192", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+                           "--neurons", "8192", "--no-cpu-baseline", "--qif-steps", "400"], capture_output=True, text=True, env=env, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, f"expected one line on stdout, got {len(lines)}"
