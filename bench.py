@@ -675,10 +675,11 @@ def batched_extra(pop, N, dev, ms_single, T=200, net=None):
     res = {"workload": f"tanh rate RNN N={N}, B trajectories per pass over W, {T} timed steps each, broadcast input",
            "unit": "trajectory-steps/s"}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    # 2..8: vector ALUs (bit-identical to unbatched runs); ("mfma", 8), 16, 32: exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32,
-    # W and source tiles by LDS-DMA; 17..32 trajectories: role-split workgroups).  Binding roof of a step: the slower of W
+    # 2, 4 (and 8 with exact=True): vector ALUs (bit-identical to unbatched runs); 8, 16, 32: exact-fp32 matrix cores
+    # (v_mfma_f32_16x16x4_f32, W and source tiles by LDS-DMA; 17..32 trajectories: role-split workgroups).  Binding roof of a step: the slower of W
     # once from HBM (4 N^2 B / 8 TB/s) and the contraction on the fp32 matrix cores (2 N^2 B flop / 157.3 TFLOP/s).
-    for B, mfma in ((2, False), (4, False), (8, False), (8, True), (16, True), (32, True)):
+    # B8 / B16 / B32: the defaults (matrix cores from 5 trajectories); B8_exact: the vector-ALU form `exact=True` keeps
+    for B, mfma in ((2, None), (4, None), (8, False), (8, None), (16, None), (32, None)):
         bp = BatchedPopulation(pop, B, mfma=mfma)
         bp.v.normal_(generator=torch.Generator(device=dev).manual_seed(B))
         bp.refresh()
@@ -692,7 +693,7 @@ def batched_extra(pop, N, dev, ms_single, T=200, net=None):
         ms = e0.elapsed_time(e1) / T
         roof_ms = max(4.0 * N * N / (HBM_PEAK_GBPS * 1e9), 2.0 * N * N * B / 157.3e12) * 1e3
         forms = {"valu": "valu", "mfma16": "mfma_f32_16x16x4 + LDS-DMA ring", "mfma32": "mfma_f32_32x32x2"}
-        res[f"B{B}" + ("_mfma" if mfma and B <= 8 else "")] = {
+        res[f"B{B}" + ("_exact" if mfma is False and B == 8 else "")] = {
             "form": forms[bp.form], "trajectory_steps_per_s": B * 1e3 / ms, "ms_per_step": ms,
             "vs_unbatched": B * ms_single / ms, "W_stream_GBps": 4.0 * N * N / (ms * 1e-3) / 1e9,
             "fma_TFLOPs": 2.0 * N * N * B / (ms * 1e-3) / 1e12,

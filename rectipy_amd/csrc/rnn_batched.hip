@@ -606,7 +606,10 @@ __global__ __launch_bounds__(512) void step_batched_mfma16_split_kernel(const Ba
     if (wave >= 4) {
         // ---------------- loader ----------------
         const int lw = wave - 4;
-        if (PROBE >= 10) __builtin_amdgcn_s_setprio(3);  // (measured: see DESIGN.md)
+        if (PROBE >= 10 && PROBE < 30) __builtin_amdgcn_s_setprio(3);  // (measured: see DESIGN.md)
+        // cache policy of the two DMA streams (measurement build: PROBE 30..37; bits: 1 = sc0, 2 = nt, 16 = sc1)
+        static constexpr int W_AUX = PROBE == 30 ? 18 : PROBE == 31 ? 19 : PROBE == 32 ? 17 : PROBE == 33 ? 0 : PROBE == 34 ? 16 : PROBE == 37 ? 3 : 2;
+        static constexpr int R_AUX = PROBE == 35 ? 1 : PROBE == 36 ? 16 : 0;
         const float* src[DPT];  // per-lane source of piece k (W pieces first), without the tile's column offset
         int quad[DPT];
 #pragma clang loop unroll(full)
@@ -643,9 +646,9 @@ __global__ __launch_bounds__(512) void step_batched_mfma16_split_kernel(const Ba
 #pragma clang loop unroll(full)
             for (int k = 0; k < DPT; ++k) {
                 if (k < W_PIECES)
-                    __builtin_amdgcn_global_load_lds((rp_gptr)(src[k] + c0), (rp_lptr)piece_lds(st, k), 16, 0, 2 /* nt */);
+                    __builtin_amdgcn_global_load_lds((rp_gptr)(src[k] + c0), (rp_lptr)piece_lds(st, k), 16, 0, W_AUX /* nt */);
                 else
-                    __builtin_amdgcn_global_load_lds((rp_gptr)(src[k] + c0), (rp_lptr)piece_lds(st, k), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((rp_gptr)(src[k] + c0), (rp_lptr)piece_lds(st, k), 16, 0, R_AUX);
             }
         };
         int slot_issue = 0;
@@ -860,6 +863,14 @@ int launch_mfma16_cfg(const BatchParams& P, int B, hipStream_t st) {
                 case 10160643: return launch_mfma16_split<MODEL, 64, 3, 10>(P, B, st);
                 case 20160643: return launch_mfma16_split<MODEL, 64, 3, 20>(P, B, st);
                 case 21160643: return launch_mfma16_split<MODEL, 64, 3, 21>(P, B, st);
+                case 30160643: return launch_mfma16_split<MODEL, 64, 3, 30>(P, B, st);
+                case 31160643: return launch_mfma16_split<MODEL, 64, 3, 31>(P, B, st);
+                case 32160643: return launch_mfma16_split<MODEL, 64, 3, 32>(P, B, st);
+                case 33160643: return launch_mfma16_split<MODEL, 64, 3, 33>(P, B, st);
+                case 34160643: return launch_mfma16_split<MODEL, 64, 3, 34>(P, B, st);
+                case 35160643: return launch_mfma16_split<MODEL, 64, 3, 35>(P, B, st);
+                case 36160643: return launch_mfma16_split<MODEL, 64, 3, 36>(P, B, st);
+                case 37160643: return launch_mfma16_split<MODEL, 64, 3, 37>(P, B, st);
                 default: break;
             }
         }

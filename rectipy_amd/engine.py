@@ -714,16 +714,19 @@ class BatchedPopulation:
     FORMS = {"valu": _abi.RP_BATCH_VALU, "mfma32": _abi.RP_BATCH_MFMA, "mfma16": _abi.RP_BATCH_MFMA16}
     DEFAULT_MFMA = "mfma16"   # which matrix-core form `mfma=True` / batch > 8 selects
 
-    def __init__(self, pop: Population, batch: int, v0=None, mfma: Optional[bool] = None, form: Optional[str] = None):
+    def __init__(self, pop: Population, batch: int, v0=None, mfma: Optional[bool] = None, form: Optional[str] = None,
+                 exact: bool = False):
         """``form``: "valu" | "mfma16" (v_mfma_f32_16x16x4_f32, LDS-DMA ring, batch-major state) | "mfma32" (the r02
-        v_mfma_f32_32x32x2_f32 form, neuron-major state); default: "valu" up to 8 trajectories, else ``DEFAULT_MFMA``
-        (``mfma=True`` asks for the matrix cores at any batch)."""
+        v_mfma_f32_32x32x2_f32 form, neuron-major state); default: "valu" up to 4 trajectories (bit-identical to unbatched
+        runs at the HBM roof), ``DEFAULT_MFMA`` from 5 (N = 32768, 8 trajectories: 0.63 ms per step against 0.87 on the
+        vector ALUs).  ``exact=True`` keeps 8 (and 16) trajectories on the vector ALUs, i.e. bit-identical to unbatched
+        runs; ``mfma=True`` asks for the matrix cores at any batch."""
         if pop.spiking:
             raise NotImplementedError("batched trajectories cover the rate models (li_tanh, li_sigmoid)")
         if pop.n % 4 or pop.W.stride(0) % 4:
             raise ValueError("batched trajectories need n % 4 == 0")
         if form is None:
-            use_mfma = (batch > 8) if mfma is None else bool(mfma)
+            use_mfma = (batch > 4 and not (exact and batch in self.BATCHES)) if mfma is None else bool(mfma)
             form = self.DEFAULT_MFMA if use_mfma else "valu"
             # more than 16 trajectories on a SMALL population: the r02 form's 32-row workgroups fill the chip where the
             # 64-row workgroups of "mfma16" cannot (scripts/sweep_mfma16.py: N = 8192, B = 32: 0.075 vs 0.096 ms per step;

@@ -494,7 +494,7 @@ class Network:
             nb = min(BatchedPopulation.SLOTS, B - b0)
             on_valu = nb <= (8 if exact else 4) and not mfma
             size = next(q for q in (2, 4, 8) if q >= nb) if on_valu else nb
-            bp = BatchedPopulation(pop, size, mfma=None if on_valu else True)
+            bp = BatchedPopulation(pop, size, mfma=not on_valu)
             bp.v.zero_()
             bp.v[:nb] = start[b0:b0 + nb]
             bp.refresh()
