@@ -512,18 +512,23 @@ typedef struct rp_rls {
        sweep P in address order, each takes one 4 KiB tile (row i, 1024 columns) and leaves the tile's partial dot
        product here; z'_i = beta_inv * (sum of row i's partials, ascending).  NULL: one wave per row (small n_in). */
     float* partials;
-    /* optional workspace [(ceil(n_in / sym_rows) + ceil(n_in / 1024)) x ldc] (ldc >= n_in, ldc % 4 == 0; needs `partials`
+    /* optional workspace [ceil(n_in / sym_rows) x ldc] (ldc >= n_in, ldc % 4 == 0; needs `partials`
        too): selects the SYMMETRIC pass.  P -= k z z^T keeps P symmetric (the reference's k * outer(z, z) does so exactly),
        so only the 1024 x 1024 blocks on and above the diagonal are streamed -- 4 n_in^2 instead of 8 n_in^2 bytes per
        update -- and every off-diagonal element serves both P_ij x_j (row partials, as in the tiled pass) and P_ij x_i
        (column partials per chunk of sym_rows rows: an i-ascending fmaf chain from 0; the chunks of a block row are added
        in ascending order to the block's column sum).  z'_i = beta_inv * (the column sums of the block rows above i's,
        ascending, then the row's tile partials from its diagonal block on, ascending).  On entry the blocks on and above
-       the diagonal are authoritative (whatever the lower ones hold); on return the off-diagonal blocks have been
-       mirrored, so P is full again.  Worth it from a few updates per call (the mirror costs about one dense pass). */
+       the diagonal are authoritative (whatever the lower ones hold: callers must only hand over a P that is symmetric);
+       on return the off-diagonal blocks have been mirrored, so P is full again -- unless defer_mirror is set.  Worth it
+       from a few updates per call (the mirror costs about one dense pass). */
     float* colparts;
     int64_t ldc;
     int32_t sym_rows;  /* rows per chunk of the symmetric pass: 16, 32 or 64 (0: 64); part of its summation order */
+    /* symmetric pass only: 1 = return WITHOUT mirroring -- the blocks on and above the diagonal stay the authoritative
+       half of P (the state the next symmetric sweep starts from anyway) and the caller restores the lower blocks with
+       rp_rls_mirror before anything else reads P.  Saves one pass over half of P per call (0.78 ms at n_in = 32768). */
+    int32_t defer_mirror;
 } rp_rls;
 
 /* `steps` consecutive rows of X [steps x ldx] (edge inputs) and Y [steps x ldy] (targets); an update happens at
@@ -533,6 +538,9 @@ typedef struct rp_rls {
 int rp_sizeof_rls(void);
 int rp_rls_sweep(const rp_rls* rls, int32_t steps, int32_t stride, const float* X, int64_t ldx, const float* Y,
                  int64_t ldy, float* pred, int64_t ldpred, float* loss, void* stream);
+/* P[j][i] = P[i][j] for every 1024 x 1024 block below the diagonal (uses n_in, P, ldp only): what a symmetric sweep with
+   defer_mirror = 1 left undone.  n_in % 4 == 0. */
+int rp_rls_mirror(const rp_rls* rls, void* stream);
 
 /* Streaming configuration of the dense step kernel, measured on the current device.  How W is walked (rows per wave,
    256-column chunks in flight, resident workgroups) never changes what is summed in which order, so every configuration

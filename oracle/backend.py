@@ -64,6 +64,7 @@ def _declare(lib):
     sig("oracle_forward_batched_mfma", C.c_int, [P(RpNet), P(_abi.RpBatch)])
     sig("oracle_forward_batched_mfma16", C.c_int, [P(RpNet), P(_abi.RpBatch)])
     sig("oracle_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp])
+    sig("oracle_rls_mirror", C.c_int, [P(RpRls)])
     sig("oracle_expf", C.c_float, [C.c_float])
     sig("oracle_tanhf", C.c_float, [C.c_float])
     sig("oracle_row_dot", C.c_float, [fp, fp, C.c_int, C.c_int, C.c_int])
@@ -165,6 +166,9 @@ class OracleBackend:
 
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
         assert self.lib.oracle_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss) == 0
+
+    def rls_mirror(self, rls, device):
+        assert self.lib.oracle_rls_mirror(C.byref(rls)) == 0
 
     def partial_rows(self, n):
         return min(64, (n + 7) // 8)

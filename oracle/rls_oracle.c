@@ -8,6 +8,7 @@
  * Pinned against golden vectors from the reference in tests/test_rls.py (G14).
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "rectipy_hip.h"
@@ -124,12 +125,14 @@ static void sym_pass(const rp_rls* r, int update, float k, const float* z, const
         }
     }
     if (!x_next) return;
+    /* column sums per block row (the z' kernel keeps them in LDS; here: a scratch of the oracle's own) */
+    float* colsum = (float*)malloc(sizeof(float) * (size_t)nb * (size_t)n);
     for (int I = 0; I + 1 < nb; ++I) {
         const int c0 = I * per_block, c1 = c0 + per_block < chunks ? c0 + per_block : chunks;
         for (int j = (I + 1) << 10; j < n; ++j) {
             float s = r->colparts[(int64_t)c0 * r->ldc + j];
             for (int c = c0 + 1; c < c1; ++c) s = s + r->colparts[(int64_t)c * r->ldc + j];
-            r->colparts[(int64_t)(chunks + I) * r->ldc + j] = s;
+            colsum[(int64_t)I * n + j] = s;
         }
     }
     for (int i = 0; i < n; ++i) {
@@ -137,7 +140,7 @@ static void sym_pass(const rp_rls* r, int update, float k, const float* z, const
         float s = 0.0f;
         int first = 1;
         for (int b = 0; b < I; ++b) {
-            const float v = r->colparts[(int64_t)(chunks + b) * r->ldc + i];
+            const float v = colsum[(int64_t)b * n + i];
             s = first ? v : s + v;
             first = 0;
         }
@@ -148,6 +151,7 @@ static void sym_pass(const rp_rls* r, int update, float k, const float* z, const
         }
         zn[i] = r->beta_inv * s;
     }
+    free(colsum);
 }
 
 static void sym_mirror(const rp_rls* r) {
@@ -209,6 +213,12 @@ int oracle_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, const float
         za = zb;
         zb = tmp;
     }
-    if (sym) sym_mirror(r);
+    if (sym && !r->defer_mirror) sym_mirror(r);
+    return RP_OK;
+}
+
+/* rp_rls_mirror: the lower blocks from the authoritative upper ones (what a sweep with defer_mirror = 1 left undone) */
+int oracle_rls_mirror(const rp_rls* r) {
+    sym_mirror(r);
     return RP_OK;
 }

@@ -221,6 +221,7 @@ class RpRls(C.Structure):
         ("colparts", fp),
         ("ldc", C.c_int64),
         ("sym_rows", C.c_int32),
+        ("defer_mirror", C.c_int32),
     ]
 
 
@@ -291,6 +292,7 @@ def declare(lib):
     sig("rp_set_gemm_dma", C.c_int, [C.c_int])
     sig("rp_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp,
                                   C.c_void_p])
+    sig("rp_rls_mirror", C.c_int, [P(RpRls), C.c_void_p])
     sig("rp_stream_probe", C.c_int, [fp, C.c_int64, fp, C.c_void_p])
     sig("rp_tune_forward", C.c_int, [C.POINTER(RpNet), C.c_void_p])
     sig("rp_forward_tuning", C.c_int, [C.POINTER(RpNet), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -314,7 +316,7 @@ EXPORTS = [
     "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum",
     "rp_outer_accum_rect", "rp_outer_store_rect", "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial",
     "rp_bwd_apply", "rp_sizeof_comm", "rp_forward_sharded", "rp_backward_sharded", "rp_ipc_alloc", "rp_ipc_open",
-    "rp_ipc_close", "rp_ipc_free", "rp_sizeof_batch", "rp_sizeof_rls", "rp_forward_batched", "rp_rls_sweep",
+    "rp_ipc_close", "rp_ipc_free", "rp_sizeof_batch", "rp_sizeof_rls", "rp_forward_batched", "rp_rls_sweep", "rp_rls_mirror",
     "rp_stream_probe", "rp_tune_forward", "rp_forward_tuning", "rp_install_forward_tuning", "rp_clear_forward_tuning",
 ]
 # the measurement build (-DRP_MEASUREMENT) adds the knobs of include/rectipy_hip.h's RP_MEASUREMENT section

@@ -819,11 +819,24 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
         za = zb;
         zb = tmp;
     }
-    if (sym) {  // the caller sees a full P again: off-diagonal blocks copied to their transposed positions
+    if (sym && !r->defer_mirror) {  // the caller sees a full P again: off-diagonal blocks copied to their transposed positions
         const int nbm = (r->n_in + 1023) / 1024;
         if (nbm > 1)
             hipLaunchKernelGGL(rls_mirror_kernel, dim3(nbm * (nbm - 1) / 2, 256), dim3(kThreads), 0, st, r->P, r->ldp, r->n_in);
     }
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
+extern "C" int rp_rls_mirror(const rp_rls* r, void* stream) {
+    if (!r || !r->P) RP_FAIL(RP_ERR_ARG, "rls / P is null");
+    if (r->n_in <= 0 || r->ldp < r->n_in) RP_FAIL(RP_ERR_SHAPE, "n_in > 0 and ldp >= n_in required");
+    if (r->n_in % 4 != 0 || r->ldp % 4 != 0 || (reinterpret_cast<uintptr_t>(r->P) & 15u))
+        RP_FAIL(RP_ERR_ARG, "rp_rls_mirror needs n_in %% 4 == 0, ldp %% 4 == 0 and a 16-byte aligned P");
+    const int nbm = (r->n_in + 1023) / 1024;
+    if (nbm > 1)
+        hipLaunchKernelGGL(rls_mirror_kernel, dim3(nbm * (nbm - 1) / 2, 256), dim3(kThreads), 0, static_cast<hipStream_t>(stream),
+                           r->P, r->ldp, r->n_in);
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;
 }

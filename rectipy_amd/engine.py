@@ -177,6 +177,10 @@ class HipBackend:
             self._check(self.lib.rp_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss,
                                                       self._stream(device)))
 
+    def rls_mirror(self, rls, device):
+        with self._on(device):
+            self._check(self.lib.rp_rls_mirror(C.byref(rls), self._stream(device)))
+
     def partial_rows(self, n):
         return int(self.lib.rp_bwd_partial_rows(n))
 

@@ -28,7 +28,9 @@ class RLS(Linear):
         super().__init__(n_in, n_out, weights=weights, dtype=torch.float32, detach=True)
         self.train_params = []
         self.beta = beta ** (-1)  # the reference stores the inverse forgetting rate (edges.py:220)
-        self.P = alpha * torch.eye(n_in, dtype=torch.float32)
+        self._P = alpha * torch.eye(n_in, dtype=torch.float32)
+        self._upper_only = False     # a symmetric sweep left the blocks below the diagonal stale (mirrored on the next read of P)
+        self._P_symmetric = True     # P is symmetric up to rounding (alpha * I and whatever the sweeps made of it); None: unchecked
         self.loss = 0.0
         self._backend = backend
         self._scratch = None
@@ -44,9 +46,34 @@ class RLS(Linear):
     SYMMETRIC_MIN_UPDATES = 4
     TILED_MIN_N = 8192  # measured (scripts/bench_rls.py, ms per update tiled / row-per-wave): n_in = 8192 0.108 / 0.113, 16384 0.386 / 0.401, 32768 1.43 / 1.68
 
+    @property
+    def P(self) -> torch.Tensor:
+        """The state-error correlation matrix (reference edges.py:216).  The symmetric pass keeps only the 1024 x 1024 blocks
+        on and above the diagonal up to date between sweeps; the blocks below are restored here, on the first read after
+        such a sweep (one copy pass over half of P -- 0.78 ms at n_in = 32768 -- paid by whoever looks at P, not by every
+        sweep)."""
+        if self._upper_only:
+            r = _abi.RpRls()
+            r.n_in, r.ldp, r.P = self.n_in, self._P.stride(0), self._P.data_ptr()
+            self._backend.rls_mirror(r, self._P.device)
+            self._upper_only = False
+        return self._P
+
+    @P.setter
+    def P(self, value: torch.Tensor):
+        """A matrix assigned from outside is taken as it is.  The symmetric pass treats the blocks on and above the diagonal
+        as authoritative, so it is only used on a P that is symmetric (up to the rounding the dense passes leave): that is
+        checked once, at the next sweep that would take the symmetric pass (one comparison pass over P); an asymmetric P
+        keeps the dense passes, which follow the reference's arithmetic on every element."""
+        self._P = value
+        self._upper_only = False
+        self._P_symmetric = None  # unknown
+
     def to(self, device: str, **kwargs):
         self.weights = self.weights.detach().to(device).contiguous()
+        sym = self._P_symmetric
         self.P = self.P.to(device).contiguous()
+        self._P_symmetric = sym
         self._scratch = None
         return self
 
@@ -93,8 +120,8 @@ class RLS(Linear):
         z, zn, scratch = self._scratch
         r = _abi.RpRls()
         r.n_in, r.n_out = self.n_in, self.n_out
-        r.ldp, r.ldw = self.P.stride(0), self.weights.stride(0)
-        r.P, r.W = self.P.data_ptr(), self.weights.data_ptr()
+        r.ldp, r.ldw = self._P.stride(0), self.weights.stride(0)
+        r.P, r.W = self._P.data_ptr(), self.weights.data_ptr()
         r.beta_inv = float(self.beta)
         r.z, r.zn, r.scratch = z.data_ptr(), zn.data_ptr(), scratch.data_ptr()
         r.partials = None if self._partials is None else self._partials.data_ptr()
@@ -102,15 +129,25 @@ class RLS(Linear):
         use_sym = self._partials is not None and (
             self.symmetric is True or (self.symmetric is None and self.n_in >= self.SYMMETRIC_MIN_N
                                        and updates >= self.SYMMETRIC_MIN_UPDATES))
+        if use_sym and self._P_symmetric is None:
+            # a P assigned from outside: symmetric up to rounding (as the dense passes leave it: (k z_i) z_j and (k z_j) z_i
+            # differ in the last bit)?  Then the half on and above the diagonal may stand for all of it.
+            scale = float(self._P.abs().max())
+            self._P_symmetric = bool(torch.allclose(self._P, self._P.T, rtol=1e-4, atol=1e-6 * scale))
+        use_sym = use_sym and bool(self._P_symmetric)
+        if self._upper_only and not use_sym:
+            self.P  # (a dense pass reads all of P: restore the lower blocks first)
         if use_sym:
             rows = self.SYMMETRIC_ROWS
-            if self._colparts is None or self._colparts.shape[0] != (self.n_in + rows - 1) // rows + (self.n_in + 1023) // 1024:
-                # column partials per chunk of `rows` rows, then one column sum per 1024-row block row
-                self._colparts = torch.zeros((self.n_in + rows - 1) // rows + (self.n_in + 1023) // 1024, self.n_in,
-                                             dtype=torch.float32, device=dev)
+            chunks = (self.n_in + rows - 1) // rows
+            if self._colparts is None or self._colparts.shape[0] != chunks:
+                # column partials per chunk of `rows` rows (their sums per block row live in the z' kernel's LDS)
+                self._colparts = torch.zeros(chunks, self.n_in, dtype=torch.float32, device=dev)
             r.colparts, r.ldc, r.sym_rows = self._colparts.data_ptr(), self._colparts.stride(0), rows
+            r.defer_mirror = 1
         self._backend.rls_sweep(r, T, int(stride), X.data_ptr(), X.stride(0) if T > 1 else self.n_in, Y.data_ptr(),
                                 Y.stride(0) if T > 1 else self.n_out, pred.data_ptr(), self.n_out, loss.data_ptr(), dev)
+        self._upper_only = bool(use_sym)
         self.loss = loss[-1]
         return pred, loss
 

@@ -212,3 +212,61 @@ def test_g34_fit_rls_n8200_default_symmetric_pass_matches_reference(target):
     assert np.abs(obs.to_numpy("out") - g["pred_f64"]).max() < 1.5e-4
     assert np.abs(obs.to_numpy("loss") - g["loss_f64"]).max() < 2e-5 * max(1.0, g["loss_f64"].max())
     assert np.abs(net.state["rnn"].cpu().numpy() - g["state_f64"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_mirror_is_deferred_until_P_is_read_and_asymmetric_P_keeps_the_dense_pass(target):
+    """The symmetric pass leaves the blocks below the diagonal stale (rp_rls.defer_mirror) and `RLS.P` restores them on the
+    first read: sweeps back to back -- nothing reads P in between -- give the bits of sweeps with a read in between.  A P
+    assigned from outside that is NOT symmetric is not handed to the symmetric pass (its lower blocks would be ignored and
+    overwritten): such an edge keeps the dense passes and equals an edge forced onto them."""
+    dev, backend = target["device"], target["backend"]
+    n, k, T = 2060, 2, 12
+    gen = torch.Generator().manual_seed(3)
+    X, Y = torch.randn(T, n, generator=gen).to(dev), torch.randn(T, k, generator=gen).to(dev)
+    W0 = torch.randn(k, n, generator=gen) * 0.1
+
+    def make(**kw):
+        e = RLS(n, k, weights=W0.clone(), beta=0.98, alpha=1.3, backend=backend).to(dev)
+        for name, v in kw.items():
+            setattr(e, name, v)
+        return e
+
+    a, b = make(tiled=True, symmetric=True), make(tiled=True, symmetric=True)
+    a.sweep(X[:6], Y[:6], 1)
+    assert a._upper_only                      # the mirror has not run ...
+    a.sweep(X[6:], Y[6:], 1)
+    b.sweep(X[:6], Y[:6], 1)
+    Pb = b.P                                  # ... here it has (a read in between)
+    assert not b._upper_only and Pb is b.P
+    b.sweep(X[6:], Y[6:], 1)
+    assert torch.equal(a.P, b.P) and torch.equal(a.weights, b.weights) and not a._upper_only
+    blk = torch.arange(n) // 1024
+    off = (blk[:, None] != blk[None, :]).to(dev)
+    assert torch.equal(a.P[off], a.P.T[off])
+    # a dense pass after a symmetric one reads ALL of P: the mirror runs first
+    c, d = make(tiled=True, symmetric=True), make(tiled=True, symmetric=True)
+    c.sweep(X[:6], Y[:6], 1)
+    c.symmetric = False
+    c.sweep(X[6:], Y[6:], 1)
+    d.sweep(X[:6], Y[:6], 1)
+    d.P
+    d.symmetric = False
+    d.sweep(X[6:], Y[6:], 1)
+    assert torch.equal(c.P, d.P)
+    # an asymmetric P from outside
+    P0 = torch.eye(n) * 1.3
+    P0[5, 1500] = 0.25                        # (only one of the two mirror positions)
+    e, f = make(tiled=True, symmetric=None), make(tiled=True, symmetric=False)
+    e.SYMMETRIC_MIN_N, e.SYMMETRIC_MIN_UPDATES = 0, 1   # by size this edge would take the symmetric pass
+    e.P, f.P = P0.clone().to(dev), P0.clone().to(dev)
+    e.sweep(X, Y, 1)
+    f.sweep(X, Y, 1)
+    assert e._P_symmetric is False and not e._upper_only
+    assert torch.equal(e.P, f.P) and torch.equal(e.weights, f.weights)
+    # ... and a symmetric one from outside is accepted
+    g_ = make(tiled=True, symmetric=None)
+    g_.SYMMETRIC_MIN_N, g_.SYMMETRIC_MIN_UPDATES = 0, 1
+    g_.P = (torch.eye(n) * 1.3).to(dev)
+    g_.sweep(X, Y, 1)
+    assert g_._P_symmetric is True and g_._upper_only
