@@ -397,12 +397,24 @@ typedef struct rp_comm {
        step s-1 have landed in this rank's current buffer, and the peer is done reading the buffer this rank is about to
        push into.  Summation order untouched: results equal the RCCL / host-loop exchange bit for bit.  `seq` is the
        number of steps exchanged so far on these buffers (in/out; flags must be zero while seq is 0).
-       comm / all_gather may be NULL in this mode; rp_backward_sharded still needs them. */
+       comm / all_gather may be NULL in this mode; rp_backward_sharded needs them unless peer_inbox is given (below). */
     int32_t mode;                 /* RP_COMM_RCCL (0) | RP_COMM_DIRECT (1)                                          */
     uint32_t seq;                 /* [host, in/out]                                                                 */
     float* const* peer_src;       /* [2 * world] (host array): peer p's source buffer k at [2 p + k]; own entries = net->src[k] */
     uint32_t* const* peer_flags;  /* [world] (host array): peer p's flag array (world words), mapped here; own entry = flags */
     uint32_t* flags;              /* this rank's flag array [world], slot q written by rank q                       */
+    /* RP_COMM_DIRECT, sharded adjoint (rp_backward_sharded): the cross-rank sum of the full-length partials W_p^T u_p
+       WITHOUT a collective and in a FIXED order.  Every rank owns an inbox of 2 x n floats (two parities x one slot of
+       `rows` floats per contributing rank), mapped by its peers.  Per adjoint step a rank pushes, for every owner q, the
+       slice [q rows, (q + 1) rows) of its partial into slot `rank` of q's inbox of the step's parity, signals with the next
+       sequence number (the same counter and flag array as the forward exchange), waits for every peer's signal and adds
+       the `world` slots of its own inbox in RANK ORDER 0, 1, ..., world - 1 (its own contribution straight from its
+       partial).  The sum is therefore the same from run to run and for every arrival order -- what an all-reduce does
+       not promise -- and the oracle mirrors it as `world` row chunks added in ascending order.  Two parities suffice:
+       a peer's signal of step s + 1 is enqueued behind its reduction of step s.  NULL: RP_COMM_DIRECT covers the forward
+       exchange only. */
+    float* const* peer_inbox;     /* [world] (host array): peer p's inbox, mapped here; own entry = inbox               */
+    float* inbox;                 /* this rank's inbox [2 x n]                                                        */
 } rp_comm;
 #define RP_COMM_RCCL 0
 #define RP_COMM_DIRECT 1

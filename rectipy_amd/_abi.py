@@ -238,6 +238,8 @@ class RpComm(C.Structure):
         ("peer_src", C.POINTER(C.c_void_p)),
         ("peer_flags", C.POINTER(C.c_void_p)),
         ("flags", C.c_void_p),
+        ("peer_inbox", C.POINTER(C.c_void_p)),
+        ("inbox", C.c_void_p),
     ]
 
 

@@ -960,10 +960,45 @@ int rp_bwd_apply(const rp_net* net, const rp_bwd* b, int32_t t, const float* z_l
     return RP_OK;
 }
 
+// RP_COMM_DIRECT: slice q of this rank's full-length partial goes into slot `rank` of owner q's inbox (peer memory mapped
+// through hipIpc; blockIdx.y = peer), 16 bytes per lane.
+struct ContribPush {
+    const float* z_full;
+    float* dst[63];   // peer q's inbox slot of this rank and parity
+    int owner[63];    // q
+    int quads, rows;
+};
+__global__ __launch_bounds__(256) void push_contrib_kernel(const ContribPush Q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < Q.quads)
+        reinterpret_cast<rp_f4*>(Q.dst[blockIdx.y])[i] =
+            reinterpret_cast<const rp_f4*>(Q.z_full + (int64_t)Q.owner[blockIdx.y] * Q.rows)[i];
+}
+
+// z_local[j] = the world contributions to neuron j of this rank added in rank order 0, 1, ..., world - 1 (the rank's own
+// one read from its partial): the fixed cross-rank summation order of the direct sharded adjoint
+__global__ __launch_bounds__(256) void reduce_contrib_kernel(const float* inbox, const float* own, float* z_local, int rows,
+                                                            int world, int rank) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= rows) return;
+    float s = rank == 0 ? own[j] : inbox[j];
+    for (int p = 1; p < world; ++p) s = s + (p == rank ? own[j] : inbox[(int64_t)p * rows + j]);
+    z_local[j] = s;
+}
+
 int rp_backward_sharded(const rp_net* net, const rp_bwd* b, const rp_comm* comm, void* stream) {
     typedef int (*reduce_scatter_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
     if (!net || !b || !comm) RP_FAIL(RP_ERR_ARG, "net/bwd/comm is null");
-    if (!comm->comm || !comm->reduce_scatter || !comm->work)
+    const bool direct = comm->mode == RP_COMM_DIRECT && comm->peer_inbox;
+    if (direct) {
+        if (!comm->work || !comm->inbox || !comm->peer_flags || !comm->flags)
+            RP_FAIL(RP_ERR_ARG, "the direct sharded adjoint needs work (n + rows floats), inbox, peer_flags and flags");
+        if (comm->world > 64 || net->rows % 4 != 0) RP_FAIL(RP_ERR_ARG, "the direct sharded adjoint: at most 64 ranks, rows %% 4 == 0");
+        for (int p = 0; p < comm->world; ++p)
+            if (!comm->peer_inbox[p] || !comm->peer_flags[p]) RP_FAIL(RP_ERR_ARG, "the direct sharded adjoint: peer %d has a null buffer", p);
+        if (comm->rank >= 0 && comm->rank < comm->world && comm->peer_inbox[comm->rank] != comm->inbox)
+            RP_FAIL(RP_ERR_ARG, "the direct sharded adjoint: this rank's entry of peer_inbox must be its own inbox");
+    } else if (!comm->comm || !comm->reduce_scatter || !comm->work)
         RP_FAIL(RP_ERR_ARG, "rp_comm needs comm, reduce_scatter and work (n + rows floats)");
     if (comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world ||
         (int64_t)net->rows * comm->world != net->n || net->row0 != comm->rank * net->rows)
@@ -974,16 +1009,43 @@ int rp_backward_sharded(const rp_net* net, const rp_bwd* b, const rp_comm* comm,
     float* z_local = comm->work + net->n;
     int rc = rp_bwd_prepare(net, b, stream);
     if (rc != RP_OK) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     for (int t = b->steps - 1; t >= 0; --t) {
         rc = rp_bwd_partial(net, b, t, z_full, stream);
         if (rc != RP_OK) return rc;
-        const int nrc = reinterpret_cast<reduce_scatter_fn>(comm->reduce_scatter)(
-            z_full, z_local, (size_t)net->rows, 7 /* ncclFloat32 */, 0 /* ncclSum */, comm->comm,
-            static_cast<hipStream_t>(stream));
-        if (nrc != 0) RP_FAIL(RP_ERR_COMM, "ncclReduceScatter returned %d at step %d", nrc, t);
+        if (direct) {
+            rp_comm* c = const_cast<rp_comm*>(comm);
+            const int parity = (int)(c->seq & 1u);  // alternates with every exchange on these buffers
+            ContribPush Q = {};
+            Q.z_full = z_full;
+            Q.rows = net->rows;
+            Q.quads = net->rows / 4;
+            int peers = 0;
+            for (int q = 0; q < comm->world; ++q)
+                if (q != comm->rank) {
+                    Q.dst[peers] = comm->peer_inbox[q] + (int64_t)parity * net->n + (int64_t)comm->rank * net->rows;
+                    Q.owner[peers++] = q;
+                }
+            if (peers > 0)
+                hipLaunchKernelGGL(push_contrib_kernel, dim3((Q.quads + 255) / 256, peers), dim3(256), 0, st, Q);
+            c->seq += 1;
+            for (int q = 0; q < comm->world; ++q)
+                if (q != comm->rank) RP_HIP_CHECK(hipStreamWriteValue32(st, comm->peer_flags[q] + comm->rank, c->seq, 0));
+            for (int q = 0; q < comm->world; ++q)  // every peer's contribution of this step has landed in the inbox
+                if (q != comm->rank)
+                    RP_HIP_CHECK(hipStreamWaitValue32(st, comm->flags + q, c->seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+            hipLaunchKernelGGL(reduce_contrib_kernel, dim3((net->rows + 255) / 256), dim3(256), 0, st,
+                               comm->inbox + (int64_t)parity * net->n, z_full + (int64_t)comm->rank * net->rows, z_local,
+                               net->rows, comm->world, comm->rank);
+        } else {
+            const int nrc = reinterpret_cast<reduce_scatter_fn>(comm->reduce_scatter)(
+                z_full, z_local, (size_t)net->rows, 7 /* ncclFloat32 */, 0 /* ncclSum */, comm->comm, st);
+            if (nrc != 0) RP_FAIL(RP_ERR_COMM, "ncclReduceScatter returned %d at step %d", nrc, t);
+        }
         rc = rp_bwd_apply(net, b, t, z_local, stream);
         if (rc != RP_OK) return rc;
     }
+    RP_HIP_CHECK(hipGetLastError());
     return RP_OK;
 }
 

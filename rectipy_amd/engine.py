@@ -568,7 +568,7 @@ class Population:
                  grad_tau=None, grad_k=None, grad_eta=None, grad_x=None, lam_s=None, grad_tau_s=None,
                  slope: float = 0.5, x: Optional[torch.Tensor] = None, x_target: int = _abi.RP_XT_MEMBRANE,
                  traj_aux=None, lam_x=None, grad_params: Optional[Dict[str, torch.Tensor]] = None,
-                 traj_aux2=None, lam_x2=None, exchange=None):
+                 traj_aux2=None, lam_x2=None, exchange=None, _args_only: bool = False):
         """Adjoint sweep over a stored window (rp_rate_backward; rp_qif_backward for the spiking models, which
         additionally take the adjoint of s, the surrogate slope and the window's input for grad_tau).
 
@@ -636,6 +636,8 @@ class Population:
                 b.x, b.ldx = x.data_ptr(), x.shape[1]
                 keep.append(x)
         net = self._net()
+        if _args_only:
+            return net, b, keep
         if not sharded:
             (self.backend.qif_backward if self.spiking else self.backend.rate_backward)(net, b, self.device)
             return keep
@@ -656,6 +658,11 @@ class Population:
             exchange.reduce_scatter(z_full, z_local)
             self.backend.bwd_apply(net, b, t, z_local.data_ptr(), self.device)
         return keep
+
+    def _backward_args(self, **kw):
+        """(rp_net, rp_bwd, tensors to keep alive) of an adjoint sweep -- the arguments :meth:`backward` would hand to the
+        library -- for callers that drive the step-wise entry points themselves (sharded.simulate_sharded_backward)."""
+        return self.backward(_args_only=True, **kw)
 
     def outer_accum(self, alpha: float, A: torch.Tensor, B: torch.Tensor, Cmat: torch.Tensor):
         """Cmat += alpha * A^T @ B on the matrix cores (A, B: [T, n])."""

@@ -81,8 +81,10 @@ class DirectExchange:
     step a rank pushes its slice into its peers' buffers and the STREAMS signal / wait on per-step sequence numbers
     (hipStreamWriteValue32 / hipStreamWaitValue32) -- no collective launch and no spinning kernel.  Opt-in
     (``ShardedPopulation(..., exchange="direct")`` or RECTIPY_AMD_EXCHANGE=direct): it has been run with two processes
-    on ONE MI355X (tests/test_direct_exchange.py: bit-equal to the host-loop exchange), never over xGMI.  Forward only;
-    the sharded adjoint keeps the RCCL reduce-scatter.  Collective constructor: every rank of `group` calls it."""
+    on ONE MI355X (tests/test_direct_exchange.py: bit-equal to the host-loop exchange), never over xGMI.  Forward: the
+    all-gather of the source slices; adjoint (r04): every rank pushes the owners' slices of its full-length partial
+    W_p^T u_p into their inboxes and the owner adds them in RANK ORDER -- a cross-rank sum that is the same from run to run
+    (an all-reduce / reduce-scatter promises no order).  Collective constructor: every rank of `group` calls it."""
 
     def __init__(self, pop: Population, group=None):
         import ctypes as C
@@ -96,7 +98,8 @@ class DirectExchange:
         self._own, self._mapped = [], []
         handles = []
         with torch.cuda.device(dev):
-            for nbytes in (4 * n, 4 * n, 4 * max(world, 1)):
+            # two source buffers, the flag array, the inbox of the sharded adjoint (2 parities x n floats)
+            for nbytes in (4 * n, 4 * n, 4 * max(world, 1), 8 * n):
                 ptr, h = C.c_void_p(), C.create_string_buffer(64)
                 _lib.check(self.lib.rp_ipc_alloc(nbytes, C.byref(ptr), h))
                 self._own.append(ptr.value)
@@ -111,6 +114,7 @@ class DirectExchange:
         dist.all_gather_object(everyone, handles, group=group)
         self.peer_src = (C.c_void_p * (2 * world))()
         self.peer_flags = (C.c_void_p * world)()
+        self.peer_inbox = (C.c_void_p * world)()
         with torch.cuda.device(dev):
             for p in range(world):
                 if p == rank:
@@ -123,20 +127,44 @@ class DirectExchange:
                         ptrs.append(q.value)
                         self._mapped.append(q.value)
                 self.peer_src[2 * p], self.peer_src[2 * p + 1], self.peer_flags[p] = ptrs[0], ptrs[1], ptrs[2]
+                self.peer_inbox[p] = ptrs[3]
         comm = _abi.RpComm()
         comm.rank, comm.world, comm.mode, comm.seq = rank, world, _abi.RP_COMM_DIRECT, 0
         comm.peer_src = C.cast(self.peer_src, C.POINTER(C.c_void_p))
         comm.peer_flags = C.cast(self.peer_flags, C.POINTER(C.c_void_p))
         comm.flags = self._own[2]
+        comm.peer_inbox = C.cast(self.peer_inbox, C.POINTER(C.c_void_p))
+        comm.inbox = self._own[3]
         self.comm = comm
+        # the own allocations are released when this object -- and with it every tensor that wraps them -- is gone
+        import weakref
+        self._finalizer = weakref.finalize(self, _release_ipc, self.lib, self._own, self._mapped)
         dist.barrier(group=group)  # nobody pushes before everybody has mapped
 
     def close(self):
-        """Unmap the peers' buffers (the own allocations stay alive with the tensors that wrap them)."""
+        """Unmap the peers' buffers (collective by convention: call it on every rank once nobody pushes any more).  The own
+        allocations stay alive with the tensors that wrap them and are freed when those are gone.
+
+        The protocol has no time-out: a rank that dies in the middle of a run leaves its peers' streams waiting for a
+        sequence number that never comes (hipStreamWaitValue32 has no deadline); the launcher ends the job, as it does for
+        a rank lost inside an RCCL collective."""
+        from . import _lib
         torch.cuda.synchronize()
-        for q in self._mapped:
-            self.lib.rp_ipc_close(q)
-        self._mapped = []
+        mapped, self._mapped[:] = list(self._mapped), []
+        for q in mapped:
+            _lib.check(self.lib.rp_ipc_close(q), self.lib)
+
+
+def _release_ipc(lib, own, mapped):
+    """Finalizer of a DirectExchange: unmap what is still mapped, free the own allocations (errors are not raised from a
+    finalizer: the process is usually shutting down)."""
+    try:
+        for q in list(mapped):
+            lib.rp_ipc_close(q)
+        for ptr in own:
+            lib.rp_ipc_free(ptr)
+    except Exception:
+        pass
 
 
 def _wrap_device_floats(ptr: int, count: int, device, owner) -> torch.Tensor:
@@ -236,6 +264,40 @@ class ShardedPopulation:
             full = self.pop.source  # the buffer the kernel just wrote this rank's slice into
             dist.all_gather_into_tensor(full, full[self.row0:self.row0 + self.rows], group=self.group)
         return idx
+
+    def backward(self, traj_v, traj_r, grad_out, grad_var, lam, u_traj, **kw):
+        """Adjoint sweep over a stored window of this rank's shard (arguments of :meth:`Population.backward`, all local):
+        per step the full-length partial W_p^T u_p, its cross-rank sum -- RCCL reduce-scatter enqueued in-library, the
+        direct exchange's rank-ordered sum (``exchange="direct"``), or the host loop -- and the local update."""
+        return self.pop.backward(traj_v, traj_r, grad_out, grad_var, lam, u_traj, exchange=_Exchange(self), **kw)
+
+
+def simulate_sharded_backward(shards: list, windows: list) -> None:
+    """The sharded adjoint sweep of `len(shards)` row shards of ONE population evaluated in ONE process: per step every
+    shard's full-length partial W_p^T u_p (rp_bwd_partial), the partials' slices added in RANK ORDER 0, 1, ... (the fixed
+    cross-rank order of the direct exchange and of the host loop, rp_comm.peer_inbox), the owners' local updates
+    (rp_bwd_apply).  `shards`: the ranks' :class:`Population` objects in rank order; `windows`: per rank the keyword
+    arguments of :meth:`Population.backward` (local trajectories, adjoint state and gradient buffers, updated in place).
+    This is the mirror the multi-process runs are compared with (tests: on the oracle backend)."""
+    world = len(shards)
+    n, rows = shards[0].n, shards[0].rows
+    dev = shards[0].device
+    T = int(windows[0]["traj_v"].shape[0])
+
+    z_full = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(world)]
+    # Population.backward drives the whole sweep of ONE rank; here the ranks advance in lock step, so the sweep is
+    # restated with the step-wise entry points
+    prepared = [pop._backward_args(**kw) for pop, kw in zip(shards, windows)]
+    for pop, (net, b, keep) in zip(shards, prepared):
+        pop.backend.bwd_prepare(net, b, pop.device)
+    for t in range(T - 1, -1, -1):
+        for p, (pop, (net, b, keep)) in enumerate(zip(shards, prepared)):
+            pop.backend.bwd_partial(net, b, t, z_full[p].data_ptr(), pop.device)
+        for q, (pop, (net, b, keep)) in enumerate(zip(shards, prepared)):
+            total = z_full[0][q * rows:(q + 1) * rows].clone()
+            for p in range(1, world):
+                total = total + z_full[p][q * rows:(q + 1) * rows]
+            pop.backend.bwd_apply(net, b, t, total.contiguous().data_ptr(), pop.device)
 
 
 def check_inlib_exchange(pop: Population, holder, steps: int, group) -> bool:
@@ -395,11 +457,26 @@ class _Exchange:
     def reduce_scatter(self, z_full, z_local):
         if self.nccl:
             dist.reduce_scatter_tensor(z_local, z_full, group=self.group)
-        else:  # gloo has no reduce-scatter: all-reduce, then keep this rank's slice
-            dist.all_reduce(z_full, group=self.group)
-            rows = z_local.numel()
-            r0 = dist.get_rank(self.group) * rows
-            z_local.copy_(z_full[r0:r0 + rows])
+            return
+        # host loop (gloo; CPU tests, GPU ranks around a CPU group): every rank's contribution to this rank's slice,
+        # added in RANK ORDER -- the fixed order of the direct exchange (include/rectipy_hip.h: rp_comm.peer_inbox), so
+        # that the host loop, the direct exchange and the oracle's mirror agree bit for bit
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        rows = z_local.numel()
+        send = [z_full[q * rows:(q + 1) * rows].detach().cpu().contiguous() for q in range(world)]
+        recv = [torch.empty(rows) for _ in range(world)]
+        dist.all_to_all(recv, send, group=self.group) if dist.get_backend(self.group) != "gloo" else self._gloo_all_to_all(recv, send)
+        total = recv[0]
+        for p in range(1, world):
+            total = total + recv[p]
+        z_local.copy_(total.to(z_local.device))
+
+    def _gloo_all_to_all(self, recv, send):
+        """gloo has no all_to_all for CPU tensors in every build: P gathers of one slice each."""
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        for q in range(world):
+            dist.gather(send[q], recv if q == rank else None, dst=dist.get_global_rank(self.group, q) if self.group else q,
+                        group=self.group)
 
 
 class _ShardedSpikeWindow(torch.autograd.Function):
@@ -487,8 +564,17 @@ class ShardedNetwork(Network):
     (reduce-scatter of the transposed product, one per step).
     """
 
-    def __init__(self, dt: float, device: str = "cuda:0", dtype: torch.dtype = torch.float32, backend=None, group=None):
+    def __init__(self, dt: float, device: str = "cuda:0", dtype: torch.dtype = torch.float32, backend=None, group=None,
+                 exchange: Optional[str] = None):
+        """``exchange``: None / "rccl" (RCCL collectives enqueued in-library; host loop for gloo groups) or "direct" (the
+        stream-ordered push exchange, :class:`DirectExchange`: all-gather of the source slices forward, rank-ordered sum of
+        the partials in the adjoint; one sharded population per network; also RECTIPY_AMD_EXCHANGE=direct)."""
+        import os
         super().__init__(dt, device=device, dtype=dtype, backend=backend)
+        self._exchange_mode = exchange or os.environ.get("RECTIPY_AMD_EXCHANGE", "rccl")
+        if self._exchange_mode not in ("rccl", "direct"):
+            raise ValueError(f"exchange must be 'rccl' or 'direct', got {self._exchange_mode!r}")
+        self.direct = None
         if not dist.is_initialized():
             raise RuntimeError("ShardedNetwork needs an initialised torch.distributed process group")
         self.group = group
@@ -513,7 +599,16 @@ class ShardedNetwork(Network):
         self._sharded[label] = (row0, rows, n)
         self._wrap(new, row0, rows)
         self._gather(new, row0, rows, clone=True)
-        if self.comm is None and not self._exchange_checked:
+        if self._exchange_mode == "direct":
+            if self.direct is not None:
+                raise NotImplementedError("the direct exchange serves ONE sharded population per network (its buffers "
+                                          "belong to the population)")
+            if not hasattr(new._pop.backend, "forward_sharded") or new._pop.device.type != "cuda":
+                raise RuntimeError("the direct exchange runs on the HIP backend only")
+            self.direct = DirectExchange(new._pop, self.group)
+            self.comm = self.direct.comm
+            self._exchange_checked = True
+        elif self.comm is None and not self._exchange_checked:
             self.comm = rccl_comm(self.group, new._pop.device, new._pop.backend)
             check_inlib_exchange(new._pop, self, 3, self.group)  # one-time guard; drops to the host loop on disagreement
             self._exchange_checked = True

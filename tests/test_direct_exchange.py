@@ -66,7 +66,7 @@ def test_comm_struct_carries_the_direct_mode_fields():
     from rectipy_amd import _abi, _lib
     lib = _lib.load()
     assert lib.rp_sizeof_comm() == C.sizeof(_abi.RpComm)
-    assert [f[0] for f in _abi.RpComm._fields_][-5:] == ["mode", "seq", "peer_src", "peer_flags", "flags"]
+    assert [f[0] for f in _abi.RpComm._fields_][-7:] == ["mode", "seq", "peer_src", "peer_flags", "flags", "peer_inbox", "inbox"]
     assert _abi.RP_COMM_RCCL == 0 and _abi.RP_COMM_DIRECT == 1
     # argument checks that need no GPU
     assert lib.rp_ipc_alloc(0, None, None) == _abi.RP_ERR_ARG
