@@ -269,6 +269,12 @@ def main():
     finite = bool(torch.isfinite(pop.v).all().item())
     streaming = pop.backend.forward_tuning(pop._net())
 
+    sharded_bwd = None
+    if use_dist and "--exchange" in sys.argv:
+        try:
+            sharded_bwd = sharded_fwd_bwd_leg(sp, x, world, rank, dev)
+        except Exception as e:  # (reported, never fatal: the forward line above is the contract)
+            sharded_bwd = {"error": f"{type(e).__name__}: {e}"}
     config5 = None
     if use_dist and args.config5_neurons > 0:
         sp = pop = samples = None  # release the strong-scaling shard first
@@ -322,6 +328,8 @@ def main():
                                    "step kernel PLUS the in-stream all-gather; achieved/frac therefore understate the kernel")
     if config5 is not None:
         out.setdefault("extra", {})["config5"] = config5
+    if sharded_bwd is not None:
+        out.setdefault("extra", {})["sharded_fwd_bwd"] = sharded_bwd
     cpu_threads = None
     if world == 1 and not use_dist and not args.no_cpu_baseline:
         out["cpu_baseline"], cpu_threads = cpu_baseline(pop, x, dt, N)
@@ -902,6 +910,50 @@ def ridge_extra(net, x, N, dev, T=2000, sampling=10, k=3):
                           # torch.linalg.solve of a process creates its rocSOLVER / hipBLAS handles)
                           "one_time_setup_in_the_first_call": wall * 1e3 - (t5 - t1) * 1e3},
             "w_out_finite": bool(torch.isfinite(w).all().item()) and bool(torch.isfinite(y).all().item())}
+
+
+def sharded_fwd_bwd_leg(sp, x, world, rank, dev, T=50):
+    """fwd+bwd of the row-sharded network (BASELINE configs[2] shape per shard) through the exchange in use: forward window
+    with the per-step all-gather, adjoint sweep with the per-step cross-rank sum of W_p^T u_p (RCCL reduce-scatter, or the
+    direct exchange's rank-ordered sum), dW_p = dt U_p^T R as one rectangular MFMA GEMM per rank.  Collective.  Runs only
+    when --exchange was given explicitly (the driver's default command line does not pay for it)."""
+    import torch.distributed as dist
+    from rectipy_amd import _abi
+    pop = sp.pop
+    rows, n = pop.rows, pop.n
+    z = lambda *shape: torch.zeros(*shape, device=dev)
+    saved_v, saved_r, full = z(T, rows), z(T, rows), z(T, n)
+    g_out = torch.randn(T, rows, device=dev, generator=torch.Generator(device=dev).manual_seed(11 + rank)) * 1e-3
+    lam, u = z(rows), z(T, rows)
+
+    def window():
+        lam.zero_()
+        sp.pop.forward(T, x=x[:T], save_v=saved_v, save_src=saved_r, save_src_full=full, comm=sp.comm) if sp.comm is not None \
+            else sp.forward(T, x=x[:T])
+        keep = sp.backward(saved_v, saved_r, g_out, _abi.RP_OUT_STATE0, lam, u)
+        gW = torch.empty(rows, n, device=dev)
+        pop.backend.outer_store_rect(rows, n, T, float(pop.dt), u.data_ptr(), rows, full.data_ptr(), n, gW.data_ptr(), n, dev)
+        return keep, gW
+
+    if sp.comm is None:
+        return None if rank else {"skipped": "no in-library exchange on this run (host loop): not timed"}
+    window()
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    keep, gW = window()
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    wall = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+    finite = torch.tensor([int(torch.isfinite(lam).all().item() and torch.isfinite(gW).all().item())], device=dev)
+    dist.all_reduce(finite, op=dist.ReduceOp.MIN)
+    del keep, gW
+    if rank:
+        return None
+    wall = float(wall.item())
+    return {"workload": f"fwd+bwd window of {T} steps, N={n} row-sharded x{world}, incl. the shard's dW GEMM",
+            "fwd_bwd_steps_per_s": T / wall, "ms_per_step_pair": wall / T * 1e3,
+            "cross_rank_sum": "direct exchange: partials added in rank order (deterministic)" if sp.direct is not None
+            else "RCCL reduce-scatter enqueued in-library", "grad_finite": bool(finite.item())}
 
 
 def config5_leg(n5, steps, world, rank, dev, dt):
