@@ -233,7 +233,10 @@ __global__ __launch_bounds__(kThreads) void outer_accum_dma_kernel(int m, int n,
     issue(0);
     if (slices > 1) issue(1);
     for (int s = 0; s < slices; ++s) {
-        if (s + 1 < slices) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // slice s has landed; s+1 may be in flight
+        // slice s has landed; the four DMA loads of slice s+1 may stay in flight -- IF slice s+1 came by DMA: a ragged
+        // last slice goes through registers (a wave whose rows lie past T issues no load for it at all), so the count of
+        // four would then cover slice s's own loads
+        if (s + 1 < slices && (s + 2) * BK <= T) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // everyone's pieces of slice s are in; everyone is done with slice s-1's stage
         __builtin_amdgcn_sched_barrier(0);

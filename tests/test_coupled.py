@@ -398,3 +398,66 @@ def test_matrices_move_into_one_allocation_and_stay_live(hip_device, monkeypatch
     a = net.run(x, verbose=False, enable_grad=False).to_numpy("out")
     b = ref.run(x, verbose=False, enable_grad=False).to_numpy("out")
     assert np.array_equal(a, b) and net._arena is arena  # (nothing to consolidate the second time)
+
+
+# ---- against the reference itself (golden G36) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_g36_feedback_network_at_kernel_sizes_matches_the_reference(target, monkeypatch):
+    """Golden G36 (tests/golden/make_golden_feedback_large.py): the reference's FeedbackNetwork.run with populations of 260
+    and 516 rate neurons (a -> b, feedback b -> a) and a QIF pair of 260 + 260 with inhibitory feedback -- the sizes at which
+    the coupled step kernel walks full 256-column chunks plus a ragged one in the recurrent AND the edge matrices.  One
+    library call per window (two with spiking members).  Tolerances: a few times the reference's own float32-vs-float64
+    deviation (1.2e-6 rate, 1.9e-6 QIF, printed by the generator)."""
+    import os
+    import sys
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    import recipes
+    g = dict(np.load(os.path.join(gold, "g36_feedback_large.npz")))
+    calls = []
+    real = engine.forward_coupled
+    monkeypatch.setattr(engine, "forward_coupled", lambda members: calls.append(len(members)) or real(members))
+    edge = lambda rows, cols, seed, gain: (recipes.normal((rows, cols), seed) * np.float32(gain / np.sqrt(cols))).astype(np.float32)
+    na, nb, T, dt = int(g["na"]), int(g["nb"]), int(g["T"]), float(g["dt"])
+    Pa = recipes.li_network(na, seed=3601, g=0.9, defaults=False)
+    Pb = recipes.li_network(nb, seed=3602, g=0.9, defaults=False)
+    W_ab, W_ba = edge(nb, na, 3603, 0.6), edge(na, nb, 3604, 0.6)
+    x = (0.5 * recipes.normal((T, na), seed=3605)).astype(np.float32)
+    for name, arr in (("Wa", Pa["W"]), ("Wb", Pb["W"]), ("W_ab", W_ab), ("W_ba", W_ba), ("x", x)):
+        assert np.array_equal(recipes.fingerprint(arr), g["fp_" + name]), f"regenerated {name} differs from the generator's"
+    net = FeedbackNetwork(dt, **target)
+    for lab, P in (("a", Pa), ("b", Pb)):
+        net.add_diffeq_node(lab, TANH, weights=P["W"], source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                            output_var="li_op/v", dtype=torch.float32,
+                            node_vars={"all/li_op/tau": P["tau"], "all/li_op/k": P["k"], "all/li_op/eta": P["eta"], "all/li_op/v": P["y0"]})
+    net.add_edge("a", "b", weights=W_ab)
+    net.add_edge("b", "a", weights=W_ba, feedback=True)
+    obs = net.run(x, sampling_steps=1, verbose=False, enable_grad=False)
+    assert calls == [2]
+    assert np.abs(obs.to_numpy("out") - g["rate_out_f64"]).max() < 6e-6
+    assert np.abs(net.state["a"].cpu().numpy() - g["rate_state_a_f64"]).max() < 6e-6
+    assert np.abs(net.state["b"].cpu().numpy() - g["rate_state_b_f64"]).max() < 6e-6
+    # QIF pair
+    nq, Tq, dtq = int(g["nq"]), int(g["Tq"]), float(g["dtq"])
+    Wq = [(recipes.uniform((nq, nq), 3610 + i) * np.float32(20.0 / nq)).astype(np.float32) for i in range(2)]
+    etaq = [(-5.0 + recipes.normal((nq,), 3612)).astype(np.float32), (12.0 + recipes.normal((nq,), 3613)).astype(np.float32)]
+    Wq_ab = (recipes.uniform((nq, nq), 3614) * np.float32(10.0 / nq)).astype(np.float32)
+    Wq_ba = (-recipes.uniform((nq, nq), 3615) * np.float32(10.0 / nq)).astype(np.float32)
+    for name, arr in (("Wq0", Wq[0]), ("Wq1", Wq[1]), ("etaq0", etaq[0]), ("etaq1", etaq[1]), ("Wq_ab", Wq_ab), ("Wq_ba", Wq_ba)):
+        assert np.array_equal(recipes.fingerprint(arr), g["fp_" + name]), f"regenerated {name} differs from the generator's"
+    assert float(g["qif_peak_f64"]) > 0.5, "the fixture must contain spikes"
+    calls.clear()
+    net = FeedbackNetwork(dtq, **target)
+    for lab, i in (("a", 0), ("b", 1)):
+        node = SpikeResetNet.from_pyrates(
+            QIF, input_var="qif_op/I_ext", output_var="qif_op/s", weights=Wq[i], source_var="qif_op/s", target_var="qif_op/s_in",
+            spike_var="qif_op/spike", reset_var="qif_op/v",
+            node_vars={"all/qif_op/eta": etaq[i], "all/qif_op/v": np.full(nq, -2.0), "all/qif_op/s": np.zeros(nq)},
+            spike_threshold=100.0, spike_reset=-100.0, dt=dtq, dtype=torch.float32, **target)
+        net.add_node(lab, node, node_type="diff_eq")
+    net.add_edge("a", "b", weights=Wq_ab)
+    net.add_edge("b", "a", weights=Wq_ba, feedback=True)
+    obs = net.run(np.full((Tq, nq), 15.0, dtype=np.float32), sampling_steps=1, verbose=False, enable_grad=False)
+    assert calls == [2, 2]
+    out = obs.to_numpy("out")
+    assert np.abs(out[::10] - g["qif_out_f64"]).max() < 5e-5 and np.abs(out[-1] - g["qif_final_f64"]).max() < 5e-5

@@ -169,7 +169,10 @@ def test_rate_backward_bit_exact(oracle_backend, hip_device, N, T, model, grad_v
 @pytest.mark.parametrize("N,T", [(48, 7), (128, 16), (200, 100), (260, 33),
                                  # full 128 x 128 tiles: the LDS-DMA ring kernel -- one slice, exactly three slices (the ring
                                  # depth), many slices + a ragged last one, a single ragged slice, T = 1
-                                 (256, 100), (384, 48), (128, 33), (640, 5), (256, 1), (128, 160)])
+                                 (256, 100), (384, 48), (128, 33), (640, 5), (256, 1), (128, 160),
+                                 # T % 16 == 1: the ragged slice holds ONE row, so three of the four waves issue no load for
+                                 # it (the counted wait in front of the slice before it must not rely on them)
+                                 (256, 17), (128, 49), (384, 161)])
 def test_outer_accum_bit_exact(oracle_backend, hip_device, N, T):
     """MFMA f32 dW GEMM == t-ordered fmaf chain of the oracle, bit for bit (incl. ragged tiles; both kernels: register-
     staged slices for ragged shapes, the LDS-DMA ring on full tiles)."""
