@@ -114,7 +114,7 @@ class RpRun(C.Structure):
         ("edge_n", C.c_int32 * RP_MAX_EDGES),
         ("edge_src", fp * RP_MAX_EDGES),
         ("edge_src_ld", C.c_int64 * RP_MAX_EDGES),
-        ("hist", fp * 2),
+        ("hist", fp * 3),
     ]
 
 

@@ -86,7 +86,9 @@ struct StepParams {
     // dense edges from other vectors into this population (rp_run.edge_*): the source vector of THIS step
     int n_edges;
     EdgeArg edge[RP_MAX_EDGES];
-    float* hist_t;  // optional: this step's pre-update output (rp_run.hist[t_abs & 1])
+    float* hist_t;     // optional: this step's pre-update output (rp_run.hist[t_abs % 3])
+    float* hist_next;  // optional (shared launch of rp_forward_coupled): the NEXT step's ring entry, i.e. this step's post-update output
+    int model, vec4;   // (read by the shared-launch kernel only: the member's model and row-dot path)
 };
 
 // ---- row dot products (rp_dot.h) ---------------------------------------------
@@ -199,6 +201,7 @@ __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum,
         v_new = v_new * (1.0f - spike) + spike * P.v_reset;
         P.y[RP_Y_V][i] = v_new;
         P.src_next[gi] = s_new;
+        if (P.hist_next) P.hist_next[i] = P.out_var == RP_OUT_STATE0 ? v_new : s_new;
         if constexpr (MODEL == RP_MODEL_QIF_SFA || MODEL >= RP_MODEL_IK) {
             P.y[RP_Y_AUX][i] = aux_new;
             if (P.save_state_t[RP_Y_AUX]) P.save_state_t[RP_Y_AUX][i] = aux;
@@ -232,6 +235,7 @@ __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum,
         const float r_new = activation<MODEL>(P, i, v_new);
         P.y[RP_Y_V][i] = v_new;
         P.src_next[gi] = r_new;
+        if (P.hist_next) P.hist_next[i] = P.out_var == RP_OUT_STATE0 ? v_new : r_new;
         if (P.save_state_t[0]) P.save_state_t[0][i] = v;
         if (P.save_src_t) P.save_src_t[i] = P.src_cur[gi];
         if (P.save_acc_t) P.save_acc_t[i] = wsum;
@@ -309,6 +313,81 @@ __global__ __launch_bounds__(kThreads) void step_edges_kernel(const StepParams P
                 mine_e = esum[j];
             }
         if (lane < R && row_base + lane < P.rows) epilogue<MODEL, true>(P, row_base + lane, mine, mine_e);
+    }
+}
+
+// ---- all members of a coupled circuit in ONE launch (rp_forward_coupled, launch-bound sizes) ---------------------------
+// At a few hundred to a few thousand neurons per population a step is bounded by the dependent-launch interval of the
+// stream, not by bytes: one launch per Euler step for the whole circuit instead of one per member.  Legal when every edge
+// reads a value from before the step (coupled_impl decides); state-variable outputs are then read from the members' hist
+// rings, never from a state vector this launch updates.  A workgroup belongs to one member (first_block); the member's
+// argument block is read in place, at a runtime offset into the kernel arguments.
+constexpr int kMergeMax = 4;
+struct MergedParams {
+    int count;
+    int first_block[kMergeMax + 1];
+    StepParams P[kMergeMax];
+};
+
+template <int MODEL, int R, int U>
+__device__ __forceinline__ void merged_rows(const StepParams& P, int block) {
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int wave = threadIdx.x >> 6;
+    const int groups = (P.rows + R - 1) / R;
+    const int g = block * kWavesPerBlock + wave;
+    if (g >= groups) return;
+    const int row_base = g * R;
+    float sum[R], esum[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) esum[j] = 0.f;
+    if (P.vec4)
+        rp_dot_rows_v4_ring<R, U, true>(dot_args(P), row_base, lane, sum);
+    else
+        dot_rows_s1<R>(P, row_base, lane, sum);
+    for (int e = 0; e < P.n_edges; ++e) {
+        // (field by field: a select between whole EdgeArg objects keeps the argument block in memory)
+#define RP_EDGE_FIELD(f) (e == 0 ? P.edge[0].f : (e == 1 ? P.edge[1].f : (e == 2 ? P.edge[2].f : P.edge[3].f)))
+        const float* eW = RP_EDGE_FIELD(W);
+        const float* eS = RP_EDGE_FIELD(src);
+        const int64_t eLd = RP_EDGE_FIELD(ld);
+        const int eN = RP_EDGE_FIELD(n), eV4 = RP_EDGE_FIELD(vec4);
+#undef RP_EDGE_FIELD
+        float es[R];
+        if (eV4)
+            rp_dot_rows_v4_ring<R, U, true>(RowDotArgs{eW, eLd, eN, P.rows, P.row0, eS}, row_base, lane, es);
+        else
+            rp_dot_rows_s1<R>(RowDotArgs{eW, eLd, eN, P.rows, P.row0, eS}, row_base, lane, es);
+#pragma unroll
+        for (int j = 0; j < R; ++j) esum[j] = e == 0 ? es[j] : esum[j] + es[j];
+    }
+    float mine = 0.f, mine_e = 0.f;
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+        if (lane == j) {
+            mine = sum[j];
+            mine_e = esum[j];
+        }
+    if (lane < R && row_base + lane < P.rows) epilogue<MODEL, true>(P, row_base + lane, mine, mine_e);
+}
+
+template <int R, int U>
+__global__ __launch_bounds__(kThreads) void step_merged_kernel(const MergedParams M) {
+    int m = 0;
+    while (m + 1 < M.count && (int)blockIdx.x >= M.first_block[m + 1]) ++m;
+    // the member's argument block, copied out of the kernel-argument segment (uniform address: scalar loads of the fields
+    // that are used; indexing the by-value argument M.P[m] with a runtime m would move all of M to scratch)
+    typedef const __attribute__((address_space(4))) char* karg_ptr;
+    StepParams P;
+    __builtin_memcpy(&P, (const void*)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MergedParams, P) +
+                                       (size_t)m * sizeof(StepParams)), sizeof(StepParams));
+    const int block = (int)blockIdx.x - M.first_block[m];
+    switch (P.model) {  // (population-mean models are never merged: they need their reduction launch in front)
+        case RP_MODEL_LI_TANH: merged_rows<RP_MODEL_LI_TANH, R, U>(P, block); break;
+        case RP_MODEL_LI_SIGMOID: merged_rows<RP_MODEL_LI_SIGMOID, R, U>(P, block); break;
+        case RP_MODEL_QIF: merged_rows<RP_MODEL_QIF, R, U>(P, block); break;
+        case RP_MODEL_QIF_SFA: merged_rows<RP_MODEL_QIF_SFA, R, U>(P, block); break;
+        case RP_MODEL_LIF: merged_rows<RP_MODEL_LIF, R, U>(P, block); break;
+        default: merged_rows<RP_MODEL_IK, R, U>(P, block); break;
     }
 }
 
@@ -655,6 +734,8 @@ void fill_static(StepParams& P, const rp_net* net) {
     P.sp_block_rows = net->sp_block_rows;
     P.sp_phases = net->sp_phases;
     P.sp_batches = net->sp_batches;
+    P.model = net->model;
+    P.vec4 = use_vec4(net) ? 1 : 0;
 }
 
 #ifdef RP_MEASUREMENT
@@ -958,8 +1039,10 @@ int check_run(const rp_net* net, const rp_run* run, bool coupled) {
                 RP_FAIL(RP_ERR_ARG, "edge %d: edge_src / edge_src_ld must be 16-byte aligned", e);
         }
     }
-    if ((run->hist[0] == nullptr) != (run->hist[1] == nullptr)) RP_FAIL(RP_ERR_ARG, "hist: both buffers or neither");
-    if (run->hist[0] && run->hist[0] == run->hist[1]) RP_FAIL(RP_ERR_ARG, "hist[0] and hist[1] must be distinct buffers");
+    if ((run->hist[0] == nullptr) != (run->hist[1] == nullptr) || (run->hist[0] == nullptr) != (run->hist[2] == nullptr))
+        RP_FAIL(RP_ERR_ARG, "hist: all three buffers or none");
+    if (run->hist[0] && (run->hist[0] == run->hist[1] || run->hist[0] == run->hist[2] || run->hist[1] == run->hist[2]))
+        RP_FAIL(RP_ERR_ARG, "the hist buffers must be distinct");
 
     // count the samples this call produces before touching anything
     int64_t produced = 0;
@@ -1001,7 +1084,8 @@ void set_step(StepParams& P, const rp_net* net, rp_run* run, int t) {
     P.src_next = net->src[net->cur ^ 1];
     P.x_t = run->x ? run->x + (int64_t)t * run->ldx : nullptr;
     P.traj_t = run->traj ? run->traj + (int64_t)t * run->ldtraj : nullptr;
-    P.hist_t = run->hist[0] ? run->hist[t_abs & 1] : nullptr;
+    P.hist_t = run->hist[0] ? run->hist[t_abs % 3] : nullptr;
+    P.hist_next = nullptr;
     for (int q = 0; q < RP_MAX_STATE; ++q)
         P.save_state_t[q] = run->save_state[q] ? run->save_state[q] + (int64_t)t * run->ldsave : nullptr;
     P.save_src_t = run->save_src ? run->save_src + (int64_t)t * run->ldsave : nullptr;
@@ -1168,17 +1252,11 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
                 RP_FAIL(RP_ERR_ARG, "member %d edge %d: source %d needs rp_run.hist", m, e, q);
             // every vector this edge can be pointed at
             const bool state_out = qrun->out_var == RP_OUT_STATE0;
-            const float* cand[2];
-            if (mode == RP_EDGE_LAG || (mode == RP_EDGE_OUT && state_out)) {
-                cand[0] = qrun->hist[0];
-                cand[1] = qrun->hist[1];
-            } else if (state_out) {
-                cand[0] = cand[1] = mem[q].net->y[RP_Y_V];
-            } else {
-                cand[0] = mem[q].net->src[0];
-                cand[1] = mem[q].net->src[1];
-            }
-            if (run->edge_n[e] % 4 == 0 && run->edge_ld[e] % 4 == 0 && (!aligned16(cand[0]) || !aligned16(cand[1])))
+            bool ok16 = true;
+            if (qrun->hist[0]) ok16 = aligned16(qrun->hist[0]) && aligned16(qrun->hist[1]) && aligned16(qrun->hist[2]);
+            ok16 = ok16 && aligned16(mem[q].net->y[RP_Y_V]) && aligned16(mem[q].net->src[0]) && aligned16(mem[q].net->src[1]);
+            (void)state_out;
+            if (run->edge_n[e] % 4 == 0 && run->edge_ld[e] % 4 == 0 && !ok16)
                 RP_FAIL(RP_ERR_ARG, "member %d edge %d: the source vectors must be 16-byte aligned", m, e);
         }
     }
@@ -1194,32 +1272,86 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
         vec4[m] = use_vec4(mem[m].net);
     }
     const int steps = mem[0].run->steps;
+
+    // One launch for all members per step?  Only values from BEFORE the step may be read: no RP_EDGE_LIVE edge from a
+    // member stepped earlier; state-variable outputs come from the hist ring (written one step ahead), so their owners
+    // need one; launch-bound sizes only (larger members want their own walk and lose nothing to the extra launches).
+    bool merged = count >= 2 && count <= kMergeMax && steps > 0;
+    int max_rows = 0;
+    for (int m = 0; m < count && merged; ++m) {
+        const rp_net* net = mem[m].net;
+        max_rows = std::max(max_rows, net->rows);
+        if (net->rows > 4096 || net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP) merged = false;
+        for (int e = 0; e < mem[m].run->n_edges && merged; ++e) {
+            const int q = mem[m].edge_source[e], mode = mem[m].edge_mode[e];
+            if (mode == RP_EDGE_LIVE && q < m) merged = false;
+            if (mode != RP_EDGE_LAG && mem[q].run->out_var == RP_OUT_STATE0 && !mem[q].run->hist[0]) merged = false;
+        }
+    }
+    if (const char* off = getenv("RECTIPY_AMD_COUPLED_LAUNCHES"); off && off[0] == 'm') merged = false;  // "member": one launch per member
+    if (merged) {
+        const int64_t a0 = mem[0].run->step0;
+        for (int m = 0; m < count; ++m) {  // ring entry of the first step: the member's current output
+            const rp_net* net = mem[m].net;
+            const rp_run* run = mem[m].run;
+            if (!run->hist[0]) continue;
+            const float* cur_out = run->out_var == RP_OUT_STATE0 ? net->y[RP_Y_V] : net->src[net->cur];
+            RP_HIP_CHECK(hipMemcpyAsync(run->hist[a0 % 3], cur_out, sizeof(float) * (size_t)net->rows, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    const int mR = max_rows <= 2048 ? 1 : 2;  // rows per wave (chunks in flight: 8, the whole row up to 2048 columns)
+
     for (int t = 0; t < steps; ++t) {
         const int64_t t_abs = mem[0].run->step0 + t;
         for (int m = 0; m < count; ++m) {
             rp_net* net = mem[m].net;
             rp_run* run = mem[m].run;
             set_step(P[m], net, run, t);
+            if (merged) {  // the ring is written one step ahead (post-update output); nothing reads this step's entry late
+                P[m].hist_t = nullptr;
+                P[m].hist_next = run->hist[0] ? run->hist[(t_abs + 1) % 3] : nullptr;
+            }
             for (int e = 0; e < run->n_edges; ++e) {
                 const int q = mem[m].edge_source[e];
                 const rp_net* qn = mem[q].net;
                 const rp_run* qr = mem[q].run;
+                const bool state_out = qr->out_var == RP_OUT_STATE0;
                 switch (mem[m].edge_mode[e]) {
-                    case RP_EDGE_LIVE:  // qn->cur names q's CURRENT source buffer: flipped already if q < m
-                        P[m].edge[e].src = qr->out_var == RP_OUT_STATE0 ? qn->y[RP_Y_V] : qn->src[qn->cur];
+                    case RP_EDGE_LIVE:  // qn->cur names q's CURRENT source buffer: flipped already if q < m (never when merged)
+                        P[m].edge[e].src = state_out ? (merged ? qr->hist[t_abs % 3] : qn->y[RP_Y_V]) : qn->src[qn->cur];
                         break;
-                    case RP_EDGE_OUT:   // q < m: its buffer of this step is the one it flipped away from
-                        P[m].edge[e].src = qr->out_var == RP_OUT_STATE0 ? qr->hist[t_abs & 1] : qn->src[qn->cur ^ 1];
+                    case RP_EDGE_OUT:   // q < m: its buffer of this step is the one it flipped away from (merged: not yet flipped)
+                        P[m].edge[e].src = state_out ? qr->hist[t_abs % 3] : qn->src[merged ? qn->cur : qn->cur ^ 1];
                         break;
                     default:            // RP_EDGE_LAG
-                        P[m].edge[e].src = qr->hist[(t_abs + 1) & 1];
+                        P[m].edge[e].src = qr->hist[(t_abs + 2) % 3];
                         break;
                 }
             }
-            const int rc = launch_population_step(net, P[m], st, cfg[m], vec4[m]);
-            if (rc != RP_OK) return rc;
+            if (!merged) {
+                const int rc = launch_population_step(net, P[m], st, cfg[m], vec4[m]);
+                if (rc != RP_OK) return rc;
+                if (t == 0) RP_HIP_CHECK(hipGetLastError());
+                net->cur ^= 1;
+            }
+        }
+        if (merged) {
+            MergedParams M = {};
+            M.count = count;
+            int blocks = 0;
+            for (int m = 0; m < count; ++m) {
+                M.first_block[m] = blocks;
+                M.P[m] = P[m];
+                const int groups = (mem[m].net->rows + mR - 1) / mR;
+                blocks += (groups + kWavesPerBlock - 1) / kWavesPerBlock;
+            }
+            M.first_block[count] = blocks;
+            if (mR == 1)
+                hipLaunchKernelGGL((step_merged_kernel<1, 8>), dim3(blocks), dim3(kThreads), 0, st, M);
+            else
+                hipLaunchKernelGGL((step_merged_kernel<2, 8>), dim3(blocks), dim3(kThreads), 0, st, M);
             if (t == 0) RP_HIP_CHECK(hipGetLastError());
-            net->cur ^= 1;
+            for (int m = 0; m < count; ++m) mem[m].net->cur ^= 1;
         }
     }
     RP_HIP_CHECK(hipGetLastError());

@@ -91,6 +91,66 @@ __device__ __forceinline__ void rp_dot_rows_v4(const RowDotArgs& P, int row_base
     for (int j = 0; j < R; ++j) sum[j] = rp_wave_allreduce(rp_lane_sum4(a[j]));
 }
 
+// The same dot products for SHORT rows (a few thousand columns: the launch-bound sizes of the shared-launch step of
+// rp_forward_coupled).  With few chunks per row the two ascending sweeps of rp_dot_rows_v4 degenerate -- their
+// remainders are loaded one chunk at a time, each a full memory round trip: 8 chunks from start chunk 3 = one batch of 4
+// and four single loads.  Here the chunk sequence m0, m0 + 1, ..., wrapping, is walked as ONE sequence in batches of U
+// (the last batch predicated), so a 2048-column row is one batch of 8 loads.  The accumulators see the same products in
+// the same order: identical bits.
+template <int R, int U, bool NT>
+__device__ __forceinline__ void rp_dot_rows_v4_ring(const RowDotArgs& P, int row_base, int lane, float (&sum)[R]) {
+    const float* wrow[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        int rr = row_base + j;
+        rr = rr < P.rows ? rr : P.rows - 1;
+        wrow[j] = P.W + (int64_t)rr * P.ldw + 4 * lane;
+    }
+    const float* sp = P.src + 4 * lane;
+    rp_f4 a[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) a[j] = rp_f4{0.f, 0.f, 0.f, 0.f};
+    const int M = P.n >> 8;
+    const int m0 = M > 0 ? (int)(((unsigned)((P.row0 + row_base) >> 3) * kStagger) % (unsigned)M) : 0;
+    for (int i = 0; i < M; i += U) {
+        rp_f4 rv[U];
+        rp_f4 w[U][R];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + u < M) {  // (wave-uniform)
+                int m = m0 + i + u;
+                m = m >= M ? m - M : m;
+                rv[u] = rp_ld4(sp + (int64_t)m * 256);
+#pragma unroll
+                for (int j = 0; j < R; ++j) w[u][j] = ld_w<NT>(wrow[j] + (int64_t)m * 256);
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i + u < M) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    a[j].x = fmaf(w[u][j].x, rv[u].x, a[j].x);
+                    a[j].y = fmaf(w[u][j].y, rv[u].y, a[j].y);
+                    a[j].z = fmaf(w[u][j].z, rv[u].z, a[j].z);
+                    a[j].w = fmaf(w[u][j].w, rv[u].w, a[j].w);
+                }
+            }
+    }
+    if ((M << 8) + 4 * lane < P.n) {  // partial last chunk (n % 4 == 0, so all 4 columns are valid)
+        rp_f4 rv = rp_ld4(sp + (int64_t)M * 256);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            rp_f4 w = ld_w<NT>(wrow[j] + (int64_t)M * 256);
+            a[j].x = fmaf(w.x, rv.x, a[j].x);
+            a[j].y = fmaf(w.y, rv.y, a[j].y);
+            a[j].z = fmaf(w.z, rv.z, a[j].z);
+            a[j].w = fmaf(w.w, rv.w, a[j].w);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) sum[j] = rp_wave_allreduce(rp_lane_sum4(a[j]));
+}
+
 // 4-byte path for sizes / alignments the 16-byte path cannot take (small test networks).
 template <int R>
 __device__ __forceinline__ void rp_dot_rows_s1(const RowDotArgs& P, int row_base, int lane, float (&sum)[R]) {

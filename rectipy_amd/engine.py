@@ -555,7 +555,7 @@ class Population:
                 run.edge_src[e] = se.data_ptr()
                 run.edge_src_ld[e] = 0 if se.dim() == 1 else (se.stride(0) if se.shape[0] > 1 else se.shape[1])
         if hist is not None:
-            for q in (0, 1):
+            for q in (0, 1, 2):
                 h = hist[q]
                 if h.dtype != torch.float32 or h.device != self.device or h.numel() != self.rows or not h.is_contiguous():
                     raise RuntimeError(f"hist[{q}] must be a contiguous float32 [{self.rows}] tensor on {self.device}")

@@ -211,8 +211,10 @@ class FeedbackNetwork(Network):
             outs[n] = self.get_node(n).forward(X)
         spiking = any(isinstance(self.get_node(p), SpikeResetNet) for p in pops)
         lag_read = {s_ for p in pops for s_, mode in plan["edges"][p] if mode == _abi.RP_EDGE_LAG}
+        # every population that is read through its state variable gets the history ring: RP_EDGE_OUT edges need it, and
+        # with it on the RP_EDGE_LIVE sources too the library may step all members in ONE launch (rp_forward_coupled)
         hist_read = lag_read | {s_ for p in pops for s_, mode in plan["edges"][p]
-                                if mode == _abi.RP_EDGE_OUT and self.get_node(s_)._out_code == _abi.RP_OUT_STATE0}
+                                if self.get_node(s_)._out_code == _abi.RP_OUT_STATE0}
         trajs, xin = {}, {}
         for p in pops:
             node: RateNet = self.get_node(p)
@@ -228,9 +230,9 @@ class FeedbackNetwork(Network):
                 trajs[p] = torch.empty(steps, pop.rows, dtype=torch.float32, device=pop.device)
             if p in hist_read:
                 if getattr(node, "_hist", None) is None:
-                    node._hist = [torch.zeros(pop.rows, dtype=torch.float32, device=pop.device) for _ in (0, 1)]
+                    node._hist = [torch.zeros(pop.rows, dtype=torch.float32, device=pop.device) for _ in (0, 1, 2)]
                 if p in lag_read:  # what a feedback edge reads at the window's first step: the node's exposed output
-                    node._hist[(a + 1) & 1].copy_(node["out"].detach())
+                    node._hist[(a + 2) % 3].copy_(node["out"].detach())
 
         def call(t0: int, t1: int, last: bool):
             members, saves = [], {}

@@ -23,7 +23,7 @@ def main():
         pops = [Population("li_tanh", mk(1.0), dict(tau=2.0, k=1.0, eta=0.0), 1e-2, dev) for _ in range(2)]
         E_ab, E_ba = mk(0.5), mk(0.5)
         x = torch.randn(T, h, device=dev, generator=gen) * 0.1
-        hist = [torch.zeros(h, device=dev), torch.zeros(h, device=dev)]
+        hist = [torch.zeros(h, device=dev) for _ in range(3)]
 
         def run(steps):
             forward_coupled([dict(pop=pops[0], run=dict(steps=steps, x=x[:steps], hist=hist), edges=[(E_ba, 1, _abi.RP_EDGE_LIVE)]),

@@ -18,7 +18,7 @@ xh = torch.randn(T, h, device=dev, generator=gen) * 0.1
 
 def timed(mats, label):
     pops = [Population("li_tanh", mats[q], dict(tau=2.0, k=1.0, eta=0.0), 1e-2, dev) for q in range(2)]
-    hist = [torch.zeros(h, device=dev), torch.zeros(h, device=dev)]
+    hist = [torch.zeros(h, device=dev) for _ in range(3)]
 
     def run(steps):
         forward_coupled([dict(pop=pops[0], run=dict(steps=steps, x=xh[:steps], hist=hist), edges=[(mats[3], 1, _abi.RP_EDGE_LIVE)]),

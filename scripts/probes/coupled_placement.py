@@ -54,7 +54,7 @@ for pad in (0, 1024, 17 * 1024 + 256, 256 * 1024 + 1024, 4 * 1024 * 1024 + 17 * 
     for q in range(2):
         assert pops[q].W.data_ptr() == views[q].data_ptr()
     xh = torch.randn(T, h, device=dev, generator=gen) * 0.1
-    hist = [torch.zeros(h, device=dev), torch.zeros(h, device=dev)]
+    hist = [torch.zeros(h, device=dev) for _ in range(3)]
 
     def run(steps):
         forward_coupled([dict(pop=pops[0], run=dict(steps=steps, x=xh[:steps], hist=hist), edges=[(views[3], 1, _abi.RP_EDGE_LIVE)]),

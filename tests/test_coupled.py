@@ -70,9 +70,9 @@ def run_circuit(pops, edges, models, out_vars, x, T, split, dev, S_every=3, cuto
     n_m = len(pops)
     trajs = [torch.zeros(T, p.rows, device=dev) for p in pops]
     samples = [torch.zeros(T, p.rows, device=dev) for p in pops]
-    hist = [[torch.zeros(p.rows, device=dev), torch.zeros(p.rows, device=dev)] for p in pops]
-    for m, p in enumerate(pops):  # what a LAG edge reads at step 0: the member's current output
-        hist[m][1].copy_(p.v if out_vars[m] == _abi.RP_OUT_STATE0 else p.source)
+    hist = [[torch.zeros(p.rows, device=dev) for _ in range(3)] for p in pops]
+    for m, p in enumerate(pops):  # what a LAG edge reads at step 0 (ring slot (0 - 1) % 3): the member's current output
+        hist[m][2].copy_(p.v if out_vars[m] == _abi.RP_OUT_STATE0 else p.source)
         p.reset_sampling()
     idx = [0] * n_m
     bounds = np.linspace(0, T, split + 1).astype(int)
@@ -211,8 +211,15 @@ def test_argument_checks(oracle_backend):
 
 # ---- HIP vs oracle ---------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("sizes,models,out_vars", CASES + [((1024, 2052, 512), ("li_tanh", "qif", "li_tanh"), (0, 1, 1))])
-def test_hip_coupled_bit_exact(oracle_backend, hip_device, sizes, models, out_vars):
+@pytest.mark.parametrize("launches", ["shared", "member"])
+@pytest.mark.parametrize("sizes,models,out_vars", CASES + [((1024, 2052, 512), ("li_tanh", "qif", "li_tanh"), (0, 1, 1)),
+                                                           ((4100, 260), ("li_tanh", "li_tanh"), (0, 0))])
+def test_hip_coupled_bit_exact(oracle_backend, hip_device, monkeypatch, sizes, models, out_vars, launches):
+    """HIP == oracle, bit for bit, both ways the library issues a step: ONE launch for all members (every edge of these
+    circuits reads a value from before the step; members of at most 4096 neurons) and one launch per member
+    (RECTIPY_AMD_COUPLED_LAUNCHES=member; the 4100-neuron case takes it by size)."""
+    if launches == "member":
+        monkeypatch.setenv("RECTIPY_AMD_COUPLED_LAUNCHES", "member")
     T = 40
     x = torch.randn(T, sizes[0], generator=torch.Generator().manual_seed(9)) * 0.5
     res = []
@@ -257,7 +264,7 @@ def test_full_size_coupled_step_against_float64(hip_device):
     v0 = [torch.randn(n, device=hip_device, generator=gen) * 0.5 for _ in range(2)]
     pops = [Population("li_tanh", W[m], dict(tau=2.0, k=1.0, eta=0.05), 1e-2, hip_device, v0=v0[m]) for m in range(2)]
     traj = [torch.zeros(T, n, device=hip_device) for _ in range(2)]
-    hist = [torch.zeros(n, device=hip_device), torch.zeros(n, device=hip_device)]
+    hist = [torch.zeros(n, device=hip_device) for _ in range(3)]
     forward_coupled([
         dict(pop=pops[0], run=dict(steps=T, x=x, traj=traj[0], hist=hist), edges=[(E_ba, 1, _abi.RP_EDGE_LIVE)]),
         dict(pop=pops[1], run=dict(steps=T, traj=traj[1]), edges=[(E_ab, 0, _abi.RP_EDGE_OUT)])])
