@@ -82,4 +82,17 @@ for B in (16, 32):
 algo["step_batched_mfma16_kernel<0, 1"] = 4.0 * N * N + 4.0 * 16 * (3 * N) + 12.0 * N
 algo["step_batched_mfma16_split_kernel"] = 4.0 * N * N + 4.0 * 32 * (3 * N) + 12.0 * N
 del popb, Wb
+# r04: the coupled step (two populations of N/2 neurons, a -> b and feedback b -> a): per launch the target's rows of W and
+# of its edge matrix, streamed by the same waves
+from rectipy_amd.engine import forward_coupled  # noqa: E402
+h = N // 2
+arena = torch.randn(4 * h * h, device=dev) / h ** 0.5
+mats = [arena[q * h * h:(q + 1) * h * h].view(h, h) for q in range(4)]
+cp = [Population("li_tanh", mats[q], dict(tau=2.0, k=1.0, eta=0.0), 1e-2, dev) for q in range(2)]
+hist = [torch.zeros(h, device=dev) for _ in range(3)]
+forward_coupled([dict(pop=cp[0], run=dict(steps=T, x=torch.zeros(T, 1, device=dev), hist=hist), edges=[(mats[3], 1, _abi.RP_EDGE_LIVE)]),
+                 dict(pop=cp[1], run=dict(steps=T), edges=[(mats[2], 0, _abi.RP_EDGE_OUT)])])
+torch.cuda.synchronize()
+algo["step_edges_kernel<0"] = 4.0 * h * (2 * h) + 4.0 * (9 * h + 2 * h)  # W rows + edge rows + vectors (two source vectors read)
+del cp, mats, arena
 print(json.dumps({"algorithmic_bytes_per_launch": algo}), flush=True)
