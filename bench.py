@@ -289,7 +289,7 @@ def main():
     # algorithmic bytes per launch: W once + per-neuron vectors (v r/w, tau, k, eta, r r/w) + input
     algo_bytes = 4.0 * rows * N + 4.0 * (7 * rows + 1)
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-    # HBM bytes per launch from the PMC counters need their own rocprofv3 passes (scripts/profile_kernels.sh); the
+    # HBM bytes per launch from the PMC counters need their own rocprofv3 passes (scripts/archive/profile_kernels.sh); the
     # figure is read from the committed summary of that run and labelled as such -- it is NOT measured by this run
     traffic, traffic_source = None, None
     for name in ("r04_step_kernel_traffic.json", "r03_step_kernel_traffic.json", "r02_step_kernel_traffic.json",

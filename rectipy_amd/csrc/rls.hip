@@ -241,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void rls_pass_kernel(const RlsParams P) {
 // [1024 c, 1024 c + 1024)): thread (wave w, lane l) owns columns 1024 c + 256 w + 4 l .. +3.  The tile's share of the
 // mat-vec: the four products of a lane, lane sum (a0+a1)+(a2+a3), butterfly; the four wave sums are added in wave order;
 // rls_zn_kernel adds a row's tile partials in ascending order (mirrored by oracle/rls_oracle.c).  Measured at
-// n_in = 32768 (scripts/sweep_rls_tiles.py): 4096-column tiles 1.54 ms per update, 2048 1.56, 1024 1.41.
+// n_in = 32768 (scripts/archive/sweep_rls_tiles.py): 4096-column tiles 1.54 ms per update, 2048 1.56, 1024 1.41.
 // (TU = 2, 4: wider tiles, thread owns columns 1024 u + 256 w + 4 l of the tile, accumulated over u ascending --
 // benchmark-only, rp_set_rls_tile; a different summation order.)
 constexpr int kTileCols = 1024;
@@ -576,7 +576,7 @@ void launch_sym_rows(const RlsParams& P, hipStream_t st) {
     const dim3 grid(nb * (nb + 1) / 2, 1024 / C);
     // An in-place read-modify-write walk is fastest with LITTLE in flight: ONE resident workgroup per CU (four waves, two
     // groups of rows each) -- 0.816 ms per update at n_in = 32768 against 0.858-0.866 with the chip filled (3-4 workgroups
-    // per CU), scripts/probes/rls_sym_cap.py; presumably because a tile's stores then reach DRAM pages its loads have
+    // per CU), scripts/archive/probes/rls_sym_cap.py; presumably because a tile's stores then reach DRAM pages its loads have
     // just opened.  The cap is an LDS allocation nobody uses.  Small matrices (fewer than four tiles per CU) are not
     // HBM-bound and run uncapped.
 #ifdef RP_MEASUREMENT

@@ -36,7 +36,7 @@ std::atomic<int> g_bwd_chunks{0};  // measurement build only (rp_set_bwd_chunks)
 // RC(n, rows): rows per chunk (multiple of 8) for `rows` rows of an n-column matrix.  The chunk count is part of the
 // summation-order contract (oracle/rnn_oracle.c mirrors it): Q = clamp(3072 / ceil(n / 256), 8, 64), i.e. about 3072
 // (chunk, 256-column strip) items -- 12 waves per CU, each with 2 rows x 1 KiB in flight, which is where the chip's
-// HBM streams fastest (scripts/tune_chunks.py, us per adjoint step, r02): n = 32768: Q = 16 634 (r01 rule), 20 616,
+// HBM streams fastest (scripts/archive/tune_chunks.py, us per adjoint step, r02): n = 32768: Q = 16 634 (r01 rule), 20 616,
 // 24 602, 28 638, 40 626 (599 with one row in flight), 64 655;  n = 65536: Q = 8 2508 (r01 rule), 12 2405, 24 2408;
 // n = 16384: Q = 32 167 (r01 rule), 40 156, 48 168.  Best chunk counts of a later sweep over other sizes (Q, rows in
 // flight x strip KiB, us): 8192: 40, 4x2, 47 (this rule: 64 -> 52);  12288: 40, 4x2, 94 (64 -> 96);  20480: 20, 4x2, 248
@@ -199,7 +199,7 @@ void launch_wt_partial(const BwdParams& P, bool vec4, hipStream_t st) {
         hipLaunchKernelGGL((wt_partial_kernel<false, 1, 1>), dim3(blocks > 4096 ? 4096 : blocks), dim3(kThreads), 0, st, P);
         return;
     }
-    // measured (scripts/size_sweep.py, scripts/tune_backward.py): 2-KiB strips with 4 rows in flight are the fastest
+    // measured (scripts/archive/size_sweep.py, scripts/archive/tune_backward.py): 2-KiB strips with 4 rows in flight are the fastest
     // shape from n = 8192 up (n = 32768: 6.7-6.8 TB/s vs 6.3 TB/s for 1-KiB strips); below that the narrow strips give
     // more waves.  2-KiB strips need >= 1024 waves.
     // r02: with >= 2560 items of 1-KiB strips, 2 rows in flight per wave on at most 768 workgroups (12 waves per CU,

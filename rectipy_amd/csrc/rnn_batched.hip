@@ -810,7 +810,7 @@ std::atomic<int> g_m16_tc{0}, g_m16_stages{0}, g_m16_waves{0};
 
 template <int MODEL, int NB>
 int launch_mfma16_cfg(const BatchParams& P, int B, hipStream_t st) {
-    // defaults (scripts/sweep_mfma16.py, r03; ms per step, (tile columns, stages, waves), waves = 16: the role-split kernel):
+    // defaults (scripts/archive/sweep_mfma16.py, r03; ms per step, (tile columns, stages, waves), waves = 16: the role-split kernel):
     //   one slot block (B <= 16)   N = 8192: (64,3,4) 0.067, (64,2,4) 0.107;  16384: 0.156 / 0.231;  32768: 0.621 / 0.618;
     //                              65536: 2.69 / 2.69  -> three stages everywhere (small N has one workgroup per CU)
     //   two slot blocks (B <= 32)  N = 16384: (64,3,4) 0.206, (64,3,8) 0.357, split 0.307;  24576: 0.524 / 0.531 / 0.464;
@@ -918,7 +918,7 @@ int launch_model(const BatchParams& P, int B, hipStream_t st) {
     }
 #endif
     switch (B) {
-        // r02 (scripts/sweep_batched.py, N = 32768, ms per step): fewer resident workgroups, as for the unbatched walk --
+        // r02 (scripts/archive/sweep_batched.py, N = 32768, ms per step): fewer resident workgroups, as for the unbatched walk --
         // B=2 (4,2) on 2048 0.627, (4,1) on 768 0.618;  B=4 (8,2) on 2048 0.639, on 512 0.629;  B=8 flat (0.86)
         case 2: launch<MODEL, 4, 2, 1>(P, st, 768); return RP_OK;
         // measured at N = 32768 (scripts/bench_batched.py): B=2 1.98x, B=4 3.91x, B=8 5.74x, B=16 5.92x the throughput of

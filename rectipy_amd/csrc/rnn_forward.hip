@@ -532,7 +532,7 @@ int launch_step_sparse_blocked(const StepParams& P, hipStream_t st, int n_cu) {
                                                  : launch_step_sparse_blocked_cfg<MODEL, 8, 3>(P, st, n_cu, lds);
     }
 #endif
-    // groups in flight per lane (scripts/tune_blocked.py, us per step, 16 waves): n = 32768 (8-row blocks) U=4 121.1,
+    // groups in flight per lane (scripts/archive/tune_blocked.py, us per step, 16 waves): n = 32768 (8-row blocks) U=4 121.1,
     // U=2 117.7, U=1 133.9;  n = 16384 (4-row blocks) U=4 39.7, U=2 38.0
     return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 2>(P, st, n_cu, lds)
                        : launch_step_sparse_blocked_cfg<MODEL, 8, 8>(P, st, n_cu, lds);
@@ -591,7 +591,7 @@ int launch_step_sparse(const StepParams& P, hipStream_t st) {
         }
     }
 #endif
-    // measured (scripts/tune_sparse.py): one row per wave with 4 groups in flight is the fastest or tied at every size
+    // measured (scripts/archive/tune_sparse.py): one row per wave with 4 groups in flight is the fastest or tied at every size
     return launch_step_sparse_cfg<MODEL, 1, 4>(P, st, n_cu);
 }
 
@@ -783,7 +783,7 @@ bool tuned_lookup(int rows, int n, int64_t ldw, StreamCfg* cfg, float* us) {
 
 bool streams_from_hbm(int rows, int n) { return rows >= 8192 && (int64_t)rows * n * 4 > (320ll << 20); }
 
-// measured with scripts/tune_forward.py / tune_shard_shapes.py / sweep_forward_shapes.py (us per step):
+// measured with scripts/archive/tune_forward.py / tune_shard_shapes.py / sweep_forward_shapes.py (us per step):
 //   n = 32768: (4,2) on 2048 workgroups 620, (2,1) on 683 604;  16384^2 (4,2) 166, (2,1) on 683 151;
 //   16384 x 32768 314 -> 303;  8192 x 32768 (4,2) 163, (2,1) on 1024 155;  4096 x 32768 (2,2) 79
 //   65536^2 and 32768 x 262144: (4,2) on 2048, 7.0 TB/s, nothing better found

@@ -373,7 +373,7 @@ class Population:
     def _block_rows(self, rows: Optional[int] = None) -> int:
         """Rows per block of the blocked packed form, 0 = per-row form.  A wave walks one block at a time, so the chip
         needs >= 16 waves x CUs blocks to stay busy: 8-row blocks from 32768 rows, 4-row blocks from 16384 rows, the
-        per-row form below (measured, scripts/tune_blocked.py: N = 32768, p = 0.1: 122 us vs 144 us per row-form step;
+        per-row form below (measured, scripts/archive/tune_blocked.py: N = 32768, p = 0.1: 122 us vs 144 us per row-form step;
         N = 16384: 39.5 vs 42.1; N = 8192: 17.8 vs 15.2)."""
         if self.sparse_block_rows:
             return int(self.sparse_block_rows)
@@ -740,7 +740,7 @@ class BatchedPopulation:
             use_mfma = (batch > 4 and not (exact and batch in self.BATCHES)) if mfma is None else bool(mfma)
             form = self.DEFAULT_MFMA if use_mfma else "valu"
             # more than 16 trajectories on a SMALL population: the r02 form's 32-row workgroups fill the chip where the
-            # 64-row workgroups of "mfma16" cannot (scripts/sweep_mfma16.py: N = 8192, B = 32: 0.075 vs 0.096 ms per step;
+            # 64-row workgroups of "mfma16" cannot (scripts/archive/sweep_mfma16.py: N = 8192, B = 32: 0.075 vs 0.096 ms per step;
             # N = 16384: 0.227 vs 0.206)
             if use_mfma and batch > 16 and pop.rows < 12288 and pop.row0 % 32 == 0:
                 form = "mfma32"

@@ -1,4 +1,6 @@
 """Trajectory-steps/s of the batched step (B trajectories share one pass over W) at N = 32768 (GPU box)."""
+import os
+os.environ.setdefault("RECTIPY_AMD_MEASUREMENT", "1")  # the rp_set_* knobs live in the measurement build (python -m rectipy_amd.build --measurement)
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

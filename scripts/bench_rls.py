@@ -1,5 +1,7 @@
 """RLS sweep at large n_in: achieved HBM bandwidth of the fused rank-1 update + next mat-vec pass (8 n^2 B/update)."""
 import os
+os.environ.setdefault("RECTIPY_AMD_MEASUREMENT", "1")  # the rp_set_* knobs live in the measurement build (python -m rectipy_amd.build --measurement)
+import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """Workload for the per-kernel HBM-traffic passes (run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE by
-scripts/profile_kernels.sh): a few launches each of the tanh step kernel, the adjoint strip kernel, the QIF step kernel
+scripts/archive/profile_kernels.sh): a few launches each of the tanh step kernel, the adjoint strip kernel, the QIF step kernel
 and the RLS pass at HBM-bound sizes.  Prints the algorithmic bytes per launch of each for the summary."""
 import json
 import os

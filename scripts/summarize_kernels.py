@@ -1,5 +1,5 @@
 """HBM bytes per launch (FETCH_SIZE x 2 on gfx950 for 16-byte streaming reads + WRITE_SIZE, KiB units) against the
-algorithmic bytes, per kernel, from the two PMC passes of scripts/profile_kernels.sh."""
+algorithmic bytes, per kernel, from the two PMC passes of scripts/archive/profile_kernels.sh."""
 import csv
 import glob
 import json
