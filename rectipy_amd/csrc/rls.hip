@@ -327,28 +327,6 @@ __global__ void rls_zn_kernel(const RlsParams P, int tile_cols) {
 // rls_sym_zn_kernel: z'_i = beta^-1 (colsum[0][i] + ... + colsum[I_i - 1][i], then rowpart[i][I_i] + ... ascending).
 // After the last update of a sweep rls_mirror_kernel copies the off-diagonal blocks to their transposed positions, so the
 // caller always sees a full P.  Mirrored by oracle/rls_oracle.c.
-template <int R>
-__device__ __forceinline__ float rows_allreduce(float (&v)[R], int lane) {
-    // sums over the 64 lanes of R per-lane values at once; afterwards lane l holds the total of value
-    // (bits of l selected level by level); same pairings (l, l ^ 32), (l, l ^ 16), ... as rp_wave_allreduce
-    int width = R;
-    int off = 32;
-#pragma unroll
-    for (; width > 1; width >>= 1, off >>= 1) {
-        const bool hi = (lane & off) != 0;
-#pragma unroll
-        for (int q = 0; q < width / 2; ++q) {
-            const float send = hi ? v[q] : v[q + width / 2];
-            const float keep = hi ? v[q + width / 2] : v[q];
-            v[q] = keep + __shfl_xor(send, off, 64);
-        }
-    }
-    float s = v[0];
-#pragma unroll
-    for (; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
-    return s;
-}
-
 // C = rows per tile (the chunk of the column partials: part of the summation order), R = rows in flight per wave (how the
 // tile is walked: groups of R rows, the next group's loads issued before the current one is processed; never the order).
 // FULL: n_in is a multiple of 1024, so every tile is complete and no access is predicated -- the loads of the next group
@@ -439,7 +417,7 @@ __global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
             for (int r = 0; r < R; ++r) t += rs[r];
             if (t == 12345.f) wsum[g][wave] = t;  // (keeps the loads alive)
         } else if (dot) {
-            const float total = rows_allreduce<R>(rs, lane);
+            const float total = rp_rows_allreduce<R>(rs, lane);
             if ((lane & (kGroup - 1)) == 0) {  // the row index of a lane's total is spelled by its lane bits, high bit first
                 int r = 0;
                 int width = R, off = 32;

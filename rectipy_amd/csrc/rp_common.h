@@ -91,3 +91,38 @@ __device__ __forceinline__ float rp_wave_allreduce(float s) {
 }
 
 __device__ __forceinline__ float rp_lane_sum4(rp_f4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+// The butterflies of R rows at once (a "transposed" butterfly): sums, over the 64 lanes, R per-lane values; afterwards lane l
+// holds the total of the row spelled by its lane bits, high bit first (rp_rows_allreduce_row).  Same pairings (l, l ^ 32),
+// (l, l ^ 16), ... as rp_wave_allreduce -- the same additions per row, R - 1 + log2(64 / R) shuffles instead of 6 R.
+template <int R>
+__device__ __forceinline__ float rp_rows_allreduce(float (&v)[R], int lane) {
+    // sums over the 64 lanes of R per-lane values at once; afterwards lane l holds the total of value
+    // (bits of l selected level by level); same pairings (l, l ^ 32), (l, l ^ 16), ... as rp_wave_allreduce
+    int width = R;
+    int off = 32;
+#pragma unroll
+    for (; width > 1; width >>= 1, off >>= 1) {
+        const bool hi = (lane & off) != 0;
+#pragma unroll
+        for (int q = 0; q < width / 2; ++q) {
+            const float send = hi ? v[q] : v[q + width / 2];
+            const float keep = hi ? v[q + width / 2] : v[q];
+            v[q] = keep + __shfl_xor(send, off, 64);
+        }
+    }
+    float s = v[0];
+#pragma unroll
+    for (; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+    return s;
+}
+
+
+template <int R>
+__device__ __forceinline__ int rp_rows_allreduce_row(int lane) {
+    int r = 0;
+    int width = R, off = 32;
+#pragma unroll
+    for (; width > 1; width >>= 1, off >>= 1) r += (lane & off) ? width / 2 : 0;
+    return r;
+}
