@@ -327,6 +327,9 @@ int rp_sizeof_member(void);
 
 /* RP_OK iff HIP device `device` exists and is gfx950. */
 int rp_device_check(int device);
+/* The device's marketing name (hipDeviceProp_t::name) into buf[len], NUL-terminated: the key under which measured walks
+   are persisted.  (Asking torch costs a process 105 ms once: torch.cuda.get_device_name initialises amdsmi.) */
+int rp_device_name(int device, char* buf, int32_t len);
 
 /* src[cur][row0+i] = act(y[0][i]) for LI models (no-op for QIF, whose source is a state). */
 int rp_refresh_source(const rp_net* net, void* stream);

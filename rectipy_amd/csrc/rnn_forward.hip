@@ -936,6 +936,14 @@ int rp_device_check(int device) {
     return RP_OK;
 }
 
+int rp_device_name(int device, char* buf, int32_t len) {
+    if (!buf || len < 2) RP_FAIL(RP_ERR_ARG, "rp_device_name: buffer missing");
+    hipDeviceProp_t prop;
+    RP_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, (size_t)len, "%s", prop.name);
+    return RP_OK;
+}
+
 int rp_refresh_source(const rp_net* net, void* stream) {
     int rc = validate_net(net);
     if (rc != RP_OK) return rc;

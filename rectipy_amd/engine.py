@@ -113,9 +113,16 @@ class HipBackend:
     def abi_version(self) -> int:
         return int(self.lib.rp_abi_version())
 
-    @staticmethod
-    def device_name(device) -> str:
-        return torch.cuda.get_device_name(device)
+    def device_name(self, device) -> str:
+        """The device's name from the library (hipGetDeviceProperties), cached: torch.cuda.get_device_name would
+        initialise amdsmi on its first call -- 105 ms, which was the whole "cold" cost of a process's first run."""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        names = self.__dict__.setdefault("_device_names", {})
+        if idx not in names:
+            buf = C.create_string_buffer(256)
+            self._check(self.lib.rp_device_name(idx, buf, 256))
+            names[idx] = buf.value.decode("utf-8", "replace")
+        return names[idx]
 
     def forward_tuning(self, net: RpNet) -> dict:
         R, U, G, m, us = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_float()

@@ -102,6 +102,9 @@ def prepare(pop, net, steps: int) -> None:
     if requested is False or mode() == "off":
         pop._tuned = True
         return
+    if pop.rows < 8192 or 4 * pop.rows * pop.n <= (320 << 20):
+        pop._tuned = True  # does not stream from HBM: rp_tune_forward has nothing to choose (its own rule), no cache entry either
+        return
     key = _key(backend.device_name(pop.device), pop.rows, pop.n, int(net.ldw), backend.abi_version())
     if not pop._cache_checked:
         pop._cache_checked = True
