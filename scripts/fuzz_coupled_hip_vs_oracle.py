@@ -1,0 +1,171 @@
+"""GPU box: FeedbackNetwork graphs and Network.run_batch on the HIP library against the same package on the CPU oracle, on
+RANDOM shapes -- 2..4 populations (tanh / sigmoid / QIF / LIF, sizes from 5 to ~1100: 4-byte and 16-byte paths, ragged
+chunks, different widths), random feed-forward chains with random feedback edges (the three edge read modes of
+rp_forward_coupled arise from their direction and the source's kind), optional input / read-out layers, recorded
+variables, sampling, cutoff, two consecutive runs; run_batch with random B, sampling and input edge.  Populations'
+outputs are compared BIT FOR BIT where no device-side torch product lies in front of them (no input layer), else to 2e-5
+(5e-4 for spiking populations, whose spike times may move by a step behind a rounded input); batched runs bit for bit
+up to 4 trajectories (vector ALUs) and to 2e-5 on the matrix cores.
+
+    python scripts/fuzz_coupled_hip_vs_oracle.py [cases] [seed] [max_n]
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.backend import OracleBackend  # noqa: E402
+from rectipy_amd import FeedbackNetwork, Network  # noqa: E402
+
+DEV = os.environ.get("FUZZ_DEVICE", "cuda:0")
+P = "neuron_model_templates."
+KINDS = {
+    "tanh": dict(path=P + "rate_neurons.leaky_integrator.tanh", op="li_op", src="tanh_op/r", tgt="li_op/r_in", outs=["li_op/v", "tanh_op/r"]),
+    "sigmoid": dict(path=P + "rate_neurons.leaky_integrator.sigmoid", op="li_op", src="sigmoid_op/r", tgt="li_op/r_in", outs=["li_op/v"]),
+    "qif": dict(path=P + "spiking_neurons.qif.qif", op="qif_op", src="qif_op/s", tgt="qif_op/s_in", outs=["qif_op/s"], spike=True),
+    "lif": dict(path=P + "spiking_neurons.lif.lif", op="lif_op", src="lif_op/s", tgt="lif_op/s_in", outs=["lif_op/s"], spike=True),
+}
+
+
+def add_population(net, label, kind, n, rng):
+    K = KINDS[kind]
+    op = K["op"]
+    if K.get("spike"):
+        W = np.abs(rng.standard_normal((n, n))) * 2.0 / n
+        lo_hi = {"qif": dict(tau=(0.8, 1.2), k=(0.5, 1.5), eta=(0.5, 3.0), tau_s=(0.5, 2.0)),
+                 "lif": dict(tau=(0.4, 0.8), k=(0.5, 1.5), eta=(2.0, 5.0), tau_s=(0.2, 0.6))}[kind]
+        node_vars = {f"all/{op}/{q}": rng.uniform(lo, hi, n) for q, (lo, hi) in lo_hi.items()}
+        kw = dict(spike_var=f"{op}/spike", reset_var=f"{op}/v", spike_threshold=1.0, spike_reset=-1.0 if kind == "qif" else 0.0)
+    else:
+        W = rng.standard_normal((n, n)) * 1.0 / np.sqrt(n)
+        node_vars = {"all/li_op/tau": rng.uniform(0.5, 2.0, n), "all/li_op/k": rng.uniform(0.5, 1.5, n),
+                     "all/li_op/eta": rng.standard_normal(n) * 0.1, "all/li_op/v": rng.standard_normal(n) * 0.5}
+        kw = {}
+    out_var = K["outs"][int(rng.integers(0, len(K["outs"])))]
+    net.add_diffeq_node(label, K["path"], weights=W, source_var=K["src"], target_var=K["tgt"], input_var=f"{op}/I_ext",
+                        output_var=out_var, dtype=torch.float32, node_vars=node_vars, **kw)
+    return f"{op}/v"
+
+
+def build_feedback(where, seed, kinds, sizes, m, k, fb_pairs):
+    rng = np.random.default_rng(seed)
+    net = FeedbackNetwork(5e-3, **where)
+    if m:
+        net.add_func_node("inp", m, "identity")
+    labels = "abcd"[:len(sizes)]
+    rec_var = None
+    for lab, kind, n in zip(labels, kinds, sizes):
+        v = add_population(net, lab, kind, n, rng)
+        rec_var = rec_var or (lab, v)
+    if k:
+        net.add_func_node("out", k, ["identity", "tanh"][int(rng.integers(0, 2))])
+    order = (["inp"] if m else []) + list(labels) + (["out"] if k else [])
+    width = dict(zip(labels, sizes), inp=m, out=k)
+    for s_, t_ in zip(order[:-1], order[1:]):
+        net.add_edge(s_, t_, weights=rng.standard_normal((width[t_], width[s_])) * 0.7 / np.sqrt(width[s_]))
+    for s_, t_ in fb_pairs:
+        net.add_edge(labels[s_], labels[t_], weights=rng.standard_normal((sizes[t_], sizes[s_])) * 0.5 / np.sqrt(sizes[s_]), feedback=True)
+    return net, rec_var
+
+
+def bits_equal(a, b):
+    a, b = np.ascontiguousarray(a, dtype=np.float32), np.ascontiguousarray(b, dtype=np.float32)
+    return a.shape == b.shape and bool(((a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))).all())
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return a.shape == b.shape and bool(np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())) if a.size else a.shape == b.shape
+
+
+def main(cases=40, seed=0, max_n=1100):
+    rng = np.random.default_rng(seed)
+    fails = 0
+    wheres = (dict(device="cpu", backend=OracleBackend()), dict(device=DEV) if DEV != "cpu" else dict(device="cpu", backend=OracleBackend()))
+    for case in range(cases):
+        cfg = {}
+        try:
+            if rng.integers(0, 3) < 2:  # ---- a FeedbackNetwork ----
+                npop = int(rng.integers(2, 5))
+                kinds = [list(KINDS)[int(rng.integers(0, 4))] for _ in range(npop)]
+                sizes = [int(rng.choice([rng.integers(5, 40), rng.integers(250, 300), rng.integers(min(500, max_n - 1), max_n)])) for _ in range(npop)]
+                m, k = int(rng.integers(0, 3)) * int(rng.integers(0, 2)), int(rng.integers(0, 3))
+                pairs = set()
+                for _ in range(int(rng.integers(1, 4))):
+                    s_, t_ = int(rng.integers(0, npop)), int(rng.integers(0, npop))
+                    if s_ != t_ and (s_, t_) not in pairs and t_ != s_ + 1:
+                        pairs.add((s_, t_))
+                if not pairs:
+                    pairs = {(npop - 1, 0)}
+                T = int(rng.integers(20, 70))
+                samp, cutoff = int(rng.integers(1, 5)), int(rng.integers(0, 6))
+                cfg = dict(kind="feedback", kinds=kinds, sizes=sizes, m=m, k=k, fb=sorted(pairs), T=T, samp=samp, cutoff=cutoff)
+                x = (rng.standard_normal((T, m if m else sizes[0])) * 0.5 + (1.5 if KINDS[kinds[0]].get("spike") else 0.0)).astype(np.float32)
+                res = []
+                for where in wheres:
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        net, rec_var = build_feedback(where, 1000 * seed + case, kinds, sizes, m, k, sorted(pairs))
+                        net.compile()
+                        planned = net._coupled_plan([]) is not None
+                        o1 = net.run(x[:T // 2], sampling_steps=samp, cutoff=cutoff, verbose=False, enable_grad=False,
+                                     record_vars=[(rec_var[0], rec_var[1], False)])
+                        o2 = net.run(x[T // 2:], sampling_steps=1, verbose=False, enable_grad=False)
+                    res.append((o1.to_numpy("out"), o2.to_numpy("out"), o1.to_numpy(rec_var),
+                                {q: v.detach().cpu().numpy() for q, v in net.state.items()}, planned))
+                exact = m == 0 and k == 0
+                spiking = any(KINDS[q].get("spike") for q in kinds)
+                tol = 5e-4 if spiking else 2e-5
+                ok = res[0][4] == res[1][4]
+                for a, b in zip(res[0][:3], res[1][:3]):
+                    ok = ok and (bits_equal(a, b) if exact else close(a, b, tol))
+                for q in res[0][3]:
+                    ok = ok and (bits_equal(res[0][3][q], res[1][3][q]) if exact else close(res[0][3][q], res[1][3][q], tol))
+                cfg["coupled_plan"] = res[0][4]
+            else:  # ---- run_batch ----
+                n = int(rng.choice([rng.integers(2, 20) * 4, rng.integers(64, 80) * 4, rng.integers(130, max(131, max_n // 4)) * 4]))
+                B = int(rng.choice([1, 2, 3, 4, 5, 8, 11, 16, 23, 32, 35]))
+                m, k = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+                T = int(rng.integers(10, 50))
+                samp, cutoff = int(rng.integers(1, 6)), int(rng.integers(0, 6))
+                exact_flag = bool(rng.integers(0, 2))
+                cfg = dict(kind="batch", n=n, B=B, m=m, k=k, T=T, samp=samp, cutoff=cutoff, exact=exact_flag)
+                x = rng.standard_normal((B, T, m if m else 1)).astype(np.float32)
+                res = []
+                for where in wheres:
+                    r2 = np.random.default_rng(1000 * seed + case)
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        net = Network(1e-2, **where)
+                        if m:
+                            net.add_func_node("inp", m, "identity")
+                        add_population(net, "rnn", "tanh", n, r2)
+                        if k:
+                            net.add_func_node("out", k, "identity")
+                            net.add_edge("rnn", "out", weights=r2.standard_normal((k, n)) / np.sqrt(n))
+                        if m:
+                            net.add_edge("inp", "rnn", weights=r2.standard_normal((n, m)))
+                        obs = net.run_batch(x, sampling_steps=samp, cutoff=cutoff, exact=exact_flag)
+                    res.append(([o.to_numpy("out") for o in obs], [o["state"].cpu().numpy() for o in obs]))
+                ok = True
+                for b in range(B):
+                    # read-outs are torch products on the device: bits only for the population's own output
+                    same = bits_equal if (k == 0) else (lambda u, v: close(u, v, 2e-5))
+                    ok = ok and same(res[0][0][b], res[1][0][b]) and bits_equal(res[0][1][b], res[1][1][b])
+        except Exception as e:  # noqa: BLE001
+            ok = False
+            cfg["exception"] = f"{type(e).__name__}: {e}"
+        if not ok:
+            fails += 1
+            print(json.dumps(dict(case=case, seed=seed, **{q: (v if not isinstance(v, (np.integer,)) else int(v)) for q, v in cfg.items()})), flush=True)
+    print(f"fuzz_coupled_hip_vs_oracle: {cases} cases, seed {seed}: {fails} failures", flush=True)
+    return fails
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    sys.exit(1 if main(int(a[0]) if a else 40, int(a[1]) if len(a) > 1 else 0, int(a[2]) if len(a) > 2 else 1100) else 0)

@@ -17,3 +17,14 @@ def test_random_front_end_sequences_hip_equals_oracle(seed, hip_device, capsys):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import fuzz_hip_vs_oracle
     assert fuzz_hip_vs_oracle.main(30, seed, 1300) == 0, capsys.readouterr().out[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [5, 6])
+def test_random_feedback_graphs_and_batched_runs_hip_equals_oracle(seed, hip_device, capsys):
+    """scripts/fuzz_coupled_hip_vs_oracle.py: random FeedbackNetwork graphs (2..4 populations, tanh / sigmoid / QIF / LIF,
+    all three edge read modes of rp_forward_coupled, shared and per-member launches by size) and random Network.run_batch
+    calls (in-kernel sampling, all three batched forms), HIP against the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_coupled_hip_vs_oracle
+    assert fuzz_coupled_hip_vs_oracle.main(25, seed, 1100) == 0, capsys.readouterr().out[-3000:]
