@@ -20,6 +20,7 @@
  *   rp_forward_coupled <- the per-step graph walk over several populations joined by dense edges, feedback edges
  *                        included                   rectipy/network.py:962-981, 1322-1357 (FeedbackNetwork._backward,
  *                                                   _edge_bwd), rectipy/edges.py:48-49
+ *   rp_backward_coupled <- autograd over that walk     rectipy/network.py:1016-1048 with 1322-1357
  *   rp_refresh_source <- (state re-initialisation)  rectipy/nodes.py:198-211,398-401
  *   rp_rate_backward, rp_qif_backward
  *                     <- torch.autograd over the unrolled loop (incl. Spike.backward, nodes.py:479-481),
@@ -372,6 +373,36 @@ int32_t rp_bwd_shard_partial_rows(int32_t n, int32_t rows);
 int rp_bwd_prepare(const rp_net* net, const rp_bwd* bwd, void* stream);
 int rp_bwd_partial(const rp_net* net, const rp_bwd* bwd, int32_t t, float* z_full, void* stream);
 int rp_bwd_apply(const rp_net* net, const rp_bwd* bwd, int32_t t, const float* z_local, void* stream);
+
+/*
+ * The adjoint of rp_forward_coupled: one sweep t = T-1 .. 0 over the stored windows of ALL members, the gradient passing
+ * through the dense edges between them (what autograd does over the reference's step-by-step graph walk,
+ * rectipy/network.py:1322-1357 under Network._bptt, network.py:1016-1048).  Member m's edges are the edges INTO m, as in
+ * the forward call.  Per adjoint step, for every edge e (q -> m) the transposed product c = W_e^T gx_m(t) -- gx_m(t) =
+ * dL/dI_m(t), row t of m's rp_bwd.grad_x, which the members' own sweeps produce -- is added to row tau of q's
+ * rp_bwd.grad_out (the gradient with respect to q's output, rp_bwd.grad_var = q's output variable), tau = t for
+ * RP_EDGE_OUT and for RP_EDGE_LIVE from a member LATER in the order, tau = t - 1 for RP_EDGE_LAG (nothing for tau < 0:
+ * the window's history is cut there, as by Network.detach); then every member's own step (rp_bwd_partial / rp_bwd_apply:
+ * z = W^T u over column strips, the element-wise update).  So rp_bwd.grad_out of a member is READ AND WRITTEN here (the
+ * caller passes a private buffer, zeros where the loss has no direct gradient), grad_x is required for every member with
+ * edges, and an RP_EDGE_LIVE edge from an EARLIER member (it reads a post-update value) is not available: such graphs
+ * keep the step-by-step autograd.  c is summed like z: per chunk of RC(n_q, rows_m) rows of the edge matrix ascending,
+ * chunks ascending (mirrored by oracle_backward_coupled).  The weight gradient of an edge is left to the caller:
+ * dW_e = sum_t gx_m(t) (x) out_q(tau) is rp_outer_store_rect on the two stored windows.
+ */
+typedef struct rp_bwd_member {
+    const rp_net* net;
+    const rp_bwd* bwd;                   /* as for rp_bwd_prepare / partial / apply (unsharded: rows == n); see above for grad_out / grad_x */
+    int32_t n_edges;
+    const float* edge_w[RP_MAX_EDGES];   /* [rows x edge_ld]: rows = this member's neurons, columns = the source's        */
+    int64_t edge_ld[RP_MAX_EDGES];
+    int32_t edge_source[RP_MAX_EDGES];
+    int32_t edge_mode[RP_MAX_EDGES];     /* RP_EDGE_OUT | RP_EDGE_LIVE (source later in the order) | RP_EDGE_LAG          */
+    float* edge_work;                    /* workspace: max over the edges of rp_bwd_shard_partial_rows(n_source, rows) * n_source floats */
+    float* z;                            /* workspace [n]                                                               */
+} rp_bwd_member;
+int rp_sizeof_bwd_member(void);
+int rp_backward_coupled(const rp_bwd_member* members, int32_t count, void* stream);
 
 /* Surrogate-gradient adjoint sweep of a spiking step (QIF, QIF_SFA, LIF, IK): gradient flows through the Heaviside
    via Spike.backward (nodes.py:479-481) but not through the reset mask (nodes.py:384). */

@@ -53,6 +53,7 @@ def _declare(lib):
     sig("oracle_refresh_source", C.c_int, [P(RpNet)])
     sig("oracle_forward", C.c_int, [P(RpNet), P(RpRun)])
     sig("oracle_forward_coupled", C.c_int, [P(_abi.RpMember), C.c_int32])
+    sig("oracle_backward_coupled", C.c_int, [P(_abi.RpBwdMember), C.c_int32])
     sig("oracle_rate_backward", C.c_int, [P(RpNet), P(RpBwd)])
     sig("oracle_qif_backward", C.c_int, [P(RpNet), P(RpBwd)])
     sig("oracle_outer_accum", C.c_int, [C.c_int32, C.c_int32, C.c_float, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64])
@@ -92,6 +93,9 @@ class OracleBackend:
 
     def forward_coupled(self, members, count, device):
         assert self.lib.oracle_forward_coupled(members, count) == 0
+
+    def backward_coupled(self, members, count, device):
+        assert self.lib.oracle_backward_coupled(members, count) == 0
 
     def rate_backward(self, net, bwd, device):
         assert self.lib.oracle_rate_backward(C.byref(net), C.byref(bwd)) == 0

@@ -127,6 +127,20 @@ class RpMember(C.Structure):
     ]
 
 
+class RpBwdMember(C.Structure):
+    _fields_ = [
+        ("net", C.c_void_p),     # const rp_net*
+        ("bwd", C.c_void_p),     # const rp_bwd*
+        ("n_edges", C.c_int32),
+        ("edge_w", fp * RP_MAX_EDGES),
+        ("edge_ld", C.c_int64 * RP_MAX_EDGES),
+        ("edge_source", C.c_int32 * RP_MAX_EDGES),
+        ("edge_mode", C.c_int32 * RP_MAX_EDGES),
+        ("edge_work", fp),
+        ("z", fp),
+    ]
+
+
 class RpBwd(C.Structure):
     _fields_ = [
         ("steps", C.c_int32),
@@ -263,6 +277,8 @@ def declare(lib):
     sig("rp_sizeof_bwd", C.c_int, [])
     sig("rp_sizeof_member", C.c_int, [])
     sig("rp_forward_coupled", C.c_int, [P(RpMember), C.c_int32, C.c_void_p])
+    sig("rp_sizeof_bwd_member", C.c_int, [])
+    sig("rp_backward_coupled", C.c_int, [P(RpBwdMember), C.c_int32, C.c_void_p])
     sig("rp_refresh_source", C.c_int, [P(RpNet), C.c_void_p])
     sig("rp_forward", C.c_int, [P(RpNet), P(RpRun), C.c_void_p])
     sig("rp_bwd_partial_rows", C.c_int32, [C.c_int32])
@@ -315,7 +331,7 @@ def declare(lib):
 
 EXPORTS = [
     "rp_abi_version", "rp_last_error", "rp_device_check", "rp_device_name", "rp_sizeof_net", "rp_sizeof_run", "rp_sizeof_bwd",
-    "rp_sizeof_member", "rp_forward_coupled",
+    "rp_sizeof_member", "rp_forward_coupled", "rp_sizeof_bwd_member", "rp_backward_coupled",
     "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum",
     "rp_outer_accum_rect", "rp_outer_store_rect", "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial",
     "rp_bwd_apply", "rp_sizeof_comm", "rp_forward_sharded", "rp_backward_sharded", "rp_ipc_alloc", "rp_ipc_open",

@@ -960,6 +960,80 @@ int rp_bwd_apply(const rp_net* net, const rp_bwd* b, int32_t t, const float* z_l
     return RP_OK;
 }
 
+// dst[c] += sum of the chunk partials of column c, in chunk order: the transposed edge product of rp_backward_coupled
+// lands in the source's output gradient
+__global__ void chunk_sum_add_kernel(const BwdParams P, float* dst) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.n) return;
+    dst[c] = dst[c] + chunk_sum(P, c);
+}
+
+int rp_sizeof_bwd_member(void) { return (int)sizeof(rp_bwd_member); }
+
+int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
+    if (!mem || count < 1 || count > 16) RP_FAIL(RP_ERR_ARG, "rp_backward_coupled: 1..16 members");
+    const int T = mem[0].bwd ? mem[0].bwd->steps : 0;
+    for (int m = 0; m < count; ++m) {
+        const rp_bwd_member& M = mem[m];
+        if (!M.net || !M.bwd || !M.z) RP_FAIL(RP_ERR_ARG, "member %d: net / bwd / z is null", m);
+        if (M.net->rows != M.net->n || M.net->row0 != 0) RP_FAIL(RP_ERR_ARG, "member %d: row shards cannot be coupled", m);
+        if (M.bwd->steps != T || T <= 0) RP_FAIL(RP_ERR_ARG, "member %d: every member sweeps the same window (steps > 0)", m);
+        if (M.net->model == RP_MODEL_IKU || M.net->model == RP_MODEL_IK_BIEXP)
+            RP_FAIL(RP_ERR_ARG, "member %d: population-mean models have no step-wise adjoint", m);
+        if (M.n_edges < 0 || M.n_edges > RP_MAX_EDGES) RP_FAIL(RP_ERR_ARG, "member %d: n_edges must be in [0, %d]", m, RP_MAX_EDGES);
+        if (M.n_edges > 0 && (!M.bwd->grad_x || !M.edge_work)) RP_FAIL(RP_ERR_ARG, "member %d has edges: grad_x and edge_work are required", m);
+        for (int e = 0; e < M.n_edges; ++e) {
+            const int q = M.edge_source[e], mode = M.edge_mode[e];
+            if (q < 0 || q >= count || !mem[q].net || !mem[q].bwd) RP_FAIL(RP_ERR_ARG, "member %d edge %d: bad source %d", m, e, q);
+            if (mode != RP_EDGE_OUT && mode != RP_EDGE_LIVE && mode != RP_EDGE_LAG) RP_FAIL(RP_ERR_ARG, "member %d edge %d: bad mode %d", m, e, mode);
+            if (mode == RP_EDGE_OUT && q >= m) RP_FAIL(RP_ERR_ARG, "member %d edge %d: RP_EDGE_OUT needs a source stepped earlier", m, e);
+            if (mode == RP_EDGE_LIVE && q <= m)
+                RP_FAIL(RP_ERR_ARG, "member %d edge %d: an RP_EDGE_LIVE edge from member %d reads a post-update value: no fused adjoint", m, e, q);
+            if (!M.edge_w[e] || M.edge_ld[e] < mem[q].net->n) RP_FAIL(RP_ERR_SHAPE, "member %d edge %d: edge_w / edge_ld", m, e);
+            if (!mem[q].bwd->grad_out || mem[q].bwd->ldg < mem[q].net->n)
+                RP_FAIL(RP_ERR_ARG, "member %d edge %d: source %d needs a (writable) grad_out buffer", m, e, q);
+        }
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int m = 0; m < count; ++m) {
+        const int rc = rp_bwd_prepare(mem[m].net, mem[m].bwd, stream);
+        if (rc != RP_OK) return rc;
+    }
+    for (int t = T - 1; t >= 0; --t) {
+        // the gradient through the edges first: gx_m(t) = row t of m's grad_x is ready (prep of the step before)
+        for (int m = 0; m < count; ++m) {
+            const rp_bwd_member& M = mem[m];
+            for (int e = 0; e < M.n_edges; ++e) {
+                const int q = M.edge_source[e];
+                const int tau = M.edge_mode[e] == RP_EDGE_LAG ? t - 1 : t;
+                if (tau < 0) continue;
+                BwdParams P = {};
+                P.W = M.edge_w[e];
+                P.ldw = M.edge_ld[e];
+                P.n = mem[q].net->n;
+                P.rows = M.net->rows;
+                P.rc = chunk_rows(P.n, P.rows);
+                P.q = (P.rows + P.rc - 1) / P.rc;
+                P.partials = M.edge_work;
+                P.u = M.bwd->grad_x + (int64_t)t * M.bwd->ldgx;
+                const bool vec4 = (P.n % 4 == 0) && (P.ldw % 4 == 0) && !(reinterpret_cast<uintptr_t>(P.W) & 15u) &&
+                                  !(reinterpret_cast<uintptr_t>(P.partials) & 15u);
+                launch_wt_partial(P, vec4, st);
+                float* dst = const_cast<float*>(mem[q].bwd->grad_out) + (int64_t)tau * mem[q].bwd->ldg;
+                hipLaunchKernelGGL(chunk_sum_add_kernel, dim3((P.n + 255) / 256), dim3(256), 0, st, P, dst);
+            }
+        }
+        for (int m = 0; m < count; ++m) {
+            int rc = rp_bwd_partial(mem[m].net, mem[m].bwd, t, mem[m].z, stream);
+            if (rc != RP_OK) return rc;
+            rc = rp_bwd_apply(mem[m].net, mem[m].bwd, t, mem[m].z, stream);
+            if (rc != RP_OK) return rc;
+        }
+    }
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
+
 // RP_COMM_DIRECT: slice q of this rank's full-length partial goes into slot `rank` of owner q's inbox (peer memory mapped
 // through hipIpc; blockIdx.y = peer), 16 bytes per lane.
 struct ContribPush {

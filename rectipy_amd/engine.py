@@ -98,6 +98,10 @@ class HipBackend:
         with self._on(device):
             self._check(self.lib.rp_forward_coupled(members, count, self._stream(device)))
 
+    def backward_coupled(self, members, count: int, device):
+        with self._on(device):
+            self._check(self.lib.rp_backward_coupled(members, count, self._stream(device)))
+
     def tune_forward(self, net: RpNet, device):
         """Measure the streaming configuration of the dense step kernel for this shape (a no-op for shapes that do not
         stream from HBM, and for a shape already measured or installed in this process).  WHEN this is called is the
@@ -584,7 +588,7 @@ class Population:
         rp_backward_sharded) or ``exchange.reduce_scatter(z_full, z_local)`` called once per step."""
         T = int(traj_v.shape[0])
         local = self.rows
-        sharded = self.rows != self.n
+        sharded = self.rows != self.n or _args_only == "stepwise"  # (the step-wise entry points: no W^T workspace)
         self._sync_packed()
         b = RpBwd()
         b.steps = T
@@ -645,6 +649,7 @@ class Population:
         net = self._net()
         if _args_only:
             return net, b, keep
+        sharded = self.rows != self.n
         if not sharded:
             (self.backend.qif_backward if self.spiking else self.backend.rate_backward)(net, b, self.device)
             return keep
@@ -669,7 +674,7 @@ class Population:
     def _backward_args(self, **kw):
         """(rp_net, rp_bwd, tensors to keep alive) of an adjoint sweep -- the arguments :meth:`backward` would hand to the
         library -- for callers that drive the step-wise entry points themselves (sharded.simulate_sharded_backward)."""
-        return self.backward(_args_only=True, **kw)
+        return self.backward(_args_only=kw.pop("_args_only", True), **kw)
 
     def outer_accum(self, alpha: float, A: torch.Tensor, B: torch.Tensor, Cmat: torch.Tensor):
         """Cmat += alpha * A^T @ B on the matrix cores (A, B: [T, n])."""
@@ -712,6 +717,48 @@ def forward_coupled(members: list) -> list:
     first = members[0]["pop"]
     first.backend.forward_coupled(arr, count, first.device)
     return [pop._finish_run(net, run, sampling, keep) for pop, net, run, sampling, keep in built]
+
+
+def backward_coupled(members: list) -> list:
+    """The adjoint of a :func:`forward_coupled` window in one library call (rp_backward_coupled): every step of the
+    backward sweep first carries the input gradient of every edge's target through W_e^T into the output gradient of its
+    source, then steps every member's own adjoint.
+
+    ``members`` (the order of the forward call): dicts with ``pop``, ``bwd`` (keyword arguments of
+    :meth:`Population.backward`; ``grad_out`` [T, rows] is required -- and written -- for every member an edge reads,
+    ``grad_x`` for every member with edges) and ``edges`` as in :func:`forward_coupled`.  Returns the tensors to keep
+    alive until the stream has run the sweep."""
+    count = len(members)
+    arr = (_abi.RpBwdMember * count)()
+    keep_all = []
+    work_floats = 0
+    for m, spec in enumerate(members):
+        pop: Population = spec["pop"]
+        for We, source, _ in spec.get("edges") or []:
+            src: Population = members[source]["pop"]
+            if We.dim() != 2 or We.shape != (pop.rows, src.n) or We.stride(1) != 1 or We.dtype != torch.float32 \
+                    or We.device != pop.device:
+                raise RuntimeError(f"member {m}: an edge matrix must be a float32 [{pop.rows}, {src.n}] matrix with unit "
+                                   f"column stride on {pop.device}")
+            work_floats = max(work_floats, pop.backend.shard_partial_rows(src.n, pop.rows) * src.n)
+    first: Population = members[0]["pop"]
+    work = torch.empty(max(work_floats, 4), dtype=torch.float32, device=first.device)
+    for m, spec in enumerate(members):
+        pop = spec["pop"]
+        net, b, keep = pop._backward_args(_args_only="stepwise", **spec["bwd"])
+        z = torch.empty(pop.n, dtype=torch.float32, device=pop.device)
+        edges = spec.get("edges") or []
+        arr[m].net, arr[m].bwd = C.addressof(net), C.addressof(b)
+        arr[m].n_edges = len(edges)
+        for e, (We, source, mode) in enumerate(edges):
+            arr[m].edge_w[e], arr[m].edge_ld[e] = We.data_ptr(), We.stride(0)
+            arr[m].edge_source[e], arr[m].edge_mode[e] = int(source), int(mode)
+        arr[m].edge_work = work.data_ptr()
+        arr[m].z = z.data_ptr()
+        keep_all.append((net, b, keep, z, [We for We, _, _ in edges]))
+    first.backend.backward_coupled(arr, count, first.device)
+    keep_all.append(work)
+    return keep_all
 
 
 class BatchedPopulation:

@@ -27,8 +27,113 @@ from networkx import DiGraph, ancestors, descendants, topological_sort
 from . import _abi
 from .edges import Linear
 from .network import _WINDOW_BYTES, Network
-from .nodes import InstantNode, RateNet, SpikeResetNet
+from .nodes import InstantNode, RateNet, SpikeResetNet, _RateWindow
 from .observer import Observer
+
+
+class _CoupledWindow(torch.autograd.Function):
+    """T Euler steps of SEVERAL rate populations joined by dense edges -- cycles through feedback edges included -- as ONE
+    autograd node: forward = rp_forward_coupled with every member's window stored, backward = rp_backward_coupled (one
+    library call for the whole sweep: per step the input gradients go back through the edge matrices into the sources'
+    output gradients, then every member's own adjoint step) + the MFMA GEMMs of the weight gradients.  Replaces autograd
+    over the per-step graph walk (reference rectipy/network.py:1028-1040 with 1322-1357).
+
+    Inputs after (net, plan, steps, a): per population x | None, v_in, W, tau, k, eta (+ r_max, s, v0 of the sigmoid), then
+    the edge matrices in plan order.  Outputs: per population its output trajectory [steps, N] and its final state."""
+
+    @staticmethod
+    def _layout(net, plan):
+        out, i = [], 4
+        for p in plan["pops"]:
+            n_act = len(_RateWindow.ACT_PARAMS) if net.get_node(p)._pop.model == "li_sigmoid" else 0
+            out.append((i, n_act))
+            i += 6 + n_act
+        return out, i
+
+    @staticmethod
+    def forward(ctx, net, plan, steps, a, *flat):
+        pops = plan["pops"]
+        layout, _ = _CoupledWindow._layout(net, plan)
+        stored, xin, widths = {}, {}, {}
+        for p, (i, _) in zip(pops, layout):
+            pop = net.get_node(p)._pop
+            x, k = flat[i - 4], flat[i - 4 + 4]
+            f32 = dict(dtype=torch.float32, device=pop.device)
+            stored[p] = dict(save_v=torch.empty(steps, pop.rows, **f32), save_src=torch.empty(steps, pop.rows, **f32),
+                             save_acc=torch.empty(steps, pop.rows, **f32) if k.requires_grad else None)
+            xin[p] = None if x is None else x.detach()
+            widths[p] = None if x is None else x.shape[1]
+        net._coupled_steps(plan, xin, steps, a, set(), {}, None, 0, 1, stored=stored)
+        outs = []
+        for p in pops:
+            node = net.get_node(p)
+            node._last_window = (stored[p]["save_v"], stored[p]["save_src"])
+            out = stored[p]["save_src"] if node._out_code == _abi.RP_OUT_SOURCE else stored[p]["save_v"]
+            outs += [out.clone(), node._pop.v.clone()]
+        ctx.net, ctx.plan, ctx.steps, ctx.stored, ctx.widths = net, plan, steps, stored, widths
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g):
+        from .engine import backward_coupled
+        net, plan, T, stored = ctx.net, ctx.plan, ctx.steps, ctx.stored
+        pops = plan["pops"]
+        index = {p: i for i, p in enumerate(pops)}
+        need = ctx.needs_input_grad
+        layout, first_edge = _CoupledWindow._layout(net, plan)
+        read = {s_ for p in pops for s_, _ in plan["edges"][p]}
+        members, res = [], []
+        for m, (p, (i, n_act)) in enumerate(zip(pops, layout)):
+            node = net.get_node(p)
+            pop = node._pop
+            N = pop.rows
+            f32 = dict(dtype=torch.float32, device=pop.device)
+            g_traj, g_vend = g[2 * m], g[2 * m + 1]
+            R = dict(lam=torch.zeros(N, **f32) if g_vend is None else g_vend.detach().to(**f32).clone().contiguous(),
+                     u=torch.empty(T, N, **f32), tau=torch.zeros(N, **f32) if need[i + 3] else None,
+                     k=torch.zeros(N, **f32) if need[i + 4] else None, eta=torch.zeros(N, **f32) if need[i + 5] else None,
+                     gx=torch.empty(T, N, **f32) if need[i] or plan["edges"][p] else None,
+                     act={name: torch.zeros(N, **f32) for j, name in enumerate(_RateWindow.ACT_PARAMS[:n_act]) if need[i + 6 + j]})
+            # the sweep adds what comes back through the edges into the output gradient of their sources: a private copy
+            if p in read:
+                R["g_out"] = torch.zeros(T, N, **f32) if g_traj is None else g_traj.detach().to(**f32).clone().contiguous()
+            else:
+                R["g_out"] = None if g_traj is None else g_traj.detach().to(**f32).contiguous()
+            res.append(R)
+            members.append(dict(pop=pop, edges=[(net.get_edge(s_, p).weights.detach(), index[s_], mode) for s_, mode in plan["edges"][p]],
+                                bwd=dict(traj_v=stored[p]["save_v"], traj_r=stored[p]["save_src"], grad_out=R["g_out"],
+                                         grad_var=node._out_code, lam=R["lam"], u_traj=R["u"], traj_acc=stored[p]["save_acc"],
+                                         grad_tau=R["tau"], grad_k=R["k"], grad_eta=R["eta"], grad_x=R["gx"],
+                                         grad_params=R["act"])))
+        keep = backward_coupled(members)
+        grads = [None] * len(need)
+        for m, (p, (i, n_act)) in enumerate(zip(pops, layout)):
+            pop, R = net.get_node(p)._pop, res[m]
+            if need[i]:
+                grads[i] = R["gx"].sum(dim=1, keepdim=True) if ctx.widths[p] == 1 else R["gx"]
+            if need[i + 1]:
+                grads[i + 1] = R["lam"]
+            if need[i + 2]:
+                grads[i + 2] = pop.outer_product(pop.dt, R["u"], stored[p]["save_src"])
+            grads[i + 3], grads[i + 4], grads[i + 5] = R["tau"], R["k"], R["eta"]
+            for j, name in enumerate(_RateWindow.ACT_PARAMS[:n_act]):
+                grads[i + 6 + j] = R["act"].get(name)
+        e = first_edge
+        for m, p in enumerate(pops):
+            pop = net.get_node(p)._pop
+            for s_, mode in plan["edges"][p]:
+                if need[e]:  # dW_e = sum_t gx_p(t) (x) out_s(t): every edge of a rate circuit reads the source's step-t output
+                    src = net.get_node(s_)
+                    out_s = stored[s_]["save_src"] if src._out_code == _abi.RP_OUT_SOURCE else stored[s_]["save_v"]
+                    gW = torch.empty(pop.rows, src._pop.rows, dtype=torch.float32, device=pop.device)
+                    gx = res[m]["gx"]
+                    pop.backend.outer_store_rect(pop.rows, src._pop.rows, T, 1.0, gx.data_ptr(), gx.stride(0) if T > 1 else pop.rows,
+                                                 out_s.data_ptr(), out_s.stride(0) if T > 1 else src._pop.rows, gW.data_ptr(),
+                                                 gW.stride(0), pop.device)
+                    grads[e] = gW
+                e += 1
+        del keep
+        return tuple(grads)
 
 
 class FeedbackNetwork(Network):
@@ -185,23 +290,67 @@ class FeedbackNetwork(Network):
             slots.append(one[0])
         return dict(pre=pre, pops=pops, post=post, edges=edges, slots=slots)
 
+    def _coupled_grad_plan(self) -> Optional[dict]:
+        """The coupled plan if its adjoint runs as one call too (rp_backward_coupled): rate populations, every edge reading
+        what its source emits at the SAME step -- feed-forward edges, and feedback edges from populations stepped later (the
+        usual direction).  Spiking members and a feedback edge from an EARLIER population (it reads a post-update state)
+        keep the per-step autograd."""
+        plan = self._coupled_plan([])
+        if plan is None or getattr(self, "_force_stepwise_adjoint", False):
+            return None
+        order = {p: i for i, p in enumerate(plan["pops"])}
+        for p in plan["pops"]:
+            node = self.get_node(p)
+            if isinstance(node, SpikeResetNet) or node._out_slice is not None:
+                return None
+            for s_, mode in plan["edges"][p]:
+                if mode == _abi.RP_EDGE_LAG or (mode == _abi.RP_EDGE_LIVE and order[s_] <= order[p]):
+                    return None
+        return plan
+
+    def _coupled_grad_outputs(self, plan: dict, inputs_ab: torch.Tensor, a: int) -> torch.Tensor:
+        """The output node's per-step outputs over the window [a, a + len), with the graph of ONE autograd node for all
+        populations (`_CoupledWindow`) between the torch ops of the input layers and the read-outs."""
+        pops = plan["pops"]
+        xin = self._coupled_inputs(plan, inputs_ab)
+        flat = []
+        for p in pops:
+            node: RateNet = self.get_node(p)
+            pop = node._pop
+            node._before_step()
+            v_in = node._y_grad
+            if v_in is None:
+                v_in = pop.v.detach().clone().requires_grad_(node._y_requires_grad)
+            act = [pop.params[q] for q in _RateWindow.ACT_PARAMS] if pop.model == "li_sigmoid" else []
+            flat += [xin[p], v_in, pop.W, pop.params["tau"], pop.params["k"], pop.params["eta"], *act]
+        for p in pops:
+            flat += [self.get_edge(s_, p).weights for s_, _ in plan["edges"][p]]
+        res = _CoupledWindow.apply(self, plan, inputs_ab.shape[0], a, *flat)
+        outs = {}
+        for i, p in enumerate(pops):
+            outs[p] = res[2 * i]
+            self.get_node(p)._y_grad = res[2 * i + 1]
+        for n in plan["post"]:
+            X = None
+            for p_ in self.graph.predecessors(n):
+                contrib = self._edge_window(self.get_edge(p_, n), outs[p_])
+                X = contrib if X is None else X + contrib
+            outs[n] = self.get_node(n).forward(X)
+        for n in self._order:
+            self[n]["out"] = None
+        self._prev_out = {}
+        return outs[self._out_node]
+
     def _coupled_wants_grad(self, inputs) -> bool:
         if not torch.is_grad_enabled():
             return False
         return bool(inputs.requires_grad or any(p.requires_grad for p in self.parameters()) or
                     any(self.get_node(n)._wants_grad(None) for n in self._order if isinstance(self.get_node(n), RateNet)))
 
-    def _coupled_window(self, plan: dict, inputs_ab: torch.Tensor, a: int, want_traj: set, rec: dict, sampler: Optional[dict],
-                        cutoff: int, sampling_steps: int) -> dict:
-        """Steps [a, a + len) of every population in one (spiking members: two) library calls.  `want_traj`: populations
-        whose per-step output is needed afterwards; `rec`: label -> {slot: buffer, "idx": next row}; `sampler`: the
-        population whose output is sampled in-kernel ({"label", "samples", "idx"}).  Returns label -> [steps, N] trajectory."""
-        from .engine import forward_coupled
-        steps = inputs_ab.shape[0]
-        pops: List[str] = plan["pops"]
-        index = {p: i for i, p in enumerate(pops)}
-        # activation nodes upstream of the populations: the whole window at once
-        outs = {}
+    def _coupled_inputs(self, plan: dict, inputs_ab: torch.Tensor) -> dict:
+        """What enters every population over the window from OUTSIDE the coupled populations: the external input and
+        the activation nodes upstream, evaluated for the whole window at once (torch ops: a gradient passes)."""
+        outs, xin = {}, {}
         for n in plan["pre"]:
             preds = list(self.graph.predecessors(n))
             X = inputs_ab if not preds else None
@@ -209,23 +358,41 @@ class FeedbackNetwork(Network):
                 contrib = self._edge_window(self.get_edge(p_, n), outs[p_])
                 X = contrib if X is None else X + contrib
             outs[n] = self.get_node(n).forward(X)
+        for p in plan["pops"]:
+            X = inputs_ab if p == self._in_node else None
+            for p_ in self.graph.predecessors(p):
+                if p_ in outs and not self.graph[p_][p].get("feedback"):
+                    contrib = self._edge_window(self.get_edge(p_, p), outs[p_])
+                    X = contrib if X is None else X + contrib
+            xin[p] = None if X is None else self._fit_width(X, self.get_node(p)._pop.rows)
+        return xin
+
+    def _coupled_window(self, plan: dict, inputs_ab: torch.Tensor, a: int, want_traj: set, rec: dict, sampler: Optional[dict],
+                        cutoff: int, sampling_steps: int) -> dict:
+        """Steps [a, a + len) of every population in one (spiking members: two) library calls.  `want_traj`: populations
+        whose per-step output is needed afterwards; `rec`: label -> {slot: buffer, "idx": next row}; `sampler`: the
+        population whose output is sampled in-kernel ({"label", "samples", "idx"}).  Returns label -> [steps, N] trajectory."""
+        xin = {p: None if X is None else X.detach() for p, X in self._coupled_inputs(plan, inputs_ab).items()}
+        return self._coupled_steps(plan, xin, inputs_ab.shape[0], a, want_traj, rec, sampler, cutoff, sampling_steps)
+
+    def _coupled_steps(self, plan: dict, xin: dict, steps: int, a: int, want_traj: set, rec: dict, sampler: Optional[dict],
+                       cutoff: int, sampling_steps: int, stored: Optional[dict] = None) -> dict:
+        """The library call(s) of `_coupled_window`; `xin`: label -> [steps, rows | 1] input (or None) without a graph;
+        `stored`: label -> keyword arguments capturing the window for the adjoint (save_v / save_src / save_acc)."""
+        from .engine import forward_coupled
+        pops: List[str] = plan["pops"]
+        index = {p: i for i, p in enumerate(pops)}
         spiking = any(isinstance(self.get_node(p), SpikeResetNet) for p in pops)
         lag_read = {s_ for p in pops for s_, mode in plan["edges"][p] if mode == _abi.RP_EDGE_LAG}
         # every population that is read through its state variable gets the history ring: RP_EDGE_OUT edges need it, and
         # with it on the RP_EDGE_LIVE sources too the library may step all members in ONE launch (rp_forward_coupled)
         hist_read = lag_read | {s_ for p in pops for s_, mode in plan["edges"][p]
                                 if self.get_node(s_)._out_code == _abi.RP_OUT_STATE0}
-        trajs, xin = {}, {}
+        trajs = {}
         for p in pops:
             node: RateNet = self.get_node(p)
             pop = node._pop
             node._coupled_begin()
-            X = inputs_ab if p == self._in_node else None
-            for p_ in self.graph.predecessors(p):
-                if p_ in outs and not self.graph[p_][p].get("feedback"):
-                    contrib = self._edge_window(self.get_edge(p_, p), outs[p_])
-                    X = contrib if X is None else X + contrib
-            xin[p] = None if X is None else self._fit_width(X.detach(), pop.rows)
             if p in want_traj:
                 trajs[p] = torch.empty(steps, pop.rows, dtype=torch.float32, device=pop.device)
             if p in hist_read:
@@ -252,6 +419,8 @@ class FeedbackNetwork(Network):
                         kw.update(samples=sampler["samples"], sample_idx=sampler["idx"])
                 if p in hist_read:
                     kw["hist"] = node._hist
+                if stored and p in stored:
+                    kw.update({k_: v_[t0:t1] for k_, v_ in stored[p].items() if v_ is not None})
                 if last and isinstance(node, SpikeResetNet):
                     saves[p] = node._state_bufs()
                     kw.update(save_v=saves[p][0], save_src=saves[p][1], save_aux=saves[p][2], save_aux2=saves[p][3])

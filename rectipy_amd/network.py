@@ -431,6 +431,9 @@ class Network:
         """Graphs with cycles (feedback edges) exist in :class:`rectipy_amd.feedback.FeedbackNetwork` only."""
         return None
 
+    def _coupled_grad_plan(self):
+        return None
+
     # ---- B trajectories through one pass over W -------------------------------------------------------
     def run_batch(self, inputs, sampling_steps: int = 1, cutoff: int = 0, y0=None, verbose: bool = False,
                   mfma: Optional[bool] = None, exact: bool = False) -> List[Observer]:
@@ -855,10 +858,12 @@ class Network:
         rec_vars = list(obs.recorded_state_variables)
         steps = inp.shape[0]
         windows = plan is None and not rec_vars and self._dag_plan([]) is not None  # several populations, no cycles
-        if (plan is None and not windows) or rec_vars:
+        # populations joined by dense edges, cycles included (FeedbackNetwork): forward and adjoint one call per window each
+        coupled = self._coupled_grad_plan() if plan is None and not windows and not rec_vars else None
+        if (plan is None and not windows and coupled is None) or rec_vars:
             return self._bptt_stepwise(inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps,
                                        optim_steps, verbose)
-        if not windows:
+        if not windows and coupled is None:
             pre, label, post = plan
             rnn: RateNet = self.get_node(label)
             N = rnn._pop.rows
@@ -876,6 +881,8 @@ class Network:
             with torch.enable_grad():
                 if windows:
                     preds = self._window_outputs(inp[a:b], a, True, {}, 0, 1)[self._out_node]
+                elif coupled is not None:
+                    preds = self._coupled_grad_outputs(coupled, inp[a:b], a)
                 else:
                     X = self._apply_chain(pre, inp[a:b], None, label) if pre else inp[a:b]
                     # the adjoint sweep runs only if a gradient has to pass INTO the population: its own trainable

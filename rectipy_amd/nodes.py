@@ -378,7 +378,15 @@ class RateNet:
         if item in self._param_map:
             return self._tensor(self._param_map[item])
         if item == "out" and not self._spiking and self._out_code == _abi.RP_OUT_SOURCE:
-            return self._pop.source_local.clone()   # output variable r = act(v) of the current state
+            r = self._pop.source_local.clone()   # output variable r = act(v) of the current state
+            v = self._pop.v if self._y_grad is None else self._y_grad
+            par = self._pop.params
+            sigmoid = self._pop.model == "li_sigmoid"
+            if torch.is_grad_enabled() and (v.requires_grad or (sigmoid and any(par[q].requires_grad for q in _RateWindow.ACT_PARAMS))):
+                # a feedback edge reads this inside a recorded graph: the kernel's value, the gradient of act(v)
+                g = par["r_max"] / (1.0 + torch.exp(par["s"] * (par["v0"] - v))) if sigmoid else torch.tanh(v)
+                r = g + (r - g).detach()
+            return r
         if item in self._template.derived:
             # r = act(v) lives in a ping-pong buffer the kernels overwrite two steps later; the reference computes a
             # fresh tensor per step, so hand out a copy that a per-step recorder may keep (observer.py:100-101)

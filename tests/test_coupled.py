@@ -468,3 +468,196 @@ def test_g36_feedback_network_at_kernel_sizes_matches_the_reference(target, monk
     assert calls == [2, 2]
     out = obs.to_numpy("out")
     assert np.abs(out[::10] - g["qif_out_f64"]).max() < 5e-5 and np.abs(out[-1] - g["qif_final_f64"]).max() < 5e-5
+
+
+# ---- adjoint of a coupled window (rp_backward_coupled) -----------------------------------------------------------------
+def torch_walk_rate(pops, edges, out_vars, x, T, leaves):
+    """float64 torch restatement of the walk for rate members, differentiable in `leaves` (per member: v0, W, tau, k, eta;
+    per edge: its matrix; the input x of member 0)."""
+    v = [leaves["v0"][m] for m in range(len(pops))]
+    outs = [[] for _ in pops]
+    for t in range(T):
+        ret = {}
+        for m, p in enumerate(pops):
+            E = 0.0
+            for s_ in range(len(pops)):
+                if s_ == m:
+                    continue
+                if s_ < m:
+                    vec = ret[s_]
+                else:
+                    vec = v[s_] if out_vars[s_] == _abi.RP_OUT_STATE0 else torch.tanh(v[s_])
+                E = E + leaves["edges"][(s_, m)] @ vec
+            I = (leaves["x"][t] if m == 0 else 0.0) + E
+            r = torch.tanh(v[m])
+            ret[m] = v[m] if out_vars[m] == _abi.RP_OUT_STATE0 else r
+            v[m] = v[m] + p.dt * (-v[m] / leaves["tau"][m] + leaves["k"][m] * (leaves["W"][m] @ r) + I + leaves["eta"][m])
+            outs[m].append(ret[m])
+    return [torch.stack(o) for o in outs], v
+
+
+def coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev):
+    """Forward with the window stored, then rp_backward_coupled; returns the gradients per member / edge."""
+    from rectipy_amd.engine import backward_coupled
+    n_m = len(pops)
+    f32 = dict(dtype=torch.float32, device=dev)
+    saved = [dict(v=torch.zeros(T, p.rows, **f32), r=torch.zeros(T, p.rows, **f32), acc=torch.zeros(T, p.rows, **f32)) for p in pops]
+    hist = [[torch.zeros(p.rows, **f32) for _ in range(3)] for p in pops]
+    members = []
+    for m, p in enumerate(pops):
+        run = dict(steps=T, step0=0, out_var=out_vars[m], save_v=saved[m]["v"], save_src=saved[m]["r"], save_acc=saved[m]["acc"],
+                   hist=hist[m])
+        if m == 0:
+            run["x"] = x
+        members.append(dict(pop=p, run=run, edges=[(edges[(s_, m)], s_, _abi.RP_EDGE_OUT if s_ < m else _abi.RP_EDGE_LIVE)
+                                                   for s_ in range(n_m) if s_ != m]))
+    forward_coupled(members)
+    res, bw = [], []
+    for m, p in enumerate(pops):
+        N = p.rows
+        R = dict(lam=g_vend[m].to(**f32).clone(), u=torch.zeros(T, N, **f32), g_out=g_out[m].to(**f32).clone(),
+                 tau=torch.zeros(N, **f32), k=torch.zeros(N, **f32), eta=torch.zeros(N, **f32), gx=torch.zeros(T, N, **f32))
+        res.append(R)
+        bw.append(dict(pop=p, edges=members[m]["edges"],
+                       bwd=dict(traj_v=saved[m]["v"], traj_r=saved[m]["r"], grad_out=R["g_out"], grad_var=out_vars[m], lam=R["lam"],
+                                u_traj=R["u"], traj_acc=saved[m]["acc"], grad_tau=R["tau"], grad_k=R["k"], grad_eta=R["eta"],
+                                grad_x=R["gx"])))
+    keep = backward_coupled(bw)
+    del keep
+    for m, p in enumerate(pops):
+        res[m]["W"] = p.dt * res[m]["u"].T @ saved[m]["r"]
+        res[m]["out"] = saved[m]["v"] if out_vars[m] == _abi.RP_OUT_STATE0 else saved[m]["r"]
+    g_edges = {(s_, m): res[m]["gx"].T @ res[s_]["out"] for (s_, m) in edges}
+    return res, g_edges
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("sizes,out_vars", [((24, 40, 16), (0, 0, 1)), ((17, 30), (1, 0)), ((64,), (1,)), ((260, 136, 72), (1, 1, 0))])
+def test_coupled_adjoint_against_float64_autograd(target, sizes, out_vars):
+    dev, T = target["device"], 23
+    models = ("li_tanh",) * len(sizes)
+    pops, edges = circuit(sizes, models, 5, dev, target["backend"])
+    gen = torch.Generator().manual_seed(9)
+    x = (torch.randn(T, sizes[0], generator=gen) * 0.5).to(dev)
+    g_out = [torch.randn(T, n, generator=gen) for n in sizes]
+    g_vend = [torch.randn(n, generator=gen) for n in sizes]
+    d = lambda t: t.detach().cpu().double().clone().requires_grad_(True)
+    leaves = dict(v0=[d(p.v) for p in pops], W=[d(p.W) for p in pops], tau=[d(p.params["tau"]) for p in pops],
+                  k=[d(p.params["k"]) for p in pops], eta=[d(p.params["eta"]) for p in pops],
+                  edges={key: d(We) for key, We in edges.items()}, x=d(x))
+    outs, v_end = torch_walk_rate(pops, edges, out_vars, x, T, leaves)
+    loss = sum((o * g.double()).sum() for o, g in zip(outs, g_out)) + sum((v * g.double()).sum() for v, g in zip(v_end, g_vend))
+    loss.backward()
+    res, g_edges = coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev)
+
+    def close(got, want, what):
+        got, want = got.detach().cpu().double(), want.detach()
+        scale = float(want.abs().max()) + 1e-12
+        assert float((got - want).abs().max()) <= 2e-4 * scale, f"{what}: {float((got - want).abs().max())} of {scale}"
+
+    for m in range(len(sizes)):
+        close(res[m]["lam"], leaves["v0"][m].grad, f"member {m} d/dv0")
+        close(res[m]["W"], leaves["W"][m].grad, f"member {m} dW")
+        for name in ("tau", "k", "eta"):
+            close(res[m][name], leaves[name][m].grad, f"member {m} d{name}")
+    close(res[0]["gx"], leaves["x"].grad, "d/dx")
+    for key in edges:
+        close(g_edges[key], leaves["edges"][key].grad, f"edge {key}")
+
+
+def build_trained(target, stepwise, sizes=(12, 20, 8), sigmoid=False, out_r=False, fb_to_later=False):
+    """inp -> a -> b (-> c) -> out with feedback edges from the last population to the first (and from c to b); everything
+    trainable: W, tau, k and eta of the populations, the edges between them, the input layer and the read-out."""
+    net = FeedbackNetwork(1e-2, **target)
+    r = np.random.default_rng(3)
+    net.add_func_node("inp", 3, "tanh")
+    labs = "abc"[:len(sizes)]
+    SIG = "neuron_model_templates.rate_neurons.leaky_integrator.sigmoid"
+    for lab, n in zip(labs, sizes):
+        W = r.standard_normal((n, n)) / np.sqrt(n)
+        if sigmoid and lab == "b":
+            net.add_diffeq_node(lab, SIG, weights=W, source_var="sigmoid_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                                output_var="li_op/v", dtype=torch.float32,
+                                node_vars={"all/li_op/v": r.standard_normal(n) * 0.5, "all/li_op/tau": r.uniform(0.5, 2, n)},
+                                train_params=["weights", "li_op/tau", "sigmoid_op/s"])
+        else:
+            net.add_diffeq_node(lab, TANH, weights=W, source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                                output_var="tanh_op/r" if out_r else "li_op/v", dtype=torch.float32,
+                                node_vars={"all/li_op/v": r.standard_normal(n) * 0.5, "all/li_op/tau": r.uniform(0.5, 2, n)},
+                                train_params=["weights", "li_op/tau", "li_op/k", "li_op/eta"])
+    net.add_func_node("out", 2, "identity")
+    order = ["inp"] + list(labs) + ["out"]
+    width = dict(zip(labs, sizes), inp=3, out=2)
+    for s_, t_ in zip(order[:-1], order[1:]):
+        net.add_edge(s_, t_, weights=r.standard_normal((width[t_], width[s_])) * 0.5, train="gd")
+    net.add_edge(labs[-1], labs[0], weights=r.standard_normal((sizes[0], sizes[-1])) * 0.5, feedback=True, train="gd")
+    if len(labs) > 2:
+        net.add_edge("c", "b", weights=r.standard_normal((sizes[1], sizes[2])) * 0.5, feedback=True, train="gd")
+    if fb_to_later:  # reads a post-update state: no fused adjoint
+        net.add_edge("a", labs[-1], weights=r.standard_normal((sizes[-1], sizes[0])) * 0.5, feedback=True)
+    net._force_stepwise_adjoint = stepwise
+    return net
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("cfg", [dict(), dict(sizes=(16, 24), out_r=True), dict(sigmoid=True), dict(sizes=(260, 136), lr=1e-3)],
+                         ids=["three", "two_rates_out", "sigmoid", "wide"])
+def test_fit_bptt_through_cycles_is_one_forward_and_one_adjoint_call_per_window(target, cfg, monkeypatch):
+    """FeedbackNetwork.fit_bptt: every window is ONE rp_forward_coupled and ONE rp_backward_coupled call; the parameters
+    after three SGD windows (and the recorded losses) equal those of autograd over the per-step walk."""
+    fwd, bwd = [], []
+    real_f, real_b = engine.forward_coupled, engine.backward_coupled
+    monkeypatch.setattr(engine, "forward_coupled", lambda members: fwd.append(len(members)) or real_f(members))
+    monkeypatch.setattr(engine, "backward_coupled", lambda members: bwd.append(len(members)) or real_b(members))
+    T, win = 70, 20
+    r = np.random.default_rng(0)
+    x, y = r.standard_normal((T, 3)).astype(np.float32), r.standard_normal((T, 2)).astype(np.float32) * 0.3
+    res = []
+    for stepwise in (True, False):
+        fwd.clear(), bwd.clear()
+        net = build_trained(target, stepwise, **{k_: v_ for k_, v_ in cfg.items() if k_ != "lr"})
+        obs = net.fit_bptt(x, y, optimizer="sgd", lr=cfg.get("lr", 0.05), update_steps=win, sampling_steps=1, verbose=False)
+        n_pop = len(cfg.get("sizes", (12, 20, 8)))
+        assert (fwd, bwd) == (([], []) if stepwise else ([n_pop] * 4, [n_pop] * 3)), (fwd, bwd)
+        res.append(([p.detach().cpu().numpy().copy() for p in net.parameters()], obs.to_numpy("loss"), obs.to_numpy("out"),
+                    {k_: v_.detach().cpu().numpy().copy() for k_, v_ in net.state.items()}))
+    assert len(res[0][0]) == len(res[1][0]) >= 10
+    for a, b in zip(res[0][0], res[1][0]):
+        assert a.shape == b.shape and np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), np.abs(a - b).max()
+    assert np.abs(res[0][1] - res[1][1]).max() < 1e-5 * max(1.0, res[0][1].max()) and np.abs(res[0][2] - res[1][2]).max() < 2e-5 * max(1.0, np.abs(res[0][2]).max())
+    for k_ in res[0][3]:
+        assert np.abs(res[0][3][k_] - res[1][3][k_]).max() < 2e-5, k_
+
+
+def test_adjoint_that_stays_on_the_walk(oracle_backend, monkeypatch):
+    """A feedback edge from an EARLIER population delivers a post-update state: fit_bptt keeps the per-step autograd."""
+    bwd = []
+    real_b = engine.backward_coupled
+    monkeypatch.setattr(engine, "backward_coupled", lambda members: bwd.append(len(members)) or real_b(members))
+    net = build_trained(dict(device="cpu", backend=oracle_backend), False, fb_to_later=True)
+    r = np.random.default_rng(0)
+    net.fit_bptt(r.standard_normal((20, 3)).astype(np.float32), r.standard_normal((20, 2)).astype(np.float32), optimizer="sgd",
+                 lr=0.05, update_steps=10, sampling_steps=1, verbose=False)
+    assert bwd == [] and net._coupled_grad_plan() is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes,out_vars", [((24, 40, 16), (0, 0, 1)), ((17, 30), (1, 0)), ((260, 136, 72), (1, 1, 0)),
+                                            ((1024, 2052, 512), (0, 1, 1)), ((4100, 520), (1, 0))])
+def test_hip_coupled_adjoint_bit_exact(oracle_backend, hip_device, sizes, out_vars):
+    """rp_backward_coupled on the GPU against the C oracle: adjoint states, per-step u, input gradients, the output
+    gradients the edges accumulate into and the per-neuron parameter gradients, bit for bit."""
+    T = 19
+    models = ("li_tanh",) * len(sizes)
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(T, sizes[0], generator=gen) * 0.5
+    g_out = [torch.randn(T, n, generator=gen) for n in sizes]
+    g_vend = [torch.randn(n, generator=gen) for n in sizes]
+    got = []
+    for dev, backend in (("cpu", oracle_backend), (hip_device, None)):
+        pops, edges = circuit(sizes, models, 5, dev, backend)
+        res, _ = coupled_adjoint(pops, edges, out_vars, x.to(dev), T, g_out, g_vend, dev)
+        got.append(res)
+    for m in range(len(sizes)):
+        for key in ("lam", "u", "gx", "g_out", "tau", "k", "eta"):
+            assert_same(got[0][m][key], got[1][m][key], f"member {m} {key}")
