@@ -341,6 +341,20 @@ class FeedbackNetwork(Network):
         self._prev_out = {}
         return outs[self._out_node]
 
+    def _run_coupled_grad(self, plan: dict, inputs, sampling_steps, cutoff, truncate_steps, obs: Observer, verbose):
+        """`run` with a gradient: windows of `truncate_steps` steps, each ONE autograd node over all populations."""
+        T = inputs.shape[0]
+        sample_at = self._sample_steps(T, cutoff, sampling_steps)
+        pending = []
+        for a in range(0, T, truncate_steps):
+            b = min(a + truncate_steps, T)
+            pending.append(self._coupled_grad_outputs(plan, inputs[a:b], a))
+            if truncate_steps < T and b - a == truncate_steps:
+                self.detach()
+            if verbose:
+                print(f"Progress: {b}/{T} integration steps finished.")
+        obs.record_block(sample_at, self._buffer_means(torch.cat(pending), sample_at, cutoff), 0.0, [])
+
     def _coupled_wants_grad(self, inputs) -> bool:
         if not torch.is_grad_enabled():
             return False

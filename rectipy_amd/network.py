@@ -424,6 +424,10 @@ class Network:
                     with torch.no_grad():
                         self._run_coupled(coupled, inputs, sampling_steps, cutoff, obs, rec_vars, verbose)
                     return obs
+                grad_plan = None if rec_vars else self._coupled_grad_plan()
+                if grad_plan is not None:  # ... and the graph of one autograd node per window (rp_backward_coupled)
+                    self._run_coupled_grad(grad_plan, inputs, sampling_steps, cutoff, truncate_steps, obs, verbose)
+                    return obs
         self._run_stepwise(inputs, sampling_steps, cutoff, truncate_steps, obs, rec_vars, enable_grad, verbose)
         return obs
 

@@ -661,3 +661,32 @@ def test_hip_coupled_adjoint_bit_exact(oracle_backend, hip_device, sizes, out_va
     for m in range(len(sizes)):
         for key in ("lam", "u", "gx", "g_out", "tau", "k", "eta"):
             assert_same(got[0][m][key], got[1][m][key], f"member {m} {key}")
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_run_with_gradient_and_epoch_fit_take_the_fused_adjoint(target, monkeypatch):
+    """`run(enable_grad=True, truncate_steps=...)` and `fit_bptt` with list inputs (one update per epoch on the sampled
+    outputs): windows of the coupled autograd node; gradients and updates equal those of the per-step walk."""
+    bwd = []
+    real_b = engine.backward_coupled
+    monkeypatch.setattr(engine, "backward_coupled", lambda members: bwd.append(len(members)) or real_b(members))
+    r = np.random.default_rng(4)
+    T = 45
+    x, y = r.standard_normal((T, 3)).astype(np.float32), r.standard_normal((T, 2)).astype(np.float32) * 0.3
+    res = []
+    for stepwise in (True, False):
+        bwd.clear()
+        net = build_trained(target, stepwise, sizes=(16, 24))
+        obs = net.run(x, sampling_steps=2, cutoff=3, truncate_steps=20, verbose=False, enable_grad=True)
+        out = obs.stacked("out")
+        (out ** 2).sum().backward()
+        grads = [p.grad.detach().cpu().numpy().copy() for p in net.parameters()]
+        assert bwd == ([] if stepwise else [2] * 3), bwd   # three windows, cut from each other by truncate_steps
+        net = build_trained(target, stepwise, sizes=(16, 24))
+        obs2 = net.fit_bptt([x, x[:30]], [y[::2], y[:30:2]], optimizer="sgd", lr=0.05, sampling_steps=2, verbose=False)
+        res.append((out.detach().cpu().numpy(), grads, [p.detach().cpu().numpy().copy() for p in net.parameters()],
+                    np.asarray(obs2["epoch_loss"], dtype=np.float64)))
+    assert np.abs(res[0][0] - res[1][0]).max() < 2e-5
+    for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
+        assert a.shape == b.shape and np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), np.abs(a - b).max()
+    assert np.abs(res[0][3] - res[1][3]).max() < 1e-5
