@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 11
+#define RP_ABI_VERSION 12
 #define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0
@@ -235,6 +235,10 @@ typedef struct rp_run {
        slots so that, in the shared launch, step a can store the output of step a + 1 (its post-update value) while
        other members still read those of steps a and a - 1. */
     float* hist[3];
+    /* optional [steps x ldsave]: the node input I_t of every step -- the external input plus the edge sums, as the epilogue
+       received it.  The adjoint of a spiking population with edges needs it where it otherwise takes the window's external
+       input (rp_bwd.x, RP_X_FULL): rp_backward_coupled. */
+    float* save_in;
 } rp_run;
 
 /* what an edge of rp_forward_coupled reads from its source population q (q's output variable, rp_run.out_var) */

@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 11
+RP_ABI_VERSION = 12
 RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_MFMA16, RP_BATCH_SLOTS = 0, 1, 2, 32
 RP_COMM_RCCL, RP_COMM_DIRECT = 0, 1
 
@@ -115,6 +115,7 @@ class RpRun(C.Structure):
         ("edge_src", fp * RP_MAX_EDGES),
         ("edge_src_ld", C.c_int64 * RP_MAX_EDGES),
         ("hist", fp * 3),
+        ("save_in", fp),
     ]
 
 

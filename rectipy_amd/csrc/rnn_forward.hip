@@ -65,6 +65,7 @@ struct StepParams {
     float* save_state_t[RP_MAX_STATE];
     float* save_src_t;
     float* save_acc_t;
+    float* save_in_t;
     float* acc;
     int flags;
     float count;
@@ -153,6 +154,7 @@ __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum,
     const int gi = P.row0 + i;
     float I = input_current(P, i);
     if constexpr (EDGES) I = P.x_mode != RP_X_NONE ? I + esum : esum;
+    if (P.save_in_t) P.save_in_t[i] = I;
     if constexpr (MODEL >= RP_MODEL_QIF) {
         // SpikeResetNet.forward (nodes.py:382-392) with the field of the spiking template:
         //   QIF      qif.yaml:11-12     v' = (v^2 + eta + I)/tau + k s_in;          s' = -s/tau_s + spike
@@ -1009,7 +1011,7 @@ int check_run(const rp_net* net, const rp_run* run, bool coupled) {
         default: RP_FAIL(RP_ERR_ARG, "bad x_mode %d", run->x_mode);
     }
     if (run->traj && run->ldtraj < net->rows) RP_FAIL(RP_ERR_SHAPE, "ldtraj < rows");
-    bool any_save = run->save_src || run->save_acc;
+    bool any_save = run->save_src || run->save_acc || run->save_in;
     for (int q = 0; q < RP_MAX_STATE; ++q) any_save = any_save || run->save_state[q];
     if (any_save && run->ldsave < net->rows) RP_FAIL(RP_ERR_SHAPE, "ldsave < rows");
     bool any_rec = false;
@@ -1098,6 +1100,7 @@ void set_step(StepParams& P, const rp_net* net, rp_run* run, int t) {
         P.save_state_t[q] = run->save_state[q] ? run->save_state[q] + (int64_t)t * run->ldsave : nullptr;
     P.save_src_t = run->save_src ? run->save_src + (int64_t)t * run->ldsave : nullptr;
     P.save_acc_t = run->save_acc ? run->save_acc + (int64_t)t * run->ldsave : nullptr;
+    P.save_in_t = run->save_in ? run->save_in + (int64_t)t * run->ldsave : nullptr;
     P.t_abs = (int)t_abs;
     P.spike_src = t == 0 ? run->spike_src : nullptr;
     P.flags = 0;

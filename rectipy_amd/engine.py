@@ -420,7 +420,7 @@ class Population:
                 x_target: int = _abi.RP_XT_MEMBRANE, save_aux: Optional[torch.Tensor] = None,
                 save_aux2: Optional[torch.Tensor] = None, comm=None,
                 save_src_full: Optional[torch.Tensor] = None, spike_src: Optional[torch.Tensor] = None,
-                edges: Optional[list] = None, hist: Optional[list] = None) -> int:
+                edges: Optional[list] = None, hist: Optional[list] = None, save_in: Optional[torch.Tensor] = None) -> int:
         """Integrate ``steps`` Euler steps in one library call.  Returns the next sample index.
         ``comm`` (an ``RpComm``): this population is a row shard and every step ends with the in-library RCCL
         all-gather of the source vector (rp_forward_sharded).
@@ -431,7 +431,7 @@ class Population:
         """
         run, keep, sampling = self._make_run(steps, x, w_in, out_var, step0, cutoff, sampling_steps, samples, sample_idx,
                                              rec, traj, save_v, save_src, save_acc, spike_events, spike_count, x_target,
-                                             save_aux, save_aux2, save_src_full, spike_src, edges, hist)
+                                             save_aux, save_aux2, save_src_full, spike_src, edges, hist, save_in)
         net = self._net()
         if not self._tuned:  # static rule unless a measurement was asked for or this call is long enough to repay one
             tuning.prepare(self, net, steps)
@@ -451,7 +451,7 @@ class Population:
     def _make_run(self, steps, x=None, w_in=None, out_var=_abi.RP_OUT_STATE0, step0=0, cutoff=0, sampling_steps=1,
                   samples=None, sample_idx=0, rec=None, traj=None, save_v=None, save_src=None, save_acc=None,
                   spike_events=None, spike_count=None, x_target=_abi.RP_XT_MEMBRANE, save_aux=None, save_aux2=None,
-                  save_src_full=None, spike_src=None, edges=None, hist=None):
+                  save_src_full=None, spike_src=None, edges=None, hist=None, save_in=None):
         """The rp_run of one call (see :meth:`forward`): (run, tensors to keep alive until the call returned, sampling?).
         Edge sources given as ``None`` are left for rp_forward_coupled to fill in."""
         run = RpRun()
@@ -497,7 +497,8 @@ class Population:
 
         run.traj, run.ldtraj = rowbuf(traj, "traj", steps)
         ld_save = 0
-        for t, field in ((save_v, 0), (save_aux, 1), (save_aux2, 2), (save_src, "save_src"), (save_acc, "save_acc")):
+        for t, field in ((save_v, 0), (save_aux, 1), (save_aux2, 2), (save_src, "save_src"), (save_acc, "save_acc"),
+                         (save_in, "save_in")):
             p, ld = rowbuf(t, "save buffer", steps)
             if p is not None:
                 if ld_save and ld != ld_save:

@@ -32,45 +32,68 @@ from .observer import Observer
 
 
 class _CoupledWindow(torch.autograd.Function):
-    """T Euler steps of SEVERAL rate populations joined by dense edges -- cycles through feedback edges included -- as ONE
+    """T Euler steps of SEVERAL populations joined by dense edges -- cycles through feedback edges included -- as ONE
     autograd node: forward = rp_forward_coupled with every member's window stored, backward = rp_backward_coupled (one
     library call for the whole sweep: per step the input gradients go back through the edge matrices into the sources'
-    output gradients, then every member's own adjoint step) + the MFMA GEMMs of the weight gradients.  Replaces autograd
-    over the per-step graph walk (reference rectipy/network.py:1028-1040 with 1322-1357).
+    output gradients, then every member's own adjoint step; surrogate gradient for spiking members) + the MFMA GEMMs of
+    the weight gradients.  Replaces autograd over the per-step graph walk (reference rectipy/network.py:1028-1040 with
+    1322-1357).
 
-    Inputs after (net, plan, steps, a): per population x | None, v_in, W, tau, k, eta (+ r_max, s, v0 of the sigmoid), then
-    the edge matrices in plan order.  Outputs: per population its output trajectory [steps, N] and its final state."""
+    Inputs after (net, plan, steps, a): per population x | None, its state handle (v of a rate population, the packed state
+    of a spiking one), W and its per-neuron parameters (`_names`), then the edge matrices in plan order.  Outputs: per
+    population its output trajectory [steps, N] and its final state.  What a feedback edge from a spiking population reads at
+    the window's FIRST step (that population's output one step before the window) is a constant of the window."""
+
+    @staticmethod
+    def _names(pop) -> tuple:
+        from .spiking_autograd import TRAINABLE
+        if pop.spiking:
+            return TRAINABLE[pop.model]
+        return ("tau", "k", "eta") + (_RateWindow.ACT_PARAMS if pop.model == "li_sigmoid" else ())
 
     @staticmethod
     def _layout(net, plan):
         out, i = [], 4
         for p in plan["pops"]:
-            n_act = len(_RateWindow.ACT_PARAMS) if net.get_node(p)._pop.model == "li_sigmoid" else 0
-            out.append((i, n_act))
-            i += 6 + n_act
+            names = _CoupledWindow._names(net.get_node(p)._pop)
+            out.append((i, names))
+            i += 3 + len(names)
         return out, i
 
     @staticmethod
     def forward(ctx, net, plan, steps, a, *flat):
         pops = plan["pops"]
         layout, _ = _CoupledWindow._layout(net, plan)
-        stored, xin, widths = {}, {}, {}
-        for p, (i, _) in zip(pops, layout):
-            pop = net.get_node(p)._pop
-            x, k = flat[i - 4], flat[i - 4 + 4]
+        stored, xin, widths, lag0 = {}, {}, {}, {}
+        for p, (i, names) in zip(pops, layout):
+            node = net.get_node(p)
+            pop = node._pop
+            x = flat[i - 4]
+            req = {name: flat[i - 4 + 3 + j].requires_grad for j, name in enumerate(names)}
             f32 = dict(dtype=torch.float32, device=pop.device)
-            stored[p] = dict(save_v=torch.empty(steps, pop.rows, **f32), save_src=torch.empty(steps, pop.rows, **f32),
-                             save_acc=torch.empty(steps, pop.rows, **f32) if k.requires_grad else None)
+            buf = lambda: torch.empty(steps, pop.rows, **f32)
+            need_acc = req.get("k", False) or pop.model in ("ik", "iku", "ik_biexp")
+            stored[p] = dict(save_v=buf(), save_src=buf(), save_acc=buf() if need_acc else None)
+            if pop.spiking:
+                stored[p].update(save_aux=buf() if pop.aux is not None else None, save_aux2=buf() if pop.aux2 is not None else None,
+                                 save_in=buf() if plan["edges"][p] else None)  # (the input the adjoint of tau / C needs)
             xin[p] = None if x is None else x.detach()
             widths[p] = None if x is None else x.shape[1]
+        for p in {s_ for q in pops for s_, mode in plan["edges"][q] if mode == _abi.RP_EDGE_LAG}:
+            lag0[p] = net.get_node(p)["out"].detach().clone()
         net._coupled_steps(plan, xin, steps, a, set(), {}, None, 0, 1, stored=stored)
         outs = []
         for p in pops:
             node = net.get_node(p)
-            node._last_window = (stored[p]["save_v"], stored[p]["save_src"])
-            out = stored[p]["save_src"] if node._out_code == _abi.RP_OUT_SOURCE else stored[p]["save_v"]
-            outs += [out.clone(), node._pop.v.clone()]
-        ctx.net, ctx.plan, ctx.steps, ctx.stored, ctx.widths = net, plan, steps, stored, widths
+            pop, st = node._pop, stored[p]
+            out = st["save_src"] if node._out_code == _abi.RP_OUT_SOURCE else st["save_v"]
+            if pop.spiking:
+                node._last_window = (st["save_v"], st["save_src"], st["save_aux"], st["save_aux2"])
+                outs += [out.clone(), node._pack(pop.v, pop.source_local, pop.aux, pop.aux2)]
+            else:
+                node._last_window = (st["save_v"], st["save_src"])
+                outs += [out.clone(), pop.v.clone()]
+        ctx.net, ctx.plan, ctx.steps, ctx.stored, ctx.widths, ctx.xin, ctx.lag0 = net, plan, steps, stored, widths, xin, lag0
         return tuple(outs)
 
     @staticmethod
@@ -83,48 +106,66 @@ class _CoupledWindow(torch.autograd.Function):
         layout, first_edge = _CoupledWindow._layout(net, plan)
         read = {s_ for p in pops for s_, _ in plan["edges"][p]}
         members, res = [], []
-        for m, (p, (i, n_act)) in enumerate(zip(pops, layout)):
+        for m, (p, (i, names)) in enumerate(zip(pops, layout)):
             node = net.get_node(p)
             pop = node._pop
             N = pop.rows
             f32 = dict(dtype=torch.float32, device=pop.device)
-            g_traj, g_vend = g[2 * m], g[2 * m + 1]
-            R = dict(lam=torch.zeros(N, **f32) if g_vend is None else g_vend.detach().to(**f32).clone().contiguous(),
-                     u=torch.empty(T, N, **f32), tau=torch.zeros(N, **f32) if need[i + 3] else None,
-                     k=torch.zeros(N, **f32) if need[i + 4] else None, eta=torch.zeros(N, **f32) if need[i + 5] else None,
-                     gx=torch.empty(T, N, **f32) if need[i] or plan["edges"][p] else None,
-                     act={name: torch.zeros(N, **f32) for j, name in enumerate(_RateWindow.ACT_PARAMS[:n_act]) if need[i + 6 + j]})
+            g_traj, g_end = g[2 * m], g[2 * m + 1]
+            st = stored[p]
+            R = dict(u=torch.empty(T, N, **f32), gx=torch.empty(T, N, **f32) if need[i] or plan["edges"][p] else None,
+                     par={name: torch.zeros(N, **f32) for j, name in enumerate(names) if need[i + 3 + j]})
             # the sweep adds what comes back through the edges into the output gradient of their sources: a private copy
             if p in read:
                 R["g_out"] = torch.zeros(T, N, **f32) if g_traj is None else g_traj.detach().to(**f32).clone().contiguous()
             else:
                 R["g_out"] = None if g_traj is None else g_traj.detach().to(**f32).contiguous()
+            kw = dict(traj_v=st["save_v"], traj_r=st["save_src"], grad_out=R["g_out"], grad_var=node._out_code, u_traj=R["u"],
+                      traj_acc=st["save_acc"], grad_x=R["gx"])
+            if pop.spiking:
+                tpl = node._template
+
+                def piece(name, g_end=g_end, node=node, N=N, f32=f32):
+                    if g_end is None or name is None:
+                        return torch.zeros(N, **f32)
+                    lo, hi = getattr(node, "_internal_var_map", node._var_map)[name]
+                    return g_end.detach().to(**f32)[lo:hi].clone().contiguous()
+
+                R["lam"], R["lam_s"] = piece(tpl.reset_var), piece(tpl.source_var)
+                R["lam_x"] = piece(node._aux_name) if node._aux_name else None
+                R["lam_x2"] = piece(node._aux2_name) if node._aux2_name else None
+                kw.update(lam=R["lam"], lam_s=R["lam_s"], slope=node._spike_slope, x_target=node._x_target,
+                          x=st["save_in"] if st["save_in"] is not None else ctx.xin[p], traj_aux=st["save_aux"],
+                          lam_x=R["lam_x"], traj_aux2=st["save_aux2"], lam_x2=R["lam_x2"], grad_params=R["par"])
+            else:
+                R["lam"] = torch.zeros(N, **f32) if g_end is None else g_end.detach().to(**f32).clone().contiguous()
+                kw.update(lam=R["lam"], grad_tau=R["par"].get("tau"), grad_k=R["par"].get("k"), grad_eta=R["par"].get("eta"),
+                          grad_params={k_: v_ for k_, v_ in R["par"].items() if k_ in _RateWindow.ACT_PARAMS})
             res.append(R)
-            members.append(dict(pop=pop, edges=[(net.get_edge(s_, p).weights.detach(), index[s_], mode) for s_, mode in plan["edges"][p]],
-                                bwd=dict(traj_v=stored[p]["save_v"], traj_r=stored[p]["save_src"], grad_out=R["g_out"],
-                                         grad_var=node._out_code, lam=R["lam"], u_traj=R["u"], traj_acc=stored[p]["save_acc"],
-                                         grad_tau=R["tau"], grad_k=R["k"], grad_eta=R["eta"], grad_x=R["gx"],
-                                         grad_params=R["act"])))
+            members.append(dict(pop=pop, bwd=kw, edges=[(net.get_edge(s_, p).weights.detach(), index[s_], mode)
+                                                        for s_, mode in plan["edges"][p]]))
         keep = backward_coupled(members)
         grads = [None] * len(need)
-        for m, (p, (i, n_act)) in enumerate(zip(pops, layout)):
-            pop, R = net.get_node(p)._pop, res[m]
+        for m, (p, (i, names)) in enumerate(zip(pops, layout)):
+            node = net.get_node(p)
+            pop, R = node._pop, res[m]
             if need[i]:
                 grads[i] = R["gx"].sum(dim=1, keepdim=True) if ctx.widths[p] == 1 else R["gx"]
             if need[i + 1]:
-                grads[i + 1] = R["lam"]
+                grads[i + 1] = node._pack(R["lam"], R["lam_s"], R["lam_x"], R["lam_x2"]) if pop.spiking else R["lam"]
             if need[i + 2]:
                 grads[i + 2] = pop.outer_product(pop.dt, R["u"], stored[p]["save_src"])
-            grads[i + 3], grads[i + 4], grads[i + 5] = R["tau"], R["k"], R["eta"]
-            for j, name in enumerate(_RateWindow.ACT_PARAMS[:n_act]):
-                grads[i + 6 + j] = R["act"].get(name)
+            for j, name in enumerate(names):
+                grads[i + 3 + j] = R["par"].get(name)
         e = first_edge
         for m, p in enumerate(pops):
             pop = net.get_node(p)._pop
             for s_, mode in plan["edges"][p]:
-                if need[e]:  # dW_e = sum_t gx_p(t) (x) out_s(t): every edge of a rate circuit reads the source's step-t output
+                if need[e]:  # dW_e = sum_t gx_p(t) (x) (what the edge read at step t)
                     src = net.get_node(s_)
                     out_s = stored[s_]["save_src"] if src._out_code == _abi.RP_OUT_SOURCE else stored[s_]["save_v"]
+                    if mode == _abi.RP_EDGE_LAG:  # the source's output one step earlier; before the window: its value then
+                        out_s = torch.cat([ctx.lag0[s_][None, :], out_s[:-1]])
                     gW = torch.empty(pop.rows, src._pop.rows, dtype=torch.float32, device=pop.device)
                     gx = res[m]["gx"]
                     pop.backend.outer_store_rect(pop.rows, src._pop.rows, T, 1.0, gx.data_ptr(), gx.stride(0) if T > 1 else pop.rows,
@@ -164,6 +205,25 @@ class FeedbackNetwork(Network):
         self._in_node, self._out_node = in_nodes[0], out_nodes[0]
         self._order = list(topological_sort(g))
         self._prev_out = {}
+
+    def parameters(self, recurse: bool = True):
+        """The reference yields the parameters of the feed-forward graph and then those of the feedback graph
+        (network.py:1308-1322, 946-952): the nodes at either end of a feedback edge come TWICE, so an optimiser built from
+        this list holds them twice and applies two steps per update to them (torch warns about the duplicates; with SGD
+        their effective learning rate doubles).  Kept as it is: a training run then ends where the reference's does
+        (fixture G37, tests/test_coupled.py)."""
+        fb = [(s, t) for s, t, d in self.graph.edges(data=True) if d.get("feedback")]
+        for n in self.graph.nodes:
+            yield from self.get_node(n).parameters(recurse=recurse)
+        for s, t, d in self.graph.edges(data=True):
+            if not d.get("feedback"):
+                yield from self.get_edge(s, t).parameters()
+        ends = {n for e in fb for n in e}
+        for n in self.graph.nodes:
+            if n in ends:
+                yield from self.get_node(n).parameters(recurse=recurse)
+        for s, t in fb:
+            yield from self.get_edge(s, t).parameters()
 
     def _chain_plan(self):
         if any(d.get("feedback") for _, _, d in self.graph.edges(data=True)):
@@ -291,20 +351,24 @@ class FeedbackNetwork(Network):
         return dict(pre=pre, pops=pops, post=post, edges=edges, slots=slots)
 
     def _coupled_grad_plan(self) -> Optional[dict]:
-        """The coupled plan if its adjoint runs as one call too (rp_backward_coupled): rate populations, every edge reading
-        what its source emits at the SAME step -- feed-forward edges, and feedback edges from populations stepped later (the
-        usual direction).  Spiking members and a feedback edge from an EARLIER population (it reads a post-update state)
-        keep the per-step autograd."""
+        """The coupled plan if its adjoint runs as one call too (rp_backward_coupled): every edge reads what its source
+        emitted before it was stepped -- feed-forward edges, feedback edges from rate populations stepped later (the usual
+        direction) and feedback edges from spiking populations (their exposed state lags one step).  A feedback edge from an
+        EARLIER rate population (it reads a post-update state) and the population-mean spiking models keep the per-step
+        autograd."""
+        from .spiking_autograd import TRAINABLE
         plan = self._coupled_plan([])
         if plan is None or getattr(self, "_force_stepwise_adjoint", False):
             return None
         order = {p: i for i, p in enumerate(plan["pops"])}
         for p in plan["pops"]:
             node = self.get_node(p)
-            if isinstance(node, SpikeResetNet) or node._out_slice is not None:
+            if node._out_slice is not None or node._pop.model in ("iku", "ik_biexp"):
+                return None
+            if node._pop.spiking and node._pop.model not in TRAINABLE:
                 return None
             for s_, mode in plan["edges"][p]:
-                if mode == _abi.RP_EDGE_LAG or (mode == _abi.RP_EDGE_LIVE and order[s_] <= order[p]):
+                if mode == _abi.RP_EDGE_LIVE and order[s_] <= order[p]:
                     return None
         return plan
 
@@ -317,19 +381,27 @@ class FeedbackNetwork(Network):
         for p in pops:
             node: RateNet = self.get_node(p)
             pop = node._pop
-            node._before_step()
-            v_in = node._y_grad
-            if v_in is None:
-                v_in = pop.v.detach().clone().requires_grad_(node._y_requires_grad)
-            act = [pop.params[q] for q in _RateWindow.ACT_PARAMS] if pop.model == "li_sigmoid" else []
-            flat += [xin[p], v_in, pop.W, pop.params["tau"], pop.params["k"], pop.params["eta"], *act]
+            state_in = node._y_grad
+            if pop.spiking:
+                if state_in is None:
+                    state_in = node.current_state.detach().requires_grad_(node._y_requires_grad)
+            else:
+                node._before_step()
+                state_in = node._y_grad
+                if state_in is None:
+                    state_in = pop.v.detach().clone().requires_grad_(node._y_requires_grad)
+            flat += [xin[p], state_in, pop.W] + [pop.params[q] for q in _CoupledWindow._names(pop)]
         for p in pops:
             flat += [self.get_edge(s_, p).weights for s_, _ in plan["edges"][p]]
         res = _CoupledWindow.apply(self, plan, inputs_ab.shape[0], a, *flat)
         outs = {}
         for i, p in enumerate(pops):
+            node = self.get_node(p)
             outs[p] = res[2 * i]
-            self.get_node(p)._y_grad = res[2 * i + 1]
+            node._y_grad = res[2 * i + 1]
+            if node._pop.spiking:  # `y` exposes the pre-update state of the window's last step (nodes.py:387-392)
+                tv, ts, ta, tb = node._last_window
+                node._y_prev = node._pack(tv[-1], ts[-1], None if ta is None else ta[-1], None if tb is None else tb[-1])
         for n in plan["post"]:
             X = None
             for p_ in self.graph.predecessors(n):
@@ -435,7 +507,7 @@ class FeedbackNetwork(Network):
                     kw["hist"] = node._hist
                 if stored and p in stored:
                     kw.update({k_: v_[t0:t1] for k_, v_ in stored[p].items() if v_ is not None})
-                if last and isinstance(node, SpikeResetNet):
+                if last and isinstance(node, SpikeResetNet) and not (stored and p in stored):
                     saves[p] = node._state_bufs()
                     kw.update(save_v=saves[p][0], save_src=saves[p][1], save_aux=saves[p][2], save_aux2=saves[p][3])
                 members.append(dict(pop=pop, run=kw, edges=[(self.get_edge(s_, p).weights, index[s_], mode)
@@ -449,6 +521,8 @@ class FeedbackNetwork(Network):
             for p, bufs in saves.items():
                 self.get_node(p)._coupled_end(bufs)
 
+        if stored:  # (a stored window holds the pre-update state of its last step already)
+            spiking = any(isinstance(self.get_node(p), SpikeResetNet) and p not in stored for p in pops)
         if spiking and steps > 1:  # the last step on its own: it leaves the pre-update state a spiking node exposes as `y`
             call(0, steps - 1, False)
             call(steps - 1, steps, True)

@@ -751,6 +751,8 @@ class SpikeResetNet(RateNet):
         lo, hi = self._var_map[var]
         if self._y_prev is None:
             self._y_prev = self.current_state
+        elif self._y_prev.requires_grad:  # (the handle of a recorded step: leave it to its graph)
+            self._y_prev = self._y_prev.detach().clone()
         with torch.no_grad():
             self._y_prev[lo:hi] = torch.as_tensor(val, dtype=torch.float32).to(self._pop.device)
 
@@ -798,8 +800,17 @@ class SpikeResetNet(RateNet):
         traj, y_end = SpikeWindow.apply(self, steps, x, y_in, pop.W, *params)
         self._y_grad = y_end
         tv, ts, ta, tb = self._last_window
-        self._y_prev = self._pack(tv[-1], ts[-1], None if ta is None else ta[-1], None if tb is None else tb[-1])
+        # `y` exposes the pre-update state of the last step.  After a single recorded step that is the handle the step
+        # started from: a feedback edge reading `node["out"]` then carries the gradient into this population's earlier
+        # steps, as the reference's `self.y = torch.cat(...)` does (nodes.py:387; pinned by G37)
+        self._y_prev = y_in if steps == 1 else \
+            self._pack(tv[-1], ts[-1], None if ta is None else ta[-1], None if tb is None else tb[-1])
         return traj
+
+    def detach(self, requires_grad: bool = False, detach_params: bool = False):
+        super().detach(requires_grad=requires_grad, detach_params=detach_params)
+        if self._y_prev is not None:
+            self._y_prev = self._y_prev.detach()
 
     def forward(self, x, edges: Optional[list] = None) -> torch.Tensor:
         x2 = self._as_input(x)

@@ -496,38 +496,46 @@ def torch_walk_rate(pops, edges, out_vars, x, T, leaves):
     return [torch.stack(o) for o in outs], v
 
 
-def coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev):
+def coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev, models=None):
     """Forward with the window stored, then rp_backward_coupled; returns the gradients per member / edge."""
     from rectipy_amd.engine import backward_coupled
     n_m = len(pops)
+    models = models or ("li_tanh",) * n_m
     f32 = dict(dtype=torch.float32, device=dev)
-    saved = [dict(v=torch.zeros(T, p.rows, **f32), r=torch.zeros(T, p.rows, **f32), acc=torch.zeros(T, p.rows, **f32)) for p in pops]
+    saved = [dict(v=torch.zeros(T, p.rows, **f32), r=torch.zeros(T, p.rows, **f32), acc=torch.zeros(T, p.rows, **f32),
+                  inp=torch.zeros(T, p.rows, **f32)) for p in pops]
     hist = [[torch.zeros(p.rows, **f32) for _ in range(3)] for p in pops]
     members = []
     for m, p in enumerate(pops):
+        hist[m][2].copy_(p.v if out_vars[m] == _abi.RP_OUT_STATE0 else p.source)  # (what a LAG edge reads at step 0)
         run = dict(steps=T, step0=0, out_var=out_vars[m], save_v=saved[m]["v"], save_src=saved[m]["r"], save_acc=saved[m]["acc"],
-                   hist=hist[m])
+                   save_in=saved[m]["inp"], hist=hist[m])
         if m == 0:
             run["x"] = x
-        members.append(dict(pop=p, run=run, edges=[(edges[(s_, m)], s_, _abi.RP_EDGE_OUT if s_ < m else _abi.RP_EDGE_LIVE)
-                                                   for s_ in range(n_m) if s_ != m]))
+        members.append(dict(pop=p, run=run, edges=[(edges[(s_, m)], s_, modes_for(models, s_, m)) for s_ in range(n_m) if s_ != m]))
     forward_coupled(members)
     res, bw = [], []
     for m, p in enumerate(pops):
         N = p.rows
         R = dict(lam=g_vend[m].to(**f32).clone(), u=torch.zeros(T, N, **f32), g_out=g_out[m].to(**f32).clone(),
                  tau=torch.zeros(N, **f32), k=torch.zeros(N, **f32), eta=torch.zeros(N, **f32), gx=torch.zeros(T, N, **f32))
+        kw = dict(traj_v=saved[m]["v"], traj_r=saved[m]["r"], grad_out=R["g_out"], grad_var=out_vars[m], lam=R["lam"],
+                  u_traj=R["u"], traj_acc=saved[m]["acc"], grad_x=R["gx"])
+        if models[m] == "qif":
+            R.update(lam_s=(g_vend[m] * 0.5).to(**f32).clone(), tau_s=torch.zeros(N, **f32))
+            kw.update(lam_s=R["lam_s"], slope=0.5, x=saved[m]["inp"],
+                      grad_params={k_: R[k_] for k_ in ("tau", "k", "eta", "tau_s")})
+        else:
+            kw.update(grad_tau=R["tau"], grad_k=R["k"], grad_eta=R["eta"])
         res.append(R)
-        bw.append(dict(pop=p, edges=members[m]["edges"],
-                       bwd=dict(traj_v=saved[m]["v"], traj_r=saved[m]["r"], grad_out=R["g_out"], grad_var=out_vars[m], lam=R["lam"],
-                                u_traj=R["u"], traj_acc=saved[m]["acc"], grad_tau=R["tau"], grad_k=R["k"], grad_eta=R["eta"],
-                                grad_x=R["gx"])))
+        bw.append(dict(pop=p, edges=members[m]["edges"], bwd=kw))
     keep = backward_coupled(bw)
     del keep
     for m, p in enumerate(pops):
         res[m]["W"] = p.dt * res[m]["u"].T @ saved[m]["r"]
         res[m]["out"] = saved[m]["v"] if out_vars[m] == _abi.RP_OUT_STATE0 else saved[m]["r"]
-    g_edges = {(s_, m): res[m]["gx"].T @ res[s_]["out"] for (s_, m) in edges}
+        res[m]["v_traj"] = saved[m]["v"]
+    g_edges = {(s_, m): res[m]["gx"].T @ res[s_]["out"] for (s_, m) in edges}  # (edges that read the same step's output)
     return res, g_edges
 
 
@@ -565,7 +573,7 @@ def test_coupled_adjoint_against_float64_autograd(target, sizes, out_vars):
         close(g_edges[key], leaves["edges"][key].grad, f"edge {key}")
 
 
-def build_trained(target, stepwise, sizes=(12, 20, 8), sigmoid=False, out_r=False, fb_to_later=False):
+def build_trained(target, stepwise, sizes=(12, 20, 8), sigmoid=False, out_r=False, fb_to_later=False, spiking=None):
     """inp -> a -> b (-> c) -> out with feedback edges from the last population to the first (and from c to b); everything
     trainable: W, tau, k and eta of the populations, the edges between them, the input layer and the read-out."""
     net = FeedbackNetwork(1e-2, **target)
@@ -573,9 +581,17 @@ def build_trained(target, stepwise, sizes=(12, 20, 8), sigmoid=False, out_r=Fals
     net.add_func_node("inp", 3, "tanh")
     labs = "abc"[:len(sizes)]
     SIG = "neuron_model_templates.rate_neurons.leaky_integrator.sigmoid"
-    for lab, n in zip(labs, sizes):
+    for lab, n, sp in zip(labs, sizes, spiking or (False,) * len(sizes)):
         W = r.standard_normal((n, n)) / np.sqrt(n)
-        if sigmoid and lab == "b":
+        if sp:
+            node = SpikeResetNet.from_pyrates(
+                QIF, input_var="qif_op/I_ext", output_var="qif_op/s", weights=np.abs(W) * 3, source_var="qif_op/s",
+                target_var="qif_op/s_in", spike_var="qif_op/spike", reset_var="qif_op/v",
+                train_params=["weights", "qif_op/tau", "qif_op/k", "qif_op/eta", "qif_op/tau_s"],
+                node_vars={"all/qif_op/eta": r.standard_normal(n) + 3, "all/qif_op/v": r.uniform(-2, 9, n), "all/qif_op/s": r.uniform(0, 0.5, n)},
+                spike_threshold=10.0, spike_reset=-10.0, dt=1e-2, dtype=torch.float32, **target)
+            net.add_node(lab, node, node_type="diff_eq")
+        elif sigmoid and lab == "b":
             net.add_diffeq_node(lab, SIG, weights=W, source_var="sigmoid_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
                                 output_var="li_op/v", dtype=torch.float32,
                                 node_vars={"all/li_op/v": r.standard_normal(n) * 0.5, "all/li_op/tau": r.uniform(0.5, 2, n)},
@@ -600,8 +616,10 @@ def build_trained(target, stepwise, sizes=(12, 20, 8), sigmoid=False, out_r=Fals
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
-@pytest.mark.parametrize("cfg", [dict(), dict(sizes=(16, 24), out_r=True), dict(sigmoid=True), dict(sizes=(260, 136), lr=1e-3)],
-                         ids=["three", "two_rates_out", "sigmoid", "wide"])
+@pytest.mark.parametrize("cfg", [dict(), dict(sizes=(16, 24), out_r=True), dict(sigmoid=True), dict(sizes=(260, 136), lr=1e-3),
+                                 dict(spiking=(True, False, True), lr=2e-3), dict(sizes=(16, 24), spiking=(True, True), lr=2e-3),
+                                 dict(sizes=(20, 12), spiking=(False, True), lr=2e-3)],
+                         ids=["three", "two_rates_out", "sigmoid", "wide", "qif_rate_qif", "qif_pair", "rate_qif"])
 def test_fit_bptt_through_cycles_is_one_forward_and_one_adjoint_call_per_window(target, cfg, monkeypatch):
     """FeedbackNetwork.fit_bptt: every window is ONE rp_forward_coupled and ONE rp_backward_coupled call; the parameters
     after three SGD windows (and the recorded losses) equal those of autograd over the per-step walk."""
@@ -642,24 +660,29 @@ def test_adjoint_that_stays_on_the_walk(oracle_backend, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sizes,out_vars", [((24, 40, 16), (0, 0, 1)), ((17, 30), (1, 0)), ((260, 136, 72), (1, 1, 0)),
-                                            ((1024, 2052, 512), (0, 1, 1)), ((4100, 520), (1, 0))])
-def test_hip_coupled_adjoint_bit_exact(oracle_backend, hip_device, sizes, out_vars):
+@pytest.mark.parametrize("sizes,out_vars,models", [
+    ((24, 40, 16), (0, 0, 1), None), ((17, 30), (1, 0), None), ((260, 136, 72), (1, 1, 0), None),
+    ((1024, 2052, 512), (0, 1, 1), None), ((4100, 520), (1, 0), None),
+    ((32, 20), (1, 0), ("qif", "li_tanh")), ((17, 30, 12), (1, 1, 0), ("li_tanh", "qif", "qif")),
+    ((520, 1028), (1, 1), ("qif", "qif"))])
+def test_hip_coupled_adjoint_bit_exact(oracle_backend, hip_device, sizes, out_vars, models):
     """rp_backward_coupled on the GPU against the C oracle: adjoint states, per-step u, input gradients, the output
     gradients the edges accumulate into and the per-neuron parameter gradients, bit for bit."""
     T = 19
-    models = ("li_tanh",) * len(sizes)
+    models = models or ("li_tanh",) * len(sizes)
     gen = torch.Generator().manual_seed(21)
     x = torch.randn(T, sizes[0], generator=gen) * 0.5
     g_out = [torch.randn(T, n, generator=gen) for n in sizes]
     g_vend = [torch.randn(n, generator=gen) for n in sizes]
     got = []
     for dev, backend in (("cpu", oracle_backend), (hip_device, None)):
-        pops, edges = circuit(sizes, models, 5, dev, backend)
-        res, _ = coupled_adjoint(pops, edges, out_vars, x.to(dev), T, g_out, g_vend, dev)
+        pops, edges = circuit(sizes, models, 5, dev, backend, dt=0.08 if "qif" in models else 1e-2)
+        res, _ = coupled_adjoint(pops, edges, out_vars, x.to(dev), T, g_out, g_vend, dev, models)
         got.append(res)
     for m in range(len(sizes)):
-        for key in ("lam", "u", "gx", "g_out", "tau", "k", "eta"):
+        if models[m] == "qif":  # spikes inside the window: the sweep passes resets and surrogate gradients
+            assert int((got[0][m]["v_traj"] >= pops[m].theta).sum()) >= 3
+        for key in ("lam", "u", "gx", "g_out", "tau", "k", "eta") + (("lam_s", "tau_s") if models[m] == "qif" else ()):
             assert_same(got[0][m][key], got[1][m][key], f"member {m} {key}")
 
 
@@ -690,3 +713,108 @@ def test_run_with_gradient_and_epoch_fit_take_the_fused_adjoint(target, monkeypa
     for a, b in zip(res[0][1] + res[0][2], res[1][1] + res[1][2]):
         assert a.shape == b.shape and np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), np.abs(a - b).max()
     assert np.abs(res[0][3] - res[1][3]).max() < 1e-5
+
+
+# ---- training through cycles against the reference itself (golden G37) ------------------------------------------------------
+def g37():
+    import os
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g37_feedback_fit.npz")))
+
+
+def assert_grad(param, ref, what, rel):
+    """The gradient the last window left on the parameter against the reference's, relative to its largest entry."""
+    got = param.grad.detach().cpu().numpy().astype(np.float64)
+    assert np.abs(got - ref).max() <= rel * np.abs(ref).max(), f"grad {what}: off by {np.abs(got - ref).max() / np.abs(ref).max():.2e} of max"
+
+
+def assert_update(got, ref, start, what, rel=2e-4):
+    """The parameter after training against the reference's: the deviation is measured against the size of the UPDATE."""
+    got = got.detach().cpu().numpy().astype(np.float64)
+    step = max(np.abs(ref - start).max(), 1e-12)
+    assert np.abs(got - ref).max() <= rel * step + 2e-7 * max(1.0, np.abs(ref).max()), \
+        f"{what}: off by {np.abs(got - ref).max():.3e}, update {step:.3e}"
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("adjoint", ["fused", "walk"])
+def test_g37_rate_cycle_fit_matches_the_reference(target, adjoint, monkeypatch):
+    """Golden G37 (a): the reference's FeedbackNetwork.fit_bptt, two SGD windows through a -> b -> out with feedback b -> a,
+    every parameter trained.  Both the fused adjoint (one rp_backward_coupled call per window) and the per-step autograd end
+    at the reference's float64 parameters (tolerance: 2e-4 of each parameter's update; the reference's own float32 run
+    deviates by 1.7e-6 absolute)."""
+    g = g37()
+    bwd = []
+    real_b = engine.backward_coupled
+    monkeypatch.setattr(engine, "backward_coupled", lambda members: bwd.append(len(members)) or real_b(members))
+    net = FeedbackNetwork(float(g["dt"]), **target)
+    names = ["weights", "li_op/tau", "li_op/k", "li_op/eta"]
+    for lab in "ab":
+        net.add_diffeq_node(lab, TANH, weights=g[f"rate_{lab}0_W"], source_var="tanh_op/r", target_var="li_op/r_in",
+                            input_var="li_op/I_ext", output_var="li_op/v", dtype=torch.float32, train_params=list(names),
+                            node_vars={"all/li_op/tau": g[f"rate_{lab}0_tau"], "all/li_op/k": g[f"rate_{lab}0_k"],
+                                       "all/li_op/eta": g[f"rate_{lab}0_eta"], "all/li_op/v": g[f"rate_{lab}0_y0"]})
+    net.add_func_node("out", 3, "identity")
+    e_ab = net.add_edge("a", "b", weights=g["rate_W_ab0"], train="gd")
+    e_out = net.add_edge("b", "out", weights=g["rate_W_out0"], train="gd")
+    e_ba = net.add_edge("b", "a", weights=g["rate_W_ba0"], feedback=True, train="gd")
+    net._force_stepwise_adjoint = adjoint == "walk"
+    obs = net.fit_bptt(g["rate_x"].astype(np.float32), g["rate_target"].astype(np.float32), optimizer="sgd", lr=float(g["lr"]),
+                       update_steps=int(g["win"]), sampling_steps=1, verbose=False)
+    assert bwd == ([2, 2] if adjoint == "fused" else [])
+    for lab in "ab":
+        node = net.get_node(lab)
+        for key, start in zip(names, ("W", "tau", "k", "eta")):
+            assert_update(node[key], g[f"rate_{lab}_{key.split('/')[-1]}_f64"], g[f"rate_{lab}0_{start}"], f"{lab} {key}")
+            assert_grad(node[key], g[f"rate_grad_{lab}_{key.split('/')[-1]}_f64"], f"{lab} {key}", 1e-4)
+    for edge, key in ((e_ab, "W_ab"), (e_ba, "W_ba"), (e_out, "W_out")):
+        assert_update(edge.weights, g[f"rate_{key}_f64"], g[f"rate_{key}0"], key)
+        assert_grad(edge.weights, g[f"rate_grad_{key}_f64"], key, 1e-4)
+    assert np.abs(obs.to_numpy("out") - g["rate_pred_f64"]).max() < 1e-5
+    assert np.abs(obs.to_numpy("loss") - g["rate_loss_f64"]).max() < 1e-5
+
+
+def build_g37_qif(g, target):
+    net = FeedbackNetwork(float(g["dtq"]), **target)
+    names = ["weights", "qif_op/tau", "qif_op/k", "qif_op/eta", "qif_op/tau_s"]
+    nq = g["qif_a0_eta"].shape[0]
+    for lab in "ab":
+        node = SpikeResetNet.from_pyrates(
+            QIF, input_var="qif_op/I_ext", output_var="qif_op/s", weights=g[f"qif_{lab}0_W"], source_var="qif_op/s",
+            target_var="qif_op/s_in", spike_var="qif_op/spike", reset_var="qif_op/v", train_params=list(names),
+            node_vars={"all/qif_op/eta": g[f"qif_{lab}0_eta"], "all/qif_op/tau": g[f"qif_{lab}0_tau"], "all/qif_op/k": g[f"qif_{lab}0_k"],
+                       "all/qif_op/tau_s": g[f"qif_{lab}0_tau_s"], "all/qif_op/v": g[f"qif_{lab}0_y0"][:nq],
+                       "all/qif_op/s": g[f"qif_{lab}0_y0"][nq:]},
+            spike_threshold=float(g["theta"]), spike_reset=float(g["v_reset"]), dt=float(g["dtq"]), dtype=torch.float32, **target)
+        net.add_node(lab, node, node_type="diff_eq")
+    net.add_func_node("out", 2, "identity")
+    edges = dict(W_ab=net.add_edge("a", "b", weights=g["qif_W_ab0"], train="gd"),
+                 W_out=net.add_edge("b", "out", weights=g["qif_W_out0"], train="gd"),
+                 W_ba=net.add_edge("b", "a", weights=g["qif_W_ba0"], feedback=True, train="gd"))
+    return net, names, edges
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("adjoint", ["fused", "walk"])
+def test_g37_qif_cycle_fit_matches_the_reference(target, adjoint, monkeypatch):
+    """Golden G37 (b): the reference's FeedbackNetwork.fit_bptt through a QIF pair a -> b -> out with feedback b -> a (the edge
+    reads b's state of the previous step and the surrogate gradient passes back through that read), one SGD window with
+    spikes in both populations, every parameter trained.  Tolerance: 1e-3 of each parameter's update (the reference's own
+    float32 run: 3.5e-6 absolute on updates of up to 0.28)."""
+    g = g37()
+    bwd = []
+    real_b = engine.backward_coupled
+    monkeypatch.setattr(engine, "backward_coupled", lambda members: bwd.append(len(members)) or real_b(members))
+    net, names, edges = build_g37_qif(g, target)
+    net._force_stepwise_adjoint = adjoint == "walk"
+    obs = net.fit_bptt(g["qif_x"].astype(np.float32), g["qif_target"].astype(np.float32), optimizer="sgd", lr=float(g["lrq"]),
+                       update_steps=int(g["winq"]), sampling_steps=1, verbose=False)
+    assert bwd == ([2] if adjoint == "fused" else [])
+    assert np.abs(obs.to_numpy("out") - g["qif_pred_f64"]).max() < 2e-5
+    for lab in "ab":
+        node = net.get_node(lab)
+        for key, start in zip(names, ("W", "tau", "k", "eta", "tau_s")):
+            assert_update(node[key], g[f"qif_{lab}_{key.split('/')[-1]}_f64"], g[f"qif_{lab}0_{start}"], f"{lab} {key}", rel=1e-3)
+            assert_grad(node[key], g[f"qif_grad_{lab}_{key.split('/')[-1]}_f64"], f"{lab} {key}", 1e-3)
+    for key, edge in edges.items():
+        assert_update(edge.weights, g[f"qif_{key}_f64"], g[f"qif_{key}0"], key, rel=1e-3)
+        assert_grad(edge.weights, g[f"qif_grad_{key}_f64"], key, 1e-3)
