@@ -1104,7 +1104,18 @@ class Network:
     def _get_optimizer(optimizer: str, lr: float, model_params: Iterator, optimizer_kwargs: dict = None):
         if optimizer not in _OPTIMIZERS:
             raise ValueError(f"Invalid optimizer choice '{optimizer}'. Valid options: {sorted(_OPTIMIZERS)}.")
-        return _OPTIMIZERS[optimizer](model_params, lr=lr, **(optimizer_kwargs or {}))
+        params = list(model_params)
+        kwargs = dict(optimizer_kwargs or {})
+        cls = _OPTIMIZERS[optimizer]
+        if len({id(p) for p in params}) < len(params) and "foreach" not in kwargs and "fused" not in kwargs:
+            # the same tensor twice in the list (FeedbackNetwork.parameters follows the reference, which repeats the nodes at
+            # a feedback edge): torch then steps it twice per update.  Its multi-tensor path -- the default on a GPU -- would
+            # run both steps inside ONE kernel, racing on the tensor; one parameter after the other is what the reference's
+            # CPU runs do, and is deterministic.
+            import inspect
+            if "foreach" in inspect.signature(cls.__init__).parameters:
+                kwargs["foreach"] = False
+        return cls(params, lr=lr, **kwargs)
 
     @staticmethod
     def _get_loss_function(loss: str, loss_kwargs: dict = None) -> Callable:

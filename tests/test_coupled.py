@@ -818,3 +818,19 @@ def test_g37_qif_cycle_fit_matches_the_reference(target, adjoint, monkeypatch):
     for key, edge in edges.items():
         assert_update(edge.weights, g[f"qif_{key}_f64"], g[f"qif_{key}0"], key, rel=1e-3)
         assert_grad(edge.weights, g[f"qif_grad_{key}_f64"], key, 1e-3)
+
+
+def test_repeated_parameters_are_stepped_one_after_the_other(oracle_backend):
+    """FeedbackNetwork.parameters() repeats the nodes at a feedback edge (the reference's list, network.py:1308-1322), so an
+    optimiser steps them twice per update.  torch's multi-tensor path (its default on a GPU) would do both steps in one
+    kernel, racing on the tensor (seen on MI355X: run-to-run different parameters); the optimiser is built without it."""
+    net = build_trained(dict(device="cpu", backend=oracle_backend), False, sizes=(16, 24))
+    net.compile()
+    params = list(net.parameters())
+    assert len(params) == 20 and len({id(p) for p in params}) == 12   # a and b: W, tau, k, eta twice; four edges once
+    opt = net._get_optimizer("sgd", 0.1, net.parameters())
+    assert opt.defaults["foreach"] is False
+    opt = net._get_optimizer("adam", 0.1, net.parameters(), {"foreach": True})   # (an explicit choice stands)
+    assert opt.defaults["foreach"] is True
+    plain = net._get_optimizer("sgd", 0.1, iter(params[:4]))
+    assert plain.defaults["foreach"] is None
