@@ -402,7 +402,7 @@ typedef struct rp_bwd_member {
     int64_t edge_ld[RP_MAX_EDGES];
     int32_t edge_source[RP_MAX_EDGES];
     int32_t edge_mode[RP_MAX_EDGES];     /* RP_EDGE_OUT | RP_EDGE_LIVE (source later in the order) | RP_EDGE_LAG          */
-    float* edge_work;                    /* workspace: max over the edges of rp_bwd_shard_partial_rows(n_source, rows) * n_source floats */
+    float* edge_work;                    /* workspace: SUM over this member's edges of rp_bwd_shard_partial_rows(n_source, rows) * n_source floats (16-byte aligned) */
     float* z;                            /* workspace [n]                                                               */
 } rp_bwd_member;
 int rp_sizeof_bwd_member(void);

@@ -112,7 +112,7 @@ struct BwdParams {
 // partials[q][j] = sum_{i in chunk q, ascending} W[i][j] * u[i]
 // SW = 16-byte column groups per lane: a wave covers a strip of 256*SW columns (SW KiB contiguous per row).
 template <bool VEC4, int U, int SW>
-__global__ __launch_bounds__(kThreads) void wt_partial_kernel(const BwdParams P) {
+__device__ __forceinline__ void wt_partial_body(const BwdParams& P) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row indices and u[i] go scalar
     constexpr int CW = VEC4 ? 256 * SW : 64;  // columns per strip
@@ -185,6 +185,11 @@ __global__ __launch_bounds__(kThreads) void wt_partial_kernel(const BwdParams P)
             }
         }
     }
+}
+
+template <bool VEC4, int U, int SW>
+__global__ __launch_bounds__(kThreads) void wt_partial_kernel(const BwdParams P) {
+    wt_partial_body<VEC4, U, SW>(P);
 }
 
 #ifdef RP_MEASUREMENT
@@ -968,7 +973,170 @@ __global__ void chunk_sum_add_kernel(const BwdParams P, float* dst) {
     dst[c] = dst[c] + chunk_sum(P, c);
 }
 
+
+// ---- small coupled circuits: two launches per backward step ---------------------------------------------------------------
+// Up to 4 members of at most 4096 neurons joined by at most 8 edges are launch-bound: the per-matrix path above issues two
+// launches per edge and three per member and step.  Here ONE launch forms the chunk partials of every transposed product of
+// the step (blockIdx.y = matrix: the members' W^T u and the edges' W_e^T gx, all of which depend on the step before only), and
+// ONE launch does the rest per (member, neuron): adds the edge products into the row of the member's output gradient they
+// belong to (edges in member / edge order, each a chunk-ordered sum: the order of the per-matrix path), sums the chunks of
+// W^T u and applies the member's adjoint step.  Same additions in the same order: bit-identical to the per-matrix path.
+constexpr int kFusedMembers = 4, kFusedEdges = 8, kFusedMaxN = 4096;
+
+struct PartArg {  // one transposed product: partials[chunk][j] = sum_{i in chunk} W[i][j] u[i]
+    const float* W;
+    int64_t ldw;
+    const float* u;
+    float* partials;
+    int n, rows, rc, q;
+};
+struct PartArgs {
+    PartArg a[kFusedMembers + kFusedEdges];
+};
+
+__global__ __launch_bounds__(kThreads) void coupled_partials_kernel(const PartArgs A) {
+    typedef const __attribute__((address_space(4))) char* karg_ptr;
+    PartArg a;  // this block's matrix, straight from the kernel-argument segment (scalar loads at a uniform offset)
+    __builtin_memcpy(&a, (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PartArgs, a) + sizeof(PartArg) * blockIdx.y,
+                     sizeof(PartArg));
+    BwdParams P = {};
+    P.W = a.W;
+    P.ldw = a.ldw;
+    P.u = a.u;
+    P.partials = a.partials;
+    P.n = a.n;
+    P.rows = a.rows;
+    P.rc = a.rc;
+    P.q = a.q;
+    const int strips = (P.n + 255) / 256;
+    if ((int)blockIdx.x * (kThreads / 64) >= strips * P.q) return;  // (the grid is sized for the largest matrix)
+    wt_partial_body<true, 8, 1>(P);
+}
+
+struct EdgeSum {  // the chunk partials of one edge product and where their sum goes (null: the row lies before the window)
+    const float* partials;
+    float* dst;
+    int n, q;
+};
+struct CoupledFin {
+    BwdParams mem[kFusedMembers];
+    SpkGrad grad[kFusedMembers];
+    EdgeSum in[kFusedMembers][kFusedEdges];  // by SOURCE member, in member / edge order
+    int n_in[kFusedMembers];
+};
+
+static_assert(sizeof(CoupledFin) <= 4000, "the argument block of coupled_finalize_kernel must fit the kernel-argument segment");
+
+__global__ __launch_bounds__(256) void coupled_finalize_kernel(const CoupledFin F) {
+    typedef const __attribute__((address_space(4))) char* karg_ptr;
+    const karg_ptr base = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const int m = blockIdx.y;
+    BwdParams P;
+    SpkGrad G;
+    __builtin_memcpy(&P, base + offsetof(CoupledFin, mem) + sizeof(BwdParams) * m, sizeof(BwdParams));
+    __builtin_memcpy(&G, base + offsetof(CoupledFin, grad) + sizeof(SpkGrad) * m, sizeof(SpkGrad));
+    int n_in;
+    __builtin_memcpy(&n_in, base + offsetof(CoupledFin, n_in) + sizeof(int) * m, sizeof(int));
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= P.rows) return;
+    for (int e = 0; e < n_in; ++e) {
+        EdgeSum E;
+        __builtin_memcpy(&E, base + offsetof(CoupledFin, in) + sizeof(EdgeSum) * (m * kFusedEdges + e), sizeof(EdgeSum));
+        if (!E.dst) continue;
+        BwdParams Q = {};
+        Q.partials = const_cast<float*>(E.partials);
+        Q.n = E.n;
+        Q.q = E.q;
+        E.dst[j] = E.dst[j] + chunk_sum(Q, j);
+    }
+    const float z = chunk_sum(P, j);
+    if (P.model >= RP_MODEL_QIF)
+        spk_finalize_elem(P, G, j, z);
+    else
+        finalize_elem(P, j, z);
+}
+
 int rp_sizeof_bwd_member(void) { return (int)sizeof(rp_bwd_member); }
+
+
+static int spk_setup(const rp_net* net, const rp_bwd* b, BwdParams& P, SpkGrad& G, bool& vec4);
+static void spk_set_step(const rp_bwd* b, BwdParams& P, int t);
+
+// every matrix of the circuit small and on the 16-byte path, few enough members and edges for one argument block
+static bool coupled_fused_ok(const rp_bwd_member* mem, int count) {
+    if (count > kFusedMembers) return false;
+    int edges = 0;
+    auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    for (int m = 0; m < count; ++m) {
+        const rp_net* net = mem[m].net;
+        if (net->n > kFusedMaxN || net->n % 4 || net->ldw % 4 || !aligned(net->W) || !aligned(mem[m].bwd->partials)) return false;
+        int64_t off = 0;
+        for (int e = 0; e < mem[m].n_edges; ++e) {
+            const int nq = mem[mem[m].edge_source[e]].net->n;
+            if (nq % 4 || mem[m].edge_ld[e] % 4 || !aligned(mem[m].edge_w[e]) || !aligned(mem[m].edge_work + off)) return false;
+            const int rc = chunk_rows(nq, net->rows);
+            off += (int64_t)((net->rows + rc - 1) / rc) * nq;
+            ++edges;
+        }
+    }
+    return edges <= kFusedEdges;
+}
+
+static int coupled_fused_sweep(const rp_bwd_member* mem, int count, int T, hipStream_t st) {
+    CoupledFin F = {};
+    PartArgs A = {};
+    bool vec4;
+    for (int m = 0; m < count; ++m) {
+        const int rc = is_spiking(mem[m].net) ? spk_setup(mem[m].net, mem[m].bwd, F.mem[m], F.grad[m], vec4)
+                                              : sharded_params(mem[m].net, mem[m].bwd, F.mem[m], vec4);
+        if (rc != RP_OK) return rc;
+    }
+    int max_rows = 0, max_blocks = 1;
+    for (int t = T - 1; t >= 0; --t) {
+        int mats = 0;
+        for (int m = 0; m < count; ++m) F.n_in[m] = 0;
+        for (int m = 0; m < count; ++m) {
+            const rp_bwd* b = mem[m].bwd;
+            BwdParams& P = F.mem[m];
+            A.a[mats++] = PartArg{P.W, P.ldw, b->u_traj + (int64_t)t * b->ld, P.partials, P.n, P.rows, P.rc, P.q};
+            int64_t off = 0;
+            for (int e = 0; e < mem[m].n_edges; ++e) {
+                const int q = mem[m].edge_source[e];
+                const int nq = mem[q].net->n;
+                const int rc = chunk_rows(nq, P.rows), chunks = (P.rows + rc - 1) / rc;
+                float* work = mem[m].edge_work + off;
+                off += (int64_t)chunks * nq;
+                const int tau = mem[m].edge_mode[e] == RP_EDGE_LAG ? t - 1 : t;
+                if (tau < 0) continue;
+                A.a[mats++] = PartArg{mem[m].edge_w[e], mem[m].edge_ld[e], b->grad_x + (int64_t)t * b->ldgx, work, nq, P.rows, rc, chunks};
+                F.in[q][F.n_in[q]++] = EdgeSum{work, const_cast<float*>(mem[q].bwd->grad_out) + (int64_t)tau * mem[q].bwd->ldg, nq, chunks};
+            }
+            // this member's own step (rp_bwd_apply)
+            if (is_spiking(mem[m].net)) {
+                spk_set_step(b, P, t);
+            } else {
+                P.t = t;
+                P.v_t = b->traj_v + (int64_t)t * b->ld;
+                P.r_t = b->traj_r + (int64_t)t * b->ld;
+                P.g_t = b->grad_out ? b->grad_out + (int64_t)t * b->ldg : nullptr;
+                if (t > 0)
+                    sharded_set_prep(b, P, t - 1);
+                else
+                    P.u_next = nullptr;
+            }
+            P.z_direct = nullptr;
+            if (P.rows > max_rows) max_rows = P.rows;
+        }
+        for (int i = 0; i < mats; ++i) {
+            const int blocks = (((A.a[i].n + 255) / 256) * A.a[i].q + 3) / 4;
+            if (blocks > max_blocks) max_blocks = blocks;
+        }
+        hipLaunchKernelGGL(coupled_partials_kernel, dim3(max_blocks, mats), dim3(kThreads), 0, st, A);
+        hipLaunchKernelGGL(coupled_finalize_kernel, dim3((max_rows + 255) / 256, count), dim3(256), 0, st, F);
+    }
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
+}
 
 int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
     if (!mem || count < 1 || count > 16) RP_FAIL(RP_ERR_ARG, "rp_backward_coupled: 1..16 members");
@@ -999,6 +1167,7 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
         const int rc = rp_bwd_prepare(mem[m].net, mem[m].bwd, stream);
         if (rc != RP_OK) return rc;
     }
+    if (coupled_fused_ok(mem, count)) return coupled_fused_sweep(mem, count, T, st);
     for (int t = T - 1; t >= 0; --t) {
         // the gradient through the edges first: gx_m(t) = row t of m's grad_x is ready (prep of the step before)
         for (int m = 0; m < count; ++m) {
@@ -1007,7 +1176,7 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
                 const int q = M.edge_source[e];
                 const int tau = M.edge_mode[e] == RP_EDGE_LAG ? t - 1 : t;
                 if (tau < 0) continue;
-                BwdParams P = {};
+                BwdParams P = {};  // (the edges of a member are evaluated one after the other: they share edge_work)
                 P.W = M.edge_w[e];
                 P.ldw = M.edge_ld[e];
                 P.n = mem[q].net->n;

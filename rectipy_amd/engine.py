@@ -732,7 +732,7 @@ def backward_coupled(members: list) -> list:
     count = len(members)
     arr = (_abi.RpBwdMember * count)()
     keep_all = []
-    work_floats = 0
+    work_floats = [0] * count
     for m, spec in enumerate(members):
         pop: Population = spec["pop"]
         for We, source, _ in spec.get("edges") or []:
@@ -741,11 +741,11 @@ def backward_coupled(members: list) -> list:
                     or We.device != pop.device:
                 raise RuntimeError(f"member {m}: an edge matrix must be a float32 [{pop.rows}, {src.n}] matrix with unit "
                                    f"column stride on {pop.device}")
-            work_floats = max(work_floats, pop.backend.shard_partial_rows(src.n, pop.rows) * src.n)
+            work_floats[m] += pop.backend.shard_partial_rows(src.n, pop.rows) * src.n  # (every edge its own slice)
     first: Population = members[0]["pop"]
-    work = torch.empty(max(work_floats, 4), dtype=torch.float32, device=first.device)
     for m, spec in enumerate(members):
         pop = spec["pop"]
+        work = torch.empty(max(work_floats[m], 4), dtype=torch.float32, device=pop.device)
         net, b, keep = pop._backward_args(_args_only="stepwise", **spec["bwd"])
         z = torch.empty(pop.n, dtype=torch.float32, device=pop.device)
         edges = spec.get("edges") or []
@@ -756,9 +756,8 @@ def backward_coupled(members: list) -> list:
             arr[m].edge_source[e], arr[m].edge_mode[e] = int(source), int(mode)
         arr[m].edge_work = work.data_ptr()
         arr[m].z = z.data_ptr()
-        keep_all.append((net, b, keep, z, [We for We, _, _ in edges]))
+        keep_all.append((net, b, keep, z, work, [We for We, _, _ in edges]))
     first.backend.backward_coupled(arr, count, first.device)
-    keep_all.append(work)
     return keep_all
 
 
