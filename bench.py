@@ -797,7 +797,10 @@ def stepwise_extra(dev):
     takes the fused-window plan; the same graph forced onto the step-by-step walk is what r02 paid; (iii) a
     FeedbackNetwork of two populations of N/2 neurons (a -> b, feedback b -> a; dense N/2 x N/2 edges) -- r04: one
     rp_forward_coupled call per window, both edge matrices streamed by the targets' step kernels (r03: a Python walk per
-    step with the edge products in rocBLAS); the same graph forced onto the per-step walk is reported next to it."""
+    step with the edge products in rocBLAS); the same graph forced onto the per-step walk is reported next to it; (iv) the
+    same two populations trained: FeedbackNetwork.fit_bptt, both W and both edge matrices trainable plus a read-out of
+    width 3, SGD windows of 50 steps -- r04: one rp_forward_coupled and one rp_backward_coupled call per window (+ the
+    weight-gradient GEMMs and the optimiser); at N = 4096 also with the adjoint forced onto autograd over the per-step walk."""
     import contextlib
     from rectipy_amd import FeedbackNetwork, Network
     tanh = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
@@ -863,7 +866,34 @@ def stepwise_extra(dev):
             fb._force_stepwise = True
             rec["feedback_two_populations_step_by_step_walk"] = timed(
                 lambda steps: fb.run(x_h[:steps], sampling_steps=steps, verbose=False, enable_grad=False), T)
-            del fb, x_h
+            del fb
+            torch.cuda.empty_cache()
+            # (iv) the two populations trained through the cycle
+            train_kw = lambda Wm: dict(node_kw(Wm), train_params=["weights"])
+            y_h = torch.randn(T, 3, device=dev, generator=gen) * 0.1
+            for walk in ((False, True) if N <= 4096 else (False,)):
+                fb = FeedbackNetwork(dt=1e-2, device=str(dev))
+                fb.add_diffeq_node("a", tanh, **train_kw(gen_rows(h, 0, h, dev, g=0.8)))
+                fb.add_diffeq_node("b", tanh, **train_kw(gen_rows(h, 0, h, dev, g=0.8)))
+                fb.add_func_node("out", 3, "identity")
+                fb.add_edge("a", "b", weights=gen_rows(h, 0, h, dev, g=0.5), train="gd")
+                fb.add_edge("b", "a", weights=gen_rows(h, 0, h, dev, g=0.5), feedback=True, train="gd")
+                fb.add_edge("b", "out", weights=torch.randn(3, h, device=dev, generator=gen) / h ** 0.5, train="gd")
+                fb._force_stepwise_adjoint = walk
+                Tf = T // 50 * 50 if not walk else 200
+
+                def fit(steps, fb=fb):
+                    steps = max(50, steps // 50 * 50)
+                    fb.fit_bptt(x_h[:steps], y_h[:steps], optimizer="sgd", lr=1e-4, update_steps=50, sampling_steps=50, verbose=False)
+                fit(50)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fit(Tf)
+                torch.cuda.synchronize()
+                rec["feedback_fit_bptt" + ("_adjoint_on_the_per_step_walk" if walk else "")] = (time.perf_counter() - t0) / Tf * 1e6
+                del fb
+                torch.cuda.empty_cache()
+            del x_h, y_h
             torch.cuda.empty_cache()
             res["sizes"][f"N{N}"] = {k_: round(v_, 2) for k_, v_ in rec.items()}
     return res
