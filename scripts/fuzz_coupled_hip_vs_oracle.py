@@ -2,7 +2,9 @@
 RANDOM shapes -- 2..4 populations (tanh / sigmoid / QIF / LIF, sizes from 5 to ~1100: 4-byte and 16-byte paths, ragged
 chunks, different widths), random feed-forward chains with random feedback edges (the three edge read modes of
 rp_forward_coupled arise from their direction and the source's kind), optional input / read-out layers, recorded
-variables, sampling, cutoff, two consecutive runs; run_batch with random B, sampling and input edge.  Populations'
+variables, sampling, cutoff, two consecutive runs; the same graphs with every parameter trained (fit_bptt, two SGD windows:
+the fused adjoint rp_backward_coupled on the GPU and on the oracle against autograd over the per-step walk, to 1e-4, 5e-3
+with spiking populations); run_batch with random B, sampling and input edge.  Populations'
 outputs are compared BIT FOR BIT where no device-side torch product lies in front of them (no input layer), else to 2e-5
 (5e-4 for spiking populations, whose spike times may move by a step behind a rounded input); batched runs bit for bit
 up to 4 trajectories (vector ALUs) and to 2e-5 on the matrix cores.
@@ -33,7 +35,7 @@ KINDS = {
 }
 
 
-def add_population(net, label, kind, n, rng):
+def add_population(net, label, kind, n, rng, train=False):
     K = KINDS[kind]
     op = K["op"]
     if K.get("spike"):
@@ -48,12 +50,14 @@ def add_population(net, label, kind, n, rng):
                      "all/li_op/eta": rng.standard_normal(n) * 0.1, "all/li_op/v": rng.standard_normal(n) * 0.5}
         kw = {}
     out_var = K["outs"][int(rng.integers(0, len(K["outs"])))]
+    if train:
+        kw["train_params"] = ["weights", f"{op}/tau", f"{op}/k", f"{op}/eta"] + ([f"{op}/tau_s"] if K.get("spike") else [])
     net.add_diffeq_node(label, K["path"], weights=W, source_var=K["src"], target_var=K["tgt"], input_var=f"{op}/I_ext",
                         output_var=out_var, dtype=torch.float32, node_vars=node_vars, **kw)
     return f"{op}/v"
 
 
-def build_feedback(where, seed, kinds, sizes, m, k, fb_pairs):
+def build_feedback(where, seed, kinds, sizes, m, k, fb_pairs, train=False):
     rng = np.random.default_rng(seed)
     net = FeedbackNetwork(5e-3, **where)
     if m:
@@ -61,16 +65,17 @@ def build_feedback(where, seed, kinds, sizes, m, k, fb_pairs):
     labels = "abcd"[:len(sizes)]
     rec_var = None
     for lab, kind, n in zip(labels, kinds, sizes):
-        v = add_population(net, lab, kind, n, rng)
+        v = add_population(net, lab, kind, n, rng, train)
         rec_var = rec_var or (lab, v)
     if k:
         net.add_func_node("out", k, ["identity", "tanh"][int(rng.integers(0, 2))])
     order = (["inp"] if m else []) + list(labels) + (["out"] if k else [])
     width = dict(zip(labels, sizes), inp=m, out=k)
     for s_, t_ in zip(order[:-1], order[1:]):
-        net.add_edge(s_, t_, weights=rng.standard_normal((width[t_], width[s_])) * 0.7 / np.sqrt(width[s_]))
+        net.add_edge(s_, t_, weights=rng.standard_normal((width[t_], width[s_])) * 0.7 / np.sqrt(width[s_]), train="gd" if train else None)
     for s_, t_ in fb_pairs:
-        net.add_edge(labels[s_], labels[t_], weights=rng.standard_normal((sizes[t_], sizes[s_])) * 0.5 / np.sqrt(sizes[s_]), feedback=True)
+        net.add_edge(labels[s_], labels[t_], weights=rng.standard_normal((sizes[t_], sizes[s_])) * 0.5 / np.sqrt(sizes[s_]), feedback=True,
+                     train="gd" if train else None)
     return net, rec_var
 
 
@@ -91,7 +96,43 @@ def main(cases=40, seed=0, max_n=1100):
     for case in range(cases):
         cfg = {}
         try:
-            if rng.integers(0, 3) < 2:  # ---- a FeedbackNetwork ----
+            mode = int(rng.integers(0, 4))
+            if mode == 3:  # ---- a FeedbackNetwork trained through its cycles: fit_bptt, every parameter ----
+                npop = int(rng.integers(2, 4))
+                kinds = [list(KINDS)[int(rng.integers(0, 4))] for _ in range(npop)]
+                sizes = [int(rng.choice([rng.integers(5, 40), rng.integers(250, 300), rng.integers(min(500, max_n - 1), max_n)])) for _ in range(npop)]
+                m, k = int(rng.integers(0, 3)), int(rng.integers(1, 3))
+                pairs = set()
+                for _ in range(int(rng.integers(1, 3))):
+                    s_, t_ = int(rng.integers(0, npop)), int(rng.integers(0, npop))
+                    if s_ != t_ and (s_, t_) not in pairs and t_ != s_ + 1:
+                        pairs.add((s_, t_))
+                if not pairs:
+                    pairs = {(npop - 1, 0)}
+                win = int(rng.integers(8, 25))
+                T = 2 * win + int(rng.integers(0, 5))
+                spiking = any(KINDS[q].get("spike") for q in kinds)
+                cfg = dict(kind="fit", kinds=kinds, sizes=sizes, m=m, k=k, fb=sorted(pairs), T=T, win=win)
+                x = (rng.standard_normal((T, m if m else sizes[0])) * 0.5 + (1.5 if KINDS[kinds[0]].get("spike") else 0.0)).astype(np.float32)
+                y = (rng.standard_normal((T, k)) * 0.2).astype(np.float32)
+                res = []
+                for where, walk in ((wheres[0], True), (wheres[0], False), (wheres[1], False)):
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        net, _ = build_feedback(where, 1000 * seed + case, kinds, sizes, m, k, sorted(pairs), train=True)
+                        net._force_stepwise_adjoint = walk
+                        net.compile()
+                        fused = net._coupled_grad_plan() is not None
+                        obs = net.fit_bptt(x, y, optimizer="sgd", lr=2e-3 if spiking else 2e-2, update_steps=win, sampling_steps=1, verbose=False)
+                    uniq = list({id(q): q for q in net.parameters()}.values())
+                    res.append(([q.detach().cpu().numpy() for q in uniq], obs.to_numpy("out"), fused))
+                tol = 5e-3 if spiking else 1e-4
+                ok = res[1][2] == res[2][2] and not res[0][2]
+                for other in (1, 2):   # oracle fused vs oracle walk; HIP fused vs oracle walk
+                    for a, b in zip(res[0][0], res[other][0]):
+                        ok = ok and close(a, b, tol)
+                    ok = ok and close(res[0][1], res[other][1], tol)
+                cfg["fused_adjoint"] = res[1][2]
+            elif mode < 2:  # ---- a FeedbackNetwork ----
                 npop = int(rng.integers(2, 5))
                 kinds = [list(KINDS)[int(rng.integers(0, 4))] for _ in range(npop)]
                 sizes = [int(rng.choice([rng.integers(5, 40), rng.integers(250, 300), rng.integers(min(500, max_n - 1), max_n)])) for _ in range(npop)]

@@ -23,7 +23,8 @@ def test_random_front_end_sequences_hip_equals_oracle(seed, hip_device, capsys):
 @pytest.mark.parametrize("seed", [5, 6])
 def test_random_feedback_graphs_and_batched_runs_hip_equals_oracle(seed, hip_device, capsys):
     """scripts/fuzz_coupled_hip_vs_oracle.py: random FeedbackNetwork graphs (2..4 populations, tanh / sigmoid / QIF / LIF,
-    all three edge read modes of rp_forward_coupled, shared and per-member launches by size) and random Network.run_batch
+    all three edge read modes of rp_forward_coupled, shared and per-member launches by size), the same graphs trained through
+    their cycles (fit_bptt: the fused adjoint on the GPU against autograd over the per-step walk) and random Network.run_batch
     calls (in-kernel sampling, all three batched forms), HIP against the oracle."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import fuzz_coupled_hip_vs_oracle
