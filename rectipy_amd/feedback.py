@@ -376,6 +376,7 @@ class FeedbackNetwork(Network):
         """The output node's per-step outputs over the window [a, a + len), with the graph of ONE autograd node for all
         populations (`_CoupledWindow`) between the torch ops of the input layers and the read-outs."""
         pops = plan["pops"]
+        self._consolidate(plan)
         xin = self._coupled_inputs(plan, inputs_ab)
         flat = []
         for p in pops:
@@ -538,8 +539,8 @@ class FeedbackNetwork(Network):
         Measured on MI355X (scripts/probes/coupled_alloc2.py; two populations of 16384 neurons, four 1 GiB matrices): out
         of one allocation the step takes 603-619 us on every box and trial -- the single-population kernel's time for the
         same bytes -- while four separate 1 GiB allocations give 611-619 us or 653-667 us depending on where the driver
-        happened to place them (same kernel, same data; which matrices share a launch does not matter).  Trained matrices
-        stay where they are (an optimiser holds on to its parameter tensors)."""
+        happened to place them (same kernel, same data; which matrices share a launch does not matter).  A trained matrix
+        keeps its tensor object (an optimiser holds on to it): its `.data` becomes the view."""
         mats = []
         for p in plan["pops"]:
             pop = self.get_node(p)._pop
@@ -547,7 +548,8 @@ class FeedbackNetwork(Network):
             for s_, _ in plan["edges"][p]:
                 mats.append((self.get_edge(s_, p), "weights"))
         tensors = [getattr(o, a) for o, a in mats]
-        if not tensors or tensors[0].device.type != "cuda" or any(t.requires_grad or not t.is_contiguous() for t in tensors):
+        if not tensors or tensors[0].device.type != "cuda" or any(not t.is_contiguous() or (t.requires_grad and not t.is_leaf)
+                                                                  for t in tensors):
             return
         total = sum(t.numel() for t in tensors)
         if 4 * total < self.ARENA_MIN_BYTES:
@@ -563,8 +565,11 @@ class FeedbackNetwork(Network):
         arena = torch.empty(off, dtype=torch.float32, device=tensors[0].device)
         for (obj, attr), t, o in zip(mats, tensors, offs):
             view = arena[o:o + t.numel()].view(t.shape)
-            view.copy_(t)
-            setattr(obj, attr, view)
+            view.copy_(t.detach())
+            if t.requires_grad:
+                t.data = view
+            else:
+                setattr(obj, attr, view)
             if attr == "W":
                 obj._net_cache = None
                 if obj.packed is not None:

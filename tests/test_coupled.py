@@ -407,6 +407,29 @@ def test_matrices_move_into_one_allocation_and_stay_live(hip_device, monkeypatch
     assert np.array_equal(a, b) and net._arena is arena  # (nothing to consolidate the second time)
 
 
+@pytest.mark.gpu
+def test_trained_matrices_move_too_and_keep_their_tensor_objects(hip_device, monkeypatch):
+    """fit_bptt through a cycle: the trained matrices are consolidated as well -- the parameter objects the optimiser holds
+    stay the same, their storage becomes the arena -- and training ends where it ends without consolidation."""
+    r = np.random.default_rng(0)
+    x, y = r.standard_normal((40, 3)).astype(np.float32), r.standard_normal((40, 2)).astype(np.float32) * 0.3
+    target = dict(device="cuda:0", backend=None)
+    res = []
+    for arena_min in (1 << 60, 0):
+        monkeypatch.setattr(FeedbackNetwork, "ARENA_MIN_BYTES", arena_min)
+        net = build_trained(target, False, sizes=(16, 24))
+        net.compile()
+        before = {id(p) for p in net.parameters()}
+        net.fit_bptt(x, y, optimizer="sgd", lr=0.05, update_steps=20, sampling_steps=1, verbose=False)
+        assert {id(p) for p in net.parameters()} == before
+        mats = [net.get_node("a")["weights"], net.get_node("b")["weights"], net.get_edge("a", "b").weights, net.get_edge("b", "a").weights]
+        assert (len({t.untyped_storage().data_ptr() for t in mats}) == 1) == (arena_min == 0)
+        assert all(t.requires_grad and t.is_leaf for t in mats)
+        res.append([p.detach().cpu().numpy().copy() for p in net.parameters()])
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
 # ---- against the reference itself (golden G36) ---------------------------------------------------------------------------
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
 def test_g36_feedback_network_at_kernel_sizes_matches_the_reference(target, monkeypatch):
