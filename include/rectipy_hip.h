@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 12
+#define RP_ABI_VERSION 13
 #define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0
@@ -589,6 +589,21 @@ typedef struct rp_rls {
        half of P (the state the next symmetric sweep starts from anyway) and the caller restores the lower blocks with
        rp_rls_mirror before anything else reads P.  Saves one pass over half of P per call (0.78 ms at n_in = 32768). */
     int32_t defer_mirror;
+    /* symmetric pass only: block > 1 (2, 4 or 8) selects the BLOCKED sweep -- P is streamed once per `block` updates.
+       The inputs of a whole window are known in advance, and P_{t-1} = P_b - sum_{i<t} k_i z_i z_i^T inside a block that
+       starts from P_b, so ONE pass applies the block before's rank-1 updates (element by element in update order: the bits
+       of that many separate passes) and forms Y_j = beta^-1 P_b x_j for all inputs x_j of the block (each exactly as the
+       symmetric pass forms z'); then, per update j of the block, without touching P:
+           z_j = Y_j - sum_{i<j} g_ij z_i,  g_ij = beta^-1 (k_i c_ij),  c_ij = z_i . x_j,  k_j = 1 / (1 + z_j . x_j)
+       IN DOUBLE PRECISION -- consecutive inputs of a slowly moving population are alike, so z_j is a small difference of
+       large vectors: acc = Y_j[q]; acc = fma(-g_ij, z_i[q], acc) for i ascending; z_j[q] = (float)acc; the dot products
+       in the order of x.z with double accumulators -- and the prediction, the loss and the weight update from z_j and k_j as
+       always.  Mathematically the reference's recursion; measured against its float64 run the blocked sweep is as close as
+       the pass per update (G31 / G34).  Workspaces grow by the factor `block`: partials [block x n_in x ceil(n_in /
+       1024)], colparts [block x chunks x ldc]; blk: 2 * block * n_in floats (Y, the block's z vectors), block^2 doubles
+       (c_ij), block floats (k_i), 16-byte aligned.  0 / 1: one pass per update (above). */
+    int32_t block;
+    float* blk;
 } rp_rls;
 
 /* `steps` consecutive rows of X [steps x ldx] (edge inputs) and Y [steps x ldy] (targets); an update happens at

@@ -33,6 +33,17 @@ static float block_dot(const float* a, const float* b, int n) {
     return red[0];
 }
 
+/* the same tree in double precision (rls_blk_scalars_kernel: x.z and the c_ij of the blocked sweep) */
+static double block_dot64(const float* a, const float* b, int n) {
+    static double red[1024];
+#pragma omp threadprivate(red)
+    for (int t = 0; t < 1024; ++t) red[t] = 0.0;
+    for (int j = 0; j < n; ++j) red[j & 1023] = fma((double)a[j], (double)b[j], red[j & 1023]);
+    for (int off = 512; off >= 1; off >>= 1)
+        for (int t = 0; t < off; ++t) red[t] = red[t] + red[t + off];
+    return red[0];
+}
+
 static float wave_dot(const float* a, const float* b, int n) { /* rls_predict_kernel */
     float s[64];
     for (int l = 0; l < 64; ++l) s[l] = 0.0f;
@@ -160,6 +171,68 @@ static void sym_mirror(const rp_rls* r) {
         for (int j = ((i >> 10) + 1) << 10; j < n; ++j) r->P[(int64_t)j * r->ldp + i] = r->P[(int64_t)i * r->ldp + j];
 }
 
+/* blocked symmetric sweep (rp_rls.block > 1): P is visited once per `block` updates.  The pass applies the rank-1 updates
+   of the block before (one after the other: element by element the arithmetic of the fused kernel) and forms
+   Y_j = beta^-1 P x_j for the block's inputs; the block's z vectors follow from Y and the earlier z of the block. */
+static int sweep_blocked(const rp_rls* r, int32_t steps, int32_t stride, const float* X, int64_t ldx, const float* Y,
+                         int64_t ldy, float* pred, int64_t ldpred, float* loss) {
+    const int n = r->n_in, m = r->n_out, K = r->block;
+    float* Yb = r->blk;
+    float* Zb = Yb + (int64_t)K * n;
+    double* cm = (double*)(Zb + (int64_t)K * n);  /* c_ij, double */
+    float* kk = (float*)(cm + K * K);
+    float* err = r->scratch + 4;
+    const int updates = (steps + stride - 1) / stride;
+    int pending = 0;
+    for (int u0 = 0; u0 < updates; u0 += K) {
+        const int cnt = updates - u0 < K ? updates - u0 : K;
+        for (int i = 0; i < pending; ++i) sym_pass(r, 1, kk[i], Zb + (int64_t)i * n, 0, 0);
+        for (int j = 0; j < cnt; ++j) sym_pass(r, 0, 0.0f, 0, X + (int64_t)(u0 + j) * stride * ldx, Yb + (int64_t)j * n);
+        for (int j = 0; j < cnt; ++j) {
+            const int t = (u0 + j) * stride;
+            const float* x = X + (int64_t)t * ldx;
+            const float* y = Y + (int64_t)t * ldy;
+            float* z = Zb + (int64_t)j * n;
+            /* the recurrence in double (z_j is a small difference of large vectors when consecutive inputs are alike) */
+            for (int q = 0; q < n; ++q) {
+                double acc = (double)Yb[(int64_t)j * n + q];
+                for (int i = 0; i < j; ++i) {
+                    const double g = (double)r->beta_inv * ((double)kk[i] * cm[i * K + j]);
+                    acc = fma(-g, (double)Zb[(int64_t)i * n + q], acc);
+                }
+                z[q] = (float)acc;
+            }
+            const float k = (float)(1.0 / (1.0 + block_dot64(z, x, n)));
+            float l = 0.0f;
+            for (int o = 0; o < m; ++o) {
+                const float yhat = block_dot(r->W + (int64_t)o * r->ldw, x, n);
+                const float e = y[o] - yhat;
+                l = fmaf(e, e, l);
+                err[o] = e;
+                if (pred) pred[(int64_t)t * ldpred + o] = yhat;
+            }
+            kk[j] = k;
+            for (int jn = j + 1; jn < cnt; ++jn) cm[j * K + jn] = block_dot64(z, X + (int64_t)(u0 + jn) * stride * ldx, n);
+            const int seg = t + stride <= steps ? stride : steps - t;
+            if (loss)
+                for (int q = 0; q < seg; ++q) loss[t + q] = l;
+            for (int o = 0; o < m; ++o)
+                for (int q = 0; q < n; ++q) {
+                    float* w = r->W + (int64_t)o * r->ldw + q;
+                    *w = *w + (k * err[o]) * z[q];
+                }
+            if (pred)
+                for (int q = 1; q < seg; ++q)
+                    for (int o = 0; o < m; ++o)
+                        pred[(int64_t)(t + q) * ldpred + o] = wave_dot(r->W + (int64_t)o * r->ldw, X + (int64_t)(t + q) * ldx, n);
+        }
+        pending = cnt;
+    }
+    for (int i = 0; i < pending; ++i) sym_pass(r, 1, kk[i], Zb + (int64_t)i * n, 0, 0);
+    if (!r->defer_mirror) sym_mirror(r);
+    return RP_OK;
+}
+
 int oracle_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, const float* X, int64_t ldx, const float* Y,
                      int64_t ldy, float* pred, int64_t ldpred, float* loss) {
     const int n = r->n_in, m = r->n_out;
@@ -167,6 +240,7 @@ int oracle_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, const float
     const int vec4 = (n % 4 == 0) && (r->ldp % 4 == 0) && (ldx % 4 == 0);
     const int tiled = vec4 && r->partials != 0;
     const int sym = tiled && r->colparts != 0;
+    if (sym && r->block > 1) return sweep_blocked(r, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss);
     float* za = r->z;
     float* zb = r->zn;
     float* err = r->scratch + 4;

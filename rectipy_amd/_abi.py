@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 12
+RP_ABI_VERSION = 13
 RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_MFMA16, RP_BATCH_SLOTS = 0, 1, 2, 32
 RP_COMM_RCCL, RP_COMM_DIRECT = 0, 1
 
@@ -237,6 +237,8 @@ class RpRls(C.Structure):
         ("ldc", C.c_int64),
         ("sym_rows", C.c_int32),
         ("defer_mirror", C.c_int32),
+        ("block", C.c_int32),
+        ("blk", fp),
     ]
 
 

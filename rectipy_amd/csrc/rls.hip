@@ -44,6 +44,18 @@ struct RlsParams {
     float* partials;  // tiled pass: [n_in x tiles_per_row] partial dot products
     float* colparts;  // symmetric pass: [ceil(n_in / 64) x ldc] column partials of the off-diagonal blocks
     int64_t ldc;
+    // blocked symmetric sweep (rp_rls.block): the block before's rank-1 updates and the inputs of this block
+    const float* zp;     // [npend x n_in] z vectors of the updates to apply
+    const float* kp;     // [npend] their k
+    int npend;
+    const float* xb;     // first input row of the block; row j at xb + j * xb_stride
+    int64_t xb_stride;
+    int nrhs;
+    int64_t part_stride, col_stride;  // floats between the partials / column partials of consecutive inputs
+    float* yb;           // [K x n_in] Y_j = beta^-1 P x_j
+    double* cm;          // [K x K] c_ij = z_i . x_j
+    float* kk;           // [K] k of the block's updates
+    int j, K;            // the update of the block the small kernels work on
 };
 
 // d = x.z, k = 1/(1+d), y_hat = W x, err = y - y_hat, loss = err.err.  One block per dot product (block 0: x.z, block
@@ -459,8 +471,12 @@ __global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
 // column partials colpart[c][i] of the chunks c of block row b added in ascending order from the first one.  One
 // workgroup per 32 columns: thread (c, s) adds up the block rows b = s, s + 32, ... of column c (their sums are
 // independent), thread (c, 0) chains them and the row partials in the order above.
-__global__ __launch_bounds__(1024) void rls_sym_zn_kernel(const RlsParams P, int rows_per_chunk) {
+__global__ __launch_bounds__(1024) void rls_sym_zn_kernel(const RlsParams P0, int rows_per_chunk) {
     extern __shared__ float colsum[];  // [nb][32]
+    RlsParams P = P0;  // blocked sweep: blockIdx.y = input j of the block (its slices of the partials, its row of Y)
+    P.partials += (int64_t)blockIdx.y * P0.part_stride;
+    P.colparts += (int64_t)blockIdx.y * P0.col_stride;
+    P.zn += (int64_t)blockIdx.y * P0.n_in;
     const int c = threadIdx.x & 31, slot = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + c;
     const int nb = (P.n_in + 1023) >> 10;
@@ -542,6 +558,235 @@ __global__ __launch_bounds__(kThreads) void rls_mirror_kernel(float* Pm, int64_t
     }
 }
 
+
+// ---- blocked symmetric sweep (rp_rls.block = K) ------------------------------------------------------------------------
+// The symmetric pass with K rank-1 updates and K inputs at once: per element p -= (k_0 z_0i) z_0j, then -= (k_1 z_1i) z_1j,
+// ... (update order: the bits of K separate passes), store, and for every input x_j of the block the row partial and
+// the column chain exactly as rls_sym_kernel forms them for its one input -- into slice j of the partials / column
+// partials.  Updates / inputs beyond npend / nrhs are zeros (p - 0 * 0 = p; their partials are never read).
+// The K x R lane sums of a group of R rows go through ONE transposed butterfly (K R values: the same additions per row).
+template <int K, bool UPDATE, bool DOT, int C, int R, bool FULL>
+__global__ __launch_bounds__(kThreads) void rls_symk_kernel(const RlsParams P) {
+    __shared__ float wsum[DOT ? K : 1][C][4];
+    __shared__ float kzrow[UPDATE ? K : 1][C], xrow[DOT ? K : 1][C];
+    static_assert(C % (2 * R) == 0 && (R & (R - 1)) == 0 && K * R <= 64, "groups of R rows, K R values per butterfly");
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int n = P.n_in;
+    const int nb = (n + 1023) >> 10;
+    int b = blockIdx.x, I = 0;
+    while (b >= nb - I) {
+        b -= nb - I;
+        ++I;
+    }
+    const int ct = I + b;
+    const int chunk = I * (1024 / C) + blockIdx.y;
+    const int row0 = chunk * C;
+    if (!FULL && row0 >= n) return;
+    const bool upper = ct > I;
+    const int col = ct * 1024 + 256 * wave + 4 * lane;
+    const bool valid = FULL || col < n;
+    const rp_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float* base = P.P + (int64_t)row0 * P.ldp + col;
+    rp_f4 bufA[R], bufB[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        bufA[r] = (FULL || (valid && row0 + r < n)) ? rp_ld4_stream(base + (int64_t)r * P.ldp) : zero4;
+    rp_f4 zv[UPDATE ? K : 1], xv[DOT ? K : 1];
+    if constexpr (UPDATE) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) zv[k] = (valid && k < P.npend) ? rp_ld4(P.zp + (int64_t)k * n + col) : zero4;
+    }
+    if constexpr (DOT) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) xv[k] = (valid && k < P.nrhs) ? rp_ld4(P.xb + (int64_t)k * P.xb_stride + col) : zero4;
+    }
+    for (int e = threadIdx.x; e < K * C; e += kThreads) {
+        const int k = e / C, r = e - k * C;
+        const int i = row0 + r;
+        const bool in = FULL || i < n;
+        if constexpr (UPDATE) kzrow[k][r] = (in && k < P.npend) ? P.kp[k] * P.zp[(int64_t)k * n + i] : 0.f;
+        if constexpr (DOT) xrow[k][r] = (in && k < P.nrhs) ? P.xb[(int64_t)k * P.xb_stride + i] : 0.f;
+    }
+    __syncthreads();
+    rp_f4 cp[DOT ? K : 1];
+    if constexpr (DOT) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) cp[k] = zero4;
+    }
+    constexpr int kGroup = 64 / (K * R);  // lanes that hold the same (input, row) total after the transposed butterfly
+    auto group = [&](const int g, const rp_f4 (&cur)[R]) {
+        float rs[DOT ? K * R : 1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = row0 + g + r;
+            rp_f4 p = cur[r];
+            if constexpr (UPDATE) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const float kz = kzrow[k][g + r];
+                    p.x = p.x - kz * zv[k].x;
+                    p.y = p.y - kz * zv[k].y;
+                    p.z = p.z - kz * zv[k].z;
+                    p.w = p.w - kz * zv[k].w;
+                }
+                if (FULL || (valid && i < n))
+                    __builtin_nontemporal_store(p, reinterpret_cast<rp_f4*>(base + (int64_t)(g + r) * P.ldp));
+            }
+            if constexpr (DOT) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    rp_f4 a;
+                    a.x = fmaf(p.x, xv[k].x, 0.f);
+                    a.y = fmaf(p.y, xv[k].y, 0.f);
+                    a.z = fmaf(p.z, xv[k].z, 0.f);
+                    a.w = fmaf(p.w, xv[k].w, 0.f);
+                    rs[k * R + r] = rp_lane_sum4(a);
+                    if (FULL || (upper && i < n)) {  // (on a diagonal block the chain is computed and dropped, as in rls_sym_kernel)
+                        const float xi = xrow[k][g + r];
+                        cp[k].x = fmaf(p.x, xi, cp[k].x);
+                        cp[k].y = fmaf(p.y, xi, cp[k].y);
+                        cp[k].z = fmaf(p.z, xi, cp[k].z);
+                        cp[k].w = fmaf(p.w, xi, cp[k].w);
+                    }
+                }
+            }
+        }
+        if constexpr (DOT) {
+            const float total = rp_rows_allreduce<K * R>(rs, lane);
+            if ((lane & (kGroup - 1)) == 0) {
+                const int f = rp_rows_allreduce_row<K * R>(lane);
+                wsum[f / R][g + f % R][wave] = total;
+            }
+        }
+    };
+    auto fetch = [&](const int g, rp_f4 (&buf)[R]) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            buf[r] = (FULL || (valid && row0 + g + r < n)) ? rp_ld4_stream(base + (int64_t)(g + r) * P.ldp) : zero4;
+    };
+#pragma unroll 1
+    for (int g = 0; g + 2 * R < C; g += 2 * R) {
+        fetch(g + R, bufB);
+        group(g, bufA);
+        fetch(g + 2 * R, bufA);
+        group(g + R, bufB);
+    }
+    fetch(C - R, bufB);
+    group(C - 2 * R, bufA);
+    group(C - R, bufB);
+    if constexpr (DOT) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < K * C; e += kThreads) {
+            const int k = e / C, r = e - k * C;
+            if (k < P.nrhs && (FULL || row0 + r < n))
+                P.partials[(int64_t)k * P.part_stride + (int64_t)(row0 + r) * nb + ct] =
+                    ((wsum[k][r][0] + wsum[k][r][1]) + wsum[k][r][2]) + wsum[k][r][3];
+        }
+        if (upper && valid) {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (k < P.nrhs)
+                    *reinterpret_cast<rp_f4*>(P.colparts + (int64_t)k * P.col_stride + (int64_t)chunk * P.ldc + col) = cp[k];
+        }
+    }
+}
+
+// z_j = Y_j - sum_{i<j} g_ij z_i in double: acc = Y_j[q]; acc = fma(-g_ij, z_i[q], acc), i ascending; g_ij = beta^-1 (k_i c_ij)
+__global__ __launch_bounds__(256) void rls_blk_z_kernel(const RlsParams P) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= P.n_in) return;
+    double acc = (double)P.yb[(int64_t)P.j * P.n_in + q];
+    for (int i = 0; i < P.j; ++i) {
+        const double g = (double)P.beta_inv * ((double)P.kk[i] * P.cm[i * P.K + P.j]);
+        acc = fma(-g, (double)P.z[(int64_t)(i - P.j) * P.n_in + q], acc);  // (P.z = z_j: the earlier vectors lie before it)
+    }
+    P.z[q] = (float)acc;
+}
+
+// The scalar kernel of the blocked sweep.  Block 0: d = z_j . x_j, blocks 1 + jn: c_{j, j + 1 + jn} = z_j . x_{j+1+jn} -- both
+// with DOUBLE accumulators in the order of rls_scalars_kernel -- , the last n_out blocks: y_hat_o = W_o . x_j as there.  The
+// block that finishes last forms k_j = 1 / (1 + d) (rounded once), err, loss.
+__global__ __launch_bounds__(1024) void rls_blk_scalars_kernel(const RlsParams P, int extra) {
+    __shared__ double red64[1024];
+    __shared__ float red[1024];
+    __shared__ int is_last;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    if (b <= extra) {
+        const float* x = b == 0 ? P.x : P.x + (int64_t)b * P.xb_stride;  // (x_j ... and the later inputs of the block)
+        double a = 0.0;
+        for (int j0 = tid; j0 < P.n_in; j0 += 8 * 1024) {
+            float uv[8], xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = j0 + q * 1024;
+                uv[q] = j < P.n_in ? P.z[j] : 0.f;
+                xv[q] = j < P.n_in ? x[j] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (j0 + q * 1024 < P.n_in) a = fma((double)uv[q], (double)xv[q], a);
+        }
+        red64[tid] = a;
+        __syncthreads();
+        for (int off = 512; off >= 1; off >>= 1) {
+            if (tid < off) red64[tid] = red64[tid] + red64[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) P.cm[P.j * P.K + P.j + b] = red64[0];  // (the diagonal entry holds d)
+    } else {
+        const int o = b - extra - 1;
+        const float* u = P.W + (int64_t)o * P.ldw;
+        float a = 0.f;
+        for (int j0 = tid; j0 < P.n_in; j0 += 8 * 1024) {
+            float uv[8], xv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int j = j0 + q * 1024;
+                uv[q] = j < P.n_in ? u[j] : 0.f;
+                xv[q] = j < P.n_in ? P.x[j] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (j0 + q * 1024 < P.n_in) a = fmaf(uv[q], xv[q], a);
+        }
+        red[tid] = a;
+        __syncthreads();
+        for (int off = 512; off >= 1; off >>= 1) {
+            if (tid < off) red[tid] = red[tid] + red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) P.err[o] = red[0];  // y_hat for now
+    }
+    if (tid == 0) {
+        __threadfence();
+        is_last = atomicAdd(reinterpret_cast<unsigned*>(P.scal + 3), 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    if (tid == 0) {
+        __threadfence();
+        const double d = __hip_atomic_load(P.cm + P.j * P.K + P.j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float k = (float)(1.0 / (1.0 + d));
+        float loss = 0.f;
+        for (int o = 0; o < P.n_out; ++o) {
+            const float yhat = __hip_atomic_load(P.err + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float e = P.y[o] - yhat;
+            loss = fmaf(e, e, loss);
+            P.err[o] = e;
+            if (P.pred) P.pred[o] = yhat;
+        }
+        P.scal[0] = k;
+        P.scal[1] = loss;
+        P.kk[P.j] = k;
+        *reinterpret_cast<unsigned*>(P.scal + 3) = 0u;
+        red[0] = loss;
+    }
+    __syncthreads();
+    if (P.loss_out && tid < P.loss_count) P.loss_out[tid] = red[0];
+}
+
 constexpr int kSymRowsDefault = 64;
 #ifdef RP_MEASUREMENT
 std::atomic<int> g_sym_inflight{0};  // measurement build only (rp_set_rls_sym): rows in flight per wave; 0 = built-in
@@ -607,6 +852,108 @@ int launch_sym(const RlsParams& P, int rows, hipStream_t st) {
 #undef RP_SYM
         default: return RP_ERR_ARG;
     }
+}
+
+
+template <int K, bool UPDATE, bool DOT, int C>
+void launch_symk(const RlsParams& P, hipStream_t st) {
+    constexpr int R = K >= 4 ? 2 : 4;  // rows in flight per wave (registers: K inputs and K updates per lane)
+    const int nb = (P.n_in + 1023) >> 10;
+    const dim3 grid(nb * (nb + 1) / 2, 1024 / C);
+    const int per_cu = (UPDATE && (int64_t)grid.x * grid.y >= 4 * (int64_t)rp_cu_count()) ? 1 : 0;  // as launch_sym_rows
+    const size_t lds = per_cu > 0 ? ((size_t)rp_lds_limit() - 4096) / per_cu - 16384 : 0;
+    if (P.n_in % 1024 == 0) {
+        if (lds) rp_allow_dynamic_lds<rls_symk_kernel<K, UPDATE, DOT, C, R, true>>(rp_lds_limit() - 20480);  // (up to 12 KiB static)
+        hipLaunchKernelGGL((rls_symk_kernel<K, UPDATE, DOT, C, R, true>), grid, dim3(kThreads), lds, st, P);
+    } else {
+        if (lds) rp_allow_dynamic_lds<rls_symk_kernel<K, UPDATE, DOT, C, R, false>>(rp_lds_limit() - 20480);
+        hipLaunchKernelGGL((rls_symk_kernel<K, UPDATE, DOT, C, R, false>), grid, dim3(kThreads), lds, st, P);
+    }
+    if (DOT)
+        hipLaunchKernelGGL(rls_sym_zn_kernel, dim3((P.n_in + 31) / 32, P.nrhs), dim3(1024), (size_t)nb * 32 * sizeof(float), st, P, C);
+}
+
+template <int K>
+int launch_symk_rows(const RlsParams& P, int rows, bool update, bool dot, hipStream_t st) {
+#define RP_SYMK(C_)                                                  \
+    if (rows == C_) {                                                \
+        if (update && dot) launch_symk<K, true, true, C_>(P, st);    \
+        else if (update) launch_symk<K, true, false, C_>(P, st);     \
+        else launch_symk<K, false, true, C_>(P, st);                 \
+        return RP_OK;                                                \
+    }
+    RP_SYMK(16) RP_SYMK(32) RP_SYMK(64)
+#undef RP_SYMK
+    return RP_ERR_ARG;
+}
+
+// rp_rls.block > 1: P is streamed once per K updates (include/rectipy_hip.h; mirrored by oracle/rls_oracle.c: sweep_blocked)
+int sweep_blocked(const rp_rls* r, RlsParams P, int sym_rows, int32_t steps, int32_t stride, const float* X, int64_t ldx,
+                  const float* Y, int64_t ldy, float* pred, int64_t ldpred, float* loss, hipStream_t st) {
+    const int K = r->block, n = r->n_in;
+    if (K != 2 && K != 4 && K != 8) RP_FAIL(RP_ERR_ARG, "rp_rls.block must be 0, 1, 2, 4 or 8, got %d", K);
+    if (!r->blk || (reinterpret_cast<uintptr_t>(r->blk) & 15u)) RP_FAIL(RP_ERR_ARG, "the blocked sweep needs the 16-byte aligned workspace blk");
+    const int nb = (n + 1023) >> 10, chunks = (n + sym_rows - 1) / sym_rows;
+    float* Yb = r->blk;
+    float* Zb = Yb + (int64_t)K * n;
+    P.cm = reinterpret_cast<double*>(Zb + (int64_t)K * n);
+    P.kk = reinterpret_cast<float*>(P.cm + K * K);
+    P.yb = Yb;
+    P.K = K;
+    P.zp = Zb;
+    P.kp = P.kk;
+    P.part_stride = (int64_t)n * nb;
+    P.col_stride = (int64_t)chunks * r->ldc;
+    P.xb_stride = (int64_t)stride * ldx;
+    P.zn = Yb;
+    P.x_next = nullptr;
+    RP_HIP_CHECK(hipMemsetAsync(r->scratch + 3, 0, sizeof(float), st));
+    const int updates = (steps + stride - 1) / stride;
+    int pending = 0;
+    auto pass = [&](int npend, int nrhs, const float* xb) -> int {
+        P.npend = npend;
+        P.nrhs = nrhs;
+        P.xb = xb;
+        const bool update = npend > 0, dot = nrhs > 0;
+        if (!update && !dot) return RP_OK;
+        switch (K) {
+            case 2: return launch_symk_rows<2>(P, sym_rows, update, dot, st);
+            case 4: return launch_symk_rows<4>(P, sym_rows, update, dot, st);
+            default: return launch_symk_rows<8>(P, sym_rows, update, dot, st);
+        }
+    };
+    for (int u0 = 0; u0 < updates; u0 += K) {
+        const int cnt = updates - u0 < K ? updates - u0 : K;
+        if (pass(pending, cnt, X + (int64_t)u0 * stride * ldx) != RP_OK) RP_FAIL(RP_ERR_ARG, "no blocked RLS kernel for %d rows per tile", sym_rows);
+        for (int j = 0; j < cnt; ++j) {
+            const int t = (u0 + j) * stride;
+            P.j = j;
+            P.z = Zb + (int64_t)j * n;
+            P.x = X + (int64_t)t * ldx;
+            P.y = Y + (int64_t)t * ldy;
+            P.pred = pred ? pred + (int64_t)t * ldpred : nullptr;
+            P.loss_out = loss ? loss + t : nullptr;
+            P.loss_count = t + stride <= steps ? stride : steps - t;
+            hipLaunchKernelGGL(rls_blk_z_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P);
+            const int extra = cnt - 1 - j;
+            hipLaunchKernelGGL(rls_blk_scalars_kernel, dim3(1 + extra + r->n_out), dim3(1024), 0, st, P, extra);
+            hipLaunchKernelGGL(rls_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P);
+            if (pred && stride > 1) {
+                const int count = (t + stride <= steps ? stride : steps - t) - 1;
+                if (count > 0) {
+                    const int items = count * r->n_out;
+                    hipLaunchKernelGGL(rls_predict_kernel, dim3((items + 3) / 4), dim3(256), 0, st, r->W, r->ldw, n, r->n_out,
+                                       X + (int64_t)(t + 1) * ldx, ldx, pred + (int64_t)(t + 1) * ldpred, ldpred, count);
+                }
+            }
+        }
+        pending = cnt;
+    }
+    (void)pass(pending, 0, nullptr);
+    if (!r->defer_mirror && nb > 1)
+        hipLaunchKernelGGL(rls_mirror_kernel, dim3(nb * (nb - 1) / 2, 256), dim3(kThreads), 0, st, r->P, r->ldp, n);
+    RP_HIP_CHECK(hipGetLastError());
+    return RP_OK;
 }
 
 #ifdef RP_MEASUREMENT
@@ -759,6 +1106,10 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
     P.ldc = r->ldc;
     const int sym_rows = r->sym_rows > 0 ? r->sym_rows : kSymRowsDefault;
     if (sym && sym_rows != 16 && sym_rows != 32 && sym_rows != 64) RP_FAIL(RP_ERR_ARG, "sym_rows must be 16, 32 or 64, got %d", sym_rows);
+    if (r->block > 1) {
+        if (!sym) RP_FAIL(RP_ERR_ARG, "rp_rls.block > 1 needs the symmetric pass (partials and colparts)");
+        return sweep_blocked(r, P, sym_rows, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, st);
+    }
     float* za = r->z;
     float* zb = r->zn;
 

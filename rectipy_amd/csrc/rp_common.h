@@ -95,26 +95,39 @@ __device__ __forceinline__ float rp_lane_sum4(rp_f4 a) { return (a.x + a.y) + (a
 // The butterflies of R rows at once (a "transposed" butterfly): sums, over the 64 lanes, R per-lane values; afterwards lane l
 // holds the total of the row spelled by its lane bits, high bit first (rp_rows_allreduce_row).  Same pairings (l, l ^ 32),
 // (l, l ^ 16), ... as rp_wave_allreduce -- the same additions per row, R - 1 + log2(64 / R) shuffles instead of 6 R.
+// (one level per template instance: every array index is a compile-time constant whatever R is -- a loop over the levels
+// is not always unrolled for R = 16 / 32 and then indexes the array at run time, i.e. through scratch)
+template <int R, int W, int OFF>
+__device__ __forceinline__ void rp_rows_level(float (&v)[R], int lane) {
+    if constexpr (W > 1) {
+        const bool hi = (lane & OFF) != 0;
+#pragma unroll
+        for (int q = 0; q < W / 2; ++q) {
+            const float send = hi ? v[q] : v[q + W / 2];
+            const float keep = hi ? v[q + W / 2] : v[q];
+            v[q] = keep + __shfl_xor(send, OFF, 64);
+        }
+        rp_rows_level<R, W / 2, OFF / 2>(v, lane);
+    }
+}
+
+template <int OFF>
+__device__ __forceinline__ float rp_tail_allreduce(float s) {
+    if constexpr (OFF >= 1) {
+        s = s + __shfl_xor(s, OFF, 64);
+        return rp_tail_allreduce<OFF / 2>(s);
+    } else {
+        return s;
+    }
+}
+
 template <int R>
 __device__ __forceinline__ float rp_rows_allreduce(float (&v)[R], int lane) {
     // sums over the 64 lanes of R per-lane values at once; afterwards lane l holds the total of value
     // (bits of l selected level by level); same pairings (l, l ^ 32), (l, l ^ 16), ... as rp_wave_allreduce
-    int width = R;
-    int off = 32;
-#pragma unroll
-    for (; width > 1; width >>= 1, off >>= 1) {
-        const bool hi = (lane & off) != 0;
-#pragma unroll
-        for (int q = 0; q < width / 2; ++q) {
-            const float send = hi ? v[q] : v[q + width / 2];
-            const float keep = hi ? v[q + width / 2] : v[q];
-            v[q] = keep + __shfl_xor(send, off, 64);
-        }
-    }
-    float s = v[0];
-#pragma unroll
-    for (; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
-    return s;
+    static_assert((R & (R - 1)) == 0 && R >= 1 && R <= 64, "R is a power of two");
+    rp_rows_level<R, R, 32>(v, lane);
+    return rp_tail_allreduce<32 / R>(v[0]);
 }
 
 

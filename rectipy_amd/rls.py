@@ -38,12 +38,16 @@ class RLS(Linear):
         self._colparts = None
         self.tiled = None  # None: by size; True / False: force the tiled / row-per-wave pass (tests, measurements)
         self.symmetric = None  # None: by size and updates per call; True / False: force / forbid the symmetric pass
+        self.block = None      # None: by updates per call; 1: one pass over P per update; 2 / 4 / 8: one pass per so many updates
+        self._blk = None
 
     # The symmetric pass streams only the blocks of P on and above the diagonal (4 n^2 instead of 8 n^2 bytes per update)
     # and mirrors them once per call: from a few updates per call on, on matrices far beyond the caches
     SYMMETRIC_ROWS = 32  # rows per tile of the symmetric pass (part of its summation order: rp_rls.sym_rows)
     SYMMETRIC_MIN_N = 8192
     SYMMETRIC_MIN_UPDATES = 4
+    BLOCK = 8             # updates per pass over P in the blocked symmetric sweep (rp_rls.block) ...
+    BLOCK_MIN_UPDATES = 16   # ... taken from this many updates per call
     TILED_MIN_N = 8192  # measured (scripts/bench_rls.py, ms per update tiled / row-per-wave): n_in = 8192 0.108 / 0.113, 16384 0.386 / 0.401, 32768 1.43 / 1.68
 
     @property
@@ -140,11 +144,23 @@ class RLS(Linear):
         if use_sym:
             rows = self.SYMMETRIC_ROWS
             chunks = (self.n_in + rows - 1) // rows
-            if self._colparts is None or self._colparts.shape[0] != chunks:
-                # column partials per chunk of `rows` rows (their sums per block row live in the z' kernel's LDS)
-                self._colparts = torch.zeros(chunks, self.n_in, dtype=torch.float32, device=dev)
+            # column partials per chunk of `rows` rows (their sums per block row live in the z' kernel's LDS), per input of a block
+            block = self.block if self.block is not None else (self.BLOCK if updates >= self.BLOCK_MIN_UPDATES else 1)
+            if block not in (1, 2, 4, 8):
+                raise ValueError("RLS.block must be 1, 2, 4 or 8")
+            if self._colparts is None or self._colparts.shape[0] != block * chunks:
+                self._colparts = torch.zeros(block * chunks, self.n_in, dtype=torch.float32, device=dev)
+            tiles = (self.n_in + 1023) // 1024
+            if self._partials.numel() < block * self.n_in * tiles:
+                self._partials = torch.zeros(block * self.n_in * tiles, dtype=torch.float32, device=dev)
+                r.partials = self._partials.data_ptr()
             r.colparts, r.ldc, r.sym_rows = self._colparts.data_ptr(), self._colparts.stride(0), rows
             r.defer_mirror = 1
+            if block > 1:
+                need = 2 * block * self.n_in + 2 * block * block + block
+                if self._blk is None or self._blk.numel() < need:
+                    self._blk = torch.zeros(need, dtype=torch.float32, device=dev)
+                r.block, r.blk = block, self._blk.data_ptr()
         self._backend.rls_sweep(r, T, int(stride), X.data_ptr(), X.stride(0) if T > 1 else self.n_in, Y.data_ptr(),
                                 Y.stride(0) if T > 1 else self.n_out, pred.data_ptr(), self.n_out, loss.data_ptr(), dev)
         self._upper_only = bool(use_sym)
