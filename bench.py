@@ -737,46 +737,58 @@ def batched_extra(pop, N, dev, ms_single, T=200, net=None):
     return res
 
 
-def rls_extra(dev, n_in=32768, k=3, T=20, cpu_threads=None):
+def rls_extra(dev, n_in=32768, k=3, T=64, cpu_threads=None):
     """recursive-least-squares read-out training (reference RLS.update, rectipy/edges.py:227-234) at
-    n_in = 32768: P is 4.3 GB, one update = ONE fused read-modify-write pass over it (rank-1 update of step t + the
-    mat-vec of step t+1; 8 n_in^2 algorithmic bytes; the reference makes three passes: 12 n_in^2 + an n_in^2 temporary)."""
+    n_in = 32768: P is 4.3 GB.  The reference makes three passes over P per update (12 n_in^2 bytes + an n_in^2 temporary).
+    Here, by default from 16 updates per call: the BLOCKED symmetric sweep -- the inputs of a window are known in advance, so
+    one read-modify-write pass over the blocks of P on and above the diagonal applies 8 updates and forms the products with
+    the next 8 inputs (rp_rls.block; the z vectors inside a block follow from a double-precision recurrence on n_in-vectors).
+    Reported next to it: the symmetric pass per update (r03 / r04 first half) and the dense pass per update (r02)."""
     from rectipy_amd.rls import RLS
     gen = torch.Generator(device=dev).manual_seed(5)
     X = torch.randn(T, n_in, device=dev, generator=gen) * 0.1
     Y = torch.randn(T, k, device=dev, generator=gen)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ms, finite = {}, True
-    for form in ("symmetric", "dense"):  # symmetric: the default from 4 updates per call at this size
+    for form in ("blocked", "symmetric", "dense"):
         edge = RLS(n_in, k, beta=0.99, alpha=1.0).to(dev)
-        edge.symmetric = form == "symmetric"
-        edge.sweep(X[:5], Y[:5], 1)
+        edge.symmetric = form != "dense"
+        edge.block = None if form == "blocked" else 1   # None: the default (8 updates per pass from 16 updates per call)
+        Tf = T if form == "blocked" else 20
+        edge.sweep(X[:16], Y[:16], 1)
         torch.cuda.synchronize()
         e0.record()
-        edge.sweep(X, Y, 1)
+        edge.sweep(X[:Tf], Y[:Tf], 1)
         e1.record()
         torch.cuda.synchronize()
-        ms[form] = e0.elapsed_time(e1) / (T + 1)  # T fused passes + the initial mat-vec pass (+ the mirror, symmetric form)
+        # blocked: everything a call costs per update; pass per update: Tf fused passes + the initial mat-vec pass
+        ms[form] = e0.elapsed_time(e1) / (Tf if form == "blocked" else Tf + 1)
         finite = finite and bool(torch.isfinite(edge.P).all().item())
+        block = edge.BLOCK
         del edge
         torch.cuda.empty_cache()
     nb = (n_in + 1023) // 1024
     dense_bytes = 8.0 * n_in * n_in
     sym_bytes = 8.0 * 1024.0 * 1024.0 * nb * (nb + 1) / 2 if n_in % 1024 == 0 else dense_bytes * (nb + 1) / (2.0 * nb)
-    gb_sym, gb_dense = sym_bytes / (ms["symmetric"] * 1e-3) / 1e9, dense_bytes / (ms["dense"] * 1e-3) / 1e9
+    gb = {"blocked": sym_bytes / block / (ms["blocked"] * 1e-3) / 1e9, "symmetric": sym_bytes / (ms["symmetric"] * 1e-3) / 1e9,
+          "dense": dense_bytes / (ms["dense"] * 1e-3) / 1e9}
+    roof = lambda form, bytes_, note: {"bound": "hbm", "achieved": gb[form], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                       "frac": gb[form] / HBM_PEAK_GBPS, "algorithmic_bytes_per_update": bytes_, "note": note}
     res = {"workload": f"RLS read-out training, n_in={n_in}, n_out={k}, {T} consecutive updates (rp_rls_sweep)",
-           "updates_per_s": 1e3 / ms["symmetric"], "ms_per_update": ms["symmetric"],
-           "form": "symmetric pass: only the 1024 x 1024 blocks of P on and above the diagonal are streamed (P -= k z z^T "
-                   "keeps P symmetric), mirrored once per call",
-           "roofline": {"bound": "hbm", "achieved": gb_sym, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gb_sym / HBM_PEAK_GBPS,
-                        "algorithmic_bytes_per_update": sym_bytes,
-                        "note": "bytes of the blocks on and above the diagonal, read + written once; the dense pass's "
-                                "8 n_in^2 bytes in this time would be " + f"{dense_bytes / (ms['symmetric'] * 1e-3) / 1e9:.0f} GB/s"},
+           "updates_per_s": 1e3 / ms["blocked"], "ms_per_update": ms["blocked"],
+           "form": f"blocked symmetric sweep: one read-modify-write pass over the 1024 x 1024 blocks of P on and above the diagonal "
+                   f"per {block} updates (their rank-1 updates + the products with the next {block} inputs), the z vectors of a "
+                   "block by a double-precision recurrence; bit-exact against the oracle, as close to the reference's float64 run "
+                   "as a pass per update (G31 / G34)",
+           "roofline": roof("blocked", sym_bytes / block,
+                            f"the pass's bytes (blocks on and above the diagonal, read + written once) / {block} updates; the per-update "
+                            "kernels (z recurrence, dot products, weights) and the column-partial traffic are the rest of the time"),
+           "symmetric_pass_per_update": {"ms_per_update": ms["symmetric"], "updates_per_s": 1e3 / ms["symmetric"],
+                                         "roofline": roof("symmetric", sym_bytes, "r04 first half: 0.76 ms")},
            "dense_pass": {"ms_per_update": ms["dense"], "updates_per_s": 1e3 / ms["dense"],
-                          "roofline": {"bound": "hbm", "achieved": gb_dense, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                       "frac": gb_dense / HBM_PEAK_GBPS, "algorithmic_bytes_per_update": dense_bytes,
-                                       "note": "an in-place read-modify-write of 4 GiB reaches 6.7-6.8 TB/s on this chip"}},
-           "speedup_over_dense_pass": ms["dense"] / ms["symmetric"],
+                          "roofline": roof("dense", dense_bytes, "an in-place read-modify-write of 4 GiB reaches 6.7-6.8 TB/s on this chip")},
+           "speedup_over_dense_pass": ms["dense"] / ms["blocked"],
+           "speedup_over_symmetric_pass_per_update": ms["symmetric"] / ms["blocked"],
            "state_finite": finite}
     del X, Y
     torch.cuda.empty_cache()

@@ -584,7 +584,7 @@ typedef struct rp_rls {
        from a few updates per call (the mirror costs about one dense pass). */
     float* colparts;
     int64_t ldc;
-    int32_t sym_rows;  /* rows per chunk of the symmetric pass: 16, 32 or 64 (0: 64); part of its summation order */
+    int32_t sym_rows;  /* rows per chunk of the symmetric pass: 16, 32 or 64 (0: 64; blocked sweep: 32, 64 or 128); part of its summation order */
     /* symmetric pass only: 1 = return WITHOUT mirroring -- the blocks on and above the diagonal stay the authoritative
        half of P (the state the next symmetric sweep starts from anyway) and the caller restores the lower blocks with
        rp_rls_mirror before anything else reads P.  Saves one pass over half of P per call (0.78 ms at n_in = 32768). */
@@ -672,6 +672,7 @@ int rp_set_bwd_chunks(int max_chunks);
 int rp_set_rls_tuning(int rows_per_wave, int unroll, int nontemporal_store);
 int rp_set_gemm_dma(int on); /* measurement: 0 = rp_outer_accum always uses the register-staged kernel (1: LDS-DMA ring on full tiles); identical bits */
 int rp_set_rls_sym(int rows_in_flight); /* measurement: bits 0-7 rows in flight per wave of the symmetric pass (1, 2, 4, 8; 0 = built-in), bits 8-11 resident workgroups per CU (an LDS allocation; 0 = built-in, 15 = no cap); never the bits */
+int rp_set_rls_blk(int rows_in_flight, int workgroups_per_cu);  /* blocked sweep's pass: rows in flight (0: built-in), residency cap (-1: built-in) */
 int rp_set_rls_tile(int kcols_per_tile, int workgroups_per_cu); /* measurement: tile width (x 1024 columns; changes the summation order) and residency cap of the tiled RLS pass; 0, 0 = built-in */
 
 #endif /* RP_MEASUREMENT */

@@ -328,6 +328,7 @@ def declare(lib):
     sig("rp_set_bwd_tuning", C.c_int, [C.c_int, C.c_int])
     sig("rp_set_bwd_chunks", C.c_int, [C.c_int])
     sig("rp_set_rls_tile", C.c_int, [C.c_int, C.c_int])
+    sig("rp_set_rls_blk", C.c_int, [C.c_int, C.c_int])
     sig("rp_set_rls_tuning", C.c_int, [C.c_int, C.c_int, C.c_int])
     return lib
 
@@ -345,5 +346,5 @@ EXPORTS = [
 MEASUREMENT_EXPORTS = [
     "rp_set_batched_tuning", "rp_set_batched_mfma_tuning", "rp_set_batched_grid", "rp_set_tuning", "rp_set_sparse_tuning",
     "rp_set_blocked_tuning", "rp_set_bwd_tuning", "rp_set_bwd_grid", "rp_set_bwd_chunks", "rp_set_rls_tuning",
-    "rp_set_rls_sym", "rp_set_gemm_dma", "rp_set_rls_tile",
+    "rp_set_rls_sym", "rp_set_gemm_dma", "rp_set_rls_tile", "rp_set_rls_blk",
 ]

@@ -58,6 +58,26 @@ struct RlsParams {
     int j, K;            // the update of the block the small kernels work on
 };
 
+
+// eight operand pairs of a thread's chain, j = j0 + 1024 q: a full batch is loaded without predicates -- behind a bounds
+// branch per element the compiler waits for every load before it issues the next one (16 round trips instead of one)
+__device__ __forceinline__ void rls_load8(const float* u, const float* x, int j0, int n, float (&uv)[8], float (&xv)[8]) {
+    if (j0 + 7 * 1024 < n) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            uv[q] = u[j0 + q * 1024];
+            xv[q] = x[j0 + q * 1024];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = j0 + q * 1024;
+            uv[q] = j < n ? u[j] : 0.f;
+            xv[q] = j < n ? x[j] : 0.f;
+        }
+    }
+}
+
 // d = x.z, k = 1/(1+d), y_hat = W x, err = y - y_hat, loss = err.err.  One block per dot product (block 0: x.z, block
 // o + 1: W_o.x), each in the fixed order "per-thread fmaf chain over j = tid + 1024 m, then a 1024-leaf tree"; the block that
 // finishes last (a counter in scal[3]) turns the 1 + n_out sums into k, err, loss in output order.  A thread's operands are
@@ -71,12 +91,7 @@ __global__ __launch_bounds__(1024) void rls_scalars_kernel(const RlsParams P) {
     float a = 0.f;
     for (int j0 = tid; j0 < P.n_in; j0 += 8 * 1024) {
         float uv[8], xv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int j = j0 + q * 1024;
-            uv[q] = j < P.n_in ? u[j] : 0.f;
-            xv[q] = j < P.n_in ? P.x[j] : 0.f;
-        }
+        rls_load8(u, P.x, j0, P.n_in, uv, xv);
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             if (j0 + q * 1024 < P.n_in) a = fmaf(uv[q], xv[q], a);
@@ -718,12 +733,7 @@ __global__ __launch_bounds__(1024) void rls_blk_scalars_kernel(const RlsParams P
         double a = 0.0;
         for (int j0 = tid; j0 < P.n_in; j0 += 8 * 1024) {
             float uv[8], xv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int j = j0 + q * 1024;
-                uv[q] = j < P.n_in ? P.z[j] : 0.f;
-                xv[q] = j < P.n_in ? x[j] : 0.f;
-            }
+            rls_load8(P.z, x, j0, P.n_in, uv, xv);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 if (j0 + q * 1024 < P.n_in) a = fma((double)uv[q], (double)xv[q], a);
@@ -741,12 +751,7 @@ __global__ __launch_bounds__(1024) void rls_blk_scalars_kernel(const RlsParams P
         float a = 0.f;
         for (int j0 = tid; j0 < P.n_in; j0 += 8 * 1024) {
             float uv[8], xv[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int j = j0 + q * 1024;
-                uv[q] = j < P.n_in ? u[j] : 0.f;
-                xv[q] = j < P.n_in ? P.x[j] : 0.f;
-            }
+            rls_load8(u, P.x, j0, P.n_in, uv, xv);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 if (j0 + q * 1024 < P.n_in) a = fmaf(uv[q], xv[q], a);
@@ -855,22 +860,43 @@ int launch_sym(const RlsParams& P, int rows, hipStream_t st) {
 }
 
 
-template <int K, bool UPDATE, bool DOT, int C>
-void launch_symk(const RlsParams& P, hipStream_t st) {
-    constexpr int R = K >= 4 ? 2 : 4;  // rows in flight per wave (registers: K inputs and K updates per lane)
+#ifdef RP_MEASUREMENT
+std::atomic<int> g_blk_R{0}, g_blk_per_cu{-1};  // measurement build only (rp_set_rls_blk): rows in flight, residency cap
+#endif
+
+template <int K, bool UPDATE, bool DOT, int C, int R>
+void launch_symk_r(const RlsParams& P, hipStream_t st) {
     const int nb = (P.n_in + 1023) >> 10;
     const dim3 grid(nb * (nb + 1) / 2, 1024 / C);
-    const int per_cu = (UPDATE && (int64_t)grid.x * grid.y >= 4 * (int64_t)rp_cu_count()) ? 1 : 0;  // as launch_sym_rows
-    const size_t lds = per_cu > 0 ? ((size_t)rp_lds_limit() - 4096) / per_cu - 16384 : 0;
+    // the residency cap of launch_sym_rows -- except for K = 8: with eight updates and eight inputs per element the pass
+    // is no longer a bare read-modify-write walk and wants the chip full
+    int per_cu = (K < 8 && UPDATE && (int64_t)grid.x * grid.y >= 4 * (int64_t)rp_cu_count()) ? 1 : 0;
+#ifdef RP_MEASUREMENT
+    if (g_blk_per_cu >= 0) per_cu = g_blk_per_cu;
+#endif
+    const size_t lds = per_cu > 0 ? ((size_t)rp_lds_limit() - 4096) / per_cu - 28672 : 0;
     if (P.n_in % 1024 == 0) {
-        if (lds) rp_allow_dynamic_lds<rls_symk_kernel<K, UPDATE, DOT, C, R, true>>(rp_lds_limit() - 20480);  // (up to 12 KiB static)
+        if (lds) rp_allow_dynamic_lds<rls_symk_kernel<K, UPDATE, DOT, C, R, true>>(rp_lds_limit() - 32768);  // (up to 24 KiB static)
         hipLaunchKernelGGL((rls_symk_kernel<K, UPDATE, DOT, C, R, true>), grid, dim3(kThreads), lds, st, P);
     } else {
-        if (lds) rp_allow_dynamic_lds<rls_symk_kernel<K, UPDATE, DOT, C, R, false>>(rp_lds_limit() - 20480);
+        if (lds) rp_allow_dynamic_lds<rls_symk_kernel<K, UPDATE, DOT, C, R, false>>(rp_lds_limit() - 32768);
         hipLaunchKernelGGL((rls_symk_kernel<K, UPDATE, DOT, C, R, false>), grid, dim3(kThreads), lds, st, P);
     }
     if (DOT)
         hipLaunchKernelGGL(rls_sym_zn_kernel, dim3((P.n_in + 31) / 32, P.nrhs), dim3(1024), (size_t)nb * 32 * sizeof(float), st, P, C);
+}
+
+template <int K, bool UPDATE, bool DOT, int C>
+void launch_symk(const RlsParams& P, hipStream_t st) {
+    // rows in flight per wave (registers: K inputs and K updates per lane).  Measured at n_in = 32768, ms per update
+    // (scripts/probes/rls_blocked_sweep.py): K = 8, 64-row tiles: R = 2 0.196 with one workgroup per CU, 0.160 / 0.159 with two /
+    // no cap (R = 4: 0.170 / 0.167 / 0.169); K = 4: R = 4 0.237 with one per CU (0.248 / 0.249), R = 2 0.267 / 0.245 / 0.253
+    constexpr int R = K >= 8 ? 2 : 4;
+#ifdef RP_MEASUREMENT
+    if (g_blk_R == 4 && R != 4) return launch_symk_r<K, UPDATE, DOT, C, 4>(P, st);
+    if (g_blk_R == 2 && R != 2) return launch_symk_r<K, UPDATE, DOT, C, 2>(P, st);
+#endif
+    launch_symk_r<K, UPDATE, DOT, C, R>(P, st);
 }
 
 template <int K>
@@ -882,7 +908,7 @@ int launch_symk_rows(const RlsParams& P, int rows, bool update, bool dot, hipStr
         else launch_symk<K, false, true, C_>(P, st);                 \
         return RP_OK;                                                \
     }
-    RP_SYMK(16) RP_SYMK(32) RP_SYMK(64)
+    RP_SYMK(32) RP_SYMK(64) RP_SYMK(128)
 #undef RP_SYMK
     return RP_ERR_ARG;
 }
@@ -1054,6 +1080,12 @@ extern "C" int rp_set_rls_sym(int rows_in_flight) {
     return RP_OK;
 }
 
+extern "C" int rp_set_rls_blk(int rows_in_flight, int workgroups_per_cu) {
+    g_blk_R = rows_in_flight;          // 0: built-in; 2 / 4
+    g_blk_per_cu = workgroups_per_cu;  // -1: built-in rule; 0: no cap; n: n workgroups per CU
+    return RP_OK;
+}
+
 extern "C" int rp_set_rls_tile(int kcols_per_tile, int workgroups_per_cu) {
     if (kcols_per_tile != 0 && kcols_per_tile != 1 && kcols_per_tile != 2 && kcols_per_tile != 4)
         RP_FAIL(RP_ERR_ARG, "rp_set_rls_tile: tile of %d x 1024 columns is not built", kcols_per_tile);
@@ -1105,7 +1137,8 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
     P.colparts = sym ? r->colparts : nullptr;
     P.ldc = r->ldc;
     const int sym_rows = r->sym_rows > 0 ? r->sym_rows : kSymRowsDefault;
-    if (sym && sym_rows != 16 && sym_rows != 32 && sym_rows != 64) RP_FAIL(RP_ERR_ARG, "sym_rows must be 16, 32 or 64, got %d", sym_rows);
+    if (sym && r->block > 1 ? (sym_rows != 32 && sym_rows != 64 && sym_rows != 128) : (sym_rows != 16 && sym_rows != 32 && sym_rows != 64))
+        RP_FAIL(RP_ERR_ARG, "sym_rows must be 16, 32 or 64 (blocked sweep: 32, 64 or 128), got %d", sym_rows);
     if (r->block > 1) {
         if (!sym) RP_FAIL(RP_ERR_ARG, "rp_rls.block > 1 needs the symmetric pass (partials and colparts)");
         return sweep_blocked(r, P, sym_rows, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, st);

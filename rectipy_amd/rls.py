@@ -48,6 +48,7 @@ class RLS(Linear):
     SYMMETRIC_MIN_UPDATES = 4
     BLOCK = 8             # updates per pass over P in the blocked symmetric sweep (rp_rls.block) ...
     BLOCK_MIN_UPDATES = 16   # ... taken from this many updates per call
+    BLOCK_ROWS = 128      # rows per tile of the blocked sweep (n_in = 32768, 8 updates per pass: 0.150 ms per update; 64 rows: 0.159, 32: 0.176)
     TILED_MIN_N = 8192  # measured (scripts/bench_rls.py, ms per update tiled / row-per-wave): n_in = 8192 0.108 / 0.113, 16384 0.386 / 0.401, 32768 1.43 / 1.68
 
     @property
@@ -142,12 +143,12 @@ class RLS(Linear):
         if self._upper_only and not use_sym:
             self.P  # (a dense pass reads all of P: restore the lower blocks first)
         if use_sym:
-            rows = self.SYMMETRIC_ROWS
-            chunks = (self.n_in + rows - 1) // rows
-            # column partials per chunk of `rows` rows (their sums per block row live in the z' kernel's LDS), per input of a block
             block = self.block if self.block is not None else (self.BLOCK if updates >= self.BLOCK_MIN_UPDATES else 1)
             if block not in (1, 2, 4, 8):
                 raise ValueError("RLS.block must be 1, 2, 4 or 8")
+            rows = self.SYMMETRIC_ROWS if block == 1 else self.BLOCK_ROWS
+            chunks = (self.n_in + rows - 1) // rows
+            # column partials per chunk of `rows` rows (their sums per block row live in the z' kernel's LDS), per input of a block
             if self._colparts is None or self._colparts.shape[0] != block * chunks:
                 self._colparts = torch.zeros(block * chunks, self.n_in, dtype=torch.float32, device=dev)
             tiles = (self.n_in + 1023) // 1024

@@ -19,7 +19,8 @@ out = {}
 for rows in (32, 64):
     for block in (1, 2, 4, 8):
         edge = RLS(n_in, k, beta=0.99, alpha=1.0).to(dev)
-        edge.symmetric, edge.block, edge.SYMMETRIC_ROWS = True, block, rows
+        edge.symmetric, edge.block = True, block
+        edge.SYMMETRIC_ROWS = edge.BLOCK_ROWS = rows
         edge.sweep(X[:16], Y[:16], 1)
         torch.cuda.synchronize()
         e0.record()

@@ -281,8 +281,8 @@ def test_mirror_is_deferred_until_P_is_read_and_asymmetric_P_keeps_the_dense_pas
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_in,n_out,T,stride,block,rows", [
-    (256, 2, 25, 3, 2, 32), (1000, 4, 12, 1, 4, 32), (2048, 2, 19, 1, 8, 32), (4100, 2, 11, 1, 4, 64), (3140, 3, 21, 2, 8, 16),
-    (4096, 2, 17, 1, 8, 64), (8192, 1, 18, 2, 8, 32), (9000, 3, 20, 1, 8, 32), (9000, 2, 9, 1, 2, 64)])
+    (256, 2, 25, 3, 2, 32), (1000, 4, 12, 1, 4, 32), (2048, 2, 19, 1, 8, 32), (4100, 2, 11, 1, 4, 64), (3140, 3, 21, 2, 8, 128),
+    (4096, 2, 17, 1, 8, 64), (8192, 1, 18, 2, 8, 32), (9000, 3, 20, 1, 8, 128), (9000, 2, 9, 1, 2, 64), (9000, 2, 9, 1, 4, 64)])
 def test_blocked_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride, block, rows):
     """The blocked symmetric sweep (rp_rls.block: P streamed once per `block` updates, the block before's rank-1 updates and
     the products with all inputs of the block in one pass; the z vectors of the block by the double-precision recurrence)
@@ -297,7 +297,7 @@ def test_blocked_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T,
     for backend, dev in ((oracle_backend, "cpu"), (None, hip_device)):
         edge = RLS(n_in, n_out, weights=W0.clone(), beta=0.97, alpha=1.5, backend=backend).to(dev)
         edge.tiled, edge.symmetric, edge.block = True, True, block
-        edge.SYMMETRIC_ROWS = rows
+        edge.BLOCK_ROWS = rows
         half = (T // 2) // stride * stride
         p1, l1 = edge.sweep(X[:half].to(dev), Y[:half].to(dev), stride)
         p2, l2 = edge.sweep(X[half:].to(dev), Y[half:].to(dev), stride)
