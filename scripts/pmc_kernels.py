@@ -65,6 +65,16 @@ torch.cuda.synchronize()
 nb = n_in // 1024
 algo["rls_sym_kernel<true"] = 8.0 * 1024 * 1024 * nb * (nb + 1) / 2 + 4.0 * (n_in // 64) * n_in / 2
 del edge, edge2
+# r04: the blocked sweep's pass -- the same blocks read + written once per EIGHT updates, plus eight inputs' column partials
+# (one per 128-row tile above the diagonal) and row partials
+edge3 = RLS(n_in, 3, beta=0.99).to(dev)
+edge3.symmetric, edge3.block = True, 8
+X3 = torch.randn(32, n_in, device=dev) * 0.1
+edge3.sweep(X3, torch.randn(32, 3, device=dev), 1)
+torch.cuda.synchronize()
+algo["rls_symk_kernel<8, true, true"] = (8.0 * 1024 * 1024 * nb * (nb + 1) / 2 + 8 * 4.0 * (n_in // edge3.BLOCK_ROWS) * n_in / 2
+                                         + 8 * 4.0 * n_in * nb)
+del edge3, X3
 
 # r03: the batched matrix-core steps (W once per step for all trajectories; the source tiles come from L2)
 import bench  # noqa: E402
