@@ -1,5 +1,5 @@
 """GPU box: FeedbackNetwork graphs and Network.run_batch on the HIP library against the same package on the CPU oracle, on
-RANDOM shapes -- 2..4 populations (tanh / sigmoid / QIF / LIF, sizes from 5 to ~1100: 4-byte and 16-byte paths, ragged
+RANDOM shapes -- 2..4 populations (tanh / sigmoid / QIF / LIF / QIF_SFA / IK, sizes from 5 to ~1100: 4-byte and 16-byte paths, ragged
 chunks, different widths), random feed-forward chains with random feedback edges (the three edge read modes of
 rp_forward_coupled arise from their direction and the source's kind), optional input / read-out layers, recorded
 variables, sampling, cutoff, two consecutive runs; the same graphs with every parameter trained (fit_bptt, two SGD windows:
@@ -32,7 +32,13 @@ KINDS = {
     "sigmoid": dict(path=P + "rate_neurons.leaky_integrator.sigmoid", op="li_op", src="sigmoid_op/r", tgt="li_op/r_in", outs=["li_op/v"]),
     "qif": dict(path=P + "spiking_neurons.qif.qif", op="qif_op", src="qif_op/s", tgt="qif_op/s_in", outs=["qif_op/s"], spike=True),
     "lif": dict(path=P + "spiking_neurons.lif.lif", op="lif_op", src="lif_op/s", tgt="lif_op/s_in", outs=["lif_op/s"], spike=True),
+    "qif_sfa": dict(path=P + "spiking_neurons.qif.qif_sfa", op="qif_sfa_op", src="qif_sfa_op/s", tgt="qif_sfa_op/s_in",
+                    outs=["qif_sfa_op/s"], spike=True),
+    "ik": dict(path=P + "spiking_neurons.ik.ik", op="ik_op", src="ik_op/s", tgt="ik_op/s_in", outs=["ik_op/s"], spike=True),
 }
+TRAIN = {"tanh": ["tau", "k", "eta"], "sigmoid": ["tau", "k", "eta"], "qif": ["tau", "k", "eta", "tau_s"], "lif": ["tau", "k", "eta", "tau_s"],
+         "qif_sfa": ["tau", "k", "eta", "tau_s", "alpha", "tau_x"],
+         "ik": ["C", "k", "eta", "tau_s", "g", "b", "tau_u", "kappa", "v_r", "v_theta", "E_r"]}
 
 
 def add_population(net, label, kind, n, rng, train=False):
@@ -41,9 +47,13 @@ def add_population(net, label, kind, n, rng, train=False):
     if K.get("spike"):
         W = np.abs(rng.standard_normal((n, n))) * 2.0 / n
         lo_hi = {"qif": dict(tau=(0.8, 1.2), k=(0.5, 1.5), eta=(0.5, 3.0), tau_s=(0.5, 2.0)),
-                 "lif": dict(tau=(0.4, 0.8), k=(0.5, 1.5), eta=(2.0, 5.0), tau_s=(0.2, 0.6))}[kind]
+                 "lif": dict(tau=(0.4, 0.8), k=(0.5, 1.5), eta=(2.0, 5.0), tau_s=(0.2, 0.6)),
+                 "qif_sfa": dict(tau=(0.8, 1.2), k=(0.5, 1.5), eta=(0.5, 3.0), tau_s=(0.5, 2.0), alpha=(0.2, 1.0), tau_x=(2.0, 8.0)),
+                 "ik": dict(C=(80.0, 120.0), k=(0.5, 0.9), eta=(40.0, 90.0), tau_s=(4.0, 8.0), g=(0.5, 1.5), b=(-3.0, -1.0),
+                            tau_u=(20.0, 40.0), kappa=(5.0, 15.0), v=(-65.0, -35.0), u=(0.0, 5.0))}[kind]
         node_vars = {f"all/{op}/{q}": rng.uniform(lo, hi, n) for q, (lo, hi) in lo_hi.items()}
-        kw = dict(spike_var=f"{op}/spike", reset_var=f"{op}/v", spike_threshold=1.0, spike_reset=-1.0 if kind == "qif" else 0.0)
+        thr = {"qif": (1.0, -1.0), "lif": (1.0, 0.0), "qif_sfa": (1.0, -1.0), "ik": (-36.0, -60.0)}[kind]  # (ik: some start above it)
+        kw = dict(spike_var=f"{op}/spike", reset_var=f"{op}/v", spike_threshold=thr[0], spike_reset=thr[1])
     else:
         W = rng.standard_normal((n, n)) * 1.0 / np.sqrt(n)
         node_vars = {"all/li_op/tau": rng.uniform(0.5, 2.0, n), "all/li_op/k": rng.uniform(0.5, 1.5, n),
@@ -51,7 +61,7 @@ def add_population(net, label, kind, n, rng, train=False):
         kw = {}
     out_var = K["outs"][int(rng.integers(0, len(K["outs"])))]
     if train:
-        kw["train_params"] = ["weights", f"{op}/tau", f"{op}/k", f"{op}/eta"] + ([f"{op}/tau_s"] if K.get("spike") else [])
+        kw["train_params"] = ["weights"] + [f"{op}/{q}" for q in TRAIN[kind]]
     net.add_diffeq_node(label, K["path"], weights=W, source_var=K["src"], target_var=K["tgt"], input_var=f"{op}/I_ext",
                         output_var=out_var, dtype=torch.float32, node_vars=node_vars, **kw)
     return f"{op}/v"
@@ -99,7 +109,7 @@ def main(cases=40, seed=0, max_n=1100):
             mode = int(rng.integers(0, 4))
             if mode == 3:  # ---- a FeedbackNetwork trained through its cycles: fit_bptt, every parameter ----
                 npop = int(rng.integers(2, 4))
-                kinds = [list(KINDS)[int(rng.integers(0, 4))] for _ in range(npop)]
+                kinds = [list(KINDS)[int(rng.integers(0, len(KINDS)))] for _ in range(npop)]
                 sizes = [int(rng.choice([rng.integers(5, 40), rng.integers(250, 300), rng.integers(min(500, max_n - 1), max_n)])) for _ in range(npop)]
                 m, k = int(rng.integers(0, 3)), int(rng.integers(1, 3))
                 pairs = set()
@@ -134,7 +144,7 @@ def main(cases=40, seed=0, max_n=1100):
                 cfg["fused_adjoint"] = res[1][2]
             elif mode < 2:  # ---- a FeedbackNetwork ----
                 npop = int(rng.integers(2, 5))
-                kinds = [list(KINDS)[int(rng.integers(0, 4))] for _ in range(npop)]
+                kinds = [list(KINDS)[int(rng.integers(0, len(KINDS)))] for _ in range(npop)]
                 sizes = [int(rng.choice([rng.integers(5, 40), rng.integers(250, 300), rng.integers(min(500, max_n - 1), max_n)])) for _ in range(npop)]
                 m, k = int(rng.integers(0, 3)) * int(rng.integers(0, 2)), int(rng.integers(0, 3))
                 pairs = set()
