@@ -16,9 +16,12 @@ included -- are integrated as ONE library call per window (``rp_forward_coupled`
 steps the populations in evaluation order, one launch each, and every edge matrix is streamed by the target's step kernel
 next to its recurrent matrix (`_coupled_plan` / `_run_coupled`).  Activation nodes upstream of every population (input
 layers) are evaluated for the whole window in advance, those downstream of every population (read-outs) afterwards.
-Everything else -- an activation node BETWEEN populations, edges with memory inside the cycle, gradient-tracking runs --
-is walked step by step (`forward`), where a plain dense edge into a population is still evaluated inside that
-population's step kernel whenever no gradient has to pass through it."""
+Gradient-tracking runs of such a graph (`fit_bptt`, `run(enable_grad=True)`) record ONE autograd node per window over all
+populations (`_CoupledWindow`: forward `rp_forward_coupled` with the windows stored, backward `rp_backward_coupled`).
+Everything else -- an activation node BETWEEN populations, edges with memory inside the cycle, and with a gradient a feedback
+edge from a rate population that was already stepped or a population-mean spiking model -- is walked step by step
+(`forward`), where a plain dense edge into a population is still evaluated inside that population's step kernel whenever
+no gradient has to pass through it."""
 from typing import List, Optional
 
 import torch
