@@ -239,9 +239,57 @@ class FeedbackNetwork(Network):
         return super()._dag_plan(rec_vars)
 
     def _unreached_parameters(self, steps: int) -> list:
-        if any(d.get("feedback") for _, _, d in self.graph.edges(data=True)):
-            return []  # feedback edges open further paths to the output; the delay count of the base class does not hold
-        return super()._unreached_parameters(steps)
+        """As the base class, with the timing of feedback reads: the parameters that cannot influence any prediction of a
+        window of `steps` steps that starts from states without an older graph -- the reference's autograd leaves their
+        ``grad`` None (a stateful optimiser then skips them), a fused window's adjoint returns zeros.
+
+        V_n(t) = what node n emits at step t (a population: its state BEFORE the step).  V_p(t + 1) of a population depends
+        on its inputs of step t: V_s(t) through a feed-forward edge or a feedback edge from a rate population stepped later
+        (delay 1), V_s(t + 1) through a feedback edge from a rate population already stepped (delay 0), V_s(t - 1) through a
+        feedback edge from a spiking population not yet stepped (its exposed state lags, nodes.py:387-392: delay 2; already
+        stepped: 1) or from an activation node (its output of the step before: 2).  An activation node emits a function of
+        its inputs of the same step (delay 0).  With D(n) the smallest total delay from V_n to the output node's V, a
+        population's parameters and the weights of an edge into it act from step a on V(a + 1), i.e. on the prediction of
+        step a + 1 + D: reached iff steps >= D + 2 (an edge into an activation node: D + 1)."""
+        if not any(d.get("feedback") for _, _, d in self.graph.edges(data=True)):
+            return super()._unreached_parameters(steps)
+        from .edge_variants import LinearMasked, _Stateful
+        if any(isinstance(self.get_edge(s, t), _Stateful) and not isinstance(self.get_edge(s, t), LinearMasked)
+               for s, t in self.graph.edges):
+            return []
+        for n in self.graph.nodes:
+            handle = getattr(self.get_node(n), "_y_grad", None)
+            if handle is not None and handle.grad_fn is not None:
+                return []
+        order = {n: i for i, n in enumerate(self._order)}
+        is_pop = {n: isinstance(self.get_node(n), RateNet) for n in self._order}
+        delay = {}
+        for s_, t_, d in self.graph.edges(data=True):
+            if not is_pop[t_]:
+                w = 1 if d.get("feedback") else 0   # (a feedback edge into an activation node: the step before)
+            elif not d.get("feedback"):
+                w = 1
+            elif not is_pop[s_]:
+                w = 2
+            else:
+                stepped = order[s_] < order[t_]
+                w = (1 if stepped else 2) if isinstance(self.get_node(s_), SpikeResetNet) else (0 if stepped else 1)
+            delay[(s_, t_)] = w
+        inf = float("inf")
+        dist = {n: inf for n in self._order}
+        dist[self._out_node] = 0
+        for _ in range(len(self._order)):  # Bellman-Ford on a handful of nodes
+            for (s_, t_), w in delay.items():
+                if dist[t_] + w < dist[s_]:
+                    dist[s_] = dist[t_] + w
+        out = []
+        for n in self._order:
+            if is_pop[n] and steps < dist[n] + 2:
+                out.extend(p for p in self.get_node(n).parameters() if p.requires_grad)
+        for (s_, t_) in delay:
+            if steps < dist[t_] + (2 if is_pop[t_] else 1):
+                out.extend(p for p in self.get_edge(s_, t_).parameters() if p.requires_grad)
+        return out
 
     def forward(self, x) -> torch.Tensor:
         if not self._order:

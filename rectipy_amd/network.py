@@ -875,7 +875,7 @@ class Network:
         for a in range(0, steps, optim_steps):
             b = min(a + optim_steps, steps)
             unreached = self._unreached_parameters(b - a)
-            if unreached and b - a == optim_steps and len(unreached) == sum(p.requires_grad for p in self.parameters()) \
+            if unreached and b - a == optim_steps and {id(p) for p in unreached} == {id(p) for p in self.parameters() if p.requires_grad} \
                     and not any(getattr(self.get_node(n), "_y_requires_grad", False) or
                                 getattr(getattr(self.get_node(n), "_y_grad", None), "requires_grad", False)
                                 for n in self.graph.nodes):

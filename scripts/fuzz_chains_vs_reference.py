@@ -56,7 +56,7 @@ def pop(rng, n):
                 eta=rng.standard_normal(n) * 0.1, y0=rng.standard_normal(n) * 0.5)
 
 
-def build(rng, sizes, m, k, feedback, dt, trainable=False, spiking=False):
+def build(rng, sizes, m, k, feedback, dt, trainable=False, spiking=False, train_fb=False):
     labels = ["a", "b", "c"][:len(sizes)]
     kinds = ["qif" if spiking and rng.integers(0, 2) else "rate" for _ in sizes]
     if spiking and "qif" not in kinds:
@@ -105,8 +105,11 @@ def build(rng, sizes, m, k, feedback, dt, trainable=False, spiking=False):
             if s == t or (s, t) in zip(order[:-1], order[1:]):
                 continue
             W = rng.standard_normal((width[t], width[s])) * 0.6 / np.sqrt(width[s])
-            ref.add_edge(s, t, weights=W.copy(), feedback=True, dtype=torch.float64)
-            amd.add_edge(s, t, weights=W.copy(), feedback=True)
+            if any(t == t_ for _, t_ in fb):
+                continue  # (one feedback input per node: the reference cannot sum several, network.py:1344)
+            gd = "gd" if train_fb and rng.integers(0, 2) else None
+            ref.add_edge(s, t, weights=W.copy(), feedback=True, train=gd, dtype=torch.float64)
+            amd.add_edge(s, t, weights=W.copy(), feedback=True, train=gd)
             fb.append((s, t))
     return ref, amd, labels, (m or sizes[0]), fb, list(zip(order[:-1], order[1:])), trains
 
@@ -122,7 +125,7 @@ def params_dev(ref, amd, labels, edges, trains):
     return dev
 
 
-def main(cases=30, seed=0, tol=5e-5, trainable=False, spiking=False):
+def main(cases=30, seed=0, tol=5e-5, trainable=False, spiking=False, train_fb=False):
     rng = np.random.default_rng(seed)
     worst, worst_at = 0.0, None
     for case in range(cases):
@@ -130,9 +133,10 @@ def main(cases=30, seed=0, tol=5e-5, trainable=False, spiking=False):
         m, k = int(rng.integers(0, 4)), int(rng.integers(0, 4))
         feedback = bool(rng.integers(0, 2))
         dt = 5e-2
-        feedback = feedback and not trainable
+        feedback = (feedback and not trainable) or train_fb
         dt = 5e-3 if spiking else dt
-        ref, amd, labels, width, fb, edges, trains = build(rng, sizes, m, k, feedback, dt, trainable, spiking)
+        ref, amd, labels, width, fb, edges, trains = build(rng, sizes, m, k, feedback, dt, trainable, spiking, train_fb)
+        edges = edges + fb  # (parameter deviations include the feedback edges)
         state_len = {lab: ref.state[lab].shape[0] for lab in labels}  # (a QIF population's state is [v, s])
         n_out = k or sizes[-1]
         log = []
