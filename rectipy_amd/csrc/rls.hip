@@ -908,7 +908,7 @@ int launch_symk_rows(const RlsParams& P, int rows, bool update, bool dot, hipStr
         else launch_symk<K, false, true, C_>(P, st);                 \
         return RP_OK;                                                \
     }
-    RP_SYMK(32) RP_SYMK(64) RP_SYMK(128)
+    RP_SYMK(64) RP_SYMK(128)
 #undef RP_SYMK
     return RP_ERR_ARG;
 }
@@ -1137,8 +1137,8 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
     P.colparts = sym ? r->colparts : nullptr;
     P.ldc = r->ldc;
     const int sym_rows = r->sym_rows > 0 ? r->sym_rows : kSymRowsDefault;
-    if (sym && r->block > 1 ? (sym_rows != 32 && sym_rows != 64 && sym_rows != 128) : (sym_rows != 16 && sym_rows != 32 && sym_rows != 64))
-        RP_FAIL(RP_ERR_ARG, "sym_rows must be 16, 32 or 64 (blocked sweep: 32, 64 or 128), got %d", sym_rows);
+    if (sym && r->block > 1 ? (sym_rows != 64 && sym_rows != 128) : (sym_rows != 16 && sym_rows != 32 && sym_rows != 64))
+        RP_FAIL(RP_ERR_ARG, "sym_rows must be 16, 32 or 64 (blocked sweep: 64 or 128), got %d", sym_rows);
     if (r->block > 1) {
         if (!sym) RP_FAIL(RP_ERR_ARG, "rp_rls.block > 1 needs the symmetric pass (partials and colparts)");
         return sweep_blocked(r, P, sym_rows, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, st);

@@ -16,11 +16,11 @@ X = torch.randn(T, n_in, device=dev, generator=gen) * 0.1
 Y = torch.randn(T, k, device=dev, generator=gen)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 out = {}
-for rows in (32, 64):
+for rows in (64, 128):
     for block in (1, 2, 4, 8):
         edge = RLS(n_in, k, beta=0.99, alpha=1.0).to(dev)
         edge.symmetric, edge.block = True, block
-        edge.SYMMETRIC_ROWS = edge.BLOCK_ROWS = rows
+        edge.SYMMETRIC_ROWS, edge.BLOCK_ROWS = min(rows, 64), rows
         edge.sweep(X[:16], Y[:16], 1)
         torch.cuda.synchronize()
         e0.record()

@@ -15,7 +15,7 @@ X = torch.randn(T, n_in, device=dev, generator=gen) * 0.1
 Y = torch.randn(T, k, device=dev, generator=gen)
 edge = RLS(n_in, k, beta=0.99, alpha=1.0).to(dev)
 edge.symmetric, edge.block = True, block
-edge.SYMMETRIC_ROWS = edge.BLOCK_ROWS = rows
+edge.SYMMETRIC_ROWS, edge.BLOCK_ROWS = min(rows, 64), max(rows, 64)
 edge.sweep(X[:16], Y[:16], 1)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -281,12 +281,12 @@ def test_mirror_is_deferred_until_P_is_read_and_asymmetric_P_keeps_the_dense_pas
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_in,n_out,T,stride,block,rows", [
-    (256, 2, 25, 3, 2, 32), (1000, 4, 12, 1, 4, 32), (2048, 2, 19, 1, 8, 32), (4100, 2, 11, 1, 4, 64), (3140, 3, 21, 2, 8, 128),
-    (4096, 2, 17, 1, 8, 64), (8192, 1, 18, 2, 8, 32), (9000, 3, 20, 1, 8, 128), (9000, 2, 9, 1, 2, 64), (9000, 2, 9, 1, 4, 64)])
+    (256, 2, 25, 3, 2, 64), (1000, 4, 12, 1, 4, 128), (2048, 2, 19, 1, 8, 64), (4100, 2, 11, 1, 4, 64), (3140, 3, 21, 2, 8, 128),
+    (4096, 2, 17, 1, 8, 64), (8192, 1, 18, 2, 8, 128), (9000, 3, 20, 1, 8, 128), (9000, 2, 9, 1, 2, 64), (9000, 2, 9, 1, 4, 64)])
 def test_blocked_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride, block, rows):
     """The blocked symmetric sweep (rp_rls.block: P streamed once per `block` updates, the block before's rank-1 updates and
     the products with all inputs of the block in one pass; the z vectors of the block by the double-precision recurrence)
-    on the GPU against the C oracle, bit for bit: full and ragged blocks of updates, ragged tiles / chunks / 1024-blocks, the
+    on the GPU against the C oracle, bit for bit: full and ragged blocks of updates, ragged tiles / chunks / 1024-blocks, 64 / 128 rows per tile, the
     unpredicated kernel (n_in % 1024 == 0), enough tiles for the residency cap (8192, 9000), two consecutive sweeps."""
     gen = torch.Generator().manual_seed(n_in + T)
     base = torch.randn(n_in, generator=gen)
