@@ -38,7 +38,7 @@ class RLS(Linear):
         self._colparts = None
         self.tiled = None  # None: by size; True / False: force the tiled / row-per-wave pass (tests, measurements)
         self.symmetric = None  # None: by size and updates per call; True / False: force / forbid the symmetric pass
-        self.block = None      # None: by updates per call; 1: one pass over P per update; 2 / 4 / 8: one pass per so many updates
+        self.block = None      # None: 8 (4 below 8 updates per call); 1: one pass over P per update; 2 / 4 / 8: one pass per so many updates
         self._blk = None
 
     # The symmetric pass streams only the blocks of P on and above the diagonal (4 n^2 instead of 8 n^2 bytes per update)
@@ -46,8 +46,10 @@ class RLS(Linear):
     SYMMETRIC_ROWS = 32  # rows per tile of the symmetric pass (part of its summation order: rp_rls.sym_rows)
     SYMMETRIC_MIN_N = 8192
     SYMMETRIC_MIN_UPDATES = 4
-    BLOCK = 8             # updates per pass over P in the blocked symmetric sweep (rp_rls.block) ...
-    BLOCK_MIN_UPDATES = 16   # ... taken from this many updates per call
+    # updates per pass over P in the blocked symmetric sweep (rp_rls.block): 8 from 8 updates per call, 4 below.  A call of U
+    # updates costs one read-only pass (0.5 ms at n_in = 32768), ceil(U / 8) - 1 full passes (0.9 ms) and one update-only
+    # pass (0.9 ms) against 0.4 + 0.76 U ms with a pass per update: ahead from the 4 updates at which the symmetric pass starts
+    BLOCK = 8
     BLOCK_ROWS = 128      # rows per tile of the blocked sweep (n_in = 32768, 8 updates per pass: 0.150 ms per update; 64 rows: 0.159, 32: 0.176)
     TILED_MIN_N = 8192  # measured (scripts/bench_rls.py, ms per update tiled / row-per-wave): n_in = 8192 0.108 / 0.113, 16384 0.386 / 0.401, 32768 1.43 / 1.68
 
@@ -143,7 +145,7 @@ class RLS(Linear):
         if self._upper_only and not use_sym:
             self.P  # (a dense pass reads all of P: restore the lower blocks first)
         if use_sym:
-            block = self.block if self.block is not None else (self.BLOCK if updates >= self.BLOCK_MIN_UPDATES else 1)
+            block = self.block if self.block is not None else (self.BLOCK if updates >= self.BLOCK else 4)
             if block not in (1, 2, 4, 8):
                 raise ValueError("RLS.block must be 1, 2, 4 or 8")
             rows = self.SYMMETRIC_ROWS if block == 1 else self.BLOCK_ROWS

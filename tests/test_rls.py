@@ -61,7 +61,7 @@ def test_g14_fit_rls_matches_reference(target, stride, tiled):
         net2.forward(x[t])
         if t % stride == 0:
             edge2.update(net2["rnn"]["out"], y[t], net2["out"]["out"])
-    # (the sweep above may have taken the blocked form -- 16 updates or more on the symmetric pass -- which rounds z
+    # (the sweep above may have taken the blocked form -- the default on the symmetric pass -- which rounds z
     # differently from a pass per update: 1.1e-5 on weights of size 0.6; a pass per update on both sides: < 1e-5)
     assert np.abs(edge2.weights.cpu().numpy() - edge.weights.cpu().numpy()).max() < 2e-5
     assert np.abs(edge2.P.cpu().numpy() - edge.P.cpu().numpy()).max() < 1e-5
