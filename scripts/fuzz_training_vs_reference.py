@@ -24,7 +24,7 @@ import rectipy_amd  # noqa: E402
 TANH = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
 
 
-def build(rng, n, m, k, dt, beta, alpha):
+def build(rng, n, m, k, dt, beta, alpha, blocked=False):
     P = dict(W=rng.standard_normal((n, n)) * 0.9 / np.sqrt(n), tau=rng.uniform(0.5, 2.0, n), k=rng.uniform(0.5, 1.5, n),
              eta=rng.standard_normal(n) * 0.1, y0=rng.standard_normal(n) * 0.5)
     W_in = rng.standard_normal((n, m))
@@ -44,7 +44,9 @@ def build(rng, n, m, k, dt, beta, alpha):
                                    "all/li_op/v": P["y0"]})
     amd.add_func_node("out", k, "identity")
     amd.add_edge("inp", "rnn", weights=W_in.copy())
-    amd.add_edge("rnn", "out", weights=W0.copy(), train="rls", beta=beta, alpha=alpha)
+    edge = amd.add_edge("rnn", "out", weights=W0.copy(), train="rls", beta=beta, alpha=alpha)
+    if blocked:  # the blocked symmetric sweep (the default from n_in = 8192) forced at this size
+        edge.tiled, edge.symmetric = True, True
     return ref, amd
 
 
@@ -55,14 +57,16 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(1.0, np.abs(a).max())) if a.size else 0.0
 
 
-def main(cases=30, seed=0, tol=2e-3):
+def main(cases=30, seed=0, tol=2e-3, blocked=False):
     rng = np.random.default_rng(seed)
     worst, worst_at = 0.0, None
     quiet = contextlib.redirect_stdout(io.StringIO())
     for case in range(cases):
         n, m, k = int(rng.integers(4, 40)), int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        if blocked:
+            n = 4 * ((n + 3) // 4)   # (the symmetric pass is a 16-byte path)
         dt, beta, alpha = 1e-1, float(rng.uniform(0.9, 1.0)), float(rng.uniform(0.5, 3.0))
-        ref, amd = build(rng, n, m, k, dt, beta, alpha)
+        ref, amd = build(rng, n, m, k, dt, beta, alpha, blocked)
         log = []
         ops = [["fit_rls", "fit_rls_epochs", "run", "reset", "test"][int(rng.integers(0, 5))] for _ in range(int(rng.integers(2, 6)))]
         for op in ops + ["fit_ridge"]:

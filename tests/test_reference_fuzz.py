@@ -122,3 +122,16 @@ def test_random_trainable_chains_with_feedback_match_the_reference(seed, capsys)
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import fuzz_chains_vs_reference
     assert fuzz_chains_vs_reference.main(30, seed, tol=2e-3, trainable=True, train_fb=True) == 0, capsys.readouterr().out[-2000:]
+
+
+@pytest.mark.parametrize("seed", [2, 3])
+def test_random_readout_training_sequences_on_the_blocked_sweep_match_the_reference(seed, capsys):
+    """The read-out training sequences above with the BLOCKED symmetric RLS sweep forced at these sizes (the default from
+    n_in = 8192: P streamed once per 8 updates, rp_rls.block): fit_rls on arrays / epochs with random strides, run, reset,
+    test(), a closing fit_ridge, against the reference's float64 run.  Measured worst relative deviation over 180 sequences:
+    1.7e-5 with beta = 1 (a pass per update: 8e-6); with beta < 1 the reference's recursion itself loses the definiteness of P
+    (z = P x / beta without dividing P) and amplifies float32 rounding in either form -- worst per 30 sequences 5e-6 ... 1.3e-3
+    for a pass per update, 3e-6 ... 6.6e-2 blocked; these two seeds: 3e-6 and 9e-6."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_training_vs_reference
+    assert fuzz_training_vs_reference.main(20, seed, blocked=True) == 0, capsys.readouterr().out[-2000:]
