@@ -740,7 +740,7 @@ def batched_extra(pop, N, dev, ms_single, T=200, net=None):
 def rls_extra(dev, n_in=32768, k=3, T=64, cpu_threads=None):
     """recursive-least-squares read-out training (reference RLS.update, rectipy/edges.py:227-234) at
     n_in = 32768: P is 4.3 GB.  The reference makes three passes over P per update (12 n_in^2 bytes + an n_in^2 temporary).
-    Here, by default whenever the symmetric pass is taken: the BLOCKED symmetric sweep -- the inputs of a window are known in advance, so
+    Here (the default with the reference's default beta = 1, chosen explicitly for this leg's beta = 0.99): the BLOCKED symmetric sweep -- the inputs of a window are known in advance, so
     one read-modify-write pass over the blocks of P on and above the diagonal applies 8 updates and forms the products with
     the next 8 inputs (rp_rls.block; the z vectors inside a block follow from a double-precision recurrence on n_in-vectors).
     Reported next to it: the symmetric pass per update (r03 / r04 first half) and the dense pass per update (r02)."""
@@ -753,7 +753,7 @@ def rls_extra(dev, n_in=32768, k=3, T=64, cpu_threads=None):
     for form in ("blocked", "symmetric", "dense"):
         edge = RLS(n_in, k, beta=0.99, alpha=1.0).to(dev)
         edge.symmetric = form != "dense"
-        edge.block = None if form == "blocked" else 1   # None: the default (8 updates per pass)
+        edge.block = 8 if form == "blocked" else 1   # (8 is the default with beta = 1, the reference's default; here beta = 0.99)
         Tf = T if form == "blocked" else 20
         edge.sweep(X[:16], Y[:16], 1)
         torch.cuda.synchronize()

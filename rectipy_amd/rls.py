@@ -38,7 +38,7 @@ class RLS(Linear):
         self._colparts = None
         self.tiled = None  # None: by size; True / False: force the tiled / row-per-wave pass (tests, measurements)
         self.symmetric = None  # None: by size and updates per call; True / False: force / forbid the symmetric pass
-        self.block = None      # None: 8 (4 below 8 updates per call); 1: one pass over P per update; 2 / 4 / 8: one pass per so many updates
+        self.block = None      # None: with beta = 1: 8 (4 below 8 updates per call), else 1; 1: one pass over P per update; 2 / 4 / 8: one pass per so many updates
         self._blk = None
 
     # The symmetric pass streams only the blocks of P on and above the diagonal (4 n^2 instead of 8 n^2 bytes per update)
@@ -145,7 +145,12 @@ class RLS(Linear):
         if self._upper_only and not use_sym:
             self.P  # (a dense pass reads all of P: restore the lower blocks first)
         if use_sym:
-            block = self.block if self.block is not None else (self.BLOCK if updates >= self.BLOCK else 4)
+            block = self.block
+            if block is None:
+                # the default: blocked for the reference's own default beta = 1.  With beta < 1 its recursion makes P indefinite
+                # and amplifies rounding whatever the form: there the literal one pass per update stays
+                # the default and the blocked sweep is a choice (RLS.block = 8)
+                block = (self.BLOCK if updates >= self.BLOCK else 4) if float(self.beta) == 1.0 else 1
             if block not in (1, 2, 4, 8):
                 raise ValueError("RLS.block must be 1, 2, 4 or 8")
             rows = self.SYMMETRIC_ROWS if block == 1 else self.BLOCK_ROWS

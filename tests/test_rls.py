@@ -61,7 +61,7 @@ def test_g14_fit_rls_matches_reference(target, stride, tiled):
         net2.forward(x[t])
         if t % stride == 0:
             edge2.update(net2["rnn"]["out"], y[t], net2["out"]["out"])
-    # (the sweep above may have taken the blocked form -- the default on the symmetric pass -- which rounds z
+    # (the sweep above may have taken the blocked form -- the default on the symmetric pass with beta = 1 -- which rounds z
     # differently from a pass per update: 1.1e-5 on weights of size 0.6; a pass per update on both sides: < 1e-5)
     assert np.abs(edge2.weights.cpu().numpy() - edge.weights.cpu().numpy()).max() < 2e-5
     assert np.abs(edge2.P.cpu().numpy() - edge.P.cpu().numpy()).max() < 1e-5
@@ -338,3 +338,17 @@ def test_blocked_sweep_is_the_same_recursion_and_no_less_accurate(target):
                       np.abs(edge.P.cpu().numpy() - P).max())
     assert dev[8][0] < 1e-4 and dev[8][1] < 2e-6 and dev[8][2] < 2e-6, dev
     assert all(b <= 1.5 * a + 1e-7 for a, b in zip(dev[1], dev[8])), dev
+
+
+def test_default_form_follows_beta(oracle_backend):
+    """On the symmetric pass the blocked sweep is the default for the reference's default beta = 1; with beta < 1 (a recursion
+    that amplifies rounding in any form) the literal pass per update stays the default and the blocked sweep is a choice."""
+    gen = torch.Generator().manual_seed(0)
+    X, Y = torch.randn(12, 64, generator=gen), torch.randn(12, 2, generator=gen)
+    used = {}
+    for beta, block in ((1.0, None), (0.97, None), (0.97, 8)):
+        edge = RLS(64, 2, beta=beta, alpha=1.0, backend=oracle_backend)
+        edge.tiled, edge.symmetric, edge.block = True, True, block
+        edge.sweep(X, Y, 1)
+        used[(beta, block)] = edge._blk is not None
+    assert used == {(1.0, None): True, (0.97, None): False, (0.97, 8): True}
