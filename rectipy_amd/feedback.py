@@ -683,6 +683,38 @@ class FeedbackNetwork(Network):
             self[n]["out"] = None
         self._prev_out = {}
 
+    def _coupled_node_outputs(self, plan: dict, inputs: torch.Tensor, label: str) -> torch.Tensor:
+        """Per-step outputs [T, n] of the node `label` -- a population or a node downstream of all populations -- over the
+        whole input, the populations integrated window by window with one rp_forward_coupled call each (no gradient)."""
+        self._consolidate(plan)
+        T = inputs.shape[0]
+        pops, post = plan["pops"], plan["post"]
+        if label in pops:
+            want, chain = {label}, []
+        else:
+            chain = [n for n in post if n == label or label in descendants(self.graph, n)]
+            want = {p for p in pops if any(t_ in chain for t_ in self.graph.successors(p))}
+        for p in pops:
+            self.get_node(p)._pop.reset_sampling()
+        widest = max(self.get_node(p)._pop.rows for p in pops)
+        chunk = max(1, min(T, _WINDOW_BYTES // (4 * widest * max(1, len(want) + len(plan["pre"]) + 1))))
+        pieces = []
+        for a in range(0, T, chunk):
+            b = min(a + chunk, T)
+            outs = dict(self._coupled_window(plan, inputs[a:b], a, want, {}, None, 0, 1))
+            for n in chain:
+                X = None
+                for p_ in self.graph.predecessors(n):
+                    if p_ in outs:
+                        contrib = self._edge_window(self.get_edge(p_, n), outs[p_])
+                        X = contrib if X is None else X + contrib
+                outs[n] = self.get_node(n).forward(X)
+            pieces.append(outs[label])
+        for n in self._order:
+            self[n]["out"] = None
+        self._prev_out = {}
+        return pieces[0] if len(pieces) == 1 else torch.cat(pieces)
+
     def reset(self, state: dict = None):
         super().reset(state)
         self._prev_out = {}

@@ -1079,6 +1079,15 @@ class Network:
             with torch.no_grad():
                 outs = self._window_outputs(inp, 0, False, {}, 0, 1)
                 return edge.sweep(outs[src], tgt, optim_steps)
+        coupled = None
+        if not rec_vars and dst == self._out_node and getattr(self.get_node(dst), "name", None) == "identity" \
+                and self._chain_plan() is None:
+            coupled = self._coupled_plan([])
+        if coupled is not None and dst in coupled["post"] and src in coupled["pops"] + coupled["post"]:
+            # populations joined by dense edges, cycles included (FeedbackNetwork): the read-out does not feed back, so all
+            # populations integrate the whole input first (one rp_forward_coupled call per window), then the RLS sweep
+            with torch.no_grad():
+                return edge.sweep(self._coupled_node_outputs(coupled, inp, src), tgt, optim_steps)
         steps, loss, losses = inp.shape[0], 0.0, []
         with torch.no_grad():
             for step in range(steps):

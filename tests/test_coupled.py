@@ -857,3 +857,31 @@ def test_repeated_parameters_are_stepped_one_after_the_other(oracle_backend):
     assert opt.defaults["foreach"] is True
     plain = net._get_optimizer("sgd", 0.1, iter(params[:4]))
     assert plain.defaults["foreach"] is None
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("stride", [1, 3])
+def test_fit_rls_behind_coupled_populations_is_windows_plus_one_sweep(target, stride, monkeypatch):
+    """fit_rls on a read-out of populations joined in a cycle: the read-out does not feed back, so the populations integrate
+    the whole input with one rp_forward_coupled call per window and the RLS sweep runs over the stored edge inputs; same
+    predictions, losses, weights, P and final state as the step-by-step walk with one RLS.update per step."""
+    calls = []
+    real = engine.forward_coupled
+    monkeypatch.setattr(engine, "forward_coupled", lambda members: calls.append(len(members)) or real(members))
+    r = np.random.default_rng(2)
+    x, y = r.standard_normal((41, 3)).astype(np.float32), r.standard_normal((41, 2)).astype(np.float32)
+    res = []
+    for force in (True, False):
+        calls.clear()
+        net = build_net(target, force, sizes=(16, 24), k=0)
+        net.add_func_node("out", 2, "identity")
+        net.add_edge("b", "out", train="rls", beta=1.0, alpha=1.5)
+        obs = net.fit_rls(x, y, update_steps=stride, sampling_steps=1, verbose=False)
+        edge = net.get_edge("b", "out")
+        assert calls == ([] if force else [2]), calls
+        res.append((obs.to_numpy("out"), obs.to_numpy("loss"), edge.weights.cpu().numpy().copy(), edge.P.cpu().numpy().copy(),
+                    {k_: v_.detach().cpu().numpy().copy() for k_, v_ in net.state.items()}))
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert a.shape == b.shape and np.abs(a - b).max() < 2e-5 * max(1.0, np.abs(a).max())
+    for k_ in res[0][4]:
+        assert np.abs(res[0][4][k_] - res[1][4][k_]).max() < 5e-6, k_
