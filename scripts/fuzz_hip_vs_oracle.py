@@ -109,6 +109,12 @@ def main(cases=50, seed=0, max_n=2100):
         args = (int(rng.integers(0, 1 << 30)), name, n, m, k, train, out_var, readout, sparse)
         cpu = build(dict(device="cpu", backend=OracleBackend()), *args)
         gpu = build(dict(device=DEV) if DEV != "cpu" else dict(device="cpu", backend=OracleBackend()), *args)
+        if mode == "rls" and n % 4 == 0 and rng.integers(0, 2):
+            # the symmetric pass and its blocked sweep (chosen by size from n_in = 8192) forced at this size
+            block, rows = int([1, 2, 4, 8][int(rng.integers(0, 4))]), int([64, 128][int(rng.integers(0, 2))])
+            for net_ in (cpu, gpu):
+                e_ = net_.get_edge("rnn", "out")
+                e_.tiled, e_.symmetric, e_.block, e_.BLOCK_ROWS = True, True, block, rows
         width = m or n
         n_out = k or n
         # an input node's projection is a torch product on the device (rocBLAS) and on the host (MKL): equal to rounding only,
