@@ -885,3 +885,58 @@ def test_fit_rls_behind_coupled_populations_is_windows_plus_one_sweep(target, st
         assert a.shape == b.shape and np.abs(a - b).max() < 2e-5 * max(1.0, np.abs(a).max())
     for k_ in res[0][4]:
         assert np.abs(res[0][4][k_] - res[1][4][k_]).max() < 5e-6, k_
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_g38_cycle_fit_at_kernel_sizes_matches_the_reference(target, monkeypatch):
+    """Golden G38 (tests/golden/make_golden_feedback_fit_large.py): the reference's FeedbackNetwork.fit_bptt with populations
+    of 260 and 516 neurons (a -> b -> read-out, feedback b -> a), one SGD window of 40 steps, every parameter trained -- the
+    sizes at which the coupled adjoint's chunked products walk full 256-column strips plus a ragged one in the recurrent and
+    the edge matrices.  The gradients the window leaves on the parameters against the reference's float64 autograd: the
+    per-neuron vectors whole, eight rows and eight columns of every matrix and its sum / sum of squares.  Tolerance 2e-5 of
+    each gradient's largest entry (the reference's own float32 run: 4.9e-7)."""
+    import os
+    import sys
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, gold)
+    import recipes
+    g = dict(np.load(os.path.join(gold, "g38_feedback_fit_large.npz")))
+    bwd = []
+    real_b = engine.backward_coupled
+    monkeypatch.setattr(engine, "backward_coupled", lambda members: bwd.append(len(members)) or real_b(members))
+    edge = lambda rows, cols, seed, gain: (recipes.normal((rows, cols), seed) * np.float32(gain / np.sqrt(cols))).astype(np.float32)
+    na, nb, T = int(g["na"]), int(g["nb"]), int(g["T"])
+    Pa = recipes.li_network(na, seed=3801, g=1.1, defaults=False)
+    Pb = recipes.li_network(nb, seed=3802, g=1.1, defaults=False)
+    W_ab, W_ba, W_out = edge(nb, na, 3803, 0.6), edge(na, nb, 3804, 0.6), edge(3, nb, 3805, 1.0)
+    x = (0.5 * recipes.normal((T, na), seed=3806)).astype(np.float32)
+    tgt = (0.2 * recipes.normal((T, 3), seed=3807)).astype(np.float32)
+    for name, arr in (("Wa", Pa["W"]), ("Wb", Pb["W"]), ("W_ab", W_ab), ("W_ba", W_ba), ("W_out", W_out), ("x", x), ("target", tgt)):
+        assert np.array_equal(recipes.fingerprint(arr), g["fp_" + name]), f"regenerated {name} differs from the generator's"
+    net = FeedbackNetwork(float(g["dt"]), **target)
+    names = ["weights", "li_op/tau", "li_op/k", "li_op/eta"]
+    for lab, P in (("a", Pa), ("b", Pb)):
+        net.add_diffeq_node(lab, TANH, weights=P["W"], source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                            output_var="li_op/v", dtype=torch.float32, train_params=list(names),
+                            node_vars={"all/li_op/tau": P["tau"], "all/li_op/k": P["k"], "all/li_op/eta": P["eta"], "all/li_op/v": P["y0"]})
+    net.add_func_node("out", 3, "identity")
+    e_ab = net.add_edge("a", "b", weights=W_ab, train="gd")
+    e_out = net.add_edge("b", "out", weights=W_out, train="gd")
+    e_ba = net.add_edge("b", "a", weights=W_ba, feedback=True, train="gd")
+    obs = net.fit_bptt(x, tgt, optimizer="sgd", lr=float(g["lr"]), update_steps=T, sampling_steps=1, verbose=False)
+    assert bwd == [2]
+    assert np.abs(obs.to_numpy("out") - g["pred_f64"]).max() < 1e-5
+    rows = {"a": g["rows_a"], "b": g["rows_b"]}
+    for lab in "ab":
+        for key in names[1:]:
+            assert_grad(net.get_node(lab)[key], g[f"grad_{lab}_{key.split('/')[-1]}_f64"], f"{lab} {key}", 2e-5)
+    mats = {"Wa": (net.get_node("a")["weights"], "a", "a"), "Wb": (net.get_node("b")["weights"], "b", "b"), "W_ab": (e_ab.weights, "b", "a"),
+            "W_ba": (e_ba.weights, "a", "b"), "W_out": (e_out.weights, None, "b")}
+    for key, (param, rlab, clab) in mats.items():
+        got = param.grad.detach().cpu().numpy().astype(np.float64)
+        ref_rows, ref_cols, fp_ref = g[f"grad_{key}_rows_f64"], g[f"grad_{key}_cols_f64"], g[f"grad_{key}_fp_f64"]
+        scale = max(np.abs(ref_rows).max(), np.abs(ref_cols).max())
+        assert np.abs((got[rows[rlab]] if rlab else got) - ref_rows).max() <= 2e-5 * scale, key
+        assert np.abs(got[:, rows[clab]] - ref_cols).max() <= 2e-5 * scale, key
+        fp = recipes.fingerprint(got)
+        assert abs(fp[1] - fp_ref[1]) <= 1e-5 * fp_ref[1], key   # sum of squares of all entries
