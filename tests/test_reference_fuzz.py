@@ -135,3 +135,16 @@ def test_random_readout_training_sequences_on_the_blocked_sweep_match_the_refere
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import fuzz_training_vs_reference
     assert fuzz_training_vs_reference.main(20, seed, blocked=True) == 0, capsys.readouterr().out[-2000:]
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_spiking_chains_trained_through_feedback_match_the_reference(seed, capsys):
+    """Chains mixing tanh and QIF populations with (trained) feedback edges and trainable population parameters: run / reset /
+    forward sequences closed by ONE fit_bptt window with spikes inside (the reference's detach leaves the spike argument of a
+    SpikeResetNet attached, so it allows one backward per network) -- surrogate gradients through the cycle, the lagging
+    read of a spiking source included, by the fused coupled adjoint where the plan allows it.  Measured worst deviation
+    over 75 sequences: 1.4e-6."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import fuzz_chains_vs_reference
+    assert fuzz_chains_vs_reference.main(20, seed, tol=2e-3, spiking=True, train_fb=True, spiking_fit=True) == 0, \
+        capsys.readouterr().out[-2000:]
