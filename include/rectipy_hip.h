@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 13
+#define RP_ABI_VERSION 14
 #define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0
@@ -389,9 +389,13 @@ int rp_bwd_apply(const rp_net* net, const rp_bwd* bwd, int32_t t, const float* z
  * the window's history is cut there, as by Network.detach); then every member's own step (rp_bwd_partial / rp_bwd_apply:
  * z = W^T u over column strips, the element-wise update).  So rp_bwd.grad_out of a member is READ AND WRITTEN here (the
  * caller passes a private buffer, zeros where the loss has no direct gradient), grad_x is required for every member with
- * edges, and an RP_EDGE_LIVE edge from an EARLIER member (it reads a post-update value) is not available: such graphs
- * keep the step-by-step autograd.  c is summed like z: per chunk of RC(n_q, rows_m) rows of the edge matrix ascending,
- * chunks ascending (mirrored by oracle_backward_coupled).  The weight gradient of an edge is left to the caller:
+ * edges.  An RP_EDGE_LIVE edge from an EARLIER member q reads q's output AFTER q's step of the same Euler step, i.e. the
+ * output of step t + 1: its c = W_e^T gx_m(t) goes into row t + 1 of q's output gradient -- for t + 1 = steps into q's final
+ * adjoint lam (times act'(r_final) when the output variable is the source: rp_bwd_member.final_src).  To have gx_m(t) in
+ * time the members take every adjoint step (and the preparation) in REVERSE order, each right after the edge products
+ * that end in its own output gradient.  c is summed like z: per chunk of RC(n_q, rows_m) rows of the edge matrix ascending,
+ * chunks ascending; the edges that end in one member's output gradient are added in member / edge order (mirrored by
+ * oracle_backward_coupled).  The weight gradient of an edge is left to the caller:
  * dW_e = sum_t gx_m(t) (x) out_q(tau) is rp_outer_store_rect on the two stored windows.
  */
 typedef struct rp_bwd_member {
@@ -404,6 +408,9 @@ typedef struct rp_bwd_member {
     int32_t edge_mode[RP_MAX_EDGES];     /* RP_EDGE_OUT | RP_EDGE_LIVE (source later in the order) | RP_EDGE_LAG          */
     float* edge_work;                    /* workspace: SUM over this member's edges of rp_bwd_shard_partial_rows(n_source, rows) * n_source floats (16-byte aligned) */
     float* z;                            /* workspace [n]                                                               */
+    const float* final_src;              /* [n] the member's source vector r at the END of the window; required when an RP_EDGE_LIVE
+                                            edge of a LATER member reads this member (a post-update read) and its output variable
+                                            is the source; else may be NULL                                               */
 } rp_bwd_member;
 int rp_sizeof_bwd_member(void);
 int rp_backward_coupled(const rp_bwd_member* members, int32_t count, void* stream);

@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 13
+RP_ABI_VERSION = 14
 RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_MFMA16, RP_BATCH_SLOTS = 0, 1, 2, 32
 RP_COMM_RCCL, RP_COMM_DIRECT = 0, 1
 
@@ -139,6 +139,7 @@ class RpBwdMember(C.Structure):
         ("edge_mode", C.c_int32 * RP_MAX_EDGES),
         ("edge_work", fp),
         ("z", fp),
+        ("final_src", fp),
     ]
 
 

@@ -1138,9 +1138,20 @@ static int coupled_fused_sweep(const rp_bwd_member* mem, int count, int T, hipSt
     return RP_OK;
 }
 
+// lam[j] += c[j] (output variable = the state) or c[j] * act'(r_final[j]) (the source): a post-update read of the LAST step of
+// the window ends in the final adjoint of its source (rp_backward_coupled)
+__global__ void lam_add_kernel(const BwdParams E, const BwdParams Q, const float* r_final) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= E.n) return;
+    const float g = chunk_sum(E, j);
+    const float gv = (Q.grad_var == RP_OUT_STATE0) ? g : g * act_deriv(Q, j, r_final[j]);
+    Q.lam[j] = Q.lam[j] + gv;
+}
+
 int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
     if (!mem || count < 1 || count > 16) RP_FAIL(RP_ERR_ARG, "rp_backward_coupled: 1..16 members");
     const int T = mem[0].bwd ? mem[0].bwd->steps : 0;
+    bool post = false;  // an RP_EDGE_LIVE edge from an earlier member: it reads a post-update output
     for (int m = 0; m < count; ++m) {
         const rp_bwd_member& M = mem[m];
         if (!M.net || !M.bwd || !M.z) RP_FAIL(RP_ERR_ARG, "member %d: net / bwd / z is null", m);
@@ -1155,47 +1166,75 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
             if (q < 0 || q >= count || !mem[q].net || !mem[q].bwd) RP_FAIL(RP_ERR_ARG, "member %d edge %d: bad source %d", m, e, q);
             if (mode != RP_EDGE_OUT && mode != RP_EDGE_LIVE && mode != RP_EDGE_LAG) RP_FAIL(RP_ERR_ARG, "member %d edge %d: bad mode %d", m, e, mode);
             if (mode == RP_EDGE_OUT && q >= m) RP_FAIL(RP_ERR_ARG, "member %d edge %d: RP_EDGE_OUT needs a source stepped earlier", m, e);
-            if (mode == RP_EDGE_LIVE && q <= m)
-                RP_FAIL(RP_ERR_ARG, "member %d edge %d: an RP_EDGE_LIVE edge from member %d reads a post-update value: no fused adjoint", m, e, q);
+            if (mode == RP_EDGE_LIVE && q == m) RP_FAIL(RP_ERR_ARG, "member %d edge %d: a member cannot read its own live output", m, e);
+            if (mode == RP_EDGE_LIVE && q < m) {
+                post = true;
+                if (mem[q].net->model != RP_MODEL_LI_TANH && mem[q].net->model != RP_MODEL_LI_SIGMOID)
+                    RP_FAIL(RP_ERR_ARG, "member %d edge %d: a post-update read needs a rate population as its source", m, e);
+                if (mem[q].bwd->grad_var != RP_OUT_STATE0 && !mem[q].final_src)
+                    RP_FAIL(RP_ERR_ARG, "member %d edge %d: source %d needs final_src (its output variable is the source)", m, e, q);
+            }
             if (!M.edge_w[e] || M.edge_ld[e] < mem[q].net->n) RP_FAIL(RP_ERR_SHAPE, "member %d edge %d: edge_w / edge_ld", m, e);
             if (!mem[q].bwd->grad_out || mem[q].bwd->ldg < mem[q].net->n)
                 RP_FAIL(RP_ERR_ARG, "member %d edge %d: source %d needs a (writable) grad_out buffer", m, e, q);
         }
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    for (int m = 0; m < count; ++m) {
-        const int rc = rp_bwd_prepare(mem[m].net, mem[m].bwd, stream);
+    // the chunk partials of c = W_e^T gx_x(row) for edge e of member x, left in x's edge_work
+    auto edge_partials = [&](int x, int e, int row, BwdParams& P) {
+        const rp_bwd_member& X = mem[x];
+        const int q = X.edge_source[e];
+        P = BwdParams{};
+        P.W = X.edge_w[e];
+        P.ldw = X.edge_ld[e];
+        P.n = mem[q].net->n;
+        P.rows = X.net->rows;
+        P.rc = chunk_rows(P.n, P.rows);
+        P.q = (P.rows + P.rc - 1) / P.rc;
+        P.partials = X.edge_work;  // (the edges are evaluated one after the other: they share the workspace)
+        P.u = X.bwd->grad_x + (int64_t)row * X.bwd->ldgx;
+        const bool vec4 = (P.n % 4 == 0) && (P.ldw % 4 == 0) && !(reinterpret_cast<uintptr_t>(P.W) & 15u) &&
+                          !(reinterpret_cast<uintptr_t>(P.partials) & 15u);
+        launch_wt_partial(P, vec4, st);
+    };
+    // preparation, last member first: a post-update read of the window's last step ends in its source's final adjoint
+    for (int q = count - 1; q >= 0; --q) {
+        for (int x = q + 1; post && x < count; ++x)
+            for (int e = 0; e < mem[x].n_edges; ++e) {
+                if (mem[x].edge_source[e] != q || mem[x].edge_mode[e] != RP_EDGE_LIVE) continue;
+                BwdParams E, Q;
+                bool v4;
+                const int rc = sharded_params(mem[q].net, mem[q].bwd, Q, v4);
+                if (rc != RP_OK) return rc;
+                edge_partials(x, e, T - 1, E);
+                hipLaunchKernelGGL(lam_add_kernel, dim3((E.n + 255) / 256), dim3(256), 0, st, E, Q, mem[q].final_src);
+            }
+        const int rc = rp_bwd_prepare(mem[q].net, mem[q].bwd, stream);
         if (rc != RP_OK) return rc;
     }
-    if (coupled_fused_ok(mem, count)) return coupled_fused_sweep(mem, count, T, st);
+    if (!post && coupled_fused_ok(mem, count)) return coupled_fused_sweep(mem, count, T, st);
     for (int t = T - 1; t >= 0; --t) {
-        // the gradient through the edges first: gx_m(t) = row t of m's grad_x is ready (prep of the step before)
-        for (int m = 0; m < count; ++m) {
-            const rp_bwd_member& M = mem[m];
-            for (int e = 0; e < M.n_edges; ++e) {
-                const int q = M.edge_source[e];
-                const int tau = M.edge_mode[e] == RP_EDGE_LAG ? t - 1 : t;
-                if (tau < 0) continue;
-                BwdParams P = {};  // (the edges of a member are evaluated one after the other: they share edge_work)
-                P.W = M.edge_w[e];
-                P.ldw = M.edge_ld[e];
-                P.n = mem[q].net->n;
-                P.rows = M.net->rows;
-                P.rc = chunk_rows(P.n, P.rows);
-                P.q = (P.rows + P.rc - 1) / P.rc;
-                P.partials = M.edge_work;
-                P.u = M.bwd->grad_x + (int64_t)t * M.bwd->ldgx;
-                const bool vec4 = (P.n % 4 == 0) && (P.ldw % 4 == 0) && !(reinterpret_cast<uintptr_t>(P.W) & 15u) &&
-                                  !(reinterpret_cast<uintptr_t>(P.partials) & 15u);
-                launch_wt_partial(P, vec4, st);
-                float* dst = const_cast<float*>(mem[q].bwd->grad_out) + (int64_t)tau * mem[q].bwd->ldg;
-                hipLaunchKernelGGL(chunk_sum_add_kernel, dim3((P.n + 255) / 256), dim3(256), 0, st, P, dst);
-            }
-        }
-        for (int m = 0; m < count; ++m) {
-            int rc = rp_bwd_partial(mem[m].net, mem[m].bwd, t, mem[m].z, stream);
+        // last member first; in front of a member's step the edge products that end in its output gradient: from gx_x(t)
+        // (ready since step t + 1) for the reads of step t's output -- into row t -- and of the output one step earlier
+        // (RP_EDGE_LAG) -- into row t - 1 --, from gx_x(t - 1) (x comes later in the order: its step t is done) for the
+        // post-update reads -- into row t
+        for (int q = count - 1; q >= 0; --q) {
+            for (int x = 0; x < count; ++x)
+                for (int e = 0; e < mem[x].n_edges; ++e) {
+                    if (mem[x].edge_source[e] != q) continue;
+                    const int mode = mem[x].edge_mode[e];
+                    const bool is_post = mode == RP_EDGE_LIVE && q < x;
+                    const int row = is_post ? t - 1 : t;                     // the row of gx_x the edge carries back
+                    const int tau = mode == RP_EDGE_LAG ? t - 1 : t;        // ... into this row of q's output gradient
+                    if (row < 0 || tau < 0) continue;
+                    BwdParams E;
+                    edge_partials(x, e, row, E);
+                    float* dst = const_cast<float*>(mem[q].bwd->grad_out) + (int64_t)tau * mem[q].bwd->ldg;
+                    hipLaunchKernelGGL(chunk_sum_add_kernel, dim3((E.n + 255) / 256), dim3(256), 0, st, E, dst);
+                }
+            int rc = rp_bwd_partial(mem[q].net, mem[q].bwd, t, mem[q].z, stream);
             if (rc != RP_OK) return rc;
-            rc = rp_bwd_apply(mem[m].net, mem[m].bwd, t, mem[m].z, stream);
+            rc = rp_bwd_apply(mem[q].net, mem[q].bwd, t, mem[q].z, stream);
             if (rc != RP_OK) return rc;
         }
     }

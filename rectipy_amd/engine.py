@@ -727,8 +727,9 @@ def backward_coupled(members: list) -> list:
 
     ``members`` (the order of the forward call): dicts with ``pop``, ``bwd`` (keyword arguments of
     :meth:`Population.backward`; ``grad_out`` [T, rows] is required -- and written -- for every member an edge reads,
-    ``grad_x`` for every member with edges) and ``edges`` as in :func:`forward_coupled`.  Returns the tensors to keep
-    alive until the stream has run the sweep."""
+    ``grad_x`` for every member with edges), ``edges`` as in :func:`forward_coupled` and, for a member whose output an
+    RP_EDGE_LIVE edge of a LATER member reads (a post-update read), ``final_src``: its source vector at the end of the window.
+    Returns the tensors to keep alive until the stream has run the sweep."""
     count = len(members)
     arr = (_abi.RpBwdMember * count)()
     keep_all = []
@@ -756,7 +757,12 @@ def backward_coupled(members: list) -> list:
             arr[m].edge_source[e], arr[m].edge_mode[e] = int(source), int(mode)
         arr[m].edge_work = work.data_ptr()
         arr[m].z = z.data_ptr()
-        keep_all.append((net, b, keep, z, work, [We for We, _, _ in edges]))
+        final_src = spec.get("final_src")  # r at the end of the window: a later member's RP_EDGE_LIVE edge read it (a post-update read)
+        if final_src is not None:
+            if final_src.dtype != torch.float32 or final_src.device != pop.device or final_src.numel() != pop.n or not final_src.is_contiguous():
+                raise RuntimeError(f"member {m}: final_src must be a contiguous float32 [{pop.n}] tensor on {pop.device}")
+            arr[m].final_src = final_src.data_ptr()
+        keep_all.append((net, b, keep, z, work, final_src, [We for We, _, _ in edges]))
     first.backend.backward_coupled(arr, count, first.device)
     return keep_all
 

@@ -18,8 +18,8 @@ next to its recurrent matrix (`_coupled_plan` / `_run_coupled`).  Activation nod
 layers) are evaluated for the whole window in advance, those downstream of every population (read-outs) afterwards.
 Gradient-tracking runs of such a graph (`fit_bptt`, `run(enable_grad=True)`) record ONE autograd node per window over all
 populations (`_CoupledWindow`: forward `rp_forward_coupled` with the windows stored, backward `rp_backward_coupled`).
-Everything else -- an activation node BETWEEN populations, edges with memory inside the cycle, and with a gradient a feedback
-edge from a rate population that was already stepped or a population-mean spiking model -- is walked step by step
+Everything else -- an activation node BETWEEN populations, edges with memory inside the cycle, and with a gradient a
+population-mean spiking model -- is walked step by step
 (`forward`), where a plain dense edge into a population is still evaluated inside that population's step kernel whenever
 no gradient has to pass through it."""
 from typing import List, Optional
@@ -86,6 +86,15 @@ class _CoupledWindow(torch.autograd.Function):
             lag0[p] = net.get_node(p)["out"].detach().clone()
         net._coupled_steps(plan, xin, steps, a, set(), {}, None, 0, 1, stored=stored)
         outs = []
+        order = {p: i for i, p in enumerate(pops)}
+        # a feedback edge from a rate population that was already stepped read its output AFTER the step: for the window's
+        # last step that is the final state -- kept for the adjoint (act'(r_final)) and the edge's weight gradient
+        final = {}
+        for p in pops:
+            for s_, mode in plan["edges"][p]:
+                if mode == _abi.RP_EDGE_LIVE and order[s_] < order[p] and s_ not in final:
+                    src = net.get_node(s_)._pop
+                    final[s_] = (src.v.clone(), src.source.clone())
         for p in pops:
             node = net.get_node(p)
             pop, st = node._pop, stored[p]
@@ -96,7 +105,7 @@ class _CoupledWindow(torch.autograd.Function):
             else:
                 node._last_window = (st["save_v"], st["save_src"])
                 outs += [out.clone(), pop.v.clone()]
-        ctx.net, ctx.plan, ctx.steps, ctx.stored, ctx.widths, ctx.xin, ctx.lag0 = net, plan, steps, stored, widths, xin, lag0
+        ctx.net, ctx.plan, ctx.steps, ctx.stored, ctx.widths, ctx.xin, ctx.lag0, ctx.final = net, plan, steps, stored, widths, xin, lag0, final
         return tuple(outs)
 
     @staticmethod
@@ -145,8 +154,8 @@ class _CoupledWindow(torch.autograd.Function):
                 kw.update(lam=R["lam"], grad_tau=R["par"].get("tau"), grad_k=R["par"].get("k"), grad_eta=R["par"].get("eta"),
                           grad_params={k_: v_ for k_, v_ in R["par"].items() if k_ in _RateWindow.ACT_PARAMS})
             res.append(R)
-            members.append(dict(pop=pop, bwd=kw, edges=[(net.get_edge(s_, p).weights.detach(), index[s_], mode)
-                                                        for s_, mode in plan["edges"][p]]))
+            members.append(dict(pop=pop, bwd=kw, final_src=ctx.final[p][1] if p in ctx.final else None,
+                                edges=[(net.get_edge(s_, p).weights.detach(), index[s_], mode) for s_, mode in plan["edges"][p]]))
         keep = backward_coupled(members)
         grads = [None] * len(need)
         for m, (p, (i, names)) in enumerate(zip(pops, layout)):
@@ -169,6 +178,9 @@ class _CoupledWindow(torch.autograd.Function):
                     out_s = stored[s_]["save_src"] if src._out_code == _abi.RP_OUT_SOURCE else stored[s_]["save_v"]
                     if mode == _abi.RP_EDGE_LAG:  # the source's output one step earlier; before the window: its value then
                         out_s = torch.cat([ctx.lag0[s_][None, :], out_s[:-1]])
+                    elif mode == _abi.RP_EDGE_LIVE and index[s_] < m:  # ... one step LATER (a post-update read); the last: the final one
+                        last = ctx.final[s_][1] if src._out_code == _abi.RP_OUT_SOURCE else ctx.final[s_][0]
+                        out_s = torch.cat([out_s[1:], last[None, :]])
                     gW = torch.empty(pop.rows, src._pop.rows, dtype=torch.float32, device=pop.device)
                     gx = res[m]["gx"]
                     pop.backend.outer_store_rect(pop.rows, src._pop.rows, T, 1.0, gx.data_ptr(), gx.stride(0) if T > 1 else pop.rows,
@@ -402,25 +414,19 @@ class FeedbackNetwork(Network):
         return dict(pre=pre, pops=pops, post=post, edges=edges, slots=slots)
 
     def _coupled_grad_plan(self) -> Optional[dict]:
-        """The coupled plan if its adjoint runs as one call too (rp_backward_coupled): every edge reads what its source
-        emitted before it was stepped -- feed-forward edges, feedback edges from rate populations stepped later (the usual
-        direction) and feedback edges from spiking populations (their exposed state lags one step).  A feedback edge from an
-        EARLIER rate population (it reads a post-update state) and the population-mean spiking models keep the per-step
-        autograd."""
+        """The coupled plan if its adjoint runs as one call too (rp_backward_coupled): feed-forward edges, feedback edges from
+        rate populations (stepped later: the usual direction; stepped earlier: a post-update read) and from spiking populations
+        (their exposed state lags one step).  The population-mean spiking models keep the per-step autograd."""
         from .spiking_autograd import TRAINABLE
         plan = self._coupled_plan([])
         if plan is None or getattr(self, "_force_stepwise_adjoint", False):
             return None
-        order = {p: i for i, p in enumerate(plan["pops"])}
         for p in plan["pops"]:
             node = self.get_node(p)
             if node._out_slice is not None or node._pop.model in ("iku", "ik_biexp"):
                 return None
             if node._pop.spiking and node._pop.model not in TRAINABLE:
                 return None
-            for s_, mode in plan["edges"][p]:
-                if mode == _abi.RP_EDGE_LIVE and order[s_] <= order[p]:
-                    return None
         return plan
 
     def _coupled_grad_outputs(self, plan: dict, inputs_ab: torch.Tensor, a: int) -> torch.Tensor:

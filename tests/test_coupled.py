@@ -494,9 +494,10 @@ def test_g36_feedback_network_at_kernel_sizes_matches_the_reference(target, monk
 
 
 # ---- adjoint of a coupled window (rp_backward_coupled) -----------------------------------------------------------------
-def torch_walk_rate(pops, edges, out_vars, x, T, leaves):
+def torch_walk_rate(pops, edges, out_vars, x, T, leaves, post=()):
     """float64 torch restatement of the walk for rate members, differentiable in `leaves` (per member: v0, W, tau, k, eta;
-    per edge: its matrix; the input x of member 0)."""
+    per edge: its matrix; the input x of member 0).  `post`: edges (s, m) with s < m that are FEEDBACK edges -- they read the
+    source's state as it stands, i.e. after its step of the same Euler step."""
     v = [leaves["v0"][m] for m in range(len(pops))]
     outs = [[] for _ in pops]
     for t in range(T):
@@ -506,7 +507,7 @@ def torch_walk_rate(pops, edges, out_vars, x, T, leaves):
             for s_ in range(len(pops)):
                 if s_ == m:
                     continue
-                if s_ < m:
+                if s_ < m and (s_, m) not in post:
                     vec = ret[s_]
                 else:
                     vec = v[s_] if out_vars[s_] == _abi.RP_OUT_STATE0 else torch.tanh(v[s_])
@@ -519,7 +520,7 @@ def torch_walk_rate(pops, edges, out_vars, x, T, leaves):
     return [torch.stack(o) for o in outs], v
 
 
-def coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev, models=None):
+def coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev, models=None, post=()):
     """Forward with the window stored, then rp_backward_coupled; returns the gradients per member / edge."""
     from rectipy_amd.engine import backward_coupled
     n_m = len(pops)
@@ -535,8 +536,10 @@ def coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev, models=None
                    save_in=saved[m]["inp"], hist=hist[m])
         if m == 0:
             run["x"] = x
-        members.append(dict(pop=p, run=run, edges=[(edges[(s_, m)], s_, modes_for(models, s_, m)) for s_ in range(n_m) if s_ != m]))
+        members.append(dict(pop=p, run=run, edges=[(edges[(s_, m)], s_, _abi.RP_EDGE_LIVE if (s_, m) in post else modes_for(models, s_, m))
+                                                   for s_ in range(n_m) if s_ != m]))
     forward_coupled(members)
+    final = [(p.v.clone(), p.source.clone()) for p in pops]   # (what a post-update read of the last step saw)
     res, bw = [], []
     for m, p in enumerate(pops):
         N = p.rows
@@ -551,20 +554,30 @@ def coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev, models=None
         else:
             kw.update(grad_tau=R["tau"], grad_k=R["k"], grad_eta=R["eta"])
         res.append(R)
-        bw.append(dict(pop=p, edges=members[m]["edges"], bwd=kw))
+        bw.append(dict(pop=p, edges=members[m]["edges"], bwd=kw, final_src=final[m][1]))
     keep = backward_coupled(bw)
     del keep
     for m, p in enumerate(pops):
         res[m]["W"] = p.dt * res[m]["u"].T @ saved[m]["r"]
         res[m]["out"] = saved[m]["v"] if out_vars[m] == _abi.RP_OUT_STATE0 else saved[m]["r"]
         res[m]["v_traj"] = saved[m]["v"]
-    g_edges = {(s_, m): res[m]["gx"].T @ res[s_]["out"] for (s_, m) in edges}  # (edges that read the same step's output)
+    g_edges = {}
+    for (s_, m) in edges:
+        out = res[s_]["out"]
+        if (s_, m) in post:  # the output one step later; for the last step: the final one
+            last = final[s_][0] if out_vars[s_] == _abi.RP_OUT_STATE0 else final[s_][1]
+            out = torch.cat([out[1:], last[None, :]])
+        g_edges[(s_, m)] = res[m]["gx"].T @ out
     return res, g_edges
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
-@pytest.mark.parametrize("sizes,out_vars", [((24, 40, 16), (0, 0, 1)), ((17, 30), (1, 0)), ((64,), (1,)), ((260, 136, 72), (1, 1, 0))])
-def test_coupled_adjoint_against_float64_autograd(target, sizes, out_vars):
+@pytest.mark.parametrize("sizes,out_vars,post", [((24, 40, 16), (0, 0, 1), ()), ((17, 30), (1, 0), ()), ((64,), (1,), ()),
+                                                 ((260, 136, 72), (1, 1, 0), ()),
+                                                 # feedback edges from members ALREADY stepped: post-update reads
+                                                 ((24, 40, 16), (0, 1, 1), ((0, 2),)), ((17, 30), (1, 0), ((0, 1),)),
+                                                 ((260, 136, 72), (1, 0, 1), ((0, 1), (1, 2), (0, 2))), ((4100, 24), (1, 0), ((0, 1),))])
+def test_coupled_adjoint_against_float64_autograd(target, sizes, out_vars, post):
     dev, T = target["device"], 23
     models = ("li_tanh",) * len(sizes)
     pops, edges = circuit(sizes, models, 5, dev, target["backend"])
@@ -576,10 +589,10 @@ def test_coupled_adjoint_against_float64_autograd(target, sizes, out_vars):
     leaves = dict(v0=[d(p.v) for p in pops], W=[d(p.W) for p in pops], tau=[d(p.params["tau"]) for p in pops],
                   k=[d(p.params["k"]) for p in pops], eta=[d(p.params["eta"]) for p in pops],
                   edges={key: d(We) for key, We in edges.items()}, x=d(x))
-    outs, v_end = torch_walk_rate(pops, edges, out_vars, x, T, leaves)
+    outs, v_end = torch_walk_rate(pops, edges, out_vars, x, T, leaves, post)
     loss = sum((o * g.double()).sum() for o, g in zip(outs, g_out)) + sum((v * g.double()).sum() for v, g in zip(v_end, g_vend))
     loss.backward()
-    res, g_edges = coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev)
+    res, g_edges = coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev, post=post)
 
     def close(got, want, what):
         got, want = got.detach().cpu().double(), want.detach()
@@ -670,29 +683,46 @@ def test_fit_bptt_through_cycles_is_one_forward_and_one_adjoint_call_per_window(
         assert np.abs(res[0][3][k_] - res[1][3][k_]).max() < 2e-5, k_
 
 
-def test_adjoint_that_stays_on_the_walk(oracle_backend, monkeypatch):
-    """A feedback edge from an EARLIER population delivers a post-update state: fit_bptt keeps the per-step autograd."""
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("out_r", [False, True])
+def test_feedback_from_a_population_already_stepped_takes_the_fused_adjoint_too(target, out_r, monkeypatch):
+    """A feedback edge from an EARLIER population delivers its post-update state (network.py:1354-1357): in the adjoint its
+    gradient lands one row later in the source's output gradient (for the last step: in the final adjoint).  Same parameters
+    after three SGD windows as autograd over the per-step walk."""
     bwd = []
     real_b = engine.backward_coupled
     monkeypatch.setattr(engine, "backward_coupled", lambda members: bwd.append(len(members)) or real_b(members))
-    net = build_trained(dict(device="cpu", backend=oracle_backend), False, fb_to_later=True)
     r = np.random.default_rng(0)
-    net.fit_bptt(r.standard_normal((20, 3)).astype(np.float32), r.standard_normal((20, 2)).astype(np.float32), optimizer="sgd",
-                 lr=0.05, update_steps=10, sampling_steps=1, verbose=False)
-    assert bwd == [] and net._coupled_grad_plan() is None
+    x, y = r.standard_normal((65, 3)).astype(np.float32), r.standard_normal((65, 2)).astype(np.float32) * 0.3
+    res = []
+    for stepwise in (True, False):
+        bwd.clear()
+        net = build_trained(target, stepwise, out_r=out_r, fb_to_later=True)
+        for s_, t_ in (("a", "c"),):
+            net.get_edge(s_, t_).weights.requires_grad_(True)   # (the post-update edge is trained as well)
+        assert (net._coupled_grad_plan() is None) == stepwise if net._order else True
+        obs = net.fit_bptt(x, y, optimizer="sgd", lr=0.05, update_steps=20, sampling_steps=1, verbose=False)
+        assert bwd == ([] if stepwise else [3] * 3), bwd
+        res.append(([p.detach().cpu().numpy().copy() for p in net.parameters()], obs.to_numpy("out")))
+    for a_, b_ in zip(res[0][0], res[1][0]):
+        assert a_.shape == b_.shape and np.abs(a_ - b_).max() <= 2e-5 * max(1.0, np.abs(a_).max()), np.abs(a_ - b_).max()
+    assert np.abs(res[0][1] - res[1][1]).max() < 2e-5 * max(1.0, np.abs(res[0][1]).max())
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("post", [(), ((0, 1),)], ids=["", "post-update-read"])
 @pytest.mark.parametrize("sizes,out_vars,models", [
     ((24, 40, 16), (0, 0, 1), None), ((17, 30), (1, 0), None), ((260, 136, 72), (1, 1, 0), None),
     ((1024, 2052, 512), (0, 1, 1), None), ((4100, 520), (1, 0), None),
     ((32, 20), (1, 0), ("qif", "li_tanh")), ((17, 30, 12), (1, 1, 0), ("li_tanh", "qif", "qif")),
     ((520, 1028), (1, 1), ("qif", "qif"))])
-def test_hip_coupled_adjoint_bit_exact(oracle_backend, hip_device, sizes, out_vars, models):
+def test_hip_coupled_adjoint_bit_exact(oracle_backend, hip_device, sizes, out_vars, models, post):
     """rp_backward_coupled on the GPU against the C oracle: adjoint states, per-step u, input gradients, the output
     gradients the edges accumulate into and the per-neuron parameter gradients, bit for bit."""
     T = 19
     models = models or ("li_tanh",) * len(sizes)
+    if post and models[0] == "qif":
+        pytest.skip("a post-update read needs a rate population as its source")
     gen = torch.Generator().manual_seed(21)
     x = torch.randn(T, sizes[0], generator=gen) * 0.5
     g_out = [torch.randn(T, n, generator=gen) for n in sizes]
@@ -700,7 +730,7 @@ def test_hip_coupled_adjoint_bit_exact(oracle_backend, hip_device, sizes, out_va
     got = []
     for dev, backend in (("cpu", oracle_backend), (hip_device, None)):
         pops, edges = circuit(sizes, models, 5, dev, backend, dt=0.08 if "qif" in models else 1e-2)
-        res, _ = coupled_adjoint(pops, edges, out_vars, x.to(dev), T, g_out, g_vend, dev, models)
+        res, _ = coupled_adjoint(pops, edges, out_vars, x.to(dev), T, g_out, g_vend, dev, models, post=post)
         got.append(res)
     for m in range(len(sizes)):
         if models[m] == "qif":  # spikes inside the window: the sweep passes resets and surrogate gradients
