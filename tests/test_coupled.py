@@ -576,7 +576,7 @@ def coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev, models=None
                                                  ((260, 136, 72), (1, 1, 0), ()),
                                                  # feedback edges from members ALREADY stepped: post-update reads
                                                  ((24, 40, 16), (0, 1, 1), ((0, 2),)), ((17, 30), (1, 0), ((0, 1),)),
-                                                 ((260, 136, 72), (1, 0, 1), ((0, 1), (1, 2), (0, 2))), ((4100, 24), (1, 0), ((0, 1),))])
+                                                 ((260, 136, 72), (1, 0, 1), ((0, 1), (1, 2), (0, 2))), ((1028, 24), (1, 0), ((0, 1),))])
 def test_coupled_adjoint_against_float64_autograd(target, sizes, out_vars, post):
     dev, T = target["device"], 23
     models = ("li_tanh",) * len(sizes)
