@@ -81,7 +81,7 @@ class RLS(Linear):
         sym = self._P_symmetric
         self.P = self.P.to(device).contiguous()
         self._P_symmetric = sym
-        self._scratch = None
+        self._scratch = self._partials = self._colparts = self._blk = None   # (workspaces follow the device at the next sweep)
         return self
 
     def _ensure(self):
