@@ -84,7 +84,12 @@ class _CoupledWindow(torch.autograd.Function):
             widths[p] = None if x is None else x.shape[1]
         for p in {s_ for q in pops for s_, mode in plan["edges"][q] if mode == _abi.RP_EDGE_LAG}:
             lag0[p] = net.get_node(p)["out"].detach().clone()
+        # (autograd runs this method without gradient mode: what `detach(requires_grad=...)` asked of the states must survive
+        # the bookkeeping of an un-recorded step)
+        asked = {p: net.get_node(p)._y_requires_grad for p in pops}
         net._coupled_steps(plan, xin, steps, a, set(), {}, None, 0, 1, stored=stored)
+        for p in pops:
+            net.get_node(p)._y_requires_grad = asked[p]
         outs = []
         order = {p: i for i, p in enumerate(pops)}
         # a feedback edge from a rate population that was already stepped read its output AFTER the step: for the window's
