@@ -583,7 +583,7 @@ __global__ __launch_bounds__(kThreads) void rls_mirror_kernel(float* Pm, int64_t
 template <int K, bool UPDATE, bool DOT, int C, int R, bool FULL>
 __global__ __launch_bounds__(kThreads) void rls_symk_kernel(const RlsParams P) {
     __shared__ float wsum[DOT ? K : 1][C][4];
-    __shared__ float kzrow[UPDATE ? K : 1][C], xrow[DOT ? K : 1][C];
+    __shared__ float kzrow[C][UPDATE ? K : 1], xrow[C][DOT ? K : 1];  // (a row's K values side by side: wide LDS reads)
     static_assert(C % (2 * R) == 0 && (R & (R - 1)) == 0 && K * R <= 64, "groups of R rows, K R values per butterfly");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -620,8 +620,8 @@ __global__ __launch_bounds__(kThreads) void rls_symk_kernel(const RlsParams P) {
         const int k = e / C, r = e - k * C;
         const int i = row0 + r;
         const bool in = FULL || i < n;
-        if constexpr (UPDATE) kzrow[k][r] = (in && k < P.npend) ? P.kp[k] * P.zp[(int64_t)k * n + i] : 0.f;
-        if constexpr (DOT) xrow[k][r] = (in && k < P.nrhs) ? P.xb[(int64_t)k * P.xb_stride + i] : 0.f;
+        if constexpr (UPDATE) kzrow[r][k] = (in && k < P.npend) ? P.kp[k] * P.zp[(int64_t)k * n + i] : 0.f;
+        if constexpr (DOT) xrow[r][k] = (in && k < P.nrhs) ? P.xb[(int64_t)k * P.xb_stride + i] : 0.f;
     }
     __syncthreads();
     rp_f4 cp[DOT ? K : 1];
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(kThreads) void rls_symk_kernel(const RlsParams P) {
             if constexpr (UPDATE) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    const float kz = kzrow[k][g + r];
+                    const float kz = kzrow[g + r][k];
                     p.x = p.x - kz * zv[k].x;
                     p.y = p.y - kz * zv[k].y;
                     p.z = p.z - kz * zv[k].z;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(kThreads) void rls_symk_kernel(const RlsParams P) {
                     a.w = fmaf(p.w, xv[k].w, 0.f);
                     rs[k * R + r] = rp_lane_sum4(a);
                     if (FULL || (upper && i < n)) {  // (on a diagonal block the chain is computed and dropped, as in rls_sym_kernel)
-                        const float xi = xrow[k][g + r];
+                        const float xi = xrow[g + r][k];
                         cp[k].x = fmaf(p.x, xi, cp[k].x);
                         cp[k].y = fmaf(p.y, xi, cp[k].y);
                         cp[k].z = fmaf(p.z, xi, cp[k].z);
