@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 14
+#define RP_ABI_VERSION 15
 #define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0
@@ -172,6 +172,18 @@ typedef struct rp_net {
  * exactly as the reference does (record iff step >= cutoff and
  * step % sampling_steps == 0, storing the mean of the buffered outputs).
  */
+/* A matrix in the packed sparse form of rectipy_amd/sparse.py (the fields of rp_net.sp_* for a matrix other than W). */
+typedef struct rp_packed {
+    const float* vals;             /* NULL: no packed form                                                   */
+    const uint16_t* cidx;
+    const int32_t* rowoff;
+    const int32_t* row_ids;        /* windowed form only                                                     */
+    const int32_t* batch_class;
+    const int32_t* phase_window;
+    int32_t phases, batches;
+    int32_t block_rows;            /* > 0: blocked form                                                      */
+} rp_packed;
+
 typedef struct rp_run {
     int32_t steps;
     int64_t step0;            /* absolute index of the first step             */
@@ -239,6 +251,14 @@ typedef struct rp_run {
        received it.  The adjoint of a spiking population with edges needs it where it otherwise takes the window's external
        input (rp_bwd.x, RP_X_FULL): rp_backward_coupled. */
     float* save_in;
+    /* rp_forward_coupled only: packed forms of the edge matrices (rows = this population's rows, row0 = 0, n = edge_n) and a
+       workspace [rows].  A member whose W is packed (rp_net.sp_vals) AND whose edges all have a packed form is stepped as
+       n_edges packed mat-vec launches -- E = (E_0 + E_1) + ..., then I = x + E into edge_sum -- followed by its own packed
+       step reading I as a full-width input: the dense arithmetic bit for bit (the packed layout reproduces the dense row
+       dot), at the bytes of the stored nonzeros.  Otherwise (any edge without a packed form, or no edge_sum) the dense
+       matrices are streamed as described above. */
+    rp_packed edge_sp[RP_MAX_EDGES];
+    float* edge_sum;
 } rp_run;
 
 /* what an edge of rp_forward_coupled reads from its source population q (q's output variable, rp_run.out_var) */

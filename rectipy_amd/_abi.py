@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 14
+RP_ABI_VERSION = 15
 RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_MFMA16, RP_BATCH_SLOTS = 0, 1, 2, 32
 RP_COMM_RCCL, RP_COMM_DIRECT = 0, 1
 
@@ -75,6 +75,13 @@ class RpNet(C.Structure):
     ]
 
 
+class RpPacked(C.Structure):
+    _fields_ = [
+        ("vals", fp), ("cidx", fp), ("rowoff", fp), ("row_ids", fp), ("batch_class", fp), ("phase_window", fp),
+        ("phases", C.c_int32), ("batches", C.c_int32), ("block_rows", C.c_int32),
+    ]
+
+
 class RpRun(C.Structure):
     _fields_ = [
         ("steps", C.c_int32),
@@ -116,6 +123,8 @@ class RpRun(C.Structure):
         ("edge_src_ld", C.c_int64 * RP_MAX_EDGES),
         ("hist", fp * 3),
         ("save_in", fp),
+        ("edge_sp", RpPacked * RP_MAX_EDGES),
+        ("edge_sum", fp),
     ]
 
 

@@ -90,6 +90,11 @@ struct StepParams {
     float* hist_t;     // optional: this step's pre-update output (rp_run.hist[t_abs % 3])
     float* hist_next;  // optional (shared launch of rp_forward_coupled): the NEXT step's ring entry, i.e. this step's post-update output
     int model, vec4;   // (read by the shared-launch kernel only: the member's model and row-dot path)
+    // the packed mat-vec of one dense-edge-turned-sparse (kModelEdgeSum): esum_out[i] = esum_prev[i] + (W_e s)_i, and behind the
+    // member's last edge + its own input -- the node input I the member's step then reads as a full-width input
+    float* esum_out;
+    const float* esum_prev;
+    int esum_final;
 };
 
 // ---- row dot products (rp_dot.h) ---------------------------------------------
@@ -401,6 +406,25 @@ __global__ __launch_bounds__(kThreads) void step_kernel_tuning_probe(const StepP
 }
 
 // ---- packed-W step (rp_net.sp_*) --------------------------------------------------------------------------------
+// An edge matrix of a coupled member in packed form (rp_run.edge_sp): the sparse kernels below with this pseudo-model form
+// the edge's row sums -- the bits of the dense row dot, as for a packed W -- and chain them in edge order,
+// E = (E_0 + E_1) + ..., the last one adding the member's own input: I = x + E (the epilogue's order).
+constexpr int kModelEdgeSum = 64;
+
+__device__ __forceinline__ void edge_sum_result(const StepParams& P, int i, float wsum) {
+    float e = P.esum_prev ? P.esum_prev[i] + wsum : wsum;
+    if (P.esum_final && P.x_mode != RP_X_NONE) e = input_current(P, i) + e;
+    P.esum_out[i] = e;
+}
+
+template <int MODEL>
+__device__ __forceinline__ void sparse_row_result(const StepParams& P, int row, float sum) {
+    if constexpr (MODEL == kModelEdgeSum)
+        edge_sum_result(P, row, sum);
+    else
+        epilogue<MODEL>(P, row, sum);
+}
+
 // Same arithmetic as step_kernel's 16-byte path, streaming only the stored nonzeros: lane l still owns the slots
 // 4l..4l+3 of a row and keeps their four accumulators; its nonzeros come as ONE list in the order the dense kernel
 // meets them (value + code = component << 14 | column chunk), four list entries per lane per group, so every
@@ -469,7 +493,7 @@ __global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepP
             const float sum = rp_wave_allreduce(rp_lane_sum4(acc[j]));
             if (lane == j) mine = sum;
         }
-        if (lane < R && row_base + lane < P.rows) epilogue<MODEL>(P, row_base + lane, mine);
+        if (lane < R && row_base + lane < P.rows) sparse_row_result<MODEL>(P, row_base + lane, mine);
     }
 }
 
@@ -479,7 +503,7 @@ __global__ __launch_bounds__(kSparseThreads) void step_sparse_windowed_kernel(co
     extern __shared__ float lds_src[];
     const SparseWindowed S{P.sp_vals, P.sp_cidx, P.sp_rowoff, P.sp_row_ids, P.sp_batch_class, P.sp_phase_window,
                            P.sp_phases, P.sp_batches};
-    rp_sparse_windowed_rows<U>(S, P.src_cur, P.n, lds_src, [&](int row, float sum) { epilogue<MODEL>(P, row, sum); });
+    rp_sparse_windowed_rows<U>(S, P.src_cur, P.n, lds_src, [&](int row, float sum) { sparse_row_result<MODEL>(P, row, sum); });
 }
 
 // Blocked form (n <= 32768): rp_sparse_blocked_rows (rp_dot.h) with the step epilogue.  Dynamic LDS = the rotated
@@ -490,7 +514,7 @@ __global__ __launch_bounds__(WAVES * RP_WAVE) void step_sparse_blocked_kernel(co
     const int n_pad = (P.n + 255) & ~255;
     rp_sparse_stage_source<WAVES * RP_WAVE>(lds_src, P.src_cur, P.n, n_pad);
     rp_sparse_blocked_rows<WAVES, U>(P.sp_vals, P.sp_cidx, P.sp_rowoff, P.rows, P.sp_block_rows, lds_src, lds_src + n_pad,
-                                     [&](int row, float sum) { epilogue<MODEL>(P, row, sum); });
+                                     [&](int row, float sum) { sparse_row_result<MODEL>(P, row, sum); });
 }
 
 #ifdef RP_MEASUREMENT
@@ -606,6 +630,7 @@ int launch_step_sparse_model(int model, const StepParams& P, hipStream_t st) {
         case RP_MODEL_LIF: return launch_step_sparse<RP_MODEL_LIF>(P, st);
         case RP_MODEL_IK: return launch_step_sparse<RP_MODEL_IK>(P, st);
         case RP_MODEL_IKU: return launch_step_sparse<RP_MODEL_IKU>(P, st);
+        case kModelEdgeSum: return launch_step_sparse<kModelEdgeSum>(P, st);
         default: return launch_step_sparse<RP_MODEL_IK_BIEXP>(P, st);
     }
 }
@@ -1299,6 +1324,20 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
             if (mode != RP_EDGE_LAG && mem[q].run->out_var == RP_OUT_STATE0 && !mem[q].run->hist[0]) merged = false;
         }
     }
+    // members on the packed path (rp_run.edge_sp): W and every edge matrix in packed form
+    bool packed[kMaxMembers];
+    for (int m = 0; m < count; ++m) {
+        const rp_run* run = mem[m].run;
+        packed[m] = mem[m].net->sp_vals && run->n_edges > 0 && run->edge_sum;
+        for (int e = 0; e < run->n_edges && packed[m]; ++e) packed[m] = run->edge_sp[e].vals != nullptr;
+        if (packed[m]) {
+            if (!aligned16(run->edge_sum)) RP_FAIL(RP_ERR_ARG, "member %d: edge_sum must be 16-byte aligned", m);
+            for (int e = 0; e < run->n_edges; ++e)
+                if (run->edge_n[e] % 4 != 0 || !run->edge_sp[e].cidx || !run->edge_sp[e].rowoff)
+                    RP_FAIL(RP_ERR_ARG, "member %d edge %d: a packed edge needs edge_n %% 4 == 0, cidx and rowoff", m, e);
+            merged = false;
+        }
+    }
     if (const char* off = getenv("RECTIPY_AMD_COUPLED_LAUNCHES"); off && off[0] == 'm') merged = false;  // "member": one launch per member
     if (merged) {
         const int64_t a0 = mem[0].run->step0;
@@ -1339,7 +1378,44 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
                         break;
                 }
             }
-            if (!merged) {
+            if (!merged && packed[m]) {
+                // one packed mat-vec per edge, chained into edge_sum (the last adds the member's input), then the member's own
+                // packed step with edge_sum as its full-width input
+                for (int e = 0; e < run->n_edges; ++e) {
+                    StepParams E = {};
+                    const rp_packed& S = run->edge_sp[e];
+                    E.n = run->edge_n[e];
+                    E.rows = net->rows;
+                    E.src_cur = P[m].edge[e].src;
+                    E.sp_vals = S.vals;
+                    E.sp_cidx = S.cidx;
+                    E.sp_rowoff = S.rowoff;
+                    E.sp_row_ids = S.row_ids;
+                    E.sp_batch_class = S.batch_class;
+                    E.sp_phase_window = S.phase_window;
+                    E.sp_phases = S.phases;
+                    E.sp_batches = S.batches;
+                    E.sp_block_rows = S.block_rows;
+                    E.esum_out = run->edge_sum;
+                    E.esum_prev = e > 0 ? run->edge_sum : nullptr;
+                    E.esum_final = e == run->n_edges - 1;
+                    E.x_mode = P[m].x_mode;
+                    E.x_t = P[m].x_t;
+                    E.m = P[m].m;
+                    E.w_in = P[m].w_in;
+                    E.ldwin = P[m].ldwin;
+                    const int rc = launch_step_sparse_model(kModelEdgeSum, E, st);
+                    if (rc != RP_OK) RP_FAIL(rc, "packed edge launch failed (device properties / LDS attribute)");
+                }
+                StepParams Q = P[m];
+                Q.n_edges = 0;
+                Q.x_mode = RP_X_FULL;
+                Q.x_t = run->edge_sum;
+                const int rc = launch_population_step(net, Q, st, cfg[m], vec4[m]);
+                if (rc != RP_OK) return rc;
+                if (t == 0) RP_HIP_CHECK(hipGetLastError());
+                net->cur ^= 1;
+            } else if (!merged) {
                 const int rc = launch_population_step(net, P[m], st, cfg[m], vec4[m]);
                 if (rc != RP_OK) return rc;
                 if (t == 0) RP_HIP_CHECK(hipGetLastError());

@@ -551,7 +551,19 @@ class Population:
             if len(edges) > _abi.RP_MAX_EDGES:
                 raise RuntimeError(f"at most {_abi.RP_MAX_EDGES} dense edges per population, got {len(edges)}")
             run.n_edges = len(edges)
-            for e, (We, se) in enumerate(edges):
+            for e, edge in enumerate(edges):
+                We, se = edge[0], edge[1]
+                pk = edge[2] if len(edge) > 2 else None   # the edge matrix in packed form (sparse.PackedRows), coupled calls only
+                if pk is not None:
+                    sp = run.edge_sp[e]
+                    sp.vals, sp.cidx, sp.rowoff, sp.block_rows = pk.vals.data_ptr(), pk.code.data_ptr(), pk.rowoff.data_ptr(), pk.block_rows
+                    if pk.row_ids is not None:
+                        sp.row_ids, sp.batch_class = pk.row_ids.data_ptr(), pk.batch_class.data_ptr()
+                        sp.phase_window, sp.phases, sp.batches = pk.phase_window.data_ptr(), pk.phases, pk.batches
+                    keep.append(pk)
+                    if getattr(self, "_edge_sum", None) is None:
+                        self._edge_sum = torch.zeros(self.rows, dtype=torch.float32, device=self.device)
+                    run.edge_sum = self._edge_sum.data_ptr()
                 if We.dtype != torch.float32 or We.device != self.device or We.dim() != 2 or We.shape[0] != self.rows \
                         or We.stride(1) != 1:
                     raise RuntimeError(f"edge {e}: weights must be a float32 [{self.rows}, n_e] row-major tensor on {self.device}")
@@ -701,7 +713,9 @@ def forward_coupled(members: list) -> list:
     Euler step steps the populations in list order, one launch each, the edge products inside the step kernels.
 
     ``members``: dicts with ``pop`` (:class:`Population`), ``run`` (keyword arguments of :meth:`Population.forward`
-    without ``edges`` / ``comm``) and ``edges``: ``[(W_e [rows, n_source], source member index, RP_EDGE_* mode)]``.
+    without ``edges`` / ``comm``) and ``edges``: ``[(W_e [rows, n_source], source member index, RP_EDGE_* mode)]``, optionally
+    with the edge matrix's packed form (``sparse.PackedRows``) as a fourth entry: a member whose W is packed and whose edges
+    all carry one streams only the stored nonzeros (rp_run.edge_sp; same bits).
     Returns the next sample index of every member."""
     count = len(members)
     arr = (_abi.RpMember * count)()
@@ -709,10 +723,10 @@ def forward_coupled(members: list) -> list:
     for m, spec in enumerate(members):
         pop: Population = spec["pop"]
         edges = spec.get("edges") or []
-        run, keep, sampling = pop._make_run(edges=[(We, None) for We, _, _ in edges], **spec["run"])
+        run, keep, sampling = pop._make_run(edges=[(edge[0], None, edge[3] if len(edge) > 3 else None) for edge in edges], **spec["run"])
         net = pop._net()
-        for e, (_, source, mode) in enumerate(edges):
-            arr[m].edge_source[e], arr[m].edge_mode[e] = int(source), int(mode)
+        for e, edge in enumerate(edges):
+            arr[m].edge_source[e], arr[m].edge_mode[e] = int(edge[1]), int(edge[2])
         arr[m].net, arr[m].run = C.pointer(net), C.pointer(run)
         built.append((pop, net, run, sampling, keep))
     first = members[0]["pop"]
@@ -736,7 +750,8 @@ def backward_coupled(members: list) -> list:
     work_floats = [0] * count
     for m, spec in enumerate(members):
         pop: Population = spec["pop"]
-        for We, source, _ in spec.get("edges") or []:
+        for edge in spec.get("edges") or []:
+            We, source = edge[0], edge[1]
             src: Population = members[source]["pop"]
             if We.dim() != 2 or We.shape != (pop.rows, src.n) or We.stride(1) != 1 or We.dtype != torch.float32 \
                     or We.device != pop.device:
@@ -752,7 +767,8 @@ def backward_coupled(members: list) -> list:
         edges = spec.get("edges") or []
         arr[m].net, arr[m].bwd = C.addressof(net), C.addressof(b)
         arr[m].n_edges = len(edges)
-        for e, (We, source, mode) in enumerate(edges):
+        for e, edge in enumerate(edges):
+            We, source, mode = edge[0], edge[1], edge[2]
             arr[m].edge_w[e], arr[m].edge_ld[e] = We.data_ptr(), We.stride(0)
             arr[m].edge_source[e], arr[m].edge_mode[e] = int(source), int(mode)
         arr[m].edge_work = work.data_ptr()
@@ -762,7 +778,7 @@ def backward_coupled(members: list) -> list:
             if final_src.dtype != torch.float32 or final_src.device != pop.device or final_src.numel() != pop.n or not final_src.is_contiguous():
                 raise RuntimeError(f"member {m}: final_src must be a contiguous float32 [{pop.n}] tensor on {pop.device}")
             arr[m].final_src = final_src.data_ptr()
-        keep_all.append((net, b, keep, z, work, final_src, [We for We, _, _ in edges]))
+        keep_all.append((net, b, keep, z, work, final_src, [edge[0] for edge in edges]))
     first.backend.backward_coupled(arr, count, first.device)
     return keep_all
 

@@ -537,6 +537,7 @@ class FeedbackNetwork(Network):
         # with it on the RP_EDGE_LIVE sources too the library may step all members in ONE launch (rp_forward_coupled)
         hist_read = lag_read | {s_ for p in pops for s_, mode in plan["edges"][p]
                                 if self.get_node(s_)._out_code == _abi.RP_OUT_STATE0}
+        packed_edges = self._packed_edges(plan)
         trajs = {}
         for p in pops:
             node: RateNet = self.get_node(p)
@@ -573,7 +574,7 @@ class FeedbackNetwork(Network):
                 if last and isinstance(node, SpikeResetNet) and not (stored and p in stored):
                     saves[p] = node._state_bufs()
                     kw.update(save_v=saves[p][0], save_src=saves[p][1], save_aux=saves[p][2], save_aux2=saves[p][3])
-                members.append(dict(pop=pop, run=kw, edges=[(self.get_edge(s_, p).weights, index[s_], mode)
+                members.append(dict(pop=pop, run=kw, edges=[(self.get_edge(s_, p).weights, index[s_], mode, packed_edges.get((s_, p)))
                                                             for s_, mode in plan["edges"][p]]))
             idx = forward_coupled(members)
             for p, i in zip(pops, idx):
@@ -592,6 +593,50 @@ class FeedbackNetwork(Network):
         else:
             call(0, steps, spiking)
         return trajs
+
+    PACKED_EDGE_MAX_DENSITY = 0.5   # (the rule of a population's own matrix, nodes.py: _maybe_pack_weights)
+
+    def _packed_edges(self, plan: dict) -> dict:
+        """(source, target) -> packed form of the edge matrix, for every member whose own W is streamed packed and whose
+        edges are ALL fixed and sparse enough: such a member streams only stored nonzeros (rp_run.edge_sp; the bits of the
+        dense products).  Packed once per edge and weight version."""
+        from . import sparse
+        out = {}
+        for p in plan["pops"]:
+            pop = self.get_node(p)._pop
+            if pop.packed is None or not plan["edges"][p]:
+                continue
+            pop._sync_packed()
+            if pop.packed is None:
+                continue
+            found = {}
+            for s_, _ in plan["edges"][p]:
+                edge = self.get_edge(s_, p)
+                W = edge.weights
+                if W.requires_grad or W.shape[1] % 4 or not W.is_contiguous() or W.device != pop.device:
+                    break
+                cache = getattr(edge, "_packed_cache", None)
+                if cache is None or cache[0] != (W._version, W.data_ptr()):
+                    if sparse.density(W) > self.PACKED_EDGE_MAX_DENSITY:
+                        cache = ((W._version, W.data_ptr()), None)
+                    else:
+                        n_src = W.shape[1]
+                        if n_src > sparse.WINDOW_COLUMNS:
+                            pk = sparse.pack_rows_windowed(W.detach())
+                        elif pop._block_rows() > 0:
+                            pk = sparse.pack_rows_blocked(W.detach(), block_rows=pop._block_rows())
+                        else:
+                            pk = sparse.pack_rows(W.detach())
+                        if pk.stored_bytes > 0.7 * 4.0 * W.shape[0] * W.shape[1]:   # (the rule of a population's own matrix)
+                            pk = None
+                        cache = ((W._version, W.data_ptr()), pk)
+                    edge._packed_cache = cache
+                if cache[1] is None:
+                    break
+                found[(s_, p)] = cache[1]
+            else:
+                out.update(found)
+        return out
 
     ARENA_MIN_BYTES = 256 << 20
 

@@ -970,3 +970,103 @@ def test_g38_cycle_fit_at_kernel_sizes_matches_the_reference(target, monkeypatch
         assert np.abs(got[:, rows[clab]] - ref_cols).max() <= 2e-5 * scale, key
         fp = recipes.fingerprint(got)
         assert abs(fp[1] - fp_ref[1]) <= 1e-5 * fp_ref[1], key   # sum of squares of all entries
+
+
+# ---- packed sparse matrices inside coupled populations (rp_run.edge_sp) -----------------------------------------------------
+def sparse_circuit(sizes, models, seed, dev, backend, density=0.1, dt=1e-2):
+    """`circuit` with every matrix thinned to `density` (zeros elsewhere), as utility.random_connectivity leaves them."""
+    gen = torch.Generator().manual_seed(seed)
+    pops, edges = [], {}
+    for n, model in zip(sizes, models):
+        mask = (torch.rand(n, n, generator=gen) < density).float()
+        if model == "qif":
+            W = torch.rand(n, n, generator=gen) * 8.0 / (n * density) * mask
+            params = dict(tau=1.0, k=1.0, eta=torch.randn(n, generator=gen) + 2.0, tau_s=torch.rand(n, generator=gen) + 0.5)
+            pops.append(Population("qif", W, params, dt, dev, v0=torch.randn(n, generator=gen), s0=torch.rand(n, generator=gen) * 0.1,
+                                   theta=5.0, v_reset=-5.0, backend=backend))
+        else:
+            W = torch.randn(n, n, generator=gen) * 1.2 / (n * density) ** 0.5 * mask
+            params = dict(tau=torch.rand(n, generator=gen) * 2 + 0.5, k=torch.rand(n, generator=gen) + 0.5,
+                          eta=torch.randn(n, generator=gen) * 0.1)
+            pops.append(Population("li_tanh", W, params, dt, dev, v0=torch.randn(n, generator=gen) * 0.5, backend=backend))
+    for t_, nt in enumerate(sizes):
+        for s_, ns in enumerate(sizes):
+            if s_ != t_:
+                mask = (torch.rand(nt, ns, generator=gen) < density).float()
+                edges[(s_, t_)] = (torch.randn(nt, ns, generator=gen) * 0.7 / (ns * density) ** 0.5 * mask).to(dev)
+    return pops, edges
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sizes,models,out_vars", [((1024, 2052), ("li_tanh", "li_tanh"), (0, 1)), ((520, 260, 1028), ("li_tanh", "qif", "li_tanh"), (1, 1, 0)),
+                                                   ((4096, 4100), ("qif", "li_tanh"), (1, 0))])
+def test_hip_packed_edges_in_coupled_members_bit_exact(oracle_backend, hip_device, sizes, models, out_vars):
+    """Members whose W and edge matrices are all in packed sparse form (rp_run.edge_sp): one packed mat-vec launch per edge,
+    then the member's packed step -- against the C oracle's DENSE arithmetic on the same (mostly zero) matrices, bit for
+    bit: trajectories, samples, final states; per-row and blocked packed forms, ragged chunks, three edges per member."""
+    from rectipy_amd import sparse
+    T = 23
+    x = torch.randn(T, sizes[0], generator=torch.Generator().manual_seed(3)) * 0.5 + (1.0 if models[0] == "qif" else 0.0)
+    res = []
+    for dev, backend in (("cpu", oracle_backend), (hip_device, None)):
+        pops, edges = sparse_circuit(sizes, models, 11, dev, backend)
+        packed = {}
+        if dev != "cpu":
+            for p in pops:
+                p.pack_weights()
+                assert p.packed is not None
+            for (s_, t_), We in edges.items():
+                rb = pops[t_]._block_rows()
+                packed[(s_, t_)] = sparse.pack_rows_blocked(We, block_rows=rb) if rb > 0 else sparse.pack_rows(We)
+        n_m = len(pops)
+        trajs = [torch.zeros(T, p.rows, device=dev) for p in pops]
+        hist = [[torch.zeros(p.rows, device=dev) for _ in range(3)] for p in pops]
+        for m, p in enumerate(pops):
+            hist[m][2].copy_(p.v if out_vars[m] == _abi.RP_OUT_STATE0 else p.source)
+        for a, b in ((0, 9), (9, T)):
+            members = []
+            for m, p in enumerate(pops):
+                run = dict(steps=b - a, step0=a, out_var=out_vars[m], traj=trajs[m][a:b], hist=hist[m])
+                if m == 0:
+                    run["x"] = x[a:b].to(dev)
+                members.append(dict(pop=p, run=run, edges=[(edges[(s_, m)], s_, modes_for(models, s_, m), packed.get((s_, m)))
+                                                           for s_ in range(n_m) if s_ != m]))
+            forward_coupled(members)
+        if dev != "cpu":  # (the packed path leaves the node input of the last step in the members' edge_sum workspace)
+            assert all(float(p._edge_sum.abs().sum()) > 0 for p in pops)
+        res.append([(trajs[m], pops[m].v, pops[m].source) for m in range(n_m)])
+    for m in range(len(sizes)):
+        for a, b, what in zip(res[0][m], res[1][m], ("trajectory", "v", "source")):
+            assert_same(a, b, f"member {m} {what}")
+
+
+@pytest.mark.gpu
+def test_sparse_feedback_network_streams_packed_matrices(oracle_backend, hip_device):
+    """FeedbackNetwork whose coupling matrices -- inside and between the populations -- are fixed and mostly zeros: the
+    populations' W are packed as for a single population, the edges between them too (`_packed_edges`), and `run` gives the
+    bits of the dense run (here: of the oracle's dense arithmetic), recordings and states included."""
+    r = np.random.default_rng(5)
+    na, nb, T = 1024, 2052, 37
+
+    def mat(rows, cols, gain):
+        return (r.standard_normal((rows, cols)) * gain / np.sqrt(cols * 0.1) * (r.uniform(size=(rows, cols)) < 0.1)).astype(np.float32)
+
+    Wa, Wb, Wab, Wba = mat(na, na, 1.0), mat(nb, nb, 1.0), mat(nb, na, 0.6), mat(na, nb, 0.6)
+    x = (r.standard_normal((T, na)) * 0.5).astype(np.float32)
+    res = []
+    for target in (dict(device="cpu", backend=oracle_backend), dict(device=hip_device)):
+        net = FeedbackNetwork(1e-2, **target)
+        for lab, W in (("a", Wa), ("b", Wb)):
+            net.add_diffeq_node(lab, TANH, weights=W, source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                                output_var="li_op/v", dtype=torch.float32, sparse_weights=True)
+        net.add_edge("a", "b", weights=Wab)
+        net.add_edge("b", "a", weights=Wba, feedback=True)
+        obs = net.run(x, sampling_steps=2, cutoff=3, verbose=False, enable_grad=False, record_vars=[("a", "li_op/v", False)])
+        if target["device"] != "cpu":
+            assert all(net.get_node(n)._pop.packed is not None for n in "ab")
+            assert all(getattr(net.get_edge(s_, t_), "_packed_cache", (None, None))[1] is not None for s_, t_ in (("a", "b"), ("b", "a")))
+            assert all(float(net.get_node(n)._pop._edge_sum.abs().sum()) > 0 for n in "ab")
+        res.append((obs.to_numpy("out"), obs.to_numpy(("a", "li_op/v")), {k_: v_.cpu().numpy() for k_, v_ in net.state.items()}))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for k_ in res[0][2]:
+        assert np.array_equal(res[0][2][k_], res[1][2][k_]), k_
