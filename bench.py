@@ -626,7 +626,47 @@ def sparse_extra(dev, N=32768, p=0.1, T=1000):
            "state_finite": bool(torch.isfinite(pop.v).all().item())}
     del pop, packed
     torch.cuda.empty_cache()
+    res["coupled_pair"] = sparse_coupled_extra(dev, N // 2, p)
     return res
+
+
+def sparse_coupled_extra(dev, h, p, T=300):
+    """Two populations of N/2 neurons coupled by dense-stored edges, one a feedback edge, EVERY matrix -- inside and between
+    the populations -- fixed with connection probability p, through FeedbackNetwork.run: the edge matrices are packed like
+    the populations' own (rp_run.edge_sp: one packed mat-vec launch per edge, then the member's packed step; the bits of the
+    dense run), next to the same network streamed densely (sparse_weights=False)."""
+    import contextlib
+    from rectipy_amd import FeedbackNetwork
+    tanh = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
+    gen = torch.Generator(device=dev).manual_seed(1)
+
+    def mat(g):
+        W = torch.randn(h, h, device=dev, generator=gen) * (g / (h * p) ** 0.5)
+        return W * (torch.rand(h, h, device=dev, generator=gen) < p)
+
+    mats = [mat(1.0), mat(1.0), mat(0.5), mat(0.5)]
+    x = torch.randn(T, h, device=dev, generator=gen) * 0.1
+    out = {"workload": f"two tanh populations of {h}, W and both edges (one feedback) fixed with p={p}, FeedbackNetwork.run",
+           "unit": "us per Euler step (wall clock)"}
+    with contextlib.redirect_stdout(sys.stderr):
+        for mode in ("auto", False):
+            fb = FeedbackNetwork(dt=1e-2, device=str(dev))
+            kw = lambda W: dict(input_var="li_op/I_ext", output_var="li_op/v", weights=W, source_var="tanh_op/r",
+                                target_var="li_op/r_in", dtype=torch.float32, sparse_weights=mode)
+            fb.add_diffeq_node("a", tanh, **kw(mats[0].clone()))
+            fb.add_diffeq_node("b", tanh, **kw(mats[1].clone()))
+            fb.add_edge("a", "b", weights=mats[2].clone())
+            fb.add_edge("b", "a", weights=mats[3].clone(), feedback=True)
+            fb.run(x[:20], sampling_steps=20, verbose=False, enable_grad=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fb.run(x, sampling_steps=T, verbose=False, enable_grad=False)
+            torch.cuda.synchronize()
+            out["packed" if mode == "auto" else "dense"] = round((time.perf_counter() - t0) / T * 1e6, 1)
+            del fb
+            torch.cuda.empty_cache()
+    out["speedup"] = round(out["dense"] / out["packed"], 2)
+    return out
 
 
 def cpu_baseline(pop, x, dt, N):
