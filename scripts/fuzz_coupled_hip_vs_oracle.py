@@ -2,7 +2,8 @@
 RANDOM shapes -- 2..4 populations (tanh / sigmoid / QIF / LIF / QIF_SFA / IK, sizes from 5 to ~1100: 4-byte and 16-byte paths, ragged
 chunks, different widths), random feed-forward chains with random feedback edges (the three edge read modes of
 rp_forward_coupled arise from their direction and the source's kind), optional input / read-out layers, recorded
-variables, sampling, cutoff, two consecutive runs; the same graphs with every parameter trained (fit_bptt, two SGD windows:
+variables, sampling, cutoff, two consecutive runs, in a third of the cases with every matrix thinned to a random density and
+streamed packed (populations and edges: rp_run.edge_sp); the same graphs with every parameter trained (fit_bptt, two SGD windows:
 the fused adjoint rp_backward_coupled on the GPU and on the oracle against autograd over the per-step walk, to 1e-4, 5e-3
 with spiking populations); run_batch with random B, sampling and input edge.  Populations'
 outputs are compared BIT FOR BIT where no device-side torch product lies in front of them (no input layer), else to 2e-5
@@ -41,7 +42,7 @@ TRAIN = {"tanh": ["tau", "k", "eta"], "sigmoid": ["tau", "k", "eta"], "qif": ["t
          "ik": ["C", "k", "eta", "tau_s", "g", "b", "tau_u", "kappa", "v_r", "v_theta", "E_r"]}
 
 
-def add_population(net, label, kind, n, rng, train=False):
+def add_population(net, label, kind, n, rng, train=False, density=None):
     K = KINDS[kind]
     op = K["op"]
     if K.get("spike"):
@@ -59,6 +60,10 @@ def add_population(net, label, kind, n, rng, train=False):
         node_vars = {"all/li_op/tau": rng.uniform(0.5, 2.0, n), "all/li_op/k": rng.uniform(0.5, 1.5, n),
                      "all/li_op/eta": rng.standard_normal(n) * 0.1, "all/li_op/v": rng.standard_normal(n) * 0.5}
         kw = {}
+    if density is not None:  # a fixed sparse matrix: streamed packed where the 16-byte path exists (forced at any size)
+        W = W * (rng.uniform(size=W.shape) < density) / density ** 0.5
+        if n % 4 == 0:
+            kw["sparse_weights"] = True
     out_var = K["outs"][int(rng.integers(0, len(K["outs"])))]
     if train:
         kw["train_params"] = ["weights"] + [f"{op}/{q}" for q in TRAIN[kind]]
@@ -67,7 +72,7 @@ def add_population(net, label, kind, n, rng, train=False):
     return f"{op}/v"
 
 
-def build_feedback(where, seed, kinds, sizes, m, k, fb_pairs, train=False):
+def build_feedback(where, seed, kinds, sizes, m, k, fb_pairs, train=False, density=None):
     rng = np.random.default_rng(seed)
     net = FeedbackNetwork(5e-3, **where)
     if m:
@@ -75,16 +80,17 @@ def build_feedback(where, seed, kinds, sizes, m, k, fb_pairs, train=False):
     labels = "abcd"[:len(sizes)]
     rec_var = None
     for lab, kind, n in zip(labels, kinds, sizes):
-        v = add_population(net, lab, kind, n, rng, train)
+        v = add_population(net, lab, kind, n, rng, train, density)
         rec_var = rec_var or (lab, v)
     if k:
         net.add_func_node("out", k, ["identity", "tanh"][int(rng.integers(0, 2))])
     order = (["inp"] if m else []) + list(labels) + (["out"] if k else [])
     width = dict(zip(labels, sizes), inp=m, out=k)
+    thin = lambda W: W if density is None else W * (rng.uniform(size=W.shape) < density) / density ** 0.5
     for s_, t_ in zip(order[:-1], order[1:]):
-        net.add_edge(s_, t_, weights=rng.standard_normal((width[t_], width[s_])) * 0.7 / np.sqrt(width[s_]), train="gd" if train else None)
+        net.add_edge(s_, t_, weights=thin(rng.standard_normal((width[t_], width[s_])) * 0.7 / np.sqrt(width[s_])), train="gd" if train else None)
     for s_, t_ in fb_pairs:
-        net.add_edge(labels[s_], labels[t_], weights=rng.standard_normal((sizes[t_], sizes[s_])) * 0.5 / np.sqrt(sizes[s_]), feedback=True,
+        net.add_edge(labels[s_], labels[t_], weights=thin(rng.standard_normal((sizes[t_], sizes[s_])) * 0.5 / np.sqrt(sizes[s_])), feedback=True,
                      train="gd" if train else None)
     return net, rec_var
 
@@ -156,12 +162,15 @@ def main(cases=40, seed=0, max_n=1100):
                     pairs = {(npop - 1, 0)}
                 T = int(rng.integers(20, 70))
                 samp, cutoff = int(rng.integers(1, 5)), int(rng.integers(0, 6))
-                cfg = dict(kind="feedback", kinds=kinds, sizes=sizes, m=m, k=k, fb=sorted(pairs), T=T, samp=samp, cutoff=cutoff)
+                density = float(rng.uniform(0.05, 0.3)) if rng.integers(0, 3) == 0 else None
+                if density is not None:
+                    sizes = [max(8, n - n % 4) if rng.integers(0, 4) else n for n in sizes]   # (mostly on the 16-byte path: packed)
+                cfg = dict(kind="feedback", kinds=kinds, sizes=sizes, m=m, k=k, fb=sorted(pairs), T=T, samp=samp, cutoff=cutoff, density=density)
                 x = (rng.standard_normal((T, m if m else sizes[0])) * 0.5 + (1.5 if KINDS[kinds[0]].get("spike") else 0.0)).astype(np.float32)
                 res = []
                 for where in wheres:
                     with contextlib.redirect_stdout(io.StringIO()):
-                        net, rec_var = build_feedback(where, 1000 * seed + case, kinds, sizes, m, k, sorted(pairs))
+                        net, rec_var = build_feedback(where, 1000 * seed + case, kinds, sizes, m, k, sorted(pairs), density=density)
                         net.compile()
                         planned = net._coupled_plan([]) is not None
                         o1 = net.run(x[:T // 2], sampling_steps=samp, cutoff=cutoff, verbose=False, enable_grad=False,
