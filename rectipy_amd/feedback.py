@@ -434,11 +434,35 @@ class FeedbackNetwork(Network):
                 return None
         return plan
 
-    def _coupled_grad_outputs(self, plan: dict, inputs_ab: torch.Tensor, a: int) -> torch.Tensor:
+    def _coupled_grad_outputs(self, plan: dict, inputs_ab: torch.Tensor, a: int, fit: bool = False) -> torch.Tensor:
         """The output node's per-step outputs over the window [a, a + len), with the graph of ONE autograd node for all
-        populations (`_CoupledWindow`) between the torch ops of the input layers and the read-outs."""
+        populations (`_CoupledWindow`) between the torch ops of the input layers and the read-outs.  ``fit`` (fit_bptt): when
+        nothing trainable lies in or upstream of the populations -- a read-out-only fit -- the populations integrate without
+        a graph (the only other thing a gradient could reach is the state leaf of the window, which no caller of fit_bptt
+        sees): same parameter updates at the forward's speed, packed sparse matrices included."""
         pops = plan["pops"]
         self._consolidate(plan)
+        if fit and not inputs_ab.requires_grad:
+            upstream = list(plan["pre"]) + list(pops)
+            trainable = any(q.requires_grad for n in upstream for q in self.get_node(n).parameters()) or \
+                any(q.requires_grad for s_, t_ in self.graph.edges if t_ in upstream for q in self.get_edge(s_, t_).parameters())
+            carried = any(getattr(self.get_node(p), "_y_grad", None) is not None and self.get_node(p)._y_grad.grad_fn is not None
+                          for p in pops)
+            if not trainable and not carried:
+                feeders = {p for p in pops if p == self._out_node or any(t_ in plan["post"] for t_ in self.graph.successors(p))}
+                with torch.no_grad():
+                    outs = dict(self._coupled_window(plan, inputs_ab, a, feeders, {}, None, 0, 1))
+                for n in plan["post"]:
+                    X = None
+                    for p_ in self.graph.predecessors(n):
+                        if p_ in outs:
+                            contrib = self._edge_window(self.get_edge(p_, n), outs[p_])
+                            X = contrib if X is None else X + contrib
+                    outs[n] = self.get_node(n).forward(X)
+                for n in self._order:
+                    self[n]["out"] = None
+                self._prev_out = {}
+                return outs[self._out_node]
         xin = self._coupled_inputs(plan, inputs_ab)
         flat = []
         for p in pops:

@@ -886,7 +886,7 @@ class Network:
                 if windows:
                     preds = self._window_outputs(inp[a:b], a, True, {}, 0, 1)[self._out_node]
                 elif coupled is not None:
-                    preds = self._coupled_grad_outputs(coupled, inp[a:b], a)
+                    preds = self._coupled_grad_outputs(coupled, inp[a:b], a, fit=True)
                 else:
                     X = self._apply_chain(pre, inp[a:b], None, label) if pre else inp[a:b]
                     # the adjoint sweep runs only if a gradient has to pass INTO the population: its own trainable

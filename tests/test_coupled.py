@@ -1070,3 +1070,30 @@ def test_sparse_feedback_network_streams_packed_matrices(oracle_backend, hip_dev
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     for k_ in res[0][2]:
         assert np.array_equal(res[0][2][k_], res[1][2][k_]), k_
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+def test_readout_only_fit_behind_coupled_populations_skips_the_adjoint(target, monkeypatch):
+    """fit_bptt with only the read-out trained: no gradient has to pass into the populations, so they integrate without a
+    graph (no rp_backward_coupled call, the windows of `run`); the read-out after three windows equals the one autograd over
+    the per-step walk leaves."""
+    bwd, fwd = [], []
+    real_b, real_f = engine.backward_coupled, engine.forward_coupled
+    monkeypatch.setattr(engine, "backward_coupled", lambda members: bwd.append(len(members)) or real_b(members))
+    monkeypatch.setattr(engine, "forward_coupled", lambda members: fwd.append(len(members)) or real_f(members))
+    r = np.random.default_rng(7)
+    x, y = r.standard_normal((60, 3)).astype(np.float32), r.standard_normal((60, 2)).astype(np.float32) * 0.3
+    res = []
+    for stepwise in (True, False):
+        bwd.clear(), fwd.clear()
+        net = build_net(target, False, sizes=(16, 24), k=0)
+        net.add_func_node("out", 2, "identity")
+        edge = net.add_edge("b", "out", weights=r.standard_normal((2, 24)) * 0.3 if stepwise else res[0][2], train="gd")
+        start = edge.weights.detach().cpu().numpy().copy()
+        net._force_stepwise_adjoint = stepwise
+        net._force_stepwise = stepwise
+        obs = net.fit_bptt(x, y, optimizer="sgd", lr=0.05, update_steps=20, sampling_steps=1, verbose=False)
+        assert bwd == [] and fwd == ([] if stepwise else [2] * 3)
+        res.append((edge.weights.detach().cpu().numpy().copy(), obs.to_numpy("out"), start))
+    assert np.abs(res[0][0] - res[1][0]).max() < 2e-5 and np.abs(res[0][1] - res[1][1]).max() < 2e-5
+    assert np.abs(res[0][0] - res[0][2]).max() > 1e-3   # (the read-out did move)
