@@ -252,11 +252,11 @@ typedef struct rp_run {
        input (rp_bwd.x, RP_X_FULL): rp_backward_coupled. */
     float* save_in;
     /* rp_forward_coupled only: packed forms of the edge matrices (rows = this population's rows, row0 = 0, n = edge_n) and a
-       workspace [rows].  A member whose W is packed (rp_net.sp_vals) AND whose edges all have a packed form is stepped as
-       n_edges packed mat-vec launches -- E = (E_0 + E_1) + ..., then I = x + E into edge_sum -- followed by its own packed
-       step reading I as a full-width input: the dense arithmetic bit for bit (the packed layout reproduces the dense row
-       dot), at the bytes of the stored nonzeros.  Otherwise (any edge without a packed form, or no edge_sum) the dense
-       matrices are streamed as described above. */
+       workspace [rows].  A member whose edges ALL have a packed form is stepped as n_edges packed mat-vec launches --
+       E = (E_0 + E_1) + ..., then I = x + E into edge_sum -- followed by its own step (packed when rp_net.sp_vals is set,
+       else the dense one) reading I as a full-width input: the dense arithmetic bit for bit (the packed layout reproduces
+       the dense row dot), at the bytes of the stored nonzeros.  Otherwise (any edge without a packed form, or no edge_sum)
+       the dense edge matrices are streamed as described above. */
     rp_packed edge_sp[RP_MAX_EDGES];
     float* edge_sum;
 } rp_run;

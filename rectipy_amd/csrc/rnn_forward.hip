@@ -1324,11 +1324,11 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
             if (mode != RP_EDGE_LAG && mem[q].run->out_var == RP_OUT_STATE0 && !mem[q].run->hist[0]) merged = false;
         }
     }
-    // members on the packed path (rp_run.edge_sp): W and every edge matrix in packed form
+    // members on the packed path (rp_run.edge_sp): every edge matrix in packed form (W itself packed or dense)
     bool packed[kMaxMembers];
     for (int m = 0; m < count; ++m) {
         const rp_run* run = mem[m].run;
-        packed[m] = mem[m].net->sp_vals && run->n_edges > 0 && run->edge_sum;
+        packed[m] = run->n_edges > 0 && run->edge_sum;
         for (int e = 0; e < run->n_edges && packed[m]; ++e) packed[m] = run->edge_sp[e].vals != nullptr;
         if (packed[m]) {
             if (!aligned16(run->edge_sum)) RP_FAIL(RP_ERR_ARG, "member %d: edge_sum must be 16-byte aligned", m);
@@ -1380,7 +1380,7 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
             }
             if (!merged && packed[m]) {
                 // one packed mat-vec per edge, chained into edge_sum (the last adds the member's input), then the member's own
-                // packed step with edge_sum as its full-width input
+                // step -- packed or dense, as its W is stored -- with edge_sum as its full-width input
                 for (int e = 0; e < run->n_edges; ++e) {
                     StepParams E = {};
                     const rp_packed& S = run->edge_sp[e];

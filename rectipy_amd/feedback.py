@@ -618,20 +618,25 @@ class FeedbackNetwork(Network):
             call(0, steps, spiking)
         return trajs
 
-    PACKED_EDGE_MAX_DENSITY = 0.5   # (the rule of a population's own matrix, nodes.py: _maybe_pack_weights)
+    PACKED_EDGE_MAX_DENSITY = 0.5   # (the rules of a population's own matrix, nodes.py: _maybe_pack_weights)
+    PACKED_EDGE_MIN_ROWS = 4096
 
     def _packed_edges(self, plan: dict) -> dict:
-        """(source, target) -> packed form of the edge matrix, for every member whose own W is streamed packed and whose
-        edges are ALL fixed and sparse enough: such a member streams only stored nonzeros (rp_run.edge_sp; the bits of the
-        dense products).  Packed once per edge and weight version."""
+        """(source, target) -> packed form of the edge matrix, for every member whose edges are ALL fixed and sparse enough
+        (sparse long-range coupling between populations, whatever their own W): their stored nonzeros are streamed by packed
+        mat-vec launches instead of the dense matrices (rp_run.edge_sp; the bits of the dense products).  Packed once per edge
+        and weight version.  Launch-bound sizes keep the in-kernel dense edges (one launch per member, or one for all)."""
         from . import sparse
         out = {}
         for p in plan["pops"]:
-            pop = self.get_node(p)._pop
-            if pop.packed is None or not plan["edges"][p]:
+            node = self.get_node(p)
+            pop = node._pop
+            if not plan["edges"][p] or pop.device.type != "cuda":
                 continue
-            pop._sync_packed()
-            if pop.packed is None:
+            if pop.packed is not None:
+                pop._sync_packed()
+            forced = getattr(node, "_sparse_mode", "auto") is True
+            if getattr(node, "_sparse_mode", "auto") is False or (not forced and pop.rows < self.PACKED_EDGE_MIN_ROWS):
                 continue
             found = {}
             for s_, _ in plan["edges"][p]:

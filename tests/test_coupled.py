@@ -998,9 +998,10 @@ def sparse_circuit(sizes, models, seed, dev, backend, density=0.1, dt=1e-2):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pack_w", [True, False], ids=["packed-W", "dense-W"])
 @pytest.mark.parametrize("sizes,models,out_vars", [((1024, 2052), ("li_tanh", "li_tanh"), (0, 1)), ((520, 260, 1028), ("li_tanh", "qif", "li_tanh"), (1, 1, 0)),
                                                    ((4096, 4100), ("qif", "li_tanh"), (1, 0))])
-def test_hip_packed_edges_in_coupled_members_bit_exact(oracle_backend, hip_device, sizes, models, out_vars):
+def test_hip_packed_edges_in_coupled_members_bit_exact(oracle_backend, hip_device, sizes, models, out_vars, pack_w):
     """Members whose W and edge matrices are all in packed sparse form (rp_run.edge_sp): one packed mat-vec launch per edge,
     then the member's packed step -- against the C oracle's DENSE arithmetic on the same (mostly zero) matrices, bit for
     bit: trajectories, samples, final states; per-row and blocked packed forms, ragged chunks, three edges per member."""
@@ -1013,8 +1014,9 @@ def test_hip_packed_edges_in_coupled_members_bit_exact(oracle_backend, hip_devic
         packed = {}
         if dev != "cpu":
             for p in pops:
-                p.pack_weights()
-                assert p.packed is not None
+                if pack_w:   # (else: dense recurrent matrices, sparse coupling between the populations)
+                    p.pack_weights()
+                assert (p.packed is not None) == pack_w
             for (s_, t_), We in edges.items():
                 rb = pops[t_]._block_rows()
                 packed[(s_, t_)] = sparse.pack_rows_blocked(We, block_rows=rb) if rb > 0 else sparse.pack_rows(We)
@@ -1041,29 +1043,32 @@ def test_hip_packed_edges_in_coupled_members_bit_exact(oracle_backend, hip_devic
 
 
 @pytest.mark.gpu
-def test_sparse_feedback_network_streams_packed_matrices(oracle_backend, hip_device):
+@pytest.mark.parametrize("dense_w", [False, True], ids=["sparse-W", "dense-W"])
+def test_sparse_feedback_network_streams_packed_matrices(oracle_backend, hip_device, dense_w):
     """FeedbackNetwork whose coupling matrices -- inside and between the populations -- are fixed and mostly zeros: the
     populations' W are packed as for a single population, the edges between them too (`_packed_edges`), and `run` gives the
     bits of the dense run (here: of the oracle's dense arithmetic), recordings and states included."""
     r = np.random.default_rng(5)
-    na, nb, T = 1024, 2052, 37
+    na, nb, T = (4096, 4100, 21) if dense_w else (1024, 2052, 37)
 
-    def mat(rows, cols, gain):
-        return (r.standard_normal((rows, cols)) * gain / np.sqrt(cols * 0.1) * (r.uniform(size=(rows, cols)) < 0.1)).astype(np.float32)
+    def mat(rows, cols, gain, p=0.1):
+        return (r.standard_normal((rows, cols)) * gain / np.sqrt(cols * p) * (r.uniform(size=(rows, cols)) < p)).astype(np.float32)
 
-    Wa, Wb, Wab, Wba = mat(na, na, 1.0), mat(nb, nb, 1.0), mat(nb, na, 0.6), mat(na, nb, 0.6)
+    # dense_w: dense recurrent matrices, sparse coupling BETWEEN the populations, everything by the defaults ("auto")
+    Wa, Wb = (mat(na, na, 1.0, 1.0), mat(nb, nb, 1.0, 1.0)) if dense_w else (mat(na, na, 1.0), mat(nb, nb, 1.0))
+    Wab, Wba = mat(nb, na, 0.6), mat(na, nb, 0.6)
     x = (r.standard_normal((T, na)) * 0.5).astype(np.float32)
     res = []
     for target in (dict(device="cpu", backend=oracle_backend), dict(device=hip_device)):
         net = FeedbackNetwork(1e-2, **target)
         for lab, W in (("a", Wa), ("b", Wb)):
             net.add_diffeq_node(lab, TANH, weights=W, source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
-                                output_var="li_op/v", dtype=torch.float32, sparse_weights=True)
+                                output_var="li_op/v", dtype=torch.float32, sparse_weights="auto" if dense_w else True)
         net.add_edge("a", "b", weights=Wab)
         net.add_edge("b", "a", weights=Wba, feedback=True)
         obs = net.run(x, sampling_steps=2, cutoff=3, verbose=False, enable_grad=False, record_vars=[("a", "li_op/v", False)])
         if target["device"] != "cpu":
-            assert all(net.get_node(n)._pop.packed is not None for n in "ab")
+            assert all((net.get_node(n)._pop.packed is None) == dense_w for n in "ab")
             assert all(getattr(net.get_edge(s_, t_), "_packed_cache", (None, None))[1] is not None for s_, t_ in (("a", "b"), ("b", "a")))
             assert all(float(net.get_node(n)._pop._edge_sum.abs().sum()) > 0 for n in "ab")
         res.append((obs.to_numpy("out"), obs.to_numpy(("a", "li_op/v")), {k_: v_.cpu().numpy() for k_, v_ in net.state.items()}))
