@@ -486,19 +486,21 @@ __global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
 // column partials colpart[c][i] of the chunks c of block row b added in ascending order from the first one.  One
 // workgroup per 32 columns: thread (c, s) adds up the block rows b = s, s + 32, ... of column c (their sums are
 // independent), thread (c, 0) chains them and the row partials in the order above.
+template <int COLS>  // columns per workgroup: a wave reads COLS * 4 contiguous bytes of a row of column partials
 __global__ __launch_bounds__(1024) void rls_sym_zn_kernel(const RlsParams P0, int rows_per_chunk) {
-    extern __shared__ float colsum[];  // [nb][32]
+    extern __shared__ float colsum[];  // [nb][COLS]
+    constexpr int SLOTS = 1024 / COLS;
     RlsParams P = P0;  // blocked sweep: blockIdx.y = input j of the block (its slices of the partials, its row of Y)
     P.partials += (int64_t)blockIdx.y * P0.part_stride;
     P.colparts += (int64_t)blockIdx.y * P0.col_stride;
     P.zn += (int64_t)blockIdx.y * P0.n_in;
-    const int c = threadIdx.x & 31, slot = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + c;
+    const int c = threadIdx.x % COLS, slot = threadIdx.x / COLS;
+    const int i = blockIdx.x * COLS + c;
     const int nb = (P.n_in + 1023) >> 10;
-    const int I = (blockIdx.x * 32) >> 10;  // (32 divides 1024: one block row per workgroup)
+    const int I = (blockIdx.x * COLS) >> 10;  // (COLS divides 1024: one block row per workgroup)
     const int per_block = 1024 / rows_per_chunk;
     if (i < P.n_in) {
-        for (int b = slot; b < I; b += 32) {
+        for (int b = slot; b < I; b += SLOTS) {
             const float* col = P.colparts + (int64_t)b * per_block * P.ldc + i;
             float s = col[0];
             int q = 1;
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(1024) void rls_sym_zn_kernel(const RlsParams P0, in
                 for (int u = 0; u < 8; ++u) s = s + v[u];
             }
             for (; q < per_block; ++q) s = s + col[(int64_t)q * P.ldc];
-            colsum[b * 32 + c] = s;
+            colsum[b * COLS + c] = s;
         }
     }
     __syncthreads();
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(1024) void rls_sym_zn_kernel(const RlsParams P0, in
     float s = 0.f;
     bool first = true;
     for (int b = 0; b < I; ++b) {
-        const float v = colsum[b * 32 + c];
+        const float v = colsum[b * COLS + c];
         s = first ? v : s + v;
         first = false;
     }
@@ -838,7 +840,7 @@ void launch_sym_rows(const RlsParams& P, hipStream_t st) {
         hipLaunchKernelGGL((rls_sym_kernel<UPDATE, C, R, false>), grid, dim3(kThreads), lds, st, P);
     }
     if (P.x_next)
-        hipLaunchKernelGGL(rls_sym_zn_kernel, dim3((P.n_in + 31) / 32), dim3(1024), (size_t)nb * 32 * sizeof(float), st, P, C);
+        hipLaunchKernelGGL(rls_sym_zn_kernel<32>, dim3((P.n_in + 31) / 32), dim3(1024), (size_t)nb * 32 * sizeof(float), st, P, C);
 }
 
 template <bool UPDATE>
@@ -883,7 +885,7 @@ void launch_symk_r(const RlsParams& P, hipStream_t st) {
         hipLaunchKernelGGL((rls_symk_kernel<K, UPDATE, DOT, C, R, false>), grid, dim3(kThreads), lds, st, P);
     }
     if (DOT)
-        hipLaunchKernelGGL(rls_sym_zn_kernel, dim3((P.n_in + 31) / 32, P.nrhs), dim3(1024), (size_t)nb * 32 * sizeof(float), st, P, C);
+        hipLaunchKernelGGL(rls_sym_zn_kernel<64>, dim3((P.n_in + 63) / 64, P.nrhs), dim3(1024), (size_t)nb * 64 * sizeof(float), st, P, C);
 }
 
 template <int K, bool UPDATE, bool DOT, int C>
