@@ -56,6 +56,7 @@ struct RlsParams {
     double* cm;          // [K x K] c_ij = z_i . x_j
     float* kk;           // [K] k of the block's updates
     int j, K;            // the update of the block the small kernels work on
+    float* z0;           // where the z vector of the block's first update goes (= Y_0)
 };
 
 
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(1024) void rls_sym_zn_kernel(const RlsParams P0, in
         first = false;
     }
     P.zn[i] = P.beta_inv * s;
+    if (P0.z0 && blockIdx.y == 0) P0.z0[i] = P.beta_inv * s;  // blocked sweep: z_0 = Y_0
 }
 
 // P[j][i] = P[i][j] for one 64 x 64 tile of an off-diagonal block (I < J), through LDS: 256-byte row pieces on both
@@ -709,16 +711,27 @@ __global__ __launch_bounds__(kThreads) void rls_symk_kernel(const RlsParams P) {
     }
 }
 
-// z_j = Y_j - sum_{i<j} g_ij z_i in double: acc = Y_j[q]; acc = fma(-g_ij, z_i[q], acc), i ascending; g_ij = beta^-1 (k_i c_ij)
-__global__ __launch_bounds__(256) void rls_blk_z_kernel(const RlsParams P) {
+// W[o][q] += (k err[o]) z_j[q] as rls_weights_kernel, and -- `next` -- the z vector of the block's NEXT update, whose
+// coefficients are complete now (k_j from this update's scalar kernel, c_{i, j+1} from the updates before):
+// z_{j+1}[q] = (float)(Y_{j+1}[q] - sum_{i<=j} g_i z_i[q]) in double: acc = Y[q]; acc = fma(-g_i, z_i[q], acc), i ascending;
+// g_i = beta^-1 (k_i c_{i, j+1})
+__global__ __launch_bounds__(256) void rls_blk_weights_kernel(const RlsParams P, int next) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= P.n_in) return;
-    double acc = (double)P.yb[(int64_t)P.j * P.n_in + q];
-    for (int i = 0; i < P.j; ++i) {
-        const double g = (double)P.beta_inv * ((double)P.kk[i] * P.cm[i * P.K + P.j]);
-        acc = fma(-g, (double)P.z[(int64_t)(i - P.j) * P.n_in + q], acc);  // (P.z = z_j: the earlier vectors lie before it)
+    const float k = P.scal[0];
+    const float zq = P.z[q];
+    for (int o = 0; o < P.n_out; ++o) {
+        float* w = P.W + (int64_t)o * P.ldw + q;
+        *w = *w + (k * P.err[o]) * zq;
     }
-    P.z[q] = (float)acc;
+    if (!next) return;
+    const int jn = P.j + 1;
+    double acc = (double)P.yb[(int64_t)jn * P.n_in + q];
+    for (int i = 0; i < jn; ++i) {
+        const double g = (double)P.beta_inv * ((double)(i == P.j ? k : P.kk[i]) * P.cm[i * P.K + jn]);
+        acc = fma(-g, (double)P.z[(int64_t)(i - P.j) * P.n_in + q], acc);
+    }
+    P.z[(int64_t)P.n_in + q] = (float)acc;
 }
 
 // The scalar kernel of the blocked sweep.  Block 0: d = z_j . x_j, blocks 1 + jn: c_{j, j + 1 + jn} = z_j . x_{j+1+jn} -- both
@@ -934,6 +947,7 @@ int sweep_blocked(const rp_rls* r, RlsParams P, int sym_rows, int32_t steps, int
     P.col_stride = (int64_t)chunks * r->ldc;
     P.xb_stride = (int64_t)stride * ldx;
     P.zn = Yb;
+    P.z0 = Zb;
     P.x_next = nullptr;
     RP_HIP_CHECK(hipMemsetAsync(r->scratch + 3, 0, sizeof(float), st));
     const int updates = (steps + stride - 1) / stride;
@@ -962,10 +976,11 @@ int sweep_blocked(const rp_rls* r, RlsParams P, int sym_rows, int32_t steps, int
             P.pred = pred ? pred + (int64_t)t * ldpred : nullptr;
             P.loss_out = loss ? loss + t : nullptr;
             P.loss_count = t + stride <= steps ? stride : steps - t;
-            hipLaunchKernelGGL(rls_blk_z_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P);
+            // two launches per update: the dot products (z_j is there: Y_0 for the block's first update, else left by the
+            // weights kernel of the update before), then the weights and the next z
             const int extra = cnt - 1 - j;
             hipLaunchKernelGGL(rls_blk_scalars_kernel, dim3(1 + extra + r->n_out), dim3(1024), 0, st, P, extra);
-            hipLaunchKernelGGL(rls_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P);
+            hipLaunchKernelGGL(rls_blk_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P, j + 1 < cnt ? 1 : 0);
             if (pred && stride > 1) {
                 const int count = (t + stride <= steps ? stride : steps - t) - 1;
                 if (count > 0) {
