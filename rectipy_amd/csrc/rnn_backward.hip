@@ -981,6 +981,8 @@ __global__ void chunk_sum_add_kernel(const BwdParams P, float* dst) {
 // ONE launch does the rest per (member, neuron): adds the edge products into the row of the member's output gradient they
 // belong to (edges in member / edge order, each a chunk-ordered sum: the order of the per-matrix path), sums the chunks of
 // W^T u and applies the member's adjoint step.  Same additions in the same order: bit-identical to the per-matrix path.
+// (measured with the limit lifted: 2 x 8192 neurons 460.2 vs 460.5 us per fit_bptt step, 2 x 16384 1411 vs 1396 -- above the
+// launch-bound sizes the per-matrix launches lose nothing)
 constexpr int kFusedMembers = 4, kFusedEdges = 8, kFusedMaxN = 4096;
 
 struct PartArg {  // one transposed product: partials[chunk][j] = sum_{i in chunk} W[i][j] u[i]
@@ -994,24 +996,29 @@ struct PartArgs {
     PartArg a[kFusedMembers + kFusedEdges];
 };
 
-__global__ __launch_bounds__(kThreads) void coupled_partials_kernel(const PartArgs A) {
-    typedef const __attribute__((address_space(4))) char* karg_ptr;
-    PartArg a;  // this block's matrix, straight from the kernel-argument segment (scalar loads at a uniform offset)
-    __builtin_memcpy(&a, (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PartArgs, a) + sizeof(PartArg) * blockIdx.y,
-                     sizeof(PartArg));
-    BwdParams P = {};
-    P.W = a.W;
-    P.ldw = a.ldw;
-    P.u = a.u;
-    P.partials = a.partials;
-    P.n = a.n;
-    P.rows = a.rows;
-    P.rc = a.rc;
-    P.q = a.q;
-    const int strips = (P.n + 255) / 256;
-    if ((int)blockIdx.x * (kThreads / 64) >= strips * P.q) return;  // (the grid is sized for the largest matrix)
-    wt_partial_body<true, 8, 1>(P);
-}
+// (two plain kernels: this part of the file has C linkage)
+#define RP_COUPLED_PARTIALS(NAME, U_, SW_)                                                                                     \
+    __global__ __launch_bounds__(kThreads) void NAME(const PartArgs A) {                                                      \
+        typedef const __attribute__((address_space(4))) char* karg_ptr;                                                       \
+        PartArg a; /* this block's matrix, straight from the kernel-argument segment (scalar loads at a uniform offset) */    \
+        __builtin_memcpy(&a, (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PartArgs, a) + sizeof(PartArg) * blockIdx.y, \
+                         sizeof(PartArg));                                                                                    \
+        BwdParams P = {};                                                                                                     \
+        P.W = a.W;                                                                                                            \
+        P.ldw = a.ldw;                                                                                                        \
+        P.u = a.u;                                                                                                            \
+        P.partials = a.partials;                                                                                              \
+        P.n = a.n;                                                                                                            \
+        P.rows = a.rows;                                                                                                      \
+        P.rc = a.rc;                                                                                                          \
+        P.q = a.q;                                                                                                            \
+        const int strips = (P.n + 256 * SW_ - 1) / (256 * SW_);                                                               \
+        if ((int)blockIdx.x * (kThreads / 64) >= strips * P.q) return; /* (the grid is sized for the largest matrix) */       \
+        wt_partial_body<true, U_, SW_>(P);                                                                                    \
+    }
+RP_COUPLED_PARTIALS(coupled_partials_kernel_8, 8, 1)
+RP_COUPLED_PARTIALS(coupled_partials_kernel_2, 2, 1)
+#undef RP_COUPLED_PARTIALS
 
 struct EdgeSum {  // the chunk partials of one edge product and where their sum goes (null: the row lies before the window)
     const float* partials;
@@ -1127,11 +1134,19 @@ static int coupled_fused_sweep(const rp_bwd_member* mem, int count, int T, hipSt
             P.z_direct = nullptr;
             if (P.rows > max_rows) max_rows = P.rows;
         }
+        // the strip shape of launch_wt_partial for the largest matrix (which strip shape a matrix is walked with never changes
+        // its sums); the grid is sized for the matrix with the most items
+        bool many = false;
+        for (int i = 0; i < mats; ++i) many = many || ((A.a[i].n + 255) / 256) * A.a[i].q >= 2560;
         for (int i = 0; i < mats; ++i) {
-            const int blocks = (((A.a[i].n + 255) / 256) * A.a[i].q + 3) / 4;
+            int blocks = (((A.a[i].n + 255) / 256) * A.a[i].q + 3) / 4;
+            if (many && blocks > 768) blocks = 768;
             if (blocks > max_blocks) max_blocks = blocks;
         }
-        hipLaunchKernelGGL(coupled_partials_kernel, dim3(max_blocks, mats), dim3(kThreads), 0, st, A);
+        if (many)
+            hipLaunchKernelGGL(coupled_partials_kernel_2, dim3(max_blocks, mats), dim3(kThreads), 0, st, A);
+        else
+            hipLaunchKernelGGL(coupled_partials_kernel_8, dim3(max_blocks, mats), dim3(kThreads), 0, st, A);
         hipLaunchKernelGGL(coupled_finalize_kernel, dim3((max_rows + 255) / 256, count), dim3(256), 0, st, F);
     }
     RP_HIP_CHECK(hipGetLastError());

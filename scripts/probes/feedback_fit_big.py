@@ -12,7 +12,7 @@ from rectipy_amd import FeedbackNetwork  # noqa: E402
 
 dev = torch.device("cuda:0")
 tanh = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
-N, T, win = 32768, 100, 50
+N, T, win = (int(sys.argv[1]) if len(sys.argv) > 1 else 32768), 100, 50
 h = N // 2
 with contextlib.redirect_stdout(sys.stderr):
     kw = lambda W: dict(input_var="li_op/I_ext", output_var="li_op/v", weights=W, source_var="tanh_op/r",
