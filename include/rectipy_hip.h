@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 15
+#define RP_ABI_VERSION 16
 #define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0
@@ -428,6 +428,10 @@ typedef struct rp_bwd_member {
     int32_t edge_mode[RP_MAX_EDGES];     /* RP_EDGE_OUT | RP_EDGE_LIVE (source later in the order) | RP_EDGE_LAG          */
     float* edge_work;                    /* workspace: SUM over this member's edges of rp_bwd_shard_partial_rows(n_source, rows) * n_source floats (16-byte aligned) */
     float* z;                            /* workspace [n]                                                               */
+    rp_packed edge_spt[RP_MAX_EDGES];    /* optional: the TRANSPOSED edge matrix [n_source x rows] in packed form (a fixed sparse edge).
+                                            Then c = W_e^T gx is formed by packed row dots -- c[j] = the forward's row dot of row j of
+                                            W_e^T with gx (its summation tree on the width `rows`, start chunk from j) -- instead of
+                                            chunk partials: other rounding than the dense form, mirrored by the oracle            */
     const float* final_src;              /* [n] the member's source vector r at the END of the window; required when an RP_EDGE_LIVE
                                             edge of a LATER member reads this member (a post-update read) and its output variable
                                             is the source; else may be NULL                                               */

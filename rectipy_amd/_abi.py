@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 15
+RP_ABI_VERSION = 16
 RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_MFMA16, RP_BATCH_SLOTS = 0, 1, 2, 32
 RP_COMM_RCCL, RP_COMM_DIRECT = 0, 1
 
@@ -148,6 +148,7 @@ class RpBwdMember(C.Structure):
         ("edge_mode", C.c_int32 * RP_MAX_EDGES),
         ("edge_work", fp),
         ("z", fp),
+        ("edge_spt", RpPacked * RP_MAX_EDGES),
         ("final_src", fp),
     ]
 

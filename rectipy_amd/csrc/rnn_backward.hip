@@ -1163,10 +1163,20 @@ __global__ void lam_add_kernel(const BwdParams E, const BwdParams Q, const float
     Q.lam[j] = Q.lam[j] + gv;
 }
 
+// the same from a finished product vector c (a packed edge)
+__global__ void lam_add_vec_kernel(const float* c, const BwdParams Q, const float* r_final, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float g = c[j];
+    const float gv = (Q.grad_var == RP_OUT_STATE0) ? g : g * act_deriv(Q, j, r_final[j]);
+    Q.lam[j] = Q.lam[j] + gv;
+}
+
 int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
     if (!mem || count < 1 || count > 16) RP_FAIL(RP_ERR_ARG, "rp_backward_coupled: 1..16 members");
     const int T = mem[0].bwd ? mem[0].bwd->steps : 0;
     bool post = false;  // an RP_EDGE_LIVE edge from an earlier member: it reads a post-update output
+    bool any_packed = false;  // a fixed sparse edge whose transposed matrix comes in packed form (edge_spt)
     for (int m = 0; m < count; ++m) {
         const rp_bwd_member& M = mem[m];
         if (!M.net || !M.bwd || !M.z) RP_FAIL(RP_ERR_ARG, "member %d: net / bwd / z is null", m);
@@ -1190,6 +1200,13 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
                     RP_FAIL(RP_ERR_ARG, "member %d edge %d: source %d needs final_src (its output variable is the source)", m, e, q);
             }
             if (!M.edge_w[e] || M.edge_ld[e] < mem[q].net->n) RP_FAIL(RP_ERR_SHAPE, "member %d edge %d: edge_w / edge_ld", m, e);
+            if (M.edge_spt[e].vals) {
+                any_packed = true;
+                if (M.net->rows % 4 != 0 || !M.edge_spt[e].cidx || !M.edge_spt[e].rowoff || (reinterpret_cast<uintptr_t>(M.edge_work) & 15u) ||
+                    M.bwd->ldgx % 4 != 0 || (reinterpret_cast<uintptr_t>(M.bwd->grad_x) & 15u) || mem[q].bwd->ldg % 4 != 0 ||
+                    (reinterpret_cast<uintptr_t>(mem[q].bwd->grad_out) & 15u))
+                    RP_FAIL(RP_ERR_ARG, "member %d edge %d: a packed transposed edge needs rows %% 4 == 0 and 16-byte aligned gradient rows", m, e);
+            }
             if (!mem[q].bwd->grad_out || mem[q].bwd->ldg < mem[q].net->n)
                 RP_FAIL(RP_ERR_ARG, "member %d edge %d: source %d needs a (writable) grad_out buffer", m, e, q);
         }
@@ -1221,13 +1238,21 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
                 bool v4;
                 const int rc = sharded_params(mem[q].net, mem[q].bwd, Q, v4);
                 if (rc != RP_OK) return rc;
+                if (mem[x].edge_spt[e].vals) {  // c into the workspace, then into lam
+                    const int nq = mem[q].net->n;
+                    const int prc = rp_internal_packed_matvec(&mem[x].edge_spt[e], mem[x].net->rows, nq,
+                                                              mem[x].bwd->grad_x + (int64_t)(T - 1) * mem[x].bwd->ldgx, nullptr, mem[x].edge_work, st);
+                    if (prc != RP_OK) RP_FAIL(prc, "packed edge launch failed (device properties / LDS attribute)");
+                    hipLaunchKernelGGL(lam_add_vec_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, mem[x].edge_work, Q, mem[q].final_src, nq);
+                    continue;
+                }
                 edge_partials(x, e, T - 1, E);
                 hipLaunchKernelGGL(lam_add_kernel, dim3((E.n + 255) / 256), dim3(256), 0, st, E, Q, mem[q].final_src);
             }
         const int rc = rp_bwd_prepare(mem[q].net, mem[q].bwd, stream);
         if (rc != RP_OK) return rc;
     }
-    if (!post && coupled_fused_ok(mem, count)) return coupled_fused_sweep(mem, count, T, st);
+    if (!post && !any_packed && coupled_fused_ok(mem, count)) return coupled_fused_sweep(mem, count, T, st);
     for (int t = T - 1; t >= 0; --t) {
         // last member first; in front of a member's step the edge products that end in its output gradient: from gx_x(t)
         // (ready since step t + 1) for the reads of step t's output -- into row t -- and of the output one step earlier
@@ -1242,9 +1267,15 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
                     const int row = is_post ? t - 1 : t;                     // the row of gx_x the edge carries back
                     const int tau = mode == RP_EDGE_LAG ? t - 1 : t;        // ... into this row of q's output gradient
                     if (row < 0 || tau < 0) continue;
+                    float* dst = const_cast<float*>(mem[q].bwd->grad_out) + (int64_t)tau * mem[q].bwd->ldg;
+                    if (mem[x].edge_spt[e].vals) {  // dst[j] = dst[j] + (row j of W_e^T) . gx_x(row): one packed launch
+                        const int prc = rp_internal_packed_matvec(&mem[x].edge_spt[e], mem[x].net->rows, mem[q].net->n,
+                                                                  mem[x].bwd->grad_x + (int64_t)row * mem[x].bwd->ldgx, dst, dst, st);
+                        if (prc != RP_OK) RP_FAIL(prc, "packed edge launch failed (device properties / LDS attribute)");
+                        continue;
+                    }
                     BwdParams E;
                     edge_partials(x, e, row, E);
-                    float* dst = const_cast<float*>(mem[q].bwd->grad_out) + (int64_t)tau * mem[q].bwd->ldg;
                     hipLaunchKernelGGL(chunk_sum_add_kernel, dim3((E.n + 255) / 256), dim3(256), 0, st, E, dst);
                 }
             int rc = rp_bwd_partial(mem[q].net, mem[q].bwd, t, mem[q].z, stream);

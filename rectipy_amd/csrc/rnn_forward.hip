@@ -1447,6 +1447,29 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
 
 }  // namespace
 
+// (declared in rp_common.h: the packed mat-vec of rp_forward_coupled's edges, also used by rp_backward_coupled for fixed sparse
+// edges -- there with the transposed matrix)
+int rp_internal_packed_matvec(const rp_packed* M, int n, int rows, const float* src, const float* prev, float* out, hipStream_t st) {
+    StepParams E = {};
+    E.n = n;
+    E.rows = rows;
+    E.src_cur = src;
+    E.sp_vals = M->vals;
+    E.sp_cidx = M->cidx;
+    E.sp_rowoff = M->rowoff;
+    E.sp_row_ids = M->row_ids;
+    E.sp_batch_class = M->batch_class;
+    E.sp_phase_window = M->phase_window;
+    E.sp_phases = M->phases;
+    E.sp_batches = M->batches;
+    E.sp_block_rows = M->block_rows;
+    E.esum_out = out;
+    E.esum_prev = prev;
+    E.esum_final = 0;
+    E.x_mode = RP_X_NONE;
+    return launch_step_sparse_model(kModelEdgeSum, E, st);
+}
+
 extern "C" {
 
 int rp_forward(rp_net* net, rp_run* run, void* stream) { return forward_impl(net, run, nullptr, stream); }

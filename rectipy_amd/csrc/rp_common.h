@@ -139,3 +139,8 @@ __device__ __forceinline__ int rp_rows_allreduce_row(int lane) {
     for (; width > 1; width >>= 1, off >>= 1) r += (lane & off) ? width / 2 : 0;
     return r;
 }
+
+// out[i] = (prev ? prev[i] : 0 +) (M s)_i for a matrix M [rows x n] in packed sparse form (rectipy_hip.h: rp_packed): the sparse
+// step kernels' row dots with a pass-through "epilogue" (rnn_forward.hip; used by rp_forward_coupled and rp_backward_coupled)
+struct rp_packed;
+int rp_internal_packed_matvec(const rp_packed* M, int n, int rows, const float* s, const float* prev, float* out, hipStream_t st);

@@ -771,6 +771,13 @@ def backward_coupled(members: list) -> list:
             We, source, mode = edge[0], edge[1], edge[2]
             arr[m].edge_w[e], arr[m].edge_ld[e] = We.data_ptr(), We.stride(0)
             arr[m].edge_source[e], arr[m].edge_mode[e] = int(source), int(mode)
+            pk = edge[3] if len(edge) > 3 else None   # the TRANSPOSED edge matrix in packed form (a fixed sparse edge)
+            if pk is not None:
+                sp = arr[m].edge_spt[e]
+                sp.vals, sp.cidx, sp.rowoff, sp.block_rows = pk.vals.data_ptr(), pk.code.data_ptr(), pk.rowoff.data_ptr(), pk.block_rows
+                if pk.row_ids is not None:
+                    sp.row_ids, sp.batch_class = pk.row_ids.data_ptr(), pk.batch_class.data_ptr()
+                    sp.phase_window, sp.phases, sp.batches = pk.phase_window.data_ptr(), pk.phases, pk.batches
         arr[m].edge_work = work.data_ptr()
         arr[m].z = z.data_ptr()
         final_src = spec.get("final_src")  # r at the end of the window: a later member's RP_EDGE_LIVE edge read it (a post-update read)
@@ -778,7 +785,7 @@ def backward_coupled(members: list) -> list:
             if final_src.dtype != torch.float32 or final_src.device != pop.device or final_src.numel() != pop.n or not final_src.is_contiguous():
                 raise RuntimeError(f"member {m}: final_src must be a contiguous float32 [{pop.n}] tensor on {pop.device}")
             arr[m].final_src = final_src.data_ptr()
-        keep_all.append((net, b, keep, z, work, final_src, [edge[0] for edge in edges]))
+        keep_all.append((net, b, keep, z, work, final_src, [edge[0] for edge in edges], [edge[3] for edge in edges if len(edge) > 3]))
     first.backend.backward_coupled(arr, count, first.device)
     return keep_all
 

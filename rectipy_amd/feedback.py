@@ -161,6 +161,10 @@ class _CoupledWindow(torch.autograd.Function):
             res.append(R)
             members.append(dict(pop=pop, bwd=kw, final_src=ctx.final[p][1] if p in ctx.final else None,
                                 edges=[(net.get_edge(s_, p).weights.detach(), index[s_], mode) for s_, mode in plan["edges"][p]]))
+        packed_t = net._packed_edges(plan, transposed=True)   # fixed sparse edges: W_e^T gx by packed row dots
+        if packed_t:
+            for m, p in enumerate(pops):
+                members[m]["edges"] = [edge + (packed_t.get((s_, p)),) for edge, (s_, _) in zip(members[m]["edges"], plan["edges"][p])]
         keep = backward_coupled(members)
         grads = [None] * len(need)
         for m, (p, (i, names)) in enumerate(zip(pops, layout)):
@@ -621,11 +625,12 @@ class FeedbackNetwork(Network):
     PACKED_EDGE_MAX_DENSITY = 0.5   # (the rules of a population's own matrix, nodes.py: _maybe_pack_weights)
     PACKED_EDGE_MIN_ROWS = 4096
 
-    def _packed_edges(self, plan: dict) -> dict:
+    def _packed_edges(self, plan: dict, transposed: bool = False) -> dict:
         """(source, target) -> packed form of the edge matrix, for every member whose edges are ALL fixed and sparse enough
         (sparse long-range coupling between populations, whatever their own W): their stored nonzeros are streamed by packed
         mat-vec launches instead of the dense matrices (rp_run.edge_sp; the bits of the dense products).  Packed once per edge
-        and weight version.  Launch-bound sizes keep the in-kernel dense edges (one launch per member, or one for all)."""
+        and weight version.  Launch-bound sizes keep the in-kernel dense edges (one launch per member, or one for all).
+        ``transposed``: the packed form of W_e^T instead, for the adjoint's products W_e^T gx (rp_bwd_member.edge_spt)."""
         from . import sparse
         out = {}
         for p in plan["pops"]:
@@ -639,27 +644,29 @@ class FeedbackNetwork(Network):
             if getattr(node, "_sparse_mode", "auto") is False or (not forced and pop.rows < self.PACKED_EDGE_MIN_ROWS):
                 continue
             found = {}
+            attr = "_packed_cache_t" if transposed else "_packed_cache"
             for s_, _ in plan["edges"][p]:
                 edge = self.get_edge(s_, p)
                 W = edge.weights
-                if W.requires_grad or W.shape[1] % 4 or not W.is_contiguous() or W.device != pop.device:
+                if W.requires_grad or W.shape[1] % 4 or W.shape[0] % 4 or not W.is_contiguous() or W.device != pop.device:
                     break
-                cache = getattr(edge, "_packed_cache", None)
+                cache = getattr(edge, attr, None)
                 if cache is None or cache[0] != (W._version, W.data_ptr()):
                     if sparse.density(W) > self.PACKED_EDGE_MAX_DENSITY:
                         cache = ((W._version, W.data_ptr()), None)
                     else:
-                        n_src = W.shape[1]
-                        if n_src > sparse.WINDOW_COLUMNS:
-                            pk = sparse.pack_rows_windowed(W.detach())
-                        elif pop._block_rows() > 0:
-                            pk = sparse.pack_rows_blocked(W.detach(), block_rows=pop._block_rows())
+                        M = W.detach().T.contiguous() if transposed else W.detach()   # [rows x columns] of the product's matrix
+                        rows_pop = self.get_node(s_)._pop if transposed else pop
+                        if M.shape[1] > sparse.WINDOW_COLUMNS:
+                            pk = sparse.pack_rows_windowed(M)
+                        elif rows_pop._block_rows() > 0:
+                            pk = sparse.pack_rows_blocked(M, block_rows=rows_pop._block_rows())
                         else:
-                            pk = sparse.pack_rows(W.detach())
+                            pk = sparse.pack_rows(M)
                         if pk.stored_bytes > 0.7 * 4.0 * W.shape[0] * W.shape[1]:   # (the rule of a population's own matrix)
                             pk = None
                         cache = ((W._version, W.data_ptr()), pk)
-                    edge._packed_cache = cache
+                    setattr(edge, attr, cache)
                 if cache[1] is None:
                     break
                 found[(s_, p)] = cache[1]

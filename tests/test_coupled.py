@@ -520,7 +520,7 @@ def torch_walk_rate(pops, edges, out_vars, x, T, leaves, post=()):
     return [torch.stack(o) for o in outs], v
 
 
-def coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev, models=None, post=()):
+def coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev, models=None, post=(), packed_t=None):
     """Forward with the window stored, then rp_backward_coupled; returns the gradients per member / edge."""
     from rectipy_amd.engine import backward_coupled
     n_m = len(pops)
@@ -554,7 +554,10 @@ def coupled_adjoint(pops, edges, out_vars, x, T, g_out, g_vend, dev, models=None
         else:
             kw.update(grad_tau=R["tau"], grad_k=R["k"], grad_eta=R["eta"])
         res.append(R)
-        bw.append(dict(pop=p, edges=members[m]["edges"], bwd=kw, final_src=final[m][1]))
+        bw_edges = members[m]["edges"]
+        if packed_t:   # fixed sparse edges: the transposed matrices in packed form
+            bw_edges = [edge[:3] + (packed_t.get((edge[1], m)),) for edge in bw_edges]
+        bw.append(dict(pop=p, edges=bw_edges, bwd=kw, final_src=final[m][1]))
     keep = backward_coupled(bw)
     del keep
     for m, p in enumerate(pops):
@@ -1102,3 +1105,81 @@ def test_readout_only_fit_behind_coupled_populations_skips_the_adjoint(target, m
         res.append((edge.weights.detach().cpu().numpy().copy(), obs.to_numpy("out"), start))
     assert np.abs(res[0][0] - res[1][0]).max() < 2e-5 and np.abs(res[0][1] - res[1][1]).max() < 2e-5
     assert np.abs(res[0][0] - res[0][2]).max() > 1e-3   # (the read-out did move)
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("sizes,out_vars,post", [((1024, 520), (0, 1), ()), ((260, 1028, 516), (1, 0, 1), ((0, 2),))])
+def test_coupled_adjoint_with_packed_transposed_edges(target, oracle_backend, sizes, out_vars, post):
+    """Fixed sparse edges in the adjoint: c = W_e^T gx by packed row dots of the transposed matrix (rp_bwd_member.edge_spt).
+    Against float64 autograd over the walk (its own summation order, so a tolerance) -- and on the GPU additionally against
+    the oracle's mirror of that order, bit for bit."""
+    from rectipy_amd import sparse
+    dev, T = target["device"], 17
+    models = ("li_tanh",) * len(sizes)
+    gen = torch.Generator().manual_seed(9)
+    x = (torch.randn(T, sizes[0], generator=gen) * 0.5)
+    g_out = [torch.randn(T, n, generator=gen) for n in sizes]
+    g_vend = [torch.randn(n, generator=gen) for n in sizes]
+
+    def run(device, backend):
+        pops, edges = sparse_circuit(sizes, models, 5, device, backend, density=0.15)
+        packed_t = {key: sparse.pack_rows(We.T.contiguous()) for key, We in edges.items()}
+        res, _ = coupled_adjoint(pops, edges, out_vars, x.to(device), T, g_out, g_vend, device, post=post, packed_t=packed_t)
+        return pops, edges, res
+
+    pops, edges, res = run(dev, target["backend"])
+    d = lambda t: t.detach().cpu().double().clone().requires_grad_(True)
+    leaves = dict(v0=[d(p.v) for p in pops], W=[d(p.W) for p in pops], tau=[d(p.params["tau"]) for p in pops],
+                  k=[d(p.params["k"]) for p in pops], eta=[d(p.params["eta"]) for p in pops],
+                  edges={key: d(We) for key, We in edges.items()}, x=d(x))
+    # (the circuit's states moved during the forward: rebuild it for the float64 walk)
+    pops0, _ = sparse_circuit(sizes, models, 5, "cpu", oracle_backend, density=0.15)
+    leaves["v0"] = [d(p.v) for p in pops0]
+    outs, v_end = torch_walk_rate(pops0, edges, out_vars, x, T, leaves, post)
+    loss = sum((o * g.double()).sum() for o, g in zip(outs, g_out)) + sum((v * g.double()).sum() for v, g in zip(v_end, g_vend))
+    loss.backward()
+    for m in range(len(sizes)):
+        for got, want, what in ((res[m]["lam"], leaves["v0"][m].grad, "d/dv0"), (res[m]["W"], leaves["W"][m].grad, "dW"),
+                                (res[m]["tau"], leaves["tau"][m].grad, "dtau")):
+            scale = float(want.abs().max()) + 1e-12
+            assert float((got.detach().cpu().double() - want).abs().max()) <= 3e-4 * scale, f"member {m} {what}"
+    if dev != "cpu":
+        _, _, ref = run("cpu", oracle_backend)
+        for m in range(len(sizes)):
+            for key in ("lam", "u", "gx", "g_out", "tau", "k", "eta"):
+                assert_same(ref[m][key], res[m][key], f"member {m} {key}")
+
+
+@pytest.mark.gpu
+def test_fit_with_fixed_sparse_edges_packs_them_in_both_directions(hip_device, monkeypatch):
+    """Trained dense recurrent matrices, FIXED sparse edges between the populations: the forward streams the packed edges
+    (rp_run.edge_sp), the adjoint the packed transposed ones (rp_bwd_member.edge_spt); the parameters after three SGD windows
+    equal those with the dense edges to float32 rounding (different summation order of the edge products)."""
+    r = np.random.default_rng(3)
+    na, nb, T = 2048, 1028, 60
+    mat = lambda rows, cols, g, p: (r.standard_normal((rows, cols)) * g / np.sqrt(cols * p) * (r.uniform(size=(rows, cols)) < p)).astype(np.float32)
+    Wa, Wb, Eab, Eba = mat(na, na, 0.9, 1.0), mat(nb, nb, 0.9, 1.0), mat(nb, na, 0.5, 0.05), mat(na, nb, 0.5, 0.05)
+    Wout = (r.standard_normal((2, nb)) / np.sqrt(nb)).astype(np.float32)
+    x, y = (r.standard_normal((T, na)) * 0.3).astype(np.float32), (r.standard_normal((T, 2)) * 0.2).astype(np.float32)
+    res = []
+    for packed in (False, True):
+        net = FeedbackNetwork(1e-2, device=hip_device)
+        net.PACKED_EDGE_MIN_ROWS = 0
+        if not packed:
+            net.PACKED_EDGE_MAX_DENSITY = 0.0
+        for lab, W in (("a", Wa), ("b", Wb)):
+            net.add_diffeq_node(lab, TANH, weights=W, source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                                output_var="li_op/v", dtype=torch.float32, train_params=["weights", "li_op/tau"])
+        net.add_func_node("out", 2, "identity")
+        net.add_edge("a", "b", weights=Eab)
+        net.add_edge("b", "out", weights=Wout, train="gd")
+        net.add_edge("b", "a", weights=Eba, feedback=True)
+        obs = net.fit_bptt(x, y, optimizer="sgd", lr=0.02, update_steps=20, sampling_steps=1, verbose=False)
+        for s_, t_ in (("a", "b"), ("b", "a")):
+            e_ = net.get_edge(s_, t_)
+            assert (getattr(e_, "_packed_cache", (None, None))[1] is not None) == packed
+            assert (getattr(e_, "_packed_cache_t", (None, None))[1] is not None) == packed
+        res.append(([p_.detach().cpu().numpy().copy() for p_ in net.parameters()], obs.to_numpy("out")))
+    for a_, b_ in zip(res[0][0], res[1][0]):
+        assert np.abs(a_ - b_).max() <= 2e-5 * max(1.0, np.abs(a_).max())
+    assert np.abs(res[0][1] - res[1][1]).max() < 2e-5 * max(1.0, np.abs(res[0][1]).max())
