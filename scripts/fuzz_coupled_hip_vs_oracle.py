@@ -72,15 +72,16 @@ def add_population(net, label, kind, n, rng, train=False, density=None):
     return f"{op}/v"
 
 
-def build_feedback(where, seed, kinds, sizes, m, k, fb_pairs, train=False, density=None):
+def build_feedback(where, seed, kinds, sizes, m, k, fb_pairs, train=False, density=None, fixed_edges=False):
     rng = np.random.default_rng(seed)
     net = FeedbackNetwork(5e-3, **where)
+    net.PACKED_EDGE_MIN_ROWS = 0   # (sparse edges are packed at any size here)
     if m:
         net.add_func_node("inp", m, "identity")
     labels = "abcd"[:len(sizes)]
     rec_var = None
     for lab, kind, n in zip(labels, kinds, sizes):
-        v = add_population(net, lab, kind, n, rng, train, density)
+        v = add_population(net, lab, kind, n, rng, train, None if fixed_edges else density)
         rec_var = rec_var or (lab, v)
     if k:
         net.add_func_node("out", k, ["identity", "tanh"][int(rng.integers(0, 2))])
@@ -88,10 +89,12 @@ def build_feedback(where, seed, kinds, sizes, m, k, fb_pairs, train=False, densi
     width = dict(zip(labels, sizes), inp=m, out=k)
     thin = lambda W: W if density is None else W * (rng.uniform(size=W.shape) < density) / density ** 0.5
     for s_, t_ in zip(order[:-1], order[1:]):
-        net.add_edge(s_, t_, weights=thin(rng.standard_normal((width[t_], width[s_])) * 0.7 / np.sqrt(width[s_])), train="gd" if train else None)
+        between = s_ in labels and t_ in labels
+        net.add_edge(s_, t_, weights=thin(rng.standard_normal((width[t_], width[s_])) * 0.7 / np.sqrt(width[s_])),
+                     train="gd" if train and not (fixed_edges and between) else None)
     for s_, t_ in fb_pairs:
         net.add_edge(labels[s_], labels[t_], weights=thin(rng.standard_normal((sizes[t_], sizes[s_])) * 0.5 / np.sqrt(sizes[s_])), feedback=True,
-                     train="gd" if train else None)
+                     train="gd" if train and not fixed_edges else None)
     return net, rec_var
 
 
@@ -128,13 +131,19 @@ def main(cases=40, seed=0, max_n=1100):
                 win = int(rng.integers(8, 25))
                 T = 2 * win + int(rng.integers(0, 5))
                 spiking = any(KINDS[q].get("spike") for q in kinds)
-                cfg = dict(kind="fit", kinds=kinds, sizes=sizes, m=m, k=k, fb=sorted(pairs), T=T, win=win)
+                # a third of the cases: trained populations, FIXED sparse edges between them (packed in forward and adjoint on the GPU)
+                fixed = rng.integers(0, 3) == 0
+                density = float(rng.uniform(0.03, 0.12)) if fixed else None
+                if fixed:
+                    sizes = [max(8, n - n % 4) for n in sizes]
+                cfg = dict(kind="fit", kinds=kinds, sizes=sizes, m=m, k=k, fb=sorted(pairs), T=T, win=win, fixed_sparse_edges=bool(fixed))
                 x = (rng.standard_normal((T, m if m else sizes[0])) * 0.5 + (1.5 if KINDS[kinds[0]].get("spike") else 0.0)).astype(np.float32)
                 y = (rng.standard_normal((T, k)) * 0.2).astype(np.float32)
                 res = []
                 for where, walk in ((wheres[0], True), (wheres[0], False), (wheres[1], False)):
                     with contextlib.redirect_stdout(io.StringIO()):
-                        net, _ = build_feedback(where, 1000 * seed + case, kinds, sizes, m, k, sorted(pairs), train=True)
+                        net, _ = build_feedback(where, 1000 * seed + case, kinds, sizes, m, k, sorted(pairs), train=True, density=density,
+                                                fixed_edges=bool(fixed))
                         net._force_stepwise_adjoint = walk
                         net.compile()
                         fused = net._coupled_grad_plan() is not None
