@@ -1186,6 +1186,11 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
             RP_FAIL(RP_ERR_ARG, "member %d: population-mean models have no step-wise adjoint", m);
         if (M.n_edges < 0 || M.n_edges > RP_MAX_EDGES) RP_FAIL(RP_ERR_ARG, "member %d: n_edges must be in [0, %d]", m, RP_MAX_EDGES);
         if (M.n_edges > 0 && (!M.bwd->grad_x || !M.edge_work)) RP_FAIL(RP_ERR_ARG, "member %d has edges: grad_x and edge_work are required", m);
+        if (M.bwd->spt_vals) {
+            any_packed = true;
+            if (M.net->n % 4 != 0 || M.bwd->ld % 4 != 0 || (reinterpret_cast<uintptr_t>(M.bwd->u_traj) & 15u) || (reinterpret_cast<uintptr_t>(M.z) & 15u))
+                RP_FAIL(RP_ERR_ARG, "member %d: the packed W^T needs n %% 4 == 0 and 16-byte aligned u_traj rows / z", m);
+        }
         for (int e = 0; e < M.n_edges; ++e) {
             const int q = M.edge_source[e], mode = M.edge_mode[e];
             if (q < 0 || q >= count || !mem[q].net || !mem[q].bwd) RP_FAIL(RP_ERR_ARG, "member %d edge %d: bad source %d", m, e, q);
@@ -1278,8 +1283,25 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
                     edge_partials(x, e, row, E);
                     hipLaunchKernelGGL(chunk_sum_add_kernel, dim3((E.n + 255) / 256), dim3(256), 0, st, E, dst);
                 }
-            int rc = rp_bwd_partial(mem[q].net, mem[q].bwd, t, mem[q].z, stream);
-            if (rc != RP_OK) return rc;
+            int rc;
+            if (mem[q].bwd->spt_vals) {  // a fixed sparse W: z = W^T u by the packed rows of W^T (rp_bwd.spt_*), one launch
+                const rp_bwd* b = mem[q].bwd;
+                rp_packed S = {};
+                S.vals = b->spt_vals;
+                S.cidx = b->spt_cidx;
+                S.rowoff = b->spt_rowoff;
+                S.row_ids = b->spt_row_ids;
+                S.batch_class = b->spt_batch_class;
+                S.phase_window = b->spt_phase_window;
+                S.phases = b->spt_phases;
+                S.batches = b->spt_batches;
+                S.block_rows = b->spt_block_rows;
+                rc = rp_internal_packed_matvec(&S, mem[q].net->n, mem[q].net->n, b->u_traj + (int64_t)t * b->ld, nullptr, mem[q].z, st);
+                if (rc != RP_OK) RP_FAIL(rc, "packed W^T launch failed (device properties / LDS attribute)");
+            } else {
+                rc = rp_bwd_partial(mem[q].net, mem[q].bwd, t, mem[q].z, stream);
+                if (rc != RP_OK) return rc;
+            }
             rc = rp_bwd_apply(mem[q].net, mem[q].bwd, t, mem[q].z, stream);
             if (rc != RP_OK) return rc;
         }

@@ -615,7 +615,7 @@ class Population:
         q = self.backend.shard_partial_rows(self.n, local) if sharded else self.backend.partial_rows(self.n)
         partials = torch.empty(q, self.n, dtype=torch.float32, device=self.device)
         b.partials = partials.data_ptr()
-        if not sharded and self.packed is not None and self.sparse_adjoint:
+        if (self.rows == self.n) and self.packed is not None and self.sparse_adjoint:  # (also for the step-wise entry points)
             # fixed sparse W: the sweep streams the packed rows of W^T (row-dot order of the transposed-copy sweep)
             pt = self._packed_transpose()
             if pt is not None:

@@ -1108,9 +1108,11 @@ def test_readout_only_fit_behind_coupled_populations_skips_the_adjoint(target, m
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("pack_w", [False, True], ids=["edges", "edges-and-W"])
 @pytest.mark.parametrize("sizes,out_vars,post", [((1024, 520), (0, 1), ()), ((260, 1028, 516), (1, 0, 1), ((0, 2),))])
-def test_coupled_adjoint_with_packed_transposed_edges(target, oracle_backend, sizes, out_vars, post):
-    """Fixed sparse edges in the adjoint: c = W_e^T gx by packed row dots of the transposed matrix (rp_bwd_member.edge_spt).
+def test_coupled_adjoint_with_packed_transposed_edges(target, oracle_backend, sizes, out_vars, post, pack_w):
+    """Fixed sparse edges -- and, "edges-and-W", fixed sparse recurrent matrices -- in the adjoint: c = W_e^T gx (z = W^T u) by
+    packed row dots of the transposed matrix (rp_bwd_member.edge_spt, rp_bwd.spt_*).
     Against float64 autograd over the walk (its own summation order, so a tolerance) -- and on the GPU additionally against
     the oracle's mirror of that order, bit for bit."""
     from rectipy_amd import sparse
@@ -1123,6 +1125,9 @@ def test_coupled_adjoint_with_packed_transposed_edges(target, oracle_backend, si
 
     def run(device, backend):
         pops, edges = sparse_circuit(sizes, models, 5, device, backend, density=0.15)
+        if pack_w:   # the members' own fixed sparse W: z = W^T u by the packed rows of W^T (rp_bwd.spt_*)
+            for p in pops:
+                p.pack_weights()
         packed_t = {key: sparse.pack_rows(We.T.contiguous()) for key, We in edges.items()}
         res, _ = coupled_adjoint(pops, edges, out_vars, x.to(device), T, g_out, g_vend, device, post=post, packed_t=packed_t)
         return pops, edges, res
