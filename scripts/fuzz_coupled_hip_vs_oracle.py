@@ -42,7 +42,7 @@ TRAIN = {"tanh": ["tau", "k", "eta"], "sigmoid": ["tau", "k", "eta"], "qif": ["t
          "ik": ["C", "k", "eta", "tau_s", "g", "b", "tau_u", "kappa", "v_r", "v_theta", "E_r"]}
 
 
-def add_population(net, label, kind, n, rng, train=False, density=None):
+def add_population(net, label, kind, n, rng, train=False, density=None, train_weights=True):
     K = KINDS[kind]
     op = K["op"]
     if K.get("spike"):
@@ -66,7 +66,7 @@ def add_population(net, label, kind, n, rng, train=False, density=None):
             kw["sparse_weights"] = True
     out_var = K["outs"][int(rng.integers(0, len(K["outs"])))]
     if train:
-        kw["train_params"] = ["weights"] + [f"{op}/{q}" for q in TRAIN[kind]]
+        kw["train_params"] = (["weights"] if train_weights else []) + [f"{op}/{q}" for q in TRAIN[kind]]
     net.add_diffeq_node(label, K["path"], weights=W, source_var=K["src"], target_var=K["tgt"], input_var=f"{op}/I_ext",
                         output_var=out_var, dtype=torch.float32, node_vars=node_vars, **kw)
     return f"{op}/v"
@@ -81,7 +81,9 @@ def build_feedback(where, seed, kinds, sizes, m, k, fb_pairs, train=False, densi
     labels = "abcd"[:len(sizes)]
     rec_var = None
     for lab, kind, n in zip(labels, kinds, sizes):
-        v = add_population(net, lab, kind, n, rng, train, None if fixed_edges else density)
+        # fixed_edges == 2: the populations' own matrices are fixed and sparse too (only per-neuron parameters trained)
+        v = add_population(net, lab, kind, n, rng, train, density if (not fixed_edges or fixed_edges == 2) else None,
+                           train_weights=fixed_edges != 2)
         rec_var = rec_var or (lab, v)
     if k:
         net.add_func_node("out", k, ["identity", "tanh"][int(rng.integers(0, 2))])
@@ -132,18 +134,18 @@ def main(cases=40, seed=0, max_n=1100):
                 T = 2 * win + int(rng.integers(0, 5))
                 spiking = any(KINDS[q].get("spike") for q in kinds)
                 # a third of the cases: trained populations, FIXED sparse edges between them (packed in forward and adjoint on the GPU)
-                fixed = rng.integers(0, 3) == 0
+                fixed = int(rng.integers(0, 3) == 0) * int(rng.integers(1, 3))   # 0 | 1: fixed sparse edges | 2: ... and fixed sparse W
                 density = float(rng.uniform(0.03, 0.12)) if fixed else None
                 if fixed:
                     sizes = [max(8, n - n % 4) for n in sizes]
-                cfg = dict(kind="fit", kinds=kinds, sizes=sizes, m=m, k=k, fb=sorted(pairs), T=T, win=win, fixed_sparse_edges=bool(fixed))
+                cfg = dict(kind="fit", kinds=kinds, sizes=sizes, m=m, k=k, fb=sorted(pairs), T=T, win=win, fixed_sparse=int(fixed))
                 x = (rng.standard_normal((T, m if m else sizes[0])) * 0.5 + (1.5 if KINDS[kinds[0]].get("spike") else 0.0)).astype(np.float32)
                 y = (rng.standard_normal((T, k)) * 0.2).astype(np.float32)
                 res = []
                 for where, walk in ((wheres[0], True), (wheres[0], False), (wheres[1], False)):
                     with contextlib.redirect_stdout(io.StringIO()):
                         net, _ = build_feedback(where, 1000 * seed + case, kinds, sizes, m, k, sorted(pairs), train=True, density=density,
-                                                fixed_edges=bool(fixed))
+                                                fixed_edges=int(fixed))
                         net._force_stepwise_adjoint = walk
                         net.compile()
                         fused = net._coupled_grad_plan() is not None
