@@ -666,6 +666,29 @@ def sparse_coupled_extra(dev, h, p, T=300):
             del fb
             torch.cuda.empty_cache()
     out["speedup"] = round(out["dense"] / out["packed"], 2)
+    # the same pair trained: tau and eta of both populations and a read-out of width 3 (the matrices stay fixed), SGD windows of 50:
+    # the adjoint streams the packed transposed matrices (rp_bwd.spt_*, rp_bwd_member.edge_spt)
+    y = torch.randn(100, 3, device=dev, generator=gen) * 0.1
+    with contextlib.redirect_stdout(sys.stderr):
+        for mode in ("auto", False):
+            fb = FeedbackNetwork(dt=1e-2, device=str(dev))
+            kw = lambda W: dict(input_var="li_op/I_ext", output_var="li_op/v", weights=W, source_var="tanh_op/r", target_var="li_op/r_in",
+                                dtype=torch.float32, train_params=["li_op/tau", "li_op/eta"], sparse_weights=mode)
+            fb.add_diffeq_node("a", tanh, **kw(mats[0].clone()))
+            fb.add_diffeq_node("b", tanh, **kw(mats[1].clone()))
+            fb.add_func_node("out", 3, "identity")
+            fb.add_edge("a", "b", weights=mats[2].clone())
+            fb.add_edge("b", "a", weights=mats[3].clone(), feedback=True)
+            fb.add_edge("b", "out", weights=torch.randn(3, h, device=dev, generator=gen) / h ** 0.5, train="gd")
+            fb.fit_bptt(x[:50], y[:50], optimizer="sgd", lr=1e-4, update_steps=50, sampling_steps=50, verbose=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fb.fit_bptt(x[:100], y, optimizer="sgd", lr=1e-4, update_steps=50, sampling_steps=50, verbose=False)
+            torch.cuda.synchronize()
+            out["fit_bptt_packed" if mode == "auto" else "fit_bptt_dense"] = round((time.perf_counter() - t0) / 100 * 1e6, 1)
+            del fb
+            torch.cuda.empty_cache()
+    out["fit_bptt_speedup"] = round(out["fit_bptt_dense"] / out["fit_bptt_packed"], 2)
     return out
 
 
