@@ -1188,3 +1188,40 @@ def test_fit_with_fixed_sparse_edges_packs_them_in_both_directions(hip_device, m
     for a_, b_ in zip(res[0][0], res[1][0]):
         assert np.abs(a_ - b_).max() <= 2e-5 * max(1.0, np.abs(a_).max())
     assert np.abs(res[0][1] - res[1][1]).max() < 2e-5 * max(1.0, np.abs(res[0][1]).max())
+
+
+@pytest.mark.gpu
+def test_packed_edges_with_a_source_wider_than_the_lds_window(hip_device):
+    """An edge whose SOURCE holds more than 32768 neurons is packed in the windowed form (the source vector staged window by
+    window, sparse.pack_rows_windowed), as a population's own matrix of that width: a pair of 4096 and 33024 neurons with every
+    matrix at p = 0.05, packed run against the same network streamed densely on the same device, bit for bit."""
+    from rectipy_amd import sparse
+    na, nb, T, p = 4096, 33024, 6, 0.05
+    gen = torch.Generator(device=hip_device).manual_seed(2)
+
+    def mat(rows, cols, g):
+        W = torch.randn(rows, cols, device=hip_device, generator=gen) * (g / (cols * p) ** 0.5)
+        return W * (torch.rand(rows, cols, device=hip_device, generator=gen) < p)
+
+    Wa, Wb, Eab, Eba = mat(na, na, 1.0), mat(nb, nb, 1.0), mat(nb, na, 0.5), mat(na, nb, 0.5)
+    x = torch.randn(T, na, device=hip_device, generator=gen) * 0.3
+    res = []
+    for packed in (True, False):
+        pops = [Population("li_tanh", W.clone(), dict(tau=2.0, k=1.0, eta=0.0), 1e-2, hip_device) for W in (Wa, Wb)]
+        pk = {}
+        if packed:
+            for pop in pops:
+                pop.pack_weights()
+            pk = {(0, 1): sparse.pack_rows_blocked(Eab, block_rows=pops[1]._block_rows()) if pops[1]._block_rows() else sparse.pack_rows(Eab),
+                  (1, 0): sparse.pack_rows_windowed(Eba)}
+            assert pk[(1, 0)].row_ids is not None and pops[1].packed.row_ids is not None
+        trajs = [torch.zeros(T, pop.rows, device=hip_device) for pop in pops]
+        hist = [[torch.zeros(pop.rows, device=hip_device) for _ in range(3)] for pop in pops]
+        forward_coupled([
+            dict(pop=pops[0], run=dict(steps=T, x=x, traj=trajs[0], hist=hist[0]), edges=[(Eba, 1, _abi.RP_EDGE_LIVE, pk.get((1, 0)))]),
+            dict(pop=pops[1], run=dict(steps=T, traj=trajs[1], hist=hist[1]), edges=[(Eab, 0, _abi.RP_EDGE_OUT, pk.get((0, 1)))])])
+        res.append([t.clone() for t in trajs] + [pop.v.clone() for pop in pops])
+        del pops, pk
+        torch.cuda.empty_cache()
+    for a, b in zip(*res):
+        assert_same(a, b, "packed vs dense")
