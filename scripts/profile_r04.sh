@@ -29,3 +29,5 @@ f=$(find $OUT/stats -name "*kernel_stats.csv" | head -1)
 cp $f $OUT/bench_kernel_stats.csv
 # the plain driver command without the profiler, for the committed bench line
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line_driver_cmd.json 2> $OUT/bench_line.err
+# the raw traces are large (gpurun merges at most 64 MiB back): keep the summaries only
+rm -rf $OUT/stats $OUT/fetch $OUT/write $K/fetch $K/write $OUT/feedback
