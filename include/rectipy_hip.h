@@ -21,6 +21,10 @@
  *                        included                   rectipy/network.py:962-981, 1322-1357 (FeedbackNetwork._backward,
  *                                                   _edge_bwd), rectipy/edges.py:48-49
  *   rp_backward_coupled <- autograd over that walk     rectipy/network.py:1016-1048 with 1322-1357
+ *   rp_run.edge_mem, rp_edge_window
+ *                     <- the edges with memory: LinearMemory / LinearFilter / LinearMemoryFilter.forward
+ *                                                   rectipy/edges.py:68-94, 97-120, 123-147
+ *   RP_MODEL_INSTANT  <- InstantNode.forward (an activation node BETWEEN populations)   rectipy/nodes.py:14-51
  *   rp_refresh_source <- (state re-initialisation)  rectipy/nodes.py:198-211,398-401
  *   rp_rate_backward, rp_qif_backward
  *                     <- torch.autograd over the unrolled loop (incl. Spike.backward, nodes.py:479-481),
@@ -51,7 +55,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 16
+#define RP_ABI_VERSION 17
 #define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0
@@ -70,11 +74,24 @@ extern "C" {
 #define RP_MODEL_IK 5         /* ik.yaml: ik_op (Izhikevich, recovery variable u) */
 #define RP_MODEL_IKU 6        /* ik.yaml: iku_op (recovery driven by the population means of v and spike)   */
 #define RP_MODEL_IK_BIEXP 7   /* ik.yaml: ik_biexp_op (iku + bi-exponential synapse, extra state x)          */
-#define RP_MODEL_COUNT 8
+/* A memory-less activation node between populations (rectipy/nodes.py:14-51) as a member of rp_forward_coupled: no state, no
+   recurrent matrix (rp_net.W / y / p may be NULL, n == rows, row0 == 0); its step is out = act(I) with I the node input of the
+   step (external input + edge sums, as for a population) and act = rp_net.act.  The output lives in the source ping-pong:
+   the step writes src[cur ^ 1] and flips, so src[cur] is the node's LAST output; an edge FROM such a member reads src[cur]
+   as it stands whatever its mode (after the member's step: this step's output; before it: the previous step's).  With the
+   identity and edge matrices NULL (rp_run.edge_w) it also serves as the partial sum of a long edge list (more than
+   RP_MAX_EDGES edges into one node: E = ((E_0 + E_1) + ...) is continued by the next member). */
+#define RP_MODEL_INSTANT 8
+#define RP_MODEL_COUNT 9
+
+#define RP_ACT_IDENTITY 0
+#define RP_ACT_TANH 1    /* rp_tanhf                                            */
+#define RP_ACT_SIGMOID 2 /* 1 / (1 + rp_expf(-x))                               */
 
 #define RP_MAX_PARAMS 12
 #define RP_MAX_STATE 4
-#define RP_MAX_EDGES 4 /* dense edges from other vectors into one population (rp_run.edge_*) */
+#define RP_MAX_EDGES 8 /* dense edges from other vectors into one population (rp_run.edge_*) */
+#define RP_MAX_MEMBERS 64 /* members of one rp_forward_coupled / rp_backward_coupled call */
 
 /* parameter slots p[] (each a per-neuron vector of length `rows`) */
 #define RP_P_TAU 0
@@ -164,6 +181,7 @@ typedef struct rp_net {
        consecutive rows share one padded stream (sp_rowoff = [blocks + 1]); bit 13 of a code (RP_SPARSE_END) closes the
        lane's segment of a row, chunk indices take 13 bits. */
     int32_t sp_block_rows;
+    int32_t act;              /* RP_MODEL_INSTANT: RP_ACT_*                                                             */
 } rp_net;
 
 /*
@@ -183,6 +201,50 @@ typedef struct rp_packed {
     int32_t phases, batches;
     int32_t block_rows;            /* > 0: blocked form                                                      */
 } rp_packed;
+
+/*
+ * The MEMORY of an edge (the reference's edge classes with state, rectipy/edges.py:68-147): a stage in front of the edge's
+ * projection.  Every step it takes the vector x the edge reads from its source (length n) and yields the vector u the
+ * projection `weights @ u` is applied to:
+ *   RP_EMEM_DELAY         LinearMemory (edges.py:91-94)        buffer = roll(buffer, -1, 1); buffer[:, delays] = x; u = buffer[:, 0]
+ *   RP_EMEM_FILTER        LinearFilter (edges.py:118-120)      y = F y + x;  u = y
+ *   RP_EMEM_DELAY_FILTER  LinearMemoryFilter (edges.py:143-146, then its parent's forward 91-94 ON TOP: the class steps its
+ *                         buffer twice per call)               B1 = F roll(B); B1[:, delays] = x;
+ *                                                              B2 = roll(B1); B2[:, delays] = B1[:, 0]; u = B2[:, 0]
+ * `buffer[:, delays] = x` writes x[j] into column delays[j] of EVERY row (and of a repeated delay the last j wins: col_chan).
+ * DELAY therefore keeps ONE row of the buffer (its rows are identical from the first `depth` steps on, whatever they held;
+ * a buffer whose rows differ is not representable here) and u = c0 * ones(n), c0 = the new column 0.
+ * Arithmetic of F v (per output row i): n > RP_EMEM_NARROW_MAX: the row dot of the recurrent matrix (summation tree of the
+ * 16-byte path iff n % 4 == 0 and ldf % 4 == 0, start chunk from row i); n <= RP_EMEM_NARROW_MAX (DELAY_FILTER: and
+ * depth * n <= 8192): a j-ascending fmaf chain from 0.  FILTER then adds x[i] (one addition: fl(fl(F y) + x)).
+ * State: two buffers in turn, `cur` names the current one (host, in/out).  DELAY: [depth] floats each; FILTER: [n];
+ * DELAY_FILTER: [depth x n], column c of the reference's buffer at state + c * n.  All 16-byte aligned.
+ */
+#define RP_EMEM_NONE 0
+#define RP_EMEM_DELAY 1
+#define RP_EMEM_FILTER 2
+#define RP_EMEM_DELAY_FILTER 3
+#define RP_EMEM_NARROW_MAX 64
+
+typedef struct rp_edge_mem {
+    int32_t kind;             /* RP_EMEM_*                                                                           */
+    int32_t n;                /* n_in: length of x and u                                                              */
+    int32_t depth;            /* DELAY*: columns of the delay buffer = largest delay + 1                              */
+    const int32_t* col_chan;  /* DELAY*: [depth] the input channel written into buffer column c every step, -1 = none  */
+    const int32_t* col_chan_host; /* [host] the same array (which columns are filtered decides the launches of a step)  */
+    const float* F;           /* FILTER*: [n x ldf] row-major                                                         */
+    int64_t ldf;
+    float* state[2];
+    int32_t cur;              /* [host, in/out]                                                                       */
+    float* u;                 /* [n] DELAY / DELAY_FILTER: receives u every step (rp_run.edge_mem; unused by rp_edge_window).
+                                 FILTER: unused, u is the new state                                                   */
+} rp_edge_mem;
+int rp_sizeof_edge_mem(void);
+
+/* `steps` consecutive steps of the stage on the rows of X [steps x ldx] into the rows of U [steps x ldu] (an ACYCLIC edge:
+   its source's whole window is known, the projection of the window then is one GEMM of the caller's).  The state after the
+   call is what `steps` calls of the reference's forward leave behind.  Narrow edges: ONE launch for the whole window. */
+int rp_edge_window(rp_edge_mem* mem, int32_t steps, const float* X, int64_t ldx, float* U, int64_t ldu, void* stream);
 
 typedef struct rp_run {
     int32_t steps;
@@ -234,7 +296,9 @@ typedef struct rp_run {
            I[i] = x-input[i] + ((E_0[i] + E_1[i]) + ...)      (just the edge sum when x_mode == RP_X_NONE),
        the order in which the front end adds a node's edge inputs.  The matrices are streamed from HBM next to W by the
        same wave that owns the row: one launch per population and step, whatever the number of edges.  Dense W only
-       (rp_net.sp_vals is ignored when n_edges > 0; the packed form gives the same bits as the dense one anyway). */
+       (rp_net.sp_vals is ignored when n_edges > 0; the packed form gives the same bits as the dense one anyway).
+       edge_w[e] == NULL: the IDENTITY edge, E_e[i] = s_e[i] (edge_n[e] == rows) -- the input of an activation-node member
+       from a member of its own width, or the running sum of a long edge list (RP_MODEL_INSTANT). */
     int32_t n_edges;                       /* 0..RP_MAX_EDGES                                                   */
     const float* edge_w[RP_MAX_EDGES];     /* [rows x edge_ld]                                                  */
     int64_t edge_ld[RP_MAX_EDGES];
@@ -259,6 +323,11 @@ typedef struct rp_run {
        the dense edge matrices are streamed as described above. */
     rp_packed edge_sp[RP_MAX_EDGES];
     float* edge_sum;
+    /* Edges with memory (kind != RP_EMEM_NONE): every step the stage is advanced with the vector the edge reads (edge_src row /
+       the source member's vector by edge_mode) right before the population's step, and the edge's product is taken with the
+       stage's output u instead; edge_n[e] == edge_mem[e].n.  The stage costs its own launches (FILTER: one streaming pass
+       over F, the recurrent matrix of the edge). */
+    rp_edge_mem edge_mem[RP_MAX_EDGES];
 } rp_run;
 
 /* what an edge of rp_forward_coupled reads from its source population q (q's output variable, rp_run.out_var) */
@@ -363,7 +432,7 @@ int rp_refresh_source(const rp_net* net, void* stream);
 int rp_forward(rp_net* net, rp_run* run, void* stream);
 
 /*
- * `count` unsharded populations joined by dense edges, cycles allowed: every Euler step steps the members in array order
+ * `count` (1..RP_MAX_MEMBERS) unsharded populations joined by dense edges, cycles allowed: every Euler step steps the members in array order
  * (the front end's topological order of the feed-forward edges), one launch per member, inside ONE host call for the
  * whole window -- what the reference does with one Python graph walk per step (rectipy/network.py:588-599, 962-981,
  * 1322-1357).  All runs must agree on steps and step0; each member samples / records / stores trajectories through its
@@ -373,7 +442,8 @@ int rp_forward(rp_net* net, rp_run* run, void* stream);
  *
  * ONE launch per Euler step for all members (instead of one per member) when every edge reads a value from BEFORE the
  * step -- no RP_EDGE_LIVE edge from a member stepped earlier --, at most four members of at most 4096 neurons each (the
- * launch-bound sizes: the reference's own scale), none with population-mean coupling, and every member that is read
+ * launch-bound sizes: the reference's own scale), none with population-mean coupling, no RP_MODEL_INSTANT member, no identity
+ * edge, no edge with memory, at most four edges into a member, and every member that is read
  * through its state variable has the hist ring: each member then also stores its post-update output as the next step's
  * ring entry, and edges read the ring instead of a state vector that the same launch updates.  Same arithmetic, same
  * bits as the launch per member (N = 2 x 2048: 13 instead of 21 us per step).

@@ -66,6 +66,7 @@ def _declare(lib):
     sig("oracle_forward_batched_mfma16", C.c_int, [P(RpNet), P(_abi.RpBatch)])
     sig("oracle_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp])
     sig("oracle_rls_mirror", C.c_int, [P(RpRls)])
+    sig("oracle_edge_window", C.c_int, [P(_abi.RpEdgeMem), C.c_int32, fp, C.c_int64, fp, C.c_int64])
     sig("oracle_expf", C.c_float, [C.c_float])
     sig("oracle_tanhf", C.c_float, [C.c_float])
     sig("oracle_row_dot", C.c_float, [fp, fp, C.c_int, C.c_int, C.c_int])
@@ -167,6 +168,9 @@ class OracleBackend:
         if sampling:
             bt.acc_count, bt.sample_idx = counts
         bt.cur = (bt.cur + bt.steps) % 2
+
+    def edge_window(self, mem, steps, X, ldx, U, ldu, device):
+        assert self.lib.oracle_edge_window(C.byref(mem), steps, X, ldx, U, ldu) == 0
 
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
         assert self.lib.oracle_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss) == 0

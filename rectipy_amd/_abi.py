@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 16
+RP_ABI_VERSION = 17
 RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_MFMA16, RP_BATCH_SLOTS = 0, 1, 2, 32
 RP_COMM_RCCL, RP_COMM_DIRECT = 0, 1
 
@@ -25,10 +25,15 @@ RP_MODEL_LIF = 4
 RP_MODEL_IK = 5
 RP_MODEL_IKU = 6
 RP_MODEL_IK_BIEXP = 7
+RP_MODEL_INSTANT = 8
+RP_ACT_IDENTITY, RP_ACT_TANH, RP_ACT_SIGMOID = 0, 1, 2
+RP_EMEM_NONE, RP_EMEM_DELAY, RP_EMEM_FILTER, RP_EMEM_DELAY_FILTER = 0, 1, 2, 3
+RP_EMEM_NARROW_MAX = 64
 
 RP_MAX_PARAMS = 12
 RP_MAX_STATE = 4
-RP_MAX_EDGES = 4
+RP_MAX_EDGES = 8
+RP_MAX_MEMBERS = 64
 RP_EDGE_LIVE, RP_EDGE_OUT, RP_EDGE_LAG = 0, 1, 2
 
 RP_P_TAU, RP_P_K, RP_P_ETA = 0, 1, 2
@@ -72,6 +77,7 @@ class RpNet(C.Structure):
         ("sp_phases", C.c_int32),
         ("sp_batches", C.c_int32),
         ("sp_block_rows", C.c_int32),
+        ("act", C.c_int32),
     ]
 
 
@@ -79,6 +85,14 @@ class RpPacked(C.Structure):
     _fields_ = [
         ("vals", fp), ("cidx", fp), ("rowoff", fp), ("row_ids", fp), ("batch_class", fp), ("phase_window", fp),
         ("phases", C.c_int32), ("batches", C.c_int32), ("block_rows", C.c_int32),
+    ]
+
+
+class RpEdgeMem(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("n", C.c_int32), ("depth", C.c_int32),
+        ("col_chan", fp), ("col_chan_host", fp), ("F", fp), ("ldf", C.c_int64),
+        ("state", fp * 2), ("cur", C.c_int32), ("u", fp),
     ]
 
 
@@ -125,6 +139,7 @@ class RpRun(C.Structure):
         ("save_in", fp),
         ("edge_sp", RpPacked * RP_MAX_EDGES),
         ("edge_sum", fp),
+        ("edge_mem", RpEdgeMem * RP_MAX_EDGES),
     ]
 
 
@@ -326,6 +341,8 @@ def declare(lib):
     sig("rp_rls_sweep", C.c_int, [P(RpRls), C.c_int32, C.c_int32, fp, C.c_int64, fp, C.c_int64, fp, C.c_int64, fp,
                                   C.c_void_p])
     sig("rp_rls_mirror", C.c_int, [P(RpRls), C.c_void_p])
+    sig("rp_sizeof_edge_mem", C.c_int, [])
+    sig("rp_edge_window", C.c_int, [P(RpEdgeMem), C.c_int32, fp, C.c_int64, fp, C.c_int64, C.c_void_p])
     sig("rp_stream_probe", C.c_int, [fp, C.c_int64, fp, C.c_void_p])
     sig("rp_tune_forward", C.c_int, [C.POINTER(RpNet), C.c_void_p])
     sig("rp_forward_tuning", C.c_int, [C.POINTER(RpNet), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
@@ -351,7 +368,7 @@ EXPORTS = [
     "rp_outer_accum_rect", "rp_outer_store_rect", "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial",
     "rp_bwd_apply", "rp_sizeof_comm", "rp_forward_sharded", "rp_backward_sharded", "rp_ipc_alloc", "rp_ipc_open",
     "rp_ipc_close", "rp_ipc_free", "rp_sizeof_batch", "rp_sizeof_rls", "rp_forward_batched", "rp_rls_sweep", "rp_rls_mirror",
-    "rp_stream_probe", "rp_tune_forward", "rp_forward_tuning", "rp_install_forward_tuning", "rp_clear_forward_tuning",
+    "rp_sizeof_edge_mem", "rp_edge_window", "rp_stream_probe", "rp_tune_forward", "rp_forward_tuning", "rp_install_forward_tuning", "rp_clear_forward_tuning",
 ]
 # the measurement build (-DRP_MEASUREMENT) adds the knobs of include/rectipy_hip.h's RP_MEASUREMENT section
 MEASUREMENT_EXPORTS = [

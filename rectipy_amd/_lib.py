@@ -48,7 +48,7 @@ def load(measure=None):
         raise HipLibraryError(f"ABI version mismatch: library {lib.rp_abi_version()}, python {_abi.RP_ABI_VERSION}")
     for name, struct in (("rp_sizeof_net", _abi.RpNet), ("rp_sizeof_run", _abi.RpRun), ("rp_sizeof_bwd", _abi.RpBwd),
                          ("rp_sizeof_member", _abi.RpMember), ("rp_sizeof_bwd_member", _abi.RpBwdMember),
-                         ("rp_sizeof_comm", _abi.RpComm),
+                         ("rp_sizeof_comm", _abi.RpComm), ("rp_sizeof_edge_mem", _abi.RpEdgeMem),
                          ("rp_sizeof_batch", _abi.RpBatch), ("rp_sizeof_rls", _abi.RpRls)):
         if getattr(lib, name)() != C.sizeof(struct):
             raise HipLibraryError(f"{name}() = {getattr(lib, name)()} but ctypes mirror is {C.sizeof(struct)} bytes")

@@ -39,7 +39,11 @@ constexpr int FLAG_BUFFER = 1;  // step >= cutoff: output joins the sampling buf
 constexpr int FLAG_SAMPLE = 2;  // record mean of the buffer at this step
 constexpr int FLAG_FIRST = 4;   // first output of a buffer (acc_count was 0): the accumulator's old contents are not read
 
-struct EdgeArg {  // one dense edge into the population (rp_run.edge_*): the source vector of THIS step
+// pseudo-models of the step kernels (not part of the C ABI's model table):
+constexpr int kModelEdgeSum = 64;  // a packed edge matrix of a coupled member: row sums chained into rp_run.edge_sum (below)
+constexpr int kModelFilter = 65;   // the recursive filter of an edge with memory (rp_edge_mem): y' = F y (+ x), no state but src
+
+struct EdgeArg {  // one dense edge into the population (rp_run.edge_*): the source vector of THIS step; W == nullptr: identity
     const float* W;
     int64_t ld;
     const float* src;
@@ -95,7 +99,12 @@ struct StepParams {
     float* esum_out;
     const float* esum_prev;
     int esum_final;
+    int act;           // RP_MODEL_INSTANT: RP_ACT_*
 };
+// by-value kernel arguments: the block (and four of them in the shared launch) must fit the kernel-argument segment, and the
+// edge descriptors are read from it at a runtime offset (step_edges_kernel)
+static_assert(sizeof(StepParams) <= 1000, "StepParams grew: check MergedParams against the kernel-argument segment");
+static_assert(offsetof(StepParams, edge) % 8 == 0 && sizeof(EdgeArg) == 32, "EdgeArg is read with scalar loads at a runtime offset");
 
 // ---- row dot products (rp_dot.h) ---------------------------------------------
 
@@ -157,10 +166,23 @@ __device__ __forceinline__ float activation(const StepParams& P, int i, float v)
 template <int MODEL, bool EDGES = false>
 __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum, float esum = 0.f) {
     const int gi = P.row0 + i;
+    if constexpr (MODEL == kModelFilter) {  // rp_edge_mem: y'_i = (F y)_i + x_i  (edges.py:119, 144)
+        P.src_next[i] = P.x_mode != RP_X_NONE ? wsum + P.x_t[i] : wsum;
+        return;
+    }
     float I = input_current(P, i);
-    if constexpr (EDGES) I = P.x_mode != RP_X_NONE ? I + esum : esum;
+    if constexpr (EDGES)
+        if (P.n_edges > 0) I = P.x_mode != RP_X_NONE ? I + esum : esum;
     if (P.save_in_t) P.save_in_t[i] = I;
-    if constexpr (MODEL >= RP_MODEL_QIF) {
+    if constexpr (MODEL == RP_MODEL_INSTANT) {  // InstantNode.forward (nodes.py:47-51): out = act(I); no state
+        float o = I;
+        if (P.act == RP_ACT_TANH)
+            o = rp_tanhf(I);
+        else if (P.act == RP_ACT_SIGMOID)
+            o = 1.0f / (1.0f + rp_expf(-I));
+        P.src_next[gi] = o;
+        sample_output(P, i, o);
+    } else if constexpr (MODEL >= RP_MODEL_QIF) {
         // SpikeResetNet.forward (nodes.py:382-392) with the field of the spiking template:
         //   QIF      qif.yaml:11-12     v' = (v^2 + eta + I)/tau + k s_in;          s' = -s/tau_s + spike
         //   QIF_SFA  qif.yaml:25-35     eta -> eta - x;                             x' = -x/tau_x + alpha spike
@@ -293,7 +315,10 @@ __global__ __launch_bounds__(kThreads) void step_edges_kernel(const StepParams P
         float sum[R], esum[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) esum[j] = 0.f;
-        if constexpr (VEC4)
+        if constexpr (MODEL == RP_MODEL_INSTANT) {  // no recurrent matrix
+#pragma unroll
+            for (int j = 0; j < R; ++j) sum[j] = 0.f;
+        } else if constexpr (VEC4)
             dot_rows_v4<R, U, true>(P, row_base, lane, sum);
         else
             dot_rows_s1<R>(P, row_base, lane, sum);
@@ -305,7 +330,10 @@ __global__ __launch_bounds__(kThreads) void step_edges_kernel(const StepParams P
             const edge_ptr Ep = (edge_ptr)((karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(StepParams, edge)) + e;
             const EdgeArg E{Ep->W, Ep->ld, Ep->src, Ep->n, Ep->vec4};
             float es[R];
-            if (E.vec4)
+            if (E.W == nullptr) {  // the identity edge: E_e[i] = s_e[i]
+#pragma unroll
+                for (int j = 0; j < R; ++j) es[j] = row_base + j < P.rows ? E.src[row_base + j] : 0.f;
+            } else if (E.vec4)
                 rp_dot_rows_v4<R, U, true>(RowDotArgs{E.W, E.ld, E.n, P.rows, P.row0, E.src}, row_base, lane, es);
             else
                 rp_dot_rows_s1<R>(RowDotArgs{E.W, E.ld, E.n, P.rows, P.row0, E.src}, row_base, lane, es);
@@ -330,11 +358,13 @@ __global__ __launch_bounds__(kThreads) void step_edges_kernel(const StepParams P
 // rings, never from a state vector this launch updates.  A workgroup belongs to one member (first_block); the member's
 // argument block is read in place, at a runtime offset into the kernel arguments.
 constexpr int kMergeMax = 4;
+constexpr int kMergeMaxEdges = 4;  // (edges into one member of the shared launch: merged_rows selects among four descriptors)
 struct MergedParams {
     int count;
     int first_block[kMergeMax + 1];
     StepParams P[kMergeMax];
 };
+static_assert(sizeof(MergedParams) <= 4000, "the argument block of step_merged_kernel must fit the kernel-argument segment");
 
 template <int MODEL, int R, int U>
 __device__ __forceinline__ void merged_rows(const StepParams& P, int block) {
@@ -409,8 +439,6 @@ __global__ __launch_bounds__(kThreads) void step_kernel_tuning_probe(const StepP
 // An edge matrix of a coupled member in packed form (rp_run.edge_sp): the sparse kernels below with this pseudo-model form
 // the edge's row sums -- the bits of the dense row dot, as for a packed W -- and chain them in edge order,
 // E = (E_0 + E_1) + ..., the last one adding the member's own input: I = x + E (the epilogue's order).
-constexpr int kModelEdgeSum = 64;
-
 __device__ __forceinline__ void edge_sum_result(const StepParams& P, int i, float wsum) {
     float e = P.esum_prev ? P.esum_prev[i] + wsum : wsum;
     if (P.esum_final && P.x_mode != RP_X_NONE) e = input_current(P, i) + e;
@@ -712,6 +740,14 @@ int validate_net(const rp_net* net) {
     if (!net) RP_FAIL(RP_ERR_ARG, "net is null");
     if (net->model < RP_MODEL_LI_TANH || net->model >= RP_MODEL_COUNT)
         RP_FAIL(RP_ERR_ARG, "unknown model id %d", net->model);
+    if (net->model == RP_MODEL_INSTANT) {  // an activation node: no matrix, no state, no parameters -- its output ping-pong only
+        if (net->n <= 0 || net->rows != net->n || net->row0 != 0) RP_FAIL(RP_ERR_SHAPE, "an activation-node member has rows == n, row0 == 0 (n=%d rows=%d row0=%d)", net->n, net->rows, net->row0);
+        if (net->act != RP_ACT_IDENTITY && net->act != RP_ACT_TANH && net->act != RP_ACT_SIGMOID) RP_FAIL(RP_ERR_ARG, "bad rp_net.act %d", net->act);
+        if (!net->src[0] || !net->src[1] || net->src[0] == net->src[1]) RP_FAIL(RP_ERR_ARG, "src[0], src[1] must be two distinct buffers");
+        if (net->cur != 0 && net->cur != 1) RP_FAIL(RP_ERR_ARG, "cur must be 0 or 1");
+        if (net->sp_vals) RP_FAIL(RP_ERR_ARG, "an activation-node member has no matrix (sp_vals)");
+        return RP_OK;
+    }
     if ((net->model == RP_MODEL_QIF_SFA || net->model >= RP_MODEL_IK) && !net->y[RP_Y_AUX])
         RP_FAIL(RP_ERR_ARG, "model %d needs the second state vector y[1]", net->model);
     if (net->model == RP_MODEL_IK_BIEXP && !net->y[RP_Y_AUX2])
@@ -763,6 +799,7 @@ void fill_static(StepParams& P, const rp_net* net) {
     P.sp_batches = net->sp_batches;
     P.model = net->model;
     P.vec4 = use_vec4(net) ? 1 : 0;
+    P.act = net->act;
 }
 
 #ifdef RP_MEASUREMENT
@@ -906,8 +943,9 @@ void launch_edges_cfg(const StepParams& P, hipStream_t st, int max_blocks) {
 
 template <int MODEL>
 void launch_step_edges(const StepParams& P, hipStream_t st, bool vec4) {
-    int64_t cols = P.n;
-    for (int e = 0; e < P.n_edges; ++e) cols += P.edge[e].n;
+    int64_t cols = MODEL == RP_MODEL_INSTANT ? 0 : P.n;
+    for (int e = 0; e < P.n_edges; ++e) cols += P.edge[e].W ? P.edge[e].n : 1;
+    if (cols < 1) cols = 1;
     StreamCfg cfg = static_cfg(P.rows, (int)std::min<int64_t>(cols, 1 << 30));
 #ifdef RP_MEASUREMENT
     if (g_tune_R > 0) cfg = StreamCfg{g_tune_R, g_tune_U, g_tune_blocks};  // sweep (rp_set_tuning)
@@ -935,6 +973,7 @@ void launch_step_edges_model(int model, const StepParams& P, hipStream_t st, boo
         case RP_MODEL_LIF: launch_step_edges<RP_MODEL_LIF>(P, st, vec4); break;
         case RP_MODEL_IK: launch_step_edges<RP_MODEL_IK>(P, st, vec4); break;
         case RP_MODEL_IKU: launch_step_edges<RP_MODEL_IKU>(P, st, vec4); break;
+        case RP_MODEL_INSTANT: launch_step_edges<RP_MODEL_INSTANT>(P, st, vec4); break;
         default: launch_step_edges<RP_MODEL_IK_BIEXP>(P, st, vec4); break;
     }
 }
@@ -1063,15 +1102,28 @@ int check_run(const rp_net* net, const rp_run* run, bool coupled) {
             RP_FAIL(RP_ERR_ARG, "sp_block_rows must be in [0, 64], without the windowed form and with n <= %d", kSparseLdsMaxN);
     }
     if (run->n_edges < 0 || run->n_edges > RP_MAX_EDGES) RP_FAIL(RP_ERR_ARG, "n_edges must be in [0, %d]", RP_MAX_EDGES);
+    if (net->model == RP_MODEL_INSTANT && (run->x_mode == RP_X_PROJ || run->hist[0] || run->save_src || run->save_acc ||
+                                           run->save_state[0] || run->spike_count || any_rec))
+        RP_FAIL(RP_ERR_ARG, "an activation-node member takes x (full / broadcast), edges, traj, samples and save_in only");
     for (int e = 0; e < run->n_edges; ++e) {
-        if (!run->edge_w[e] || run->edge_n[e] < 1 || run->edge_ld[e] < run->edge_n[e])
-            RP_FAIL(RP_ERR_SHAPE, "edge %d needs edge_w, edge_n >= 1 and edge_ld >= edge_n", e);
-        const bool v4 = run->edge_n[e] % 4 == 0 && run->edge_ld[e] % 4 == 0;
+        if (!run->edge_w[e]) {  // the identity edge
+            if (run->edge_n[e] != net->rows) RP_FAIL(RP_ERR_SHAPE, "edge %d: an identity edge (edge_w == NULL) needs edge_n == rows", e);
+            if (run->edge_sp[e].vals) RP_FAIL(RP_ERR_ARG, "edge %d: an identity edge has no packed form", e);
+        } else if (run->edge_n[e] < 1 || run->edge_ld[e] < run->edge_n[e])
+            RP_FAIL(RP_ERR_SHAPE, "edge %d needs edge_n >= 1 and edge_ld >= edge_n", e);
+        const bool v4 = run->edge_w[e] && run->edge_n[e] % 4 == 0 && run->edge_ld[e] % 4 == 0;
         if (v4 && !aligned16(run->edge_w[e])) RP_FAIL(RP_ERR_ARG, "edge %d: edge_w must be 16-byte aligned", e);
         if (!coupled) {
             if (!run->edge_src[e]) RP_FAIL(RP_ERR_ARG, "edge %d has no source vector", e);
             if (v4 && (!aligned16(run->edge_src[e]) || run->edge_src_ld[e] % 4 != 0))
                 RP_FAIL(RP_ERR_ARG, "edge %d: edge_src / edge_src_ld must be 16-byte aligned", e);
+        }
+        const rp_edge_mem& M = run->edge_mem[e];
+        if (M.kind != RP_EMEM_NONE) {
+            const int rc = rp_internal_edge_mem_check(&M);
+            if (rc != RP_OK) return rc;
+            if (M.n != run->edge_n[e]) RP_FAIL(RP_ERR_SHAPE, "edge %d: edge_mem.n = %d, edge_n = %d", e, M.n, run->edge_n[e]);
+            if (M.kind != RP_EMEM_FILTER && !M.u) RP_FAIL(RP_ERR_ARG, "edge %d: edge_mem.u is required", e);
         }
     }
     if ((run->hist[0] == nullptr) != (run->hist[1] == nullptr) || (run->hist[0] == nullptr) != (run->hist[2] == nullptr))
@@ -1107,7 +1159,7 @@ void init_params(StepParams& P, const rp_net* net, const rp_run* run) {
         P.edge[e].W = run->edge_w[e];
         P.edge[e].ld = run->edge_ld[e];
         P.edge[e].n = run->edge_n[e];
-        P.edge[e].vec4 = (run->edge_n[e] % 4 == 0 && run->edge_ld[e] % 4 == 0) ? 1 : 0;
+        P.edge[e].vec4 = (run->edge_w[e] && run->edge_n[e] % 4 == 0 && run->edge_ld[e] % 4 == 0) ? 1 : 0;
         P.edge[e].src = nullptr;
     }
 }
@@ -1151,7 +1203,7 @@ void set_step(StepParams& P, const rp_net* net, rp_run* run, int t) {
 int launch_population_step(const rp_net* net, const StepParams& P, hipStream_t st, const StreamCfg& cfg, bool vec4) {
     if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP)
         hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(1024), 0, st, P);
-    if (P.n_edges > 0) {
+    if (P.n_edges > 0 || net->model == RP_MODEL_INSTANT) {
         launch_step_edges_model(net->model, P, st, vec4);
     } else if (net->sp_vals) {
         const int src_rc = launch_step_sparse_model(net->model, P, st);
@@ -1205,7 +1257,13 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     for (int t = 0; t < run->steps; ++t) {
         const int64_t t_abs = run->step0 + t;
         set_step(P, net, run, t);
-        for (int e = 0; e < run->n_edges; ++e) P.edge[e].src = run->edge_src[e] + (int64_t)t * run->edge_src_ld[e];
+        for (int e = 0; e < run->n_edges; ++e) {
+            P.edge[e].src = run->edge_src[e] + (int64_t)t * run->edge_src_ld[e];
+            if (run->edge_mem[e].kind != RP_EMEM_NONE) {  // the edge's memory first: x -> u
+                rc = rp_internal_edge_mem_step(&run->edge_mem[e], P.edge[e].src, &P.edge[e].src, st);
+                if (rc != RP_OK) return rc;
+            }
+        }
         if (direct)  // every peer has pushed step seq (and is done with the buffer this step pushes into)
             for (int p = 0; p < comm->world; ++p)
                 if (p != comm->rank)
@@ -1253,7 +1311,7 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
 
 // rp_forward_coupled: the members' steps interleaved, one launch per member and Euler step
 int coupled_impl(rp_member* mem, int32_t count, void* stream) {
-    constexpr int kMaxMembers = 16;
+    constexpr int kMaxMembers = RP_MAX_MEMBERS;
     if (!mem || count < 1 || count > kMaxMembers) RP_FAIL(RP_ERR_ARG, "rp_forward_coupled: 1..%d members", kMaxMembers);
     for (int m = 0; m < count; ++m) {
         if (!mem[m].net || !mem[m].run) RP_FAIL(RP_ERR_ARG, "member %d: net / run is null", m);
@@ -1282,9 +1340,10 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
                 RP_FAIL(RP_ERR_SHAPE, "member %d edge %d has %d columns, its source holds %d neurons", m, e, run->edge_n[e], mem[q].net->n);
             if (mode == RP_EDGE_OUT && q >= m)
                 RP_FAIL(RP_ERR_ARG, "member %d edge %d: RP_EDGE_OUT needs a source stepped earlier (source %d)", m, e, q);
-            if (mode == RP_EDGE_LIVE && q == m && qrun->out_var == RP_OUT_STATE0)
+            const bool q_instant = mem[q].net->model == RP_MODEL_INSTANT;  // (read through src[cur], whatever the mode)
+            if (mode == RP_EDGE_LIVE && q == m && qrun->out_var == RP_OUT_STATE0 && !q_instant)
                 RP_FAIL(RP_ERR_ARG, "member %d edge %d: a population cannot read its own state while it is stepped", m, e);
-            if ((mode == RP_EDGE_LAG || (mode == RP_EDGE_OUT && qrun->out_var == RP_OUT_STATE0)) && !qrun->hist[0])
+            if (!q_instant && (mode == RP_EDGE_LAG || (mode == RP_EDGE_OUT && qrun->out_var == RP_OUT_STATE0)) && !qrun->hist[0])
                 RP_FAIL(RP_ERR_ARG, "member %d edge %d: source %d needs rp_run.hist", m, e, q);
             // every vector this edge can be pointed at
             const bool state_out = qrun->out_var == RP_OUT_STATE0;
@@ -1292,7 +1351,9 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
             if (qrun->hist[0]) ok16 = aligned16(qrun->hist[0]) && aligned16(qrun->hist[1]) && aligned16(qrun->hist[2]);
             ok16 = ok16 && aligned16(mem[q].net->y[RP_Y_V]) && aligned16(mem[q].net->src[0]) && aligned16(mem[q].net->src[1]);
             (void)state_out;
-            if (run->edge_n[e] % 4 == 0 && run->edge_ld[e] % 4 == 0 && !ok16)
+            if (run->edge_mem[e].kind != RP_EMEM_NONE && run->edge_mem[e].n % 4 == 0 && !ok16)
+                RP_FAIL(RP_ERR_ARG, "member %d edge %d: the source vectors must be 16-byte aligned", m, e);
+            if (run->edge_w[e] && run->edge_n[e] % 4 == 0 && run->edge_ld[e] % 4 == 0 && !ok16)
                 RP_FAIL(RP_ERR_ARG, "member %d edge %d: the source vectors must be 16-byte aligned", m, e);
         }
     }
@@ -1317,9 +1378,12 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
     for (int m = 0; m < count && merged; ++m) {
         const rp_net* net = mem[m].net;
         max_rows = std::max(max_rows, net->rows);
-        if (net->rows > 4096 || net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP) merged = false;
+        if (net->rows > 4096 || net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP || net->model == RP_MODEL_INSTANT ||
+            mem[m].run->n_edges > kMergeMaxEdges)
+            merged = false;
         for (int e = 0; e < mem[m].run->n_edges && merged; ++e) {
             const int q = mem[m].edge_source[e], mode = mem[m].edge_mode[e];
+            if (!mem[m].run->edge_w[e] || mem[m].run->edge_mem[e].kind != RP_EMEM_NONE) merged = false;
             if (mode == RP_EDGE_LIVE && q < m) merged = false;
             if (mode != RP_EDGE_LAG && mem[q].run->out_var == RP_OUT_STATE0 && !mem[q].run->hist[0]) merged = false;
         }
@@ -1366,6 +1430,9 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
                 const rp_net* qn = mem[q].net;
                 const rp_run* qr = mem[q].run;
                 const bool state_out = qr->out_var == RP_OUT_STATE0;
+                if (qn->model == RP_MODEL_INSTANT) {  // an activation node's output as it stands: this step's if q was stepped, else the last one
+                    P[m].edge[e].src = qn->src[qn->cur];
+                } else
                 switch (mem[m].edge_mode[e]) {
                     case RP_EDGE_LIVE:  // qn->cur names q's CURRENT source buffer: flipped already if q < m (never when merged)
                         P[m].edge[e].src = state_out ? (merged ? qr->hist[t_abs % 3] : qn->y[RP_Y_V]) : qn->src[qn->cur];
@@ -1376,6 +1443,10 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
                     default:            // RP_EDGE_LAG
                         P[m].edge[e].src = qr->hist[(t_abs + 2) % 3];
                         break;
+                }
+                if (run->edge_mem[e].kind != RP_EMEM_NONE) {  // the edge's memory first: x -> u (never in the shared launch)
+                    const int rc = rp_internal_edge_mem_step(&run->edge_mem[e], P[m].edge[e].src, &P[m].edge[e].src, st);
+                    if (rc != RP_OK) return rc;
                 }
             }
             if (!merged && packed[m]) {
@@ -1468,6 +1539,27 @@ int rp_internal_packed_matvec(const rp_packed* M, int n, int rows, const float* 
     E.esum_final = 0;
     E.x_mode = RP_X_NONE;
     return launch_step_sparse_model(kModelEdgeSum, E, st);
+}
+
+// (declared in rp_common.h) dst[i] = (F src)_i (+ x[i]) with the recurrent row dot's summation tree and streaming walk: the
+// recursive filter of an edge with memory (rnn_edges.hip)
+int rp_internal_filter_matvec(const float* F, int64_t ldf, int n, const float* src, const float* x, float* dst, hipStream_t st) {
+    StepParams P = {};
+    P.W = F;
+    P.ldw = ldf;
+    P.n = n;
+    P.rows = n;
+    P.src_cur = src;
+    P.src_next = dst;
+    P.x_mode = x ? RP_X_FULL : RP_X_NONE;
+    P.x_t = x;
+    const StreamCfg cfg = static_cfg(n, n);
+    if (n % 4 == 0 && ldf % 4 == 0) {  // (which path is taken is part of the summation order: never decided by an address)
+        if (!aligned16(F) || !aligned16(src)) RP_FAIL(RP_ERR_ARG, "edge filter: F and the state vectors must be 16-byte aligned");
+        launch_step<kModelFilter, true>(P, st, cfg);
+    } else
+        launch_step<kModelFilter, false>(P, st, cfg);
+    return RP_OK;
 }
 
 extern "C" {

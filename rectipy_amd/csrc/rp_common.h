@@ -144,3 +144,10 @@ __device__ __forceinline__ int rp_rows_allreduce_row(int lane) {
 // step kernels' row dots with a pass-through "epilogue" (rnn_forward.hip; used by rp_forward_coupled and rp_backward_coupled)
 struct rp_packed;
 int rp_internal_packed_matvec(const rp_packed* M, int n, int rows, const float* s, const float* prev, float* out, hipStream_t st);
+
+// edges with memory (rp_edge_mem, rnn_edges.hip): argument check; one step of the stage on the vector x -- *u receives the
+// stage's output vector (DELAY / DELAY_FILTER: M->u; FILTER: the new state); the row-dot mat-vec of the filter (rnn_forward.hip)
+struct rp_edge_mem;
+int rp_internal_edge_mem_check(const rp_edge_mem* M);
+int rp_internal_edge_mem_step(rp_edge_mem* M, const float* x, const float** u, hipStream_t st);
+int rp_internal_filter_matvec(const float* F, int64_t ldf, int n, const float* src, const float* x, float* dst, hipStream_t st);

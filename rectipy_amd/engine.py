@@ -183,6 +183,10 @@ class HipBackend:
         with self._on(device):
             self._check(self.lib.rp_forward_batched(C.byref(net), C.byref(batch), self._stream(device)))
 
+    def edge_window(self, mem, steps, X, ldx, U, ldu, device):
+        with self._on(device):
+            self._check(self.lib.rp_edge_window(C.byref(mem), steps, X, ldx, U, ldu, self._stream(device)))
+
     def rls_sweep(self, rls, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, device):
         with self._on(device):
             self._check(self.lib.rp_rls_sweep(C.byref(rls), steps, stride, X, ldx, Y, ldy, pred, ldpred, loss,
@@ -445,6 +449,8 @@ class Population:
         self.cur = net.cur
         if sampling:
             self.acc_count = run.acc_count
+        for e, mem in getattr(run, "_mems", ()):  # the stages of edges with memory flipped their state buffers
+            mem.cur = run.edge_mem[e].cur
         del keep
         return int(run.sample_idx)
 
@@ -564,17 +570,29 @@ class Population:
                     if getattr(self, "_edge_sum", None) is None:
                         self._edge_sum = torch.zeros(self.rows, dtype=torch.float32, device=self.device)
                     run.edge_sum = self._edge_sum.data_ptr()
-                if We.dtype != torch.float32 or We.device != self.device or We.dim() != 2 or We.shape[0] != self.rows \
-                        or We.stride(1) != 1:
-                    raise RuntimeError(f"edge {e}: weights must be a float32 [{self.rows}, n_e] row-major tensor on {self.device}")
-                keep.append(We)
-                run.edge_w[e], run.edge_ld[e], run.edge_n[e] = We.data_ptr(), We.stride(0), We.shape[1]
+                mem = edge[3] if len(edge) > 3 else None  # the edge's memory (EdgeMemory): delay buffer / recursive filter
+                if We is None:  # the identity edge: E_e = s_e
+                    run.edge_w[e], run.edge_ld[e], run.edge_n[e] = None, self.rows, self.rows
+                    n_e = self.rows
+                else:
+                    if We.dtype != torch.float32 or We.device != self.device or We.dim() != 2 or We.shape[0] != self.rows \
+                            or We.stride(1) != 1:
+                        raise RuntimeError(f"edge {e}: weights must be a float32 [{self.rows}, n_e] row-major tensor on {self.device}")
+                    keep.append(We)
+                    run.edge_w[e], run.edge_ld[e], run.edge_n[e] = We.data_ptr(), We.stride(0), We.shape[1]
+                    n_e = We.shape[1]
+                if mem is not None:
+                    if mem.n != n_e:
+                        raise RuntimeError(f"edge {e}: its memory holds {mem.n} channels, the edge has {n_e} columns")
+                    mem.fill(run.edge_mem[e])
+                    keep.append(mem)
+                    run._mems = getattr(run, "_mems", []) + [(e, mem)]
                 if se is None:
                     continue
                 se = se.detach()
-                if se.dtype != torch.float32 or se.device != self.device or se.shape[-1] != We.shape[1] or se.stride(-1) != 1 \
+                if se.dtype != torch.float32 or se.device != self.device or se.shape[-1] != n_e or se.stride(-1) != 1 \
                         or se.dim() not in (1, 2) or (se.dim() == 2 and se.shape[0] < steps):
-                    raise RuntimeError(f"edge {e}: the source must be a float32 [{We.shape[1]}] or [steps, {We.shape[1]}] tensor")
+                    raise RuntimeError(f"edge {e}: the source must be a float32 [{n_e}] or [steps, {n_e}] tensor")
                 keep.append(se)
                 run.edge_src[e] = se.data_ptr()
                 run.edge_src_ld[e] = 0 if se.dim() == 1 else (se.stride(0) if se.shape[0] > 1 else se.shape[1])
@@ -708,14 +726,136 @@ class Population:
         return out
 
 
+class InstantPopulation(Population):
+    """A memory-less activation node BETWEEN populations (reference ``InstantNode``, rectipy/nodes.py:14-51) as a member
+    of a coupled call (RP_MODEL_INSTANT): no state, no recurrent matrix -- its step is ``out = act(I)`` with I the node
+    input of the step (edge sums, plus an external input if it has one).  With ``act="identity"`` and identity edges it
+    also carries the partial sum of an edge list longer than RP_MAX_EDGES.  ``source`` is the node's last output."""
+
+    ACTS = {"identity": _abi.RP_ACT_IDENTITY, "tanh": _abi.RP_ACT_TANH, "sigmoid": _abi.RP_ACT_SIGMOID}
+
+    def __init__(self, n: int, act: str, device, backend=None):
+        if act not in self.ACTS:
+            raise ValueError(f"activation '{act}' has no in-kernel form; available: {sorted(self.ACTS)}")
+        self.model, self.act = "instant", act
+        self.device = torch.device(device)
+        self.backend = backend if backend is not None else default_backend()
+        self.backend.check_device(self.device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.rows = self.n = int(n)
+        self.row0 = 0
+        self.W = self.v = self.aux = self.aux2 = self.packed = self.packed_t = None
+        self.params = {}
+        self.dt, self.theta, self.v_reset = 1.0, 0.0, 0.0
+        self.spiking = False
+        self.src = [torch.zeros(self.n, **f32), torch.zeros(self.n, **f32)]
+        self.cur = 0
+        self.acc = torch.zeros(self.rows, **f32)
+        self.acc_count = 0
+        self.tune, self._tuned = False, True
+        self._net_struct = None
+
+    def _sync_packed(self):
+        pass
+
+    def refresh(self):
+        pass
+
+    def _net(self) -> RpNet:
+        if self._net_struct is None:
+            net = RpNet()
+            net.model, net.act = _abi.RP_MODEL_INSTANT, self.ACTS[self.act]
+            net.n = net.rows = self.n
+            net.ldw = self.n
+            net.src[0], net.src[1] = self.src[0].data_ptr(), self.src[1].data_ptr()
+            net.dt = 1.0
+            self._net_struct = net
+        self._net_struct.cur = self.cur
+        return self._net_struct
+
+
+class EdgeMemory:
+    """Device state of the MEMORY of a stateful edge -- the delay buffer of ``LinearMemory``, the recursive filter of
+    ``LinearFilter``, both for ``LinearMemoryFilter`` (reference rectipy/edges.py:68-147) -- as an ``rp_edge_mem``: the stage
+    in front of the edge's projection, advanced by the library once per step (rp_run.edge_mem inside rp_forward /
+    rp_forward_coupled; :meth:`window` = rp_edge_window for an acyclic edge, whose source window is known in advance).
+
+    ``state``: DELAY [depth] (the buffer's common row), FILTER [n], DELAY_FILTER [depth, n] (row c = column c of the
+    reference's buffer)."""
+
+    KINDS = {"delay": _abi.RP_EMEM_DELAY, "filter": _abi.RP_EMEM_FILTER, "delay_filter": _abi.RP_EMEM_DELAY_FILTER}
+
+    def __init__(self, kind: str, n: int, device, backend=None, F: Optional[torch.Tensor] = None, depth: int = 0,
+                 col_chan=None):
+        self.kind, self.n, self.depth = kind, int(n), int(depth)
+        self.device = torch.device(device)
+        self.backend = backend if backend is not None else default_backend()
+        self.backend.check_device(self.device)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        shape = {"delay": (self.depth,), "filter": (self.n,), "delay_filter": (self.depth, self.n)}[kind]
+        self.state = [torch.zeros(shape, **f32), torch.zeros(shape, **f32)]
+        self.cur = 0
+        self.u = torch.zeros(self.n, **f32)
+        self.F = None
+        if kind != "delay":
+            self.set_filter(F)
+        self.col_chan = self.col_chan_host = None
+        if kind != "filter":
+            cc = np.ascontiguousarray(np.asarray(col_chan, dtype=np.int32).reshape(-1))
+            if cc.shape[0] != self.depth:
+                raise RuntimeError(f"col_chan has {cc.shape[0]} entries, the delay buffer {self.depth} columns")
+            self.col_chan_host = cc
+            self.col_chan = torch.as_tensor(cc, device=self.device)
+
+    def set_filter(self, F: torch.Tensor):
+        F = F.detach().to(dtype=torch.float32, device=self.device)
+        if tuple(F.shape) != (self.n, self.n):
+            raise RuntimeError(f"filter weights {tuple(F.shape)} do not match the edge's {self.n} inputs")
+        self.F = F if F.stride(1) == 1 else F.contiguous()
+
+    @property
+    def current(self) -> torch.Tensor:
+        return self.state[self.cur]
+
+    def load(self, state: torch.Tensor):
+        self.state[self.cur].copy_(state.detach().to(dtype=torch.float32, device=self.device).reshape(self.state[0].shape))
+
+    def fill(self, m: "_abi.RpEdgeMem"):
+        m.kind, m.n, m.depth = self.KINDS[self.kind], self.n, self.depth
+        if self.col_chan is not None:
+            m.col_chan, m.col_chan_host = self.col_chan.data_ptr(), self.col_chan_host.ctypes.data
+        if self.F is not None:
+            m.F, m.ldf = self.F.data_ptr(), self.F.stride(0)
+        m.state[0], m.state[1] = self.state[0].data_ptr(), self.state[1].data_ptr()
+        m.cur = self.cur
+        m.u = self.u.data_ptr()
+
+    def window(self, X: torch.Tensor) -> torch.Tensor:
+        """U [T, n]: the stage's output for the T consecutive inputs X[t]; the state moves on by T steps."""
+        T = int(X.shape[0])
+        X = X.detach().to(dtype=torch.float32, device=self.device)
+        if X.dim() != 2 or X.shape[1] != self.n:
+            raise RuntimeError(f"the edge's memory takes [T, {self.n}] inputs, got {tuple(X.shape)}")
+        if X.stride(1) != 1:
+            X = X.contiguous()
+        ld = (self.n + 3) // 4 * 4   # (16-byte aligned rows: a wide filter reads row t - 1 as its source vector)
+        U = torch.empty(T, ld, dtype=torch.float32, device=self.device)
+        m = _abi.RpEdgeMem()
+        self.fill(m)
+        self.backend.edge_window(m, T, X.data_ptr(), X.stride(0) if T > 1 else self.n, U.data_ptr(), ld, self.device)
+        self.cur = m.cur
+        return U[:, :self.n]
+
+
 def forward_coupled(members: list) -> list:
     """One library call for a whole window of SEVERAL populations joined by dense edges (rp_forward_coupled): every
     Euler step steps the populations in list order, one launch each, the edge products inside the step kernels.
 
-    ``members``: dicts with ``pop`` (:class:`Population`), ``run`` (keyword arguments of :meth:`Population.forward`
-    without ``edges`` / ``comm``) and ``edges``: ``[(W_e [rows, n_source], source member index, RP_EDGE_* mode)]``, optionally
-    with the edge matrix's packed form (``sparse.PackedRows``) as a fourth entry: a member whose W is packed and whose edges
-    all carry one streams only the stored nonzeros (rp_run.edge_sp; same bits).
+    ``members``: dicts with ``pop`` (:class:`Population`, or :class:`InstantPopulation` for an activation node between
+    populations), ``run`` (keyword arguments of :meth:`Population.forward` without ``edges`` / ``comm``) and ``edges``:
+    ``[(W_e [rows, n_source] | None = identity, source member index, RP_EDGE_* mode)]``, optionally with the edge matrix's
+    packed form (``sparse.PackedRows``) as a fourth entry -- a member whose W is packed and whose edges all carry one streams
+    only the stored nonzeros (rp_run.edge_sp; same bits) -- and the edge's memory (:class:`EdgeMemory`) as a fifth.
     Returns the next sample index of every member."""
     count = len(members)
     arr = (_abi.RpMember * count)()
@@ -723,13 +863,19 @@ def forward_coupled(members: list) -> list:
     for m, spec in enumerate(members):
         pop: Population = spec["pop"]
         edges = spec.get("edges") or []
-        run, keep, sampling = pop._make_run(edges=[(edge[0], None, edge[3] if len(edge) > 3 else None) for edge in edges], **spec["run"])
+        run, keep, sampling = pop._make_run(edges=[(edge[0], None, edge[3] if len(edge) > 3 else None, edge[4] if len(edge) > 4 else None)
+                                                   for edge in edges], **spec["run"])
         net = pop._net()
         for e, edge in enumerate(edges):
             arr[m].edge_source[e], arr[m].edge_mode[e] = int(edge[1]), int(edge[2])
         arr[m].net, arr[m].run = C.pointer(net), C.pointer(run)
         built.append((pop, net, run, sampling, keep))
     first = members[0]["pop"]
+    if any(spec["pop"].device != first.device for spec in members):
+        raise RuntimeError("the members of a coupled call must live on one device: " +
+                           ", ".join(sorted({str(spec["pop"].device) for spec in members})))
+    if count > _abi.RP_MAX_MEMBERS:
+        raise RuntimeError(f"at most {_abi.RP_MAX_MEMBERS} members per coupled call, got {count}")
     first.backend.forward_coupled(arr, count, first.device)
     return [pop._finish_run(net, run, sampling, keep) for pop, net, run, sampling, keep in built]
 
