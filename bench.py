@@ -873,7 +873,8 @@ def stepwise_extra(dev):
     """What the paths cost that advance ONE Euler step per call (us per step, wall clock incl. the Python graph walk), at
     N = 4096 and N = 32768: (i) a user loop over net.forward(x) (reference rectipy_tests/test_network.py:327-333);
     (ii) inp -> LinearMemoryFilter -> rnn through Network.run -- r03: the edge is evaluated per window, so the population
-    takes the fused-window plan; the same graph forced onto the step-by-step walk is what r02 paid; (iii) a
+    takes the fused-window plan (r05: the edge's memory is one single-workgroup launch per window, rp_edge_window); the same
+    graph forced onto the step-by-step walk is what r02 paid; (iii) a
     FeedbackNetwork of two populations of N/2 neurons (a -> b, feedback b -> a; dense N/2 x N/2 edges) -- r04: one
     rp_forward_coupled call per window, both edge matrices streamed by the targets' step kernels (r03: a Python walk per
     step with the edge products in rocBLAS); the same graph forced onto the per-step walk is reported next to it; (iv) the
@@ -947,6 +948,29 @@ def stepwise_extra(dev):
                 lambda steps: fb.run(x_h[:steps], sampling_steps=steps, verbose=False, enable_grad=False), T)
             del fb
             torch.cuda.empty_cache()
+            # (iii-b) r05: the same pair with memory / an activation node on the feed-forward path, inside the library call:
+            #   a -(LinearFilter: y <- F y + x, F as large as a recurrent matrix)-> b: five matrices of (N/2)^2 per step
+            #   a -> tanh node -> b: the activation node is a member of the call, its two edge matrices stream like the rest
+            for key, build in (
+                ("feedback_pair_with_LinearFilter_edge",
+                 lambda f: f.add_edge("a", "b", weights=gen_rows(h, 0, h, dev, g=0.5), filter_weights=gen_rows(h, 0, h, dev, g=0.5))),
+                ("feedback_pair_with_tanh_node_between",
+                 lambda f: (f.add_func_node("mid", h, "tanh"), f.add_edge("a", "mid", weights=gen_rows(h, 0, h, dev, g=0.5)),
+                            f.add_edge("mid", "b", weights=gen_rows(h, 0, h, dev, g=0.5))))):
+                fb = FeedbackNetwork(dt=1e-2, device=str(dev))
+                fb.add_diffeq_node("a", tanh, **node_kw(gen_rows(h, 0, h, dev)))
+                fb.add_diffeq_node("b", tanh, **node_kw(gen_rows(h, 0, h, dev)))
+                build(fb)
+                fb.add_edge("b", "a", weights=gen_rows(h, 0, h, dev, g=0.5), feedback=True)
+                rec[key] = timed(lambda steps: fb.run(x_h[:steps], sampling_steps=steps, verbose=False, enable_grad=False), T)
+                rec[key + "_per_matrix"] = rec[key] / 5
+                if N <= 4096:
+                    fb._force_stepwise = True
+                    rec[key + "_step_by_step_walk"] = timed(
+                        lambda steps: fb.run(x_h[:steps], sampling_steps=steps, verbose=False, enable_grad=False), T)
+                del fb
+                torch.cuda.empty_cache()
+            rec["feedback_two_populations_per_matrix"] = rec["feedback_two_populations_of_N_over_2"] / 4
             # (iv) the two populations trained through the cycle
             train_kw = lambda Wm: dict(node_kw(Wm), train_params=["weights"])
             y_h = torch.randn(T, 3, device=dev, generator=gen) * 0.1

@@ -5,7 +5,7 @@ the arithmetic runs in hand-written gfx950 kernels behind the C ABI of ``include
 """
 __version__ = "0.1.0"
 
-from .network import Network
+from .network import Network, PerformanceWarning
 from .observer import Observer
 from .nodes import InstantNode, MultiSpikeResetNet, RateNet, Spike, SpikeNet, SpikeResetNet
 from .edges import Linear
@@ -13,6 +13,6 @@ from .feedback import FeedbackNetwork
 from .connectivity import (circular_connectivity, input_connections, line_connectivity, normalize,
                            random_connectivity, wta_score)
 
-__all__ = ["Network", "FeedbackNetwork", "Observer", "RateNet", "SpikeNet", "SpikeResetNet", "MultiSpikeResetNet", "Spike", "InstantNode", "Linear",
+__all__ = ["Network", "PerformanceWarning", "FeedbackNetwork", "Observer", "RateNet", "SpikeNet", "SpikeResetNet", "MultiSpikeResetNet", "Spike", "InstantNode", "Linear",
            "random_connectivity", "circular_connectivity", "line_connectivity", "input_connections", "normalize",
            "wta_score"]

@@ -4,9 +4,11 @@ follows the reference's ``forward`` methods, including the delay-buffer indexing
 
 On an ACYCLIC edge such a map is a causal function of the source's window: ``forward_window(X[T, n_in])`` evaluates it
 for all T steps of a window (state carried across windows exactly as the per-step ``forward`` carries it), so the
-populations on either side still integrate as ONE fused window each (Network._edge_window).  The delay buffer has a
-closed form over the window; the recursive filters are T small matrix-vector products in step order -- the reference's
-own arithmetic, decoupled from the populations' kernel launches."""
+populations on either side still integrate as ONE fused window each (Network._edge_window).  The edge's MEMORY -- delay
+buffer, recursive filter -- is a device stage of the library (rp_edge_mem / rp_edge_window, rectipy_amd/csrc/rnn_edges.hip):
+one call per window on an acyclic edge, advanced once per Euler step inside rp_forward_coupled when the edge lies in a
+cycle (FeedbackNetwork).  The per-step ``forward`` methods below restate the reference's classes in torch and stay the
+path a gradient through the memory takes."""
 from typing import Union
 
 import numpy as np
@@ -26,6 +28,8 @@ def _square(filter_weights, n_in, dtype):
 
 class _Stateful(Linear):
     _extra = ()
+    _backend = None   # test seam (Network(backend=...)): the library backend of the edge's memory stage on CPU tensors
+    _stage_kind = None  # "delay" | "filter" | "delay_filter": the rp_edge_mem kind of the edge's memory (engine.EdgeMemory)
 
     def to(self, device: str, **kwargs):
         super().to(device, **kwargs)
@@ -33,43 +37,68 @@ class _Stateful(Linear):
             setattr(self, name, getattr(self, name).to(device))
         return self
 
-    HOST_RECURRENCE_MAX_N_IN = 64  # narrow edges (an input node's few channels): the T-step recurrence runs on the host
-    _state = ()  # the tensors `_advance` reads and replaces (besides its constants in `_extra`)
-
     def _advance(self, x: torch.Tensor) -> torch.Tensor:
         """One step of the edge's memory: takes the source's output x, returns the vector the projection is applied to."""
         raise NotImplementedError
 
+    # ---- the memory as a device stage (rp_edge_mem: include/rectipy_hip.h, rectipy_amd/csrc/rnn_edges.hip) ------------------
+    def _stage_state(self) -> torch.Tensor:
+        """The edge's memory in the stage's layout (engine.EdgeMemory)."""
+        raise NotImplementedError
+
+    def _stage_restore(self, state: torch.Tensor):
+        raise NotImplementedError
+
+    def _stage_args(self) -> dict:
+        return {}
+
+    def memory_stage(self, no_grad_input: bool = True):
+        """The edge's memory as an :class:`rectipy_amd.engine.EdgeMemory` loaded with the edge's current state, or None when
+        the library cannot take it: a gradient would have to pass through the memory, tensors that are neither float32 on
+        a GPU nor (tests) served by an injected backend, a delay buffer whose rows differ.  After the library has advanced
+        the stage, :meth:`stage_done` writes the state back into the edge's own tensors (`buffer`, `y`), so per-step
+        `forward` calls and library windows can alternate."""
+        if self._stage_kind is None or not no_grad_input:
+            return None
+        W = self.weights
+        if W.dtype != torch.float32 or (W.device.type != "cuda" and self._backend is None):
+            return None
+        state = self._stage_state()
+        if state is None:
+            return None
+        from .engine import EdgeMemory
+        mem = getattr(self, "_mem", None)
+        if mem is None or mem.device != W.device:
+            mem = EdgeMemory(self._stage_kind, self.n_in, W.device, backend=self._backend, **self._stage_args())
+            self._mem = mem
+        F = getattr(self, "filter", None)
+        if F is not None and (mem.F is None or mem.F.data_ptr() != F.data_ptr()):
+            mem.set_filter(F)
+        mem.load(state)
+        return mem
+
+    def stage_done(self, mem):
+        self._stage_restore(mem.current)
+
     def forward_window(self, X: torch.Tensor) -> torch.Tensor:
         """The edge's outputs for the T consecutive inputs X[t] ([T, n_in] -> [T, n_out]); the edge's state afterwards
-        is what T calls of ``forward`` leave behind.  Default: exactly those T calls.
+        is what T calls of ``forward`` leave behind.
 
-        On a GPU every call is a handful of tiny launches (~10 us each, whatever the size).  For a NARROW edge without a
-        gradient the T steps of the edge's MEMORY (delay buffer, recursive filter: a few KB) therefore run on host copies
-        of its tensors (microseconds per step), and the projection of the whole window is ONE product on the device.
-        Same formulas in float32; equal to the device loop up to the rounding order of the small matrix products."""
+        The T steps of the edge's MEMORY (delay buffer, recursive filter) are one library call (rp_edge_window): narrow edges
+        -- an input node's few channels -- one single-workgroup launch for the whole window, wide ones -- an edge between two
+        populations, whose filter matrix is as large as a recurrent one -- a streaming pass over the filter per step, issued
+        from C.  The projection of the window is ONE product on the device (a gradient with respect to the weights passes
+        through it).  Only when a gradient has to pass through the memory itself (an input that requires grad), or without
+        a GPU, the T calls of ``forward`` are made one by one."""
         T = X.shape[0]
         if T == 0:
             return X.new_zeros((0, self.weights.shape[0]))
-        narrow = X.is_cuda and X.shape[1] <= self.HOST_RECURRENCE_MAX_N_IN and T > 1 and not X.requires_grad and \
-            not self.weights.requires_grad and not any(getattr(self, n).requires_grad for n in self._extra
-                                                       if isinstance(getattr(self, n), torch.Tensor))
-        if not narrow:
+        mem = self.memory_stage(no_grad_input=not (X.requires_grad and torch.is_grad_enabled()))
+        if mem is None:
             return torch.stack([self.forward(X[t]) for t in range(T)])
-        dev = X.device
-        names = tuple(self._extra)
-        on_dev = {n: getattr(self, n) for n in names}
-        host = {n: t.detach().cpu() for n, t in on_dev.items()}
-        try:
-            for n, t in host.items():
-                setattr(self, n, t)
-            Xh = X.detach().cpu()
-            U = torch.stack([self._advance(Xh[t]) for t in range(T)])
-        finally:
-            for n in names:  # state the steps REPLACED (buffer, y) goes back to the device; everything else is the original object
-                cur = getattr(self, n)
-                setattr(self, n, on_dev[n] if cur is host[n] else cur.to(dev))
-        return U.to(device=dev, dtype=self.weights.dtype) @ self.weights.T
+        U = mem.window(X.detach())
+        self.stage_done(mem)
+        return U @ self.weights.T
 
 
 class LinearMasked(_Stateful):
@@ -112,6 +141,27 @@ class LinearMemory(_Stateful):
         self._cols = cols
         self._src = torch.stack([torch.nonzero(delays == c).max() for c in cols])
         super().__init__(n_in, n_out, weights=weights, dtype=dtype, detach=detach)
+
+    _stage_kind = "delay"
+
+    def _col_chan(self) -> np.ndarray:
+        """Per buffer column the input channel `buffer[:, delays] = x` leaves there (-1: none): rp_edge_mem.col_chan."""
+        cc = -np.ones(self.buffer.shape[1], dtype=np.int32)
+        cc[self._cols.cpu().numpy()] = self._src.cpu().numpy()
+        return cc
+
+    def _stage_args(self) -> dict:
+        return dict(depth=self.buffer.shape[1], col_chan=self._col_chan())
+
+    def _stage_state(self):
+        # the stage keeps ONE row of the buffer: every write goes to all rows alike, so the rows are identical unless
+        # someone set them apart
+        if not bool((self.buffer == self.buffer[:1]).all()):
+            return None
+        return self.buffer[0]
+
+    def _stage_restore(self, state):
+        self.buffer = state.to(self.buffer.dtype).reshape(1, -1).expand(self.buffer.shape[0], -1).contiguous()
 
     def _shift(self):
         return self.buffer.roll(-1, 1)
@@ -169,6 +219,17 @@ class LinearFilter(_Stateful):
         self.y = torch.zeros(n_in, dtype=dtype)
         super().__init__(n_in, n_out, weights=weights, dtype=dtype, detach=detach)
 
+    _stage_kind = "filter"
+
+    def _stage_args(self) -> dict:
+        return dict(F=self.filter)
+
+    def _stage_state(self):
+        return self.y
+
+    def _stage_restore(self, state):
+        self.y = state.to(self.y.dtype).clone()
+
     def _advance(self, x: torch.Tensor) -> torch.Tensor:
         self.y = self.filter @ self.y + x
         return self.y
@@ -187,6 +248,17 @@ class LinearMemoryFilter(LinearMemory):
                  dtype: torch.dtype = torch.float64, detach: bool = True, **kwargs):
         self.filter = _square(filter_weights, n_in, dtype)
         super().__init__(n_in, n_out, delays=delays, weights=weights, dtype=dtype, detach=detach)
+
+    _stage_kind = "delay_filter"
+
+    def _stage_args(self) -> dict:
+        return dict(F=self.filter, depth=self.buffer.shape[1], col_chan=self._col_chan())
+
+    def _stage_state(self):
+        return self.buffer.T   # row c of the stage = column c of the buffer
+
+    def _stage_restore(self, state):
+        self.buffer = state.to(self.buffer.dtype).T.contiguous()
 
     def _advance(self, x: torch.Tensor) -> torch.Tensor:
         """The reference's step, as its classes execute it (edges.py:143-146): the filtered buffer is shifted and x is

@@ -857,6 +857,7 @@ def forward_coupled(members: list) -> list:
     packed form (``sparse.PackedRows``) as a fourth entry -- a member whose W is packed and whose edges all carry one streams
     only the stored nonzeros (rp_run.edge_sp; same bits) -- and the edge's memory (:class:`EdgeMemory`) as a fifth.
     Returns the next sample index of every member."""
+    members, real = _chain_long_edge_lists(members)
     count = len(members)
     arr = (_abi.RpMember * count)()
     built = []
@@ -877,7 +878,53 @@ def forward_coupled(members: list) -> list:
     if count > _abi.RP_MAX_MEMBERS:
         raise RuntimeError(f"at most {_abi.RP_MAX_MEMBERS} members per coupled call, got {count}")
     first.backend.forward_coupled(arr, count, first.device)
-    return [pop._finish_run(net, run, sampling, keep) for pop, net, run, sampling, keep in built]
+    done = [pop._finish_run(net, run, sampling, keep) for pop, net, run, sampling, keep in built]
+    return [done[i] for i in real]
+
+
+def _chain_long_edge_lists(members: list):
+    """A member with more than RP_MAX_EDGES edges gets partial-sum members in front of it: identity activation nodes of its
+    width (InstantPopulation, cached on the population) that add the first RP_MAX_EDGES edges, then -- through an identity edge
+    from the previous partial sum -- the next RP_MAX_EDGES - 1, and so on; the member itself keeps an identity edge from the
+    last partial sum and the remaining edges.  E = ((E_0 + E_1) + ...) is continued from member to member in the same order,
+    so the node input has the bits of one long edge list.  Returns (members, positions of the caller's members)."""
+    K = _abi.RP_MAX_EDGES
+    if all(len(spec.get("edges") or []) <= K for spec in members):
+        return members, list(range(len(members)))
+    new_index, out = {}, []
+    for m, spec in enumerate(members):  # positions first: edges name their sources by index
+        edges = spec.get("edges") or []
+        extra = 0
+        left = len(edges)
+        if left > K:
+            extra, left = 1, left - K
+            while left + 1 > K:
+                extra, left = extra + 1, left - (K - 1)
+        new_index[m] = len(out) + extra
+        out.extend([None] * (extra + 1))
+    for m, spec in enumerate(members):
+        pop = spec["pop"]
+        edges = [(e[0], new_index[e[1]]) + tuple(e[2:]) for e in (spec.get("edges") or [])]
+        at = new_index[m]
+        n_sums = at - (new_index[m - 1] + 1 if m > 0 else 0)
+        if n_sums == 0:
+            out[at] = dict(spec, edges=edges)
+            continue
+        sums = getattr(pop, "_edge_sums", None)
+        if sums is None or len(sums) < n_sums:
+            sums = pop._edge_sums = [InstantPopulation(pop.rows, "identity", pop.device, backend=pop.backend) for _ in range(n_sums)]
+        run0 = spec["run"]
+        first = at - n_sums
+        taken = 0
+        for k in range(n_sums):
+            part = edges[taken:taken + (K if k == 0 else K - 1)]
+            taken += len(part)
+            if k > 0:
+                part = [(None, first + k - 1, _abi.RP_EDGE_OUT)] + part
+            out[first + k] = dict(pop=sums[k], run=dict(steps=run0["steps"], step0=run0.get("step0", 0), out_var=_abi.RP_OUT_SOURCE),
+                                  edges=part)
+        out[at] = dict(spec, edges=[(None, at - 1, _abi.RP_EDGE_OUT)] + edges[taken:])
+    return out, [new_index[m] for m in range(len(members))]
 
 
 def backward_coupled(members: list) -> list:

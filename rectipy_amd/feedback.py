@@ -370,73 +370,121 @@ class FeedbackNetwork(Network):
 
     # ---- populations joined by dense edges: one library call per window ----------------------------------------------
     def _coupled_plan(self, rec_vars) -> Optional[dict]:
-        """How to evaluate the graph with rp_forward_coupled, or None.  Populations (compiled, fusable) may be joined by
-        plain dense edges in any pattern, feedback edges included; activation nodes must sit entirely upstream of the
+        """How to evaluate the graph with rp_forward_coupled, or None (then `_why_not["coupled"]` says why, and `run` /
+        `fit_*` warn before they walk the graph step by step).  Populations (compiled, fusable) may be joined in any pattern,
+        feedback edges included, by plain / masked projections and by the edges with memory (delay, filter: their memory is
+        a stage the library advances once per step, rp_run.edge_mem); element-wise activation nodes BETWEEN populations are
+        members of the call themselves (RP_MODEL_INSTANT); other activation nodes must sit entirely upstream of the
         populations ("pre": evaluated for the whole window in advance) or entirely downstream ("post": afterwards)."""
+        plan, why = self._coupled_plan_why(rec_vars)
+        self._why_not = dict(getattr(self, "_why_not", {}), coupled=why)
+        return plan
+
+    def _coupled_plan_why(self, rec_vars):
+        from .edge_variants import LinearMasked, _Stateful
+        from .rls import RLS
         if getattr(self, "_force_stepwise", False) or not self._order:
-            return None
+            return None, None
         g = self.graph
         pops = [n for n in self._order if isinstance(self.get_node(n), RateNet)]
-        if not pops or len(pops) > 16:
-            return None
+        if not pops:
+            return None, None
         for n in self._order:
             node = self.get_node(n)
             if isinstance(node, RateNet):
-                if not getattr(node, "_fusable", True) or node._pop.rows != node._pop.n:
-                    return None
+                if not getattr(node, "_fusable", True):
+                    return None, f"population '{n}' cannot be integrated as a fused window"
+                if node._pop.rows != node._pop.n:
+                    return None, f"population '{n}' is a row shard"
             elif not (isinstance(node, InstantNode) and node.name in InstantNode.batched):
-                return None
+                return None, f"node '{n}' ({type(node).__name__}) is neither a compiled population nor a built-in activation node"
         below = set(pops).union(*(descendants(g, p) for p in pops))   # a population or downstream of one
         above = set(pops).union(*(ancestors(g, p) for p in pops))     # a population or upstream of one
         pre = [n for n in self._order if n not in below]
         post = [n for n in self._order if n in below and n not in above]
-        if len(pre) + len(post) + len(pops) != len(self._order):
-            return None  # an activation node between populations
-        edges = {p: [] for p in pops}
+        between = [n for n in self._order if n in below and n in above and n not in pops]
+        for n in between:  # an activation node between populations: a member of the call (out = act(node input), in-kernel)
+            if self.get_node(n).name not in InstantNode.elementwise:
+                return None, (f"activation node '{n}' ({self.get_node(n).name}) lies between populations and has no in-kernel form "
+                              f"(element-wise {', '.join(InstantNode.elementwise)} do)")
+        members = [n for n in self._order if n in pops or n in between]
+        if len(members) > _abi.RP_MAX_MEMBERS:
+            return None, f"{len(members)} coupled populations / activation nodes (at most {_abi.RP_MAX_MEMBERS} per library call)"
+        pos = {n: i for i, n in enumerate(self._order)}
+        edges = {m: [] for m in members}
         for s_, t_, d in g.edges(data=True):
             edge, fb = self.get_edge(s_, t_), bool(d.get("feedback"))
             if s_ in edges and t_ in edges:
-                if type(edge) is not Linear or edge.weights.stride(1) != 1 or edge.weights.dtype != torch.float32:
-                    return None
+                stateful = isinstance(edge, _Stateful) and not isinstance(edge, LinearMasked)
+                if not (type(edge) in (Linear, RLS) or isinstance(edge, LinearMasked) or (stateful and edge._stage_kind)):
+                    return None, f"edge '{s_}' -> '{t_}' of class {type(edge).__name__} has no in-kernel form"
+                if edge.weights.stride(1) != 1 or edge.weights.dtype != torch.float32:
+                    return None, f"edge '{s_}' -> '{t_}': its weights are not a float32 row-major matrix"
+                if stateful and edge.memory_stage() is None:
+                    return None, (f"edge '{s_}' -> '{t_}' ({type(edge).__name__}): its memory cannot be held by the library "
+                                  f"(float32 tensors on the GPU; a delay buffer whose rows are identical)")
                 src_node = self.get_node(s_)
-                if s_ == t_ and not isinstance(src_node, SpikeResetNet) and src_node._out_code == _abi.RP_OUT_STATE0:
-                    return None  # a population cannot read its own state while it is stepped
-                earlier = self._order.index(s_) < self._order.index(t_)
-                if not fb:
+                earlier = pos[s_] < pos[t_]
+                if s_ in between:
+                    # the library reads an activation node's output "as it stands": this step's once the node was stepped,
+                    # else the previous step's -- the latter is what a feedback edge delivers (`_prev_out`, an extension:
+                    # the reference raises there), the former what a feed-forward edge does
+                    if fb and earlier:
+                        return None, f"feedback edge '{s_}' -> '{t_}' from an activation node that is evaluated earlier in the step"
+                    mode = _abi.RP_EDGE_LIVE if fb else _abi.RP_EDGE_OUT
+                elif s_ == t_ and not isinstance(src_node, SpikeResetNet) and src_node._out_code == _abi.RP_OUT_STATE0:
+                    return None, f"population '{s_}' reads its own state through an edge"  # (while it is stepped)
+                elif not fb:
                     mode = _abi.RP_EDGE_OUT            # what the source's step of this Euler step returned
                 elif isinstance(src_node, SpikeResetNet):
                     mode = _abi.RP_EDGE_OUT if earlier else _abi.RP_EDGE_LAG  # its exposed state lags (nodes.py:387-392)
                 else:
                     mode = _abi.RP_EDGE_LIVE           # `source["out"]` as it stands (network.py:1354-1357)
                 edges[t_].append((s_, mode))
-            elif fb or not self._windowable(edge):
-                return None  # feedback from / into an activation node; foreign edge classes
-        if any(len(v) > _abi.RP_MAX_EDGES for v in edges.values()):
-            return None
+            elif fb:
+                return None, f"feedback edge '{s_}' -> '{t_}' from / into an activation node outside the coupled populations"
+            elif not self._windowable(edge):
+                return None, f"edge '{s_}' -> '{t_}' of class {type(edge).__name__} cannot be evaluated for a whole window"
         slots = []
         for label, var in rec_vars:
             node = self.get_node(label)
             one = self._record_slots(node, [(label, var)]) if isinstance(node, RateNet) else None
             if one is None:
-                return None
+                return None, f"recorded variable '{var}' of node '{label}' is not recordable inside the step kernel"
             slots.append(one[0])
-        return dict(pre=pre, pops=pops, post=post, edges=edges, slots=slots)
+        return dict(pre=pre, pops=pops, post=post, between=between, members=members, edges=edges, slots=slots), None
 
     def _coupled_grad_plan(self) -> Optional[dict]:
         """The coupled plan if its adjoint runs as one call too (rp_backward_coupled): feed-forward edges, feedback edges from
         rate populations (stepped later: the usual direction; stepped earlier: a post-update read) and from spiking populations
-        (their exposed state lags one step).  The population-mean spiking models keep the per-step autograd."""
+        (their exposed state lags one step).  The population-mean spiking models, activation nodes between populations and
+        edges with memory / masks between populations keep the per-step autograd (`_why_not["coupled_grad"]`)."""
+        plan, why = self._coupled_grad_plan_why()
+        self._why_not = dict(getattr(self, "_why_not", {}), coupled_grad=why)
+        return plan
+
+    def _coupled_grad_plan_why(self):
         from .spiking_autograd import TRAINABLE
         plan = self._coupled_plan([])
-        if plan is None or getattr(self, "_force_stepwise_adjoint", False):
-            return None
+        if plan is None:
+            return None, self._why_not.get("coupled")
+        if getattr(self, "_force_stepwise_adjoint", False):
+            return None, None
+        if plan["between"]:
+            return None, f"activation node '{plan['between'][0]}' between populations: its adjoint is not part of rp_backward_coupled"
         for p in plan["pops"]:
             node = self.get_node(p)
-            if node._out_slice is not None or node._pop.model in ("iku", "ik_biexp"):
-                return None
+            if node._out_slice is not None:
+                return None, f"population '{p}' exposes a slice of its output variable"
+            if node._pop.model in ("iku", "ik_biexp"):
+                return None, f"population '{p}' ({node._pop.model}): the population-mean models have no step-wise adjoint"
             if node._pop.spiking and node._pop.model not in TRAINABLE:
-                return None
-        return plan
+                return None, f"population '{p}' ({node._pop.model}) has no surrogate-gradient adjoint"
+            for s_, _ in plan["edges"][p]:
+                if type(self.get_edge(s_, p)) is not Linear:
+                    return None, (f"edge '{s_}' -> '{p}' of class {type(self.get_edge(s_, p)).__name__} between populations: "
+                                  f"its adjoint is not part of rp_backward_coupled")
+        return plan, None
 
     def _coupled_grad_outputs(self, plan: dict, inputs_ab: torch.Tensor, a: int, fit: bool = False) -> torch.Tensor:
         """The output node's per-step outputs over the window [a, a + len), with the graph of ONE autograd node for all
@@ -535,14 +583,35 @@ class FeedbackNetwork(Network):
                 contrib = self._edge_window(self.get_edge(p_, n), outs[p_])
                 X = contrib if X is None else X + contrib
             outs[n] = self.get_node(n).forward(X)
-        for p in plan["pops"]:
+        for p in plan["members"]:
             X = inputs_ab if p == self._in_node else None
             for p_ in self.graph.predecessors(p):
                 if p_ in outs and not self.graph[p_][p].get("feedback"):
                     contrib = self._edge_window(self.get_edge(p_, p), outs[p_])
                     X = contrib if X is None else X + contrib
-            xin[p] = None if X is None else self._fit_width(X, self.get_node(p)._pop.rows)
+            xin[p] = None if X is None else self._fit_width(X, self._member_pop(p).rows)
         return xin
+
+    def _member_pop(self, label: str):
+        """The engine object of a member of the coupled call: a population's, or -- for an activation node between
+        populations -- an InstantPopulation created on first use (its `source` is the node's last output)."""
+        node = self.get_node(label)
+        if isinstance(node, RateNet):
+            return node._pop
+        ipop = getattr(node, "_ipop", None)
+        if ipop is None:
+            from .engine import InstantPopulation
+            dev = self.device if self._backend is None else "cpu"
+            ipop = node._ipop = InstantPopulation(node.n_in, node.name, dev, backend=self._backend)
+        return ipop
+
+    @staticmethod
+    def _edge_matrix(edge) -> torch.Tensor:
+        """The matrix the step kernel streams for an edge between members: its weights (a masked edge: weights * mask)."""
+        from .edge_variants import LinearMasked
+        if isinstance(edge, LinearMasked):
+            return (edge.weights.detach() * edge.mask).contiguous()
+        return edge.weights
 
     def _coupled_window(self, plan: dict, inputs_ab: torch.Tensor, a: int, want_traj: set, rec: dict, sampler: Optional[dict],
                         cutoff: int, sampling_steps: int) -> dict:
@@ -558,33 +627,50 @@ class FeedbackNetwork(Network):
         `stored`: label -> keyword arguments capturing the window for the adjoint (save_v / save_src / save_acc)."""
         from .engine import forward_coupled
         pops: List[str] = plan["pops"]
-        index = {p: i for i, p in enumerate(pops)}
+        members: List[str] = plan["members"]
+        index = {p: i for i, p in enumerate(members)}
         spiking = any(isinstance(self.get_node(p), SpikeResetNet) for p in pops)
-        lag_read = {s_ for p in pops for s_, mode in plan["edges"][p] if mode == _abi.RP_EDGE_LAG}
+        lag_read = {s_ for p in members for s_, mode in plan["edges"][p] if mode == _abi.RP_EDGE_LAG}
         # every population that is read through its state variable gets the history ring: RP_EDGE_OUT edges need it, and
         # with it on the RP_EDGE_LIVE sources too the library may step all members in ONE launch (rp_forward_coupled)
-        hist_read = lag_read | {s_ for p in pops for s_, mode in plan["edges"][p]
-                                if self.get_node(s_)._out_code == _abi.RP_OUT_STATE0}
+        hist_read = lag_read | {s_ for p in members for s_, mode in plan["edges"][p]
+                                if s_ in pops and self.get_node(s_)._out_code == _abi.RP_OUT_STATE0}
         packed_edges = self._packed_edges(plan)
         trajs = {}
-        for p in pops:
-            node: RateNet = self.get_node(p)
-            pop = node._pop
-            node._coupled_begin()
+        for p in members:
+            node = self.get_node(p)
+            pop = self._member_pop(p)
             if p in want_traj:
                 trajs[p] = torch.empty(steps, pop.rows, dtype=torch.float32, device=pop.device)
+            if p not in pops:  # an activation node: what a feedback edge reads before the node's first step of the window
+                prev = self._prev_out.get(p)
+                pop.source.zero_() if prev is None else pop.source.copy_(prev.detach().reshape(-1))
+                continue
+            node._coupled_begin()
             if p in hist_read:
                 if getattr(node, "_hist", None) is None:
                     node._hist = [torch.zeros(pop.rows, dtype=torch.float32, device=pop.device) for _ in (0, 1, 2)]
                 if p in lag_read:  # what a feedback edge reads at the window's first step: the node's exposed output
                     node._hist[(a + 2) % 3].copy_(node["out"].detach())
+        # the matrices the members' step kernels stream, and the memory stages of the edges that have one (loaded with the
+        # edges' current state; written back after the last call)
+        edge_args, stages = {}, []
+        for p in members:
+            row = []
+            for s_, mode in plan["edges"][p]:
+                edge = self.get_edge(s_, p)
+                mem = edge.memory_stage() if getattr(edge, "_stage_kind", None) else None
+                if mem is not None:
+                    stages.append((edge, mem))
+                row.append((self._edge_matrix(edge), index[s_], mode, packed_edges.get((s_, p)), mem))
+            edge_args[p] = row
 
         def call(t0: int, t1: int, last: bool):
-            members, saves = [], {}
-            for p in pops:
+            specs, saves = [], {}
+            for p in members:
                 node = self.get_node(p)
-                pop = node._pop
-                kw = node._coupled_kwargs()
+                pop = self._member_pop(p)
+                kw = node._coupled_kwargs() if p in pops else dict(out_var=_abi.RP_OUT_SOURCE)
                 kw.update(steps=t1 - t0, step0=a + t0, x=None if xin[p] is None else xin[p][t0:t1])
                 if p in trajs:
                     kw["traj"] = trajs[p][t0:t1]
@@ -602,10 +688,9 @@ class FeedbackNetwork(Network):
                 if last and isinstance(node, SpikeResetNet) and not (stored and p in stored):
                     saves[p] = node._state_bufs()
                     kw.update(save_v=saves[p][0], save_src=saves[p][1], save_aux=saves[p][2], save_aux2=saves[p][3])
-                members.append(dict(pop=pop, run=kw, edges=[(self.get_edge(s_, p).weights, index[s_], mode, packed_edges.get((s_, p)))
-                                                            for s_, mode in plan["edges"][p]]))
-            idx = forward_coupled(members)
-            for p, i in zip(pops, idx):
+                specs.append(dict(pop=pop, run=kw, edges=edge_args[p]))
+            idx = forward_coupled(specs)
+            for p, i in zip(members, idx):
                 if p in rec:
                     rec[p]["idx"] = i
                 if sampler and sampler["label"] == p:
@@ -620,6 +705,10 @@ class FeedbackNetwork(Network):
             call(steps - 1, steps, True)
         else:
             call(0, steps, spiking)
+        for edge, mem in stages:
+            edge.stage_done(mem)
+        for p in plan["between"]:  # what a feedback edge from the activation node reads next: its last output
+            self._prev_out[p] = self._member_pop(p).source.clone()
         return trajs
 
     PACKED_EDGE_MAX_DENSITY = 0.5   # (the rules of a population's own matrix, nodes.py: _maybe_pack_weights)
@@ -648,6 +737,8 @@ class FeedbackNetwork(Network):
             for s_, _ in plan["edges"][p]:
                 edge = self.get_edge(s_, p)
                 W = edge.weights
+                if type(edge) is not Linear or s_ in plan.get("between", ()):
+                    break
                 if W.requires_grad or W.shape[1] % 4 or W.shape[0] % 4 or not W.is_contiguous() or W.device != pop.device:
                     break
                 cache = getattr(edge, attr, None)
@@ -684,15 +775,21 @@ class FeedbackNetwork(Network):
         same bytes -- while four separate 1 GiB allocations give 611-619 us or 653-667 us depending on where the driver
         happened to place them (same kernel, same data; which matrices share a launch does not matter).  A trained matrix
         keeps its tensor object (an optimiser holds on to it): its `.data` becomes the view."""
+        from .edge_variants import LinearMasked
         mats = []
-        for p in plan["pops"]:
-            pop = self.get_node(p)._pop
-            mats.append((pop, "W"))
+        for p in plan.get("members", plan["pops"]):
+            if p in plan["pops"]:
+                mats.append((self.get_node(p)._pop, "W"))
             for s_, _ in plan["edges"][p]:
-                mats.append((self.get_edge(s_, p), "weights"))
+                edge = self.get_edge(s_, p)
+                if isinstance(edge, LinearMasked):
+                    continue  # (the kernel streams weights * mask, formed per window)
+                mats.append((edge, "weights"))
+                if getattr(edge, "_stage_kind", None) in ("filter", "delay_filter") and edge.n_in > _abi.RP_EMEM_NARROW_MAX:
+                    mats.append((edge, "filter"))  # a wide edge's filter matrix is streamed every step like a recurrent one
         tensors = [getattr(o, a) for o, a in mats]
-        if not tensors or tensors[0].device.type != "cuda" or any(not t.is_contiguous() or (t.requires_grad and not t.is_leaf)
-                                                                  for t in tensors):
+        if not tensors or tensors[0].device.type != "cuda" or any(not t.is_contiguous() or t.dtype != torch.float32 or
+                                                                  (t.requires_grad and not t.is_leaf) for t in tensors):
             return
         total = sum(t.numel() for t in tensors)
         if 4 * total < self.ARENA_MIN_BYTES:
@@ -705,10 +802,16 @@ class FeedbackNetwork(Network):
         for t in tensors:
             offs.append(off)
             off += (t.numel() + pad - 1) // pad * pad
-        arena = torch.empty(off, dtype=torch.float32, device=tensors[0].device)
+        try:
+            arena = torch.empty(off, dtype=torch.float32, device=tensors[0].device)
+        except torch.cuda.OutOfMemoryError:
+            return  # no room for a second copy of the matrices: they stay where they are (placement costs 5-8 %, not a run)
         for (obj, attr), t, o in zip(mats, tensors, offs):
             view = arena[o:o + t.numel()].view(t.shape)
             view.copy_(t.detach())
+            # a packed form built from W stays valid only if it was valid before the move (an in-place edit of W since
+            # packing must still trigger the re-pack: Population._sync_packed compares version counters)
+            valid = attr == "W" and obj.packed is not None and obj._packed_version == t._version
             if t.requires_grad:
                 t.data = view
             else:
@@ -716,7 +819,7 @@ class FeedbackNetwork(Network):
             if attr == "W":
                 obj._net_cache = None
                 if obj.packed is not None:
-                    obj._packed_version = view._version  # same values: the packed form stays valid
+                    obj._packed_version = obj.W._version if valid else -1
         self._arena = arena
 
     def _run_coupled(self, plan: dict, inputs, sampling_steps, cutoff, obs: Observer, rec_vars, verbose):
@@ -732,13 +835,14 @@ class FeedbackNetwork(Network):
             entry = rec.setdefault(label, {"idx": 0})
             if slot not in entry:
                 entry[slot] = torch.empty(S, pop.rows, dtype=torch.float32, device=pop.device)
-        for p in pops:
-            self.get_node(p)._pop.reset_sampling()
+        members = plan["members"]
+        for p in members:
+            self._member_pop(p).reset_sampling()
         # the output: sampled in-kernel when the output node is a population, or a linear memory-less read-out of ONE
         # population (it commutes with the buffer mean); otherwise per-step trajectories -> read-out -> buffer means
-        feeders = [p for p in pops if any(t_ in post for t_ in self.graph.successors(p))]
+        feeders = [p for p in members if any(t_ in post for t_ in self.graph.successors(p))]
         sampler = None
-        if out_node in pops:
+        if out_node in members:  # (a population, or an activation node inside the cycle: a member of the call itself)
             src_pop, chain = out_node, []
         elif len(feeders) == 1 and all(self.graph.in_degree(n) == 1 for n in post) and \
                 self._memoryless_linear(post, feeders[0]) and list(topological_sort(self.graph.subgraph(post))) == post:
@@ -746,10 +850,10 @@ class FeedbackNetwork(Network):
         else:
             src_pop, chain = None, None
         if src_pop is not None:
-            pop = self.get_node(src_pop)._pop
+            pop = self._member_pop(src_pop)
             sampler = dict(label=src_pop, samples=torch.empty(S, pop.rows, dtype=torch.float32, device=pop.device), idx=0)
         want_traj = set() if sampler else set(feeders)
-        widest = max(self.get_node(p)._pop.rows for p in pops)
+        widest = max(self._member_pop(p).rows for p in members)
         chunk = max(1, min(T, _WINDOW_BYTES // (4 * widest * max(1, len(want_traj) + len(plan["pre"]) + 1))))
         pending = []
         for a in range(0, T, chunk):
@@ -773,22 +877,22 @@ class FeedbackNetwork(Network):
         obs.record_block(sample_at, outputs, 0.0, [rec[label][slot] for (label, _), slot in zip(rec_vars, plan["slots"])])
         for n in self._order:  # what the per-step walk leaves in `net[n]["out"]`: not kept for windows
             self[n]["out"] = None
-        self._prev_out = {}
+        self._prev_out = {k: v for k, v in self._prev_out.items() if k in plan["between"]}
 
     def _coupled_node_outputs(self, plan: dict, inputs: torch.Tensor, label: str) -> torch.Tensor:
         """Per-step outputs [T, n] of the node `label` -- a population or a node downstream of all populations -- over the
         whole input, the populations integrated window by window with one rp_forward_coupled call each (no gradient)."""
         self._consolidate(plan)
         T = inputs.shape[0]
-        pops, post = plan["pops"], plan["post"]
+        pops, post = plan["members"], plan["post"]
         if label in pops:
             want, chain = {label}, []
         else:
             chain = [n for n in post if n == label or label in descendants(self.graph, n)]
             want = {p for p in pops if any(t_ in chain for t_ in self.graph.successors(p))}
         for p in pops:
-            self.get_node(p)._pop.reset_sampling()
-        widest = max(self.get_node(p)._pop.rows for p in pops)
+            self._member_pop(p).reset_sampling()
+        widest = max(self._member_pop(p).rows for p in pops)
         chunk = max(1, min(T, _WINDOW_BYTES // (4 * widest * max(1, len(want) + len(plan["pre"]) + 1))))
         pieces = []
         for a in range(0, T, chunk):
@@ -804,7 +908,7 @@ class FeedbackNetwork(Network):
             pieces.append(outs[label])
         for n in self._order:
             self[n]["out"] = None
-        self._prev_out = {}
+        self._prev_out = {k: v for k, v in self._prev_out.items() if k in plan["between"]}
         return pieces[0] if len(pieces) == 1 else torch.cat(pieces)
 
     def reset(self, state: dict = None):

@@ -30,6 +30,12 @@ _LOSSES = {"mse": torch.nn.MSELoss, "l1": torch.nn.L1Loss, "nll": torch.nn.NLLLo
 _WINDOW_BYTES = 2 << 30  # cap for [T, N] staging buffers of one fused call
 
 
+class PerformanceWarning(UserWarning):
+    """A graph is walked step by step from Python (one kernel launch group per node and Euler step, per-step autograd in
+    training) instead of running as fused windows inside the library: same results, several times slower.  The message names
+    the node or edge that forced it."""
+
+
 class Network:
     """Graph of diff-eq populations, activation nodes and linear edges (reference network.py:16-44)."""
 
@@ -198,6 +204,8 @@ class Network:
         else:
             raise ValueError("Invalid option for keyword argument `train`. Valid options: None, 'gd', 'rls'.")
         edge_device = self.device if self._backend is None else "cpu"
+        if self._backend is not None and hasattr(edge, "memory_stage"):
+            edge._backend = self._backend   # (test seam: the edge's memory stage on the injected backend)
         self.graph.add_edge(source, target, edge=edge.to(edge_device), trainable=train is not None, n_in=edge.n_in,
                             n_out=edge.n_out, **(edge_attrs or {}))
         return edge
@@ -428,6 +436,14 @@ class Network:
                 if grad_plan is not None:  # ... and the graph of one autograd node per window (rp_backward_coupled)
                     self._run_coupled_grad(grad_plan, inputs, sampling_steps, cutoff, truncate_steps, obs, verbose)
                     return obs
+        if coupled is not None:  # (the forward plan exists: it is the adjoint of the coupled call that is missing)
+            self._warn_stepwise("Network.run with a gradient", "coupled_grad") if not rec_vars else \
+                self._warn_stepwise("Network.run with a gradient and recorded variables")
+        elif plan is not None:
+            self._why_not = dict(getattr(self, "_why_not", {}), rec="a recorded variable is not recordable inside the step kernel")
+            self._warn_stepwise("Network.run", "rec")
+        else:
+            self._warn_stepwise("Network.run", "dag", "coupled")
         self._run_stepwise(inputs, sampling_steps, cutoff, truncate_steps, obs, rec_vars, enable_grad, verbose)
         return obs
 
@@ -544,28 +560,46 @@ class Network:
         compiled population or an element-wise activation, every edge a plain Linear/RLS projection -- else None.
         Inside one step a node only sees its predecessors' outputs of the SAME step (forward(), reference
         network.py:462-478), so node n's whole window follows from its predecessors' whole windows."""
-        from .rls import RLS
+        def no(why):
+            self._why_not = dict(getattr(self, "_why_not", {}), dag=why)
+            return None
+
         if getattr(self, "_force_stepwise", False):
-            return None
+            return no(None)
         if not any(isinstance(self.get_node(n), RateNet) for n in self._order):
-            return None
+            return no("the graph holds no compiled population")
         for n in self._order:
             node = self.get_node(n)
             if not isinstance(node, RateNet) and not (isinstance(node, InstantNode) and node.name in InstantNode.batched):
-                return None
+                return no(f"node '{n}' ({type(node).__name__}) is neither a compiled population nor a built-in activation node")
             if not getattr(node, "_fusable", True):
-                return None
+                return no(f"population '{n}' cannot be integrated as a fused window")
         for s_, t_ in self.graph.edges:
             if not self._windowable(self.get_edge(s_, t_)):
-                return None
+                return no(f"edge '{s_}' -> '{t_}' of class {type(self.get_edge(s_, t_)).__name__} cannot be evaluated for a whole window")
         slots = []
         for label, var in rec_vars:
             node = self.get_node(label)
             one = self._record_slots(node, [(label, var)]) if isinstance(node, RateNet) else None
             if one is None:
-                return None
+                return no(f"recorded variable '{var}' of node '{label}' is not recordable inside the step kernel")
             slots.append(one[0])
+        no(None)
         return slots
+
+    def _warn_stepwise(self, what: str, *plans: str):
+        """One PerformanceWarning per network and cause: `what` runs on the per-step Python walk because none of the fused
+        plans took the graph (`plans`: the keys of `_why_not` that were tried)."""
+        if getattr(self, "_force_stepwise", False) or getattr(self, "_force_stepwise_adjoint", False):
+            return  # (test seam: the walk was asked for)
+        why = [w for w in (getattr(self, "_why_not", {}).get(k) for k in plans) if w]
+        msg = (f"{what} walks the graph step by step from Python instead of running fused windows inside the library "
+               f"(several times slower, same results)" + (": " + "; ".join(dict.fromkeys(why)) if why else "") + ".")
+        seen = self.__dict__.setdefault("_warned", set())
+        if msg not in seen:
+            seen.add(msg)
+            import warnings
+            warnings.warn(msg, PerformanceWarning, stacklevel=3)
 
     def _window_outputs(self, inputs_ab: torch.Tensor, a: int, grad: bool, rec: dict, cutoff: int, sampling_steps: int):
         """Per-step output of every node over the window of steps [a, a + len): nodes in topological order, each
@@ -865,6 +899,11 @@ class Network:
         # populations joined by dense edges, cycles included (FeedbackNetwork): forward and adjoint one call per window each
         coupled = self._coupled_grad_plan() if plan is None and not windows and not rec_vars else None
         if (plan is None and not windows and coupled is None) or rec_vars:
+            if rec_vars:
+                self._why_not = dict(getattr(self, "_why_not", {}), rec="fit_bptt records state variables (record_vars)")
+                self._warn_stepwise("Network.fit_bptt", "rec")
+            else:
+                self._warn_stepwise("Network.fit_bptt", "dag", "coupled_grad")
             return self._bptt_stepwise(inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps,
                                        optim_steps, verbose)
         if not windows and coupled is None:
@@ -1088,6 +1127,7 @@ class Network:
             # populations integrate the whole input first (one rp_forward_coupled call per window), then the RLS sweep
             with torch.no_grad():
                 return edge.sweep(self._coupled_node_outputs(coupled, inp, src), tgt, optim_steps)
+        self._warn_stepwise("Network.fit_rls", "dag", "coupled")
         steps, loss, losses = inp.shape[0], 0.0, []
         with torch.no_grad():
             for step in range(steps):

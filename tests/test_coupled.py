@@ -348,38 +348,127 @@ def test_run_takes_one_call_per_window_and_matches_the_walk(target, cfg, monkeyp
         assert np.abs(res[0][3][k_] - res[1][3][k_]).max() < 5e-6, k_
 
 
-def test_what_stays_on_the_walk(oracle_backend):
-    """An activation node between populations, an edge with memory inside the cycle, a trained edge in a gradient run and
-    more than RP_MAX_EDGES edges into one population keep the step-by-step walk (and still run)."""
+def variant_net(target, force, kind):
+    """build_net's two populations a (12) -> b (20) with feedback b -> a, the feed-forward edge a -> b replaced by `kind`."""
+    r = np.random.default_rng(5)
+    net = build_net(target, force, sizes=(12, 20), k=2)
+    net.pop_edge("a", "b")
+    W = r.standard_normal((20, 12)) * 0.4
+    if kind == "activation":   # a -> tanh node -> b
+        net.add_func_node("mid", 16, "tanh")
+        net.add_edge("a", "mid", weights=r.standard_normal((16, 12)) * 0.5)
+        net.add_edge("mid", "b", weights=r.standard_normal((20, 16)) * 0.4)
+    elif kind == "sigmoid_fb":  # ... and a feedback edge from a sigmoid node behind b back into a
+        net.add_edge("a", "b", weights=W)
+        net.add_func_node("sig", 9, "sigmoid")
+        net.add_edge("b", "sig", weights=r.standard_normal((9, 20)) * 0.5)
+        net.add_edge("sig", "a", weights=r.standard_normal((12, 9)) * 0.5, feedback=True)
+        net.add_edge("sig", "out", weights=r.standard_normal((2, 9)) * 0.5)
+    elif kind == "delay":
+        net.add_edge("a", "b", weights=W, delays=(np.arange(12) * 5) % 4 + 1)
+    elif kind == "filter":
+        net.add_edge("a", "b", weights=W, filter_weights=r.standard_normal((12, 12)) * 0.25)
+    elif kind == "delay_filter":
+        net.add_edge("a", "b", weights=W, delays=np.asarray([1, 3] * 6), filter_weights=r.standard_normal((12, 12)) * 0.25)
+    elif kind == "masked":
+        net.add_edge("a", "b", weights=W, mask=(r.uniform(size=(20, 12)) < 0.5).astype(np.float32))
+    elif kind == "filter_fb":   # the edge with memory on the FEEDBACK edge of the cycle
+        net.add_edge("a", "b", weights=W)
+        net.pop_edge("b", "a")
+        net.add_edge("b", "a", weights=r.standard_normal((12, 20)) * 0.4, filter_weights=r.standard_normal((20, 20)) * 0.2, feedback=True)
+    elif kind == "many":        # eleven edges into b: more than RP_MAX_EDGES
+        net.add_edge("a", "b", weights=W)
+        for q in range(10):
+            net.add_diffeq_node(f"p{q}", TANH, weights=r.standard_normal((6, 6)) * 0.4, source_var="tanh_op/r", target_var="li_op/r_in",
+                                input_var="li_op/I_ext", output_var="li_op/v", dtype=torch.float32,
+                                node_vars={"all/li_op/v": r.standard_normal(6) * 0.5})
+            net.add_edge("a", f"p{q}", weights=r.standard_normal((6, 12)) * 0.4)
+            net.add_edge(f"p{q}", "b", weights=r.standard_normal((20, 6)) * 0.4)
+    else:
+        raise ValueError(kind)
+    return net
+
+
+VARIANTS = ["activation", "sigmoid_fb", "delay", "filter", "delay_filter", "masked", "filter_fb", "many"]
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("kind", VARIANTS)
+def test_activation_nodes_and_edges_with_memory_stay_inside_the_library(target, kind, monkeypatch, recwarn):
+    """Graphs the per-step walk used to take (r04): an activation node BETWEEN populations, a feedback edge from one, an edge
+    with memory (delay / filter / both) or a mask between populations -- feed-forward or on the cycle's feedback edge --, more
+    than RP_MAX_EDGES edges into one population.  Now ONE coupled library call per window, with the outputs, final states and
+    edge memories of the step-by-step walk of the same graph (two runs: state and memory carry over); no warning."""
+    calls = []
+    real = engine.forward_coupled
+    monkeypatch.setattr(engine, "forward_coupled", lambda members: calls.append(len(members)) or real(members))
+    x = np.random.default_rng(3).standard_normal((23, 3)).astype(np.float32)
+    res = []
+    for force in (False, True):
+        net = variant_net(target, force, kind)
+        n0 = len(calls)
+        a = net.run(x[:14], verbose=False, enable_grad=False, sampling_steps=2).to_numpy("out")
+        b = net.run(x[14:], verbose=False, enable_grad=False).to_numpy("out")
+        assert (len(calls) - n0 == 2) == (not force), (kind, force, calls)
+        mems = {}
+        for s_, t_ in net.graph.edges:
+            edge = net.get_edge(s_, t_)
+            for name in ("buffer", "y"):
+                if hasattr(edge, name):
+                    mems[(s_, t_, name)] = getattr(edge, name).detach().cpu().numpy().copy()
+        res.append((a, b, {k_: v.detach().cpu().numpy().copy() for k_, v in net.state.items()}, mems))
+    for q in (0, 1):
+        assert np.abs(res[0][q] - res[1][q]).max() < 2e-5, kind
+    for k_ in res[1][2]:
+        assert np.abs(res[0][2][k_] - res[1][2][k_]).max() < 2e-5, k_
+    for k_ in res[1][3]:
+        assert np.abs(res[0][3][k_] - res[1][3][k_]).max() < 2e-5, k_
+    from rectipy_amd import PerformanceWarning
+    assert not [w for w in recwarn.list if issubclass(w.category, PerformanceWarning)]
+
+
+def test_every_fall_back_to_the_walk_is_loud(oracle_backend):
+    """What still runs on the per-step Python walk says so, once per network, naming the cause: a normalising activation node
+    between populations, a gradient through a cycle that holds an activation node or an edge with memory, recorded
+    variables in fit_bptt.  The `_force_stepwise` test seam stays silent."""
+    from rectipy_amd import PerformanceWarning
     target = dict(device="cpu", backend=oracle_backend)
     x = np.random.default_rng(0).standard_normal((10, 3)).astype(np.float32)
     net = build_net(target, False)
     assert net.compile() is None and net._coupled_plan([]) is not None
-    # activation node between two populations
+    # a softmax node between two populations: no in-kernel form
     net = build_net(target, False, sizes=(12, 20), k=0)
     net.pop_edge("a", "b")
-    net.add_func_node("mid", 12, "tanh")
+    net.add_func_node("mid", 12, "softmax")
     net.add_edge("a", "mid", weights=np.eye(12))
     net.add_edge("mid", "b", weights=np.ones((20, 12)) * 0.1)
     net.compile()
     assert net._coupled_plan([]) is None
-    assert net.run(x, verbose=False, enable_grad=False).to_numpy("out").shape == (10, 20)
-    # an edge with memory between populations
-    net = build_net(target, False, sizes=(12, 20), k=0)
-    net.pop_edge("a", "b")
-    net.add_edge("a", "b", weights=np.ones((20, 12)) * 0.1, delays=np.arange(12) % 2)
+    with pytest.warns(PerformanceWarning, match="activation node 'mid' .softmax. lies between populations"):
+        assert net.run(x, verbose=False, enable_grad=False).to_numpy("out").shape == (10, 20)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", PerformanceWarning)   # ... once per network
+        net.run(x, verbose=False, enable_grad=False)
+    # a trained edge next to an edge with memory: the forward plan exists, its adjoint does not
+    net = variant_net(target, False, "filter")
+    net.pop_edge("b", "out")
+    net.add_edge("b", "out", weights=np.ones((2, 20)) * 0.1, train="gd")
     net.compile()
-    assert net._coupled_plan([]) is None
-    # a trained edge: no gradient passes through the in-kernel product, so a gradient-tracking run walks
-    net = build_net(target, False, sizes=(12, 20), k=0)
-    net.pop_edge("a", "b")
-    net.add_edge("a", "b", weights=np.ones((20, 12)) * 0.1, train="gd")
-    net.compile()
-    assert net._coupled_plan([]) is not None and net._coupled_wants_grad(torch.zeros(1))
-    with torch.no_grad():
-        assert not net._coupled_wants_grad(torch.zeros(1))
-    obs = net.run(x, verbose=False)   # enable_grad defaults to True: the walk, with an autograd graph
+    assert net._coupled_plan([]) is not None and net._coupled_grad_plan() is None
+    with pytest.warns(PerformanceWarning, match="LinearFilter between populations"):
+        net.fit_bptt(x, np.zeros((10, 2), dtype=np.float32), update_steps=5, verbose=False)
+    net = variant_net(target, False, "activation")
+    net.pop_edge("b", "out")
+    net.add_edge("b", "out", weights=np.ones((2, 20)) * 0.1, train="gd")
+    with pytest.warns(PerformanceWarning, match="activation node 'mid' between populations"):
+        obs = net.run(x, verbose=False)   # enable_grad defaults to True: the walk, with an autograd graph
     assert obs.stacked("out").requires_grad
+    # the test seam asks for the walk: silent
+    net = build_net(target, True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", PerformanceWarning)
+        net.run(x, verbose=False, enable_grad=False)
 
 
 @pytest.mark.gpu
