@@ -216,7 +216,11 @@ void launch_wt_partial(const BwdParams& P, bool vec4, hipStream_t st) {
 #else
     constexpr int tu = 0, tsw = 0;
 #endif
-    const int U = tu ? tu : (many ? 2 : wide ? 4 : 8), SW = tsw ? tsw : (many ? 1 : wide ? 2 : 1);
+    // r05 (scripts/probes/adj_strips.py): at n = 16384 -- a member or an edge of two coupled populations -- 2-KiB strips x 2
+    // rows in flight beat the 1-KiB strips (157.8 vs 165.2 us per 1 GiB matrix); at n = 32768 the 1-KiB strips stay ahead
+    // (599 vs 620)
+    const bool mid = many && P.n <= 16384 && ((P.n + 511) / 512) * P.q >= 1024;
+    const int U = tu ? tu : (many ? 2 : wide ? 4 : 8), SW = tsw ? tsw : (mid ? 2 : many ? 1 : wide ? 2 : 1);
     const int strips = (P.n + 256 * SW - 1) / (256 * SW);
     int blocks = (strips * P.q + 3) / 4;
     if (blocks > 4096) blocks = 4096;
@@ -229,9 +233,9 @@ void launch_wt_partial(const BwdParams& P, bool vec4, hipStream_t st) {
         hipLaunchKernelGGL((wt_partial_kernel<true, U_, SW_>), dim3(blocks), dim3(kThreads), 0, st, P);        \
         return;                                                                                                \
     }
-    RP_BW(2, 1) RP_BW(4, 2)  // (and (8, 1) below): the shapes the rule above picks
+    RP_BW(2, 1) RP_BW(4, 2) RP_BW(2, 2)  // (and (8, 1) below): the shapes the rule above picks
 #ifdef RP_MEASUREMENT
-    RP_BW(16, 1) RP_BW(4, 1) RP_BW(8, 2) RP_BW(2, 2) RP_BW(6, 2) RP_BW(32, 1) RP_BW(12, 1) RP_BW(3, 2) RP_BW(5, 2)
+    RP_BW(16, 1) RP_BW(4, 1) RP_BW(8, 2) RP_BW(6, 2) RP_BW(32, 1) RP_BW(12, 1) RP_BW(3, 2) RP_BW(5, 2)
     RP_BW(1, 1) RP_BW(3, 1) RP_BW(1, 2)
 #endif
 #undef RP_BW
@@ -1069,18 +1073,20 @@ int rp_sizeof_bwd_member(void) { return (int)sizeof(rp_bwd_member); }
 static int spk_setup(const rp_net* net, const rp_bwd* b, BwdParams& P, SpkGrad& G, bool& vec4);
 static void spk_set_step(const rp_bwd* b, BwdParams& P, int t);
 
-// every matrix of the circuit small and on the 16-byte path, few enough members and edges for one argument block
-static bool coupled_fused_ok(const rp_bwd_member* mem, int count) {
+// few enough members and edges for ONE argument block of coupled_finalize_kernel; *small: every matrix small and on the
+// 16-byte path as well, so that the transposed products of a step share one launch too
+static bool coupled_fused_ok(const rp_bwd_member* mem, int count, bool* small) {
+    *small = true;
     if (count > kFusedMembers) return false;
     int edges = 0;
     auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     for (int m = 0; m < count; ++m) {
         const rp_net* net = mem[m].net;
-        if (net->n > kFusedMaxN || net->n % 4 || net->ldw % 4 || !aligned(net->W) || !aligned(mem[m].bwd->partials)) return false;
+        if (net->n > kFusedMaxN || net->n % 4 || net->ldw % 4 || !aligned(net->W) || !aligned(mem[m].bwd->partials)) *small = false;
         int64_t off = 0;
         for (int e = 0; e < mem[m].n_edges; ++e) {
             const int nq = mem[mem[m].edge_source[e]].net->n;
-            if (nq % 4 || mem[m].edge_ld[e] % 4 || !aligned(mem[m].edge_w[e]) || !aligned(mem[m].edge_work + off)) return false;
+            if (nq % 4 || mem[m].edge_ld[e] % 4 || !aligned(mem[m].edge_w[e]) || !aligned(mem[m].edge_work + off)) *small = false;
             const int rc = chunk_rows(nq, net->rows);
             off += (int64_t)((net->rows + rc - 1) / rc) * nq;
             ++edges;
@@ -1089,7 +1095,10 @@ static bool coupled_fused_ok(const rp_bwd_member* mem, int count) {
     return edges <= kFusedEdges;
 }
 
-static int coupled_fused_sweep(const rp_bwd_member* mem, int count, int T, hipStream_t st) {
+// `one_launch`: the transposed products of a step in ONE launch (launch-bound sizes); else one strip launch per matrix, each
+// with the walk its shape wants (HBM-bound sizes) -- and in both cases ONE element-wise launch for all members.  Same partial
+// sums, same order of additions.
+static int coupled_fused_sweep(const rp_bwd_member* mem, int count, int T, hipStream_t st, bool one_launch) {
     CoupledFin F = {};
     PartArgs A = {};
     bool vec4;
@@ -1143,7 +1152,22 @@ static int coupled_fused_sweep(const rp_bwd_member* mem, int count, int T, hipSt
             if (many && blocks > 768) blocks = 768;
             if (blocks > max_blocks) max_blocks = blocks;
         }
-        if (many)
+        if (!one_launch) {
+            for (int i = 0; i < mats; ++i) {
+                BwdParams Q = {};
+                Q.W = A.a[i].W;
+                Q.ldw = A.a[i].ldw;
+                Q.u = A.a[i].u;
+                Q.partials = A.a[i].partials;
+                Q.n = A.a[i].n;
+                Q.rows = A.a[i].rows;
+                Q.rc = A.a[i].rc;
+                Q.q = A.a[i].q;
+                const bool v4 = (Q.n % 4 == 0) && (Q.ldw % 4 == 0) && !(reinterpret_cast<uintptr_t>(Q.W) & 15u) &&
+                                !(reinterpret_cast<uintptr_t>(Q.partials) & 15u);
+                launch_wt_partial(Q, v4, st);
+            }
+        } else if (many)
             hipLaunchKernelGGL(coupled_partials_kernel_2, dim3(max_blocks, mats), dim3(kThreads), 0, st, A);
         else
             hipLaunchKernelGGL(coupled_partials_kernel_8, dim3(max_blocks, mats), dim3(kThreads), 0, st, A);
@@ -1257,7 +1281,8 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
         const int rc = rp_bwd_prepare(mem[q].net, mem[q].bwd, stream);
         if (rc != RP_OK) return rc;
     }
-    if (!post && !any_packed && coupled_fused_ok(mem, count)) return coupled_fused_sweep(mem, count, T, st);
+    bool small = false;
+    if (!post && !any_packed && coupled_fused_ok(mem, count, &small)) return coupled_fused_sweep(mem, count, T, st, small);
     for (int t = T - 1; t >= 0; --t) {
         // last member first; in front of a member's step the edge products that end in its output gradient: from gx_x(t)
         // (ready since step t + 1) for the reads of step t's output -- into row t -- and of the output one step earlier

@@ -42,5 +42,48 @@ def main():
     save("g26_fit_ridge", dt=dt, alpha=alpha, x=x, x2=x2, target=target, target2=target2, W_in=W_in, **P, **out)
 
 
+def ill_conditioned():
+    """G39: as many samples as neurons and a small ridge -- the solve amplifies how the states were rounded.  The reference's
+    float64 run is the truth; its own float32 run shows what float32 STATES cost in this regime (the engine's states are
+    float32 too; its Gram matrix and solve are float64)."""
+    Network, RateNet, SpikeResetNet, Spike = import_reference()
+    n, m, kout, dt, alpha = 64, 3, 2, 1e-2, 1e-3
+    P = rng_li(n, seed=391)
+    r = np.random.default_rng(392)
+    W_in = r.standard_normal((n, m))
+    out = {}
+    for T, stride in ((60, 1), (600, 10), (120, 2)):      # T / stride = 60 samples ~ n = 64 unknowns per read-out channel
+        x = r.standard_normal((T, m))
+        mix = r.standard_normal((m, kout))
+        target = np.tanh(np.cumsum(x, axis=0) * 0.05) @ mix + 0.01 * r.standard_normal((T, kout))
+        key = f"T{T}_s{stride}"
+        out["x_" + key], out["target_" + key] = x, target
+        for tag, dtype in (("f64", torch.float64), ("f32", torch.float32)):
+            net = Network(dt, dtype=dtype)
+            net.add_func_node("inp", m, "identity")
+            net.add_node("rnn", rate_node(RateNet, P["W"], P["tau"], P["k"], P["eta"], P["y0"], dt, dtype), node_type="diff_eq")
+            net.add_edge("inp", "rnn", weights=W_in)
+            # (the reference multiplies the sampled states with the UNsampled targets, network.py:765-768: sample the targets here)
+            obs = net.fit_ridge(x, target[::stride] if stride > 1 else target, sampling_steps=stride, alpha=alpha, verbose=False) \
+                if stride == 1 else None
+            if obs is None:   # sampling_steps > 1: the reference's product fails on the shape mismatch; restate its solve on its states
+                o = net.run(x, sampling_steps=stride, verbose=False, enable_grad=False)
+                X = torch.stack(o["out"]) if isinstance(o["out"], list) else torch.as_tensor(o["out"])
+                X = X.to(dtype)
+                Y = torch.tensor(target[::stride], dtype=dtype)
+                w = torch.inverse(X.T @ X + alpha * torch.eye(n, dtype=dtype)) @ X.T @ Y
+                out[f"X_{key}_{tag}"], out[f"w_out_{key}_{tag}"] = np_(X), np_(w)
+            else:
+                out[f"X_{key}_{tag}"], out[f"w_out_{key}_{tag}"] = obs.to_numpy("out"), np_(obs["w_out"])
+        G = out[f"X_{key}_f64"].astype(np.float64)
+        s = np.linalg.svd(G, compute_uv=False)
+        print(key, "samples", G.shape[0], "cond(X^T X + alpha I) = %.3g" % np.linalg.cond(G.T @ G + alpha * np.eye(n)),
+              "smallest singular values", s[-3:],
+              "w_out f32 vs f64: %.3g of %.3g" % (np.abs(out[f"w_out_{key}_f32"] - out[f"w_out_{key}_f64"]).max(),
+                                                   np.abs(out[f"w_out_{key}_f64"]).max()))
+    save("g39_fit_ridge_illcond", dt=dt, alpha=alpha, W_in=W_in, **P, **out)
+
+
 if __name__ == "__main__":
     main()
+    ill_conditioned()

@@ -1169,6 +1169,35 @@ def test_sparse_feedback_network_streams_packed_matrices(oracle_backend, hip_dev
         assert np.array_equal(res[0][2][k_], res[1][2][k_]), k_
 
 
+@pytest.mark.gpu
+def test_weights_edited_after_packing_are_repacked_when_the_matrices_move(hip_device, monkeypatch):
+    """(advisor, r04) `node["weights"]` is live: an in-place edit AFTER the matrix was packed at construction must reach the
+    coupled path -- also when the first run moves the matrices into one arena (`_consolidate`), which used to stamp the OLD
+    packed form as current.  Packed run after the edit == dense run of the edited matrix, bit for bit."""
+    monkeypatch.setattr(FeedbackNetwork, "ARENA_MIN_BYTES", 0)
+    r = np.random.default_rng(11)
+    n, T = 1024, 17
+    mat = lambda rows, cols, p=0.1: (r.standard_normal((rows, cols)) / np.sqrt(cols * p) * (r.uniform(size=(rows, cols)) < p)).astype(np.float32)
+    Wa, Wb, Wab, Wba = mat(n, n), mat(n, n), mat(n, n) * 0.6, mat(n, n) * 0.6
+    x = (r.standard_normal((T, n)) * 0.5).astype(np.float32)
+    outs = []
+    for sparse in (True, False):
+        net = FeedbackNetwork(1e-2, device=hip_device)
+        for lab, W in (("a", Wa), ("b", Wb)):
+            net.add_diffeq_node(lab, TANH, weights=W, source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                                output_var="li_op/v", dtype=torch.float32, sparse_weights=sparse)
+        net.add_edge("a", "b", weights=Wab)
+        net.add_edge("b", "a", weights=Wba, feedback=True)
+        pop = net.get_node("a")._pop
+        assert (pop.packed is not None) == sparse
+        with torch.no_grad():
+            net.get_node("a")["weights"].mul_(1.7)        # after packing, before the first run
+        outs.append(net.run(x, verbose=False, enable_grad=False).to_numpy("out"))
+        assert net._arena is not None and pop.W.untyped_storage().data_ptr() == net._arena.untyped_storage().data_ptr()
+    assert np.array_equal(outs[0], outs[1])
+    assert np.abs(outs[0]).max() > 0
+
+
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
 def test_readout_only_fit_behind_coupled_populations_skips_the_adjoint(target, monkeypatch):
     """fit_bptt with only the read-out trained: no gradient has to pass into the populations, so they integrate without a

@@ -59,3 +59,26 @@ def test_g26_fit_ridge_then_test(target):
     assert err(net.state["rnn"], g["state_test_f64"]) <= 2e-5
     # the engine is closer to the float64 truth than the reference's own float32 run
     assert err(y, g["y_f64"]) < 0.1 * err(g["y_f32"], g["y_f64"])
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("key,stride", [("T60_s1", 1), ("T600_s10", 10), ("T120_s2", 2)])
+def test_g39_fit_ridge_with_as_many_samples_as_neurons(target, key, stride):
+    """The ill-conditioned regime (r04 review): 60 samples for 64 neurons, alpha = 1e-3, cond(X^T X + alpha I) = 3e6 ... 4e7.
+    The engine collects float32 states (2e-6 off the reference's float64 ones) and forms the Gram matrix and the solve in
+    float64: the read-out weights stay within 5e-4 of max |w_out| of the reference's float64 run -- the bound stated in
+    Network.fit_ridge -- where the reference's own float32 run is off by 7e-2 ... 1."""
+    g = dict(np.load(os.path.join(GOLD, "g39_fit_ridge_illcond.npz")))
+    net = Network(float(g["dt"]), **target)
+    net.add_func_node("inp", g["W_in"].shape[1], "identity")
+    net.add_diffeq_node("rnn", TANH, output_var="li_op/v", weights=g["W"], source_var="tanh_op/r",
+                        target_var="li_op/r_in", input_var="li_op/I_ext", dtype=torch.float32,
+                        node_vars={"all/li_op/tau": g["tau"], "all/li_op/k": g["k"], "all/li_op/eta": g["eta"],
+                                   "all/li_op/v": g["y0"]})
+    net.add_edge("inp", "rnn", weights=g["W_in"])
+    obs = net.fit_ridge(g["x_" + key], g["target_" + key], sampling_steps=stride, alpha=float(g["alpha"]), verbose=False)
+    ref, ref32 = g[f"w_out_{key}_f64"], g[f"w_out_{key}_f32"]
+    assert err(obs.to_numpy("out"), g[f"X_{key}_f64"]) <= 2e-5, "collected states"
+    scale = np.abs(ref).max()
+    assert err(obs["w_out"], ref) <= 5e-4 * scale, f"w_out {err(obs['w_out'], ref) / scale}"
+    assert err(obs["w_out"], ref) < 0.02 * err(ref32, ref)
