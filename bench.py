@@ -356,6 +356,8 @@ def main():
         out["extra"]["rls_n32768"] = rls_extra(dev, cpu_threads=cpu_threads)
         out["extra"]["qif_n65536"] = qif_extra(dev, T=args.qif_steps, cpu_threads=cpu_threads)
         out["extra"]["sparse_p0.1_n32768"] = sparse_extra(dev)
+        torch.cuda.empty_cache()
+        out["extra"]["one_rank_exchange"] = one_rank_exchange_extra()
     emit(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
@@ -590,8 +592,9 @@ def small_n_extra(dev, N=512, T=2000):
     e1.record()
     torch.cuda.synchronize()
     res["launch_floor_us"] = e0.elapsed_time(e1) / 2000 * 1e3
-    res["note"] = ("one kernel launch per Euler step (two per adjoint step): the step is bounded by the dependent-launch "
-                   "interval of the stream, not by HBM (W is 1 MiB)")
+    res["note"] = ("one kernel launch per Euler step and one per adjoint step (W^T in a workspace, the forward's row-dot kernel with "
+                   "the adjoint update as its epilogue): bounded by the dependent-launch interval of the stream, not by HBM "
+                   "(W is 1 MiB); fit_bptt adds the per-window work (W^T copy, dW GEMM, read-out, loss, optimiser) to the two launches")
     return res
 
 
@@ -999,6 +1002,32 @@ def stepwise_extra(dev):
             del x_h, y_h
             torch.cuda.empty_cache()
             res["sizes"][f"N{N}"] = {k_: round(v_, 2) for k_, v_ in rec.items()}
+    return res
+
+
+def one_rank_exchange_extra(timeout=420):
+    """The row-sharded path with ONE rank, once per exchange mode, each in a fresh CHILD process of this benchmark (the
+    parent keeps running; nothing re-executes a process that has touched the GPU): `bench.py --gpus 1 --force-dist
+    --exchange rccl|direct`, forward (200 timed steps of the N = 32768 network) and a forward + adjoint window.  With one
+    rank no data moves, so this is the in-library cost of the exchange machinery per step -- RCCL's all-gather /
+    reduce-scatter launches, the direct exchange's push + stream signal -- in a record the driver keeps; the scaling curve
+    itself needs the multi-GPU node."""
+    import subprocess
+    res = {"note": "one rank: the exchange moves no data; per-step cost of the in-library exchange path, child processes of bench.py"}
+    for mode in ("rccl", "direct"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-dist", "--exchange", mode, "--steps", "200",
+               "--warmup", "20", "--no-cpu-baseline", "--no-extra", "--config5-neurons", "0"]
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+            line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+            fb = (line.get("extra") or {}).get("sharded_fwd_bwd") or {}
+            res[mode] = {"forward_steps_per_s": line["value"], "forward_ms_per_step": line["ms_per_step"],
+                         "exchange": line["config"]["exchange"], "kernel_plus_exchange_ms": line["roofline"]["avg_launch_ms"],
+                         "fwd_bwd": {k: fb[k] for k in ("fwd_bwd_steps_per_s", "ms_per_step_pair", "cross_rank_sum", "grad_finite",
+                                                        "skipped", "error") if k in fb}}
+        except Exception as e:  # reported, never fatal
+            res[mode] = {"error": f"{type(e).__name__}: {e}"}
     return res
 
 

@@ -145,11 +145,14 @@ class DirectExchange:
         """Unmap the peers' buffers (collective by convention: call it on every rank once nobody pushes any more).  The own
         allocations stay alive with the tensors that wrap them and are freed when those are gone.
 
-        The protocol has no time-out: a rank that dies in the middle of a run leaves its peers' streams waiting for a
-        sequence number that never comes (hipStreamWaitValue32 has no deadline); the launcher ends the job, as it does for
-        a rank lost inside an RCCL collective."""
+        The protocol itself has no time-out: a rank that dies in the middle of a run leaves its peers' streams waiting for
+        a sequence number that never comes (hipStreamWaitValue32 has no deadline).  ShardedPopulation therefore runs a
+        host-side StallWatchdog next to it: no progress of the peers' sequence numbers for `deadline_s` seconds while work
+        is outstanding ends the rank with a non-zero exit code."""
         from . import _lib
         torch.cuda.synchronize()
+        if getattr(self, "_watchdog", None) is not None:
+            self._watchdog.stop()
         mapped, self._mapped[:] = list(self._mapped), []
         for q in mapped:
             _lib.check(self.lib.rp_ipc_close(q), self.lib)
@@ -177,6 +180,52 @@ def _wrap_device_floats(ptr: int, count: int, device, owner) -> torch.Tensor:
     mem.owner = owner
     mem.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
     return torch.as_tensor(mem, device=device)
+
+
+class StallWatchdog:
+    """Host-side deadline for the per-step exchange of a row-sharded run.  The stream-ordered direct exchange waits for
+    its peers with hipStreamWaitValue32, which has no time-out, and a host-loop collective blocks in the process group: a
+    rank that dies or hangs would leave its peers waiting for ever.  A daemon thread watches a PROGRESS number (the sum of
+    the rank's flag array -- the peers' sequence numbers -- read on a side stream; the host loop's step counter) while the
+    rank is BUSY (work outstanding on the compute stream / inside the host loop): no progress for `deadline_s` seconds ends
+    the process with exit code ``EXIT_CODE`` and a message on stderr, so that the launcher sees a failed rank instead of a
+    silent hang.  ``RECTIPY_AMD_EXCHANGE_DEADLINE`` (seconds; 0 = off) sets the default of ShardedPopulation."""
+
+    EXIT_CODE = 75   # EX_TEMPFAIL
+
+    def __init__(self, deadline_s: float, progress, busy, what: str = "exchange"):
+        import threading
+        self.deadline_s, self._progress, self._busy, self.what = float(deadline_s), progress, busy, what
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._watch, name="rectipy_amd-stall-watchdog", daemon=True)
+        self._thread.start()
+        import atexit
+        atexit.register(self.stop)   # (no device queries while the interpreter shuts down)
+
+    def stop(self):
+        self._stop.set()
+
+    def _watch(self):
+        import os
+        import sys
+        import time
+        last, since = None, time.monotonic()
+        poll = max(0.05, min(1.0, self.deadline_s / 4))
+        while not self._stop.wait(poll):
+            try:
+                if not self._busy():
+                    last, since = None, time.monotonic()
+                    continue
+                now = self._progress()
+            except Exception:
+                continue   # (interpreter shutting down, device gone: nothing to judge)
+            if now != last:
+                last, since = now, time.monotonic()
+            elif time.monotonic() - since > self.deadline_s:
+                sys.stderr.write(f"[rectipy_amd] rank stalled: no progress of the {self.what} for {self.deadline_s:.0f} s "
+                                 f"(a peer rank died or hangs); exiting with code {self.EXIT_CODE}\n")
+                sys.stderr.flush()
+                os._exit(self.EXIT_CODE)
 
 
 def one_rank_env(environ=None):
@@ -207,9 +256,13 @@ class ShardedPopulation:
     """One rank's shard plus the per-step exchange."""
 
     def __init__(self, model: str, weights_local, params_local: Dict[str, object], dt: float, device, n: int,
-                 v0_local=None, s0_local=None, group=None, backend=None, exchange: Optional[str] = None, **kw):
+                 v0_local=None, s0_local=None, group=None, backend=None, exchange: Optional[str] = None,
+                 deadline_s: Optional[float] = None, **kw):
         """``exchange``: None / "rccl" -- the per-step RCCL all-gather enqueued in-library (host loop for gloo groups);
-        "direct" -- the stream-ordered push exchange (:class:`DirectExchange`; opt-in, also RECTIPY_AMD_EXCHANGE=direct)."""
+        "direct" -- the stream-ordered push exchange (:class:`DirectExchange`; opt-in, also RECTIPY_AMD_EXCHANGE=direct).
+        ``deadline_s``: seconds without progress of the exchange after which the rank exits (:class:`StallWatchdog`;
+        default RECTIPY_AMD_EXCHANGE_DEADLINE or 120, 0 = off; direct exchange and host loop -- a rank lost inside an RCCL
+        collective is the launcher's and RCCL's own watchdog's to end)."""
         import os
         self.group = group
         self.world = dist.get_world_size(group)
@@ -230,6 +283,24 @@ class ShardedPopulation:
             self.comm = agreed_comm(rccl_comm(group, self.pop.device, self.pop.backend), group, self.pop.device)
         else:
             raise ValueError(f"exchange must be 'rccl' or 'direct', got {exchange!r}")
+        # a host-side deadline for a dead or hanging peer (StallWatchdog): the direct exchange and the host loop have none
+        self._beats, self._in_loop = 0, False
+        deadline = float(os.environ.get("RECTIPY_AMD_EXCHANGE_DEADLINE", "120")) if deadline_s is None else float(deadline_s)
+        self.watchdog = None
+        if deadline > 0 and self.world > 1:
+            if self.direct is not None:
+                dev = self.pop.device
+                flags = _wrap_device_floats(self.direct._own[2], self.world, dev, self.direct).view(torch.int32)
+                side = torch.cuda.Stream(device=dev)
+                main = torch.cuda.current_stream(dev)
+
+                def progress():
+                    with torch.cuda.stream(side):
+                        return int(flags.sum().item())
+                self.watchdog = StallWatchdog(deadline, progress, lambda: not main.query(), "direct exchange (peer sequence numbers)")
+                self.direct._watchdog = self.watchdog   # (stopped by DirectExchange.close: nothing is pushed afterwards)
+            elif self.comm is None:
+                self.watchdog = StallWatchdog(deadline, lambda: self._beats, lambda: self._in_loop, "host-loop exchange")
 
     def _gather_source(self):
         full = self.pop.source
@@ -257,12 +328,17 @@ class ShardedPopulation:
         if self.comm is not None:  # one library call: step kernels and RCCL all-gathers back to back on one stream
             return self.pop.forward(steps, x=x, out_var=out_var, traj=traj, step0=step0, sample_idx=idx,
                                     comm=self.comm, **sampling)
-        for t in range(steps):
-            xt = None if x is None else x[t:t + 1]
-            tr = None if traj is None else traj[t:t + 1]
-            idx = self.pop.forward(1, x=xt, out_var=out_var, traj=tr, step0=step0 + t, sample_idx=idx, **sampling)
-            full = self.pop.source  # the buffer the kernel just wrote this rank's slice into
-            dist.all_gather_into_tensor(full, full[self.row0:self.row0 + self.rows], group=self.group)
+        self._in_loop = True
+        try:
+            for t in range(steps):
+                xt = None if x is None else x[t:t + 1]
+                tr = None if traj is None else traj[t:t + 1]
+                idx = self.pop.forward(1, x=xt, out_var=out_var, traj=tr, step0=step0 + t, sample_idx=idx, **sampling)
+                full = self.pop.source  # the buffer the kernel just wrote this rank's slice into
+                dist.all_gather_into_tensor(full, full[self.row0:self.row0 + self.rows], group=self.group)
+                self._beats += 1
+        finally:
+            self._in_loop = False
         return idx
 
     def backward(self, traj_v, traj_r, grad_out, grad_var, lam, u_traj, **kw):
