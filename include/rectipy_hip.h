@@ -700,9 +700,17 @@ typedef struct rp_rls {
        large vectors: acc = Y_j[q]; acc = fma(-g_ij, z_i[q], acc) for i ascending; z_j[q] = (float)acc; the dot products
        in the order of x.z with double accumulators -- and the prediction, the loss and the weight update from z_j and k_j as
        always.  Mathematically the reference's recursion; measured against its float64 run the blocked sweep is as close as
-       the pass per update (G31 / G34).  Workspaces grow by the factor `block`: partials [block x n_in x ceil(n_in /
-       1024)], colparts [block x chunks x ldc]; blk: 2 * block * n_in floats (Y, the block's z vectors), block^2 doubles
-       (c_ij), block floats (k_i), 16-byte aligned.  0 / 1: one pass per update (above). */
+       the pass per update (G31 / G34).
+       r05: unless predictions BETWEEN updates are asked for (stride > 1 with pred) or n_out > 64, the per-update launches are replaced by
+       TWO launches per block: every z_j is a combination of the block's Y vectors, z_j = sum_{l<=j} A_jl Y_l (A_jj = 1), so
+       all dot products follow from the Gram matrix G_lj = Y_l . x_j (double, the order of x.z) and H_oj = W_o . x_j (float;
+       W as the block finds it):  c_ij = sum_{l<=i} A_il G_lj (fma, l ascending from 0), g_ij as above, A_j = e_j - sum_{i<j}
+       g_ij A_i (fma, i ascending), k_j = (float)(1 / (1 + c_jj)), yhat_j[o] = (float)(H_oj + sum_{i<j} (k_i err_i[o]) c_ij)
+       (double, i ascending) -- all on block x block doubles --; then z_j[q] = (float)(Y_j[q] + sum_{l<j} A_jl Y_l[q]) (double, fma,
+       l ascending) and W_o[q] += (k_j err_j[o]) z_j[q] for j ascending.  Every cancellation is carried in double.
+       Workspaces grow by the factor `block`: partials [block x n_in x ceil(n_in / 1024)], colparts [block x chunks x ldc];
+       blk: 2 * block * n_in floats (Y, the block's z vectors), 2 * block^2 doubles (c_ij or G_lj; A_jl), then
+       block * (1 + 2 * n_out) floats (k_i; H; k_j err_j), 16-byte aligned.  0 / 1: one pass per update (above). */
     int32_t block;
     float* blk;
 } rp_rls;

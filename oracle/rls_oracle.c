@@ -179,15 +179,72 @@ static int sweep_blocked(const rp_rls* r, int32_t steps, int32_t stride, const f
     const int n = r->n_in, m = r->n_out, K = r->block;
     float* Yb = r->blk;
     float* Zb = Yb + (int64_t)K * n;
-    double* cm = (double*)(Zb + (int64_t)K * n);  /* c_ij, double */
-    float* kk = (float*)(cm + K * K);
+    double* cm = (double*)(Zb + (int64_t)K * n);  /* c_ij (update by update) / G_lj (Gram form), double */
+    double* am = cm + K * K;                      /* A_jl of the Gram form */
+    float* kk = (float*)(am + K * K);
+    float* hm = kk + K;                           /* H_oj = W_o . x_j */
+    float* ke = hm + (int64_t)m * K;              /* k_j err_j[o] */
     float* err = r->scratch + 4;
     const int updates = (steps + stride - 1) / stride;
+    const int gram = (stride == 1 || !pred) && m <= 64; /* rp_rls.block, r05: the block's scalars from its Gram matrix */
     int pending = 0;
     for (int u0 = 0; u0 < updates; u0 += K) {
         const int cnt = updates - u0 < K ? updates - u0 : K;
         for (int i = 0; i < pending; ++i) sym_pass(r, 1, kk[i], Zb + (int64_t)i * n, 0, 0);
         for (int j = 0; j < cnt; ++j) sym_pass(r, 0, 0.0f, 0, X + (int64_t)(u0 + j) * stride * ldx, Yb + (int64_t)j * n);
+        if (gram) {
+            double c[8];
+            for (int l = 0; l < cnt; ++l)
+                for (int j = 0; j < cnt; ++j)
+                    cm[l * K + j] = block_dot64(Yb + (int64_t)l * n, X + (int64_t)(u0 + j) * stride * ldx, n);
+            for (int o = 0; o < m; ++o)
+                for (int j = 0; j < cnt; ++j)
+                    hm[o * K + j] = block_dot(r->W + (int64_t)o * r->ldw, X + (int64_t)(u0 + j) * stride * ldx, n);
+            for (int j = 0; j < cnt; ++j) {
+                const int t = (u0 + j) * stride;
+                const float* y = Y + (int64_t)t * ldy;
+                double* Aj = am + j * K;
+                for (int l = 0; l < cnt; ++l) Aj[l] = l == j ? 1.0 : 0.0;
+                for (int i = 0; i < j; ++i) {
+                    double cij = 0.0;
+                    for (int l = 0; l <= i; ++l) cij = fma(am[i * K + l], cm[l * K + j], cij);
+                    c[i] = cij;
+                    const double g = (double)r->beta_inv * ((double)kk[i] * cij);
+                    for (int l = 0; l <= i; ++l) Aj[l] = fma(-g, am[i * K + l], Aj[l]);
+                }
+                double d = 0.0;
+                for (int l = 0; l <= j; ++l) d = fma(Aj[l], cm[l * K + j], d);
+                const float k = (float)(1.0 / (1.0 + d));
+                kk[j] = k;
+                float l2 = 0.0f;
+                for (int o = 0; o < m; ++o) {
+                    double yh = (double)hm[o * K + j];
+                    for (int i = 0; i < j; ++i) yh = fma((double)ke[i * m + o], c[i], yh);
+                    const float yhat = (float)yh;
+                    const float e = y[o] - yhat;
+                    l2 = fmaf(e, e, l2);
+                    ke[j * m + o] = k * e;
+                    if (pred) pred[(int64_t)t * ldpred + o] = yhat;
+                }
+                const int seg = t + stride <= steps ? stride : steps - t;
+                if (loss)
+                    for (int q = 0; q < seg; ++q) loss[t + q] = l2;
+            }
+            for (int q = 0; q < n; ++q) {
+                for (int j = 0; j < cnt; ++j) {
+                    double acc = (double)Yb[(int64_t)j * n + q];
+                    for (int l = 0; l < j; ++l) acc = fma(am[j * K + l], (double)Yb[(int64_t)l * n + q], acc);
+                    Zb[(int64_t)j * n + q] = (float)acc;
+                }
+                for (int o = 0; o < m; ++o) {
+                    float w = r->W[(int64_t)o * r->ldw + q];
+                    for (int j = 0; j < cnt; ++j) w = w + ke[j * m + o] * Zb[(int64_t)j * n + q];
+                    r->W[(int64_t)o * r->ldw + q] = w;
+                }
+            }
+            pending = cnt;
+            continue;
+        }
         for (int j = 0; j < cnt; ++j) {
             const int t = (u0 + j) * stride;
             const float* x = X + (int64_t)t * ldx;

@@ -57,6 +57,19 @@ struct RlsParams {
     float* kk;           // [K] k of the block's updates
     int j, K;            // the update of the block the small kernels work on
     float* z0;           // where the z vector of the block's first update goes (= Y_0)
+    // the block's scalars from its Gram matrix (rls_blk_gram_kernel / rls_blk_apply_kernel)
+    double* gm;          // [K x K] G_lj = Y_l . x_j
+    double* am;          // [K x K] A: z_j = sum_l A_jl Y_l
+    float* hm;           // [n_out x K] H_oj = W_o . x_j with the weights the block starts from
+    float* ke;           // [K x n_out] k_j err_j[o]
+    int cnt;             // updates of this block
+    const float* y0;     // targets of the block's first update; update j at y0 + j * y_stride
+    int64_t y_stride;
+    float* pred0;        // prediction row of the block's first update (or null); update j at pred0 + j * pred_stride
+    int64_t pred_stride;
+    float* loss0;        // loss of update j replicated into loss0[j * loss_stride ... + loss_count_j)
+    int loss_stride, loss_tail;  // entries per update; entries of the block's LAST update
+    float* zp_out;       // [K x n_in] receives the block's z vectors (the next pass applies them)
 };
 
 
@@ -807,6 +820,172 @@ __global__ __launch_bounds__(1024) void rls_blk_scalars_kernel(const RlsParams P
     if (P.loss_out && tid < P.loss_count) P.loss_out[tid] = red[0];
 }
 
+// ---- r05: the scalars of a whole block from ONE launch ---------------------------------------------------------------------
+// Inside a block every z_j is a combination of the block's Y vectors, z_j = sum_{l <= j} A_jl Y_l (A_jj = 1), so every dot
+// product the recurrence needs follows from the Gram matrix G_lj = Y_l . x_j:  c_ij = z_i . x_j = sum_l A_il G_lj.  One launch
+// forms G (cnt^2 dot products in double, each in the order of rls_blk_scalars_kernel: per-thread chain over q = tid + 1024 m,
+// then a 1024-leaf tree) and H_oj = W_o . x_j (the predictions' part that comes from the weights the block starts from, float
+// as there); the block that finishes last runs the recurrence on K x K doubles:
+//   for j: A_j = e_j; for i < j: c_ij = sum_{l<=i} A_il G_lj (l ascending from 0, fma); g = beta^-1 (k_i c_ij); A_j -= g A_i (fma)
+//          d_j = c_jj likewise; k_j = (float)(1 / (1 + d_j))
+//          yhat_j[o] = (float)(H_oj + sum_{i<j} (k_i err_i[o]) c_ij) (double, i ascending); err, loss as always
+// and rls_blk_apply_kernel then forms all z_j (double: acc = Y_j[q]; acc = fma(A_jl, Y_l[q], acc), l ascending < j) and applies
+// the cnt weight updates one after the other per element.  Two launches per BLOCK instead of two per update; the products are
+// the mathematically identical ones, with every cancellation (z_j is a small difference of large vectors) carried in double.
+__global__ __launch_bounds__(1024) void rls_blk_gram_kernel(const RlsParams P) {
+    __shared__ double red64[1024];
+    __shared__ float red[1024];
+    __shared__ int is_last;
+    __shared__ double G[8][8], A[8][8], c[8];  // (run-time indexed: LDS, not registers)
+    const int tid = threadIdx.x, b = blockIdx.x, cnt = P.cnt, K = P.K;
+    if (b < cnt * cnt) {
+        const int l = b / cnt, j = b - l * cnt;
+        const float* yl = P.yb + (int64_t)l * P.n_in;
+        const float* x = P.xb + (int64_t)j * P.xb_stride;
+        double a = 0.0;
+        for (int j0 = tid; j0 < P.n_in; j0 += 8 * 1024) {
+            float uv[8], xv[8];
+            rls_load8(yl, x, j0, P.n_in, uv, xv);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (j0 + q * 1024 < P.n_in) a = fma((double)uv[q], (double)xv[q], a);
+        }
+        red64[tid] = a;
+        __syncthreads();
+        for (int off = 512; off >= 1; off >>= 1) {
+            if (tid < off) red64[tid] = red64[tid] + red64[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) P.gm[l * K + j] = red64[0];
+    } else {
+        const int e = b - cnt * cnt, o = e / cnt, j = e - o * cnt;
+        const float* u = P.W + (int64_t)o * P.ldw;
+        const float* x = P.xb + (int64_t)j * P.xb_stride;
+        float a = 0.f;
+        for (int j0 = tid; j0 < P.n_in; j0 += 8 * 1024) {
+            float uv[8], xv[8];
+            rls_load8(u, x, j0, P.n_in, uv, xv);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (j0 + q * 1024 < P.n_in) a = fmaf(uv[q], xv[q], a);
+        }
+        red[tid] = a;
+        __syncthreads();
+        for (int off = 512; off >= 1; off >>= 1) {
+            if (tid < off) red[tid] = red[tid] + red[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) P.hm[o * K + j] = red[0];
+    }
+    if (tid == 0) {
+        __threadfence();
+        is_last = atomicAdd(reinterpret_cast<unsigned*>(P.scal + 3), 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // The recurrence, on LDS operands, by a handful of threads in lock step (every chain in the order stated above: the work
+    // is split over the independent chains -- c_ij over i, A_jl over l, yhat_j[o] over o --, never inside one).  One thread
+    // walking it through global memory took 50 us: ~300 dependent round trips.
+    __shared__ float Hs[64][8], Ys[8][64], KE[8][64], ks[8], ls[8], yh_s[8][64];
+    const int m = P.n_out;
+    __threadfence();
+    if (tid < cnt * cnt) G[tid / cnt][tid % cnt] = __hip_atomic_load(P.gm + (tid / cnt) * K + tid % cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int e = tid; e < m * cnt; e += 1024) {
+        const int o = e / cnt, j = e - o * cnt;
+        if (o < 64) {
+            Hs[o][j] = __hip_atomic_load(P.hm + o * K + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            Ys[j][o] = P.y0[(int64_t)j * P.y_stride + o];
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < cnt; ++j) {
+        if (tid < j) {  // c_ij, i = tid
+            double cij = 0.0;
+            for (int l = 0; l <= tid; ++l) cij = fma(A[tid][l], G[l][j], cij);
+            c[tid] = cij;
+        }
+        __syncthreads();
+        if (tid < cnt) {  // A_jl, l = tid
+            double a = tid == j ? 1.0 : 0.0;
+            for (int i = 0; i < j; ++i)
+                if (tid <= i) a = fma(-((double)P.beta_inv * ((double)ks[i] * c[i])), A[i][tid], a);
+            A[j][tid] = a;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double d = 0.0;
+            for (int l = 0; l <= j; ++l) d = fma(A[j][l], G[l][j], d);
+            ks[j] = (float)(1.0 / (1.0 + d));
+        }
+        __syncthreads();
+        if (tid < m && tid < 64) {  // yhat_j[o], o = tid
+            double yh = (double)Hs[tid][j];
+            for (int i = 0; i < j; ++i) yh = fma((double)KE[i][tid], c[i], yh);
+            const float yhat = (float)yh;
+            yh_s[j][tid] = yhat;
+            KE[j][tid] = ks[j] * (Ys[j][tid] - yhat);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float loss = 0.f;
+            for (int o = 0; o < m; ++o) {
+                const float e = Ys[j][o] - yh_s[j][o];
+                loss = fmaf(e, e, loss);
+            }
+            ls[j] = loss;
+        }
+        __syncthreads();
+    }
+    // results: A, k, k err, predictions, losses
+    if (tid < cnt * cnt) P.am[(tid / cnt) * K + tid % cnt] = A[tid / cnt][tid % cnt];
+    if (tid < cnt) P.kk[tid] = ks[tid];
+    for (int e = tid; e < m * cnt; e += 1024) {
+        const int j = e / m, o = e - j * m;
+        P.ke[j * m + o] = KE[j][o];
+        if (P.pred0) P.pred0[(int64_t)j * P.pred_stride + o] = yh_s[j][o];
+    }
+    if (P.loss0)
+        for (int e = tid; e < cnt * P.loss_stride; e += 1024) {
+            const int j = e / P.loss_stride, q = e - j * P.loss_stride;
+            if (q < (j + 1 < cnt ? P.loss_stride : P.loss_tail)) P.loss0[(int64_t)j * P.loss_stride + q] = ls[j];
+        }
+    if (tid == 0) {
+        P.scal[0] = ks[cnt - 1];
+        P.scal[1] = ls[cnt - 1];
+        *reinterpret_cast<unsigned*>(P.scal + 3) = 0u;
+    }
+}
+
+// z_j[q] for every update of the block, then the block's weight updates element by element in update order
+__global__ __launch_bounds__(256) void rls_blk_apply_kernel(const RlsParams P) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= P.n_in) return;
+    const int cnt = P.cnt, K = P.K;
+    float z[8];
+    float yv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) yv[j] = j < cnt ? P.yb[(int64_t)j * P.n_in + q] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < cnt) {
+            double acc = (double)yv[j];
+#pragma unroll
+            for (int l = 0; l < 8; ++l)
+                if (l < j) acc = fma(P.am[j * K + l], (double)yv[l], acc);
+            z[j] = (float)acc;
+            P.zp_out[(int64_t)j * P.n_in + q] = z[j];
+        }
+    }
+    for (int o = 0; o < P.n_out; ++o) {
+        float* wp = P.W + (int64_t)o * P.ldw + q;
+        float w = *wp;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < cnt) w = w + P.ke[j * P.n_out + o] * z[j];
+        *wp = w;
+    }
+}
+
 constexpr int kSymRowsDefault = 64;
 #ifdef RP_MEASUREMENT
 std::atomic<int> g_sym_inflight{0};  // measurement build only (rp_set_rls_sym): rows in flight per wave; 0 = built-in
@@ -938,7 +1117,13 @@ int sweep_blocked(const rp_rls* r, RlsParams P, int sym_rows, int32_t steps, int
     float* Yb = r->blk;
     float* Zb = Yb + (int64_t)K * n;
     P.cm = reinterpret_cast<double*>(Zb + (int64_t)K * n);
-    P.kk = reinterpret_cast<float*>(P.cm + K * K);
+    P.gm = P.cm;                 // (the Gram form keeps G where the update-by-update form keeps c)
+    P.am = P.cm + K * K;
+    P.kk = reinterpret_cast<float*>(P.am + K * K);
+    P.hm = P.kk + K;             // [n_out x K]
+    P.ke = P.hm + (int64_t)r->n_out * K;  // [K x n_out]
+    // predictions BETWEEN updates (stride > 1 with pred) need the weights after every single update: the update-by-update form
+    const bool gram = (stride == 1 || !pred) && r->n_out <= 64;   // (the recurrence keeps its operands in LDS: <= 64 read-out channels)
     P.yb = Yb;
     P.K = K;
     P.zp = Zb;
@@ -967,6 +1152,23 @@ int sweep_blocked(const rp_rls* r, RlsParams P, int sym_rows, int32_t steps, int
     for (int u0 = 0; u0 < updates; u0 += K) {
         const int cnt = updates - u0 < K ? updates - u0 : K;
         if (pass(pending, cnt, X + (int64_t)u0 * stride * ldx) != RP_OK) RP_FAIL(RP_ERR_ARG, "no blocked RLS kernel for %d rows per tile", sym_rows);
+        if (gram) {  // the block's scalars from its Gram matrix: two launches per block
+            const int t0 = u0 * stride;
+            P.cnt = cnt;
+            P.y0 = Y + (int64_t)t0 * ldy;
+            P.y_stride = (int64_t)stride * ldy;
+            P.pred0 = pred ? pred + (int64_t)t0 * ldpred : nullptr;
+            P.pred_stride = (int64_t)stride * ldpred;
+            P.loss0 = loss ? loss + t0 : nullptr;
+            P.loss_stride = stride;
+            const int t_last = (u0 + cnt - 1) * stride;
+            P.loss_tail = t_last + stride <= steps ? stride : steps - t_last;
+            P.zp_out = Zb;
+            hipLaunchKernelGGL(rls_blk_gram_kernel, dim3(cnt * cnt + r->n_out * cnt), dim3(1024), 0, st, P);
+            hipLaunchKernelGGL(rls_blk_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, st, P);
+            pending = cnt;
+            continue;
+        }
         for (int j = 0; j < cnt; ++j) {
             const int t = (u0 + j) * stride;
             P.j = j;

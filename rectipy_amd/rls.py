@@ -165,7 +165,7 @@ class RLS(Linear):
             r.colparts, r.ldc, r.sym_rows = self._colparts.data_ptr(), self._colparts.stride(0), rows
             r.defer_mirror = 1
             if block > 1:
-                need = 2 * block * self.n_in + 2 * block * block + block
+                need = 2 * block * self.n_in + 4 * block * block + block * (1 + 2 * self.n_out)   # (rp_rls.blk)
                 if self._blk is None or self._blk.numel() < need:
                     self._blk = torch.zeros(need, dtype=torch.float32, device=dev)
                 r.block, r.blk = block, self._blk.data_ptr()
