@@ -910,6 +910,8 @@ int rp_bwd_prepare(const rp_net* net, const rp_bwd* b, void* stream) {
         if (rc != RP_OK) return rc;
         if (b->steps <= 0) RP_FAIL(RP_ERR_ARG, "steps must be > 0");
         spk_set_prep(b, P, b->steps - 1);
+        if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP)  // the adjoint's population means (unsharded only: spk_setup)
+            hipLaunchKernelGGL(adj_mean_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), P);
         hipLaunchKernelGGL(spk_prep_kernel, dim3((P.rows + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), P, G);
         RP_HIP_CHECK(hipGetLastError());
         return RP_OK;
@@ -947,6 +949,8 @@ int rp_bwd_apply(const rp_net* net, const rp_bwd* b, int32_t t, const float* z_l
         if (t < 0 || t >= b->steps || !z_local) RP_FAIL(RP_ERR_ARG, "bad step index or null z_local");
         P.z_direct = z_local;
         spk_set_step(b, P, t);
+        if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP)
+            hipLaunchKernelGGL(adj_mean_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), P);
         hipLaunchKernelGGL(spk_finalize_kernel, dim3((P.rows + 255) / 256), dim3(256), 0,
                            static_cast<hipStream_t>(stream), P, G);
         RP_HIP_CHECK(hipGetLastError());
@@ -1206,8 +1210,6 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
         if (!M.net || !M.bwd || !M.z) RP_FAIL(RP_ERR_ARG, "member %d: net / bwd / z is null", m);
         if (M.net->rows != M.net->n || M.net->row0 != 0) RP_FAIL(RP_ERR_ARG, "member %d: row shards cannot be coupled", m);
         if (M.bwd->steps != T || T <= 0) RP_FAIL(RP_ERR_ARG, "member %d: every member sweeps the same window (steps > 0)", m);
-        if (M.net->model == RP_MODEL_IKU || M.net->model == RP_MODEL_IK_BIEXP)
-            RP_FAIL(RP_ERR_ARG, "member %d: population-mean models have no step-wise adjoint", m);
         if (M.n_edges < 0 || M.n_edges > RP_MAX_EDGES) RP_FAIL(RP_ERR_ARG, "member %d: n_edges must be in [0, %d]", m, RP_MAX_EDGES);
         if (M.n_edges > 0 && (!M.bwd->grad_x || !M.edge_work)) RP_FAIL(RP_ERR_ARG, "member %d has edges: grad_x and edge_work are required", m);
         if (M.bwd->spt_vals) {
@@ -1281,8 +1283,9 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
         const int rc = rp_bwd_prepare(mem[q].net, mem[q].bwd, stream);
         if (rc != RP_OK) return rc;
     }
-    bool small = false;
-    if (!post && !any_packed && coupled_fused_ok(mem, count, &small)) return coupled_fused_sweep(mem, count, T, st, small);
+    bool small = false, means = false;  // (population-mean members need their reduction launch in front of every step: per-member path)
+    for (int m = 0; m < count; ++m) means = means || mem[m].net->model == RP_MODEL_IKU || mem[m].net->model == RP_MODEL_IK_BIEXP;
+    if (!post && !any_packed && !means && coupled_fused_ok(mem, count, &small)) return coupled_fused_sweep(mem, count, T, st, small);
     for (int t = T - 1; t >= 0; --t) {
         // last member first; in front of a member's step the edge products that end in its output gradient: from gx_x(t)
         // (ready since step t + 1) for the reads of step t's output -- into row t -- and of the output one step earlier

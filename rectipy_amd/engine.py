@@ -657,7 +657,7 @@ class Population:
         keep = [partials]  # returned so the caller keeps the workspaces alive until the stream has consumed them
         if self.spiking:
             if self.model in NEEDS_MEANS:
-                if sharded:
+                if self.rows != self.n:
                     raise NotImplementedError(f"the '{self.model}' model (population-mean coupling) cannot be row-sharded")
                 means = torch.zeros(4, dtype=torch.float32, device=self.device)
                 keep.append(means)

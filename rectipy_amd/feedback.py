@@ -457,8 +457,9 @@ class FeedbackNetwork(Network):
     def _coupled_grad_plan(self) -> Optional[dict]:
         """The coupled plan if its adjoint runs as one call too (rp_backward_coupled): feed-forward edges, feedback edges from
         rate populations (stepped later: the usual direction; stepped earlier: a post-update read) and from spiking populations
-        (their exposed state lags one step).  The population-mean spiking models, activation nodes between populations and
-        edges with memory / masks between populations keep the per-step autograd (`_why_not["coupled_grad"]`)."""
+        (their exposed state lags one step), the population-mean spiking models included (their adjoint means are one more
+        reduction launch per member and step).  Activation nodes between populations and edges with memory / masks between
+        populations keep the per-step autograd (`_why_not["coupled_grad"]`)."""
         plan, why = self._coupled_grad_plan_why()
         self._why_not = dict(getattr(self, "_why_not", {}), coupled_grad=why)
         return plan
@@ -476,8 +477,6 @@ class FeedbackNetwork(Network):
             node = self.get_node(p)
             if node._out_slice is not None:
                 return None, f"population '{p}' exposes a slice of its output variable"
-            if node._pop.model in ("iku", "ik_biexp"):
-                return None, f"population '{p}' ({node._pop.model}): the population-mean models have no step-wise adjoint"
             if node._pop.spiking and node._pop.model not in TRAINABLE:
                 return None, f"population '{p}' ({node._pop.model}) has no surrogate-gradient adjoint"
             for s_, _ in plan["edges"][p]:

@@ -776,6 +776,57 @@ def test_fit_bptt_through_cycles_is_one_forward_and_one_adjoint_call_per_window(
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("case", ["iku", "ik_biexp"])
+def test_population_mean_models_take_the_fused_adjoint(target, case, monkeypatch):
+    """(r05) A cycle with a population-mean spiking population (iku_op / ik_biexp_op, ik.yaml:34-68): the coupled adjoint runs
+    as ONE rp_backward_coupled call per window -- the member's adjoint means are one more reduction launch per step -- and
+    leaves the parameters autograd over the per-step walk leaves (whose single-population form is pinned to the reference by
+    G20 / G21).  inp -> a (mean-coupled IK, parameters and start state of the fixture) -> b (tanh) -> out, feedback b -> a."""
+    import os
+    from test_spiking_bptt import BASE, MEAN_CASES
+    c = MEAN_CASES[case]
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", c["gold"] + ".npz")))
+    n, op = g["W"].shape[0], c["op"]
+    bwd = []
+    real_b = engine.backward_coupled
+    monkeypatch.setattr(engine, "backward_coupled", lambda members: bwd.append(len(members)) or real_b(members))
+    r = np.random.default_rng(8)
+    T, win, nb = 90, 30, 20
+    xin = np.asarray(g["x"][:T], dtype=np.float32)   # [T, n]: the fixture's input drives population a
+    y = r.standard_normal((T, 2)).astype(np.float32) * 0.1
+    Wb, Wab, Wba, Wout = (r.standard_normal(sh) * sc for sh, sc in (((nb, nb), 0.2), ((nb, n), 0.3), ((n, nb), 2.0), ((2, nb), 0.3)))
+    res = []
+    for stepwise in (True, False):
+        bwd.clear()
+        net = FeedbackNetwork(float(g["dt"]), **target)
+        node_vars = {f"all/{op}/{q}": g[q] for q in c["params"]}
+        for i, st in enumerate(c["states"]):
+            node_vars[f"all/{op}/{st}"] = g["y0"][i * n:(i + 1) * n]
+        node = SpikeResetNet.from_pyrates(
+            BASE + c["template"], input_var=f"{op}/I_ext", output_var=f"{op}/s", weights=g["W"], source_var=f"{op}/s",
+            target_var=f"{op}/s_in", spike_var=f"{op}/spike", reset_var=f"{op}/v", node_vars=node_vars,
+            spike_threshold=float(g["theta"]), spike_reset=float(g["v_reset"]), dt=float(g["dt"]), dtype=torch.float32,
+            train_params=["weights"] + [f"{op}/{q}" for q in c["params"]], **target)
+        node.enable_spike_recording(8192)
+        net.add_node("a", node, node_type="diff_eq")
+        net.add_diffeq_node("b", TANH, weights=Wb, source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                            output_var="tanh_op/r", dtype=torch.float32, train_params=["weights", "li_op/tau"])
+        net.add_func_node("out", 2, "identity")
+        net.add_edge("a", "b", weights=Wab, train="gd")
+        net.add_edge("b", "out", weights=Wout, train="gd")
+        net.add_edge("b", "a", weights=Wba, feedback=True, train="gd")
+        net._force_stepwise_adjoint = stepwise
+        obs = net.fit_bptt(xin, y, optimizer="sgd", lr=float(g["lr"]) * 0.1, update_steps=win, sampling_steps=1, verbose=False)
+        assert bwd == ([] if stepwise else [2] * 3), bwd
+        assert len(node.spikes()) >= 10, "the windows must contain spikes"
+        res.append(([p.detach().cpu().numpy().copy() for p in net.parameters()], obs.to_numpy("out")))
+    assert len(res[0][0]) == len(res[1][0]) >= 12
+    for a_, b_ in zip(res[0][0], res[1][0]):
+        assert a_.shape == b_.shape and np.abs(a_ - b_).max() <= 5e-5 * max(1.0, np.abs(a_).max()), np.abs(a_ - b_).max()
+    assert np.abs(res[0][1] - res[1][1]).max() < 5e-5 * max(1.0, np.abs(res[0][1]).max())
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
 @pytest.mark.parametrize("out_r", [False, True])
 def test_feedback_from_a_population_already_stepped_takes_the_fused_adjoint_too(target, out_r, monkeypatch):
     """A feedback edge from an EARLIER population delivers its post-update state (network.py:1354-1357): in the adjoint its
