@@ -571,8 +571,8 @@ __global__ __launch_bounds__(kSparseThreads) void adj_sparse_kernel(const BwdPar
     const int wave = threadIdx.x >> 6;
     constexpr int kWaves = kSparseThreads / RP_WAVE;
     if constexpr (LDS_SRC) rp_sparse_stage_source(lds_u, P.u, P.n, (P.n + 255) & ~255);
-    const int lane_base = LDS_SRC ? 64 * (lane >> 4) : 4 * lane;
-    const int lane_rot = 4 * (lane & 15) + (lane >> 4);
+    const int lane_base = LDS_SRC ? lane : 4 * lane;  // (LDS: the lane's position inside a staged chunk, rp_sparse_stage_source)
+    const int lane_rot = 0;
     const float* xs = LDS_SRC ? lds_u : P.u;
     typedef unsigned short us4 __attribute__((ext_vector_type(4)));
     for (int j = blockIdx.x * kWaves + wave; j < P.n; j += gridDim.x * kWaves) {
@@ -656,7 +656,7 @@ int launch_adj_sparse(const BwdParams& P, const SpkGrad& G, hipStream_t st) {
         const size_t per_wave = sizeof(float) * RP_WAVE * (size_t)P.spt_block_rows;
         const size_t limit = rp_lds_limit();
         if (src_bytes + 16 * per_wave <= limit)
-            return launch_adj_sparse_blocked_cfg<SPIKING, 16, 2>(P, G, st, n_cu, src_bytes + 16 * per_wave);  // (2 groups in flight: as the step kernel)
+            return launch_adj_sparse_blocked_cfg<SPIKING, 16, 1>(P, G, st, n_cu, src_bytes + 16 * per_wave);  // (two register sets of one group: as the step kernel)
         if (src_bytes + 8 * per_wave <= limit)
             return launch_adj_sparse_blocked_cfg<SPIKING, 8, 8>(P, G, st, n_cu, src_bytes + 8 * per_wave);
         return RP_ERR_HIP;

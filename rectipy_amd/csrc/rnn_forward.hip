@@ -458,7 +458,7 @@ __device__ __forceinline__ void sparse_row_result(const StepParams& P, int row, 
 // meets them (value + code = component << 14 | column chunk), four list entries per lane per group, so every
 // accumulator sees the same fmaf sequence and the result is bit-identical.  One row per wave at a time, U groups
 // (1.5 KiB each) in flight.  The source vector is gathered per entry: from LDS when it fits (n <= 32768: one
-// 1024-thread workgroup per CU keeps all of it, stored with a per-64-block rotation by (column >> 6) & 3 so that the
+// 1024-thread workgroup per CU keeps all of it, stored component-major inside every 256-column chunk so that the
 // 64 lanes of a gather hit 64 different banks whatever their chunks and components), else from L2.
 template <int MODEL, bool LDS_SRC, int R, int U>
 __global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepParams P) {
@@ -467,9 +467,9 @@ __global__ __launch_bounds__(kSparseThreads) void step_sparse_kernel(const StepP
     const int wave = threadIdx.x >> 6;
     constexpr int kWaves = kSparseThreads / RP_WAVE;
     if constexpr (LDS_SRC) rp_sparse_stage_source(lds_src, P.src_cur, P.n, (P.n + 255) & ~255);
-    // LDS: 64-column block of this lane inside a chunk and its rotated offset; global: first of its four columns
-    const int lane_base = LDS_SRC ? 64 * (lane >> 4) : 4 * lane;
-    const int lane_rot = 4 * (lane & 15) + (lane >> 4);
+    // LDS: the position of this lane's columns inside a staged chunk; global: first of its four columns
+    const int lane_base = LDS_SRC ? lane : 4 * lane;  // (LDS: the lane's position inside a staged chunk, rp_sparse_stage_source)
+    const int lane_rot = 0;
     const float* xs = LDS_SRC ? lds_src : P.src_cur;
     typedef unsigned short us4 __attribute__((ext_vector_type(4)));
     // R consecutive rows per wave, interleaved (R * U groups in flight, R independent accumulator sets); row lengths
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kSparseThreads) void step_sparse_windowed_kernel(co
     rp_sparse_windowed_rows<U>(S, P.src_cur, P.n, lds_src, [&](int row, float sum) { sparse_row_result<MODEL>(P, row, sum); });
 }
 
-// Blocked form (n <= 32768): rp_sparse_blocked_rows (rp_dot.h) with the step epilogue.  Dynamic LDS = the rotated
+// Blocked form (n <= 32768): rp_sparse_blocked_rows (rp_dot.h) with the step epilogue.  Dynamic LDS = the staged
 // source vector + WAVES x sp_block_rows x 64 parked lane sums.
 template <int MODEL, int WAVES, int U>
 __global__ __launch_bounds__(WAVES * RP_WAVE) void step_sparse_blocked_kernel(const StepParams P) {
@@ -586,9 +586,9 @@ int launch_step_sparse_blocked(const StepParams& P, hipStream_t st, int n_cu) {
                                                  : launch_step_sparse_blocked_cfg<MODEL, 8, 3>(P, st, n_cu, lds);
     }
 #endif
-    // groups in flight per lane (scripts/archive/tune_blocked.py, us per step, 16 waves): n = 32768 (8-row blocks) U=4 121.1,
-    // U=2 117.7, U=1 133.9;  n = 16384 (4-row blocks) U=4 39.7, U=2 38.0
-    return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 2>(P, st, n_cu, lds)
+    // groups per register set -- two sets are in flight per lane since r05 (scripts/probes/sparse_blocked_sweep.py, us per step,
+    // 16 waves, n = 32768, 8-row blocks): U=1 115.9, U=2 119.2, U=3 123.1, U=4 124.3 (r02-r04, one set: U=2 117.7-121, U=1 133.9)
+    return waves == 16 ? launch_step_sparse_blocked_cfg<MODEL, 16, 1>(P, st, n_cu, lds)
                        : launch_step_sparse_blocked_cfg<MODEL, 8, 8>(P, st, n_cu, lds);
 }
 

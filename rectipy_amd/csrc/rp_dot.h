@@ -173,7 +173,7 @@ __device__ __forceinline__ void rp_dot_rows_s1(const RowDotArgs& P, int row_base
 // ---- packed sparse rows (rectipy_amd/sparse.py) ------------------------------------------------------------------
 // Shared by the sparse step kernel and the sparse adjoint (packed W^T).  A lane walks its entry list (value + code =
 // component << 14 | column chunk, four entries per lane per group) and feeds the accumulator the code names; the source
-// vector is gathered per entry from LDS (rotated layout, conflict-free) or from L2.
+// vector is gathered per entry from LDS (component-major layout, conflict-free) or from L2.
 constexpr int kSparseThreads = 1024;
 constexpr int kSparseLdsMaxN = 32768;
 
@@ -187,11 +187,16 @@ __device__ __forceinline__ void rp_sparse_stage_source(float* lds_src, const flo
                                                        int n_total) {
     for (int c4 = threadIdx.x * 4; c4 < n_total; c4 += THREADS * 4) {
         const rp_f4 v = c4 < n_valid ? rp_ld4(src + c4) : rp_f4{0.f, 0.f, 0.f, 0.f};
-        const int base = c4 & ~63, h = (c4 >> 6) & 3, o = c4 & 63;
-        lds_src[base | ((o + 0 + h) & 63)] = v.x;
-        lds_src[base | ((o + 1 + h) & 63)] = v.y;
-        lds_src[base | ((o + 2 + h) & 63)] = v.z;
-        lds_src[base | ((o + 3 + h) & 63)] = v.w;
+        // component-major inside every 256-column chunk: column 256 m + 4 l + c at 256 m + 64 c + l.  A gather of the 64
+        // lanes -- each asking for its own (m, c) -- then hits bank l mod 32 in either half of the wave (ds_read_b32 is
+        // served in two groups of 32 lanes over 32 banks): conflict-free whatever the entries ask for.  (r01-r04 rotated the
+        // components inside 64-column blocks, which is conflict-free over 64 banks only: the counters showed half of the
+        // LDS cycles of the sparse step as bank conflicts, profiles/r05_sparse_pmc.json.)
+        const int pos = (c4 & ~255) + ((c4 & 255) >> 2);
+        lds_src[pos] = v.x;
+        lds_src[pos + 64] = v.y;
+        lds_src[pos + 128] = v.z;
+        lds_src[pos + 192] = v.w;
     }
     __syncthreads();
 }
@@ -201,8 +206,10 @@ __device__ __forceinline__ void sparse_entry(float v, unsigned code, const float
                                              rp_f4& a) {
     float a0 = a.x, a1 = a.y, a2 = a.z, a3 = a.w;
     const int c = (int)(code >> 14), m = (int)(code & 0x3fffu);
-    // LDS: position of column 256 m + 4 l + c in the rotated layout; global: the column itself
-    const int idx = LDS_SRC ? (m << 8) + lane_base + ((lane_rot + c) & 63) : (m << 8) + lane_base + c;
+    // LDS: position of column 256 m + 4 l + c in the component-major layout (lane_base = l); global: the column itself
+    // (lane_base = 4 l)
+    (void)lane_rot;
+    const int idx = LDS_SRC ? (m << 8) + (c << 6) + lane_base : (m << 8) + lane_base + c;
     const float x = xs[idx];
     const float acc = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
     const float r = fmaf(v, x, acc);
@@ -225,8 +232,8 @@ __device__ __forceinline__ void rp_sparse_blocked_rows(const float* __restrict__
                                                        const float* lds_src, float* lds_stash, Epi epi) {
     const int lane = threadIdx.x & (RP_WAVE - 1);
     const int wave = threadIdx.x >> 6;
-    const int lane_base = 64 * (lane >> 4);
-    const int lane_rot = 4 * (lane & 15) + (lane >> 4);
+    const int lane_base = lane;  // (position of the lane's columns inside a staged chunk: rp_sparse_stage_source)
+    const int lane_rot = 0;
     float* const stash = lds_stash + (size_t)wave * RB * RP_WAVE + lane;
     typedef unsigned short us4 __attribute__((ext_vector_type(4)));
     const int nblocks = (rows + RB - 1) / RB;
@@ -244,15 +251,20 @@ __device__ __forceinline__ void rp_sparse_blocked_rows(const float* __restrict__
                 acc = rp_f4{0.f, 0.f, 0.f, 0.f};
             }
         };
-        for (int k = 0; k < len; k += U) {
-            rp_f4 v[U];
-            us4 m[U];
+        // two register sets in turn: the next U groups are requested before the current ones are worked through (r05: the
+        // counters showed the waves 64 % of their time at s_waitcnt with the vector ALUs 36 % and the LDS 20 % busy -- a wave
+        // that requests, waits, then works leaves its stream idle while it works; same entries in the same order)
+        rp_f4 va[U], vb[U];
+        us4 ma[U], mb[U];
+        auto fetch = [&](int k, rp_f4 (&v)[U], us4 (&m)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (k + u < len) {
                     v[u] = rp_ld4_stream(vp + (int64_t)(k + u) * 256);
                     m[u] = __builtin_nontemporal_load(reinterpret_cast<const us4*>(ip + (int64_t)(k + u) * 256));
                 }
+        };
+        auto work = [&](int k, const rp_f4 (&v)[U], const us4 (&m)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u)
                 if (k + u < len) {
@@ -261,6 +273,13 @@ __device__ __forceinline__ void rp_sparse_blocked_rows(const float* __restrict__
                     entry(v[u].z, m[u].z);
                     entry(v[u].w, m[u].w);
                 }
+        };
+        fetch(0, va, ma);
+        for (int k = 0; k < len; k += 2 * U) {
+            fetch(k + U, vb, mb);
+            work(k, va, ma);
+            fetch(k + 2 * U, va, ma);
+            work(k + U, vb, mb);
         }
         const int nr = min(RB, rows - b * RB);
         float mine = 0.f;
@@ -297,8 +316,8 @@ __device__ __forceinline__ void rp_sparse_windowed_rows(const SparseWindowed& S,
     const int lane = threadIdx.x & (RP_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     constexpr int RB = kBatchRows / (kSparseThreads / RP_WAVE);  // rows per wave
-    const int lane_base = 64 * (lane >> 4);
-    const int lane_rot = 4 * (lane & 15) + (lane >> 4);
+    const int lane_base = lane;  // (position of the lane's columns inside a staged chunk: rp_sparse_stage_source)
+    const int lane_rot = 0;
     const int NP = S.phases;
     typedef unsigned short us4 __attribute__((ext_vector_type(4)));
     for (int batch = blockIdx.x; batch < S.batches; batch += gridDim.x) {
