@@ -292,7 +292,7 @@ def main():
     # HBM bytes per launch from the PMC counters need their own rocprofv3 passes (scripts/archive/profile_kernels.sh); the
     # figure is read from the committed summary of that run and labelled as such -- it is NOT measured by this run
     traffic, traffic_source = None, None
-    for name in ("r04_step_kernel_traffic.json", "r03_step_kernel_traffic.json", "r02_step_kernel_traffic.json",
+    for name in ("r05_step_kernel_traffic.json", "r04_step_kernel_traffic.json", "r03_step_kernel_traffic.json", "r02_step_kernel_traffic.json",
                  "r01_step_kernel_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if world == 1 and N == 32768 and os.path.exists(tpath):
@@ -357,7 +357,8 @@ def main():
         out["extra"]["qif_n65536"] = qif_extra(dev, T=args.qif_steps, cpu_threads=cpu_threads)
         out["extra"]["sparse_p0.1_n32768"] = sparse_extra(dev)
         torch.cuda.empty_cache()
-        out["extra"]["one_rank_exchange"] = one_rank_exchange_extra()
+        if os.environ.get("RECTIPY_AMD_BENCH_NO_CHILD") != "1":  # (skipped under a profiler: its preload would follow the children)
+            out["extra"]["one_rank_exchange"] = one_rank_exchange_extra()
     emit(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
@@ -847,12 +848,14 @@ def rls_extra(dev, n_in=32768, k=3, T=64, cpu_threads=None):
     res = {"workload": f"RLS read-out training, n_in={n_in}, n_out={k}, {T} consecutive updates (rp_rls_sweep)",
            "updates_per_s": 1e3 / ms["blocked"], "ms_per_update": ms["blocked"],
            "form": f"blocked symmetric sweep: one read-modify-write pass over the 1024 x 1024 blocks of P on and above the diagonal "
-                   f"per {block} updates (their rank-1 updates + the products with the next {block} inputs), the z vectors of a "
-                   "block by a double-precision recurrence; bit-exact against the oracle, as close to the reference's float64 run "
-                   "as a pass per update (G31 / G34)",
+                   f"per {block} updates (their rank-1 updates + the products with the next {block} inputs); the block's scalars "
+                   "(k, errors, the z vectors' coefficients) from its Gram matrix in double precision: two small launches per BLOCK "
+                   "(r05; r04: two per update); bit-exact against the oracle, as close to the reference's float64 run as a pass "
+                   "per update (G31 / G34)",
            "roofline": roof("blocked", sym_bytes / block,
-                            f"the pass's bytes (blocks on and above the diagonal, read + written once) / {block} updates; the per-update "
-                            "kernels (z recurrence, dot products, weights) and the column-partial traffic are the rest of the time"),
+                            f"the pass's bytes (blocks on and above the diagonal, read + written once) / {block} updates; a call of U updates "
+                            f"makes U / {block} + 1 passes (the first read-only, the last update-only); the Y-from-partials kernel, the "
+                            "Gram / apply launches and the column-partial traffic are the rest of the time"),
            "symmetric_pass_per_update": {"ms_per_update": ms["symmetric"], "updates_per_s": 1e3 / ms["symmetric"],
                                          "roofline": roof("symmetric", sym_bytes, "r04 first half: 0.76 ms")},
            "dense_pass": {"ms_per_update": ms["dense"], "updates_per_s": 1e3 / ms["dense"],

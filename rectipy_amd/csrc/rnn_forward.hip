@@ -540,8 +540,8 @@ template <int MODEL, int WAVES, int U>
 __global__ __launch_bounds__(WAVES * RP_WAVE) void step_sparse_blocked_kernel(const StepParams P) {
     extern __shared__ float lds_src[];
     const int n_pad = (P.n + 255) & ~255;
-    rp_sparse_stage_source<WAVES * RP_WAVE>(lds_src, P.src_cur, P.n, n_pad);
     rp_sparse_blocked_rows<WAVES, U>(P.sp_vals, P.sp_cidx, P.sp_rowoff, P.rows, P.sp_block_rows, lds_src, lds_src + n_pad,
+                                     [&] { rp_sparse_stage_source<WAVES * RP_WAVE>(lds_src, P.src_cur, P.n, n_pad); },
                                      [&](int row, float sum) { sparse_row_result<MODEL>(P, row, sum); });
 }
 

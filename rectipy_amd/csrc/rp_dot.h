@@ -226,10 +226,13 @@ __device__ __forceinline__ void sparse_entry(float v, unsigned code, const float
 // accumulators; when the block's stream is exhausted every lane has parked RB sums and the rows' butterflies run.  Only
 // the block is padded to its longest lane list (1.08x the ideal bytes at RB = 16, p = 0.1, n = 32768; per-row: 1.35x).
 // A lane only ever reads back its own slots, so no barrier is needed.  `epi(row, sum)` is called by one lane per row.
-template <int WAVES, int U, typename Epi>
+// `stage()` brings the gathered vector into the LDS (it ends with the workgroup's barrier); it is called once per wave, AFTER
+// the wave has requested the first groups of its first block, so that the stream's first round trip overlaps the staging.
+template <int WAVES, int U, typename Stage, typename Epi>
 __device__ __forceinline__ void rp_sparse_blocked_rows(const float* __restrict__ vals, const uint16_t* __restrict__ code,
                                                        const int32_t* __restrict__ blkoff, int rows, int RB,
-                                                       const float* lds_src, float* lds_stash, Epi epi) {
+                                                       const float* lds_src, float* lds_stash, Stage stage, Epi epi) {
+    bool staged = false;
     const int lane = threadIdx.x & (RP_WAVE - 1);
     const int wave = threadIdx.x >> 6;
     const int lane_base = lane;  // (position of the lane's columns inside a staged chunk: rp_sparse_stage_source)
@@ -275,6 +278,10 @@ __device__ __forceinline__ void rp_sparse_blocked_rows(const float* __restrict__
                 }
         };
         fetch(0, va, ma);
+        if (!staged) {
+            stage();
+            staged = true;
+        }
         for (int k = 0; k < len; k += 2 * U) {
             fetch(k + U, vb, mb);
             work(k, va, ma);
@@ -289,6 +296,15 @@ __device__ __forceinline__ void rp_sparse_blocked_rows(const float* __restrict__
         }
         if (lane < nr) epi(b * RB + lane, mine);
     }
+    if (!staged) stage();  // (a wave without a block still takes part in the staging and its barrier)
+}
+
+// the same with the vector staged by the caller beforehand
+template <int WAVES, int U, typename Epi>
+__device__ __forceinline__ void rp_sparse_blocked_rows(const float* __restrict__ vals, const uint16_t* __restrict__ code,
+                                                       const int32_t* __restrict__ blkoff, int rows, int RB,
+                                                       const float* lds_src, float* lds_stash, Epi epi) {
+    rp_sparse_blocked_rows<WAVES, U>(vals, code, blkoff, rows, RB, lds_src, lds_stash, [] {}, epi);
 }
 
 // ---- windowed form (n > 32768; sparse.py: pack_rows_windowed) ----------------------------------------------------

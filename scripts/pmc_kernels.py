@@ -105,4 +105,21 @@ forward_coupled([dict(pop=cp[0], run=dict(steps=T, x=torch.zeros(T, 1, device=de
 torch.cuda.synchronize()
 algo["step_edges_kernel<0"] = 4.0 * h * (2 * h) + 4.0 * (9 * h + 2 * h)  # W rows + edge rows + vectors (two source vectors read)
 del cp, mats, arena
+# r05: the recursive filter of an edge with memory between two populations (rp_edge_mem: y <- F y + x, F as large as a
+# recurrent matrix; the recurrent row-dot kernel with the filter's epilogue), and the adjoint strips at the coupled fit's
+# matrix size (16384 x 16384: 2-KiB strips x 2 rows in flight since r05)
+from rectipy_amd.engine import EdgeMemory  # noqa: E402
+Ff = bench.gen_rows(h, 0, h, dev, g=0.5)
+mem = EdgeMemory("filter", h, dev, F=Ff)
+mem.window(torch.randn(T, h, device=dev) * 0.1)
+torch.cuda.synchronize()
+algo["step_kernel<65"] = 4.0 * h * h + 4.0 * 3 * h       # F once + y read, x read, y' written
+del mem, Ff
+pa = Population("li_tanh", bench.gen_rows(h, 0, h, dev), dict(tau=10.0, k=1.0, eta=0.0), 1e-2, dev)
+tv2, tr2, ut2 = (torch.zeros(T, h, device=dev) for _ in range(3))
+pa.forward(T, x=torch.zeros(T, 1, device=dev), save_v=tv2, save_src=tr2)
+keep2 = pa.backward(tv2, tr2, torch.randn(T, h, device=dev) * 0.01, _abi.RP_OUT_STATE0, torch.zeros(h, device=dev), ut2)
+torch.cuda.synchronize()
+algo["wt_partial_kernel<true, 2, 2>"] = 4.0 * h * h + 4.0 * (h + 48 * h)  # the matrix + u + the Q = 48 chunk partials written
+del pa, keep2
 print(json.dumps({"algorithmic_bytes_per_launch": algo}), flush=True)
