@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 17
+#define RP_ABI_VERSION 18
 #define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0
@@ -238,6 +238,9 @@ typedef struct rp_edge_mem {
     int32_t cur;              /* [host, in/out]                                                                       */
     float* u;                 /* [n] DELAY / DELAY_FILTER: receives u every step (rp_run.edge_mem; unused by rp_edge_window).
                                  FILTER: unused, u is the new state                                                   */
+    float* save_u;            /* optional [steps x ld_save] (rp_run.edge_mem only): row t receives the u of step t -- what the
+                                 edge's projection read; the edge's adjoint and weight gradient need it (rp_backward_coupled) */
+    int64_t ld_save;
 } rp_edge_mem;
 int rp_sizeof_edge_mem(void);
 
@@ -505,7 +508,32 @@ typedef struct rp_bwd_member {
     const float* final_src;              /* [n] the member's source vector r at the END of the window; required when an RP_EDGE_LIVE
                                             edge of a LATER member reads this member (a post-update read) and its output variable
                                             is the source; else may be NULL                                               */
+    /* v18: the adjoint through an edge's MEMORY (rp_run.edge_mem of the forward call; none for RP_EMEM_DELAY_FILTER).  With
+       c(t) = W_e^T gx_m(t) as for a plain edge (row / tau by edge_mode as above; not for the post-update read of an RP_EDGE_LIVE
+       edge from an earlier member):
+         RP_EMEM_FILTER  y_t = F y_{t-1} + x_t:  ly(t) = c(t) + F^T ly(t + 1)  (ly = 0 behind the window), and ly(t) -- not c(t) --
+                         is added to row tau of the source's output gradient.  F^T ly is summed like every transposed product
+                         (chunks of RC(n, n) rows of F ascending, chunk partials ascending), ly(t) = (chunk sum of c) + (chunk sum
+                         of F^T ly); edge_lam [n_source] carries ly (in: zeros; out: ly of the window's first step)
+         RP_EMEM_DELAY   u_t = x_{t - d}[j] * ones(n) with d = edge_delay (the smallest delay) and j = edge_chan (its channel):
+                         the TOTAL of c(t) -- per-thread chains over q = tid + 1024 m of the columns' chunk sums, then a
+                         1024-leaf halving tree -- is added to element j of row tau - d of the source's output gradient (rows
+                         before the window: dropped).
+       The weight gradient of such an edge is dW_e = sum_t gx_m(t) (x) u_t on the window the forward call saved
+       (rp_edge_mem.save_u); a masked edge streams weights * mask in both directions (its gradient: the plain one times the mask). */
+    int32_t edge_mem_kind[RP_MAX_EDGES]; /* RP_EMEM_NONE | RP_EMEM_FILTER | RP_EMEM_DELAY                                   */
+    const float* edge_F[RP_MAX_EDGES];   /* FILTER: [n_source x edge_ldf]                                                   */
+    int64_t edge_ldf[RP_MAX_EDGES];
+    float* edge_lam[RP_MAX_EDGES];       /* FILTER: [n_source], 16-byte aligned                                             */
+    float* edge_fwork[RP_MAX_EDGES];     /* FILTER: workspace rp_bwd_shard_partial_rows(n_source, n_source) * n_source floats */
+    int32_t edge_delay[RP_MAX_EDGES];    /* DELAY: d                                                                        */
+    int32_t edge_chan[RP_MAX_EDGES];     /* DELAY: j                                                                        */
 } rp_bwd_member;
+/* An RP_MODEL_INSTANT member (an activation node between populations) in rp_backward_coupled: its rp_bwd carries steps,
+   traj_r = the node's outputs of the window ([steps x ld], rp_run.traj of the forward call), grad_out (read and written like
+   a population's) and grad_x; its adjoint step is gx(t)[i] = grad_out(t)[i] * act'(out(t)[i]) -- act' = 1 (identity),
+   1 - o^2 (tanh: computed as fmaf(-o, o, 1)), o * (1 - o) (sigmoid) -- taken, like a population's step, right after the edge
+   products that end in its output gradient.  No state, no parameters; lam / u_traj / partials / z are not used. */
 int rp_sizeof_bwd_member(void);
 int rp_backward_coupled(const rp_bwd_member* members, int32_t count, void* stream);
 

@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 17
+RP_ABI_VERSION = 18
 RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_MFMA16, RP_BATCH_SLOTS = 0, 1, 2, 32
 RP_COMM_RCCL, RP_COMM_DIRECT = 0, 1
 
@@ -92,7 +92,7 @@ class RpEdgeMem(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("n", C.c_int32), ("depth", C.c_int32),
         ("col_chan", fp), ("col_chan_host", fp), ("F", fp), ("ldf", C.c_int64),
-        ("state", fp * 2), ("cur", C.c_int32), ("u", fp),
+        ("state", fp * 2), ("cur", C.c_int32), ("u", fp), ("save_u", fp), ("ld_save", C.c_int64),
     ]
 
 
@@ -165,6 +165,13 @@ class RpBwdMember(C.Structure):
         ("z", fp),
         ("edge_spt", RpPacked * RP_MAX_EDGES),
         ("final_src", fp),
+        ("edge_mem_kind", C.c_int32 * RP_MAX_EDGES),
+        ("edge_F", fp * RP_MAX_EDGES),
+        ("edge_ldf", C.c_int64 * RP_MAX_EDGES),
+        ("edge_lam", fp * RP_MAX_EDGES),
+        ("edge_fwork", fp * RP_MAX_EDGES),
+        ("edge_delay", C.c_int32 * RP_MAX_EDGES),
+        ("edge_chan", C.c_int32 * RP_MAX_EDGES),
     ]
 
 

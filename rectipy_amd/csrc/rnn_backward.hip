@@ -1200,16 +1200,60 @@ __global__ void lam_add_vec_kernel(const float* c, const BwdParams Q, const floa
     Q.lam[j] = Q.lam[j] + gv;
 }
 
+// ---- v18: the adjoint through an edge's memory, and of an activation-node member ----------------------------------------------
+// FILTER edge: ly(t) = (chunk sum of W_e^T gx) + (chunk sum of F^T ly(t + 1)); dst += ly(t)
+__global__ void filter_adj_kernel(const BwdParams E, const BwdParams F, float* lam, float* dst) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= E.n) return;
+    const float l = chunk_sum(E, j) + chunk_sum(F, j);
+    lam[j] = l;
+    dst[j] = dst[j] + l;
+}
+
+// DELAY edge: the total of c = W_e^T gx (per-thread chains over j = tid + 1024 m of the columns' chunk sums, 1024-leaf tree)
+// goes to ONE element of the source's output gradient
+__global__ __launch_bounds__(1024) void delay_adj_kernel(const BwdParams E, float* dst_elem) {
+    __shared__ float red[1024];
+    const int tid = threadIdx.x;
+    float a = 0.f;
+    for (int j = tid; j < E.n; j += 1024) a = a + chunk_sum(E, j);
+    red[tid] = a;
+    __syncthreads();
+    for (int off = 512; off >= 1; off >>= 1) {
+        if (tid < off) red[tid] = red[tid] + red[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) *dst_elem = *dst_elem + red[0];
+}
+
+// activation-node member: gx(t) = g_out(t) * act'(out(t))
+__global__ void instant_adj_kernel(const float* out_t, const float* g_t, float* gx_t, int n, int act) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const float o = out_t[j];
+    const float d = act == RP_ACT_TANH ? fmaf(-o, o, 1.0f) : (act == RP_ACT_SIGMOID ? o * (1.0f - o) : 1.0f);
+    gx_t[j] = g_t[j] * d;
+}
+
 int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
-    if (!mem || count < 1 || count > 16) RP_FAIL(RP_ERR_ARG, "rp_backward_coupled: 1..16 members");
+    if (!mem || count < 1 || count > RP_MAX_MEMBERS) RP_FAIL(RP_ERR_ARG, "rp_backward_coupled: 1..%d members", RP_MAX_MEMBERS);
+    bool plain = true;  // no activation-node member, no edge with memory: the launch-fused sweeps may take the circuit
     const int T = mem[0].bwd ? mem[0].bwd->steps : 0;
     bool post = false;  // an RP_EDGE_LIVE edge from an earlier member: it reads a post-update output
     bool any_packed = false;  // a fixed sparse edge whose transposed matrix comes in packed form (edge_spt)
     for (int m = 0; m < count; ++m) {
         const rp_bwd_member& M = mem[m];
-        if (!M.net || !M.bwd || !M.z) RP_FAIL(RP_ERR_ARG, "member %d: net / bwd / z is null", m);
+        if (!M.net || !M.bwd) RP_FAIL(RP_ERR_ARG, "member %d: net / bwd is null", m);
+        const bool instant = M.net->model == RP_MODEL_INSTANT;
+        if (!instant && !M.z) RP_FAIL(RP_ERR_ARG, "member %d: z is null", m);
         if (M.net->rows != M.net->n || M.net->row0 != 0) RP_FAIL(RP_ERR_ARG, "member %d: row shards cannot be coupled", m);
         if (M.bwd->steps != T || T <= 0) RP_FAIL(RP_ERR_ARG, "member %d: every member sweeps the same window (steps > 0)", m);
+        if (instant) {
+            plain = false;
+            if (!M.bwd->traj_r || !M.bwd->grad_out || !M.bwd->grad_x || M.bwd->ld < M.net->n || M.bwd->ldg < M.net->n || M.bwd->ldgx < M.net->n)
+                RP_FAIL(RP_ERR_ARG, "member %d (activation node): traj_r (its outputs), grad_out and grad_x are required", m);
+            if (M.bwd->spt_vals) RP_FAIL(RP_ERR_ARG, "member %d: an activation-node member has no matrix", m);
+        }
         if (M.n_edges < 0 || M.n_edges > RP_MAX_EDGES) RP_FAIL(RP_ERR_ARG, "member %d: n_edges must be in [0, %d]", m, RP_MAX_EDGES);
         if (M.n_edges > 0 && (!M.bwd->grad_x || !M.edge_work)) RP_FAIL(RP_ERR_ARG, "member %d has edges: grad_x and edge_work are required", m);
         if (M.bwd->spt_vals) {
@@ -1231,6 +1275,21 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
                     RP_FAIL(RP_ERR_ARG, "member %d edge %d: source %d needs final_src (its output variable is the source)", m, e, q);
             }
             if (!M.edge_w[e] || M.edge_ld[e] < mem[q].net->n) RP_FAIL(RP_ERR_SHAPE, "member %d edge %d: edge_w / edge_ld", m, e);
+            if (mem[q].net->model == RP_MODEL_INSTANT && mode == RP_EDGE_LIVE)
+                RP_FAIL(RP_ERR_ARG, "member %d edge %d: an edge from an activation node is RP_EDGE_OUT (this step's output) or RP_EDGE_LAG (the previous one)", m, e);
+            const int kind = M.edge_mem_kind[e];
+            if (kind != RP_EMEM_NONE) {
+                plain = false;
+                if (kind != RP_EMEM_FILTER && kind != RP_EMEM_DELAY) RP_FAIL(RP_ERR_ARG, "member %d edge %d: no adjoint for edge memory kind %d", m, e, kind);
+                if (mode == RP_EDGE_LIVE && q < m) RP_FAIL(RP_ERR_ARG, "member %d edge %d: an edge with memory cannot be a post-update read here", m, e);
+                if (M.edge_spt[e].vals) RP_FAIL(RP_ERR_ARG, "member %d edge %d: an edge with memory has no packed transposed form", m, e);
+                if (kind == RP_EMEM_FILTER) {
+                    if (!M.edge_F[e] || M.edge_ldf[e] < mem[q].net->n || !M.edge_lam[e] || !M.edge_fwork[e] ||
+                        (reinterpret_cast<uintptr_t>(M.edge_lam[e]) & 15u) || (reinterpret_cast<uintptr_t>(M.edge_fwork[e]) & 15u))
+                        RP_FAIL(RP_ERR_ARG, "member %d edge %d: a filter edge needs edge_F, edge_lam and edge_fwork (16-byte aligned)", m, e);
+                } else if (M.edge_delay[e] < 0 || M.edge_chan[e] < 0 || M.edge_chan[e] >= mem[q].net->n)
+                    RP_FAIL(RP_ERR_ARG, "member %d edge %d: edge_delay / edge_chan", m, e);
+            }
             if (M.edge_spt[e].vals) {
                 any_packed = true;
                 if (M.net->rows % 4 != 0 || !M.edge_spt[e].cidx || !M.edge_spt[e].rowoff || (reinterpret_cast<uintptr_t>(M.edge_work) & 15u) ||
@@ -1280,10 +1339,11 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
                 edge_partials(x, e, T - 1, E);
                 hipLaunchKernelGGL(lam_add_kernel, dim3((E.n + 255) / 256), dim3(256), 0, st, E, Q, mem[q].final_src);
             }
+        if (mem[q].net->model == RP_MODEL_INSTANT) continue;  // (no state: nothing to prepare)
         const int rc = rp_bwd_prepare(mem[q].net, mem[q].bwd, stream);
         if (rc != RP_OK) return rc;
     }
-    bool small = false, means = false;  // (population-mean members need their reduction launch in front of every step: per-member path)
+    bool small = false, means = !plain;  // (population-mean members need their reduction launch in front of every step: per-member path)
     for (int m = 0; m < count; ++m) means = means || mem[m].net->model == RP_MODEL_IKU || mem[m].net->model == RP_MODEL_IK_BIEXP;
     if (!post && !any_packed && !means && coupled_fused_ok(mem, count, &small)) return coupled_fused_sweep(mem, count, T, st, small);
     for (int t = T - 1; t >= 0; --t) {
@@ -1309,8 +1369,34 @@ int rp_backward_coupled(const rp_bwd_member* mem, int32_t count, void* stream) {
                     }
                     BwdParams E;
                     edge_partials(x, e, row, E);
-                    hipLaunchKernelGGL(chunk_sum_add_kernel, dim3((E.n + 255) / 256), dim3(256), 0, st, E, dst);
+                    const int kind = mem[x].edge_mem_kind[e];
+                    if (kind == RP_EMEM_FILTER) {  // ly(t) = c(t) + F^T ly(t + 1); ly(t) into the source's output gradient
+                        BwdParams Fp = {};
+                        Fp.W = mem[x].edge_F[e];
+                        Fp.ldw = mem[x].edge_ldf[e];
+                        Fp.n = Fp.rows = E.n;
+                        Fp.rc = chunk_rows(Fp.n, Fp.rows);
+                        Fp.q = (Fp.rows + Fp.rc - 1) / Fp.rc;
+                        Fp.partials = mem[x].edge_fwork[e];
+                        Fp.u = mem[x].edge_lam[e];
+                        const bool v4 = (Fp.n % 4 == 0) && (Fp.ldw % 4 == 0) && !(reinterpret_cast<uintptr_t>(Fp.W) & 15u);
+                        launch_wt_partial(Fp, v4, st);
+                        hipLaunchKernelGGL(filter_adj_kernel, dim3((E.n + 255) / 256), dim3(256), 0, st, E, Fp, mem[x].edge_lam[e], dst);
+                    } else if (kind == RP_EMEM_DELAY) {
+                        const int rd = tau - mem[x].edge_delay[e];
+                        if (rd >= 0)
+                            hipLaunchKernelGGL(delay_adj_kernel, dim3(1), dim3(1024), 0, st, E,
+                                               const_cast<float*>(mem[q].bwd->grad_out) + (int64_t)rd * mem[q].bwd->ldg + mem[x].edge_chan[e]);
+                    } else
+                        hipLaunchKernelGGL(chunk_sum_add_kernel, dim3((E.n + 255) / 256), dim3(256), 0, st, E, dst);
                 }
+            if (mem[q].net->model == RP_MODEL_INSTANT) {  // gx(t) = g_out(t) * act'(out(t)): ready for the edges into this node
+                const rp_bwd* b = mem[q].bwd;
+                const int n = mem[q].net->n;
+                hipLaunchKernelGGL(instant_adj_kernel, dim3((n + 255) / 256), dim3(256), 0, st, b->traj_r + (int64_t)t * b->ld,
+                                   b->grad_out + (int64_t)t * b->ldg, b->grad_x + (int64_t)t * b->ldgx, n, mem[q].net->act);
+                continue;
+            }
             int rc;
             if (mem[q].bwd->spt_vals) {  // a fixed sparse W: z = W^T u by the packed rows of W^T (rp_bwd.spt_*), one launch
                 const rp_bwd* b = mem[q].bwd;

@@ -236,6 +236,7 @@ int rp_internal_edge_mem_check(const rp_edge_mem* M) {
     if (!aligned16(M->state[0]) || !aligned16(M->state[1]) || (M->u && !aligned16(M->u)))
         RP_FAIL(RP_ERR_ARG, "rp_edge_mem.state / u must be 16-byte aligned");
     if (M->cur != 0 && M->cur != 1) RP_FAIL(RP_ERR_ARG, "rp_edge_mem.cur must be 0 or 1");
+    if (M->save_u && M->ld_save < M->n) RP_FAIL(RP_ERR_SHAPE, "rp_edge_mem.ld_save < n");
     if (M->kind != RP_EMEM_FILTER) {
         if (M->depth < 1 || !M->col_chan || !M->col_chan_host) RP_FAIL(RP_ERR_ARG, "a delay buffer needs depth >= 1, col_chan and col_chan_host");
         if (M->kind == RP_EMEM_DELAY && M->depth > kDelayMaxDepth) RP_FAIL(RP_ERR_SHAPE, "delay buffers of at most %d columns", kDelayMaxDepth);
@@ -247,7 +248,18 @@ int rp_internal_edge_mem_check(const rp_edge_mem* M) {
     return RP_OK;
 }
 
-int rp_internal_edge_mem_step(rp_edge_mem* M, const float* x, const float** u, hipStream_t st) {
+static int edge_mem_step(rp_edge_mem* M, const float* x, const float** u, hipStream_t st);
+
+// one step of the stage; `save_row`: the call's step index for rp_edge_mem.save_u (< 0: nothing is saved)
+int rp_internal_edge_mem_step(rp_edge_mem* M, const float* x, const float** u, hipStream_t st, int save_row) {
+    const int rc = edge_mem_step(M, x, u, st);
+    if (rc != RP_OK) return rc;
+    if (M->save_u && save_row >= 0)
+        RP_HIP_CHECK(hipMemcpyAsync(M->save_u + (int64_t)save_row * M->ld_save, *u, sizeof(float) * (size_t)M->n, hipMemcpyDeviceToDevice, st));
+    return RP_OK;
+}
+
+static int edge_mem_step(rp_edge_mem* M, const float* x, const float** u, hipStream_t st) {
     switch (M->kind) {
         case RP_EMEM_DELAY: {
             DelayArgs A = {M->col_chan, M->state[M->cur], M->state[M->cur ^ 1], x, M->u, M->n, M->depth};

@@ -1260,7 +1260,7 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
         for (int e = 0; e < run->n_edges; ++e) {
             P.edge[e].src = run->edge_src[e] + (int64_t)t * run->edge_src_ld[e];
             if (run->edge_mem[e].kind != RP_EMEM_NONE) {  // the edge's memory first: x -> u
-                rc = rp_internal_edge_mem_step(&run->edge_mem[e], P.edge[e].src, &P.edge[e].src, st);
+                rc = rp_internal_edge_mem_step(&run->edge_mem[e], P.edge[e].src, &P.edge[e].src, st, t);
                 if (rc != RP_OK) return rc;
             }
         }
@@ -1445,7 +1445,7 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
                         break;
                 }
                 if (run->edge_mem[e].kind != RP_EMEM_NONE) {  // the edge's memory first: x -> u (never in the shared launch)
-                    const int rc = rp_internal_edge_mem_step(&run->edge_mem[e], P[m].edge[e].src, &P[m].edge[e].src, st);
+                    const int rc = rp_internal_edge_mem_step(&run->edge_mem[e], P[m].edge[e].src, &P[m].edge[e].src, st, t);
                     if (rc != RP_OK) return rc;
                 }
             }

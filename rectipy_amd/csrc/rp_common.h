@@ -149,5 +149,5 @@ int rp_internal_packed_matvec(const rp_packed* M, int n, int rows, const float* 
 // stage's output vector (DELAY / DELAY_FILTER: M->u; FILTER: the new state); the row-dot mat-vec of the filter (rnn_forward.hip)
 struct rp_edge_mem;
 int rp_internal_edge_mem_check(const rp_edge_mem* M);
-int rp_internal_edge_mem_step(rp_edge_mem* M, const float* x, const float** u, hipStream_t st);
+int rp_internal_edge_mem_step(rp_edge_mem* M, const float* x, const float** u, hipStream_t st, int save_row);
 int rp_internal_filter_matvec(const float* F, int64_t ldf, int n, const float* src, const float* x, float* dst, hipStream_t st);

@@ -796,6 +796,8 @@ class EdgeMemory:
         self.state = [torch.zeros(shape, **f32), torch.zeros(shape, **f32)]
         self.cur = 0
         self.u = torch.zeros(self.n, **f32)
+        self.save, self.save_row0 = None, 0   # optional [steps, ld] window of the stage's outputs u_t (rp_edge_mem.save_u) and the
+        #                                       row the next library call starts at
         self.F = None
         if kind != "delay":
             self.set_filter(F)
@@ -829,6 +831,8 @@ class EdgeMemory:
         m.state[0], m.state[1] = self.state[0].data_ptr(), self.state[1].data_ptr()
         m.cur = self.cur
         m.u = self.u.data_ptr()
+        if self.save is not None:
+            m.save_u, m.ld_save = self.save[self.save_row0:].data_ptr(), self.save.stride(0)
 
     def window(self, X: torch.Tensor) -> torch.Tensor:
         """U [T, n]: the stage's output for the T consecutive inputs X[t]; the state moves on by T steps."""
@@ -934,18 +938,35 @@ def backward_coupled(members: list) -> list:
 
     ``members`` (the order of the forward call): dicts with ``pop``, ``bwd`` (keyword arguments of
     :meth:`Population.backward`; ``grad_out`` [T, rows] is required -- and written -- for every member an edge reads,
-    ``grad_x`` for every member with edges), ``edges`` as in :func:`forward_coupled` and, for a member whose output an
+    ``grad_x`` for every member with edges; for an activation-node member -- an :class:`InstantPopulation` --
+    ``dict(instant=True, traj_r=its outputs [T, n], grad_out=..., grad_x=...)``), ``edges`` and, for a member whose output an
     RP_EDGE_LIVE edge of a LATER member reads (a post-update read), ``final_src``: its source vector at the end of the window.
+    An edge is ``(W_e, source index, RP_EDGE_* mode[, packed transposed form])`` or a dict ``W / source / mode / packed_t /
+    memory ("delay" | "filter" | None) / edge`` -- ``edge``: the front end's edge object, which names the filter matrix or
+    the delays of an edge with memory (the gradient then passes through the memory: rp_bwd_member.edge_mem_kind).
     Returns the tensors to keep alive until the stream has run the sweep."""
     count = len(members)
+    if count > _abi.RP_MAX_MEMBERS:
+        raise RuntimeError(f"at most {_abi.RP_MAX_MEMBERS} members per coupled call, got {count}")
     arr = (_abi.RpBwdMember * count)()
     keep_all = []
+    norm = []   # every edge as a dict
+    for spec in members:
+        row = []
+        for edge in spec.get("edges") or []:
+            if isinstance(edge, dict):
+                row.append(dict(W=edge["W"], source=edge["source"], mode=edge["mode"], packed_t=edge.get("packed_t"),
+                                memory=edge.get("memory"), edge=edge.get("edge")))
+            else:
+                row.append(dict(W=edge[0], source=edge[1], mode=edge[2], packed_t=edge[3] if len(edge) > 3 else None, memory=None, edge=None))
+        norm.append(row)
     work_floats = [0] * count
     for m, spec in enumerate(members):
         pop: Population = spec["pop"]
-        for edge in spec.get("edges") or []:
-            We, source = edge[0], edge[1]
-            src: Population = members[source]["pop"]
+        if len(norm[m]) > _abi.RP_MAX_EDGES:
+            raise RuntimeError(f"member {m}: at most {_abi.RP_MAX_EDGES} edges per member in the coupled adjoint, got {len(norm[m])}")
+        for edge in norm[m]:
+            We, src = edge["W"], members[edge["source"]]["pop"]
             if We.dim() != 2 or We.shape != (pop.rows, src.n) or We.stride(1) != 1 or We.dtype != torch.float32 \
                     or We.device != pop.device:
                 raise RuntimeError(f"member {m}: an edge matrix must be a float32 [{pop.rows}, {src.n}] matrix with unit "
@@ -955,30 +976,56 @@ def backward_coupled(members: list) -> list:
     for m, spec in enumerate(members):
         pop = spec["pop"]
         work = torch.empty(max(work_floats[m], 4), dtype=torch.float32, device=pop.device)
-        net, b, keep = pop._backward_args(_args_only="stepwise", **spec["bwd"])
-        z = torch.empty(pop.n, dtype=torch.float32, device=pop.device)
-        edges = spec.get("edges") or []
+        extra = []
+        if spec["bwd"].get("instant"):   # an activation node: its outputs, its output gradient (in / out), its input gradient (out)
+            kw = spec["bwd"]
+            net, b, keep, z = pop._net(), RpBwd(), [], None
+            T = int(kw["traj_r"].shape[0])
+            b.steps = T
+            b.traj_r, b.ld = kw["traj_r"].data_ptr(), kw["traj_r"].stride(0) if T > 1 else pop.rows
+            b.grad_out, b.ldg = kw["grad_out"].data_ptr(), kw["grad_out"].stride(0) if T > 1 else pop.rows
+            b.grad_x, b.ldgx = kw["grad_x"].data_ptr(), kw["grad_x"].stride(0) if T > 1 else pop.rows
+            b.grad_var = _abi.RP_OUT_SOURCE
+        else:
+            net, b, keep = pop._backward_args(_args_only="stepwise", **spec["bwd"])
+            z = torch.empty(pop.n, dtype=torch.float32, device=pop.device)
+            arr[m].z = z.data_ptr()
         arr[m].net, arr[m].bwd = C.addressof(net), C.addressof(b)
-        arr[m].n_edges = len(edges)
-        for e, edge in enumerate(edges):
-            We, source, mode = edge[0], edge[1], edge[2]
+        arr[m].n_edges = len(norm[m])
+        for e, edge in enumerate(norm[m]):
+            We = edge["W"]
             arr[m].edge_w[e], arr[m].edge_ld[e] = We.data_ptr(), We.stride(0)
-            arr[m].edge_source[e], arr[m].edge_mode[e] = int(source), int(mode)
-            pk = edge[3] if len(edge) > 3 else None   # the TRANSPOSED edge matrix in packed form (a fixed sparse edge)
+            arr[m].edge_source[e], arr[m].edge_mode[e] = int(edge["source"]), int(edge["mode"])
+            pk = edge["packed_t"]   # the TRANSPOSED edge matrix in packed form (a fixed sparse edge)
             if pk is not None:
                 sp = arr[m].edge_spt[e]
                 sp.vals, sp.cidx, sp.rowoff, sp.block_rows = pk.vals.data_ptr(), pk.code.data_ptr(), pk.rowoff.data_ptr(), pk.block_rows
                 if pk.row_ids is not None:
                     sp.row_ids, sp.batch_class = pk.row_ids.data_ptr(), pk.batch_class.data_ptr()
                     sp.phase_window, sp.phases, sp.batches = pk.phase_window.data_ptr(), pk.phases, pk.batches
+            if edge["memory"] == "filter":   # ly(t) = W_e^T gx(t) + F^T ly(t + 1) goes into the source's output gradient
+                n_s = We.shape[1]
+                F = edge["edge"].filter.detach().to(dtype=torch.float32, device=pop.device)
+                F = F if F.stride(1) == 1 else F.contiguous()
+                lam = torch.zeros(n_s, dtype=torch.float32, device=pop.device)
+                fwork = torch.empty(max(4, pop.backend.shard_partial_rows(n_s, n_s) * n_s), dtype=torch.float32, device=pop.device)
+                arr[m].edge_mem_kind[e] = _abi.RP_EMEM_FILTER
+                arr[m].edge_F[e], arr[m].edge_ldf[e] = F.data_ptr(), F.stride(0)
+                arr[m].edge_lam[e], arr[m].edge_fwork[e] = lam.data_ptr(), fwork.data_ptr()
+                extra += [F, lam, fwork]
+            elif edge["memory"] == "delay":  # u_t = x_{t - d}[j] * ones: d the smallest delay, j the channel written there
+                obj = edge["edge"]
+                arr[m].edge_mem_kind[e] = _abi.RP_EMEM_DELAY
+                arr[m].edge_delay[e], arr[m].edge_chan[e] = int(obj._cols[0]), int(obj._src[0])
+            elif edge["memory"] is not None:
+                raise RuntimeError(f"member {m}: no adjoint through an edge memory of kind '{edge['memory']}'")
         arr[m].edge_work = work.data_ptr()
-        arr[m].z = z.data_ptr()
         final_src = spec.get("final_src")  # r at the end of the window: a later member's RP_EDGE_LIVE edge read it (a post-update read)
         if final_src is not None:
             if final_src.dtype != torch.float32 or final_src.device != pop.device or final_src.numel() != pop.n or not final_src.is_contiguous():
                 raise RuntimeError(f"member {m}: final_src must be a contiguous float32 [{pop.n}] tensor on {pop.device}")
             arr[m].final_src = final_src.data_ptr()
-        keep_all.append((net, b, keep, z, work, final_src, [edge[0] for edge in edges], [edge[3] for edge in edges if len(edge) > 3]))
+        keep_all.append((net, b, keep, z, work, final_src, [edge["W"] for edge in norm[m]], [edge["packed_t"] for edge in norm[m]], extra))
     first.backend.backward_coupled(arr, count, first.device)
     return keep_all
 

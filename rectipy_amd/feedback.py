@@ -42,67 +42,94 @@ class _CoupledWindow(torch.autograd.Function):
     the weight gradients.  Replaces autograd over the per-step graph walk (reference rectipy/network.py:1028-1040 with
     1322-1357).
 
-    Inputs after (net, plan, steps, a): per population x | None, its state handle (v of a rate population, the packed state
-    of a spiking one), W and its per-neuron parameters (`_names`), then the edge matrices in plan order.  Outputs: per
-    population its output trajectory [steps, N] and its final state.  What a feedback edge from a spiking population reads at
-    the window's FIRST step (that population's output one step before the window) is a constant of the window."""
+    Members (r05): populations AND element-wise activation nodes between them (their adjoint step is gx = g_out * act'(out));
+    edges between members may be plain, masked (the kernels stream weights * mask; the gradient is the plain one times the
+    mask) or carry a delay / filter memory (the gradient passes through the memory: rp_bwd_member.edge_mem_kind).
+
+    Inputs after (net, plan, steps, a): per member x | None and, for a population, its state handle (v of a rate population,
+    the packed state of a spiking one), W and its per-neuron parameters (`_names`); then the edge matrices in plan order.
+    Outputs: per member its output trajectory [steps, N] and, for a population, its final state.  What a feedback edge from a
+    spiking population (or an activation node) reads at the window's FIRST step -- that member's output one step before the
+    window -- is a constant of the window."""
 
     @staticmethod
     def _names(pop) -> tuple:
         from .spiking_autograd import TRAINABLE
+        if pop.model == "instant":
+            return ()
         if pop.spiking:
             return TRAINABLE[pop.model]
         return ("tau", "k", "eta") + (_RateWindow.ACT_PARAMS if pop.model == "li_sigmoid" else ())
 
     @staticmethod
     def _layout(net, plan):
+        """Per member (index of its x among the inputs, names of its parameters, is a population); index of the first edge."""
         out, i = [], 4
-        for p in plan["pops"]:
-            names = _CoupledWindow._names(net.get_node(p)._pop)
-            out.append((i, names))
-            i += 3 + len(names)
+        for p in plan["members"]:
+            if p in plan["pops"]:
+                names = _CoupledWindow._names(net.get_node(p)._pop)
+                out.append((i, names, True))
+                i += 3 + len(names)
+            else:
+                out.append((i, (), False))
+                i += 1
         return out, i
 
     @staticmethod
     def forward(ctx, net, plan, steps, a, *flat):
-        pops = plan["pops"]
+        members = plan["members"]
         layout, _ = _CoupledWindow._layout(net, plan)
         stored, xin, widths, lag0 = {}, {}, {}, {}
-        for p, (i, names) in zip(pops, layout):
-            node = net.get_node(p)
-            pop = node._pop
+        for p, (i, names, is_pop) in zip(members, layout):
+            pop = net._member_pop(p)
             x = flat[i - 4]
-            req = {name: flat[i - 4 + 3 + j].requires_grad for j, name in enumerate(names)}
             f32 = dict(dtype=torch.float32, device=pop.device)
-            buf = lambda: torch.empty(steps, pop.rows, **f32)
-            need_acc = req.get("k", False) or pop.model in ("ik", "iku", "ik_biexp")
-            stored[p] = dict(save_v=buf(), save_src=buf(), save_acc=buf() if need_acc else None)
-            if pop.spiking:
-                stored[p].update(save_aux=buf() if pop.aux is not None else None, save_aux2=buf() if pop.aux2 is not None else None,
-                                 save_in=buf() if plan["edges"][p] else None)  # (the input the adjoint of tau / C needs)
+            buf = lambda pop=pop, f32=f32: torch.empty(steps, pop.rows, **f32)
+            if is_pop:
+                req = {name: flat[i - 4 + 3 + j].requires_grad for j, name in enumerate(names)}
+                need_acc = req.get("k", False) or pop.model in ("ik", "iku", "ik_biexp")
+                stored[p] = dict(save_v=buf(), save_src=buf(), save_acc=buf() if need_acc else None)
+                if pop.spiking:
+                    stored[p].update(save_aux=buf() if pop.aux is not None else None, save_aux2=buf() if pop.aux2 is not None else None,
+                                     save_in=buf() if plan["edges"][p] else None)  # (the input the adjoint of tau / C needs)
+            else:
+                stored[p] = dict(traj=buf())   # an activation node: its outputs are all its adjoint needs
             xin[p] = None if x is None else x.detach()
             widths[p] = None if x is None else x.shape[1]
-        for p in {s_ for q in pops for s_, mode in plan["edges"][q] if mode == _abi.RP_EDGE_LAG}:
-            lag0[p] = net.get_node(p)["out"].detach().clone()
+        for p in {s_ for q in members for s_, mode in plan["edges"][q] if net._bwd_mode(plan, s_, mode) == _abi.RP_EDGE_LAG}:
+            lag0[p] = net._exposed_output(plan, p).detach().clone()
+        # the windows of what the edges with memory hand to their projections (u_t): their adjoint and weight gradients need them
+        saved_u = {}
+        for q in members:
+            for s_, _ in plan["edges"][q]:
+                edge = net.get_edge(s_, q)
+                if getattr(edge, "_stage_kind", None):
+                    n_s = net._member_pop(s_).rows
+                    saved_u[(s_, q)] = torch.empty(steps, (n_s + 3) // 4 * 4, dtype=torch.float32, device=net._member_pop(q).device)
         # (autograd runs this method without gradient mode: what `detach(requires_grad=...)` asked of the states must survive
         # the bookkeeping of an un-recorded step)
+        pops = plan["pops"]
         asked = {p: net.get_node(p)._y_requires_grad for p in pops}
-        net._coupled_steps(plan, xin, steps, a, set(), {}, None, 0, 1, stored=stored)
+        net._coupled_steps(plan, xin, steps, a, set(), {}, None, 0, 1, stored=stored, saved_u=saved_u)
         for p in pops:
             net.get_node(p)._y_requires_grad = asked[p]
         outs = []
-        order = {p: i for i, p in enumerate(pops)}
+        order = {p: i for i, p in enumerate(members)}
         # a feedback edge from a rate population that was already stepped read its output AFTER the step: for the window's
         # last step that is the final state -- kept for the adjoint (act'(r_final)) and the edge's weight gradient
         final = {}
-        for p in pops:
+        for p in members:
             for s_, mode in plan["edges"][p]:
-                if mode == _abi.RP_EDGE_LIVE and order[s_] < order[p] and s_ not in final:
+                if mode == _abi.RP_EDGE_LIVE and s_ in pops and order[s_] < order[p] and s_ not in final:
                     src = net.get_node(s_)._pop
                     final[s_] = (src.v.clone(), src.source.clone())
-        for p in pops:
+        for p, (_, _, is_pop) in zip(members, layout):
+            st = stored[p]
+            if not is_pop:
+                outs.append(st["traj"].clone())
+                continue
             node = net.get_node(p)
-            pop, st = node._pop, stored[p]
+            pop = node._pop
             out = st["save_src"] if node._out_code == _abi.RP_OUT_SOURCE else st["save_v"]
             if pop.spiking:
                 node._last_window = (st["save_v"], st["save_src"], st["save_aux"], st["save_aux2"])
@@ -111,67 +138,82 @@ class _CoupledWindow(torch.autograd.Function):
                 node._last_window = (st["save_v"], st["save_src"])
                 outs += [out.clone(), pop.v.clone()]
         ctx.net, ctx.plan, ctx.steps, ctx.stored, ctx.widths, ctx.xin, ctx.lag0, ctx.final = net, plan, steps, stored, widths, xin, lag0, final
+        ctx.saved_u = saved_u
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *g):
+        from .edge_variants import LinearMasked
         from .engine import backward_coupled
         net, plan, T, stored = ctx.net, ctx.plan, ctx.steps, ctx.stored
-        pops = plan["pops"]
-        index = {p: i for i, p in enumerate(pops)}
+        members, pops = plan["members"], plan["pops"]
+        index = {p: i for i, p in enumerate(members)}
         need = ctx.needs_input_grad
         layout, first_edge = _CoupledWindow._layout(net, plan)
-        read = {s_ for p in pops for s_, _ in plan["edges"][p]}
-        members, res = [], []
-        for m, (p, (i, names)) in enumerate(zip(pops, layout)):
-            node = net.get_node(p)
-            pop = node._pop
+        read = {s_ for p in members for s_, _ in plan["edges"][p]}
+        specs, res = [], []
+        gpos = 0   # position in g: a population has two outputs (trajectory, final state), an activation node one
+        for m, (p, (i, names, is_pop)) in enumerate(zip(members, layout)):
+            pop = net._member_pop(p)
             N = pop.rows
             f32 = dict(dtype=torch.float32, device=pop.device)
-            g_traj, g_end = g[2 * m], g[2 * m + 1]
+            g_traj = g[gpos]
+            g_end = g[gpos + 1] if is_pop else None
+            gpos += 2 if is_pop else 1
             st = stored[p]
-            R = dict(u=torch.empty(T, N, **f32), gx=torch.empty(T, N, **f32) if need[i] or plan["edges"][p] else None,
-                     par={name: torch.zeros(N, **f32) for j, name in enumerate(names) if need[i + 3 + j]})
+            R = dict(gx=torch.empty(T, N, **f32) if need[i] or plan["edges"][p] or not is_pop else None)
             # the sweep adds what comes back through the edges into the output gradient of their sources: a private copy
-            if p in read:
+            if p in read or not is_pop:
                 R["g_out"] = torch.zeros(T, N, **f32) if g_traj is None else g_traj.detach().to(**f32).clone().contiguous()
             else:
                 R["g_out"] = None if g_traj is None else g_traj.detach().to(**f32).contiguous()
-            kw = dict(traj_v=st["save_v"], traj_r=st["save_src"], grad_out=R["g_out"], grad_var=node._out_code, u_traj=R["u"],
-                      traj_acc=st["save_acc"], grad_x=R["gx"])
-            if pop.spiking:
-                tpl = node._template
-
-                def piece(name, g_end=g_end, node=node, N=N, f32=f32):
-                    if g_end is None or name is None:
-                        return torch.zeros(N, **f32)
-                    lo, hi = getattr(node, "_internal_var_map", node._var_map)[name]
-                    return g_end.detach().to(**f32)[lo:hi].clone().contiguous()
-
-                R["lam"], R["lam_s"] = piece(tpl.reset_var), piece(tpl.source_var)
-                R["lam_x"] = piece(node._aux_name) if node._aux_name else None
-                R["lam_x2"] = piece(node._aux2_name) if node._aux2_name else None
-                kw.update(lam=R["lam"], lam_s=R["lam_s"], slope=node._spike_slope, x_target=node._x_target,
-                          x=st["save_in"] if st["save_in"] is not None else ctx.xin[p], traj_aux=st["save_aux"],
-                          lam_x=R["lam_x"], traj_aux2=st["save_aux2"], lam_x2=R["lam_x2"], grad_params=R["par"])
+            if not is_pop:
+                kw = dict(instant=True, traj_r=st["traj"], grad_out=R["g_out"], grad_x=R["gx"])
             else:
-                R["lam"] = torch.zeros(N, **f32) if g_end is None else g_end.detach().to(**f32).clone().contiguous()
-                kw.update(lam=R["lam"], grad_tau=R["par"].get("tau"), grad_k=R["par"].get("k"), grad_eta=R["par"].get("eta"),
-                          grad_params={k_: v_ for k_, v_ in R["par"].items() if k_ in _RateWindow.ACT_PARAMS})
+                node = net.get_node(p)
+                R.update(u=torch.empty(T, N, **f32), par={name: torch.zeros(N, **f32) for j, name in enumerate(names) if need[i + 3 + j]})
+                kw = dict(traj_v=st["save_v"], traj_r=st["save_src"], grad_out=R["g_out"], grad_var=node._out_code, u_traj=R["u"],
+                          traj_acc=st["save_acc"], grad_x=R["gx"])
+                if pop.spiking:
+                    tpl = node._template
+
+                    def piece(name, g_end=g_end, node=node, N=N, f32=f32):
+                        if g_end is None or name is None:
+                            return torch.zeros(N, **f32)
+                        lo, hi = getattr(node, "_internal_var_map", node._var_map)[name]
+                        return g_end.detach().to(**f32)[lo:hi].clone().contiguous()
+
+                    R["lam"], R["lam_s"] = piece(tpl.reset_var), piece(tpl.source_var)
+                    R["lam_x"] = piece(node._aux_name) if node._aux_name else None
+                    R["lam_x2"] = piece(node._aux2_name) if node._aux2_name else None
+                    kw.update(lam=R["lam"], lam_s=R["lam_s"], slope=node._spike_slope, x_target=node._x_target,
+                              x=st["save_in"] if st["save_in"] is not None else ctx.xin[p], traj_aux=st["save_aux"],
+                              lam_x=R["lam_x"], traj_aux2=st["save_aux2"], lam_x2=R["lam_x2"], grad_params=R["par"])
+                else:
+                    R["lam"] = torch.zeros(N, **f32) if g_end is None else g_end.detach().to(**f32).clone().contiguous()
+                    kw.update(lam=R["lam"], grad_tau=R["par"].get("tau"), grad_k=R["par"].get("k"), grad_eta=R["par"].get("eta"),
+                              grad_params={k_: v_ for k_, v_ in R["par"].items() if k_ in _RateWindow.ACT_PARAMS})
             res.append(R)
-            members.append(dict(pop=pop, bwd=kw, final_src=ctx.final[p][1] if p in ctx.final else None,
-                                edges=[(net.get_edge(s_, p).weights.detach(), index[s_], mode) for s_, mode in plan["edges"][p]]))
+            edges = []
+            for s_, mode in plan["edges"][p]:
+                edge = net.get_edge(s_, p)
+                edges.append(dict(W=net._edge_matrix(edge).detach(), source=index[s_], mode=net._bwd_mode(plan, s_, mode),
+                                  memory=getattr(edge, "_stage_kind", None), edge=edge))
+            specs.append(dict(pop=pop, bwd=kw, final_src=ctx.final[p][1] if p in ctx.final else None, edges=edges))
         packed_t = net._packed_edges(plan, transposed=True)   # fixed sparse edges: W_e^T gx by packed row dots
-        if packed_t:
-            for m, p in enumerate(pops):
-                members[m]["edges"] = [edge + (packed_t.get((s_, p)),) for edge, (s_, _) in zip(members[m]["edges"], plan["edges"][p])]
-        keep = backward_coupled(members)
+        for m, p in enumerate(members):
+            for spec, (s_, _) in zip(specs[m]["edges"], plan["edges"][p]):
+                spec["packed_t"] = packed_t.get((s_, p)) if packed_t else None
+        keep = backward_coupled(specs)
         grads = [None] * len(need)
-        for m, (p, (i, names)) in enumerate(zip(pops, layout)):
-            node = net.get_node(p)
-            pop, R = node._pop, res[m]
+        for m, (p, (i, names, is_pop)) in enumerate(zip(members, layout)):
+            R = res[m]
             if need[i]:
                 grads[i] = R["gx"].sum(dim=1, keepdim=True) if ctx.widths[p] == 1 else R["gx"]
+            if not is_pop:
+                continue
+            node = net.get_node(p)
+            pop = node._pop
             if need[i + 1]:
                 grads[i + 1] = node._pack(R["lam"], R["lam_s"], R["lam_x"], R["lam_x2"]) if pop.spiking else R["lam"]
             if need[i + 2]:
@@ -179,22 +221,34 @@ class _CoupledWindow(torch.autograd.Function):
             for j, name in enumerate(names):
                 grads[i + 3 + j] = R["par"].get(name)
         e = first_edge
-        for m, p in enumerate(pops):
-            pop = net.get_node(p)._pop
+        for m, p in enumerate(members):
+            pop = net._member_pop(p)
             for s_, mode in plan["edges"][p]:
-                if need[e]:  # dW_e = sum_t gx_p(t) (x) (what the edge read at step t)
-                    src = net.get_node(s_)
-                    out_s = stored[s_]["save_src"] if src._out_code == _abi.RP_OUT_SOURCE else stored[s_]["save_v"]
-                    if mode == _abi.RP_EDGE_LAG:  # the source's output one step earlier; before the window: its value then
-                        out_s = torch.cat([ctx.lag0[s_][None, :], out_s[:-1]])
-                    elif mode == _abi.RP_EDGE_LIVE and index[s_] < m:  # ... one step LATER (a post-update read); the last: the final one
-                        last = ctx.final[s_][1] if src._out_code == _abi.RP_OUT_SOURCE else ctx.final[s_][0]
-                        out_s = torch.cat([out_s[1:], last[None, :]])
-                    gW = torch.empty(pop.rows, src._pop.rows, dtype=torch.float32, device=pop.device)
+                if need[e]:  # dW_e = sum_t gx_p(t) (x) (what the edge's projection read at step t)
+                    edge = net.get_edge(s_, p)
+                    src_pop = net._member_pop(s_)
+                    if (s_, p) in ctx.saved_u:   # an edge with memory: the u_t the forward call saved
+                        out_s = ctx.saved_u[(s_, p)]
+                    else:
+                        if s_ in pops:
+                            src = net.get_node(s_)
+                            out_s = stored[s_]["save_src"] if src._out_code == _abi.RP_OUT_SOURCE else stored[s_]["save_v"]
+                        else:
+                            out_s = stored[s_]["traj"]
+                        bmode = net._bwd_mode(plan, s_, mode)
+                        if bmode == _abi.RP_EDGE_LAG:  # the source's output one step earlier; before the window: its value then
+                            out_s = torch.cat([ctx.lag0[s_][None, :], out_s[:-1]])
+                        elif bmode == _abi.RP_EDGE_LIVE and index[s_] < m:  # ... one step LATER (a post-update read); the last: the final one
+                            src = net.get_node(s_)
+                            last = ctx.final[s_][1] if src._out_code == _abi.RP_OUT_SOURCE else ctx.final[s_][0]
+                            out_s = torch.cat([out_s[1:], last[None, :]])
+                    gW = torch.empty(pop.rows, src_pop.rows, dtype=torch.float32, device=pop.device)
                     gx = res[m]["gx"]
-                    pop.backend.outer_store_rect(pop.rows, src._pop.rows, T, 1.0, gx.data_ptr(), gx.stride(0) if T > 1 else pop.rows,
-                                                 out_s.data_ptr(), out_s.stride(0) if T > 1 else src._pop.rows, gW.data_ptr(),
+                    pop.backend.outer_store_rect(pop.rows, src_pop.rows, T, 1.0, gx.data_ptr(), gx.stride(0) if T > 1 else pop.rows,
+                                                 out_s.data_ptr(), out_s.stride(0) if T > 1 else src_pop.rows, gW.data_ptr(),
                                                  gW.stride(0), pop.device)
+                    if isinstance(edge, LinearMasked):
+                        gW = gW * edge.mask
                     grads[e] = gW
                 e += 1
         del keep
@@ -353,7 +407,9 @@ class FeedbackNetwork(Network):
                 inp = x if inp is None else x + inp
             new_out[n] = node.forward(inp, edges=in_kernel) if in_kernel else node.forward(inp)
             self[n]["out"] = new_out[n]
-        self._prev_out = {k: v.detach() for k, v in new_out.items()}
+        # (with their history: like the reference's node["out"], network.py:1349-1355, the gradient passes through a feedback
+        # edge from an activation node too -- until `detach` ends the window)
+        self._prev_out = dict(new_out)
         return new_out[self._out_node]
 
     @staticmethod
@@ -471,19 +527,42 @@ class FeedbackNetwork(Network):
             return None, self._why_not.get("coupled")
         if getattr(self, "_force_stepwise_adjoint", False):
             return None, None
-        if plan["between"]:
-            return None, f"activation node '{plan['between'][0]}' between populations: its adjoint is not part of rp_backward_coupled"
+        from .edge_variants import LinearMasked
+        pos = {n: i for i, n in enumerate(plan["members"])}
         for p in plan["pops"]:
             node = self.get_node(p)
             if node._out_slice is not None:
                 return None, f"population '{p}' exposes a slice of its output variable"
             if node._pop.spiking and node._pop.model not in TRAINABLE:
                 return None, f"population '{p}' ({node._pop.model}) has no surrogate-gradient adjoint"
-            for s_, _ in plan["edges"][p]:
-                if type(self.get_edge(s_, p)) is not Linear:
-                    return None, (f"edge '{s_}' -> '{p}' of class {type(self.get_edge(s_, p)).__name__} between populations: "
+        for p in plan["members"]:
+            for s_, mode in plan["edges"][p]:
+                edge = self.get_edge(s_, p)
+                kind = getattr(edge, "_stage_kind", None)
+                if not (type(edge) is Linear or isinstance(edge, LinearMasked) or kind in ("delay", "filter")):
+                    return None, (f"edge '{s_}' -> '{p}' of class {type(edge).__name__} between populations: "
                                   f"its adjoint is not part of rp_backward_coupled")
+                if kind and mode == _abi.RP_EDGE_LIVE and pos[s_] < pos[p]:
+                    return None, f"edge '{s_}' -> '{p}' ({type(edge).__name__}) is a feedback edge from a population already stepped"
+                if any(q.requires_grad for q in (getattr(edge, "filter", None),) if isinstance(q, torch.Tensor)):
+                    return None, f"edge '{s_}' -> '{p}': a trained filter matrix"
         return plan, None
+
+    def _bwd_mode(self, plan: dict, source: str, mode: int) -> int:
+        """The read mode of an edge as rp_backward_coupled wants it: a feedback edge from an activation node delivered the
+        node's output of the step BEFORE (the library read it "as it stands" before the node's step) -- RP_EDGE_LAG."""
+        if source in plan.get("between", ()) and mode == _abi.RP_EDGE_LIVE:
+            return _abi.RP_EDGE_LAG
+        return mode
+
+    def _exposed_output(self, plan: dict, label: str) -> torch.Tensor:
+        """What a lagging read of `label` sees at a window's first step: a spiking population's exposed `y` slice; an
+        activation node's previous output (zeros before its first step)."""
+        if label in plan["pops"]:
+            return self.get_node(label)["out"]
+        prev = self._prev_out.get(label)
+        pop = self._member_pop(label)
+        return torch.zeros(pop.rows, dtype=torch.float32, device=pop.device) if prev is None else prev.reshape(-1)
 
     def _coupled_grad_outputs(self, plan: dict, inputs_ab: torch.Tensor, a: int, fit: bool = False) -> torch.Tensor:
         """The output node's per-step outputs over the window [a, a + len), with the graph of ONE autograd node for all
@@ -512,11 +591,14 @@ class FeedbackNetwork(Network):
                     outs[n] = self.get_node(n).forward(X)
                 for n in self._order:
                     self[n]["out"] = None
-                self._prev_out = {}
+                self._prev_out = {k: v for k, v in self._prev_out.items() if k in plan["between"]}
                 return outs[self._out_node]
         xin = self._coupled_inputs(plan, inputs_ab)
         flat = []
-        for p in pops:
+        for p in plan["members"]:
+            if p not in pops:   # an activation node between populations: a member without state or parameters
+                flat.append(xin[p])
+                continue
             node: RateNet = self.get_node(p)
             pop = node._pop
             state_in = node._y_grad
@@ -529,14 +611,18 @@ class FeedbackNetwork(Network):
                 if state_in is None:
                     state_in = pop.v.detach().clone().requires_grad_(node._y_requires_grad)
             flat += [xin[p], state_in, pop.W] + [pop.params[q] for q in _CoupledWindow._names(pop)]
-        for p in pops:
+        for p in plan["members"]:
             flat += [self.get_edge(s_, p).weights for s_, _ in plan["edges"][p]]
         res = _CoupledWindow.apply(self, plan, inputs_ab.shape[0], a, *flat)
-        outs = {}
-        for i, p in enumerate(pops):
+        outs, i = {}, 0
+        for p in plan["members"]:
+            outs[p] = res[i]
+            if p not in pops:
+                i += 1
+                continue
             node = self.get_node(p)
-            outs[p] = res[2 * i]
-            node._y_grad = res[2 * i + 1]
+            node._y_grad = res[i + 1]
+            i += 2
             if node._pop.spiking:  # `y` exposes the pre-update state of the window's last step (nodes.py:387-392)
                 tv, ts, ta, tb = node._last_window
                 node._y_prev = node._pack(tv[-1], ts[-1], None if ta is None else ta[-1], None if tb is None else tb[-1])
@@ -548,7 +634,7 @@ class FeedbackNetwork(Network):
             outs[n] = self.get_node(n).forward(X)
         for n in self._order:
             self[n]["out"] = None
-        self._prev_out = {}
+        self._prev_out = {k: v for k, v in self._prev_out.items() if k in plan["between"]}
         return outs[self._out_node]
 
     def _run_coupled_grad(self, plan: dict, inputs, sampling_steps, cutoff, truncate_steps, obs: Observer, verbose):
@@ -621,7 +707,7 @@ class FeedbackNetwork(Network):
         return self._coupled_steps(plan, xin, inputs_ab.shape[0], a, want_traj, rec, sampler, cutoff, sampling_steps)
 
     def _coupled_steps(self, plan: dict, xin: dict, steps: int, a: int, want_traj: set, rec: dict, sampler: Optional[dict],
-                       cutoff: int, sampling_steps: int, stored: Optional[dict] = None) -> dict:
+                       cutoff: int, sampling_steps: int, stored: Optional[dict] = None, saved_u: Optional[dict] = None) -> dict:
         """The library call(s) of `_coupled_window`; `xin`: label -> [steps, rows | 1] input (or None) without a graph;
         `stored`: label -> keyword arguments capturing the window for the adjoint (save_v / save_src / save_acc)."""
         from .engine import forward_coupled
@@ -661,11 +747,14 @@ class FeedbackNetwork(Network):
                 mem = edge.memory_stage() if getattr(edge, "_stage_kind", None) else None
                 if mem is not None:
                     stages.append((edge, mem))
+                    mem.save = saved_u.get((s_, p)) if saved_u else None   # (the window of u_t, for the edge's adjoint)
                 row.append((self._edge_matrix(edge), index[s_], mode, packed_edges.get((s_, p)), mem))
             edge_args[p] = row
 
         def call(t0: int, t1: int, last: bool):
             specs, saves = [], {}
+            for _, mem in stages:
+                mem.save_row0 = t0
             for p in members:
                 node = self.get_node(p)
                 pop = self._member_pop(p)
@@ -706,6 +795,7 @@ class FeedbackNetwork(Network):
             call(0, steps, spiking)
         for edge, mem in stages:
             edge.stage_done(mem)
+            mem.save = None
         for p in plan["between"]:  # what a feedback edge from the activation node reads next: its last output
             self._prev_out[p] = self._member_pop(p).source.clone()
         return trajs
@@ -913,3 +1003,7 @@ class FeedbackNetwork(Network):
     def reset(self, state: dict = None):
         super().reset(state)
         self._prev_out = {}
+
+    def detach(self, requires_grad: bool = True, detach_params: bool = False) -> None:
+        super().detach(requires_grad=requires_grad, detach_params=detach_params)
+        self._prev_out = {k: v.detach() for k, v in self._prev_out.items()}   # (a window ends: the fed-back outputs become constants)

@@ -277,6 +277,14 @@ class Network:
             node = self.get_node(n)
             if hasattr(node, "y"):
                 node.detach(requires_grad=requires_grad, detach_params=detach_params)
+        # the memory of the edges (delay buffer, filter state) becomes a constant of the next window too -- an extension: the
+        # reference (network.py:511-514) leaves it attached, and its second truncated window fails in autograd
+        for s_, t_ in self.graph.edges:
+            edge = self.get_edge(s_, t_)
+            for name in ("buffer", "y"):
+                val = getattr(edge, name, None)
+                if isinstance(val, torch.Tensor) and val.grad_fn is not None:
+                    setattr(edge, name, val.detach())
 
     def reset(self, state: dict = None):
         for n in self.nodes:

@@ -427,6 +427,57 @@ def test_activation_nodes_and_edges_with_memory_stay_inside_the_library(target, 
     assert not [w for w in recwarn.list if issubclass(w.category, PerformanceWarning)]
 
 
+def variant_trained(target, stepwise_adjoint, kind):
+    """`variant_net` with every edge trained (input layer, the edges between the members incl. the varied one, the feedback edge,
+    the read-out): the gradient has to pass through the populations AND through the varied element."""
+    net = variant_net(target, False, kind)
+    for s_, t_ in net.graph.edges:
+        edge = net.get_edge(s_, t_)
+        edge.weights.requires_grad_(True)
+        edge.train_params = [edge.weights]
+    net._force_stepwise_adjoint = stepwise_adjoint
+    return net
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("kind", ["activation", "sigmoid_fb", "delay", "filter", "masked", "filter_fb"])
+def test_training_through_activation_nodes_and_edges_with_memory_is_fused(target, kind, monkeypatch, recwarn):
+    """(r05) fit_bptt through a cycle that holds an activation node between populations, a feedback edge from one, a delay or
+    filter edge (feed-forward or on the feedback edge) or a masked edge: ONE rp_forward_coupled and ONE rp_backward_coupled call
+    per window -- the gradient passes through the node (gx = g_out * act'(out)) and through the edge's memory (filter:
+    ly(t) = W_e^T gx(t) + F^T ly(t + 1); delay: the total of W_e^T gx(t) into one element d steps earlier) inside the library --
+    and the parameters after three SGD windows equal those of autograd over the per-step walk.  No PerformanceWarning."""
+    fwd, bwd = [], []
+    real_f, real_b = engine.forward_coupled, engine.backward_coupled
+    monkeypatch.setattr(engine, "forward_coupled", lambda members: fwd.append(len(members)) or real_f(members))
+    monkeypatch.setattr(engine, "backward_coupled", lambda members: bwd.append(len(members)) or real_b(members))
+    T, win = 64, 20
+    r = np.random.default_rng(1)
+    x, y = r.standard_normal((T, 3)).astype(np.float32), r.standard_normal((T, 2)).astype(np.float32) * 0.3
+    res = []
+    for stepwise in (True, False):
+        fwd.clear(), bwd.clear()
+        net = variant_trained(target, stepwise, kind)
+        obs = net.fit_bptt(x, y, optimizer="sgd", lr=0.05, update_steps=win, sampling_steps=1, verbose=False)
+        n_mem = 3 if kind in ("activation", "sigmoid_fb") else 2
+        assert (fwd, bwd) == (([], []) if stepwise else ([n_mem] * 4, [n_mem] * 3)), (kind, fwd, bwd)
+        mems = {}
+        for s_, t_ in net.graph.edges:
+            for name in ("buffer", "y"):
+                if hasattr(net.get_edge(s_, t_), name):
+                    mems[(s_, t_, name)] = getattr(net.get_edge(s_, t_), name).detach().cpu().numpy().copy()
+        res.append(([p.detach().cpu().numpy().copy() for p in net.parameters()], obs.to_numpy("loss"), obs.to_numpy("out"), mems))
+    assert len(res[0][0]) == len(res[1][0]) >= 4
+    for a_, b_ in zip(res[0][0], res[1][0]):
+        assert a_.shape == b_.shape and np.abs(a_ - b_).max() <= 3e-5 * max(1.0, np.abs(a_).max()), (kind, np.abs(a_ - b_).max())
+    assert np.abs(res[0][1] - res[1][1]).max() < 2e-5 * max(1.0, res[0][1].max())
+    assert np.abs(res[0][2] - res[1][2]).max() < 3e-5 * max(1.0, np.abs(res[0][2]).max())
+    for k_ in res[0][3]:
+        assert np.abs(res[0][3][k_] - res[1][3][k_]).max() < 3e-5, k_
+    from rectipy_amd import PerformanceWarning
+    assert not [w for w in recwarn.list if issubclass(w.category, PerformanceWarning)]
+
+
 def test_every_fall_back_to_the_walk_is_loud(oracle_backend):
     """What still runs on the per-step Python walk says so, once per network, naming the cause: a normalising activation node
     between populations, a gradient through a cycle that holds an activation node or an edge with memory, recorded
@@ -450,19 +501,16 @@ def test_every_fall_back_to_the_walk_is_loud(oracle_backend):
     with warnings.catch_warnings():
         warnings.simplefilter("error", PerformanceWarning)   # ... once per network
         net.run(x, verbose=False, enable_grad=False)
-    # a trained edge next to an edge with memory: the forward plan exists, its adjoint does not
-    net = variant_net(target, False, "filter")
+    # a trained edge next to a delay + filter edge: the forward plan exists, its adjoint does not (delay and filter edges have one)
+    net = variant_net(target, False, "delay_filter")
     net.pop_edge("b", "out")
     net.add_edge("b", "out", weights=np.ones((2, 20)) * 0.1, train="gd")
     net.compile()
     assert net._coupled_plan([]) is not None and net._coupled_grad_plan() is None
-    with pytest.warns(PerformanceWarning, match="LinearFilter between populations"):
+    with pytest.warns(PerformanceWarning, match="LinearMemoryFilter between populations"):
         net.fit_bptt(x, np.zeros((10, 2), dtype=np.float32), update_steps=5, verbose=False)
-    net = variant_net(target, False, "activation")
-    net.pop_edge("b", "out")
-    net.add_edge("b", "out", weights=np.ones((2, 20)) * 0.1, train="gd")
-    with pytest.warns(PerformanceWarning, match="activation node 'mid' between populations"):
-        obs = net.run(x, verbose=False)   # enable_grad defaults to True: the walk, with an autograd graph
+    with pytest.warns(PerformanceWarning, match="LinearMemoryFilter between populations"):
+        obs = variant_trained(target, False, "delay_filter").run(x, verbose=False)   # enable_grad defaults to True: the walk, with a graph
     assert obs.stacked("out").requires_grad
     # the test seam asks for the walk: silent
     net = build_net(target, True)

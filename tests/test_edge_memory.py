@@ -210,3 +210,112 @@ def test_coupled_circuit_with_activation_node_identity_and_memory_edges(target, 
     once = run_built(C1, x.to(dev), T, 1, dev)
     for w, g_ in zip(once, got):
         assert_same(w, g_, "split windows")
+
+
+# ---- the adjoint of such a circuit (rp_backward_coupled, ABI v18) -----------------------------------------------------------
+def adjoint_built(C, x, T, g_out, g_end, dev):
+    """a -> f (tanh node) -> b, a -> b through the DELAY edge, feedback b -> a through the FILTER edge: the window stored, then ONE
+    rp_backward_coupled call.  Returns per member its gradient tensors and, per edge, the weight gradient gx_target^T (what the
+    edge's projection read)."""
+    import types
+    from rectipy_amd.engine import backward_coupled
+    a, f, b, W = C["a"], C["f"], C["b"], C["W"]
+    f32 = dict(dtype=torch.float32, device=dev)
+    order = [a, f, b]
+    OUT, LIVE = _abi.RP_EDGE_OUT, _abi.RP_EDGE_LIVE
+    saved = [dict(v=torch.zeros(T, p.rows, **f32), r=torch.zeros(T, p.rows, **f32), acc=torch.zeros(T, p.rows, **f32)) for p in order]
+    for mem, n in ((C["mem_ab"], a.rows), (C["mem_ba"], b.rows)):
+        mem.save, mem.save_row0 = torch.zeros(T, (n + 3) // 4 * 4, **f32), 0
+    run = lambda m: dict(steps=T, step0=0, out_var=_abi.RP_OUT_SOURCE, save_v=saved[m]["v"], save_src=saved[m]["r"], save_acc=saved[m]["acc"])
+    fwd = [dict(pop=a, run=dict(run(0), x=x), edges=[(W["ba"], 2, LIVE, None, C["mem_ba"])]),
+           dict(pop=f, run=dict(steps=T, step0=0, out_var=_abi.RP_OUT_SOURCE, traj=saved[1]["r"]), edges=[(W["af"], 0, OUT)]),
+           dict(pop=b, run=run(2), edges=[(W["fb"], 1, OUT), (W["ab"], 0, OUT, None, C["mem_ab"])])]
+    forward_coupled(fwd)
+    res, specs = [], []
+    for m, p in enumerate(order):
+        R = dict(g_out=g_out[m].to(**f32).clone(), gx=torch.zeros(T, p.rows, **f32))
+        if m == 1:
+            kw = dict(instant=True, traj_r=saved[1]["r"], grad_out=R["g_out"], grad_x=R["gx"])
+        else:
+            R.update(lam=g_end[m].to(**f32).clone(), u=torch.zeros(T, p.rows, **f32), tau=torch.zeros(p.rows, **f32),
+                     k=torch.zeros(p.rows, **f32), eta=torch.zeros(p.rows, **f32))
+            kw = dict(traj_v=saved[m]["v"], traj_r=saved[m]["r"], grad_out=R["g_out"], grad_var=_abi.RP_OUT_SOURCE, lam=R["lam"],
+                      u_traj=R["u"], traj_acc=saved[m]["acc"], grad_x=R["gx"], grad_tau=R["tau"], grad_k=R["k"], grad_eta=R["eta"])
+        res.append(R)
+        specs.append(dict(pop=p, bwd=kw))
+    d = int(C["delays"].min())
+    delay_obj = types.SimpleNamespace(_cols=[d], _src=[int(np.nonzero(C["delays"] == d)[0].max())])
+    filter_obj = types.SimpleNamespace(filter=C["mem_ba"].F)
+    specs[0]["edges"] = [dict(W=W["ba"], source=2, mode=LIVE, memory="filter", edge=filter_obj)]
+    specs[1]["edges"] = [dict(W=W["af"], source=0, mode=OUT)]
+    specs[2]["edges"] = [dict(W=W["fb"], source=1, mode=OUT), dict(W=W["ab"], source=0, mode=OUT, memory="delay", edge=delay_obj)]
+    keep = backward_coupled(specs)
+    del keep
+    gW = dict(ba=res[0]["gx"].T @ C["mem_ba"].save[:, :b.rows], af=res[1]["gx"].T @ saved[0]["r"], fb=res[2]["gx"].T @ saved[1]["r"],
+              ab=res[2]["gx"].T @ C["mem_ab"].save[:, :a.rows])
+    return res, gW
+
+
+def float64_adjoint(C, x, T, g_out, g_end):
+    """torch float64 restatement of the same window, differentiated by autograd: (gradient of x, of the start states, of the edge
+    matrices) for the loss sum_m <g_out_m, out_m> + sum_pops <g_end, v_end>."""
+    f64 = lambda t: t.detach().cpu().to(torch.float64)
+    a, b = C["a"], C["b"]
+    W = {k: f64(v).requires_grad_(True) for k, v in C["W"].items() if k in ("ba", "af", "fb", "ab")}
+    xs = f64(x).requires_grad_(True)
+    v0 = dict(a=f64(a.v).requires_grad_(True), b=f64(b.v).requires_grad_(True))
+    par = {k: dict(W=f64(p.W), **{q: f64(t) for q, t in p.params.items()}) for k, p in (("a", a), ("b", b))}
+    cc = col_chan_of(C["delays"])
+    ring = [f64(C["mem_ab"].current)[c] for c in range(len(cc))]
+    y, F = f64(C["mem_ba"].current), f64(C["mem_ba"].F)
+    v, dt = dict(v0), a.dt
+    loss = 0.0
+    for t in range(T):
+        ra, rb = torch.tanh(v["a"]), torch.tanh(v["b"])
+        y = F @ y + rb
+        Ia = xs[t] + W["ba"] @ y
+        fo = torch.tanh(W["af"] @ ra)
+        ring = [ra[cc[c]] if cc[c] >= 0 else ring[(c + 1) % len(ring)] for c in range(len(ring))]
+        Ib = W["fb"] @ fo + W["ab"] @ (ring[0] * torch.ones_like(ra))
+        for k, r, I in (("a", ra, Ia), ("b", rb, Ib)):
+            P = par[k]
+            v[k] = v[k] + dt * (-v[k] / P["tau"] + P["k"] * (P["W"] @ r) + I + P["eta"])
+        loss = loss + (f64(g_out[0][t]) * ra).sum() + (f64(g_out[1][t]) * fo).sum() + (f64(g_out[2][t]) * rb).sum()
+    loss = loss + (f64(g_end[0]) * v["a"]).sum() + (f64(g_end[2]) * v["b"]).sum()
+    loss.backward()
+    return dict(x=xs.grad, va=v0["a"].grad, vb=v0["b"].grad, **{k: w.grad for k, w in W.items()})
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("sizes", [(24, 16, 20), (260, 72, 132), (17, 9, 30)])
+def test_coupled_adjoint_through_activation_node_and_memory_edges(target, sizes, oracle_backend):
+    """(r05, ABI v18) rp_backward_coupled through an activation-node member (gx = g_out * act'(out)), a FILTER edge on the feedback
+    edge (ly(t) = W_e^T gx(t) + F^T ly(t + 1)) and a DELAY edge (the total of W_e^T gx(t) into one element, d steps earlier):
+    against float64 autograd of the same window; on the GPU also bit for bit against the oracle."""
+    dev = target["device"]
+    T = 23
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(T, sizes[0], generator=gen) * 0.3
+    order = (sizes[0], sizes[1], sizes[2])
+    g_out = [torch.randn(T, n, generator=gen) for n in order]
+    g_end = [torch.randn(n, generator=gen) for n in order]
+    C = build_circuit(dev, target["backend"], sizes)
+    starts = [torch.randn(mem.current.shape, generator=gen) * 0.3 for mem in (C["mem_ab"], C["mem_ba"])]
+    for mem, src in zip((C["mem_ab"], C["mem_ba"]), starts):  # (a start state that is not zero)
+        mem.load(src)
+    want = float64_adjoint(C, x, T, g_out, g_end)
+    res, gW = adjoint_built(C, x.to(dev), T, g_out, g_end, dev)
+    close = lambda got, ref, what: np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=0, atol=2e-5 * max(1.0, float(ref.abs().max())), err_msg=what)
+    close(res[0]["gx"], want["x"], "grad x")
+    close(res[0]["lam"], want["va"], "grad v_a(0)")
+    close(res[2]["lam"], want["vb"], "grad v_b(0)")
+    for k in ("ba", "af", "fb", "ab"):
+        close(gW[k], want[k], f"grad W[{k}]")
+    if dev != "cpu":
+        Co = build_circuit("cpu", oracle_backend, sizes)
+        for mem, src in ((Co["mem_ab"], starts[0]), (Co["mem_ba"], starts[1])):
+            mem.load(src)
+        ref, _ = adjoint_built(Co, x, T, g_out, g_end, "cpu")
+        for m in range(3):
+            for key in res[m]:
+                assert_same(ref[m][key], res[m][key], f"member {m} {key}")
