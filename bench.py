@@ -1002,6 +1002,37 @@ def stepwise_extra(dev):
                 rec["feedback_fit_bptt" + ("_adjoint_on_the_per_step_walk" if walk else "")] = (time.perf_counter() - t0) / Tf * 1e6
                 del fb
                 torch.cuda.empty_cache()
+            # (iv-b) r05 (ABI v18): the same training with an activation node / an edge with memory inside the cycle -- the gradient
+            # passes through them inside rp_backward_coupled (five matrices of (N/2)^2 forward, five transposed ones backward)
+            for key, build in (
+                ("feedback_fit_bptt_through_tanh_node",
+                 lambda f: (f.add_func_node("mid", h, "tanh"), f.add_edge("a", "mid", weights=gen_rows(h, 0, h, dev, g=0.5), train="gd"),
+                            f.add_edge("mid", "b", weights=gen_rows(h, 0, h, dev, g=0.5), train="gd"))),
+                ("feedback_fit_bptt_through_LinearFilter_edge",
+                 lambda f: f.add_edge("a", "b", weights=gen_rows(h, 0, h, dev, g=0.5), filter_weights=gen_rows(h, 0, h, dev, g=0.5),
+                                      train="gd"))):
+                for walk in ((False, True) if N <= 4096 else (False,)):
+                    fb = FeedbackNetwork(dt=1e-2, device=str(dev))
+                    fb.add_diffeq_node("a", tanh, **train_kw(gen_rows(h, 0, h, dev, g=0.8)))
+                    fb.add_diffeq_node("b", tanh, **train_kw(gen_rows(h, 0, h, dev, g=0.8)))
+                    fb.add_func_node("out", 3, "identity")
+                    build(fb)
+                    fb.add_edge("b", "a", weights=gen_rows(h, 0, h, dev, g=0.5), feedback=True, train="gd")
+                    fb.add_edge("b", "out", weights=torch.randn(3, h, device=dev, generator=gen) / h ** 0.5, train="gd")
+                    fb._force_stepwise_adjoint = walk
+                    Tf = T // 50 * 50 if not walk else 100
+
+                    def fit(steps, fb=fb):
+                        steps = max(50, steps // 50 * 50)
+                        fb.fit_bptt(x_h[:steps], y_h[:steps], optimizer="sgd", lr=1e-4, update_steps=50, sampling_steps=50, verbose=False)
+                    fit(50)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    fit(Tf)
+                    torch.cuda.synchronize()
+                    rec[key + ("_adjoint_on_the_per_step_walk" if walk else "")] = (time.perf_counter() - t0) / Tf * 1e6
+                    del fb
+                    torch.cuda.empty_cache()
             del x_h, y_h
             torch.cuda.empty_cache()
             res["sizes"][f"N{N}"] = {k_: round(v_, 2) for k_, v_ in rec.items()}

@@ -100,7 +100,7 @@ def build_feedback(where, seed, kinds, sizes, m, k, fb_pairs, train=False, densi
     return net, rec_var
 
 
-def vary_edges(net, labels, sizes, fb_pairs, rng):
+def vary_edges(net, labels, sizes, fb_pairs, rng, train=False, kinds=("plain", "delay", "filter", "delay_filter", "masked", "node"), many=True):
     """r05: replace edges between populations by the variants that used to force the per-step walk -- edges with memory
     (delay / filter / delay + filter), masked edges, an element-wise activation node in between -- and, rarely, pile more than
     RP_MAX_EDGES edges onto one population through small side populations.  Returns what was done (for the failure report)."""
@@ -108,13 +108,15 @@ def vary_edges(net, labels, sizes, fb_pairs, rng):
     pairs = [(labels[i], labels[i + 1], False) for i in range(len(labels) - 1)] + [(labels[s_], labels[t_], True) for s_, t_ in fb_pairs]
     width = dict(zip(labels, sizes))
     for s_, t_, fb in pairs:
-        kind = ["plain", "delay", "filter", "delay_filter", "masked", "node"][int(rng.integers(0, 6))]
+        kind = kinds[int(rng.integers(0, len(kinds)))]
         if kind == "plain" or (fb and kind == "node"):
             continue
         ns, nt = width[s_], width[t_]
         W = rng.standard_normal((nt, ns)) * 0.6 / np.sqrt(ns)
         net.pop_edge(s_, t_)
         kw = dict(feedback=True) if fb else {}
+        if train:
+            kw["train"] = "gd"
         if kind == "delay":
             net.add_edge(s_, t_, weights=W, delays=rng.integers(0, 5, size=ns), **kw)
         elif kind == "filter":
@@ -127,10 +129,10 @@ def vary_edges(net, labels, sizes, fb_pairs, rng):
             w = int(rng.integers(3, 70))
             name = f"f_{s_}{t_}"
             net.add_func_node(name, w, ["tanh", "sigmoid", "identity"][int(rng.integers(0, 3))])
-            net.add_edge(s_, name, weights=rng.standard_normal((w, ns)) * 0.7 / np.sqrt(ns))
-            net.add_edge(name, t_, weights=rng.standard_normal((nt, w)) * 0.7 / np.sqrt(w))
+            net.add_edge(s_, name, weights=rng.standard_normal((w, ns)) * 0.7 / np.sqrt(ns), train="gd" if train else None)
+            net.add_edge(name, t_, weights=rng.standard_normal((nt, w)) * 0.7 / np.sqrt(w), train="gd" if train else None)
         done.append(f"{s_}->{t_}:{kind}")
-    if rng.integers(0, 5) == 0 and len(labels) >= 2:   # ten more edges into the last population
+    if many and rng.integers(0, 5) == 0 and len(labels) >= 2:   # ten more edges into the last population
         t_ = labels[-1]
         for q in range(10):
             add_population(net, f"p{q}", "tanh", 6, rng)
@@ -220,7 +222,8 @@ def main(cases=40, seed=0, max_n=1100):
                 density = float(rng.uniform(0.03, 0.12)) if fixed else None
                 if fixed:
                     sizes = [max(8, n - n % 4) for n in sizes]
-                cfg = dict(kind="fit", kinds=kinds, sizes=sizes, m=m, k=k, fb=sorted(pairs), T=T, win=win, fixed_sparse=int(fixed))
+                varied = (not fixed) and int(rng.integers(0, 2)) == 0
+                cfg = dict(kind="fit", kinds=kinds, sizes=sizes, m=m, k=k, fb=sorted(pairs), T=T, win=win, fixed_sparse=int(fixed), varied=varied)
                 x = (rng.standard_normal((T, m if m else sizes[0])) * 0.5 + (1.5 if KINDS[kinds[0]].get("spike") else 0.0)).astype(np.float32)
                 y = (rng.standard_normal((T, k)) * 0.2).astype(np.float32)
                 res = []
@@ -228,6 +231,9 @@ def main(cases=40, seed=0, max_n=1100):
                     with contextlib.redirect_stdout(io.StringIO()):
                         net, _ = build_feedback(where, 1000 * seed + case, kinds, sizes, m, k, sorted(pairs), train=True, density=density,
                                                 fixed_edges=int(fixed))
+                        if varied:   # r05 (ABI v18): trained edges with memory / masks / activation nodes inside the cycle
+                            cfg["edges"] = vary_edges(net, "abcd"[:npop], sizes, sorted(pairs), np.random.default_rng(9000 * seed + case), train=True,
+                                                      kinds=("plain", "delay", "filter", "masked", "node"), many=False)
                         net._force_stepwise_adjoint = walk
                         net.compile()
                         fused = net._coupled_grad_plan() is not None
@@ -312,6 +318,8 @@ def main(cases=40, seed=0, max_n=1100):
         except Exception as e:  # noqa: BLE001
             ok = False
             cfg["exception"] = f"{type(e).__name__}: {e}"
+        if ok and os.environ.get("FUZZ_VERBOSE") and cfg.get("kind") in ("fit", "variants"):
+            print("ok", json.dumps({q: v for q, v in cfg.items() if q in ("kind", "kinds", "sizes", "edges", "varied", "fused_adjoint", "coupled_plan")}), flush=True)
         if not ok:
             fails += 1
             print(json.dumps(dict(case=case, seed=seed, **{q: (v if not isinstance(v, (np.integer,)) else int(v)) for q, v in cfg.items()})), flush=True)
