@@ -436,20 +436,13 @@ __global__ __launch_bounds__(kThreads) void rls_sym_kernel(const RlsParams P) {
                 if (FULL || (valid && i < n))
                     __builtin_nontemporal_store(p, reinterpret_cast<rp_f4*>(base + (int64_t)(g + r) * P.ldp));
             }
-            rp_f4 a;
-            a.x = fmaf(p.x, xv.x, 0.f);
-            a.y = fmaf(p.y, xv.y, 0.f);
-            a.z = fmaf(p.z, xv.z, 0.f);
-            a.w = fmaf(p.w, xv.w, 0.f);
+            const rp_f4 a = rp_fma4(p, xv, zero4);
             rs[r] = rp_lane_sum4(a);
             // (rows past the end must not touch the chain: the oracle stops at n.  On a diagonal block the chain is
             // computed and dropped -- 32 of 528 blocks -- rather than branched around: no divergent path in the loop)
             if (!(PROBE & 1) && (FULL || (upper && i < n))) {
                 const float xi = xr[r];
-                cp.x = fmaf(p.x, xi, cp.x);
-                cp.y = fmaf(p.y, xi, cp.y);
-                cp.z = fmaf(p.z, xi, cp.z);
-                cp.w = fmaf(p.w, xi, cp.w);
+                cp = rp_fma4s(p, xi, cp);
             }
         }
         if (PROBE & 2) {
@@ -668,18 +661,10 @@ __global__ __launch_bounds__(kThreads) void rls_symk_kernel(const RlsParams P) {
             if constexpr (DOT) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
-                    rp_f4 a;
-                    a.x = fmaf(p.x, xv[k].x, 0.f);
-                    a.y = fmaf(p.y, xv[k].y, 0.f);
-                    a.z = fmaf(p.z, xv[k].z, 0.f);
-                    a.w = fmaf(p.w, xv[k].w, 0.f);
+                    const rp_f4 a = rp_fma4(p, xv[k], zero4);
                     rs[k * R + r] = rp_lane_sum4(a);
                     if (FULL || (upper && i < n)) {  // (on a diagonal block the chain is computed and dropped, as in rls_sym_kernel)
-                        const float xi = xrow[g + r][k];
-                        cp[k].x = fmaf(p.x, xi, cp[k].x);
-                        cp[k].y = fmaf(p.y, xi, cp[k].y);
-                        cp[k].z = fmaf(p.z, xi, cp[k].z);
-                        cp[k].w = fmaf(p.w, xi, cp[k].w);
+                        cp[k] = rp_fma4s(p, xrow[g + r][k], cp[k]);
                     }
                 }
             }

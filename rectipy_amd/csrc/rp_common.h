@@ -84,13 +84,61 @@ __device__ __forceinline__ rp_f4 rp_ld4(const float* p) {
 
 // Fixed butterfly: after it every lane holds the same total.  s[l] += s[l ^ off]
 // for off = 32,16,8,4,2,1 (the order is part of the summation spec).
+// The value of lane l ^ OFF, without the LDS crossbar (ds_bpermute) wherever gfx950 has a register form: the half / quarter
+// swaps v_permlane32_swap / v_permlane16_swap (OFF = 32, 16: rp_pair_sum below), DPP row_ror:8, two bank-masked DPP
+// row shifts (OFF = 4), DPP quad permutations (OFF = 2, 1).  Lane patterns measured on the chip: scripts/probes/lane_ops_probe.hip.
+typedef unsigned rp_u2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ float rp_lane_xor(float v) {
+    static_assert(OFF == 8 || OFF == 4 || OFF == 2 || OFF == 1, "register forms of lane ^ OFF inside a row of 16");
+    const unsigned u = __float_as_uint(v);
+    if constexpr (OFF == 8) return __uint_as_float(__builtin_amdgcn_update_dpp(0u, u, 0x128, 0xf, 0xf, false));       // row_ror:8
+    else if constexpr (OFF == 2) return __uint_as_float(__builtin_amdgcn_update_dpp(0u, u, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    else if constexpr (OFF == 1) return __uint_as_float(__builtin_amdgcn_update_dpp(0u, u, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    else {
+        unsigned r = __builtin_amdgcn_update_dpp(0u, u, 0x104, 0xf, 0x5, false);   // row_shl:4 into banks 0, 2: lane + 4
+        r = __builtin_amdgcn_update_dpp(r, u, 0x114, 0xf, 0xa, false);             // row_shr:4 into banks 1, 3: lane - 4
+        return __uint_as_float(r);
+    }
+}
+// a[l] + a[l ^ OFF] in the lanes with (l & OFF) == 0 and b[l] + b[l ^ OFF] in the others, OFF = 32 | 16: one swap of the
+// halves (quarters) of the two registers and ONE addition -- the additions of `keep + shuffled(send)` (a + b == b + a)
+template <int OFF>
+__device__ __forceinline__ float rp_pair_sum(float a, float b) {
+    static_assert(OFF == 32 || OFF == 16, "half / quarter swaps");
+    rp_u2 r;
+    if constexpr (OFF == 32) r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    else r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
 __device__ __forceinline__ float rp_wave_allreduce(float s) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, RP_WAVE);
+    s = rp_pair_sum<32>(s, s);
+    s = rp_pair_sum<16>(s, s);
+    s = s + rp_lane_xor<8>(s);
+    s = s + rp_lane_xor<4>(s);
+    s = s + rp_lane_xor<2>(s);
+    s = s + rp_lane_xor<1>(s);
     return s;
 }
 
 __device__ __forceinline__ float rp_lane_sum4(rp_f4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+// c + p * s per component, every component one fused multiply-add (fmaf): two v_pk_fma_f32 instead of four v_fma_f32
+typedef float rp_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ rp_f4 rp_fma4(rp_f4 p, rp_f4 x, rp_f4 c) {
+    rp_f4 r;
+    r.xy = __builtin_elementwise_fma(p.xy, x.xy, c.xy);
+    r.zw = __builtin_elementwise_fma(p.zw, x.zw, c.zw);
+    return r;
+}
+__device__ __forceinline__ rp_f4 rp_fma4s(rp_f4 p, float s, rp_f4 c) {
+    const rp_f2 s2 = {s, s};
+    rp_f4 r;
+    r.xy = __builtin_elementwise_fma(p.xy, s2, c.xy);
+    r.zw = __builtin_elementwise_fma(p.zw, s2, c.zw);
+    return r;
+}
 
 // The butterflies of R rows at once (a "transposed" butterfly): sums, over the 64 lanes, R per-lane values; afterwards lane l
 // holds the total of the row spelled by its lane bits, high bit first (rp_rows_allreduce_row).  Same pairings (l, l ^ 32),
@@ -100,12 +148,17 @@ __device__ __forceinline__ float rp_lane_sum4(rp_f4 a) { return (a.x + a.y) + (a
 template <int R, int W, int OFF>
 __device__ __forceinline__ void rp_rows_level(float (&v)[R], int lane) {
     if constexpr (W > 1) {
-        const bool hi = (lane & OFF) != 0;
+        if constexpr (OFF >= 16) {
 #pragma unroll
-        for (int q = 0; q < W / 2; ++q) {
-            const float send = hi ? v[q] : v[q + W / 2];
-            const float keep = hi ? v[q + W / 2] : v[q];
-            v[q] = keep + __shfl_xor(send, OFF, 64);
+            for (int q = 0; q < W / 2; ++q) v[q] = rp_pair_sum<OFF>(v[q], v[q + W / 2]);
+        } else {
+            const bool hi = (lane & OFF) != 0;
+#pragma unroll
+            for (int q = 0; q < W / 2; ++q) {
+                const float send = hi ? v[q] : v[q + W / 2];
+                const float keep = hi ? v[q + W / 2] : v[q];
+                v[q] = keep + rp_lane_xor<OFF>(send);
+            }
         }
         rp_rows_level<R, W / 2, OFF / 2>(v, lane);
     }
@@ -114,7 +167,8 @@ __device__ __forceinline__ void rp_rows_level(float (&v)[R], int lane) {
 template <int OFF>
 __device__ __forceinline__ float rp_tail_allreduce(float s) {
     if constexpr (OFF >= 1) {
-        s = s + __shfl_xor(s, OFF, 64);
+        if constexpr (OFF >= 16) s = rp_pair_sum<OFF>(s, s);
+        else s = s + rp_lane_xor<OFF>(s);
         return rp_tail_allreduce<OFF / 2>(s);
     } else {
         return s;
