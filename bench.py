@@ -827,6 +827,8 @@ def rls_extra(dev, n_in=32768, k=3, T=64, cpu_threads=None):
         edge.block = 8 if form == "blocked" else 1   # (8 is the default with beta = 1, the reference's default; here beta = 0.99)
         Tf = T if form == "blocked" else 20
         edge.sweep(X[:16], Y[:16], 1)
+        edge.sweep(X[:Tf], Y[:Tf], 1)   # (warm-up: a call of the timed length -- the first pass pattern over the 4 GiB of P after
+        #                                  its allocation runs 15 % slower than every later one, scripts/probes/rls_ab_libs.py)
         torch.cuda.synchronize()
         e0.record()
         edge.sweep(X[:Tf], Y[:Tf], 1)

@@ -713,7 +713,7 @@ typedef struct rp_rls {
        from a few updates per call (the mirror costs about one dense pass). */
     float* colparts;
     int64_t ldc;
-    int32_t sym_rows;  /* rows per chunk of the symmetric pass: 16, 32 or 64 (0: 64; blocked sweep: 64 or 128); part of its summation order */
+    int32_t sym_rows;  /* rows per chunk of the symmetric pass: 16, 32 or 64 (0: 64; blocked sweep: 64, 128 or 256); part of its summation order */
     /* symmetric pass only: 1 = return WITHOUT mirroring -- the blocks on and above the diagonal stay the authoritative
        half of P (the state the next symmetric sweep starts from anyway) and the caller restores the lower blocks with
        rp_rls_mirror before anything else reads P.  Saves one pass over half of P per call (0.78 ms at n_in = 32768). */

@@ -682,6 +682,8 @@ __global__ __launch_bounds__(kThreads) void rls_symk_kernel(const RlsParams P) {
         for (int r = 0; r < R; ++r)
             buf[r] = (FULL || (valid && row0 + g + r < n)) ? rp_ld4_stream(base + (int64_t)(g + r) * P.ldp) : zero4;
     };
+    // (r05: a ring of four register buffers -- three groups of rows in flight -- was measured: 0.150 against 0.127 ms per update;
+    // the extra registers cost more than the latency they cover)
 #pragma unroll 1
     for (int g = 0; g + 2 * R < C; g += 2 * R) {
         fetch(g + R, bufB);
@@ -1070,7 +1072,8 @@ void launch_symk(const RlsParams& P, hipStream_t st) {
     // rows in flight per wave (registers: K inputs and K updates per lane).  Measured at n_in = 32768, ms per update
     // (scripts/probes/rls_blocked_sweep.py): K = 8, 64-row tiles: R = 2 0.196 with one workgroup per CU, 0.160 / 0.159 with two /
     // no cap (R = 4: 0.170 / 0.167 / 0.169); K = 4: R = 4 0.237 with one per CU (0.248 / 0.249), R = 2 0.267 / 0.245 / 0.253
-    constexpr int R = K >= 8 ? 2 : 4;
+    // r05 (register cross-lane reductions, packed fma): K = 8, 128-row tiles: R = 4 0.1247 / 0.1248 (two per CU / no cap), R = 2 0.137 / 0.127
+    constexpr int R = 4;
 #ifdef RP_MEASUREMENT
     if (g_blk_R == 4 && R != 4) return launch_symk_r<K, UPDATE, DOT, C, 4>(P, st);
     if (g_blk_R == 2 && R != 2) return launch_symk_r<K, UPDATE, DOT, C, 2>(P, st);
@@ -1087,7 +1090,7 @@ int launch_symk_rows(const RlsParams& P, int rows, bool update, bool dot, hipStr
         else launch_symk<K, false, true, C_>(P, st);                 \
         return RP_OK;                                                \
     }
-    RP_SYMK(64) RP_SYMK(128)
+    RP_SYMK(64) RP_SYMK(128) RP_SYMK(256)
 #undef RP_SYMK
     return RP_ERR_ARG;
 }
@@ -1341,8 +1344,8 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
     P.colparts = sym ? r->colparts : nullptr;
     P.ldc = r->ldc;
     const int sym_rows = r->sym_rows > 0 ? r->sym_rows : kSymRowsDefault;
-    if (sym && r->block > 1 ? (sym_rows != 64 && sym_rows != 128) : (sym_rows != 16 && sym_rows != 32 && sym_rows != 64))
-        RP_FAIL(RP_ERR_ARG, "sym_rows must be 16, 32 or 64 (blocked sweep: 64 or 128), got %d", sym_rows);
+    if (sym && r->block > 1 ? (sym_rows != 64 && sym_rows != 128 && sym_rows != 256) : (sym_rows != 16 && sym_rows != 32 && sym_rows != 64))
+        RP_FAIL(RP_ERR_ARG, "sym_rows must be 16, 32 or 64 (blocked sweep: 64, 128 or 256), got %d", sym_rows);
     if (r->block > 1) {
         if (!sym) RP_FAIL(RP_ERR_ARG, "rp_rls.block > 1 needs the symmetric pass (partials and colparts)");
         return sweep_blocked(r, P, sym_rows, steps, stride, X, ldx, Y, ldy, pred, ldpred, loss, st);

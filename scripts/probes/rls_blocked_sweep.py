@@ -18,11 +18,11 @@ Y = torch.randn(T, k, device=dev, generator=gen)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 out = {}
 for block in (8,):
-    for rows in (128, 64):
+    for rows in (128, 256):
         edge = RLS(n_in, k, beta=0.99, alpha=1.0, backend=mb).to(dev)
         edge.symmetric, edge.block, edge.BLOCK_ROWS = True, block, rows
         for R in (2, 4):
-            for cap in (2, 0):
+            for cap in ((2, 0) if rows <= 128 else (0,)):
                 mb.lib.rp_set_rls_blk(R, cap)
                 edge.sweep(X[:16], Y[:16], 1)
                 torch.cuda.synchronize()
