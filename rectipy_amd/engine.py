@@ -1060,6 +1060,9 @@ class BatchedPopulation:
         if pop.n % 4 or pop.W.stride(0) % 4:
             raise ValueError("batched trajectories need n % 4 == 0")
         if form is None:
+            if exact and mfma is None and batch > 4 and batch not in self.BATCHES:
+                raise ValueError(f"exact=True (bit-identical to unbatched runs) needs a vector-ALU batch size {self.BATCHES} or at most 4 "
+                                 f"trajectories, got {batch} (Network.run_batch pads to the next one)")
             use_mfma = (batch > 4 and not (exact and batch in self.BATCHES)) if mfma is None else bool(mfma)
             form = self.DEFAULT_MFMA if use_mfma else "valu"
             # more than 16 trajectories on a SMALL population: the r02 form's 32-row workgroups fill the chip where the

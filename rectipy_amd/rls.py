@@ -31,6 +31,7 @@ class RLS(Linear):
         self._P = alpha * torch.eye(n_in, dtype=torch.float32)
         self._upper_only = False     # a symmetric sweep left the blocks below the diagonal stale (mirrored on the next read of P)
         self._P_symmetric = True     # P is symmetric up to rounding (alpha * I and whatever the sweeps made of it); None: unchecked
+        self._P_version = self._P._version   # (an in-place edit through the `P` property since the last sweep voids `_P_symmetric`)
         self.loss = 0.0
         self._backend = backend
         self._scratch = None
@@ -75,6 +76,19 @@ class RLS(Linear):
         self._P = value
         self._upper_only = False
         self._P_symmetric = None  # unknown
+        self._P_version = value._version
+
+    def _symmetric_up_to_rounding(self) -> bool:
+        """P == P^T up to the rounding the dense passes leave, checked in strips of 1024 rows (no full-matrix temporaries: at
+        n_in = 32768 a whole-matrix `allclose` would allocate several times the 4 GiB of P)."""
+        P, n = self._P, self.n_in
+        scale = 0.0
+        for a in range(0, n, 1024):
+            scale = max(scale, float(P[a:a + 1024].abs().max()))
+        for a in range(0, n, 1024):
+            if not torch.allclose(P[a:a + 1024, a:], P[a:, a:a + 1024].T, rtol=1e-4, atol=1e-6 * scale):
+                return False
+        return True
 
     def to(self, device: str, **kwargs):
         self.weights = self.weights.detach().to(device).contiguous()
@@ -136,11 +150,14 @@ class RLS(Linear):
         use_sym = self._partials is not None and (
             self.symmetric is True or (self.symmetric is None and self.n_in >= self.SYMMETRIC_MIN_N
                                        and updates >= self.SYMMETRIC_MIN_UPDATES))
+        if getattr(self, "_P_version", None) != self._P._version:
+            # P was edited in place through the `P` property since the last sweep (the library itself writes through the raw
+            # pointer and leaves the counter alone): what is known about its symmetry is void
+            self._P_symmetric = None
         if use_sym and self._P_symmetric is None:
-            # a P assigned from outside: symmetric up to rounding (as the dense passes leave it: (k z_i) z_j and (k z_j) z_i
-            # differ in the last bit)?  Then the half on and above the diagonal may stand for all of it.
-            scale = float(self._P.abs().max())
-            self._P_symmetric = bool(torch.allclose(self._P, self._P.T, rtol=1e-4, atol=1e-6 * scale))
+            # a P assigned or edited from outside: symmetric up to rounding (as the dense passes leave it: (k z_i) z_j and
+            # (k z_j) z_i differ in the last bit)?  Then the half on and above the diagonal may stand for all of it.
+            self._P_symmetric = self._symmetric_up_to_rounding()
         use_sym = use_sym and bool(self._P_symmetric)
         if self._upper_only and not use_sym:
             self.P  # (a dense pass reads all of P: restore the lower blocks first)
@@ -172,6 +189,7 @@ class RLS(Linear):
         self._backend.rls_sweep(r, T, int(stride), X.data_ptr(), X.stride(0) if T > 1 else self.n_in, Y.data_ptr(),
                                 Y.stride(0) if T > 1 else self.n_out, pred.data_ptr(), self.n_out, loss.data_ptr(), dev)
         self._upper_only = bool(use_sym)
+        self._P_version = self._P._version
         self.loss = loss[-1]
         return pred, loss
 

@@ -85,6 +85,9 @@ def test_batched_argument_errors(oracle_backend):
         BatchedPopulation(pop, 3, mfma=False)
     with pytest.raises(ValueError):
         BatchedPopulation(pop, 33)
+    with pytest.raises(ValueError, match="exact=True"):   # (5..7 trajectories have no bit-identical form: no silent matrix-core run)
+        BatchedPopulation(pop, 6, exact=True)
+    assert not BatchedPopulation(pop, 8, exact=True).mfma and BatchedPopulation(pop, 6).mfma
     bp = BatchedPopulation(pop, 2)
     with pytest.raises(RuntimeError):
         bp.forward(5, x=torch.zeros(5, 3, 64))

@@ -277,16 +277,38 @@ def test_mirror_is_deferred_until_P_is_read_and_asymmetric_P_keeps_the_dense_pas
     g_.P = (torch.eye(n) * 1.3).to(dev)
     g_.sweep(X, Y, 1)
     assert g_._P_symmetric is True and g_._upper_only
+    # an IN-PLACE edit through the `P` property between sweeps (r05): what was known about P's symmetry is void -- an edit that
+    # breaks it sends the next sweep to the dense passes (on every element, as the reference), one that keeps it stays symmetric
+    h, i_ = make(tiled=True, symmetric=None), make(tiled=True, symmetric=False)
+    h.SYMMETRIC_MIN_N, h.SYMMETRIC_MIN_UPDATES = 0, 1
+    h.sweep(X[:6], Y[:6], 1)
+    i_.sweep(X[:6], Y[:6], 1)
+    assert h._upper_only and h._P_symmetric is True
+    i_.P = h.P.clone()                        # (the same start for the comparison: all of P, mirrored)
+    i_.weights.copy_(h.weights)
+    h.P[7, 1800] += 0.5                       # one of the two mirror positions
+    i_.P[7, 1800] += 0.5
+    h.sweep(X[6:], Y[6:], 1)
+    i_.sweep(X[6:], Y[6:], 1)
+    assert h._P_symmetric is False and not h._upper_only
+    assert torch.equal(h.P, i_.P) and torch.equal(h.weights, i_.weights)
+    j_ = make(tiled=True, symmetric=None)
+    j_.SYMMETRIC_MIN_N, j_.SYMMETRIC_MIN_UPDATES = 0, 1
+    j_.sweep(X[:6], Y[:6], 1)
+    j_.P.mul_(1.01)                           # keeps the symmetry
+    j_.sweep(X[6:], Y[6:], 1)
+    assert j_._P_symmetric is True and j_._upper_only
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_in,n_out,T,stride,block,rows", [
     (256, 2, 25, 3, 2, 64), (1000, 4, 12, 1, 4, 128), (2048, 2, 19, 1, 8, 64), (4100, 2, 11, 1, 4, 64), (3140, 3, 21, 2, 8, 128),
-    (4096, 2, 17, 1, 8, 64), (8192, 1, 18, 2, 8, 128), (9000, 3, 20, 1, 8, 128), (9000, 2, 9, 1, 2, 64), (9000, 2, 9, 1, 4, 64)])
+    (4096, 2, 17, 1, 8, 64), (8192, 1, 18, 2, 8, 128), (9000, 3, 20, 1, 8, 128), (9000, 2, 9, 1, 2, 64), (9000, 2, 9, 1, 4, 64),
+    (3140, 2, 19, 1, 8, 256), (4096, 3, 10, 2, 4, 256), (2300, 2, 9, 1, 2, 256)])
 def test_blocked_rls_sweep_bit_exact(oracle_backend, hip_device, n_in, n_out, T, stride, block, rows):
     """The blocked symmetric sweep (rp_rls.block: P streamed once per `block` updates, the block before's rank-1 updates and
     the products with all inputs of the block in one pass; the z vectors of the block by the double-precision recurrence)
-    on the GPU against the C oracle, bit for bit: full and ragged blocks of updates, ragged tiles / chunks / 1024-blocks, 64 / 128 rows per tile, the
+    on the GPU against the C oracle, bit for bit: full and ragged blocks of updates, ragged tiles / chunks / 1024-blocks, 64 / 128 / 256 rows per tile, the
     unpredicated kernel (n_in % 1024 == 0), enough tiles for the residency cap (8192, 9000), two consecutive sweeps."""
     gen = torch.Generator().manual_seed(n_in + T)
     base = torch.randn(n_in, generator=gen)
