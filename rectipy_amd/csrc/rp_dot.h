@@ -289,12 +289,30 @@ __device__ __forceinline__ void rp_sparse_blocked_rows(const float* __restrict__
             work(k + U, vb, mb);
         }
         const int nr = min(RB, rows - b * RB);
-        float mine = 0.f;
-        for (int r = 0; r < nr; ++r) {
-            const float sum = rp_wave_allreduce(stash[r * RP_WAVE]);
-            if (lane == r) mine = sum;
+        // the rows' butterflies at once (rp_rows_allreduce: the same pairings, i.e. the same additions per row; 8 rows: 10 cross-lane
+        // steps instead of 48); lanes 0, 64 / RB, ... end up with the total of row rp_rows_allreduce_row<RB>(lane)
+        if (RB == 16) {
+            float part[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r] = r < nr ? stash[r * RP_WAVE] : 0.f;
+            const float total = rp_rows_allreduce<16>(part, lane);
+            const int f = rp_rows_allreduce_row<16>(lane);
+            if ((lane & 3) == 0 && f < nr) epi(b * RB + f, total);
+        } else if (RB == 8) {
+            float part[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) part[r] = r < nr ? stash[r * RP_WAVE] : 0.f;
+            const float total = rp_rows_allreduce<8>(part, lane);
+            const int f = rp_rows_allreduce_row<8>(lane);
+            if ((lane & 7) == 0 && f < nr) epi(b * RB + f, total);
+        } else {
+            float mine = 0.f;
+            for (int r = 0; r < nr; ++r) {
+                const float sum = rp_wave_allreduce(stash[r * RP_WAVE]);
+                if (lane == r) mine = sum;
+            }
+            if (lane < nr) epi(b * RB + lane, mine);
         }
-        if (lane < nr) epi(b * RB + lane, mine);
     }
     if (!staged) stage();  // (a wave without a block still takes part in the staging and its barrier)
 }
