@@ -287,7 +287,7 @@ def float64_adjoint(C, x, T, g_out, g_end):
 
 
 @pytest.mark.parametrize("target", TARGETS, indirect=True)
-@pytest.mark.parametrize("sizes", [(24, 16, 20), (260, 72, 132), (17, 9, 30)])
+@pytest.mark.parametrize("sizes", [(24, 16, 20), (260, 72, 132), (17, 9, 30), (1028, 520, 2052), (4100, 64, 1024)])
 def test_coupled_adjoint_through_activation_node_and_memory_edges(target, sizes, oracle_backend):
     """(r05, ABI v18) rp_backward_coupled through an activation-node member (gx = g_out * act'(out)), a FILTER edge on the feedback
     edge (ly(t) = W_e^T gx(t) + F^T ly(t + 1)) and a DELAY edge (the total of W_e^T gx(t) into one element, d steps earlier):
