@@ -163,14 +163,14 @@ __device__ __forceinline__ float activation(const StepParams& P, int i, float v)
 }
 
 // EDGES: `esum` = ((E_0 + E_1) + ...) of the population's dense edges joins the node input (rp_run.edge_*)
+// `I_x`: the step's external input of neuron i (input_current), `v` / `s`: its state and source value BEFORE the step -- read by
+// the caller (the per-step kernels: from memory right here; the resident kernel: its own values of the step before, kept in
+// registers, and the input fetched while it waits for the source vector).  Returns the new source value; *v_new: the new state.
 template <int MODEL, bool EDGES = false>
-__device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum, float esum = 0.f) {
+__device__ __forceinline__ float epilogue_core(const StepParams& P, int i, float wsum, float esum, float I_x, float v, float s,
+                                               float* v_new_out) {
     const int gi = P.row0 + i;
-    if constexpr (MODEL == kModelFilter) {  // rp_edge_mem: y'_i = (F y)_i + x_i  (edges.py:119, 144)
-        P.src_next[i] = P.x_mode != RP_X_NONE ? wsum + P.x_t[i] : wsum;
-        return;
-    }
-    float I = input_current(P, i);
+    float I = I_x;
     if constexpr (EDGES)
         if (P.n_edges > 0) I = P.x_mode != RP_X_NONE ? I + esum : esum;
     if (P.save_in_t) P.save_in_t[i] = I;
@@ -182,6 +182,7 @@ __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum,
             o = 1.0f / (1.0f + rp_expf(-I));
         P.src_next[gi] = o;
         sample_output(P, i, o);
+        return o;
     } else if constexpr (MODEL >= RP_MODEL_QIF) {
         // SpikeResetNet.forward (nodes.py:382-392) with the field of the spiking template:
         //   QIF      qif.yaml:11-12     v' = (v^2 + eta + I)/tau + k s_in;          s' = -s/tau_s + spike
@@ -189,8 +190,6 @@ __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum,
         //   LIF      lif.yaml:10-16     v' = -v/tau + k s_in + I + eta;             s' = -s/tau_s + spike + s_ext
         //   IK       ik.yaml:8-12       v' = (k(v-v_r)(v-v_theta) - u + I + eta + g s_in (E_r - v))/C
         //                               u' = (b(v-v_r) - u)/tau_u + kappa spike;    s' = -s/tau_s + spike
-        const float v = P.y[RP_Y_V][i];
-        const float s = P.src_cur[gi];
         const float v_det = P.spike_src ? P.spike_src[i] : v;     // MultiSpikeResetNet's detector copy (nodes.py:451-453)
         const float spike = (v_det - P.theta >= 0.0f) ? 1.0f : 0.0f;  // heaviside(v-theta, 1): equality spikes
         const float spike_in = spike * P.inv_dt;                   // nodes.py:385
@@ -256,9 +255,10 @@ __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum,
                 P.spike_events[2 * slot + 1] = gi;
             }
         }
+        *v_new_out = v_new;
+        return s_new;
     } else {
         // RateNet.forward, nodes.py:166-170; field leaky_integrator.yaml:10
-        const float v = P.y[RP_Y_V][i];
         const float dv = ((-v / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * wsum) + I) + P.p[RP_P_ETA][i];
         const float v_new = v + P.dt * dv;
         const float r_new = activation<MODEL>(P, i, v_new);
@@ -266,13 +266,29 @@ __device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum,
         P.src_next[gi] = r_new;
         if (P.hist_next) P.hist_next[i] = P.out_var == RP_OUT_STATE0 ? v_new : r_new;
         if (P.save_state_t[0]) P.save_state_t[0][i] = v;
-        if (P.save_src_t) P.save_src_t[i] = P.src_cur[gi];
+        if (P.save_src_t) P.save_src_t[i] = s;
         if (P.save_acc_t) P.save_acc_t[i] = wsum;
-        sample_output(P, i, P.out_var == RP_OUT_STATE0 ? v : P.src_cur[gi]);
+        sample_output(P, i, P.out_var == RP_OUT_STATE0 ? v : s);
         if (P.flags & FLAG_SAMPLE) {  // post-update values (network.py:147-148)
             if (P.rec_row[0]) P.rec_row[0][i] = v_new;
             if (P.rec_row[1]) P.rec_row[1][i] = r_new;
         }
+        *v_new_out = v_new;
+        return r_new;
+    }
+}
+
+template <int MODEL, bool EDGES = false>
+__device__ __forceinline__ void epilogue(const StepParams& P, int i, float wsum, float esum = 0.f) {
+    if constexpr (MODEL == kModelFilter) {  // rp_edge_mem: y'_i = (F y)_i + x_i  (edges.py:119, 144)
+        P.src_next[i] = P.x_mode != RP_X_NONE ? wsum + P.x_t[i] : wsum;
+    } else {
+        float v = 0.f, s = 0.f, v_new;
+        if constexpr (MODEL != RP_MODEL_INSTANT) {
+            v = P.y[RP_Y_V][i];
+            s = P.src_cur[P.row0 + i];
+        }
+        (void)epilogue_core<MODEL, EDGES>(P, i, wsum, esum, input_current(P, i), v, s, &v_new);
     }
 }
 
@@ -299,6 +315,182 @@ __device__ __forceinline__ void step_body(const StepParams& P) {
 template <int MODEL, int R, int U, bool VEC4, bool NT>
 __global__ __launch_bounds__(kThreads) void step_kernel(const StepParams P) {
     step_body<MODEL, R, U, VEC4, NT>(P);
+}
+
+// ---- launch-bound sizes: ALL steps of a call in ONE launch (r05) ------------------------------------------------------------
+// At n <= 1024 a step is bounded by the dependent-launch interval of the stream (about 4 us; W is 1 MiB at n = 512), not by
+// bytes.  Here every wave keeps its rows of W in REGISTERS for the whole call and the waves hand the source vector around
+// themselves: at the end of step t the lane that ran row i's epilogue stores the 8-byte granule {tag = t + 1, r_i} (one
+// write-through store, agent scope), and at the start of step t + 1 every wave sweeps the n granules of that parity until all
+// tags read t + 1 -- the data is its own flag (no barrier, no separate flag, no fence: one round trip per step; two granule
+// buffers alternate, so a wave can only overwrite a granule once every wave has consumed it).  The row dot products visit
+// the chunks in the contract's order and reduce through the same butterflies (rp_dot.h), the epilogue is the per-step
+// kernel's: bit-identical to a launch per step.  Every sweep is bounded: a wave that times out raises `fail`, every wave that
+// sees it leaves, the host returns an error.  (r04 tried a grid barrier per step -- arrive, poll, then agent-scope loads: four to
+// five dependent trips through the fabric -- and lost against the launches: 4.95-6.0 us.)
+struct ResidentArgs {
+    int steps, cur0;
+    float* src[2];
+    unsigned long long* gran[2];
+    int* fail;
+    unsigned spin_cap;
+    const float* x;
+    int64_t ldx;
+    float* traj;
+    int64_t ldtraj;
+    float* hist[3];
+    float* save_state[RP_MAX_STATE];
+    float* save_src;
+    float* save_acc;
+    float* save_in;
+    int64_t ldsave;
+    int64_t step0, cutoff;
+    int sampling_steps, acc_count0, sample_idx0, has_acc;
+    float* samples;
+    int64_t ldsamples;
+    float* rec[RP_MAX_STATE];
+};
+
+typedef __attribute__((address_space(1))) unsigned long long rp_gu64;
+typedef __attribute__((address_space(1))) int rp_gi32;
+
+// set_step on the device (the same bookkeeping, step by step)
+__device__ __forceinline__ void resident_set_step(StepParams& P, const ResidentArgs& A, int t, int& acc_count, int& sample_idx) {
+    const int64_t t_abs = A.step0 + t;
+    const int cur = A.cur0 ^ (t & 1);
+    P.src_cur = A.src[cur];
+    P.src_next = A.src[cur ^ 1];
+    P.x_t = A.x ? A.x + (int64_t)t * A.ldx : nullptr;
+    P.traj_t = A.traj ? A.traj + (int64_t)t * A.ldtraj : nullptr;
+    P.hist_t = A.hist[0] ? A.hist[t_abs % 3] : nullptr;
+    P.hist_next = nullptr;
+#pragma unroll
+    for (int q = 0; q < RP_MAX_STATE; ++q) P.save_state_t[q] = A.save_state[q] ? A.save_state[q] + (int64_t)t * A.ldsave : nullptr;
+    P.save_src_t = A.save_src ? A.save_src + (int64_t)t * A.ldsave : nullptr;
+    P.save_acc_t = A.save_acc ? A.save_acc + (int64_t)t * A.ldsave : nullptr;
+    P.save_in_t = A.save_in ? A.save_in + (int64_t)t * A.ldsave : nullptr;
+    P.t_abs = (int)t_abs;
+    P.flags = 0;
+    P.sample_row = nullptr;
+#pragma unroll
+    for (int q = 0; q < RP_MAX_STATE; ++q) P.rec_row[q] = nullptr;
+    if (A.has_acc && t_abs >= A.cutoff) {
+        P.flags |= FLAG_BUFFER;
+        if (acc_count == 0) P.flags |= FLAG_FIRST;
+        acc_count += 1;
+        if (t_abs % A.sampling_steps == 0) {
+            P.flags |= FLAG_SAMPLE;
+            P.count = (float)acc_count;
+            const int64_t off = (int64_t)sample_idx * A.ldsamples;
+            P.sample_row = A.samples ? A.samples + off : nullptr;
+#pragma unroll
+            for (int q = 0; q < RP_MAX_STATE; ++q) P.rec_row[q] = A.rec[q] ? A.rec[q] + off : nullptr;
+            sample_idx += 1;
+            acc_count = 0;
+        }
+    }
+}
+
+// eight rows (one stagger group: the same start chunk M0) against the NC chunks of the source vector, in the contract's order
+template <int NC, int M0>
+__device__ __forceinline__ void resident_dot8(const rp_f4 (*w)[NC], const rp_f4 (&r)[NC], float* rs) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        rp_f4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int m = (M0 + i) % NC;
+            a = rp_fma4(w[j][m], r[m], a);
+        }
+        rs[j] = rp_lane_sum4(a);
+    }
+}
+
+template <int MODEL, int NC, int RW>
+__global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0, const ResidentArgs A) {
+    static_assert(RW == 8 || RW == 16, "one or two stagger groups of eight rows per wave");
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int gw = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);   // this wave's rows: [RW gw, RW gw + RW)
+    const int row_w0 = gw * RW;
+    StepParams P = P0;
+    rp_f4 w[RW][NC];
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+        for (int m = 0; m < NC; ++m) w[j][m] = rp_ld4(P.W + (int64_t)(row_w0 + j) * P.ldw + 256 * m + 4 * lane);
+    int acc_count = A.acc_count0, sample_idx = A.sample_idx0;
+    constexpr int kGroup = 64 / RW;                    // lanes that hold the same row total after the transposed butterfly
+    const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
+    const bool epi_lane = (lane & (kGroup - 1)) == 0;
+    rp_gi32* const fail = (rp_gi32*)A.fail;
+    // the epilogue lane's own state and source value stay in registers from step to step
+    float v_reg = 0.f, s_reg = 0.f;
+    if (epi_lane) {
+        v_reg = P0.y[RP_Y_V][my_row];
+        s_reg = A.src[A.cur0][P0.row0 + my_row];
+    }
+    for (int t = 0; t < A.steps; ++t) {
+        resident_set_step(P, A, t, acc_count, sample_idx);
+        P.spike_src = t == 0 ? P0.spike_src : nullptr;
+        const float I_x = epi_lane ? input_current(P, my_row) : 0.f;   // (requested before the wait for the source vector)
+        rp_f4 r[NC];
+        if (t == 0) {
+#pragma unroll
+            for (int m = 0; m < NC; ++m) r[m] = rp_ld4(P.src_cur + 256 * m + 4 * lane);
+        } else {
+            // the granules of step t - 1 (tag t): re-read until every tag matches
+            const rp_gu64* g = (const rp_gu64*)A.gran[(t - 1) & 1] + 4 * lane;
+            const unsigned want = (unsigned)t;
+            bool done = false;
+            for (unsigned spins = 0; !done; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int m = 0; m < NC; ++m) {
+                    unsigned long long q[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) q[c] = __hip_atomic_load(g + 256 * m + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ok = ok && (unsigned)(q[c] >> 32) == want;
+                    r[m].x = __uint_as_float((unsigned)q[0]);
+                    r[m].y = __uint_as_float((unsigned)q[1]);
+                    r[m].z = __uint_as_float((unsigned)q[2]);
+                    r[m].w = __uint_as_float((unsigned)q[3]);
+                }
+                done = __all(ok);
+                if (!done) {
+                    if (spins > A.spin_cap || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        if (lane == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return;   // (wave-uniform: every wave sees the flag at its next sweep and leaves)
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+        }
+        float rs[RW];
+#pragma unroll
+        for (int h = 0; h < RW / 8; ++h) {
+            const int m0 = (int)(((unsigned)((P.row0 + row_w0 + 8 * h) >> 3) * kStagger) % (unsigned)NC);   // wave-uniform
+            if constexpr (NC == 1) {
+                resident_dot8<NC, 0>(w + 8 * h, r, rs + 8 * h);
+            } else {
+                switch (m0) {
+                    case 0: resident_dot8<NC, 0>(w + 8 * h, r, rs + 8 * h); break;
+                    case 1: resident_dot8<NC, 1>(w + 8 * h, r, rs + 8 * h); break;
+                    case 2: resident_dot8<NC, 2 % NC>(w + 8 * h, r, rs + 8 * h); break;
+                    default: resident_dot8<NC, 3 % NC>(w + 8 * h, r, rs + 8 * h); break;
+                }
+            }
+        }
+        const float total = rp_rows_allreduce<RW>(rs, lane);
+        if (epi_lane) {
+            float v_new;
+            s_reg = epilogue_core<MODEL>(P, my_row, total, 0.f, I_x, v_reg, s_reg, &v_new);
+            v_reg = v_new;
+            if (t + 1 < A.steps)
+                __hip_atomic_store((rp_gu64*)A.gran[t & 1] + my_row, ((unsigned long long)(unsigned)(t + 1) << 32) | __float_as_uint(s_reg),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Step of a population with dense edges from other vectors (rp_run.edge_*, rp_forward_coupled): the wave that owns a
@@ -1216,6 +1408,94 @@ int launch_population_step(const rp_net* net, const StepParams& P, hipStream_t s
     return RP_OK;
 }
 
+// ---- the resident launch (resident_kernel): eligibility and the call ------------------------------------------------------
+template <int MODEL>
+void launch_resident_model(const StepParams& P, const ResidentArgs& A, hipStream_t st) {
+    const int nc = P.n >> 8;
+    switch (nc) {
+        case 1: hipLaunchKernelGGL((resident_kernel<MODEL, 1, 16>), dim3(P.n / 16 / kWavesPerBlock), dim3(kThreads), 0, st, P, A); break;
+        case 2: hipLaunchKernelGGL((resident_kernel<MODEL, 2, 16>), dim3(P.n / 16 / kWavesPerBlock), dim3(kThreads), 0, st, P, A); break;
+        case 3: hipLaunchKernelGGL((resident_kernel<MODEL, 3, 8>), dim3(P.n / 8 / kWavesPerBlock), dim3(kThreads), 0, st, P, A); break;
+        default: hipLaunchKernelGGL((resident_kernel<MODEL, 4, 8>), dim3(P.n / 8 / kWavesPerBlock), dim3(kThreads), 0, st, P, A); break;
+    }
+}
+
+constexpr int kResidentMinSteps = 4;
+bool resident_ok(const rp_net* net, const rp_run* run) {
+    if (const char* e = getenv("RECTIPY_AMD_RESIDENT"); e && e[0] == '0') return false;   // (read per call: tests compare both paths)
+    if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP || net->model == RP_MODEL_INSTANT || net->model < 0 ||
+        net->model > RP_MODEL_IK_BIEXP)
+        return false;
+    if (net->sp_vals || run->n_edges > 0 || run->save_src_full || run->steps < kResidentMinSteps) return false;
+    if (net->rows != net->n || net->row0 != 0 || net->n % 256 != 0 || net->n > 1024 || net->ldw % 4 != 0) return false;
+    return aligned16(net->W) && aligned16(net->src[0]) && aligned16(net->src[1]);
+}
+
+int forward_resident(rp_net* net, rp_run* run, StepParams& P, hipStream_t st) {
+    const int n = net->n;
+    ResidentArgs A = {};
+    A.steps = run->steps;
+    A.cur0 = net->cur;
+    A.src[0] = net->src[0];
+    A.src[1] = net->src[1];
+    A.spin_cap = 1u << 22;   // polls of about a microsecond each: seconds -- only a GPU that never runs all waves together gets there
+    A.x = run->x;
+    A.ldx = run->ldx;
+    A.traj = run->traj;
+    A.ldtraj = run->ldtraj;
+    for (int q = 0; q < 3; ++q) A.hist[q] = run->hist[q];
+    for (int q = 0; q < RP_MAX_STATE; ++q) {
+        A.save_state[q] = run->save_state[q];
+        A.rec[q] = run->rec[q];
+    }
+    A.save_src = run->save_src;
+    A.save_acc = run->save_acc;
+    A.save_in = run->save_in;
+    A.ldsave = run->ldsave;
+    A.step0 = run->step0;
+    A.cutoff = run->cutoff;
+    A.sampling_steps = run->sampling_steps;
+    A.acc_count0 = run->acc_count;
+    A.sample_idx0 = run->sample_idx;
+    A.has_acc = run->acc ? 1 : 0;
+    A.samples = run->samples;
+    A.ldsamples = run->ldsamples;
+    // granules [2][n] and the failure word: stream-ordered scratch, zeroed (a tag is never 0)
+    const size_t bytes = (size_t)2 * n * sizeof(unsigned long long) + 64;
+    void* ws = nullptr;
+    RP_HIP_CHECK(hipMallocAsync(&ws, bytes, st));
+    RP_HIP_CHECK(hipMemsetAsync(ws, 0, bytes, st));
+    A.gran[0] = static_cast<unsigned long long*>(ws);
+    A.gran[1] = A.gran[0] + n;
+    A.fail = reinterpret_cast<int*>(A.gran[1] + n);
+    set_step(P, net, run, 0);   // (step 0's arguments -- the kernel forms every step's itself; the bookkeeping is advanced below)
+    switch (net->model) {
+        case RP_MODEL_LI_TANH: launch_resident_model<RP_MODEL_LI_TANH>(P, A, st); break;
+        case RP_MODEL_LI_SIGMOID: launch_resident_model<RP_MODEL_LI_SIGMOID>(P, A, st); break;
+        case RP_MODEL_QIF: launch_resident_model<RP_MODEL_QIF>(P, A, st); break;
+        case RP_MODEL_QIF_SFA: launch_resident_model<RP_MODEL_QIF_SFA>(P, A, st); break;
+        case RP_MODEL_LIF: launch_resident_model<RP_MODEL_LIF>(P, A, st); break;
+        default: launch_resident_model<RP_MODEL_IK>(P, A, st); break;
+    }
+    const hipError_t launched = hipGetLastError();
+    int failed = 0;
+    hipError_t rc = hipMemcpyAsync(&failed, A.fail, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(st);
+    (void)hipFreeAsync(ws, st);
+    if (launched != hipSuccess) RP_FAIL(RP_ERR_HIP, "resident step kernel: %s", hipGetErrorString(launched));
+    if (rc != hipSuccess) RP_FAIL(RP_ERR_HIP, "resident step kernel: %s", hipGetErrorString(rc));
+    if (failed)
+        RP_FAIL(RP_ERR_HIP, "the resident step kernel timed out waiting for a peer wave (its %d workgroups were never resident together: "
+                            "is another kernel holding the GPU?); RECTIPY_AMD_RESIDENT=0 selects one launch per step", n / 64);
+    StepParams Q = P;
+    net->cur ^= 1;
+    for (int t = 1; t < run->steps; ++t) {   // the sampling bookkeeping and the buffer parity of the steps the kernel ran
+        set_step(Q, net, run, t);
+        net->cur ^= 1;
+    }
+    return RP_OK;
+}
+
 // rp_forward / rp_forward_sharded: `comm` != nullptr adds the per-step all-gather of the source slices.
 int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     int rc = validate_net(net);
@@ -1253,6 +1533,7 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     const StreamCfg stream_cfg = choose_cfg(net);
     StepParams P = {};
     init_params(P, net, run);
+    if (!comm && vec4 && resident_ok(net, run)) return forward_resident(net, run, P, st);
 
     for (int t = 0; t < run->steps; ++t) {
         const int64_t t_abs = run->step0 + t;

@@ -1,0 +1,79 @@
+"""The resident step kernel (r05): all steps of an rp_forward call in ONE launch at launch-bound sizes (n <= 1024, n % 256 == 0) --
+W in registers, the source vector handed from wave to wave as tagged 8-byte granules -- against one launch per step
+(RECTIPY_AMD_RESIDENT=0): bit for bit, every model the per-step kernel integrates without population means, every run option."""
+import numpy as np
+import pytest
+import torch
+
+from rectipy_amd import _abi
+from rectipy_amd.engine import Population
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b, what):
+    a, b = a.detach().cpu().numpy(), b.detach().cpu().numpy()
+    eq = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
+    assert eq.all(), f"{what}: {np.count_nonzero(~eq)} of {a.size} differ, max abs {np.abs(a - b).max()}"
+
+
+def make(model, n, dev, seed=0):
+    gen = torch.Generator().manual_seed(seed + n)
+    u = lambda lo, hi: torch.rand(n, generator=gen) * (hi - lo) + lo
+    if model in ("li_tanh", "li_sigmoid"):
+        W = torch.randn(n, n, generator=gen) * 1.3 / n ** 0.5
+        par = dict(tau=u(0.5, 2.0), k=u(0.5, 1.5), eta=torch.randn(n, generator=gen) * 0.1)
+        if model == "li_sigmoid":
+            par.update(r_max=u(0.8, 1.2), s=u(0.5, 2.0), v0=torch.randn(n, generator=gen) * 0.2)
+        return Population(model, W, par, 1e-2, dev, v0=torch.randn(n, generator=gen) * 0.5)
+    W = torch.rand(n, n, generator=gen) * 2.0 / n
+    if model == "qif":
+        par = dict(tau=u(0.8, 1.2), k=u(0.5, 1.5), eta=u(0.5, 3.0), tau_s=u(0.5, 2.0))
+        return Population(model, W, par, 5e-3, dev, v0=torch.randn(n, generator=gen), theta=1.0, v_reset=-1.0)
+    if model == "lif":
+        par = dict(tau=u(0.4, 0.8), k=u(0.5, 1.5), eta=u(2.0, 5.0), tau_s=u(0.2, 0.6))
+        return Population(model, W, par, 5e-3, dev, v0=torch.rand(n, generator=gen), theta=1.0, v_reset=0.0)
+    raise AssertionError(model)
+
+
+@pytest.mark.parametrize("model,n", [("li_tanh", 256), ("li_tanh", 512), ("li_tanh", 768), ("li_tanh", 1024), ("li_sigmoid", 512),
+                                     ("qif", 512), ("qif", 1024), ("lif", 256)])
+def test_resident_launch_equals_a_launch_per_step(hip_device, monkeypatch, model, n):
+    T = 57
+    gen = torch.Generator().manual_seed(3)
+    x = (torch.randn(T, n, generator=gen) * 0.5 + (1.5 if model in ("qif", "lif") else 0.0)).to(hip_device)
+    got = []
+    for resident in ("1", "0"):
+        monkeypatch.setenv("RECTIPY_AMD_RESIDENT", resident)
+        pop = make(model, n, hip_device)
+        f32 = dict(dtype=torch.float32, device=hip_device)
+        traj, sv, ss = torch.zeros(T, n, **f32), torch.zeros(T, n, **f32), torch.zeros(T, n, **f32)
+        samples = torch.zeros(T, n, **f32)
+        # two calls (the second starts from the first's state and sampling bookkeeping), cutoff and a sampling stride
+        a = 23
+        kw = dict(out_var=_abi.RP_OUT_SOURCE, cutoff=5, sampling_steps=3, samples=samples)
+        i0 = pop.forward(a, x=x[:a], traj=traj[:a], save_v=sv[:a], save_src=ss[:a], step0=0, sample_idx=0, **kw)
+        pop.forward(T - a, x=x[a:], traj=traj[a:], save_v=sv[a:], save_src=ss[a:], step0=a, sample_idx=i0, **kw)
+        got.append(dict(traj=traj, save_v=sv, save_src=ss, samples=samples, acc=pop.acc.clone(), v=pop.v.clone(), src=pop.source.clone()))
+    for key in got[0]:
+        same(got[0][key], got[1][key], f"{model} n={n}: {key}")
+    if model in ("qif", "lif"):
+        assert float(got[0]["traj"].abs().max()) > 0   # (spikes happened: the synaptic variable moved)
+
+
+def test_broadcast_and_projected_inputs(hip_device, monkeypatch):
+    n, m, T = 512, 5, 40
+    gen = torch.Generator().manual_seed(8)
+    xb = torch.randn(T, 1, generator=gen).to(hip_device)
+    xm = torch.randn(T, m, generator=gen).to(hip_device)
+    w_in = torch.randn(n, m, generator=gen).to(hip_device)
+    for kw in (dict(x=xb), dict(x=xm, w_in=w_in)):
+        got = []
+        for resident in ("1", "0"):
+            monkeypatch.setenv("RECTIPY_AMD_RESIDENT", resident)
+            pop = make("li_tanh", n, hip_device)
+            traj = torch.zeros(T, n, device=hip_device)
+            pop.forward(T, traj=traj, out_var=_abi.RP_OUT_STATE0, **kw)
+            got.append((traj, pop.v.clone(), pop.source.clone()))
+        for u, v, name in zip(got[0], got[1], ("traj", "v", "source")):
+            same(u, v, f"{sorted(kw)}: {name}")
