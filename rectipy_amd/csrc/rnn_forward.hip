@@ -330,6 +330,8 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepParams P) {
 // five dependent trips through the fabric -- and lost against the launches: 4.95-6.0 us.)
 struct ResidentArgs {
     int steps, cur0;
+    int need_blocks, one_xcd;   // workgroups that take part; one_xcd: only workgroups on the XCD of the first arriver do (by ticket)
+    unsigned* ctl;              // [0] the XCD (+ 1) of the first workgroup to arrive, [1] tickets taken, [2] workgroups arrived
     float* src[2];
     unsigned long long* gran[2];
     int* fail;
@@ -410,7 +412,48 @@ template <int MODEL, int NC, int RW>
 __global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0, const ResidentArgs A) {
     static_assert(RW == 8 || RW == 16, "one or two stagger groups of eight rows per wave");
     const int lane = threadIdx.x & (RP_WAVE - 1);
-    const int gw = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);   // this wave's rows: [RW gw, RW gw + RW)
+    rp_gi32* const fail = (rp_gi32*)A.fail;
+    // Placement (speed only -- every shared word is an agent-scope access whatever the placement): with up to 8 workgroups the
+    // hand-off is 0.9 us per step faster when all of them sit on ONE XCD (scripts/probes/granule_probe.hip: n = 512: 1.29
+    // against 2.21 us per step with no arithmetic at all).  Eight times the workgroups are launched; the first to arrive
+    // names its XCD (HW_REG_XCC_ID), the workgroups on that XCD take tickets -- the ticket is the work index --, the others
+    // leave.  Nothing is written before the roster is complete: the workgroup that arrives last raises `fail` if the XCD
+    // got too few, the ticket holders see it at the gate and leave, and the host falls back to a launch per step.
+    __shared__ int block_s;
+    if (threadIdx.x == 0) {
+        int b = (int)blockIdx.x;
+        if (A.one_xcd) {
+            typedef __attribute__((address_space(1))) unsigned rp_gu32;
+            rp_gu32* const ctl = (rp_gu32*)A.ctl;
+            const unsigned xcc = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu) + 1u;
+            unsigned chosen = 0u;
+            __hip_atomic_compare_exchange_strong(ctl, &chosen, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (chosen == 0u) chosen = xcc;   // (this workgroup was the first)
+            b = chosen == xcc ? (int)__hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A.need_blocks;
+            const unsigned arrived = __hip_atomic_fetch_add(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            if (arrived == gridDim.x && __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)A.need_blocks)
+                __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b < A.need_blocks) {   // the gate: all tickets taken (or the launch given up)
+                for (unsigned spins = 0;; ++spins) {
+                    if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)A.need_blocks) break;
+                    if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {   // (1: the XCD got too few workgroups)
+                        b = A.need_blocks;
+                        break;
+                    }
+                    if (spins > A.spin_cap) {   // (2: a hard failure -- others may already be past the gate)
+                        __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        b = A.need_blocks;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+        block_s = b;
+    }
+    __syncthreads();
+    if (block_s >= A.need_blocks) return;
+    const int gw = block_s * kWavesPerBlock + (threadIdx.x >> 6);   // this wave's rows: [RW gw, RW gw + RW)
     const int row_w0 = gw * RW;
     StepParams P = P0;
     rp_f4 w[RW][NC];
@@ -422,7 +465,6 @@ __global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0,
     constexpr int kGroup = 64 / RW;                    // lanes that hold the same row total after the transposed butterfly
     const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
     const bool epi_lane = (lane & (kGroup - 1)) == 0;
-    rp_gi32* const fail = (rp_gi32*)A.fail;
     // the epilogue lane's own state and source value stay in registers from step to step
     float v_reg = 0.f, s_reg = 0.f;
     if (epi_lane) {
@@ -458,9 +500,10 @@ __global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0,
                 }
                 done = __all(ok);
                 if (!done) {
-                    if (spins > A.spin_cap || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        if (lane == 0) __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        return;   // (wave-uniform: every wave sees the flag at its next sweep and leaves)
+                    if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // (wave-uniform)
+                    if (spins > A.spin_cap) {
+                        if (lane == 0) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        return;   // (every wave sees the flag at its next sweep and leaves)
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -1409,18 +1452,22 @@ int launch_population_step(const rp_net* net, const StepParams& P, hipStream_t s
 }
 
 // ---- the resident launch (resident_kernel): eligibility and the call ------------------------------------------------------
+constexpr int resident_rows_per_wave(int n) { return (n >> 8) <= 2 ? 16 : 8; }
+
 template <int MODEL>
 void launch_resident_model(const StepParams& P, const ResidentArgs& A, hipStream_t st) {
     const int nc = P.n >> 8;
+    const dim3 grid(A.one_xcd ? 8 * A.need_blocks + 8 : A.need_blocks);
     switch (nc) {
-        case 1: hipLaunchKernelGGL((resident_kernel<MODEL, 1, 16>), dim3(P.n / 16 / kWavesPerBlock), dim3(kThreads), 0, st, P, A); break;
-        case 2: hipLaunchKernelGGL((resident_kernel<MODEL, 2, 16>), dim3(P.n / 16 / kWavesPerBlock), dim3(kThreads), 0, st, P, A); break;
-        case 3: hipLaunchKernelGGL((resident_kernel<MODEL, 3, 8>), dim3(P.n / 8 / kWavesPerBlock), dim3(kThreads), 0, st, P, A); break;
-        default: hipLaunchKernelGGL((resident_kernel<MODEL, 4, 8>), dim3(P.n / 8 / kWavesPerBlock), dim3(kThreads), 0, st, P, A); break;
+        case 1: hipLaunchKernelGGL((resident_kernel<MODEL, 1, 16>), grid, dim3(kThreads), 0, st, P, A); break;
+        case 2: hipLaunchKernelGGL((resident_kernel<MODEL, 2, 16>), grid, dim3(kThreads), 0, st, P, A); break;
+        case 3: hipLaunchKernelGGL((resident_kernel<MODEL, 3, 8>), grid, dim3(kThreads), 0, st, P, A); break;
+        default: hipLaunchKernelGGL((resident_kernel<MODEL, 4, 8>), grid, dim3(kThreads), 0, st, P, A); break;
     }
 }
 
 constexpr int kResidentMinSteps = 4;
+constexpr int kResidentGaveUp = 1;   // (internal: forward_resident changed nothing, the caller launches per step)
 bool resident_ok(const rp_net* net, const rp_run* run) {
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT"); e && e[0] == '0') return false;   // (read per call: tests compare both paths)
     if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP || net->model == RP_MODEL_INSTANT || net->model < 0 ||
@@ -1468,6 +1515,12 @@ int forward_resident(rp_net* net, rp_run* run, StepParams& P, hipStream_t st) {
     A.gran[0] = static_cast<unsigned long long*>(ws);
     A.gran[1] = A.gran[0] + n;
     A.fail = reinterpret_cast<int*>(A.gran[1] + n);
+    A.ctl = reinterpret_cast<unsigned*>(A.fail) + 4;
+    A.need_blocks = n / resident_rows_per_wave(n) / kWavesPerBlock;
+    A.one_xcd = A.need_blocks <= 8 ? 1 : 0;   // (measured: 24 or 32 workgroups on one XCD are slower than spread out)
+    if (const char* e = getenv("RECTIPY_AMD_RESIDENT_XCD"); e && e[0] == '0') A.one_xcd = 0;
+    const rp_net net0 = *net;     // (a launch that gives up at the gate has changed nothing: the caller then launches per step)
+    const rp_run run0 = *run;
     set_step(P, net, run, 0);   // (step 0's arguments -- the kernel forms every step's itself; the bookkeeping is advanced below)
     switch (net->model) {
         case RP_MODEL_LI_TANH: launch_resident_model<RP_MODEL_LI_TANH>(P, A, st); break;
@@ -1484,9 +1537,14 @@ int forward_resident(rp_net* net, rp_run* run, StepParams& P, hipStream_t st) {
     (void)hipFreeAsync(ws, st);
     if (launched != hipSuccess) RP_FAIL(RP_ERR_HIP, "resident step kernel: %s", hipGetErrorString(launched));
     if (rc != hipSuccess) RP_FAIL(RP_ERR_HIP, "resident step kernel: %s", hipGetErrorString(rc));
+    if (failed == 1) {   // given up at the gate, nothing written: one launch per step instead
+        *net = net0;
+        *run = run0;
+        return kResidentGaveUp;
+    }
     if (failed)
         RP_FAIL(RP_ERR_HIP, "the resident step kernel timed out waiting for a peer wave (its %d workgroups were never resident together: "
-                            "is another kernel holding the GPU?); RECTIPY_AMD_RESIDENT=0 selects one launch per step", n / 64);
+                            "is another kernel holding the GPU?); RECTIPY_AMD_RESIDENT=0 selects one launch per step", A.need_blocks);
     StepParams Q = P;
     net->cur ^= 1;
     for (int t = 1; t < run->steps; ++t) {   // the sampling bookkeeping and the buffer parity of the steps the kernel ran
@@ -1533,7 +1591,11 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     const StreamCfg stream_cfg = choose_cfg(net);
     StepParams P = {};
     init_params(P, net, run);
-    if (!comm && vec4 && resident_ok(net, run)) return forward_resident(net, run, P, st);
+    if (!comm && vec4 && resident_ok(net, run)) {
+        rc = forward_resident(net, run, P, st);
+        if (rc != kResidentGaveUp) return rc;
+        init_params(P, net, run);
+    }
 
     for (int t = 0; t < run->steps; ++t) {
         const int64_t t_abs = run->step0 + t;
