@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define RP_ABI_VERSION 18
+#define RP_ABI_VERSION 19
 #define RP_SPARSE_END 0x2000 /* blocked packed form: last entry of a lane's row segment */
 
 #define RP_OK 0
@@ -415,6 +415,15 @@ typedef struct rp_bwd {
 
 int rp_abi_version(void);
 const char* rp_last_error(void);
+
+/* (v19) At launch-bound sizes (dense W, no edges, rows == n, n % 256 == 0, n <= 1024, 4 steps or more) rp_forward and -- rate models,
+   transposed-copy sweep -- rp_rate_backward run ALL their steps in ONE launch (rectipy_amd/csrc/rp_resident.h; bit-identical
+   to a launch per step; RECTIPY_AMD_RESIDENT=0 in the environment selects the launches).  Such a launch is as asynchronous as the
+   launches it replaces; the one thing it can report only afterwards is a wave that timed out waiting for its peers (seconds: the
+   GPU never ran the launch's workgroups together).  The library's next rp_forward / rp_rate_backward call returns RP_ERR_HIP
+   then; a caller that has synchronised the stream asks here: RP_OK, or RP_ERR_HIP once per such launch (its results are not valid;
+   reference: the time loops of rectipy/network.py:542-601 and 1016-1048, which this replaces step for step). */
+int rp_async_status(void);
 
 /* sizeof the three argument structs as compiled (lets a binding verify its layout) */
 int rp_sizeof_net(void);

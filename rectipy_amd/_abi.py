@@ -5,7 +5,7 @@ struct sizes against the values the compiled library reports.
 """
 import ctypes as C
 
-RP_ABI_VERSION = 18
+RP_ABI_VERSION = 19
 RP_BATCH_VALU, RP_BATCH_MFMA, RP_BATCH_MFMA16, RP_BATCH_SLOTS = 0, 1, 2, 32
 RP_COMM_RCCL, RP_COMM_DIRECT = 0, 1
 
@@ -306,6 +306,7 @@ def declare(lib):
 
     sig("rp_abi_version", C.c_int, [])
     sig("rp_last_error", C.c_char_p, [])
+    sig("rp_async_status", C.c_int, [])
     sig("rp_device_check", C.c_int, [C.c_int])
     sig("rp_device_name", C.c_int, [C.c_int, C.c_char_p, C.c_int32])
     sig("rp_sizeof_net", C.c_int, [])
@@ -369,7 +370,7 @@ def declare(lib):
 
 
 EXPORTS = [
-    "rp_abi_version", "rp_last_error", "rp_device_check", "rp_device_name", "rp_sizeof_net", "rp_sizeof_run", "rp_sizeof_bwd",
+    "rp_abi_version", "rp_last_error", "rp_async_status", "rp_device_check", "rp_device_name", "rp_sizeof_net", "rp_sizeof_run", "rp_sizeof_bwd",
     "rp_sizeof_member", "rp_forward_coupled", "rp_sizeof_bwd_member", "rp_backward_coupled",
     "rp_refresh_source", "rp_forward", "rp_bwd_partial_rows", "rp_rate_backward", "rp_qif_backward", "rp_outer_accum",
     "rp_outer_accum_rect", "rp_outer_store_rect", "rp_bwd_shard_partial_rows", "rp_bwd_prepare", "rp_bwd_partial",

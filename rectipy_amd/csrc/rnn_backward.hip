@@ -24,6 +24,7 @@
 
 #include "rp_common.h"
 #include "rp_dot.h"
+#include "rp_resident.h"
 
 namespace {
 
@@ -264,17 +265,48 @@ __device__ __forceinline__ float chunk_sum(const BwdParams& P, int j) {
     return z;
 }
 
-// u_next = k * lam and the per-neuron parameter gradients that pair lambda_{t+1} with step t
-__device__ __forceinline__ void prep_step(const BwdParams& P, int j, float lam) {
-    P.u_next[j] = P.p[RP_P_K][j] * lam;
+// The per-neuron gradient sums of the rate sweep (tau, k, eta; the sigmoid's r_max, s, v0): the per-step kernels add into
+// memory step by step, the resident sweep keeps neuron j's sums in registers from the sweep's first step to its last -- the same
+// additions in the same order.
+struct RateAcc {
+    float eta, k, tau, act[3];
+};
+__device__ __forceinline__ RateAcc rate_acc_load(const BwdParams& P, int j) {
+    RateAcc G;
+    G.eta = P.grad_eta ? P.grad_eta[j] : 0.f;
+    G.k = P.grad_k ? P.grad_k[j] : 0.f;
+    G.tau = P.grad_tau ? P.grad_tau[j] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) G.act[q] = P.grad_act[q] ? P.grad_act[q][j] : 0.f;
+    return G;
+}
+__device__ __forceinline__ void rate_acc_store(const BwdParams& P, int j, const RateAcc& G) {
+    if (P.grad_eta) P.grad_eta[j] = G.eta;
+    if (P.grad_k) P.grad_k[j] = G.k;
+    if (P.grad_tau) P.grad_tau[j] = G.tau;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (P.grad_act[q]) P.grad_act[q][j] = G.act[q];
+}
+
+// u_next = k * lam and the per-neuron parameter gradients that pair lambda_{t+1} with step t; returns u_next[j]
+__device__ __forceinline__ float prep_core(const BwdParams& P, int j, float lam, RateAcc& G) {
+    const float u = P.p[RP_P_K][j] * lam;
+    P.u_next[j] = u;
     const float dl = P.dt * lam;
-    if (P.grad_eta) P.grad_eta[j] += dl;
-    if (P.grad_k) P.grad_k[j] += dl * P.acc_prev[j];
+    if (P.grad_eta) G.eta += dl;
+    if (P.grad_k) G.k += dl * P.acc_prev[j];
     if (P.grad_tau) {
         const float tau = P.p[RP_P_TAU][j];
-        P.grad_tau[j] += dl * (P.v_prev[j] / (tau * tau));
+        G.tau += dl * (P.v_prev[j] / (tau * tau));
     }
     if (P.gx_prev) P.gx_prev[j] = dl;
+    return u;
+}
+__device__ __forceinline__ void prep_step(const BwdParams& P, int j, float lam) {
+    RateAcc G = rate_acc_load(P, j);
+    (void)prep_core(P, j, lam, G);
+    rate_acc_store(P, j, G);
 }
 
 __global__ void prep_kernel(const BwdParams P) {
@@ -289,8 +321,9 @@ __global__ void chunk_sum_kernel(const BwdParams P, float* z_full) {
     z_full[c] = chunk_sum(P, c);
 }
 
-__device__ __forceinline__ void finalize_elem(const BwdParams& P, int j, float z) {
-    const float lam = P.lam[j];
+// `lam`: the adjoint state of neuron j before the step (the per-step kernels read it from memory, the resident sweep keeps it in a
+// register); returns the new one, *u_out: u_next[j] (0 at the sweep's last step)
+__device__ __forceinline__ float finalize_core(const BwdParams& P, int j, float z, float lam, float* u_out, RateAcc& G) {
     const float d = act_deriv(P, j, P.r_t[j]);
     const float g = P.g_t ? P.g_t[j] : 0.f;
     const float gv = (P.grad_var == RP_OUT_STATE0) ? g : g * d;
@@ -301,11 +334,19 @@ __device__ __forceinline__ void finalize_elem(const BwdParams& P, int j, float z
         // dL/dr_t = dt z (+ G_t);  dr/dr_max = r / r_max,  dr/ds = -(v0 - v) r (1 - r/r_max),  dr/dv0 = -act'(v)
         const float r = P.r_t[j], rmax = P.p[RP_P_RMAX][j];
         const float dr = P.dt * z + ((P.grad_var == RP_OUT_STATE0) ? 0.f : g);
-        if (P.grad_act[0]) P.grad_act[0][j] += dr * (r / rmax);
-        if (P.grad_act[1]) P.grad_act[1][j] += -(dr * ((P.p[RP_P_V0][j] - P.v_t[j]) * (r * (1.0f - r / rmax))));
-        if (P.grad_act[2]) P.grad_act[2][j] += -(dr * d);
+        if (P.grad_act[0]) G.act[0] += dr * (r / rmax);
+        if (P.grad_act[1]) G.act[1] += -(dr * ((P.p[RP_P_V0][j] - P.v_t[j]) * (r * (1.0f - r / rmax))));
+        if (P.grad_act[2]) G.act[2] += -(dr * d);
     }
-    if (P.u_next) prep_step(P, j, lam_new);
+    *u_out = P.u_next ? prep_core(P, j, lam_new, G) : 0.f;
+    return lam_new;
+}
+
+__device__ __forceinline__ void finalize_elem(const BwdParams& P, int j, float z) {
+    float u;
+    RateAcc G = rate_acc_load(P, j);
+    (void)finalize_core(P, j, z, P.lam[j], &u, G);
+    rate_acc_store(P, j, G);
 }
 
 __global__ void finalize_kernel(const BwdParams P) {
@@ -543,6 +584,96 @@ __global__ __launch_bounds__(kThreads) void adj_rowdot_kernel(const BwdParams P,
     }
 }
 
+// ---- the rate models' adjoint sweep in ONE launch at launch-bound sizes (r05; the machinery: rp_resident.h) --------------------
+// The transposed-copy sweep (adj_rowdot_kernel: one launch per adjoint step) with the rows of W^T in registers for the whole
+// sweep and u_{t+1} = k lam handed from wave to wave as tagged granules; the element-wise update is finalize_core, its lane keeps
+// lam in a register.  Bit-identical to the launches.
+struct AdjResidentArgs {
+    rp_resident_ctl C;
+    int steps;
+    float* u_traj;
+    const float* traj_v;
+    const float* traj_r;
+    const float* traj_acc;
+    int64_t ld;
+    const float* grad_out;
+    int64_t ldg;
+    float* grad_x;
+    int64_t ldgx;
+};
+
+template <int NC, int RW>
+__global__ __launch_bounds__(kThreads) void resident_adj_kernel(const BwdParams P0, const AdjResidentArgs A) {
+    static_assert(kThreads == 64 * kResidentWaves, "rp_resident.h counts four waves per workgroup");
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int block = rp_resident_join(A.C);
+    if (block < 0) return;
+    const int row_w0 = (block * kResidentWaves + (threadIdx.x >> 6)) * RW;
+    BwdParams P = P0;
+    rp_f4 w[RW][NC];
+    rp_resident_load_rows<NC, RW>(w, P.W, P.ldw, row_w0, lane);   // (P.W: the transposed copy)
+    const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
+    const bool epi_lane = (lane & (64 / RW - 1)) == 0;
+    float lam_reg = epi_lane ? P0.lam[my_row] : 0.f;
+    RateAcc G = {};
+    if (epi_lane) G = rate_acc_load(P0, my_row);   // (what the prep launch in front left there)
+    const int T = A.steps;
+    for (int s = 0; s < T; ++s) {
+        const int t = T - 1 - s;
+        P.t = t;
+        P.u = A.u_traj + (int64_t)t * A.ld;
+        P.v_t = A.traj_v + (int64_t)t * A.ld;
+        P.r_t = A.traj_r + (int64_t)t * A.ld;
+        P.g_t = A.grad_out ? A.grad_out + (int64_t)t * A.ldg : nullptr;
+        if (t > 0) {
+            P.u_next = A.u_traj + (int64_t)(t - 1) * A.ld;
+            P.v_prev = A.traj_v + (int64_t)(t - 1) * A.ld;
+            P.acc_prev = A.traj_acc ? A.traj_acc + (int64_t)(t - 1) * A.ld : nullptr;
+            P.gx_prev = A.grad_x ? A.grad_x + (int64_t)(t - 1) * A.ldgx : nullptr;
+        } else {
+            P.u_next = nullptr;
+        }
+        rp_f4 r[NC];
+        if (s == 0) {   // u_T: written by the prep launch in front of this one
+#pragma unroll
+            for (int m = 0; m < NC; ++m) r[m] = rp_ld4(P.u + 256 * m + 4 * lane);
+        } else if (!rp_resident_sweep<NC>(A.C, (s - 1) & 1, (unsigned)s, r, lane)) {
+            return;
+        }
+        const float z = rp_resident_dots<NC, RW>(w, r, row_w0, lane);
+        if (epi_lane) {
+            float u;
+            lam_reg = finalize_core(P, my_row, z, lam_reg, &u, G);
+            if (t > 0) rp_resident_publish(A.C, s & 1, my_row, (unsigned)(s + 1), u);
+        }
+    }
+    if (epi_lane) rate_acc_store(P0, my_row, G);
+}
+
+int launch_resident_adj(const BwdParams& P, const rp_bwd* b, hipStream_t st) {
+    AdjResidentArgs A = {};
+    A.steps = b->steps;
+    A.u_traj = b->u_traj;
+    A.traj_v = b->traj_v;
+    A.traj_r = b->traj_r;
+    A.traj_acc = b->traj_acc;
+    A.ld = b->ld;
+    A.grad_out = b->grad_out;
+    A.ldg = b->ldg;
+    A.grad_x = b->grad_x;
+    A.ldgx = b->ldgx;
+    void* ws = nullptr;
+    if (rp_resident_begin(P.n, st, &A.C, &ws) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident adjoint sweep: no stream-ordered scratch");
+    const dim3 grid(rp_resident_grid(A.C));
+    switch (P.n >> 8) {
+        case 1: hipLaunchKernelGGL((resident_adj_kernel<1, 16>), grid, dim3(kThreads), 0, st, P, A); break;
+        case 2: hipLaunchKernelGGL((resident_adj_kernel<2, 16>), grid, dim3(kThreads), 0, st, P, A); break;
+        case 3: hipLaunchKernelGGL((resident_adj_kernel<3, 8>), grid, dim3(kThreads), 0, st, P, A); break;
+        default: hipLaunchKernelGGL((resident_adj_kernel<4, 8>), grid, dim3(kThreads), 0, st, P, A); break;
+    }
+    return rp_resident_end(A.C, ws, st, "the resident adjoint sweep");
+}
+
 // Launch shapes follow the forward's small-n choices (rnn_forward.hip launch_step): 1 row x 4 chunks per wave up to
 // n = 2048, 2 rows x 2 chunks above.
 template <bool SPIKING>
@@ -741,6 +872,7 @@ int32_t rp_bwd_partial_rows(int32_t n) {
 }
 
 int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
+    if (const int prc = rp_resident_poll(); prc != RP_OK) return prc;
     if (!net || !b) RP_FAIL(RP_ERR_ARG, "net/bwd is null");
     if (net->model != RP_MODEL_LI_TANH && net->model != RP_MODEL_LI_SIGMOID)
         RP_FAIL(RP_ERR_ARG, "rp_rate_backward supports the leaky-integrator models only (model=%d)", net->model);
@@ -815,6 +947,10 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     if (use_wt) launch_transpose(net, b, st);
     set_prep(T - 1);
     hipLaunchKernelGGL(prep_kernel, dim3(eblocks), dim3(256), 0, st, P);
+    if (use_wt && vec4_t && rp_resident_enabled() && n % 256 == 0 && n <= 1024 && T >= 4 && b->ld % 4 == 0 &&
+        !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u)) {
+        return launch_resident_adj(P, b, st);   // the whole sweep in one launch
+    }
     for (int t = T - 1; t >= 0; --t) {
         P.t = t;
         P.u = b->u_traj + (int64_t)t * b->ld;

@@ -27,6 +27,7 @@
 
 #include "rp_common.h"
 #include "rp_dot.h"
+#include "rp_resident.h"
 
 thread_local char rp_err_buf[512] = "";
 
@@ -317,25 +318,17 @@ __global__ __launch_bounds__(kThreads) void step_kernel(const StepParams P) {
     step_body<MODEL, R, U, VEC4, NT>(P);
 }
 
-// ---- launch-bound sizes: ALL steps of a call in ONE launch (r05) ------------------------------------------------------------
+// ---- launch-bound sizes: ALL steps of a call in ONE launch (r05; the machinery: rp_resident.h) --------------------------------
 // At n <= 1024 a step is bounded by the dependent-launch interval of the stream (about 4 us; W is 1 MiB at n = 512), not by
-// bytes.  Here every wave keeps its rows of W in REGISTERS for the whole call and the waves hand the source vector around
-// themselves: at the end of step t the lane that ran row i's epilogue stores the 8-byte granule {tag = t + 1, r_i} (one
-// write-through store, agent scope), and at the start of step t + 1 every wave sweeps the n granules of that parity until all
-// tags read t + 1 -- the data is its own flag (no barrier, no separate flag, no fence: one round trip per step; two granule
-// buffers alternate, so a wave can only overwrite a granule once every wave has consumed it).  The row dot products visit
-// the chunks in the contract's order and reduce through the same butterflies (rp_dot.h), the epilogue is the per-step
-// kernel's: bit-identical to a launch per step.  Every sweep is bounded: a wave that times out raises `fail`, every wave that
-// sees it leaves, the host returns an error.  (r04 tried a grid barrier per step -- arrive, poll, then agent-scope loads: four to
-// five dependent trips through the fabric -- and lost against the launches: 4.95-6.0 us.)
+// bytes.  Every wave keeps its rows of W in registers, the source vector goes from wave to wave as tagged granules, the row dot
+// products visit the chunks in the contract's order and reduce through the same butterflies (rp_dot.h), the epilogue is the
+// per-step kernel's (its lane keeps the neuron's state and source value in registers and fetches the step's input while it
+// waits for the vector): bit-identical to a launch per step.  (r04 tried a grid barrier per step -- arrive, poll, then
+// agent-scope loads: four to five dependent trips through the fabric -- and lost against the launches: 4.95-6.0 us.)
 struct ResidentArgs {
+    rp_resident_ctl C;
     int steps, cur0;
-    int need_blocks, one_xcd;   // workgroups that take part; one_xcd: only workgroups on the XCD of the first arriver do (by ticket)
-    unsigned* ctl;              // [0] the XCD (+ 1) of the first workgroup to arrive, [1] tickets taken, [2] workgroups arrived
     float* src[2];
-    unsigned long long* gran[2];
-    int* fail;
-    unsigned spin_cap;
     const float* x;
     int64_t ldx;
     float* traj;
@@ -352,9 +345,6 @@ struct ResidentArgs {
     int64_t ldsamples;
     float* rec[RP_MAX_STATE];
 };
-
-typedef __attribute__((address_space(1))) unsigned long long rp_gu64;
-typedef __attribute__((address_space(1))) int rp_gi32;
 
 // set_step on the device (the same bookkeeping, step by step)
 __device__ __forceinline__ void resident_set_step(StepParams& P, const ResidentArgs& A, int t, int& acc_count, int& sample_idx) {
@@ -393,78 +383,19 @@ __device__ __forceinline__ void resident_set_step(StepParams& P, const ResidentA
     }
 }
 
-// eight rows (one stagger group: the same start chunk M0) against the NC chunks of the source vector, in the contract's order
-template <int NC, int M0>
-__device__ __forceinline__ void resident_dot8(const rp_f4 (*w)[NC], const rp_f4 (&r)[NC], float* rs) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        rp_f4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int m = (M0 + i) % NC;
-            a = rp_fma4(w[j][m], r[m], a);
-        }
-        rs[j] = rp_lane_sum4(a);
-    }
-}
-
 template <int MODEL, int NC, int RW>
 __global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0, const ResidentArgs A) {
-    static_assert(RW == 8 || RW == 16, "one or two stagger groups of eight rows per wave");
+    static_assert(kWavesPerBlock == kResidentWaves, "rp_resident.h counts four waves per workgroup");
     const int lane = threadIdx.x & (RP_WAVE - 1);
-    rp_gi32* const fail = (rp_gi32*)A.fail;
-    // Placement (speed only -- every shared word is an agent-scope access whatever the placement): with up to 8 workgroups the
-    // hand-off is 0.9 us per step faster when all of them sit on ONE XCD (scripts/probes/granule_probe.hip: n = 512: 1.29
-    // against 2.21 us per step with no arithmetic at all).  Eight times the workgroups are launched; the first to arrive
-    // names its XCD (HW_REG_XCC_ID), the workgroups on that XCD take tickets -- the ticket is the work index --, the others
-    // leave.  Nothing is written before the roster is complete: the workgroup that arrives last raises `fail` if the XCD
-    // got too few, the ticket holders see it at the gate and leave, and the host falls back to a launch per step.
-    __shared__ int block_s;
-    if (threadIdx.x == 0) {
-        int b = (int)blockIdx.x;
-        if (A.one_xcd) {
-            typedef __attribute__((address_space(1))) unsigned rp_gu32;
-            rp_gu32* const ctl = (rp_gu32*)A.ctl;
-            const unsigned xcc = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu) + 1u;
-            unsigned chosen = 0u;
-            __hip_atomic_compare_exchange_strong(ctl, &chosen, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (chosen == 0u) chosen = xcc;   // (this workgroup was the first)
-            b = chosen == xcc ? (int)__hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : A.need_blocks;
-            const unsigned arrived = __hip_atomic_fetch_add(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-            if (arrived == gridDim.x && __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)A.need_blocks)
-                __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (b < A.need_blocks) {   // the gate: all tickets taken (or the launch given up)
-                for (unsigned spins = 0;; ++spins) {
-                    if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)A.need_blocks) break;
-                    if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {   // (1: the XCD got too few workgroups)
-                        b = A.need_blocks;
-                        break;
-                    }
-                    if (spins > A.spin_cap) {   // (2: a hard failure -- others may already be past the gate)
-                        __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        b = A.need_blocks;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-        }
-        block_s = b;
-    }
-    __syncthreads();
-    if (block_s >= A.need_blocks) return;
-    const int gw = block_s * kWavesPerBlock + (threadIdx.x >> 6);   // this wave's rows: [RW gw, RW gw + RW)
-    const int row_w0 = gw * RW;
+    const int block = rp_resident_join(A.C);
+    if (block < 0) return;
+    const int row_w0 = (block * kWavesPerBlock + (threadIdx.x >> 6)) * RW;   // this wave's rows: [row_w0, row_w0 + RW)
     StepParams P = P0;
     rp_f4 w[RW][NC];
-#pragma unroll
-    for (int j = 0; j < RW; ++j)
-#pragma unroll
-        for (int m = 0; m < NC; ++m) w[j][m] = rp_ld4(P.W + (int64_t)(row_w0 + j) * P.ldw + 256 * m + 4 * lane);
+    rp_resident_load_rows<NC, RW>(w, P.W, P.ldw, row_w0, lane);
     int acc_count = A.acc_count0, sample_idx = A.sample_idx0;
-    constexpr int kGroup = 64 / RW;                    // lanes that hold the same row total after the transposed butterfly
     const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
-    const bool epi_lane = (lane & (kGroup - 1)) == 0;
+    const bool epi_lane = (lane & (64 / RW - 1)) == 0;   // (the lanes of a group hold the same row total after the butterfly)
     // the epilogue lane's own state and source value stay in registers from step to step
     float v_reg = 0.f, s_reg = 0.f;
     if (epi_lane) {
@@ -479,59 +410,15 @@ __global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0,
         if (t == 0) {
 #pragma unroll
             for (int m = 0; m < NC; ++m) r[m] = rp_ld4(P.src_cur + 256 * m + 4 * lane);
-        } else {
-            // the granules of step t - 1 (tag t): re-read until every tag matches
-            const rp_gu64* g = (const rp_gu64*)A.gran[(t - 1) & 1] + 4 * lane;
-            const unsigned want = (unsigned)t;
-            bool done = false;
-            for (unsigned spins = 0; !done; ++spins) {
-                bool ok = true;
-#pragma unroll
-                for (int m = 0; m < NC; ++m) {
-                    unsigned long long q[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) q[c] = __hip_atomic_load(g + 256 * m + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) ok = ok && (unsigned)(q[c] >> 32) == want;
-                    r[m].x = __uint_as_float((unsigned)q[0]);
-                    r[m].y = __uint_as_float((unsigned)q[1]);
-                    r[m].z = __uint_as_float((unsigned)q[2]);
-                    r[m].w = __uint_as_float((unsigned)q[3]);
-                }
-                done = __all(ok);
-                if (!done) {
-                    if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;   // (wave-uniform)
-                    if (spins > A.spin_cap) {
-                        if (lane == 0) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        return;   // (every wave sees the flag at its next sweep and leaves)
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
+        } else if (!rp_resident_sweep<NC>(A.C, (t - 1) & 1, (unsigned)t, r, lane)) {
+            return;
         }
-        float rs[RW];
-#pragma unroll
-        for (int h = 0; h < RW / 8; ++h) {
-            const int m0 = (int)(((unsigned)((P.row0 + row_w0 + 8 * h) >> 3) * kStagger) % (unsigned)NC);   // wave-uniform
-            if constexpr (NC == 1) {
-                resident_dot8<NC, 0>(w + 8 * h, r, rs + 8 * h);
-            } else {
-                switch (m0) {
-                    case 0: resident_dot8<NC, 0>(w + 8 * h, r, rs + 8 * h); break;
-                    case 1: resident_dot8<NC, 1>(w + 8 * h, r, rs + 8 * h); break;
-                    case 2: resident_dot8<NC, 2 % NC>(w + 8 * h, r, rs + 8 * h); break;
-                    default: resident_dot8<NC, 3 % NC>(w + 8 * h, r, rs + 8 * h); break;
-                }
-            }
-        }
-        const float total = rp_rows_allreduce<RW>(rs, lane);
+        const float total = rp_resident_dots<NC, RW>(w, r, P.row0 + row_w0, lane);
         if (epi_lane) {
             float v_new;
             s_reg = epilogue_core<MODEL>(P, my_row, total, 0.f, I_x, v_reg, s_reg, &v_new);
             v_reg = v_new;
-            if (t + 1 < A.steps)
-                __hip_atomic_store((rp_gu64*)A.gran[t & 1] + my_row, ((unsigned long long)(unsigned)(t + 1) << 32) | __float_as_uint(s_reg),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t + 1 < A.steps) rp_resident_publish(A.C, t & 1, my_row, (unsigned)(t + 1), s_reg);
         }
     }
 }
@@ -1218,6 +1105,7 @@ void launch_step_edges_model(int model, const StepParams& P, hipStream_t st, boo
 extern "C" {
 
 int rp_abi_version(void) { return RP_ABI_VERSION; }
+int rp_async_status(void) { return rp_resident_poll(); }
 
 const char* rp_last_error(void) { return rp_err_buf; }
 
@@ -1452,13 +1340,10 @@ int launch_population_step(const rp_net* net, const StepParams& P, hipStream_t s
 }
 
 // ---- the resident launch (resident_kernel): eligibility and the call ------------------------------------------------------
-constexpr int resident_rows_per_wave(int n) { return (n >> 8) <= 2 ? 16 : 8; }
-
 template <int MODEL>
 void launch_resident_model(const StepParams& P, const ResidentArgs& A, hipStream_t st) {
-    const int nc = P.n >> 8;
-    const dim3 grid(A.one_xcd ? 8 * A.need_blocks + 8 : A.need_blocks);
-    switch (nc) {
+    const dim3 grid(rp_resident_grid(A.C));
+    switch (P.n >> 8) {
         case 1: hipLaunchKernelGGL((resident_kernel<MODEL, 1, 16>), grid, dim3(kThreads), 0, st, P, A); break;
         case 2: hipLaunchKernelGGL((resident_kernel<MODEL, 2, 16>), grid, dim3(kThreads), 0, st, P, A); break;
         case 3: hipLaunchKernelGGL((resident_kernel<MODEL, 3, 8>), grid, dim3(kThreads), 0, st, P, A); break;
@@ -1467,9 +1352,8 @@ void launch_resident_model(const StepParams& P, const ResidentArgs& A, hipStream
 }
 
 constexpr int kResidentMinSteps = 4;
-constexpr int kResidentGaveUp = 1;   // (internal: forward_resident changed nothing, the caller launches per step)
 bool resident_ok(const rp_net* net, const rp_run* run) {
-    if (const char* e = getenv("RECTIPY_AMD_RESIDENT"); e && e[0] == '0') return false;   // (read per call: tests compare both paths)
+    if (!rp_resident_enabled()) return false;
     if (net->model == RP_MODEL_IKU || net->model == RP_MODEL_IK_BIEXP || net->model == RP_MODEL_INSTANT || net->model < 0 ||
         net->model > RP_MODEL_IK_BIEXP)
         return false;
@@ -1479,13 +1363,11 @@ bool resident_ok(const rp_net* net, const rp_run* run) {
 }
 
 int forward_resident(rp_net* net, rp_run* run, StepParams& P, hipStream_t st) {
-    const int n = net->n;
     ResidentArgs A = {};
     A.steps = run->steps;
     A.cur0 = net->cur;
     A.src[0] = net->src[0];
     A.src[1] = net->src[1];
-    A.spin_cap = 1u << 22;   // polls of about a microsecond each: seconds -- only a GPU that never runs all waves together gets there
     A.x = run->x;
     A.ldx = run->ldx;
     A.traj = run->traj;
@@ -1507,20 +1389,8 @@ int forward_resident(rp_net* net, rp_run* run, StepParams& P, hipStream_t st) {
     A.has_acc = run->acc ? 1 : 0;
     A.samples = run->samples;
     A.ldsamples = run->ldsamples;
-    // granules [2][n] and the failure word: stream-ordered scratch, zeroed (a tag is never 0)
-    const size_t bytes = (size_t)2 * n * sizeof(unsigned long long) + 64;
     void* ws = nullptr;
-    RP_HIP_CHECK(hipMallocAsync(&ws, bytes, st));
-    RP_HIP_CHECK(hipMemsetAsync(ws, 0, bytes, st));
-    A.gran[0] = static_cast<unsigned long long*>(ws);
-    A.gran[1] = A.gran[0] + n;
-    A.fail = reinterpret_cast<int*>(A.gran[1] + n);
-    A.ctl = reinterpret_cast<unsigned*>(A.fail) + 4;
-    A.need_blocks = n / resident_rows_per_wave(n) / kWavesPerBlock;
-    A.one_xcd = A.need_blocks <= 8 ? 1 : 0;   // (measured: 24 or 32 workgroups on one XCD are slower than spread out)
-    if (const char* e = getenv("RECTIPY_AMD_RESIDENT_XCD"); e && e[0] == '0') A.one_xcd = 0;
-    const rp_net net0 = *net;     // (a launch that gives up at the gate has changed nothing: the caller then launches per step)
-    const rp_run run0 = *run;
+    if (rp_resident_begin(net->n, st, &A.C, &ws) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident step kernel: no stream-ordered scratch");
     set_step(P, net, run, 0);   // (step 0's arguments -- the kernel forms every step's itself; the bookkeeping is advanced below)
     switch (net->model) {
         case RP_MODEL_LI_TANH: launch_resident_model<RP_MODEL_LI_TANH>(P, A, st); break;
@@ -1530,21 +1400,8 @@ int forward_resident(rp_net* net, rp_run* run, StepParams& P, hipStream_t st) {
         case RP_MODEL_LIF: launch_resident_model<RP_MODEL_LIF>(P, A, st); break;
         default: launch_resident_model<RP_MODEL_IK>(P, A, st); break;
     }
-    const hipError_t launched = hipGetLastError();
-    int failed = 0;
-    hipError_t rc = hipMemcpyAsync(&failed, A.fail, sizeof(int), hipMemcpyDeviceToHost, st);
-    if (rc == hipSuccess) rc = hipStreamSynchronize(st);
-    (void)hipFreeAsync(ws, st);
-    if (launched != hipSuccess) RP_FAIL(RP_ERR_HIP, "resident step kernel: %s", hipGetErrorString(launched));
-    if (rc != hipSuccess) RP_FAIL(RP_ERR_HIP, "resident step kernel: %s", hipGetErrorString(rc));
-    if (failed == 1) {   // given up at the gate, nothing written: one launch per step instead
-        *net = net0;
-        *run = run0;
-        return kResidentGaveUp;
-    }
-    if (failed)
-        RP_FAIL(RP_ERR_HIP, "the resident step kernel timed out waiting for a peer wave (its %d workgroups were never resident together: "
-                            "is another kernel holding the GPU?); RECTIPY_AMD_RESIDENT=0 selects one launch per step", A.need_blocks);
+    const int rc = rp_resident_end(A.C, ws, st, "the resident step kernel");
+    if (rc != RP_OK) return rc;
     StepParams Q = P;
     net->cur ^= 1;
     for (int t = 1; t < run->steps; ++t) {   // the sampling bookkeeping and the buffer parity of the steps the kernel ran
@@ -1556,7 +1413,9 @@ int forward_resident(rp_net* net, rp_run* run, StepParams& P, hipStream_t st) {
 
 // rp_forward / rp_forward_sharded: `comm` != nullptr adds the per-step all-gather of the source slices.
 int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
-    int rc = validate_net(net);
+    int rc = rp_resident_poll();
+    if (rc != RP_OK) return rc;
+    rc = validate_net(net);
     if (rc != RP_OK) return rc;
     if (!run) RP_FAIL(RP_ERR_ARG, "run is null");
     const bool direct = comm && comm->mode == RP_COMM_DIRECT;
@@ -1591,11 +1450,7 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     const StreamCfg stream_cfg = choose_cfg(net);
     StepParams P = {};
     init_params(P, net, run);
-    if (!comm && vec4 && resident_ok(net, run)) {
-        rc = forward_resident(net, run, P, st);
-        if (rc != kResidentGaveUp) return rc;
-        init_params(P, net, run);
-    }
+    if (!comm && vec4 && resident_ok(net, run)) return forward_resident(net, run, P, st);
 
     for (int t = 0; t < run->steps; ++t) {
         const int64_t t_abs = run->step0 + t;

@@ -1,0 +1,226 @@
+// rp_resident.h -- the machinery of the resident multi-step kernels (launch-bound sizes: n <= 1024, n % 256 == 0): the forward
+// step (rnn_forward.hip: resident_kernel) and the adjoint step of the rate models (rnn_backward.hip: resident_adj_kernel).
+//
+// Every wave keeps RW rows of the matrix in REGISTERS for the whole call; between steps the waves hand the vector the rows are
+// multiplied with around themselves: the lane that finished element i stores ONE 8-byte granule {tag = step + 1, value}
+// (agent scope, write-through), and every wave sweeps the n granules of that parity until all tags match -- the data is its
+// own flag: no barrier, no separate flag, no fence; two granule buffers alternate, so a granule is only overwritten once every
+// wave has consumed it.  Placement is for speed only (every shared word is an agent-scope access wherever the workgroups
+// sit): with up to 8 workgroups the hand-off is 0.9 us per step faster when all of them are on ONE XCD
+// (scripts/probes/granule_probe.hip: n = 512, no arithmetic: 1.29 against 2.21 us per step; 24 or 32 workgroups on one XCD
+// are slower than spread out).  Then eight times the workgroups are launched; the first to arrive names its XCD
+// (HW_REG_XCC_ID), the workgroups on that XCD take tickets -- the ticket is the work index -- and count themselves arrived; the
+// others count themselves arrived and wait: they leave once all tickets are gone, or take what is left once EVERY workgroup
+// has arrived (the XCD got too few: the roster completes anyway, a little slower per step).  Nothing is written before the
+// roster is complete.  Every spin is bounded: a wave that waited for seconds (the GPU never ran all workgroups together) raises
+// `fail`, every wave that sees it leaves; the host learns of it without synchronising -- the word is copied to pinned memory
+// behind the launch and looked at by the library's next calls (rp_resident_poll) and by rp_async_status.
+#pragma once
+
+#include <atomic>
+
+#include "rp_common.h"
+#include "rp_dot.h"
+
+struct rp_resident_ctl {
+    unsigned long long* gran[2];  // [n] granules per parity
+    int* fail;
+    unsigned* ctl;                // [0] the XCD (+ 1) of the first workgroup to arrive, [1] tickets taken, [2] workgroups arrived
+    int need_blocks, one_xcd;
+    unsigned spin_cap;
+};
+
+typedef __attribute__((address_space(1))) unsigned long long rp_gu64;
+typedef __attribute__((address_space(1))) unsigned rp_gu32;
+typedef __attribute__((address_space(1))) int rp_gi32;
+
+constexpr int kResidentWaves = 4;                     // waves per workgroup
+constexpr int rp_resident_rows_per_wave(int n) { return (n >> 8) <= 2 ? 16 : 8; }
+
+// the work index of this workgroup, or -1 (it leaves).  Ends with the workgroup's barrier.
+__device__ __forceinline__ int rp_resident_join(const rp_resident_ctl& C) {
+    __shared__ int block_s;
+    if (threadIdx.x == 0) {
+        int b = (int)blockIdx.x;
+        if (C.one_xcd) {
+            rp_gu32* const ctl = (rp_gu32*)C.ctl;
+            rp_gi32* const fail = (rp_gi32*)C.fail;
+            const unsigned need = (unsigned)C.need_blocks;
+            const unsigned xcc = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu) + 1u;
+            unsigned chosen = 0u;
+            __hip_atomic_compare_exchange_strong(ctl, &chosen, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (chosen == 0u) chosen = xcc;   // (this workgroup was the first)
+            bool take = chosen == xcc;
+            if (take) b = (int)__hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ticket, THEN arrival
+            __hip_atomic_fetch_add(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!take) {   // another XCD: leave when the roster is complete, step in when everyone is here and it is not
+                b = C.need_blocks;
+                for (unsigned spins = 0;; ++spins) {
+                    if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+                    if (__hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) {
+                        b = (int)__hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    if (spins > C.spin_cap || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (b < C.need_blocks) {   // the gate: all tickets taken
+                for (unsigned spins = 0;; ++spins) {
+                    if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
+                    if (spins > C.spin_cap || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        b = C.need_blocks;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
+        block_s = b;
+    }
+    __syncthreads();
+    return block_s < C.need_blocks ? block_s : -1;
+}
+
+// the n = 256 NC values tagged `want` in the lane layout of the row dots (lane l: columns 256 m + 4 l .. + 3); false: give up
+template <int NC>
+__device__ __forceinline__ bool rp_resident_sweep(const rp_resident_ctl& C, int parity, unsigned want, rp_f4 (&r)[NC], int lane) {
+    const rp_gu64* g = (const rp_gu64*)C.gran[parity] + 4 * lane;
+    rp_gi32* const fail = (rp_gi32*)C.fail;
+    for (unsigned spins = 0;; ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+            unsigned long long q[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) q[c] = __hip_atomic_load(g + 256 * m + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ok = ok && (unsigned)(q[c] >> 32) == want;
+            r[m].x = __uint_as_float((unsigned)q[0]);
+            r[m].y = __uint_as_float((unsigned)q[1]);
+            r[m].z = __uint_as_float((unsigned)q[2]);
+            r[m].w = __uint_as_float((unsigned)q[3]);
+        }
+        if (__all(ok)) return true;
+        if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;   // (wave-uniform)
+        if (spins > C.spin_cap) {
+            if (lane == 0) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;   // (every wave sees the flag at its next sweep and leaves)
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+__device__ __forceinline__ void rp_resident_publish(const rp_resident_ctl& C, int parity, int row, unsigned tag, float value) {
+    __hip_atomic_store((rp_gu64*)C.gran[parity] + row, ((unsigned long long)tag << 32) | __float_as_uint(value), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// eight rows (one stagger group: the same start chunk M0) against the NC chunks of the vector, in the contract's order (rp_dot.h)
+template <int NC, int M0>
+__device__ __forceinline__ void rp_resident_dot8(const rp_f4 (*w)[NC], const rp_f4 (&r)[NC], float* rs) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        rp_f4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int m = (M0 + i) % NC;
+            a = rp_fma4(w[j][m], r[m], a);
+        }
+        rs[j] = rp_lane_sum4(a);
+    }
+}
+
+template <int NC, int RW>
+__device__ __forceinline__ void rp_resident_load_rows(rp_f4 (&w)[RW][NC], const float* W, int64_t ldw, int row_w0, int lane) {
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+        for (int m = 0; m < NC; ++m) w[j][m] = rp_ld4(W + (int64_t)(row_w0 + j) * ldw + 256 * m + 4 * lane);
+}
+
+// the totals of the wave's RW rows: afterwards lane l holds the total of row rp_rows_allreduce_row<RW>(l) of the wave
+template <int NC, int RW>
+__device__ __forceinline__ float rp_resident_dots(const rp_f4 (&w)[RW][NC], const rp_f4 (&r)[NC], int global_row_w0, int lane) {
+    static_assert(RW == 8 || RW == 16, "one or two stagger groups of eight rows per wave");
+    float rs[RW];
+#pragma unroll
+    for (int h = 0; h < RW / 8; ++h) {
+        const int m0 = (int)(((unsigned)((global_row_w0 + 8 * h) >> 3) * kStagger) % (unsigned)NC);   // wave-uniform
+        if constexpr (NC == 1) {
+            rp_resident_dot8<NC, 0>(w + 8 * h, r, rs + 8 * h);
+        } else {
+            switch (m0) {
+                case 0: rp_resident_dot8<NC, 0>(w + 8 * h, r, rs + 8 * h); break;
+                case 1: rp_resident_dot8<NC, 1>(w + 8 * h, r, rs + 8 * h); break;
+                case 2: rp_resident_dot8<NC, 2 % NC>(w + 8 * h, r, rs + 8 * h); break;
+                default: rp_resident_dot8<NC, 3 % NC>(w + 8 * h, r, rs + 8 * h); break;
+            }
+        }
+    }
+    return rp_rows_allreduce<RW>(rs, lane);
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------
+// stream-ordered scratch (granules, failure word, roster), zeroed: a tag is never 0
+inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** ws) {
+    const size_t bytes = (size_t)2 * n * sizeof(unsigned long long) + 64;
+    *ws = nullptr;
+    if (hipMallocAsync(ws, bytes, st) != hipSuccess) return RP_ERR_HIP;
+    if (hipMemsetAsync(*ws, 0, bytes, st) != hipSuccess) return RP_ERR_HIP;
+    C->gran[0] = static_cast<unsigned long long*>(*ws);
+    C->gran[1] = C->gran[0] + n;
+    C->fail = reinterpret_cast<int*>(C->gran[1] + n);
+    C->ctl = reinterpret_cast<unsigned*>(C->fail) + 4;
+    C->need_blocks = n / rp_resident_rows_per_wave(n) / kResidentWaves;
+    C->one_xcd = C->need_blocks <= 8 ? 1 : 0;
+    if (const char* e = getenv("RECTIPY_AMD_RESIDENT_XCD"); e && e[0] == '0') C->one_xcd = 0;
+    C->spin_cap = 1u << 22;   // polls of about a microsecond each: seconds
+    return RP_OK;
+}
+inline unsigned rp_resident_grid(const rp_resident_ctl& C) { return (unsigned)(C.one_xcd ? 8 * C.need_blocks + 8 : C.need_blocks); }
+
+// A failure word travels to pinned host memory behind its launch (no synchronisation); the library's next calls look at the
+// slots that have landed (rp_resident_poll), rp_async_status lets a caller ask after it has synchronised.
+constexpr int kResidentSlots = 64;
+inline volatile int* rp_resident_slots() {
+    static int* slots = [] {
+        int* p = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void**>(&p), kResidentSlots * sizeof(int), hipHostMallocDefault) != hipSuccess) return (int*)nullptr;
+        for (int i = 0; i < kResidentSlots; ++i) p[i] = 0;
+        return p;
+    }();
+    return slots;
+}
+inline int rp_resident_poll() {   // a resident launch that timed out since the last look?
+    volatile int* slots = rp_resident_slots();
+    bool bad = false;
+    for (int i = 0; slots && i < kResidentSlots; ++i)
+        if (slots[i] != 0) {
+            slots[i] = 0;
+            bad = true;
+        }
+    if (bad)
+        RP_FAIL(RP_ERR_HIP, "a resident multi-step launch timed out waiting for a peer wave (its workgroups were never resident together: is "
+                            "another kernel holding the GPU?); its results are not valid.  RECTIPY_AMD_RESIDENT=0 selects one launch per step");
+    return RP_OK;
+}
+
+// after the launch: the failure word on its way to the host, the scratch back to the pool -- no synchronisation
+inline int rp_resident_end(const rp_resident_ctl& C, void* ws, hipStream_t st, const char* what) {
+    static std::atomic<unsigned> next{0};
+    const hipError_t launched = hipGetLastError();
+    volatile int* slots = rp_resident_slots();
+    hipError_t rc = hipSuccess;
+    if (slots) rc = hipMemcpyAsync(const_cast<int*>(slots) + next.fetch_add(1) % kResidentSlots, C.fail, sizeof(int), hipMemcpyDeviceToHost, st);
+    (void)hipFreeAsync(ws, st);
+    if (launched != hipSuccess) RP_FAIL(RP_ERR_HIP, "%s: %s", what, hipGetErrorString(launched));
+    if (rc != hipSuccess) RP_FAIL(RP_ERR_HIP, "%s: %s", what, hipGetErrorString(rc));
+    return RP_OK;
+}
+
+inline bool rp_resident_enabled() {
+    const char* e = getenv("RECTIPY_AMD_RESIDENT");   // (read per call: tests compare both paths)
+    return !(e && e[0] == '0');
+}

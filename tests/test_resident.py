@@ -77,3 +77,32 @@ def test_broadcast_and_projected_inputs(hip_device, monkeypatch):
             got.append((traj, pop.v.clone(), pop.source.clone()))
         for u, v, name in zip(got[0], got[1], ("traj", "v", "source")):
             same(u, v, f"{sorted(kw)}: {name}")
+
+
+@pytest.mark.parametrize("model,n", [("li_tanh", 256), ("li_tanh", 512), ("li_tanh", 768), ("li_tanh", 1024), ("li_sigmoid", 512)])
+@pytest.mark.parametrize("grad_var", [_abi.RP_OUT_STATE0, _abi.RP_OUT_SOURCE])
+def test_resident_adjoint_sweep_equals_a_launch_per_step(hip_device, monkeypatch, model, n, grad_var):
+    """The rate models' adjoint (transposed-copy sweep) in ONE launch against one launch per adjoint step: adjoint state, u, input
+    gradients and every per-neuron parameter gradient, bit for bit."""
+    T = 37
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.randn(T, n, generator=gen) * 0.5).to(hip_device)
+    g_out = (torch.randn(T, n, generator=gen) * 0.1).to(hip_device)
+    lam_T = (torch.randn(n, generator=gen) * 0.01).to(hip_device)
+    got = []
+    for resident in ("1", "0"):
+        monkeypatch.setenv("RECTIPY_AMD_RESIDENT", resident)
+        pop = make(model, n, hip_device)
+        pop.transposed_adjoint = True
+        tv, tr, ta, ut, gx = (torch.zeros(T, n, device=hip_device) for _ in range(5))
+        pop.forward(T, x=x, save_v=tv, save_src=tr, save_acc=ta)
+        lam = lam_T.clone()
+        gt, gk, ge = (torch.zeros(n, device=hip_device) for _ in range(3))
+        ga = {q: torch.zeros(n, device=hip_device) for q in (("r_max", "s", "v0") if model == "li_sigmoid" else ())}
+        keep = pop.backward(tv, tr, g_out, grad_var, lam, ut, traj_acc=ta, grad_tau=gt, grad_k=gk, grad_eta=ge, grad_x=gx, grad_params=ga)
+        torch.cuda.synchronize()
+        del keep
+        got.append(dict(lam=lam, u=ut, grad_tau=gt, grad_k=gk, grad_eta=ge, grad_x=gx, **ga))
+    assert float(got[0]["lam"].abs().max()) > 0
+    for key in got[0]:
+        same(got[0][key], got[1][key], f"{model} n={n}: {key}")
