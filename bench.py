@@ -593,9 +593,26 @@ def small_n_extra(dev, N=512, T=2000):
     e1.record()
     torch.cuda.synchronize()
     res["launch_floor_us"] = e0.elapsed_time(e1) / 2000 * 1e3
-    res["note"] = ("one kernel launch per Euler step and one per adjoint step (W^T in a workspace, the forward's row-dot kernel with "
-                   "the adjoint update as its epilogue): bounded by the dependent-launch interval of the stream, not by HBM "
-                   "(W is 1 MiB); fit_bptt adds the per-window work (W^T copy, dW GEMM, read-out, loss, optimiser) to the two launches")
+    res["note"] = ("r05: up to n = 1024 ALL steps of a call run in ONE launch, forward and (rate models) adjoint -- W / W^T in registers, "
+                   "the vector handed from wave to wave as tagged 8-byte granules, bit-identical to a launch per step "
+                   "(rectipy_amd/csrc/rp_resident.h); with one launch per step (RECTIPY_AMD_RESIDENT=0: `launch_per_step`) a step is bounded by "
+                   "the dependent-launch interval of the stream and fit_bptt by the host's launch rate; fit_bptt adds the per-window work "
+                   "(W^T copy, dW GEMM, read-out, loss, optimiser)")
+    # the same two calls with one launch per step (the r04 path), for the record
+    os.environ["RECTIPY_AMD_RESIDENT"] = "0"
+    try:
+        with contextlib.redirect_stdout(sys.stderr):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            net.run(x, sampling_steps=1, verbose=False, enable_grad=False)
+            torch.cuda.synchronize()
+            per_step_run = (time.perf_counter() - t0) / T * 1e6
+            t0 = time.perf_counter()
+            fit.fit_bptt(x, target, optimizer="sgd", lr=1e-3, update_steps=100, sampling_steps=100, verbose=False)
+            torch.cuda.synchronize()
+            res["launch_per_step"] = {"Network_run": per_step_run, "Network_fit_bptt_sgd_100_step_windows": (time.perf_counter() - t0) / T * 1e6}
+    finally:
+        os.environ.pop("RECTIPY_AMD_RESIDENT", None)
     return res
 
 

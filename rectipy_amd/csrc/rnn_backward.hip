@@ -674,6 +674,101 @@ int launch_resident_adj(const BwdParams& P, const rp_bwd* b, hipStream_t st) {
     return rp_resident_end(A.C, ws, st, "the resident adjoint sweep");
 }
 
+// the spiking sweep (QIF, QIF_SFA, LIF, IK; not the population-mean models) the same way: spk_finalize_elem as it stands --
+// adjoint states and gradient sums in memory, all a neuron's own --, then the u it left in row t - 1 of u_traj goes on as a granule
+struct SpkResidentArgs {
+    rp_resident_ctl C;
+    int steps;
+    float* u_traj;
+    const float* traj_v;
+    const float* traj_r;
+    const float* traj_aux;
+    const float* traj_aux2;
+    const float* traj_acc;
+    int64_t ld;
+    const float* grad_out;
+    int64_t ldg;
+    float* grad_x;
+    int64_t ldgx;
+    const float* x;
+    int64_t ldx;
+};
+
+template <int NC, int RW>
+__global__ __launch_bounds__(kThreads) void resident_spk_adj_kernel(const BwdParams P0, const SpkGrad G, const SpkResidentArgs A) {
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const int block = rp_resident_join(A.C);
+    if (block < 0) return;
+    const int row_w0 = (block * kResidentWaves + (threadIdx.x >> 6)) * RW;
+    BwdParams P = P0;
+    rp_f4 w[RW][NC];
+    rp_resident_load_rows<NC, RW>(w, P.W, P.ldw, row_w0, lane);   // (P.W: the transposed copy)
+    const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
+    const bool epi_lane = (lane & (64 / RW - 1)) == 0;
+    const int T = A.steps;
+    for (int s = 0; s < T; ++s) {
+        const int t = T - 1 - s;
+        P.t = t;
+        P.u = A.u_traj + (int64_t)t * A.ld;
+        P.v_t = A.traj_v + (int64_t)t * A.ld;
+        P.acc_t = A.traj_acc ? A.traj_acc + (int64_t)t * A.ld : nullptr;
+        P.g_t = A.grad_out ? A.grad_out + (int64_t)t * A.ldg : nullptr;
+        if (t > 0) {   // (spk_set_prep)
+            const int64_t o = (int64_t)(t - 1) * A.ld;
+            P.u_next = A.u_traj + o;
+            P.v_prev = A.traj_v + o;
+            P.s_prev = A.traj_r + o;
+            P.aux_prev = A.traj_aux ? A.traj_aux + o : nullptr;
+            P.aux2_prev = A.traj_aux2 ? A.traj_aux2 + o : nullptr;
+            P.acc_prev = A.traj_acc ? A.traj_acc + o : nullptr;
+            P.gx_prev = A.grad_x ? A.grad_x + (int64_t)(t - 1) * A.ldgx : nullptr;
+            P.x_prev = A.x ? A.x + (int64_t)(t - 1) * A.ldx : nullptr;
+        } else {
+            P.u_next = nullptr;
+        }
+        rp_f4 r[NC];
+        if (s == 0) {
+#pragma unroll
+            for (int m = 0; m < NC; ++m) r[m] = rp_ld4(P.u + 256 * m + 4 * lane);
+        } else if (!rp_resident_sweep<NC>(A.C, (s - 1) & 1, (unsigned)s, r, lane)) {
+            return;
+        }
+        const float z = rp_resident_dots<NC, RW>(w, r, row_w0, lane);
+        if (epi_lane) {
+            spk_finalize_elem(P, G, my_row, z);
+            if (t > 0) rp_resident_publish(A.C, s & 1, my_row, (unsigned)(s + 1), P.u_next[my_row]);   // (this lane's own store)
+        }
+    }
+}
+
+int launch_resident_spk_adj(const BwdParams& P, const SpkGrad& G, const rp_bwd* b, hipStream_t st) {
+    SpkResidentArgs A = {};
+    A.steps = b->steps;
+    A.u_traj = b->u_traj;
+    A.traj_v = b->traj_v;
+    A.traj_r = b->traj_r;
+    A.traj_aux = b->traj_aux;
+    A.traj_aux2 = b->traj_aux2;
+    A.traj_acc = b->traj_acc;
+    A.ld = b->ld;
+    A.grad_out = b->grad_out;
+    A.ldg = b->ldg;
+    A.grad_x = b->grad_x;
+    A.ldgx = b->ldgx;
+    A.x = b->x;
+    A.ldx = b->ldx;
+    void* ws = nullptr;
+    if (rp_resident_begin(P.n, st, &A.C, &ws) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident adjoint sweep: no stream-ordered scratch");
+    const dim3 grid(rp_resident_grid(A.C));
+    switch (P.n >> 8) {
+        case 1: hipLaunchKernelGGL((resident_spk_adj_kernel<1, 16>), grid, dim3(kThreads), 0, st, P, G, A); break;
+        case 2: hipLaunchKernelGGL((resident_spk_adj_kernel<2, 16>), grid, dim3(kThreads), 0, st, P, G, A); break;
+        case 3: hipLaunchKernelGGL((resident_spk_adj_kernel<3, 8>), grid, dim3(kThreads), 0, st, P, G, A); break;
+        default: hipLaunchKernelGGL((resident_spk_adj_kernel<4, 8>), grid, dim3(kThreads), 0, st, P, G, A); break;
+    }
+    return rp_resident_end(A.C, ws, st, "the resident adjoint sweep");
+}
+
 // Launch shapes follow the forward's small-n choices (rnn_forward.hip launch_step): 1 row x 4 chunks per wave up to
 // n = 2048, 2 rows x 2 chunks above.
 template <bool SPIKING>
@@ -1775,6 +1870,7 @@ static void spk_set_step(const rp_bwd* b, BwdParams& P, int t) {
 }
 
 int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
+    if (const int prc = rp_resident_poll(); prc != RP_OK) return prc;
     BwdParams P;
     SpkGrad G;
     bool vec4;
@@ -1804,6 +1900,9 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     spk_set_prep(b, P, T - 1);
     if (mean_coupled) hipLaunchKernelGGL(adj_mean_kernel, dim3(1), dim3(1024), 0, st, P);
     hipLaunchKernelGGL(spk_prep_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
+    if (use_wt && vec4_t && !mean_coupled && rp_resident_enabled() && P.n % 256 == 0 && P.n <= 1024 && T >= 4 && b->ld % 4 == 0 &&
+        !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u))
+        return launch_resident_spk_adj(P, G, b, st);   // the whole sweep in one launch
     for (int t = T - 1; t >= 0; --t) {
         P.u = b->u_traj + (int64_t)t * b->ld;
         if (!use_wt && !use_spt) launch_wt_partial(P, vec4, st);

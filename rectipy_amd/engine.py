@@ -117,6 +117,11 @@ class HipBackend:
     def abi_version(self) -> int:
         return int(self.lib.rp_abi_version())
 
+    def async_status(self):
+        """Raises if a resident multi-step launch (rp_resident.h: all steps of a call in one launch at n <= 1024) reported a timed-out
+        wave since the last look -- the one failure such a launch can only report after the fact (rp_async_status)."""
+        self._check(self.lib.rp_async_status())
+
     def device_name(self, device) -> str:
         """The device's name from the library (hipGetDeviceProperties), cached: torch.cuda.get_device_name would
         initialise amdsmi on its first call -- 105 ms, which was the whole "cold" cost of a process's first run."""

@@ -106,3 +106,43 @@ def test_resident_adjoint_sweep_equals_a_launch_per_step(hip_device, monkeypatch
     assert float(got[0]["lam"].abs().max()) > 0
     for key in got[0]:
         same(got[0][key], got[1][key], f"{model} n={n}: {key}")
+
+
+@pytest.mark.parametrize("n", [256, 512, 1024])
+@pytest.mark.parametrize("grad_var,xw", [(_abi.RP_OUT_SOURCE, "full"), (_abi.RP_OUT_STATE0, "bcast")])
+def test_resident_spiking_adjoint_sweep_equals_a_launch_per_step(hip_device, monkeypatch, n, grad_var, xw):
+    """The spiking sweep (QIF: resets, surrogate gradient) in ONE launch against one launch per adjoint step, bit for bit."""
+    T = 41
+    gen = torch.Generator().manual_seed(n + T)
+    W = torch.rand(n, n, generator=gen) * 20.0 / n
+    params = dict(tau=torch.rand(n, generator=gen) * 0.4 + 0.8, k=torch.rand(n, generator=gen) * 0.4 + 0.8,
+                  eta=torch.randn(n, generator=gen) - 5.0, tau_s=torch.rand(n, generator=gen) + 0.5)
+    v0 = torch.rand(n, generator=gen) * 65.0 - 5.0
+    s0 = torch.rand(n, generator=gen)
+    x = (15.0 + torch.randn(T, n if xw == "full" else 1, generator=gen)).to(hip_device)
+    g_out = (torch.randn(T, n, generator=gen) * 0.1).to(hip_device)
+    lv0, ls0 = torch.randn(n, generator=gen) * 0.01, torch.randn(n, generator=gen) * 0.01
+    got = []
+    for resident in ("1", "0"):
+        monkeypatch.setenv("RECTIPY_AMD_RESIDENT", resident)
+        pop = Population("qif", W, params, 1e-3, hip_device, v0=v0, s0=s0, theta=100.0, v_reset=-100.0)
+        pop.transposed_adjoint = True
+        tv, ts, ta, ut, gx = (torch.zeros(T, n, device=hip_device) for _ in range(5))
+        pop.forward(T, x=x, save_v=tv, save_src=ts, save_acc=ta)
+        lv, ls = lv0.clone().to(hip_device), ls0.clone().to(hip_device)
+        gt, gk, ge, gts = (torch.zeros(n, device=hip_device) for _ in range(4))
+        keep = pop.backward(tv, ts, g_out, grad_var, lv, ut, traj_acc=ta, grad_tau=gt, grad_k=gk, grad_eta=ge, grad_x=gx, lam_s=ls,
+                            grad_tau_s=gts, slope=0.5, x=x)
+        torch.cuda.synchronize()
+        del keep
+        got.append(dict(lam_v=lv, lam_s=ls, u=ut, grad_tau=gt, grad_k=gk, grad_eta=ge, grad_tau_s=gts, grad_x=gx, v_traj=tv))
+    assert int((got[0]["v_traj"] >= 100.0).sum()) > 0   # (spikes inside the window)
+    for key in got[0]:
+        same(got[0][key], got[1][key], f"qif n={n}: {key}")
+
+
+def test_no_resident_launch_reported_a_timeout(hip_device):
+    """After synchronising: no resident launch of this process (the tests above) timed out waiting for a peer wave."""
+    from rectipy_amd.engine import default_backend
+    torch.cuda.synchronize()
+    default_backend().async_status()
