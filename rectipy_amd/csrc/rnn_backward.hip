@@ -602,7 +602,7 @@ struct AdjResidentArgs {
     int64_t ldgx;
 };
 
-template <int NC, int RW>
+template <int NC, int RW, bool PARTIAL>
 __global__ __launch_bounds__(kThreads) void resident_adj_kernel(const BwdParams P0, const AdjResidentArgs A) {
     static_assert(kThreads == 64 * kResidentWaves, "rp_resident.h counts four waves per workgroup");
     const int lane = threadIdx.x & (RP_WAVE - 1);
@@ -611,9 +611,9 @@ __global__ __launch_bounds__(kThreads) void resident_adj_kernel(const BwdParams 
     const int row_w0 = (block * kResidentWaves + (threadIdx.x >> 6)) * RW;
     BwdParams P = P0;
     rp_f4 w[RW][NC];
-    rp_resident_load_rows<NC, RW>(w, P.W, P.ldw, row_w0, lane);   // (P.W: the transposed copy)
+    rp_resident_load_rows<NC, RW>(w, P.W, P.ldw, row_w0, lane, P.n);   // (P.W: the transposed copy)
     const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
-    const bool epi_lane = (lane & (64 / RW - 1)) == 0;
+    const bool epi_lane = (lane & (64 / RW - 1)) == 0 && my_row < P.n;
     float lam_reg = epi_lane ? P0.lam[my_row] : 0.f;
     RateAcc G = {};
     if (epi_lane) G = rate_acc_load(P0, my_row);   // (what the prep launch in front left there)
@@ -635,12 +635,11 @@ __global__ __launch_bounds__(kThreads) void resident_adj_kernel(const BwdParams 
         }
         rp_f4 r[NC];
         if (s == 0) {   // u_T: written by the prep launch in front of this one
-#pragma unroll
-            for (int m = 0; m < NC; ++m) r[m] = rp_ld4(P.u + 256 * m + 4 * lane);
-        } else if (!rp_resident_sweep<NC>(A.C, (s - 1) & 1, (unsigned)s, r, lane)) {
+            rp_resident_load_vec<NC>(r, P.u, lane, P.n);
+        } else if (!rp_resident_sweep<NC>(A.C, (s - 1) & 1, (unsigned)s, r, lane, P.n)) {
             return;
         }
-        const float z = rp_resident_dots<NC, RW>(w, r, row_w0, lane);
+        const float z = rp_resident_dots<NC, RW, PARTIAL>(w, r, row_w0, lane);
         if (epi_lane) {
             float u;
             lam_reg = finalize_core(P, my_row, z, lam_reg, &u, G);
@@ -665,12 +664,9 @@ int launch_resident_adj(const BwdParams& P, const rp_bwd* b, hipStream_t st) {
     void* ws = nullptr;
     if (rp_resident_begin(P.n, st, &A.C, &ws) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident adjoint sweep: no stream-ordered scratch");
     const dim3 grid(rp_resident_grid(A.C));
-    switch (P.n >> 8) {
-        case 1: hipLaunchKernelGGL((resident_adj_kernel<1, 16>), grid, dim3(kThreads), 0, st, P, A); break;
-        case 2: hipLaunchKernelGGL((resident_adj_kernel<2, 16>), grid, dim3(kThreads), 0, st, P, A); break;
-        case 3: hipLaunchKernelGGL((resident_adj_kernel<3, 8>), grid, dim3(kThreads), 0, st, P, A); break;
-        default: hipLaunchKernelGGL((resident_adj_kernel<4, 8>), grid, dim3(kThreads), 0, st, P, A); break;
-    }
+#define RP_LAUNCH_(NC_, RW_, PART_) hipLaunchKernelGGL((resident_adj_kernel<NC_, RW_, PART_>), grid, dim3(kThreads), 0, st, P, A)
+    RP_RESIDENT_DISPATCH(P.n, RP_LAUNCH_)
+#undef RP_LAUNCH_
     return rp_resident_end(A.C, ws, st, "the resident adjoint sweep");
 }
 
@@ -694,7 +690,7 @@ struct SpkResidentArgs {
     int64_t ldx;
 };
 
-template <int NC, int RW>
+template <int NC, int RW, bool PARTIAL>
 __global__ __launch_bounds__(kThreads) void resident_spk_adj_kernel(const BwdParams P0, const SpkGrad G, const SpkResidentArgs A) {
     const int lane = threadIdx.x & (RP_WAVE - 1);
     const int block = rp_resident_join(A.C);
@@ -702,9 +698,9 @@ __global__ __launch_bounds__(kThreads) void resident_spk_adj_kernel(const BwdPar
     const int row_w0 = (block * kResidentWaves + (threadIdx.x >> 6)) * RW;
     BwdParams P = P0;
     rp_f4 w[RW][NC];
-    rp_resident_load_rows<NC, RW>(w, P.W, P.ldw, row_w0, lane);   // (P.W: the transposed copy)
+    rp_resident_load_rows<NC, RW>(w, P.W, P.ldw, row_w0, lane, P.n);   // (P.W: the transposed copy)
     const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
-    const bool epi_lane = (lane & (64 / RW - 1)) == 0;
+    const bool epi_lane = (lane & (64 / RW - 1)) == 0 && my_row < P.n;
     const int T = A.steps;
     for (int s = 0; s < T; ++s) {
         const int t = T - 1 - s;
@@ -728,12 +724,11 @@ __global__ __launch_bounds__(kThreads) void resident_spk_adj_kernel(const BwdPar
         }
         rp_f4 r[NC];
         if (s == 0) {
-#pragma unroll
-            for (int m = 0; m < NC; ++m) r[m] = rp_ld4(P.u + 256 * m + 4 * lane);
-        } else if (!rp_resident_sweep<NC>(A.C, (s - 1) & 1, (unsigned)s, r, lane)) {
+            rp_resident_load_vec<NC>(r, P.u, lane, P.n);
+        } else if (!rp_resident_sweep<NC>(A.C, (s - 1) & 1, (unsigned)s, r, lane, P.n)) {
             return;
         }
-        const float z = rp_resident_dots<NC, RW>(w, r, row_w0, lane);
+        const float z = rp_resident_dots<NC, RW, PARTIAL>(w, r, row_w0, lane);
         if (epi_lane) {
             spk_finalize_elem(P, G, my_row, z);
             if (t > 0) rp_resident_publish(A.C, s & 1, my_row, (unsigned)(s + 1), P.u_next[my_row]);   // (this lane's own store)
@@ -760,12 +755,9 @@ int launch_resident_spk_adj(const BwdParams& P, const SpkGrad& G, const rp_bwd* 
     void* ws = nullptr;
     if (rp_resident_begin(P.n, st, &A.C, &ws) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident adjoint sweep: no stream-ordered scratch");
     const dim3 grid(rp_resident_grid(A.C));
-    switch (P.n >> 8) {
-        case 1: hipLaunchKernelGGL((resident_spk_adj_kernel<1, 16>), grid, dim3(kThreads), 0, st, P, G, A); break;
-        case 2: hipLaunchKernelGGL((resident_spk_adj_kernel<2, 16>), grid, dim3(kThreads), 0, st, P, G, A); break;
-        case 3: hipLaunchKernelGGL((resident_spk_adj_kernel<3, 8>), grid, dim3(kThreads), 0, st, P, G, A); break;
-        default: hipLaunchKernelGGL((resident_spk_adj_kernel<4, 8>), grid, dim3(kThreads), 0, st, P, G, A); break;
-    }
+#define RP_LAUNCH_(NC_, RW_, PART_) hipLaunchKernelGGL((resident_spk_adj_kernel<NC_, RW_, PART_>), grid, dim3(kThreads), 0, st, P, G, A)
+    RP_RESIDENT_DISPATCH(P.n, RP_LAUNCH_)
+#undef RP_LAUNCH_
     return rp_resident_end(A.C, ws, st, "the resident adjoint sweep");
 }
 
@@ -1042,7 +1034,7 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     if (use_wt) launch_transpose(net, b, st);
     set_prep(T - 1);
     hipLaunchKernelGGL(prep_kernel, dim3(eblocks), dim3(256), 0, st, P);
-    if (use_wt && vec4_t && rp_resident_enabled() && n % 256 == 0 && n <= 1024 && T >= 4 && b->ld % 4 == 0 &&
+    if (use_wt && vec4_t && rp_resident_enabled() && rp_resident_shape(n, b->ldwt) && T >= 4 && b->ld % 4 == 0 &&
         !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u)) {
         return launch_resident_adj(P, b, st);   // the whole sweep in one launch
     }
@@ -1900,7 +1892,7 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     spk_set_prep(b, P, T - 1);
     if (mean_coupled) hipLaunchKernelGGL(adj_mean_kernel, dim3(1), dim3(1024), 0, st, P);
     hipLaunchKernelGGL(spk_prep_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
-    if (use_wt && vec4_t && !mean_coupled && rp_resident_enabled() && P.n % 256 == 0 && P.n <= 1024 && T >= 4 && b->ld % 4 == 0 &&
+    if (use_wt && vec4_t && !mean_coupled && rp_resident_enabled() && rp_resident_shape(P.n, b->ldwt) && T >= 4 && b->ld % 4 == 0 &&
         !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u))
         return launch_resident_spk_adj(P, G, b, st);   // the whole sweep in one launch
     for (int t = T - 1; t >= 0; --t) {

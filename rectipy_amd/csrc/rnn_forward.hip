@@ -383,7 +383,7 @@ __device__ __forceinline__ void resident_set_step(StepParams& P, const ResidentA
     }
 }
 
-template <int MODEL, int NC, int RW>
+template <int MODEL, int NC, int RW, bool PARTIAL>
 __global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0, const ResidentArgs A) {
     static_assert(kWavesPerBlock == kResidentWaves, "rp_resident.h counts four waves per workgroup");
     const int lane = threadIdx.x & (RP_WAVE - 1);
@@ -392,10 +392,10 @@ __global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0,
     const int row_w0 = (block * kWavesPerBlock + (threadIdx.x >> 6)) * RW;   // this wave's rows: [row_w0, row_w0 + RW)
     StepParams P = P0;
     rp_f4 w[RW][NC];
-    rp_resident_load_rows<NC, RW>(w, P.W, P.ldw, row_w0, lane);
+    rp_resident_load_rows<NC, RW>(w, P.W, P.ldw, row_w0, lane, P.n);
     int acc_count = A.acc_count0, sample_idx = A.sample_idx0;
     const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
-    const bool epi_lane = (lane & (64 / RW - 1)) == 0;   // (the lanes of a group hold the same row total after the butterfly)
+    const bool epi_lane = (lane & (64 / RW - 1)) == 0 && my_row < P.n;   // (the lanes of a group hold the same row total after the butterfly)
     // the epilogue lane's own state and source value stay in registers from step to step
     float v_reg = 0.f, s_reg = 0.f;
     if (epi_lane) {
@@ -408,12 +408,11 @@ __global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0,
         const float I_x = epi_lane ? input_current(P, my_row) : 0.f;   // (requested before the wait for the source vector)
         rp_f4 r[NC];
         if (t == 0) {
-#pragma unroll
-            for (int m = 0; m < NC; ++m) r[m] = rp_ld4(P.src_cur + 256 * m + 4 * lane);
-        } else if (!rp_resident_sweep<NC>(A.C, (t - 1) & 1, (unsigned)t, r, lane)) {
+            rp_resident_load_vec<NC>(r, P.src_cur, lane, P.n);
+        } else if (!rp_resident_sweep<NC>(A.C, (t - 1) & 1, (unsigned)t, r, lane, P.n)) {
             return;
         }
-        const float total = rp_resident_dots<NC, RW>(w, r, P.row0 + row_w0, lane);
+        const float total = rp_resident_dots<NC, RW, PARTIAL>(w, r, P.row0 + row_w0, lane);
         if (epi_lane) {
             float v_new;
             s_reg = epilogue_core<MODEL>(P, my_row, total, 0.f, I_x, v_reg, s_reg, &v_new);
@@ -1343,12 +1342,9 @@ int launch_population_step(const rp_net* net, const StepParams& P, hipStream_t s
 template <int MODEL>
 void launch_resident_model(const StepParams& P, const ResidentArgs& A, hipStream_t st) {
     const dim3 grid(rp_resident_grid(A.C));
-    switch (P.n >> 8) {
-        case 1: hipLaunchKernelGGL((resident_kernel<MODEL, 1, 16>), grid, dim3(kThreads), 0, st, P, A); break;
-        case 2: hipLaunchKernelGGL((resident_kernel<MODEL, 2, 16>), grid, dim3(kThreads), 0, st, P, A); break;
-        case 3: hipLaunchKernelGGL((resident_kernel<MODEL, 3, 8>), grid, dim3(kThreads), 0, st, P, A); break;
-        default: hipLaunchKernelGGL((resident_kernel<MODEL, 4, 8>), grid, dim3(kThreads), 0, st, P, A); break;
-    }
+#define RP_LAUNCH_(NC_, RW_, PART_) hipLaunchKernelGGL((resident_kernel<MODEL, NC_, RW_, PART_>), grid, dim3(kThreads), 0, st, P, A)
+    RP_RESIDENT_DISPATCH(P.n, RP_LAUNCH_)
+#undef RP_LAUNCH_
 }
 
 constexpr int kResidentMinSteps = 4;
@@ -1358,7 +1354,7 @@ bool resident_ok(const rp_net* net, const rp_run* run) {
         net->model > RP_MODEL_IK_BIEXP)
         return false;
     if (net->sp_vals || run->n_edges > 0 || run->save_src_full || run->steps < kResidentMinSteps) return false;
-    if (net->rows != net->n || net->row0 != 0 || net->n % 256 != 0 || net->n > 1024 || net->ldw % 4 != 0) return false;
+    if (net->rows != net->n || net->row0 != 0 || !rp_resident_shape(net->n, net->ldw)) return false;
     return aligned16(net->W) && aligned16(net->src[0]) && aligned16(net->src[1]);
 }
 

@@ -1,4 +1,4 @@
-// rp_resident.h -- the machinery of the resident multi-step kernels (launch-bound sizes: n <= 1024, n % 256 == 0): the forward
+// rp_resident.h -- the machinery of the resident multi-step kernels (launch-bound sizes: n <= 1024, n % 4 == 0): the forward
 // step (rnn_forward.hip: resident_kernel) and the adjoint step of the rate models (rnn_backward.hip: resident_adj_kernel).
 //
 // Every wave keeps RW rows of the matrix in REGISTERS for the whole call; between steps the waves hand the vector the rows are
@@ -35,7 +35,8 @@ typedef __attribute__((address_space(1))) unsigned rp_gu32;
 typedef __attribute__((address_space(1))) int rp_gi32;
 
 constexpr int kResidentWaves = 4;                     // waves per workgroup
-constexpr int rp_resident_rows_per_wave(int n) { return (n >> 8) <= 2 ? 16 : 8; }
+constexpr int rp_resident_chunks(int n) { return (n + 255) >> 8; }   // 256-column chunks, the last one possibly partial
+constexpr int rp_resident_rows_per_wave(int n) { return rp_resident_chunks(n) <= 2 ? 16 : 8; }
 
 // the work index of this workgroup, or -1 (it leaves).  Ends with the workgroup's barrier.
 __device__ __forceinline__ int rp_resident_join(const rp_resident_ctl& C) {
@@ -83,24 +84,29 @@ __device__ __forceinline__ int rp_resident_join(const rp_resident_ctl& C) {
     return block_s < C.need_blocks ? block_s : -1;
 }
 
-// the n = 256 NC values tagged `want` in the lane layout of the row dots (lane l: columns 256 m + 4 l .. + 3); false: give up
+// the n values tagged `want` in the lane layout of the row dots (lane l: columns 256 m + 4 l .. + 3; zeros past n -- n % 4 == 0,
+// so a lane's four columns are all there or all past the end); false: give up
 template <int NC>
-__device__ __forceinline__ bool rp_resident_sweep(const rp_resident_ctl& C, int parity, unsigned want, rp_f4 (&r)[NC], int lane) {
+__device__ __forceinline__ bool rp_resident_sweep(const rp_resident_ctl& C, int parity, unsigned want, rp_f4 (&r)[NC], int lane, int n) {
     const rp_gu64* g = (const rp_gu64*)C.gran[parity] + 4 * lane;
     rp_gi32* const fail = (rp_gi32*)C.fail;
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
 #pragma unroll
         for (int m = 0; m < NC; ++m) {
-            unsigned long long q[4];
+            if (256 * m + 4 * lane < n) {
+                unsigned long long q[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) q[c] = __hip_atomic_load(g + 256 * m + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int c = 0; c < 4; ++c) q[c] = __hip_atomic_load(g + 256 * m + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ok = ok && (unsigned)(q[c] >> 32) == want;
-            r[m].x = __uint_as_float((unsigned)q[0]);
-            r[m].y = __uint_as_float((unsigned)q[1]);
-            r[m].z = __uint_as_float((unsigned)q[2]);
-            r[m].w = __uint_as_float((unsigned)q[3]);
+                for (int c = 0; c < 4; ++c) ok = ok && (unsigned)(q[c] >> 32) == want;
+                r[m].x = __uint_as_float((unsigned)q[0]);
+                r[m].y = __uint_as_float((unsigned)q[1]);
+                r[m].z = __uint_as_float((unsigned)q[2]);
+                r[m].w = __uint_as_float((unsigned)q[3]);
+            } else {
+                r[m] = rp_f4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         if (__all(ok)) return true;
         if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;   // (wave-uniform)
@@ -112,55 +118,82 @@ __device__ __forceinline__ bool rp_resident_sweep(const rp_resident_ctl& C, int 
     }
 }
 
+// the vector as it lies in memory, in the same layout (the first step of a call)
+template <int NC>
+__device__ __forceinline__ void rp_resident_load_vec(rp_f4 (&r)[NC], const float* v, int lane, int n) {
+#pragma unroll
+    for (int m = 0; m < NC; ++m) r[m] = 256 * m + 4 * lane < n ? rp_ld4(v + 256 * m + 4 * lane) : rp_f4{0.f, 0.f, 0.f, 0.f};
+}
+
 __device__ __forceinline__ void rp_resident_publish(const rp_resident_ctl& C, int parity, int row, unsigned tag, float value) {
     __hip_atomic_store((rp_gu64*)C.gran[parity] + row, ((unsigned long long)tag << 32) | __float_as_uint(value), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// eight rows (one stagger group: the same start chunk M0) against the NC chunks of the vector, in the contract's order (rp_dot.h)
-template <int NC, int M0>
+// eight rows (one stagger group: the same start chunk M0) against the chunks of the vector, in the contract's order (rp_dot.h:
+// the MF full chunks from M0 on, wrapping; then the partial last chunk -- its lanes past n hold zeros: fma(0, 0, a) == a)
+template <int NC, int MF, int M0>
 __device__ __forceinline__ void rp_resident_dot8(const rp_f4 (*w)[NC], const rp_f4 (&r)[NC], float* rs) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         rp_f4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int m = (M0 + i) % NC;
+        for (int i = 0; i < MF; ++i) {
+            const int m = (M0 + i) % (MF > 0 ? MF : 1);
             a = rp_fma4(w[j][m], r[m], a);
         }
+        if constexpr (MF < NC) a = rp_fma4(w[j][NC - 1], r[NC - 1], a);
         rs[j] = rp_lane_sum4(a);
     }
 }
 
+// rows past n and the lanes of a partial chunk past n hold zeros
 template <int NC, int RW>
-__device__ __forceinline__ void rp_resident_load_rows(rp_f4 (&w)[RW][NC], const float* W, int64_t ldw, int row_w0, int lane) {
+__device__ __forceinline__ void rp_resident_load_rows(rp_f4 (&w)[RW][NC], const float* W, int64_t ldw, int row_w0, int lane, int n) {
 #pragma unroll
     for (int j = 0; j < RW; ++j)
 #pragma unroll
-        for (int m = 0; m < NC; ++m) w[j][m] = rp_ld4(W + (int64_t)(row_w0 + j) * ldw + 256 * m + 4 * lane);
+        for (int m = 0; m < NC; ++m)
+            w[j][m] = (row_w0 + j < n && 256 * m + 4 * lane < n) ? rp_ld4(W + (int64_t)(row_w0 + j) * ldw + 256 * m + 4 * lane)
+                                                                 : rp_f4{0.f, 0.f, 0.f, 0.f};
 }
 
-// the totals of the wave's RW rows: afterwards lane l holds the total of row rp_rows_allreduce_row<RW>(l) of the wave
-template <int NC, int RW>
+// the totals of the wave's RW rows: afterwards lane l holds the total of row rp_rows_allreduce_row<RW>(l) of the wave.
+// PARTIAL: the last of the NC chunks is a partial one (n % 256 != 0)
+template <int NC, int RW, bool PARTIAL>
 __device__ __forceinline__ float rp_resident_dots(const rp_f4 (&w)[RW][NC], const rp_f4 (&r)[NC], int global_row_w0, int lane) {
     static_assert(RW == 8 || RW == 16, "one or two stagger groups of eight rows per wave");
+    constexpr int MF = PARTIAL ? NC - 1 : NC;   // full chunks
     float rs[RW];
 #pragma unroll
     for (int h = 0; h < RW / 8; ++h) {
-        const int m0 = (int)(((unsigned)((global_row_w0 + 8 * h) >> 3) * kStagger) % (unsigned)NC);   // wave-uniform
-        if constexpr (NC == 1) {
-            rp_resident_dot8<NC, 0>(w + 8 * h, r, rs + 8 * h);
+        if constexpr (MF <= 1) {
+            rp_resident_dot8<NC, MF, 0>(w + 8 * h, r, rs + 8 * h);
         } else {
+            const int m0 = (int)(((unsigned)((global_row_w0 + 8 * h) >> 3) * kStagger) % (unsigned)MF);   // wave-uniform
             switch (m0) {
-                case 0: rp_resident_dot8<NC, 0>(w + 8 * h, r, rs + 8 * h); break;
-                case 1: rp_resident_dot8<NC, 1>(w + 8 * h, r, rs + 8 * h); break;
-                case 2: rp_resident_dot8<NC, 2 % NC>(w + 8 * h, r, rs + 8 * h); break;
-                default: rp_resident_dot8<NC, 3 % NC>(w + 8 * h, r, rs + 8 * h); break;
+                case 0: rp_resident_dot8<NC, MF, 0>(w + 8 * h, r, rs + 8 * h); break;
+                case 1: rp_resident_dot8<NC, MF, 1>(w + 8 * h, r, rs + 8 * h); break;
+                case 2: rp_resident_dot8<NC, MF, 2 % MF>(w + 8 * h, r, rs + 8 * h); break;
+                default: rp_resident_dot8<NC, MF, 3 % MF>(w + 8 * h, r, rs + 8 * h); break;
             }
         }
     }
     return rp_rows_allreduce<RW>(rs, lane);
 }
+
+// the launch: kernel template K<NC, RW, PARTIAL> for n columns
+#define RP_RESIDENT_DISPATCH(n_, LAUNCH)                                   \
+    switch (rp_resident_chunks(n_) * 2 + ((n_) % 256 != 0 ? 1 : 0)) {     \
+        case 2: LAUNCH(1, 16, false); break;                               \
+        case 3: LAUNCH(1, 16, true); break;                                \
+        case 4: LAUNCH(2, 16, false); break;                               \
+        case 5: LAUNCH(2, 16, true); break;                                \
+        case 6: LAUNCH(3, 8, false); break;                                \
+        case 7: LAUNCH(3, 8, true); break;                                 \
+        case 8: LAUNCH(4, 8, false); break;                                \
+        default: LAUNCH(4, 8, true); break;                                \
+    }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
 // stream-ordered scratch (granules, failure word, roster), zeroed: a tag is never 0
@@ -173,7 +206,8 @@ inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** w
     C->gran[1] = C->gran[0] + n;
     C->fail = reinterpret_cast<int*>(C->gran[1] + n);
     C->ctl = reinterpret_cast<unsigned*>(C->fail) + 4;
-    C->need_blocks = n / rp_resident_rows_per_wave(n) / kResidentWaves;
+    const int waves = (n + rp_resident_rows_per_wave(n) - 1) / rp_resident_rows_per_wave(n);
+    C->need_blocks = (waves + kResidentWaves - 1) / kResidentWaves;
     C->one_xcd = C->need_blocks <= 8 ? 1 : 0;
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT_XCD"); e && e[0] == '0') C->one_xcd = 0;
     C->spin_cap = 1u << 22;   // polls of about a microsecond each: seconds
@@ -219,6 +253,9 @@ inline int rp_resident_end(const rp_resident_ctl& C, void* ws, hipStream_t st, c
     if (rc != hipSuccess) RP_FAIL(RP_ERR_HIP, "%s: %s", what, hipGetErrorString(rc));
     return RP_OK;
 }
+
+// n <= 1024 on the 16-byte path
+inline bool rp_resident_shape(int n, int64_t ld) { return n >= 4 && n <= 1024 && n % 4 == 0 && ld % 4 == 0; }
 
 inline bool rp_resident_enabled() {
     const char* e = getenv("RECTIPY_AMD_RESIDENT");   // (read per call: tests compare both paths)
