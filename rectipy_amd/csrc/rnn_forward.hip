@@ -153,13 +153,32 @@ __device__ __forceinline__ void sample_output(const StepParams& P, int i, float 
     }
 }
 
+// A rate neuron's parameters in registers (the resident kernel reads them once per call) and -v / tau of the coming step, formed
+// while the wave waits for the source vector
+struct RateRegs {
+    float tau, k, eta, rmax, slope, v0, mv_tau;
+};
 template <int MODEL>
-__device__ __forceinline__ float activation(const StepParams& P, int i, float v) {
+__device__ __forceinline__ RateRegs rate_regs_load(const StepParams& P, int i) {
+    RateRegs R = {};
+    R.tau = P.p[RP_P_TAU][i];
+    R.k = P.p[RP_P_K][i];
+    R.eta = P.p[RP_P_ETA][i];
+    if constexpr (MODEL == RP_MODEL_LI_SIGMOID) {
+        R.rmax = P.p[RP_P_RMAX][i];
+        R.slope = P.p[RP_P_SLOPE][i];
+        R.v0 = P.p[RP_P_V0][i];
+    }
+    return R;
+}
+
+template <int MODEL>
+__device__ __forceinline__ float activation(const RateRegs& R, float v) {
     if constexpr (MODEL == RP_MODEL_LI_TANH) {
         return rp_tanhf(v);
     } else {  // r = r_max / (1 + exp(s*(v0 - v)))   leaky_integrator.yaml:22
-        float e = rp_expf(P.p[RP_P_SLOPE][i] * (P.p[RP_P_V0][i] - v));
-        return P.p[RP_P_RMAX][i] / (1.0f + e);
+        float e = rp_expf(R.slope * (R.v0 - v));
+        return R.rmax / (1.0f + e);
     }
 }
 
@@ -167,9 +186,10 @@ __device__ __forceinline__ float activation(const StepParams& P, int i, float v)
 // `I_x`: the step's external input of neuron i (input_current), `v` / `s`: its state and source value BEFORE the step -- read by
 // the caller (the per-step kernels: from memory right here; the resident kernel: its own values of the step before, kept in
 // registers, and the input fetched while it waits for the source vector).  Returns the new source value; *v_new: the new state.
+// `regs` (rate models, optional): the neuron's parameters and -v / tau already in registers
 template <int MODEL, bool EDGES = false>
 __device__ __forceinline__ float epilogue_core(const StepParams& P, int i, float wsum, float esum, float I_x, float v, float s,
-                                               float* v_new_out) {
+                                               float* v_new_out, const RateRegs* regs = nullptr) {
     const int gi = P.row0 + i;
     float I = I_x;
     if constexpr (EDGES)
@@ -260,9 +280,16 @@ __device__ __forceinline__ float epilogue_core(const StepParams& P, int i, float
         return s_new;
     } else {
         // RateNet.forward, nodes.py:166-170; field leaky_integrator.yaml:10
-        const float dv = ((-v / P.p[RP_P_TAU][i] + P.p[RP_P_K][i] * wsum) + I) + P.p[RP_P_ETA][i];
+        RateRegs R;
+        if (regs) {
+            R = *regs;
+        } else {
+            R = rate_regs_load<MODEL>(P, i);
+            R.mv_tau = -v / R.tau;
+        }
+        const float dv = ((R.mv_tau + R.k * wsum) + I) + R.eta;
         const float v_new = v + P.dt * dv;
-        const float r_new = activation<MODEL>(P, i, v_new);
+        const float r_new = activation<MODEL>(R, v_new);
         P.y[RP_Y_V][i] = v_new;
         P.src_next[gi] = r_new;
         if (P.hist_next) P.hist_next[i] = P.out_var == RP_OUT_STATE0 ? v_new : r_new;
@@ -398,14 +425,18 @@ __global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0,
     const bool epi_lane = (lane & (64 / RW - 1)) == 0 && my_row < P.n;   // (the lanes of a group hold the same row total after the butterfly)
     // the epilogue lane's own state and source value stay in registers from step to step
     float v_reg = 0.f, s_reg = 0.f;
+    RateRegs R = {};
+    constexpr bool kRate = MODEL == RP_MODEL_LI_TANH || MODEL == RP_MODEL_LI_SIGMOID;
     if (epi_lane) {
         v_reg = P0.y[RP_Y_V][my_row];
         s_reg = A.src[A.cur0][P0.row0 + my_row];
+        if constexpr (kRate) R = rate_regs_load<MODEL>(P0, my_row);
     }
     for (int t = 0; t < A.steps; ++t) {
         resident_set_step(P, A, t, acc_count, sample_idx);
         P.spike_src = t == 0 ? P0.spike_src : nullptr;
         const float I_x = epi_lane ? input_current(P, my_row) : 0.f;   // (requested before the wait for the source vector)
+        if constexpr (kRate) R.mv_tau = -v_reg / R.tau;
         rp_f4 r[NC];
         if (t == 0) {
             rp_resident_load_vec<NC>(r, P.src_cur, lane, P.n);
@@ -415,7 +446,7 @@ __global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0,
         const float total = rp_resident_dots<NC, RW, PARTIAL>(w, r, P.row0 + row_w0, lane);
         if (epi_lane) {
             float v_new;
-            s_reg = epilogue_core<MODEL>(P, my_row, total, 0.f, I_x, v_reg, s_reg, &v_new);
+            s_reg = epilogue_core<MODEL>(P, my_row, total, 0.f, I_x, v_reg, s_reg, &v_new, kRate ? &R : nullptr);
             v_reg = v_new;
             if (t + 1 < A.steps) rp_resident_publish(A.C, t & 1, my_row, (unsigned)(t + 1), s_reg);
         }
@@ -815,7 +846,7 @@ __global__ __launch_bounds__(1024) void mean_kernel(const StepParams P) {
 template <int MODEL>
 __global__ void refresh_kernel(const StepParams P) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P.rows) P.src_next[P.row0 + i] = activation<MODEL>(P, i, P.y[RP_Y_V][i]);
+    if (i < P.rows) P.src_next[P.row0 + i] = activation<MODEL>(rate_regs_load<MODEL>(P, i), P.y[RP_Y_V][i]);
 }
 
 __global__ void stream_probe_kernel(const float* __restrict__ buf, int64_t n4, float* out) {
