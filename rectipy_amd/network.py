@@ -953,7 +953,9 @@ class Network:
             if sample_at:
                 # the loss recorded at a step is that of the last COMPLETED window at that step (network.py:1043-1046)
                 losses = [error if (t == b - 1 and b - a == optim_steps) else prev_error for t in sample_at]
-                obs.record_block(sample_at, preds.detach()[[t - a for t in sample_at]], losses, [])
+                # (a strided view: indexing with a Python list builds an index tensor on the host and copies it to the device --
+                # a blocking copy that waits for the whole window's kernels, once per window)
+                obs.record_block(sample_at, preds.detach()[sample_at[0] - a::sampling_steps].clone(), losses, [])
                 if verbose:
                     print(f"Progress: {sample_at[-1]}/{steps} training steps finished. Current loss: {error}.")
         return obs
