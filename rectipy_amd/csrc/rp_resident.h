@@ -1,5 +1,6 @@
 // rp_resident.h -- the machinery of the resident multi-step kernels (launch-bound sizes: n <= 1024, n % 4 == 0): the forward
-// step (rnn_forward.hip: resident_kernel) and the adjoint step of the rate models (rnn_backward.hip: resident_adj_kernel).
+// step (rnn_forward.hip: resident_kernel) and the adjoint sweeps on the transposed copy (rnn_backward.hip: resident_adj_kernel for
+// the rate models, resident_spk_adj_kernel for the spiking ones).
 //
 // Every wave keeps RW rows of the matrix in REGISTERS for the whole call; between steps the waves hand the vector the rows are
 // multiplied with around themselves: the lane that finished element i stores ONE 8-byte granule {tag = step + 1, value}
@@ -160,14 +161,15 @@ __device__ __forceinline__ void rp_resident_load_rows(rp_f4 (&w)[RW][NC], const 
 
 // the totals of the wave's RW rows: afterwards lane l holds the total of row rp_rows_allreduce_row<RW>(l) of the wave.
 // PARTIAL: the last of the NC chunks is a partial one (n % 256 != 0)
-template <int NC, int RW, bool PARTIAL>
+// STAGGER = false: every row starts at chunk 0 (the RLS passes)
+template <int NC, int RW, bool PARTIAL, bool STAGGER = true>
 __device__ __forceinline__ float rp_resident_dots(const rp_f4 (&w)[RW][NC], const rp_f4 (&r)[NC], int global_row_w0, int lane) {
     static_assert(RW == 8 || RW == 16, "one or two stagger groups of eight rows per wave");
     constexpr int MF = PARTIAL ? NC - 1 : NC;   // full chunks
     float rs[RW];
 #pragma unroll
     for (int h = 0; h < RW / 8; ++h) {
-        if constexpr (MF <= 1) {
+        if constexpr (MF <= 1 || !STAGGER) {
             rp_resident_dot8<NC, MF, 0>(w + 8 * h, r, rs + 8 * h);
         } else {
             const int m0 = (int)(((unsigned)((global_row_w0 + 8 * h) >> 3) * kStagger) % (unsigned)MF);   // wave-uniform

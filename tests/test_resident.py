@@ -145,6 +145,28 @@ def test_resident_spiking_adjoint_sweep_equals_a_launch_per_step(hip_device, mon
         same(got[0][key], got[1][key], f"qif n={n}: {key}")
 
 
+@pytest.mark.parametrize("n_in,n_out,T", [(256, 2, 30), (512, 3, 41), (1024, 1, 20), (100, 2, 57), (500, 4, 33), (900, 3, 12), (8, 1, 9)])
+def test_resident_rls_sweep_equals_the_launches(hip_device, monkeypatch, n_in, n_out, T):
+    """RLS with an update every step at launch-bound sizes: the whole sweep in ONE launch (P and W in registers, z exchanged as
+    granules) against three launches per update: predictions, losses, weights and P, bit for bit; two consecutive sweeps."""
+    from rectipy_amd.rls import RLS
+    gen = torch.Generator().manual_seed(n_in + T)
+    X = (torch.randn(T, n_in, generator=gen) * 0.3).to(hip_device)
+    Y = torch.randn(T, n_out, generator=gen).to(hip_device)
+    W0 = torch.randn(n_out, n_in, generator=gen) * 0.1
+    got = []
+    for resident in ("1", "0"):
+        monkeypatch.setenv("RECTIPY_AMD_RESIDENT", resident)
+        edge = RLS(n_in, n_out, weights=W0.clone(), beta=0.97, alpha=1.5).to(hip_device)
+        half = T // 2
+        p1, l1 = edge.sweep(X[:half], Y[:half], 1)
+        p2, l2 = edge.sweep(X[half:], Y[half:], 1)
+        torch.cuda.synchronize()
+        got.append(dict(pred=torch.cat([p1, p2]), loss=torch.cat([l1, l2]), weights=edge.weights.clone(), P=edge.P.clone()))
+    for key in got[0]:
+        same(got[0][key], got[1][key], f"rls n_in={n_in} n_out={n_out}: {key}")
+
+
 def test_no_resident_launch_reported_a_timeout(hip_device):
     """After synchronising: no resident launch of this process (the tests above) timed out waiting for a peer wave."""
     from rectipy_amd.engine import default_backend
