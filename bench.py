@@ -581,6 +581,18 @@ def small_n_extra(dev, N=512, T=2000):
         fit.fit_bptt(x, target, optimizer="sgd", lr=1e-3, update_steps=100, sampling_steps=100, verbose=False)
         torch.cuda.synchronize()
         res["Network_fit_bptt_sgd_100_step_windows"] = (time.perf_counter() - t0) / T * 1e6
+        # RLS read-out training with an update every step (the reference's default update_steps = 1, network.py:786-856)
+        rls_net = Network(dt=1e-2, device=str(dev))
+        rls_net.add_diffeq_node("rnn", tanh, input_var="li_op/I_ext", output_var="tanh_op/r", weights=W * 0.5, source_var="tanh_op/r",
+                                target_var="li_op/r_in", dtype=torch.float32)
+        rls_net.add_func_node("out", 3, "identity")
+        rls_net.add_edge("rnn", "out", weights=torch.randn(3, N, device=dev, generator=gen) / N ** 0.5, train="rls")
+        rls_net.fit_rls(x[:200], target[:200], update_steps=1, sampling_steps=100, verbose=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rls_net.fit_rls(x, target, update_steps=1, sampling_steps=100, verbose=False)
+        torch.cuda.synchronize()
+        res["Network_fit_rls_update_every_step"] = (time.perf_counter() - t0) / T * 1e6
     # launch floor: dependent tiny kernels back to back on the stream
     z = torch.zeros(64, device=dev)
     for _ in range(200):
@@ -597,8 +609,9 @@ def small_n_extra(dev, N=512, T=2000):
                    "the vector handed from wave to wave as tagged 8-byte granules, bit-identical to a launch per step "
                    "(rectipy_amd/csrc/rp_resident.h); with one launch per step (RECTIPY_AMD_RESIDENT=0: `launch_per_step`) a step is bounded by "
                    "the dependent-launch interval of the stream and fit_bptt by the host's launch rate; fit_bptt adds the per-window work "
-                   "(W^T copy, dW GEMM, read-out, loss, optimiser)")
-    # the same two calls with one launch per step (the r04 path), for the record
+                   "(W^T copy, dW GEMM, read-out, loss, optimiser); fit_rls with an update every step: the RLS sweep of a window is one "
+                   "launch too (P and W in registers, one exchange per update; three launches per update before)")
+    # the same calls with one launch per step (the r04 path), for the record
     os.environ["RECTIPY_AMD_RESIDENT"] = "0"
     try:
         with contextlib.redirect_stdout(sys.stderr):
@@ -610,7 +623,12 @@ def small_n_extra(dev, N=512, T=2000):
             t0 = time.perf_counter()
             fit.fit_bptt(x, target, optimizer="sgd", lr=1e-3, update_steps=100, sampling_steps=100, verbose=False)
             torch.cuda.synchronize()
-            res["launch_per_step"] = {"Network_run": per_step_run, "Network_fit_bptt_sgd_100_step_windows": (time.perf_counter() - t0) / T * 1e6}
+            per_step_fit = (time.perf_counter() - t0) / T * 1e6
+            t0 = time.perf_counter()
+            rls_net.fit_rls(x, target, update_steps=1, sampling_steps=100, verbose=False)
+            torch.cuda.synchronize()
+            res["launch_per_step"] = {"Network_run": per_step_run, "Network_fit_bptt_sgd_100_step_windows": per_step_fit,
+                                      "Network_fit_rls_update_every_step": (time.perf_counter() - t0) / T * 1e6}
     finally:
         os.environ.pop("RECTIPY_AMD_RESIDENT", None)
     return res
