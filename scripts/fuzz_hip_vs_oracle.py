@@ -203,7 +203,9 @@ def main(cases=50, seed=0, max_n=2100):
                     tgt = (rng.standard_normal((Tr, 2))).astype(np.float32)
                     a, b = cpu.fit_ridge(xr, tgt, sampling_steps=1, alpha=1e-2, verbose=False), \
                         gpu.fit_ridge(xr, tgt, sampling_steps=1, alpha=1e-2, verbose=False)
-                    ok = close(a["w_out"].detach().numpy(), b["w_out"].detach().cpu().numpy(), 2e-4)
+                    # (T = n + 20 samples: an ill-conditioned solve -- behind a trained W, which differs by rounding between the two
+                    # devices, the read-out moves by more than behind identical states: docs/semantics.md, G39)
+                    ok = close(a["w_out"].detach().numpy(), b["w_out"].detach().cpu().numpy(), 5e-3 if trained else 2e-4)
             sa, sb = cpu.state["rnn"].detach().numpy(), gpu.state["rnn"].detach().cpu().numpy()
             if M.get("spike") and trained:
                 lo = 2 * n if name.startswith("ik") else n  # compare s: v (and IK's u) jump at a spike, which may land a step apart
