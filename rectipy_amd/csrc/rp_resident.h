@@ -14,8 +14,8 @@
 // others count themselves arrived and wait: they leave once all tickets are gone, or take what is left once EVERY workgroup
 // has arrived (the XCD got too few: the roster completes anyway, a little slower per step).  Nothing is written before the
 // roster is complete.  Every spin is bounded: a wave that waited for seconds (the GPU never ran all workgroups together) raises
-// `fail`, every wave that sees it leaves; the host learns of it without synchronising -- the word is copied to pinned memory
-// behind the launch and looked at by the library's next calls (rp_resident_poll) and by rp_async_status.
+// `fail` (the launch's own word: every wave that sees it leaves) and sets a sticky word in pinned host memory; the host learns of
+// it without synchronising -- the library's next calls (rp_resident_poll) and rp_async_status look at that word.
 #pragma once
 
 #include <atomic>
@@ -26,9 +26,11 @@
 struct rp_resident_ctl {
     unsigned long long* gran[2];  // [n] granules per parity
     int* fail;
+    int* host_fail;               // pinned host memory, mapped: set (never cleared by the device) when a wave of ANY launch timed out
     unsigned* ctl;                // [0] the XCD (+ 1) of the first workgroup to arrive, [1] tickets taken, [2] workgroups arrived
     int need_blocks, one_xcd;
     unsigned spin_cap;
+    int test_fault;               // (RECTIPY_AMD_RESIDENT_TEST_FAULT: element 0 is never handed on -- the tests' way to a timeout)
 };
 
 typedef __attribute__((address_space(1))) unsigned long long rp_gu64;
@@ -72,6 +74,7 @@ __device__ __forceinline__ int rp_resident_join(const rp_resident_ctl& C) {
                     if (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) break;
                     if (spins > C.spin_cap || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                         __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (C.host_fail) __hip_atomic_store(C.host_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         b = C.need_blocks;
                         break;
                     }
@@ -112,7 +115,10 @@ __device__ __forceinline__ bool rp_resident_sweep(const rp_resident_ctl& C, int 
         if (__all(ok)) return true;
         if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;   // (wave-uniform)
         if (spins > C.spin_cap) {
-            if (lane == 0) __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+                __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (C.host_fail) __hip_atomic_store(C.host_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             return false;   // (every wave sees the flag at its next sweep and leaves)
         }
         __builtin_amdgcn_s_sleep(1);
@@ -127,6 +133,7 @@ __device__ __forceinline__ void rp_resident_load_vec(rp_f4 (&r)[NC], const float
 }
 
 __device__ __forceinline__ void rp_resident_publish(const rp_resident_ctl& C, int parity, int row, unsigned tag, float value) {
+    if (C.test_fault && row == 0) return;
     __hip_atomic_store((rp_gu64*)C.gran[parity] + row, ((unsigned long long)tag << 32) | __float_as_uint(value), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -198,6 +205,25 @@ __device__ __forceinline__ float rp_resident_dots(const rp_f4 (&w)[RW][NC], cons
     }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
+// The sticky failure word: pinned host memory the device can write (one int per process), looked at by the library's next calls
+// (rp_resident_poll) and by rp_async_status -- no copy, no synchronisation.
+inline int* rp_resident_host_word(int** device_view) {
+    struct Word {
+        int* host = nullptr;
+        int* dev = nullptr;
+        Word() {
+            if (hipHostMalloc(reinterpret_cast<void**>(&host), 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+                host = nullptr;
+                return;
+            }
+            *host = 0;
+            if (hipHostGetDevicePointer(reinterpret_cast<void**>(&dev), host, 0) != hipSuccess) dev = nullptr;
+        }
+    };
+    static Word w;
+    if (device_view) *device_view = w.dev;
+    return w.host;
+}
 // stream-ordered scratch (granules, failure word, roster), zeroed: a tag is never 0
 inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** ws) {
     const size_t bytes = (size_t)2 * n * sizeof(unsigned long long) + 64;
@@ -208,51 +234,37 @@ inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** w
     C->gran[1] = C->gran[0] + n;
     C->fail = reinterpret_cast<int*>(C->gran[1] + n);
     C->ctl = reinterpret_cast<unsigned*>(C->fail) + 4;
+    (void)rp_resident_host_word(&C->host_fail);
     const int waves = (n + rp_resident_rows_per_wave(n) - 1) / rp_resident_rows_per_wave(n);
     C->need_blocks = (waves + kResidentWaves - 1) / kResidentWaves;
     C->one_xcd = C->need_blocks <= 8 ? 1 : 0;
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT_XCD"); e && e[0] == '0') C->one_xcd = 0;
     C->spin_cap = 1u << 22;   // polls of about a microsecond each: seconds
+    C->test_fault = 0;
+    if (const char* e = getenv("RECTIPY_AMD_RESIDENT_TEST_FAULT"); e && e[0] == '1') {   // (test seam: a peer that never delivers)
+        C->test_fault = 1;
+        C->spin_cap = 4000;
+    }
     return RP_OK;
 }
 inline unsigned rp_resident_grid(const rp_resident_ctl& C) { return (unsigned)(C.one_xcd ? 8 * C.need_blocks + 8 : C.need_blocks); }
 
-// A failure word travels to pinned host memory behind its launch (no synchronisation); the library's next calls look at the
-// slots that have landed (rp_resident_poll), rp_async_status lets a caller ask after it has synchronised.
-constexpr int kResidentSlots = 64;
-inline volatile int* rp_resident_slots() {
-    static int* slots = [] {
-        int* p = nullptr;
-        if (hipHostMalloc(reinterpret_cast<void**>(&p), kResidentSlots * sizeof(int), hipHostMallocDefault) != hipSuccess) return (int*)nullptr;
-        for (int i = 0; i < kResidentSlots; ++i) p[i] = 0;
-        return p;
-    }();
-    return slots;
-}
 inline int rp_resident_poll() {   // a resident launch that timed out since the last look?
-    volatile int* slots = rp_resident_slots();
-    bool bad = false;
-    for (int i = 0; slots && i < kResidentSlots; ++i)
-        if (slots[i] != 0) {
-            slots[i] = 0;
-            bad = true;
-        }
-    if (bad)
+    volatile int* word = rp_resident_host_word(nullptr);
+    if (word && *word != 0) {
+        *word = 0;
         RP_FAIL(RP_ERR_HIP, "a resident multi-step launch timed out waiting for a peer wave (its workgroups were never resident together: is "
                             "another kernel holding the GPU?); its results are not valid.  RECTIPY_AMD_RESIDENT=0 selects one launch per step");
+    }
     return RP_OK;
 }
 
-// after the launch: the failure word on its way to the host, the scratch back to the pool -- no synchronisation
+// after the launch: the scratch back to the pool -- no synchronisation
 inline int rp_resident_end(const rp_resident_ctl& C, void* ws, hipStream_t st, const char* what) {
-    static std::atomic<unsigned> next{0};
+    (void)C;
     const hipError_t launched = hipGetLastError();
-    volatile int* slots = rp_resident_slots();
-    hipError_t rc = hipSuccess;
-    if (slots) rc = hipMemcpyAsync(const_cast<int*>(slots) + next.fetch_add(1) % kResidentSlots, C.fail, sizeof(int), hipMemcpyDeviceToHost, st);
     (void)hipFreeAsync(ws, st);
     if (launched != hipSuccess) RP_FAIL(RP_ERR_HIP, "%s: %s", what, hipGetErrorString(launched));
-    if (rc != hipSuccess) RP_FAIL(RP_ERR_HIP, "%s: %s", what, hipGetErrorString(rc));
     return RP_OK;
 }
 

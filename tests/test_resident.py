@@ -167,6 +167,30 @@ def test_resident_rls_sweep_equals_the_launches(hip_device, monkeypatch, n_in, n
         same(got[0][key], got[1][key], f"rls n_in={n_in} n_out={n_out}: {key}")
 
 
+def test_a_timed_out_resident_launch_is_reported(hip_device, monkeypatch):
+    """A wave that waits in vain for a peer's element gives up after its bounded spin, every wave leaves, and the failure -- the one
+    thing a resident launch can only report afterwards -- reaches the host without a synchronisation inside the library: the next
+    library call (or rp_async_status after the caller synchronised) raises.  (RECTIPY_AMD_RESIDENT_TEST_FAULT: element 0 is never
+    handed on.)"""
+    from rectipy_amd.engine import default_backend
+    torch.cuda.synchronize()
+    default_backend().async_status()   # (nothing pending from the tests before)
+    monkeypatch.setenv("RECTIPY_AMD_RESIDENT_TEST_FAULT", "1")
+    pop = make("li_tanh", 512, hip_device)
+    pop.forward(12, x=torch.zeros(12, 512, device=hip_device))   # returns: the launch is asynchronous
+    torch.cuda.synchronize()
+    monkeypatch.delenv("RECTIPY_AMD_RESIDENT_TEST_FAULT")
+    with pytest.raises(RuntimeError, match="timed out waiting for a peer wave"):
+        default_backend().async_status()
+    default_backend().async_status()   # (reported once)
+    # the library is usable afterwards
+    good = make("li_tanh", 512, hip_device)
+    good.forward(12, x=torch.zeros(12, 512, device=hip_device))
+    torch.cuda.synchronize()
+    default_backend().async_status()
+    assert bool(torch.isfinite(good.v).all())
+
+
 def test_no_resident_launch_reported_a_timeout(hip_device):
     """After synchronising: no resident launch of this process (the tests above) timed out waiting for a peer wave."""
     from rectipy_amd.engine import default_backend
