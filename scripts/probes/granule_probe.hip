@@ -115,14 +115,17 @@ int run(const char* name, int one_xcd, int work) {
 
 int main() {
     // (workgroup scope -- sc0 loads and stores meeting in the XCD's L2 -- never sees the granules: measured, FAILED at the first sweep)
-    for (int round = 0; round < 2; ++round)
-        for (int work : {0, 40}) {
-            if (run<0, 2, 16>("agent scope, any placement", 0, work)) return 1;
-            if (run<0, 2, 16>("agent scope, one XCD", 1, work)) return 1;
-            if (run<0, 1, 16>("agent scope, any placement", 0, work)) return 1;
-            if (run<0, 1, 16>("agent scope, one XCD", 1, work)) return 1;
-            if (run<0, 4, 8>("agent scope, any placement", 0, work)) return 1;
-            if (run<0, 4, 16>("agent scope, any placement", 0, work)) return 1;
-        }
+    for (int work : {0, 40}) {
+        if (run<0, 2, 16>("agent scope, any placement", 0, work)) return 1;
+        if (run<0, 2, 16>("agent scope, one XCD", 1, work)) return 1;
+        if (run<0, 1, 16>("agent scope, any placement", 0, work)) return 1;
+        if (run<0, 1, 16>("agent scope, one XCD", 1, work)) return 1;
+        if (run<0, 3, 16>("agent scope, any placement", 0, work)) return 1;   // n = 768 with 16 rows per wave: 12 workgroups
+        if (run<0, 3, 16>("agent scope, one XCD", 1, work)) return 1;
+        if (run<0, 3, 8>("agent scope, any placement", 0, work)) return 1;    // ... with 8 rows per wave: 24
+        if (run<0, 4, 8>("agent scope, any placement", 0, work)) return 1;    // n = 1024: 32 workgroups
+        if (run<0, 4, 16>("agent scope, any placement", 0, work)) return 1;   // (16 rows per wave would not fit the registers: for reference)
+        if (run<0, 4, 16>("agent scope, one XCD", 1, work)) return 1;
+    }
     return 0;
 }
