@@ -55,6 +55,7 @@ __device__ __forceinline__ int rp_resident_join(const rp_resident_ctl& C) {
             __hip_atomic_compare_exchange_strong(ctl, &chosen, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (chosen == 0u) chosen = xcc;   // (this workgroup was the first)
             bool take = chosen == xcc;
+            if (C.one_xcd == 2) take = take && (blockIdx.x & 31u) == 0u;   // (test seam: the XCD "gets" too few workgroups)
             if (take) b = (int)__hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ticket, THEN arrival
             __hip_atomic_fetch_add(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!take) {   // another XCD: leave when the roster is complete, step in when everyone is here and it is not
@@ -239,6 +240,7 @@ inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** w
     C->need_blocks = (waves + kResidentWaves - 1) / kResidentWaves;
     C->one_xcd = C->need_blocks <= 8 ? 1 : 0;
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT_XCD"); e && e[0] == '0') C->one_xcd = 0;
+    else if (e && e[0] == '2' && C->one_xcd) C->one_xcd = 2;   // (tests: most of the roster has to come from the other XCDs)
     C->spin_cap = 1u << 22;   // polls of about a microsecond each: seconds
     C->test_fault = 0;
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT_TEST_FAULT"); e && e[0] == '1') {   // (test seam: a peer that never delivers)

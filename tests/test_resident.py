@@ -167,6 +167,26 @@ def test_resident_rls_sweep_equals_the_launches(hip_device, monkeypatch, n_in, n
         same(got[0][key], got[1][key], f"rls n_in={n_in} n_out={n_out}: {key}")
 
 
+@pytest.mark.parametrize("xcd", ["0", "2"], ids=["any-placement", "short-roster"])
+def test_the_roster_completes_on_any_placement(hip_device, monkeypatch, xcd):
+    """Placement is for speed only: with the one-XCD placement switched off, and with an XCD that "gets" too few workgroups (a test
+    switch: only every 32nd workgroup of the chosen XCD takes a ticket, the rest of the roster comes from the other XCDs once every
+    workgroup has arrived), the launch gives the bits of one launch per step."""
+    n, T = 512, 33
+    x = (torch.randn(T, n, generator=torch.Generator().manual_seed(2)) * 0.5).to(hip_device)
+    got = []
+    for resident in ("1", "0"):
+        monkeypatch.setenv("RECTIPY_AMD_RESIDENT", resident)
+        monkeypatch.setenv("RECTIPY_AMD_RESIDENT_XCD", xcd)
+        pop = make("li_tanh", n, hip_device)
+        traj = torch.zeros(T, n, device=hip_device)
+        for _ in range(3):
+            pop.forward(T, x=x, traj=traj)
+        got.append((traj, pop.v.clone()))
+    same(got[0][0], got[1][0], "traj")
+    same(got[0][1], got[1][1], "v")
+
+
 def test_a_timed_out_resident_launch_is_reported(hip_device, monkeypatch):
     """A wave that waits in vain for a peer's element gives up after its bounded spin, every wave leaves, and the failure -- the one
     thing a resident launch can only report afterwards -- reaches the host without a synchronisation inside the library: the next
