@@ -602,16 +602,17 @@ struct AdjResidentArgs {
     int64_t ldgx;
 };
 
-template <int NC, int RW, bool PARTIAL>
+template <class L>
 __global__ __launch_bounds__(kThreads) void resident_adj_kernel(const BwdParams P0, const AdjResidentArgs A) {
     static_assert(kThreads == 64 * kResidentWaves, "rp_resident.h counts four waves per workgroup");
+    constexpr int RW = L::RW;
     const int lane = threadIdx.x & (RP_WAVE - 1);
     const int block = rp_resident_join(A.C);
     if (block < 0) return;
     const int row_w0 = (block * kResidentWaves + (threadIdx.x >> 6)) * RW;
     BwdParams P = P0;
-    rp_f4 w[RW][NC];
-    rp_resident_load_rows<NC, RW>(w, P.W, P.ldw, row_w0, lane, P.n);   // (P.W: the transposed copy)
+    typename L::Rows rows;
+    L::load_rows(rows, P.W, P.ldw, row_w0, lane, P.n);   // (P.W: the transposed copy)
     const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
     const bool epi_lane = (lane & (64 / RW - 1)) == 0 && my_row < P.n;
     float lam_reg = epi_lane ? P0.lam[my_row] : 0.f;
@@ -633,13 +634,13 @@ __global__ __launch_bounds__(kThreads) void resident_adj_kernel(const BwdParams 
         } else {
             P.u_next = nullptr;
         }
-        rp_f4 r[NC];
+        typename L::Vec r;
         if (s == 0) {   // u_T: written by the prep launch in front of this one
-            rp_resident_load_vec<NC>(r, P.u, lane, P.n);
-        } else if (!rp_resident_sweep<NC>(A.C, (s - 1) & 1, (unsigned)s, r, lane, P.n)) {
+            L::load_vec(r, P.u, lane, P.n);
+        } else if (!L::sweep(A.C, (s - 1) & 1, (unsigned)s, r, lane, P.n)) {
             return;
         }
-        const float z = rp_resident_dots<NC, RW, PARTIAL>(w, r, row_w0, lane);
+        const float z = L::dots(rows, r, row_w0, lane);
         if (epi_lane) {
             float u;
             lam_reg = finalize_core(P, my_row, z, lam_reg, &u, G);
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(kThreads) void resident_adj_kernel(const BwdParams 
     if (epi_lane) rate_acc_store(P0, my_row, G);
 }
 
-int launch_resident_adj(const BwdParams& P, const rp_bwd* b, hipStream_t st) {
+int launch_resident_adj(const BwdParams& P, const rp_bwd* b, bool v4, hipStream_t st) {
     AdjResidentArgs A = {};
     A.steps = b->steps;
     A.u_traj = b->u_traj;
@@ -662,10 +663,10 @@ int launch_resident_adj(const BwdParams& P, const rp_bwd* b, hipStream_t st) {
     A.grad_x = b->grad_x;
     A.ldgx = b->ldgx;
     void* ws = nullptr;
-    if (rp_resident_begin(P.n, st, &A.C, &ws) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident adjoint sweep: no stream-ordered scratch");
+    if (rp_resident_begin(P.n, st, &A.C, &ws, v4) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident adjoint sweep: no stream-ordered scratch");
     const dim3 grid(rp_resident_grid(A.C));
-#define RP_LAUNCH_(NC_, RW_, PART_) hipLaunchKernelGGL((resident_adj_kernel<NC_, RW_, PART_>), grid, dim3(kThreads), 0, st, P, A)
-    RP_RESIDENT_DISPATCH(P.n, RP_LAUNCH_)
+#define RP_LAUNCH_(L_) hipLaunchKernelGGL((resident_adj_kernel<RP_UNPAREN L_>), grid, dim3(kThreads), 0, st, P, A)
+    RP_RESIDENT_DISPATCH_LAYOUT(P.n, v4, RP_LAUNCH_)
 #undef RP_LAUNCH_
     return rp_resident_end(A.C, ws, st, "the resident adjoint sweep");
 }
@@ -690,15 +691,16 @@ struct SpkResidentArgs {
     int64_t ldx;
 };
 
-template <int NC, int RW, bool PARTIAL>
+template <class L>
 __global__ __launch_bounds__(kThreads) void resident_spk_adj_kernel(const BwdParams P0, const SpkGrad G, const SpkResidentArgs A) {
+    constexpr int RW = L::RW;
     const int lane = threadIdx.x & (RP_WAVE - 1);
     const int block = rp_resident_join(A.C);
     if (block < 0) return;
     const int row_w0 = (block * kResidentWaves + (threadIdx.x >> 6)) * RW;
     BwdParams P = P0;
-    rp_f4 w[RW][NC];
-    rp_resident_load_rows<NC, RW>(w, P.W, P.ldw, row_w0, lane, P.n);   // (P.W: the transposed copy)
+    typename L::Rows rows;
+    L::load_rows(rows, P.W, P.ldw, row_w0, lane, P.n);   // (P.W: the transposed copy)
     const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
     const bool epi_lane = (lane & (64 / RW - 1)) == 0 && my_row < P.n;
     const int T = A.steps;
@@ -722,13 +724,13 @@ __global__ __launch_bounds__(kThreads) void resident_spk_adj_kernel(const BwdPar
         } else {
             P.u_next = nullptr;
         }
-        rp_f4 r[NC];
+        typename L::Vec r;
         if (s == 0) {
-            rp_resident_load_vec<NC>(r, P.u, lane, P.n);
-        } else if (!rp_resident_sweep<NC>(A.C, (s - 1) & 1, (unsigned)s, r, lane, P.n)) {
+            L::load_vec(r, P.u, lane, P.n);
+        } else if (!L::sweep(A.C, (s - 1) & 1, (unsigned)s, r, lane, P.n)) {
             return;
         }
-        const float z = rp_resident_dots<NC, RW, PARTIAL>(w, r, row_w0, lane);
+        const float z = L::dots(rows, r, row_w0, lane);
         if (epi_lane) {
             spk_finalize_elem(P, G, my_row, z);
             if (t > 0) rp_resident_publish(A.C, s & 1, my_row, (unsigned)(s + 1), P.u_next[my_row]);   // (this lane's own store)
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(kThreads) void resident_spk_adj_kernel(const BwdPar
     }
 }
 
-int launch_resident_spk_adj(const BwdParams& P, const SpkGrad& G, const rp_bwd* b, hipStream_t st) {
+int launch_resident_spk_adj(const BwdParams& P, const SpkGrad& G, const rp_bwd* b, bool v4, hipStream_t st) {
     SpkResidentArgs A = {};
     A.steps = b->steps;
     A.u_traj = b->u_traj;
@@ -753,10 +755,10 @@ int launch_resident_spk_adj(const BwdParams& P, const SpkGrad& G, const rp_bwd* 
     A.x = b->x;
     A.ldx = b->ldx;
     void* ws = nullptr;
-    if (rp_resident_begin(P.n, st, &A.C, &ws) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident adjoint sweep: no stream-ordered scratch");
+    if (rp_resident_begin(P.n, st, &A.C, &ws, v4) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident adjoint sweep: no stream-ordered scratch");
     const dim3 grid(rp_resident_grid(A.C));
-#define RP_LAUNCH_(NC_, RW_, PART_) hipLaunchKernelGGL((resident_spk_adj_kernel<NC_, RW_, PART_>), grid, dim3(kThreads), 0, st, P, G, A)
-    RP_RESIDENT_DISPATCH(P.n, RP_LAUNCH_)
+#define RP_LAUNCH_(L_) hipLaunchKernelGGL((resident_spk_adj_kernel<RP_UNPAREN L_>), grid, dim3(kThreads), 0, st, P, G, A)
+    RP_RESIDENT_DISPATCH_LAYOUT(P.n, v4, RP_LAUNCH_)
 #undef RP_LAUNCH_
     return rp_resident_end(A.C, ws, st, "the resident adjoint sweep");
 }
@@ -1034,10 +1036,9 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     if (use_wt) launch_transpose(net, b, st);
     set_prep(T - 1);
     hipLaunchKernelGGL(prep_kernel, dim3(eblocks), dim3(256), 0, st, P);
-    if (use_wt && vec4_t && rp_resident_enabled() && rp_resident_shape(n, b->ldwt) && T >= 4 && b->ld % 4 == 0 &&
-        !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u)) {
-        return launch_resident_adj(P, b, st);   // the whole sweep in one launch
-    }
+    if (use_wt && rp_resident_enabled() && T >= 4 &&
+        (vec4_t ? (rp_resident_shape(n, b->ldwt) && b->ld % 4 == 0 && !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u)) : rp_resident_shape_any(n)))
+        return launch_resident_adj(P, b, vec4_t, st);   // the whole sweep in one launch (the row-dot path the launches would take)
     for (int t = T - 1; t >= 0; --t) {
         P.t = t;
         P.u = b->u_traj + (int64_t)t * b->ld;
@@ -1892,9 +1893,10 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     spk_set_prep(b, P, T - 1);
     if (mean_coupled) hipLaunchKernelGGL(adj_mean_kernel, dim3(1), dim3(1024), 0, st, P);
     hipLaunchKernelGGL(spk_prep_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
-    if (use_wt && vec4_t && !mean_coupled && rp_resident_enabled() && rp_resident_shape(P.n, b->ldwt) && T >= 4 && b->ld % 4 == 0 &&
-        !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u))
-        return launch_resident_spk_adj(P, G, b, st);   // the whole sweep in one launch
+    if (use_wt && !mean_coupled && rp_resident_enabled() && T >= 4 &&
+        (vec4_t ? (rp_resident_shape(P.n, b->ldwt) && b->ld % 4 == 0 && !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u))
+                : rp_resident_shape_any(P.n)))
+        return launch_resident_spk_adj(P, G, b, vec4_t, st);   // the whole sweep in one launch
     for (int t = T - 1; t >= 0; --t) {
         P.u = b->u_traj + (int64_t)t * b->ld;
         if (!use_wt && !use_spt) launch_wt_partial(P, vec4, st);

@@ -410,16 +410,17 @@ __device__ __forceinline__ void resident_set_step(StepParams& P, const ResidentA
     }
 }
 
-template <int MODEL, int NC, int RW, bool PARTIAL>
+template <int MODEL, class L>
 __global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0, const ResidentArgs A) {
     static_assert(kWavesPerBlock == kResidentWaves, "rp_resident.h counts four waves per workgroup");
+    constexpr int RW = L::RW;
     const int lane = threadIdx.x & (RP_WAVE - 1);
     const int block = rp_resident_join(A.C);
     if (block < 0) return;
     const int row_w0 = (block * kWavesPerBlock + (threadIdx.x >> 6)) * RW;   // this wave's rows: [row_w0, row_w0 + RW)
     StepParams P = P0;
-    rp_f4 w[RW][NC];
-    rp_resident_load_rows<NC, RW>(w, P.W, P.ldw, row_w0, lane, P.n);
+    typename L::Rows rows;
+    L::load_rows(rows, P.W, P.ldw, row_w0, lane, P.n);
     int acc_count = A.acc_count0, sample_idx = A.sample_idx0;
     const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
     const bool epi_lane = (lane & (64 / RW - 1)) == 0 && my_row < P.n;   // (the lanes of a group hold the same row total after the butterfly)
@@ -437,13 +438,13 @@ __global__ __launch_bounds__(kThreads) void resident_kernel(const StepParams P0,
         P.spike_src = t == 0 ? P0.spike_src : nullptr;
         const float I_x = epi_lane ? input_current(P, my_row) : 0.f;   // (requested before the wait for the source vector)
         if constexpr (kRate) R.mv_tau = -v_reg / R.tau;
-        rp_f4 r[NC];
+        typename L::Vec r;
         if (t == 0) {
-            rp_resident_load_vec<NC>(r, P.src_cur, lane, P.n);
-        } else if (!rp_resident_sweep<NC>(A.C, (t - 1) & 1, (unsigned)t, r, lane, P.n)) {
+            L::load_vec(r, P.src_cur, lane, P.n);
+        } else if (!L::sweep(A.C, (t - 1) & 1, (unsigned)t, r, lane, P.n)) {
             return;
         }
-        const float total = rp_resident_dots<NC, RW, PARTIAL>(w, r, P.row0 + row_w0, lane);
+        const float total = L::dots(rows, r, P.row0 + row_w0, lane);
         if (epi_lane) {
             float v_new;
             s_reg = epilogue_core<MODEL>(P, my_row, total, 0.f, I_x, v_reg, s_reg, &v_new, kRate ? &R : nullptr);
@@ -1371,10 +1372,10 @@ int launch_population_step(const rp_net* net, const StepParams& P, hipStream_t s
 
 // ---- the resident launch (resident_kernel): eligibility and the call ------------------------------------------------------
 template <int MODEL>
-void launch_resident_model(const StepParams& P, const ResidentArgs& A, hipStream_t st) {
+void launch_resident_model(const StepParams& P, const ResidentArgs& A, bool v4, hipStream_t st) {
     const dim3 grid(rp_resident_grid(A.C));
-#define RP_LAUNCH_(NC_, RW_, PART_) hipLaunchKernelGGL((resident_kernel<MODEL, NC_, RW_, PART_>), grid, dim3(kThreads), 0, st, P, A)
-    RP_RESIDENT_DISPATCH(P.n, RP_LAUNCH_)
+#define RP_LAUNCH_(L_) hipLaunchKernelGGL((resident_kernel<MODEL, RP_UNPAREN L_>), grid, dim3(kThreads), 0, st, P, A)
+    RP_RESIDENT_DISPATCH_LAYOUT(P.n, v4, RP_LAUNCH_)
 #undef RP_LAUNCH_
 }
 
@@ -1385,8 +1386,10 @@ bool resident_ok(const rp_net* net, const rp_run* run) {
         net->model > RP_MODEL_IK_BIEXP)
         return false;
     if (net->sp_vals || run->n_edges > 0 || run->save_src_full || run->steps < kResidentMinSteps) return false;
-    if (net->rows != net->n || net->row0 != 0 || !rp_resident_shape(net->n, net->ldw)) return false;
-    return aligned16(net->W) && aligned16(net->src[0]) && aligned16(net->src[1]);
+    if (net->rows != net->n || net->row0 != 0) return false;
+    if (use_vec4(net))   // the 16-byte path of the per-step kernels, or their 4-byte path: the same rule, the same bits
+        return rp_resident_shape(net->n, net->ldw) && aligned16(net->W) && aligned16(net->src[0]) && aligned16(net->src[1]);
+    return rp_resident_shape_any(net->n);
 }
 
 int forward_resident(rp_net* net, rp_run* run, StepParams& P, hipStream_t st) {
@@ -1417,15 +1420,16 @@ int forward_resident(rp_net* net, rp_run* run, StepParams& P, hipStream_t st) {
     A.samples = run->samples;
     A.ldsamples = run->ldsamples;
     void* ws = nullptr;
-    if (rp_resident_begin(net->n, st, &A.C, &ws) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident step kernel: no stream-ordered scratch");
+    const bool v4 = use_vec4(net);
+    if (rp_resident_begin(net->n, st, &A.C, &ws, v4) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident step kernel: no stream-ordered scratch");
     set_step(P, net, run, 0);   // (step 0's arguments -- the kernel forms every step's itself; the bookkeeping is advanced below)
     switch (net->model) {
-        case RP_MODEL_LI_TANH: launch_resident_model<RP_MODEL_LI_TANH>(P, A, st); break;
-        case RP_MODEL_LI_SIGMOID: launch_resident_model<RP_MODEL_LI_SIGMOID>(P, A, st); break;
-        case RP_MODEL_QIF: launch_resident_model<RP_MODEL_QIF>(P, A, st); break;
-        case RP_MODEL_QIF_SFA: launch_resident_model<RP_MODEL_QIF_SFA>(P, A, st); break;
-        case RP_MODEL_LIF: launch_resident_model<RP_MODEL_LIF>(P, A, st); break;
-        default: launch_resident_model<RP_MODEL_IK>(P, A, st); break;
+        case RP_MODEL_LI_TANH: launch_resident_model<RP_MODEL_LI_TANH>(P, A, v4, st); break;
+        case RP_MODEL_LI_SIGMOID: launch_resident_model<RP_MODEL_LI_SIGMOID>(P, A, v4, st); break;
+        case RP_MODEL_QIF: launch_resident_model<RP_MODEL_QIF>(P, A, v4, st); break;
+        case RP_MODEL_QIF_SFA: launch_resident_model<RP_MODEL_QIF_SFA>(P, A, v4, st); break;
+        case RP_MODEL_LIF: launch_resident_model<RP_MODEL_LIF>(P, A, v4, st); break;
+        default: launch_resident_model<RP_MODEL_IK>(P, A, v4, st); break;
     }
     const int rc = rp_resident_end(A.C, ws, st, "the resident step kernel");
     if (rc != RP_OK) return rc;
@@ -1477,7 +1481,7 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     const StreamCfg stream_cfg = choose_cfg(net);
     StepParams P = {};
     init_params(P, net, run);
-    if (!comm && vec4 && resident_ok(net, run)) return forward_resident(net, run, P, st);
+    if (!comm && resident_ok(net, run)) return forward_resident(net, run, P, st);
 
     for (int t = 0; t < run->steps; ++t) {
         const int64_t t_abs = run->step0 + t;

@@ -1,4 +1,4 @@
-// rp_resident.h -- the machinery of the resident multi-step kernels (launch-bound sizes: n <= 1024, n % 4 == 0): the forward
+// rp_resident.h -- the machinery of the resident multi-step kernels (launch-bound sizes: n <= 1024): the forward
 // step (rnn_forward.hip: resident_kernel) and the adjoint sweeps on the transposed copy (rnn_backward.hip: resident_adj_kernel for
 // the rate models, resident_spk_adj_kernel for the spiking ones).
 //
@@ -192,6 +192,119 @@ __device__ __forceinline__ float rp_resident_dots(const rp_f4 (&w)[RW][NC], cons
     return rp_rows_allreduce<RW>(rs, lane);
 }
 
+// ---- the two row-dot contracts as layouts of a wave's registers ------------------------------------------------------------------
+// 16-byte path (rp_dot_rows_v4: n % 4 == 0, ld % 4 == 0): lane l holds columns 256 m + 4 l .. + 3 of NC chunks
+template <int NC, int RW_, bool PARTIAL>
+struct rp_layout_v4 {
+    static constexpr int RW = RW_;
+    struct Vec {
+        rp_f4 c[NC];
+    };
+    struct Rows {
+        rp_f4 w[RW_][NC];
+    };
+    static __device__ __forceinline__ void load_rows(Rows& R, const float* W, int64_t ldw, int row_w0, int lane, int n) {
+        rp_resident_load_rows<NC, RW_>(R.w, W, ldw, row_w0, lane, n);
+    }
+    static __device__ __forceinline__ void load_vec(Vec& v, const float* src, int lane, int n) { rp_resident_load_vec<NC>(v.c, src, lane, n); }
+    static __device__ __forceinline__ bool sweep(const rp_resident_ctl& C, int parity, unsigned want, Vec& v, int lane, int n) {
+        return rp_resident_sweep<NC>(C, parity, want, v.c, lane, n);
+    }
+    static __device__ __forceinline__ float dots(const Rows& R, const Vec& v, int global_row_w0, int lane) {
+        return rp_resident_dots<NC, RW_, PARTIAL>(R.w, v.c, global_row_w0, lane);
+    }
+};
+
+// 4-byte path (rp_dot_rows_s1: any n and ld): lane l holds columns l + 64 k of KC strides (zeros past n), ONE accumulator per row
+// fed in ascending k, then the wave butterfly
+template <int KC, int RW_>
+struct rp_layout_s1 {
+    static constexpr int RW = RW_;
+    struct Vec {
+        float c[KC];
+    };
+    struct Rows {
+        float w[RW_][KC];
+    };
+    static __device__ __forceinline__ void load_rows(Rows& R, const float* W, int64_t ldw, int row_w0, int lane, int n) {
+#pragma unroll
+        for (int j = 0; j < RW_; ++j)
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                R.w[j][k] = (row_w0 + j < n && lane + 64 * k < n) ? W[(int64_t)(row_w0 + j) * ldw + lane + 64 * k] : 0.f;
+    }
+    static __device__ __forceinline__ void load_vec(Vec& v, const float* src, int lane, int n) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) v.c[k] = lane + 64 * k < n ? src[lane + 64 * k] : 0.f;
+    }
+    static __device__ __forceinline__ bool sweep(const rp_resident_ctl& C, int parity, unsigned want, Vec& v, int lane, int n) {
+        const rp_gu64* g = (const rp_gu64*)C.gran[parity] + lane;
+        rp_gi32* const fail = (rp_gi32*)C.fail;
+        for (unsigned spins = 0;; ++spins) {
+            bool ok = true;
+            unsigned long long q[KC];
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                q[k] = lane + 64 * k < n ? __hip_atomic_load(g + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)want << 32);
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                ok = ok && (unsigned)(q[k] >> 32) == want;
+                v.c[k] = __uint_as_float((unsigned)q[k]);
+            }
+            if (__all(ok)) return true;
+            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (spins > C.spin_cap) {
+                if (lane == 0) {
+                    __hip_atomic_store(fail, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (C.host_fail) __hip_atomic_store(C.host_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    static __device__ __forceinline__ float dots(const Rows& R, const Vec& v, int /*global_row_w0*/, int lane) {
+        float rs[RW_];
+#pragma unroll
+        for (int j = 0; j < RW_; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) a = fmaf(R.w[j][k], v.c[k], a);
+            rs[j] = a;
+        }
+        return rp_rows_allreduce<RW_>(rs, lane);
+    }
+};
+constexpr int rp_resident_strides_s1(int n) {   // 64-column strides per lane, rounded up to a power of two (zero-padded)
+    const int k = (n + 63) / 64;
+    return k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : (k <= 8 ? 8 : 16)));
+}
+constexpr int rp_resident_rows_per_wave_s1(int n) { return rp_resident_strides_s1(n) >= 16 ? 8 : 16; }
+
+#define RP_UNPAREN(...) __VA_ARGS__
+// the launch: LAUNCH((layout type)) for n columns on the 16-byte path (v4 = true) or the 4-byte path
+#define RP_RESIDENT_DISPATCH_LAYOUT(n_, v4_, LAUNCH)                                       \
+    if (v4_) {                                                                             \
+        switch (rp_resident_chunks(n_) * 2 + ((n_) % 256 != 0 ? 1 : 0)) {                 \
+            case 2: LAUNCH((rp_layout_v4<1, 16, false>)); break;                           \
+            case 3: LAUNCH((rp_layout_v4<1, 16, true>)); break;                            \
+            case 4: LAUNCH((rp_layout_v4<2, 16, false>)); break;                           \
+            case 5: LAUNCH((rp_layout_v4<2, 16, true>)); break;                            \
+            case 6: LAUNCH((rp_layout_v4<3, 8, false>)); break;                            \
+            case 7: LAUNCH((rp_layout_v4<3, 8, true>)); break;                             \
+            case 8: LAUNCH((rp_layout_v4<4, 8, false>)); break;                            \
+            default: LAUNCH((rp_layout_v4<4, 8, true>)); break;                            \
+        }                                                                                  \
+    } else {                                                                               \
+        switch (rp_resident_strides_s1(n_)) {                                              \
+            case 1: LAUNCH((rp_layout_s1<1, 16>)); break;                                  \
+            case 2: LAUNCH((rp_layout_s1<2, 16>)); break;                                  \
+            case 4: LAUNCH((rp_layout_s1<4, 16>)); break;                                  \
+            case 8: LAUNCH((rp_layout_s1<8, 16>)); break;                                  \
+            default: LAUNCH((rp_layout_s1<16, 8>)); break;                                 \
+        }                                                                                  \
+    }
+
 // the launch: kernel template K<NC, RW, PARTIAL> for n columns
 #define RP_RESIDENT_DISPATCH(n_, LAUNCH)                                   \
     switch (rp_resident_chunks(n_) * 2 + ((n_) % 256 != 0 ? 1 : 0)) {     \
@@ -226,7 +339,7 @@ inline int* rp_resident_host_word(int** device_view) {
     return w.host;
 }
 // stream-ordered scratch (granules, failure word, roster), zeroed: a tag is never 0
-inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** ws) {
+inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** ws, bool v4 = true) {
     const size_t bytes = (size_t)2 * n * sizeof(unsigned long long) + 64;
     *ws = nullptr;
     if (hipMallocAsync(ws, bytes, st) != hipSuccess) return RP_ERR_HIP;
@@ -236,7 +349,8 @@ inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** w
     C->fail = reinterpret_cast<int*>(C->gran[1] + n);
     C->ctl = reinterpret_cast<unsigned*>(C->fail) + 4;
     (void)rp_resident_host_word(&C->host_fail);
-    const int waves = (n + rp_resident_rows_per_wave(n) - 1) / rp_resident_rows_per_wave(n);
+    const int rw = v4 ? rp_resident_rows_per_wave(n) : rp_resident_rows_per_wave_s1(n);
+    const int waves = (n + rw - 1) / rw;
     C->need_blocks = (waves + kResidentWaves - 1) / kResidentWaves;
     C->one_xcd = C->need_blocks <= 8 ? 1 : 0;
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT_XCD"); e && e[0] == '0') C->one_xcd = 0;
@@ -272,6 +386,8 @@ inline int rp_resident_end(const rp_resident_ctl& C, void* ws, hipStream_t st, c
 
 // n <= 1024 on the 16-byte path
 inline bool rp_resident_shape(int n, int64_t ld) { return n >= 4 && n <= 1024 && n % 4 == 0 && ld % 4 == 0; }
+// ... or on the 4-byte path (any n, any leading dimension)
+inline bool rp_resident_shape_any(int n) { return n >= 1 && n <= 1024; }
 
 inline bool rp_resident_enabled() {
     const char* e = getenv("RECTIPY_AMD_RESIDENT");   // (read per call: tests compare both paths)

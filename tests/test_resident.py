@@ -40,7 +40,10 @@ def make(model, n, dev, seed=0):
                                      ("qif", 512), ("qif", 1024), ("lif", 256),
                                      # ragged sizes: a partial last chunk, rows that do not fill the last wave, fewer than 256 columns
                                      ("li_tanh", 8), ("li_tanh", 100), ("li_tanh", 260), ("li_tanh", 500), ("li_tanh", 1000), ("li_sigmoid", 200),
-                                     ("qif", 300), ("lif", 772)])
+                                     ("qif", 300), ("lif", 772),
+                                     # n % 4 != 0: the 4-byte row-dot path (lane l: columns l, l + 64, ...) -- its own resident layout
+                                     ("li_tanh", 5), ("li_tanh", 50), ("li_tanh", 125), ("li_tanh", 250), ("li_tanh", 999), ("li_sigmoid", 301),
+                                     ("qif", 10), ("qif", 1023), ("lif", 150)])
 def test_resident_launch_equals_a_launch_per_step(hip_device, monkeypatch, model, n):
     T = 57
     gen = torch.Generator().manual_seed(3)
@@ -83,7 +86,8 @@ def test_broadcast_and_projected_inputs(hip_device, monkeypatch):
 
 
 @pytest.mark.parametrize("model,n", [("li_tanh", 256), ("li_tanh", 512), ("li_tanh", 768), ("li_tanh", 1024), ("li_sigmoid", 512),
-                                     ("li_tanh", 12), ("li_tanh", 100), ("li_tanh", 500), ("li_tanh", 1000), ("li_sigmoid", 644)])
+                                     ("li_tanh", 12), ("li_tanh", 100), ("li_tanh", 500), ("li_tanh", 1000), ("li_sigmoid", 644),
+                                     ("li_tanh", 5), ("li_tanh", 50), ("li_tanh", 250), ("li_tanh", 1001), ("li_sigmoid", 125)])
 @pytest.mark.parametrize("grad_var", [_abi.RP_OUT_STATE0, _abi.RP_OUT_SOURCE])
 def test_resident_adjoint_sweep_equals_a_launch_per_step(hip_device, monkeypatch, model, n, grad_var):
     """The rate models' adjoint (transposed-copy sweep) in ONE launch against one launch per adjoint step: adjoint state, u, input
@@ -112,7 +116,7 @@ def test_resident_adjoint_sweep_equals_a_launch_per_step(hip_device, monkeypatch
         same(got[0][key], got[1][key], f"{model} n={n}: {key}")
 
 
-@pytest.mark.parametrize("n", [256, 512, 1024, 100, 500, 900])
+@pytest.mark.parametrize("n", [256, 512, 1024, 100, 500, 900, 10, 250, 999])
 @pytest.mark.parametrize("grad_var,xw", [(_abi.RP_OUT_SOURCE, "full"), (_abi.RP_OUT_STATE0, "bcast")])
 def test_resident_spiking_adjoint_sweep_equals_a_launch_per_step(hip_device, monkeypatch, n, grad_var, xw):
     """The spiking sweep (QIF: resets, surrogate gradient) in ONE launch against one launch per adjoint step, bit for bit."""
