@@ -171,6 +171,31 @@ def test_resident_rls_sweep_equals_the_launches(hip_device, monkeypatch, n_in, n
         same(got[0][key], got[1][key], f"rls n_in={n_in} n_out={n_out}: {key}")
 
 
+def test_random_shapes_and_windows_keep_the_bits(hip_device, monkeypatch):
+    """Forty random (size, model, window length) draws -- any n up to 1024, both row-dot paths --, three consecutive windows each: the
+    resident launch and the launch per step leave the same trajectories and states (a fixed-seed slice of
+    scripts/probes/resident_soak.py)."""
+    rng = np.random.default_rng(12)
+    for case in range(40):
+        n = int(rng.integers(1, 257)) * 4 if rng.integers(0, 3) else int(rng.integers(1, 1025))
+        model = ["li_tanh", "qif"][int(rng.integers(0, 2))]
+        pops = []
+        for resident in ("1", "0"):
+            monkeypatch.setenv("RECTIPY_AMD_RESIDENT", resident)
+            pops.append(make(model, n, hip_device, seed=case))
+        for w in range(3):
+            T = int(rng.integers(4, 60))
+            x = (torch.randn(T, n, generator=torch.Generator().manual_seed(case * 7 + w)) * 0.5 + (1.5 if model == "qif" else 0.0)).to(hip_device)
+            outs = []
+            for resident, pop in zip(("1", "0"), pops):
+                monkeypatch.setenv("RECTIPY_AMD_RESIDENT", resident)
+                traj = torch.zeros(T, n, device=hip_device)
+                pop.forward(T, x=x, traj=traj, out_var=_abi.RP_OUT_SOURCE)
+                outs.append((traj, pop.v.clone(), pop.source.clone()))
+            for a, b, name in zip(outs[0], outs[1], ("traj", "v", "source")):
+                same(a, b, f"case {case} ({model}, n={n}, window {w}, T={T}): {name}")
+
+
 @pytest.mark.parametrize("xcd", ["0", "2"], ids=["any-placement", "short-roster"])
 def test_the_roster_completes_on_any_placement(hip_device, monkeypatch, xcd):
     """Placement is for speed only: with the one-XCD placement switched off, and with an XCD that "gets" too few workgroups (a test
