@@ -300,26 +300,6 @@ struct RlsResidentArgs {
     float beta_inv;
 };
 
-// the scalar kernel's dot product (rls_scalars_kernel) from operands in the lane layout of the row dots; every lane gets the total
-template <int NC>
-__device__ __forceinline__ float rls_tree_dot(const rp_f4 (&u)[NC], const rp_f4 (&x)[NC]) {
-    const rp_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    rp_f4 a[NC];
-#pragma unroll
-    for (int m = 0; m < NC; ++m) a[m] = rp_fma4(u[m], x[m], zero4);
-    rp_f4 b0 = a[0], b1 = zero4;   // level 512: leaf j + leaf j + 512 (chunks m and m + 2); absent chunks are zeros: x + 0 == x
-    if constexpr (NC > 2) b0 = a[0] + a[2];
-    if constexpr (NC > 1) b1 = a[1];
-    if constexpr (NC > 3) b1 = a[1] + a[3];
-    rp_f4 c = b0;
-    if constexpr (NC > 1) c = b0 + b1;   // level 256
-    c.x = rp_wave_allreduce(c.x);        // levels 128 .. 4: lane l with lane l ^ 32, 16, 8, 4, 2, 1
-    c.y = rp_wave_allreduce(c.y);
-    c.z = rp_wave_allreduce(c.z);
-    c.w = rp_wave_allreduce(c.w);
-    return (c.x + c.z) + (c.y + c.w);    // levels 2 and 1
-}
-
 // the lane that holds row j of a wave after rp_rows_allreduce<RW> (the inverse of rp_rows_allreduce_row)
 template <int RW>
 __host__ __device__ constexpr int rls_lane_of_row(int j) {
@@ -329,50 +309,50 @@ __host__ __device__ constexpr int rls_lane_of_row(int j) {
     return lane;
 }
 
-template <int NC, int RW, bool PARTIAL>
+// L: the register layout of the dense pass's row-dot path (rp_resident.h: rp_layout_v4 on the 16-byte path, rp_layout_s1 else)
+template <class L>
 __global__ __launch_bounds__(kThreads) void resident_rls_kernel(const RlsResidentArgs A) {
     static_assert(kThreads == 64 * kResidentWaves, "rp_resident.h counts four waves per workgroup");
     constexpr int NO = 4;   // rows of W a wave carries (n_out <= 4)
+    constexpr int RW = L::RW;
     const int lane = threadIdx.x & (RP_WAVE - 1);
     const int block = rp_resident_join(A.C);
     if (block < 0) return;
     const int gw = block * kResidentWaves + (threadIdx.x >> 6);
     const int row_w0 = gw * RW;
     const int n = A.n_in;
-    const rp_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    rp_f4 p[RW][NC];
-    rp_resident_load_rows<NC, RW>(p, A.P, A.ldp, row_w0, lane, n);
-    rp_f4 wv[NO][NC];
+    typename L::Rows p;
+    L::load_rows(p, A.P, A.ldp, row_w0, lane, n);
+    typename L::Vec wv[NO];
 #pragma unroll
-    for (int o = 0; o < NO; ++o)
-#pragma unroll
-        for (int m = 0; m < NC; ++m)
-            wv[o][m] = (o < A.n_out && 256 * m + 4 * lane < n) ? rp_ld4(A.W + (int64_t)o * A.ldw + 256 * m + 4 * lane) : zero4;
+    for (int o = 0; o < NO; ++o) {
+        if (o < A.n_out) L::load_vec(wv[o], A.W + (int64_t)o * A.ldw, lane, n);
+        else L::zero_vec(wv[o]);
+    }
     const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
     const bool epi_lane = (lane & (64 / RW - 1)) == 0 && my_row < n;
-    rp_f4 x[NC], z[NC];
+    typename L::Vec x, z;
     float zi[RW];   // z of the wave's own rows (uniform)
-    // z_0 = beta^-1 P x_0: the row dots of the pass kernel -- chunks ascending, no stagger --, lane sum, butterfly
+    // z = beta^-1 P x: the row dots of the pass kernel -- chunks ascending, no stagger --, lane sum, butterfly
     auto dots = [&](int q) -> bool {   // publishes exchange q (tag q + 1, parity q & 1) and gathers z; false: give up
-        const float total = rp_resident_dots<NC, RW, PARTIAL, false>(p, x, 0, lane);   // (no stagger: every row starts at chunk 0)
-        const float zt = A.beta_inv * total;
+        const float zt = A.beta_inv * L::dots_plain(p, x, lane);
 #pragma unroll
         for (int j = 0; j < RW; ++j) zi[j] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(zt), rls_lane_of_row<RW>(j)));
         if (epi_lane) rp_resident_publish(A.C, q & 1, my_row, (unsigned)(q + 1), zt);
-        return rp_resident_sweep<NC>(A.C, q & 1, (unsigned)(q + 1), z, lane, n);
+        return L::sweep(A.C, q & 1, (unsigned)(q + 1), z, lane, n);
     };
-    rp_resident_load_vec<NC>(x, A.X, lane, n);
+    L::load_vec(x, A.X, lane, n);
     if (!dots(0)) return;
     for (int t = 0; t < A.updates; ++t) {
         // scalars: d = x . z, k, y_hat = W x, err, loss
-        const float d = rls_tree_dot<NC>(z, x);
+        const float d = L::tree_dot(z, x);
         const float k = 1.0f / (1.0f + d);
         float err[NO], loss = 0.f;
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
             err[o] = 0.f;
             if (o < A.n_out) {   // (uniform)
-                const float yhat = rls_tree_dot<NC>(wv[o], x);
+                const float yhat = L::tree_dot(wv[o], x);
                 const float e = A.Y[(int64_t)t * A.ldy + o] - yhat;
                 loss = fmaf(e, e, loss);
                 err[o] = e;
@@ -382,52 +362,27 @@ __global__ __launch_bounds__(kThreads) void resident_rls_kernel(const RlsResiden
         if (gw == 0 && lane == 0 && A.loss) A.loss[t] = loss;
         // weights: W_o += (k err_o) z
 #pragma unroll
-        for (int o = 0; o < NO; ++o) {
-            if (o < A.n_out) {
-                const float ke = k * err[o];
-#pragma unroll
-                for (int m = 0; m < NC; ++m) {
-                    wv[o][m].x = wv[o][m].x + ke * z[m].x;
-                    wv[o][m].y = wv[o][m].y + ke * z[m].y;
-                    wv[o][m].z = wv[o][m].z + ke * z[m].z;
-                    wv[o][m].w = wv[o][m].w + ke * z[m].w;
-                }
-            }
-        }
+        for (int o = 0; o < NO; ++o)
+            if (o < A.n_out) L::add_scaled(wv[o], k * err[o], z);
         // the pass: p -= (k z_i) z_j, then the row dots with the next input
 #pragma unroll
-        for (int j = 0; j < RW; ++j) {
-            const float kz = k * zi[j];
-#pragma unroll
-            for (int m = 0; m < NC; ++m) {
-                p[j][m].x = p[j][m].x - kz * z[m].x;
-                p[j][m].y = p[j][m].y - kz * z[m].y;
-                p[j][m].z = p[j][m].z - kz * z[m].z;
-                p[j][m].w = p[j][m].w - kz * z[m].w;
-            }
-        }
+        for (int j = 0; j < RW; ++j) L::row_sub_scaled(p, j, k * zi[j], z);
         if (t + 1 < A.updates) {
-            rp_resident_load_vec<NC>(x, A.X + (int64_t)(t + 1) * A.ldx, lane, n);
+            L::load_vec(x, A.X + (int64_t)(t + 1) * A.ldx, lane, n);
             if (!dots(t + 1)) return;
         }
     }
     // the state back to memory: every wave its rows of P, the first wave W
-#pragma unroll
-    for (int j = 0; j < RW; ++j)
-#pragma unroll
-        for (int m = 0; m < NC; ++m)
-            if (row_w0 + j < n && 256 * m + 4 * lane < n) *reinterpret_cast<rp_f4*>(A.P + (int64_t)(row_w0 + j) * A.ldp + 256 * m + 4 * lane) = p[j][m];
+    L::store_rows(p, A.P, A.ldp, row_w0, lane, n);
     if (gw == 0) {
 #pragma unroll
         for (int o = 0; o < NO; ++o)
-#pragma unroll
-            for (int m = 0; m < NC; ++m)
-                if (o < A.n_out && 256 * m + 4 * lane < n) *reinterpret_cast<rp_f4*>(A.W + (int64_t)o * A.ldw + 256 * m + 4 * lane) = wv[o][m];
+            if (o < A.n_out) L::store_vec(wv[o], A.W + (int64_t)o * A.ldw, lane, n);
     }
 }
 
 int launch_resident_rls(const rp_rls* r, int32_t steps, const float* X, int64_t ldx, const float* Y, int64_t ldy, float* pred,
-                        int64_t ldpred, float* loss, hipStream_t st) {
+                        int64_t ldpred, float* loss, bool v4, hipStream_t st) {
     RlsResidentArgs A = {};
     A.updates = steps;
     A.n_in = r->n_in;
@@ -445,10 +400,10 @@ int launch_resident_rls(const rp_rls* r, int32_t steps, const float* X, int64_t 
     A.ldw = r->ldw;
     A.beta_inv = r->beta_inv;
     void* ws = nullptr;
-    if (rp_resident_begin(r->n_in, st, &A.C, &ws) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident RLS sweep: no stream-ordered scratch");
+    if (rp_resident_begin(r->n_in, st, &A.C, &ws, v4) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident RLS sweep: no stream-ordered scratch");
     const dim3 grid(rp_resident_grid(A.C));
-#define RP_LAUNCH_(NC_, RW_, PART_) hipLaunchKernelGGL((resident_rls_kernel<NC_, RW_, PART_>), grid, dim3(kThreads), 0, st, A)
-    RP_RESIDENT_DISPATCH(r->n_in, RP_LAUNCH_)
+#define RP_LAUNCH_(L_) hipLaunchKernelGGL((resident_rls_kernel<RP_UNPAREN L_>), grid, dim3(kThreads), 0, st, A)
+    RP_RESIDENT_DISPATCH_LAYOUT(r->n_in, v4, RP_LAUNCH_)
 #undef RP_LAUNCH_
     return rp_resident_end(A.C, ws, st, "the resident RLS sweep");
 }
@@ -1531,10 +1486,11 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
     }
     // launch-bound sizes, an update every step: the whole sweep in one launch
     // (the row-per-wave pass only: the tiled pass -- rp_rls.partials -- sums a row in its own order)
-    if (!sym && !r->partials && vec4 && stride == 1 && steps >= 4 && r->n_out <= 4 && rp_resident_enabled() && rp_resident_shape(r->n_in, r->ldp) &&
-        r->ldw % 4 == 0 && !(reinterpret_cast<uintptr_t>(r->W) & 15u) && g_rls_nts < 0) {
+    // (either row-dot path of that pass: the 16-byte one, or -- n_in % 4 != 0, up to 512 inputs: its registers -- the 4-byte one)
+    if (!sym && !r->partials && stride == 1 && steps >= 4 && r->n_out <= 4 && rp_resident_enabled() && g_rls_nts < 0 &&
+        (vec4 ? (rp_resident_shape(r->n_in, r->ldp) && r->ldw % 4 == 0 && !(reinterpret_cast<uintptr_t>(r->W) & 15u)) : r->n_in <= 512)) {
         if (const int prc = rp_resident_poll(); prc != RP_OK) return prc;
-        return launch_resident_rls(r, steps, X, ldx, Y, ldy, pred, ldpred, loss, st);
+        return launch_resident_rls(r, steps, X, ldx, Y, ldy, pred, ldpred, loss, vec4, st);
     }
     float* za = r->z;
     float* zb = r->zn;

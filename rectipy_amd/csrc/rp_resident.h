@@ -213,6 +213,63 @@ struct rp_layout_v4 {
     static __device__ __forceinline__ float dots(const Rows& R, const Vec& v, int global_row_w0, int lane) {
         return rp_resident_dots<NC, RW_, PARTIAL>(R.w, v.c, global_row_w0, lane);
     }
+    // ---- the RLS sweep's operations in this layout ----
+    static __device__ __forceinline__ float dots_plain(const Rows& R, const Vec& v, int lane) {   // every row from chunk 0 on
+        return rp_resident_dots<NC, RW_, PARTIAL, false>(R.w, v.c, 0, lane);
+    }
+    // rls_scalars_kernel's dot product: leaf j = fmaf(u_j, x_j, 0), then the 1024-leaf tree -- levels 512 / 256: a lane's own
+    // chunks, levels 128 .. 4: the wave butterfly, levels 2 / 1: (x + z) + (y + w) of the lane's components
+    static __device__ __forceinline__ float tree_dot(const Vec& u, const Vec& x) {
+        const rp_f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        rp_f4 a[NC];
+#pragma unroll
+        for (int m = 0; m < NC; ++m) a[m] = rp_fma4(u.c[m], x.c[m], zero4);
+        rp_f4 b0 = a[0], b1 = zero4;
+        if constexpr (NC > 2) b0 = a[0] + a[2];
+        if constexpr (NC > 1) b1 = a[1];
+        if constexpr (NC > 3) b1 = a[1] + a[3];
+        rp_f4 c = b0;
+        if constexpr (NC > 1) c = b0 + b1;
+        c.x = rp_wave_allreduce(c.x);
+        c.y = rp_wave_allreduce(c.y);
+        c.z = rp_wave_allreduce(c.z);
+        c.w = rp_wave_allreduce(c.w);
+        return (c.x + c.z) + (c.y + c.w);
+    }
+    static __device__ __forceinline__ void add_scaled(Vec& w, float a, const Vec& z) {   // w = w + a z (product, then sum)
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+            w.c[m].x = w.c[m].x + a * z.c[m].x;
+            w.c[m].y = w.c[m].y + a * z.c[m].y;
+            w.c[m].z = w.c[m].z + a * z.c[m].z;
+            w.c[m].w = w.c[m].w + a * z.c[m].w;
+        }
+    }
+    static __device__ __forceinline__ void row_sub_scaled(Rows& R, int j, float a, const Vec& z) {   // row j: p = p - a z
+#pragma unroll
+        for (int m = 0; m < NC; ++m) {
+            R.w[j][m].x = R.w[j][m].x - a * z.c[m].x;
+            R.w[j][m].y = R.w[j][m].y - a * z.c[m].y;
+            R.w[j][m].z = R.w[j][m].z - a * z.c[m].z;
+            R.w[j][m].w = R.w[j][m].w - a * z.c[m].w;
+        }
+    }
+    static __device__ __forceinline__ void zero_vec(Vec& v) {
+#pragma unroll
+        for (int m = 0; m < NC; ++m) v.c[m] = rp_f4{0.f, 0.f, 0.f, 0.f};
+    }
+    static __device__ __forceinline__ void store_vec(const Vec& v, float* dst, int lane, int n) {
+#pragma unroll
+        for (int m = 0; m < NC; ++m)
+            if (256 * m + 4 * lane < n) *reinterpret_cast<rp_f4*>(dst + 256 * m + 4 * lane) = v.c[m];
+    }
+    static __device__ __forceinline__ void store_rows(const Rows& R, float* P, int64_t ldp, int row_w0, int lane, int n) {
+#pragma unroll
+        for (int j = 0; j < RW_; ++j)
+#pragma unroll
+            for (int m = 0; m < NC; ++m)
+                if (row_w0 + j < n && 256 * m + 4 * lane < n) *reinterpret_cast<rp_f4*>(P + (int64_t)(row_w0 + j) * ldp + 256 * m + 4 * lane) = R.w[j][m];
+    }
 };
 
 // 4-byte path (rp_dot_rows_s1: any n and ld): lane l holds columns l + 64 k of KC strides (zeros past n), ONE accumulator per row
@@ -273,6 +330,45 @@ struct rp_layout_s1 {
             rs[j] = a;
         }
         return rp_rows_allreduce<RW_>(rs, lane);
+    }
+    // ---- the RLS sweep's operations in this layout ----
+    static __device__ __forceinline__ float dots_plain(const Rows& R, const Vec& v, int lane) { return dots(R, v, 0, lane); }
+    // rls_scalars_kernel's tree with leaf j = l + 64 k in lane l: levels 512 .. 64 add a lane's own strides (k + 8, + 4, + 2, + 1),
+    // levels 32 .. 1 are the wave butterfly
+    static __device__ __forceinline__ float tree_dot(const Vec& u, const Vec& x) {
+        float a[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = k < KC ? fmaf(u.c[k < KC ? k : 0], x.c[k < KC ? k : 0], 0.f) : 0.f;
+#pragma unroll
+        for (int w = 8; w >= 1; w >>= 1)
+#pragma unroll
+            for (int k = 0; k < w; ++k)
+                if (k + w < KC) a[k] = a[k] + a[k + w];   // (absent strides are zeros: x + 0 == x)
+        return rp_wave_allreduce(a[0]);
+    }
+    static __device__ __forceinline__ void add_scaled(Vec& w, float a, const Vec& z) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) w.c[k] = w.c[k] + a * z.c[k];
+    }
+    static __device__ __forceinline__ void row_sub_scaled(Rows& R, int j, float a, const Vec& z) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) R.w[j][k] = R.w[j][k] - a * z.c[k];
+    }
+    static __device__ __forceinline__ void zero_vec(Vec& v) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) v.c[k] = 0.f;
+    }
+    static __device__ __forceinline__ void store_vec(const Vec& v, float* dst, int lane, int n) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            if (lane + 64 * k < n) dst[lane + 64 * k] = v.c[k];
+    }
+    static __device__ __forceinline__ void store_rows(const Rows& R, float* P, int64_t ldp, int row_w0, int lane, int n) {
+#pragma unroll
+        for (int j = 0; j < RW_; ++j)
+#pragma unroll
+            for (int k = 0; k < KC; ++k)
+                if (row_w0 + j < n && lane + 64 * k < n) P[(int64_t)(row_w0 + j) * ldp + lane + 64 * k] = R.w[j][k];
     }
 };
 constexpr int rp_resident_strides_s1(int n) {   // 64-column strides per lane, rounded up to a power of two (zero-padded)

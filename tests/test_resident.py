@@ -149,7 +149,8 @@ def test_resident_spiking_adjoint_sweep_equals_a_launch_per_step(hip_device, mon
         same(got[0][key], got[1][key], f"qif n={n}: {key}")
 
 
-@pytest.mark.parametrize("n_in,n_out,T", [(256, 2, 30), (512, 3, 41), (1024, 1, 20), (100, 2, 57), (500, 4, 33), (900, 3, 12), (8, 1, 9)])
+@pytest.mark.parametrize("n_in,n_out,T", [(256, 2, 30), (512, 3, 41), (1024, 1, 20), (100, 2, 57), (500, 4, 33), (900, 3, 12), (8, 1, 9),
+                                          (5, 1, 12), (50, 2, 30), (250, 3, 25), (301, 4, 19), (511, 2, 14)])   # (n_in % 4 != 0: the 4-byte path)
 def test_resident_rls_sweep_equals_the_launches(hip_device, monkeypatch, n_in, n_out, T):
     """RLS with an update every step at launch-bound sizes: the whole sweep in ONE launch (P and W in registers, z exchanged as
     granules) against three launches per update: predictions, losses, weights and P, bit for bit; two consecutive sweeps."""
