@@ -401,19 +401,6 @@ constexpr int rp_resident_rows_per_wave_s1(int n) { return rp_resident_strides_s
         }                                                                                  \
     }
 
-// the launch: kernel template K<NC, RW, PARTIAL> for n columns
-#define RP_RESIDENT_DISPATCH(n_, LAUNCH)                                   \
-    switch (rp_resident_chunks(n_) * 2 + ((n_) % 256 != 0 ? 1 : 0)) {     \
-        case 2: LAUNCH(1, 16, false); break;                               \
-        case 3: LAUNCH(1, 16, true); break;                                \
-        case 4: LAUNCH(2, 16, false); break;                               \
-        case 5: LAUNCH(2, 16, true); break;                                \
-        case 6: LAUNCH(3, 8, false); break;                                \
-        case 7: LAUNCH(3, 8, true); break;                                 \
-        case 8: LAUNCH(4, 8, false); break;                                \
-        default: LAUNCH(4, 8, true); break;                                \
-    }
-
 // ---- host side ------------------------------------------------------------------------------------------------------------
 // The sticky failure word: pinned host memory the device can write (one int per process), looked at by the library's next calls
 // (rp_resident_poll) and by rp_async_status -- no copy, no synchronisation.
