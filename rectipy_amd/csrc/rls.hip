@@ -400,7 +400,10 @@ int launch_resident_rls(const rp_rls* r, int32_t steps, const float* X, int64_t 
     A.ldw = r->ldw;
     A.beta_inv = r->beta_inv;
     void* ws = nullptr;
-    if (rp_resident_begin(r->n_in, st, &A.C, &ws, v4) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident RLS sweep: no stream-ordered scratch");
+    if (rp_resident_begin(r->n_in, st, &A.C, &ws, v4) != RP_OK) {
+        (void)hipGetLastError();
+        return kResidentUnavailable;
+    }
     const dim3 grid(rp_resident_grid(A.C));
 #define RP_LAUNCH_(L_) hipLaunchKernelGGL((resident_rls_kernel<RP_UNPAREN L_>), grid, dim3(kThreads), 0, st, A)
     RP_RESIDENT_DISPATCH_LAYOUT(r->n_in, v4, RP_LAUNCH_)
@@ -1490,7 +1493,8 @@ extern "C" int rp_rls_sweep(const rp_rls* r, int32_t steps, int32_t stride, cons
     if (!sym && !r->partials && stride == 1 && steps >= 4 && r->n_out <= 4 && rp_resident_enabled() && g_rls_nts < 0 &&
         (vec4 ? (rp_resident_shape(r->n_in, r->ldp) && r->ldw % 4 == 0 && !(reinterpret_cast<uintptr_t>(r->W) & 15u)) : r->n_in <= 512)) {
         if (const int prc = rp_resident_poll(); prc != RP_OK) return prc;
-        return launch_resident_rls(r, steps, X, ldx, Y, ldy, pred, ldpred, loss, vec4, st);
+        const int rrc = launch_resident_rls(r, steps, X, ldx, Y, ldy, pred, ldpred, loss, vec4, st);
+        if (rrc != kResidentUnavailable) return rrc;
     }
     float* za = r->z;
     float* zb = r->zn;

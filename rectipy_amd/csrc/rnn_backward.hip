@@ -663,7 +663,10 @@ int launch_resident_adj(const BwdParams& P, const rp_bwd* b, bool v4, hipStream_
     A.grad_x = b->grad_x;
     A.ldgx = b->ldgx;
     void* ws = nullptr;
-    if (rp_resident_begin(P.n, st, &A.C, &ws, v4) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident adjoint sweep: no stream-ordered scratch");
+    if (rp_resident_begin(P.n, st, &A.C, &ws, v4) != RP_OK) {
+        (void)hipGetLastError();
+        return kResidentUnavailable;
+    }
     const dim3 grid(rp_resident_grid(A.C));
 #define RP_LAUNCH_(L_) hipLaunchKernelGGL((resident_adj_kernel<RP_UNPAREN L_>), grid, dim3(kThreads), 0, st, P, A)
     RP_RESIDENT_DISPATCH_LAYOUT(P.n, v4, RP_LAUNCH_)
@@ -755,7 +758,10 @@ int launch_resident_spk_adj(const BwdParams& P, const SpkGrad& G, const rp_bwd* 
     A.x = b->x;
     A.ldx = b->ldx;
     void* ws = nullptr;
-    if (rp_resident_begin(P.n, st, &A.C, &ws, v4) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident adjoint sweep: no stream-ordered scratch");
+    if (rp_resident_begin(P.n, st, &A.C, &ws, v4) != RP_OK) {
+        (void)hipGetLastError();
+        return kResidentUnavailable;
+    }
     const dim3 grid(rp_resident_grid(A.C));
 #define RP_LAUNCH_(L_) hipLaunchKernelGGL((resident_spk_adj_kernel<RP_UNPAREN L_>), grid, dim3(kThreads), 0, st, P, G, A)
     RP_RESIDENT_DISPATCH_LAYOUT(P.n, v4, RP_LAUNCH_)
@@ -1038,7 +1044,10 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     hipLaunchKernelGGL(prep_kernel, dim3(eblocks), dim3(256), 0, st, P);
     if (use_wt && rp_resident_enabled() && T >= 4 &&
         (vec4_t ? (rp_resident_shape(n, b->ldwt) && b->ld % 4 == 0 && !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u)) : rp_resident_shape_any(n)))
-        return launch_resident_adj(P, b, vec4_t, st);   // the whole sweep in one launch (the row-dot path the launches would take)
+    {
+        const int rrc = launch_resident_adj(P, b, vec4_t, st);   // the whole sweep in one launch (the row-dot path the launches would take)
+        if (rrc != kResidentUnavailable) return rrc;
+    }
     for (int t = T - 1; t >= 0; --t) {
         P.t = t;
         P.u = b->u_traj + (int64_t)t * b->ld;
@@ -1896,7 +1905,10 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     if (use_wt && !mean_coupled && rp_resident_enabled() && T >= 4 &&
         (vec4_t ? (rp_resident_shape(P.n, b->ldwt) && b->ld % 4 == 0 && !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u))
                 : rp_resident_shape_any(P.n)))
-        return launch_resident_spk_adj(P, G, b, vec4_t, st);   // the whole sweep in one launch
+    {
+        const int rrc = launch_resident_spk_adj(P, G, b, vec4_t, st);   // the whole sweep in one launch
+        if (rrc != kResidentUnavailable) return rrc;
+    }
     for (int t = T - 1; t >= 0; --t) {
         P.u = b->u_traj + (int64_t)t * b->ld;
         if (!use_wt && !use_spt) launch_wt_partial(P, vec4, st);

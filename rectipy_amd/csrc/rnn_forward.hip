@@ -1421,7 +1421,10 @@ int forward_resident(rp_net* net, rp_run* run, StepParams& P, hipStream_t st) {
     A.ldsamples = run->ldsamples;
     void* ws = nullptr;
     const bool v4 = use_vec4(net);
-    if (rp_resident_begin(net->n, st, &A.C, &ws, v4) != RP_OK) RP_FAIL(RP_ERR_HIP, "resident step kernel: no stream-ordered scratch");
+    if (rp_resident_begin(net->n, st, &A.C, &ws, v4) != RP_OK) {   // (no stream-ordered allocator: one launch per step)
+        (void)hipGetLastError();
+        return kResidentUnavailable;
+    }
     set_step(P, net, run, 0);   // (step 0's arguments -- the kernel forms every step's itself; the bookkeeping is advanced below)
     switch (net->model) {
         case RP_MODEL_LI_TANH: launch_resident_model<RP_MODEL_LI_TANH>(P, A, v4, st); break;
@@ -1481,7 +1484,10 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     const StreamCfg stream_cfg = choose_cfg(net);
     StepParams P = {};
     init_params(P, net, run);
-    if (!comm && resident_ok(net, run)) return forward_resident(net, run, P, st);
+    if (!comm && resident_ok(net, run)) {
+        rc = forward_resident(net, run, P, st);
+        if (rc != kResidentUnavailable) return rc;
+    }
 
     for (int t = 0; t < run->steps; ++t) {
         const int64_t t_abs = run->step0 + t;

@@ -38,6 +38,7 @@ typedef __attribute__((address_space(1))) unsigned rp_gu32;
 typedef __attribute__((address_space(1))) int rp_gi32;
 
 constexpr int kResidentWaves = 4;                     // waves per workgroup
+constexpr int kResidentUnavailable = 1;               // (internal: no stream-ordered scratch -- nothing launched, the caller launches per step)
 constexpr int rp_resident_chunks(int n) { return (n + 255) >> 8; }   // 256-column chunks, the last one possibly partial
 constexpr int rp_resident_rows_per_wave(int n) { return rp_resident_chunks(n) <= 2 ? 16 : 8; }
 
@@ -425,8 +426,12 @@ inline int* rp_resident_host_word(int** device_view) {
 inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** ws, bool v4 = true) {
     const size_t bytes = (size_t)2 * n * sizeof(unsigned long long) + 64;
     *ws = nullptr;
+    if (const char* e = getenv("RECTIPY_AMD_RESIDENT_TEST_FAULT"); e && e[0] == '2') return RP_ERR_HIP;   // (test seam: no scratch)
     if (hipMallocAsync(ws, bytes, st) != hipSuccess) return RP_ERR_HIP;
-    if (hipMemsetAsync(*ws, 0, bytes, st) != hipSuccess) return RP_ERR_HIP;
+    if (hipMemsetAsync(*ws, 0, bytes, st) != hipSuccess) {
+        (void)hipFreeAsync(*ws, st);
+        return RP_ERR_HIP;
+    }
     C->gran[0] = static_cast<unsigned long long*>(*ws);
     C->gran[1] = C->gran[0] + n;
     C->fail = reinterpret_cast<int*>(C->gran[1] + n);

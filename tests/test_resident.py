@@ -217,6 +217,38 @@ def test_the_roster_completes_on_any_placement(hip_device, monkeypatch, xcd):
     same(got[0][1], got[1][1], "v")
 
 
+def test_without_stream_ordered_scratch_the_launches_take_over(hip_device, monkeypatch):
+    """No stream-ordered allocator (a test switch refuses the scratch): nothing is launched resident, the call runs with one launch
+    per step -- forward, adjoint sweep and RLS sweep -- and raises nothing."""
+    from rectipy_amd.rls import RLS
+    from rectipy_amd.engine import default_backend
+    n, T = 256, 20
+    gen = torch.Generator().manual_seed(4)
+    x = (torch.randn(T, n, generator=gen) * 0.5).to(hip_device)
+    g_out = (torch.randn(T, n, generator=gen) * 0.1).to(hip_device)
+    Y = torch.randn(T, 2, generator=gen).to(hip_device)
+    got = []
+    for fault in ("2", None):
+        if fault:
+            monkeypatch.setenv("RECTIPY_AMD_RESIDENT_TEST_FAULT", fault)
+        else:
+            monkeypatch.delenv("RECTIPY_AMD_RESIDENT_TEST_FAULT", raising=False)
+        pop = make("li_tanh", n, hip_device)
+        pop.transposed_adjoint = True
+        tv, tr, ta, ut = (torch.zeros(T, n, device=hip_device) for _ in range(4))
+        pop.forward(T, x=x, save_v=tv, save_src=tr, save_acc=ta)
+        lam = torch.zeros(n, device=hip_device)
+        keep = pop.backward(tv, tr, g_out, _abi.RP_OUT_SOURCE, lam, ut, traj_acc=ta)
+        edge = RLS(n, 2, beta=0.97, alpha=1.5).to(hip_device)
+        pred, loss = edge.sweep(tr, Y, 1)
+        torch.cuda.synchronize()
+        del keep
+        got.append(dict(v=pop.v.clone(), lam=lam, u=ut, pred=pred, W=edge.weights.clone()))
+    default_backend().async_status()
+    for key in got[0]:
+        same(got[0][key], got[1][key], key)
+
+
 def test_a_timed_out_resident_launch_is_reported(hip_device, monkeypatch):
     """A wave that waits in vain for a peer's element gives up after its bounded spin, every wave leaves, and the failure -- the one
     thing a resident launch can only report afterwards -- reaches the host without a synchronisation inside the library: the next
