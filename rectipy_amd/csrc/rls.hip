@@ -646,16 +646,19 @@ __global__ __launch_bounds__(1024) void rls_sym_zn_kernel(const RlsParams P0, in
     if (i < P.n_in) {
         for (int b = slot; b < I; b += SLOTS) {
             const float* col = P.colparts + (int64_t)b * per_block * P.ldc + i;
-            float s = col[0];
-            int q = 1;
-            for (; q + 8 <= per_block; q += 8) {  // eight independent loads in flight, added in ascending order
+            // eight independent loads in flight, added in ascending order (r05: the first batch starts at chunk 0 -- with 8 chunks per
+            // block row, 128-row tiles, the old "first, then batches of eight" took the one-load-at-a-time tail for all of them)
+            float s = 0.f;
+            int q = 0;
+            for (; q + 8 <= per_block; q += 8) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = col[(int64_t)(q + u) * P.ldc];
+                s = q == 0 ? v[0] : s + v[0];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) s = s + v[u];
+                for (int u = 1; u < 8; ++u) s = s + v[u];
             }
-            for (; q < per_block; ++q) s = s + col[(int64_t)q * P.ldc];
+            for (; q < per_block; ++q) s = q == 0 ? col[0] : s + col[(int64_t)q * P.ldc];
             colsum[b * COLS + c] = s;
         }
     }
