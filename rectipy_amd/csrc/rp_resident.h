@@ -427,6 +427,18 @@ inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** w
     const size_t bytes = (size_t)2 * n * sizeof(unsigned long long) + 64;
     *ws = nullptr;
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT_TEST_FAULT"); e && e[0] == '2') return RP_ERR_HIP;   // (test seam: no scratch)
+    {   // once per device: the default pool keeps the few KiB of scratch across synchronisations instead of returning them to the system
+        static unsigned char kept[RP_MAX_DEVICES];
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < RP_MAX_DEVICES && !kept[dev]) {
+            hipMemPool_t pool = nullptr;
+            uint64_t keep = 1u << 20;
+            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool)
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            (void)hipGetLastError();
+            kept[dev] = 1;
+        }
+    }
     if (hipMallocAsync(ws, bytes, st) != hipSuccess) return RP_ERR_HIP;
     if (hipMemsetAsync(*ws, 0, bytes, st) != hipSuccess) {
         (void)hipFreeAsync(*ws, st);
