@@ -139,6 +139,7 @@ class _CoupledWindow(torch.autograd.Function):
                 outs += [out.clone(), pop.v.clone()]
         ctx.net, ctx.plan, ctx.steps, ctx.stored, ctx.widths, ctx.xin, ctx.lag0, ctx.final = net, plan, steps, stored, widths, xin, lag0, final
         ctx.saved_u = saved_u
+        ctx.flat = flat   # (the leaves themselves: a plain-SGD fit applies a matrix's update in the gradient GEMM, see backward)
         return tuple(outs)
 
     @staticmethod
@@ -151,6 +152,7 @@ class _CoupledWindow(torch.autograd.Function):
         need = ctx.needs_input_grad
         layout, first_edge = _CoupledWindow._layout(net, plan)
         read = {s_ for p in members for s_, _ in plan["edges"][p]}
+        fused = getattr(net, "_fused_sgd", None)   # id(leaf) -> summed learning rate (a plain-SGD fit_bptt: Network._fused_sgd_plan)
         specs, res = [], []
         gpos = 0   # position in g: a population has two outputs (trajectory, final state), an activation node one
         for m, (p, (i, names, is_pop)) in enumerate(zip(members, layout)):
@@ -217,7 +219,15 @@ class _CoupledWindow(torch.autograd.Function):
             if need[i + 1]:
                 grads[i + 1] = node._pack(R["lam"], R["lam_s"], R["lam_x"], R["lam_x2"]) if pop.spiking else R["lam"]
             if need[i + 2]:
-                grads[i + 2] = pop.outer_product(pop.dt, R["u"], stored[p]["save_src"])
+                Wt = ctx.flat[i - 4 + 2]
+                lr_total = fused.get(id(Wt)) if fused else None
+                if lr_total is not None and Wt.is_contiguous() and Wt.dtype == torch.float32 and pop.packed is None:
+                    # plain SGD: W <- W - lr (dt u^T r) inside the GEMM's epilogue (read + write of W) instead of a stored
+                    # gradient matrix and the optimiser's three passes over it; the gradient stays None: the optimiser skips W
+                    pop.outer_accum(-lr_total * pop.dt, R["u"], stored[p]["save_src"], Wt.detach())
+                    torch.autograd.graph.increment_version(Wt)   # (an in-place write torch did not see: caches keyed on W._version)
+                else:
+                    grads[i + 2] = pop.outer_product(pop.dt, R["u"], stored[p]["save_src"])
             for j, name in enumerate(names):
                 grads[i + 3 + j] = R["par"].get(name)
         e = first_edge
@@ -242,14 +252,23 @@ class _CoupledWindow(torch.autograd.Function):
                             src = net.get_node(s_)
                             last = ctx.final[s_][1] if src._out_code == _abi.RP_OUT_SOURCE else ctx.final[s_][0]
                             out_s = torch.cat([out_s[1:], last[None, :]])
-                    gW = torch.empty(pop.rows, src_pop.rows, dtype=torch.float32, device=pop.device)
                     gx = res[m]["gx"]
-                    pop.backend.outer_store_rect(pop.rows, src_pop.rows, T, 1.0, gx.data_ptr(), gx.stride(0) if T > 1 else pop.rows,
-                                                 out_s.data_ptr(), out_s.stride(0) if T > 1 else src_pop.rows, gW.data_ptr(),
-                                                 gW.stride(0), pop.device)
-                    if isinstance(edge, LinearMasked):
-                        gW = gW * edge.mask
-                    grads[e] = gW
+                    We = ctx.flat[e - 4]
+                    lr_total = fused.get(id(We)) if fused else None
+                    if lr_total is not None and not isinstance(edge, LinearMasked) and We.dtype == torch.float32 and We.stride(1) == 1 \
+                            and tuple(We.shape) == (pop.rows, src_pop.rows):
+                        pop.backend.outer_accum_rect(pop.rows, src_pop.rows, T, -lr_total, gx.data_ptr(), gx.stride(0) if T > 1 else pop.rows,
+                                                     out_s.data_ptr(), out_s.stride(0) if T > 1 else src_pop.rows, We.data_ptr(),
+                                                     We.stride(0), pop.device)   # (the update itself: plain SGD, see above)
+                        torch.autograd.graph.increment_version(We)
+                    else:
+                        gW = torch.empty(pop.rows, src_pop.rows, dtype=torch.float32, device=pop.device)
+                        pop.backend.outer_store_rect(pop.rows, src_pop.rows, T, 1.0, gx.data_ptr(), gx.stride(0) if T > 1 else pop.rows,
+                                                     out_s.data_ptr(), out_s.stride(0) if T > 1 else src_pop.rows, gW.data_ptr(),
+                                                     gW.stride(0), pop.device)
+                        if isinstance(edge, LinearMasked):
+                            gW = gW * edge.mask
+                        grads[e] = gW
                 e += 1
         del keep
         return tuple(grads)

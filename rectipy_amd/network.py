@@ -864,6 +864,29 @@ class Network:
         optimizer.step(**step_kwargs)
         return error.detach() if lazy else error.item()
 
+    @staticmethod
+    def _fused_sgd_plan(optimizer, step_kwargs) -> Optional[dict]:
+        """id(parameter) -> its learning rate summed over its occurrences in the optimiser's groups, when the optimiser is PLAIN
+        stochastic gradient descent (torch.optim.SGD without momentum, dampening, weight decay, Nesterov, maximize; no closure):
+        p <- p - lr g per occurrence.  A coupled window then applies the update of a trained matrix in the gradient GEMM's epilogue
+        (W += -lr * dW: one read and one write of W) instead of storing dW and leaving three more passes over the matrix to the
+        optimiser -- which skips a parameter whose gradient is None.  The same update up to the rounding of the last bit (the
+        occurrences of a repeated parameter, network.py:1308-1322, are one addition instead of one after the other; lr * dW is
+        rounded once inside the GEMM instead of dW and lr * dW in turn).  Not observable from outside fit_bptt: the call's last
+        complete window takes the optimiser's route, so every parameter carries that window's gradient afterwards, as in the
+        reference.  RECTIPY_AMD_FUSED_SGD=0 keeps the optimiser's passes in every window."""
+        import os
+        if os.environ.get("RECTIPY_AMD_FUSED_SGD", "1") == "0" or type(optimizer) is not torch.optim.SGD or step_kwargs:
+            return None
+        plan = {}
+        for g in optimizer.param_groups:
+            if g.get("momentum", 0) != 0 or g.get("dampening", 0) != 0 or g.get("weight_decay", 0) != 0 or g.get("nesterov") \
+                    or g.get("maximize"):
+                return None
+            for p in g["params"]:
+                plan[id(p)] = plan.get(id(p), 0.0) + float(g["lr"])
+        return plan
+
     def _unreached_parameters(self, steps: int) -> list:
         """Trainable parameters that cannot influence any prediction of a window of `steps` steps that starts from
         states without an older graph.  A population hands on its state from BEFORE the step (nodes.py:166-170), so every
@@ -914,11 +937,19 @@ class Network:
                 self._warn_stepwise("Network.fit_bptt", "dag", "coupled_grad")
             return self._bptt_stepwise(inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps,
                                        optim_steps, verbose)
+        try:
+            return self._bptt_windows(inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps, optim_steps,
+                                      verbose, plan, windows, coupled)
+        finally:
+            self._fused_sgd = None   # (an exception inside a window must not leave the plan to a later backward call)
+
+    def _bptt_windows(self, inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps, optim_steps, verbose,
+                      plan, windows, coupled) -> Observer:
+        steps, error = inp.shape[0], 0.0
         if not windows and coupled is None:
             pre, label, post = plan
             rnn: RateNet = self.get_node(label)
             N = rnn._pop.rows
-        error = 0.0
         for a in range(0, steps, optim_steps):
             b = min(a + optim_steps, steps)
             unreached = self._unreached_parameters(b - a)
@@ -929,6 +960,10 @@ class Network:
                 # the window's loss depends on nothing trainable and on no tracked state: the reference's backward()
                 # fails with exactly this message (network.py:1128)
                 raise RuntimeError("element 0 of tensors does not require grad and does not have a grad_fn")
+            # (a complete window of a coupled fit under plain SGD: the trained matrices are updated inside the backward call --
+            # except in the fit's LAST complete window, which leaves its gradient on every parameter as the reference does)
+            self._fused_sgd = self._fused_sgd_plan(optimizer, step_kwargs) if coupled is not None and not error_kwargs and \
+                b + optim_steps <= steps else None
             with torch.enable_grad():
                 if windows:
                     preds = self._window_outputs(inp[a:b], a, True, {}, 0, 1)[self._out_node]
@@ -948,6 +983,7 @@ class Network:
                 if b - a == optim_steps:  # only complete windows trigger an update (network.py:1035)
                     error = self._bptt_step(preds, target[a:b], optimizer, loss, error_kwargs, step_kwargs,
                                             lazy=not verbose, unreached=unreached)
+                    self._fused_sgd = None
                     self.detach()
             sample_at = [t for t in range(a, b) if t % sampling_steps == 0]
             if sample_at:

@@ -54,4 +54,13 @@ with contextlib.redirect_stdout(sys.stderr):
     out["forward_with_window_stores_us_per_step"] = timed(fwd_with_stores, T)
     out["run_no_grad_again_us_per_step"] = timed(lambda: fb.run(x, sampling_steps=T, verbose=False, enable_grad=False), T)
     out["fit_again_us_per_step"] = timed(fit, T)
+    # plain SGD applies a trained matrix's update in the gradient GEMM in every window but the call's last complete one
+    # (Network._fused_sgd_plan): a longer fit shows more of it; RECTIPY_AMD_FUSED_SGD=0 is the optimiser's passes everywhere
+    x4, y4 = x.repeat(4, 1), y.repeat(4, 1)
+    fit4 = lambda: fb.fit_bptt(x4, y4, optimizer="sgd", lr=1e-4, update_steps=win, sampling_steps=win, verbose=False)
+    out["fit_12_windows_us_per_step"] = timed(fit4, 4 * T)
+    os.environ["RECTIPY_AMD_FUSED_SGD"] = "0"
+    out["fit_optimizer_passes_us_per_step"] = timed(fit, T)
+    out["fit_12_windows_optimizer_passes_us_per_step"] = timed(fit4, 4 * T)
+    del os.environ["RECTIPY_AMD_FUSED_SGD"]
 print(json.dumps(out))

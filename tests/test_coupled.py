@@ -1442,3 +1442,50 @@ def test_packed_edges_with_a_source_wider_than_the_lds_window(hip_device):
         torch.cuda.empty_cache()
     for a, b in zip(*res):
         assert_same(a, b, "packed vs dense")
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("kind", ["plain", "momentum"])
+def test_plain_sgd_update_inside_the_gradient_gemm(target, kind, monkeypatch):
+    """fit_bptt under plain SGD applies the update of the trained matrices in the gradient GEMM (W += -lr dW, Network._fused_sgd_plan)
+    in every window but the call's last complete one; with RECTIPY_AMD_FUSED_SGD=0 the optimiser makes its passes.  Same parameters
+    (the rounding of lr * dW differs in the last bit), the same predictions, and the last window's gradient on every parameter
+    either way.  A masked edge keeps the optimiser's route, and so does everything under an optimiser with a state (momentum)."""
+    from rectipy_amd.engine import Population
+    accum = []
+    real = Population.outer_accum
+    monkeypatch.setattr(Population, "outer_accum", lambda self, *a: accum.append("W") or real(self, *a))
+    r = np.random.default_rng(3)
+    sizes, T, win = dict(a=24, b=40), 67, 12      # five complete windows and a ragged tail
+    x, y = r.standard_normal((T, 24)).astype(np.float32) * 0.5, r.standard_normal((T, 3)).astype(np.float32) * 0.3
+    init = {k_: r.standard_normal(s_) * 0.3 for k_, s_ in dict(a=(24, 24), b=(40, 40), ab=(40, 24), ba=(24, 40), bb=(24, 40), out=(3, 40)).items()}
+    mask = (r.uniform(size=(24, 40)) < 0.5).astype(np.float32)
+    res = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("RECTIPY_AMD_FUSED_SGD", env)
+        accum.clear()
+        net = FeedbackNetwork(1e-2, **target)
+        for lab in "ab":
+            net.add_diffeq_node(lab, TANH, weights=init[lab], source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                                output_var="li_op/v", dtype=torch.float32, train_params=["weights", "li_op/tau"],
+                                node_vars={"all/li_op/tau": r.uniform(0.5, 2, sizes[lab]) * 0 + 1.0})
+        net.add_func_node("out", 3, "identity")
+        edges = [net.add_edge("a", "b", weights=init["ab"], train="gd"), net.add_edge("b", "a", weights=init["ba"], feedback=True, train="gd"),
+                 net.add_edge("b", "out", weights=init["out"], train="gd")]
+        backend = net.get_node("a")._pop.backend
+        real_rect = type(backend).outer_accum_rect
+        monkeypatch.setattr(type(backend), "outer_accum_rect", lambda self, *a: accum.append("E") or real_rect(self, *a))
+        obs = net.fit_bptt(x, y, optimizer="sgd", lr=5.0, update_steps=win, sampling_steps=1, verbose=False,
+                           optimizer_kwargs=dict(momentum=0.5) if kind == "momentum" else None)
+        monkeypatch.setattr(type(backend), "outer_accum_rect", real_rect)
+        fused_windows = 4 if env == "1" and kind == "plain" else 0     # (five complete windows: all but the last)
+        assert sorted(accum) == ["E"] * (2 * fused_windows) + ["W"] * (2 * fused_windows)
+        params = [net.get_node(lab)[k_] for lab in "ab" for k_ in ("weights", "li_op/tau")] + [e.weights for e in edges]
+        assert all(p.grad is not None for p in params)
+        res.append(([p.detach().cpu().numpy().copy() for p in params], [p.grad.detach().cpu().numpy().copy() for p in params],
+                    obs.to_numpy("out"), obs.to_numpy("loss")))
+    for (p1, p0, g1, g0) in zip(res[0][0], res[1][0], res[0][1], res[1][1]):
+        assert np.abs(p1 - p0).max() <= 1e-6 and np.abs(g1 - g0).max() <= 1e-4 * np.abs(g0).max()
+    assert np.abs(res[0][2] - res[1][2]).max() < 1e-5 and np.abs(res[0][3] - res[1][3]).max() < 1e-5
+    for i, key in ((0, "a"), (2, "b"), (4, "ab"), (5, "ba")):
+        assert np.abs(res[0][0][i] - init[key]).max() > 5e-5, key     # (the matrices did move: fifty times the tolerance and more)
