@@ -1037,6 +1037,22 @@ def stepwise_extra(dev):
                 fit(Tf)
                 torch.cuda.synchronize()
                 rec["feedback_fit_bptt" + ("_adjoint_on_the_per_step_walk" if walk else "")] = (time.perf_counter() - t0) / Tf * 1e6
+                if not walk:
+                    # plain SGD: the update of a trained matrix happens in the gradient GEMM in every window but the call's last
+                    # complete one (Network._fused_sgd_plan), so a longer fit shows more of it; and the optimiser's passes instead
+                    x3, y3 = x_h[:Tf].repeat(3, 1), y_h[:Tf].repeat(3, 1)
+                    for key_, env_ in (("feedback_fit_bptt_three_times_the_windows", None), ("feedback_fit_bptt_optimizer_passes", "0")):
+                        if env_ is not None:
+                            os.environ["RECTIPY_AMD_FUSED_SGD"] = env_
+                        try:
+                            torch.cuda.synchronize()
+                            t0 = time.perf_counter()
+                            fb.fit_bptt(x3, y3, optimizer="sgd", lr=1e-4, update_steps=50, sampling_steps=50, verbose=False)
+                            torch.cuda.synchronize()
+                            rec[key_] = (time.perf_counter() - t0) / (3 * Tf) * 1e6
+                        finally:
+                            os.environ.pop("RECTIPY_AMD_FUSED_SGD", None)
+                    del x3, y3
                 del fb
                 torch.cuda.empty_cache()
             # (iv-b) r05 (ABI v18): the same training with an activation node / an edge with memory inside the cycle -- the gradient

@@ -941,7 +941,15 @@ class Network:
             return self._bptt_windows(inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps, optim_steps,
                                       verbose, plan, windows, coupled)
         finally:
-            self._fused_sgd = None   # (an exception inside a window must not leave the plan to a later backward call)
+            self._set_fused_sgd(None)   # (an exception inside a window must not leave the plan to a later backward call)
+
+    def _set_fused_sgd(self, plan: Optional[dict]) -> None:
+        """Hand the plain-SGD plan (or None) to the window nodes that apply it: the coupled window reads it from the network, a
+        rate population's own window from the node."""
+        self._fused_sgd = plan
+        for n in self.graph.nodes:
+            if self[n]["node_type"] == "diff_eq":
+                self.get_node(n)._fused_sgd = plan
 
     def _bptt_windows(self, inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps, optim_steps, verbose,
                       plan, windows, coupled) -> Observer:
@@ -962,8 +970,8 @@ class Network:
                 raise RuntimeError("element 0 of tensors does not require grad and does not have a grad_fn")
             # (a complete window of a coupled fit under plain SGD: the trained matrices are updated inside the backward call --
             # except in the fit's LAST complete window, which leaves its gradient on every parameter as the reference does)
-            self._fused_sgd = self._fused_sgd_plan(optimizer, step_kwargs) if coupled is not None and not error_kwargs and \
-                b + optim_steps <= steps else None
+            self._set_fused_sgd(self._fused_sgd_plan(optimizer, step_kwargs) if not error_kwargs and b + optim_steps <= steps
+                                else None)
             with torch.enable_grad():
                 if windows:
                     preds = self._window_outputs(inp[a:b], a, True, {}, 0, 1)[self._out_node]
@@ -983,7 +991,7 @@ class Network:
                 if b - a == optim_steps:  # only complete windows trigger an update (network.py:1035)
                     error = self._bptt_step(preds, target[a:b], optimizer, loss, error_kwargs, step_kwargs,
                                             lazy=not verbose, unreached=unreached)
-                    self._fused_sgd = None
+                    self._set_fused_sgd(None)
                     self.detach()
             sample_at = [t for t in range(a, b) if t % sampling_steps == 0]
             if sample_at:

@@ -93,6 +93,7 @@ class _RateWindow(torch.autograd.Function):
         ctx.steps = steps
         ctx.x_width = None if x is None else x.shape[1]
         ctx.saved = (traj_v, traj_r, traj_acc)
+        ctx.W = W   # (the leaf itself: a plain-SGD fit applies its update in the gradient GEMM, see backward)
         node._last_window = (traj_v, traj_r)
         out = traj_r if node._out_code == _abi.RP_OUT_SOURCE else traj_v
         return out.clone(), pop.v.clone()
@@ -118,7 +119,16 @@ class _RateWindow(torch.autograd.Function):
                             grad_tau=g_tau, grad_k=g_k, grad_eta=g_eta, grad_x=g_x, grad_params=g_act)
         g_W = None
         if need[4]:
-            g_W = pop.outer_product(pop.dt, u_traj, traj_r)
+            fused = getattr(node, "_fused_sgd", None)   # id(leaf) -> learning rate (a plain-SGD fit_bptt: Network._fused_sgd_plan)
+            lr_total = fused.get(id(ctx.W)) if fused else None
+            if lr_total is not None and ctx.W.is_contiguous() and ctx.W.dtype == torch.float32 and pop.packed is None \
+                    and tuple(ctx.W.shape) == (N, N):
+                # W <- W - lr (dt u^T r) in the GEMM's epilogue: one read and one write of W instead of a stored gradient matrix
+                # and the optimiser's three passes over it; the gradient stays None and the optimiser skips W
+                pop.outer_accum(-lr_total * pop.dt, u_traj, traj_r, ctx.W.detach())
+                torch.autograd.graph.increment_version(ctx.W)   # (an in-place write torch did not see)
+            else:
+                g_W = pop.outer_product(pop.dt, u_traj, traj_r)
         if g_x is not None and ctx.x_width == 1:
             g_x = g_x.sum(dim=1, keepdim=True)
         del keep

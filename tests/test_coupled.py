@@ -1489,3 +1489,43 @@ def test_plain_sgd_update_inside_the_gradient_gemm(target, kind, monkeypatch):
     assert np.abs(res[0][2] - res[1][2]).max() < 1e-5 and np.abs(res[0][3] - res[1][3]).max() < 1e-5
     for i, key in ((0, "a"), (2, "b"), (4, "ab"), (5, "ba")):
         assert np.abs(res[0][0][i] - init[key]).max() > 5e-5, key     # (the matrices did move: fifty times the tolerance and more)
+
+
+@pytest.mark.parametrize("target", TARGETS, indirect=True)
+@pytest.mark.parametrize("shape", ["one-population", "two-in-a-row"])
+def test_plain_sgd_update_inside_the_gradient_gemm_single_population_windows(target, shape, monkeypatch):
+    """The same for Network.fit_bptt over a population's own autograd window (_RateWindow; one population behind a read-out, and two
+    populations in a row -- no cycle): every window but the last complete one updates the trained W in the gradient GEMM."""
+    from rectipy_amd import Network
+    from rectipy_amd.engine import Population
+    accum = []
+    real = Population.outer_accum
+    monkeypatch.setattr(Population, "outer_accum", lambda self, *a: accum.append("W") or real(self, *a))
+    r = np.random.default_rng(5)
+    n, T, win = 48, 45, 10      # four complete windows and a ragged tail
+    labs = "a" if shape == "one-population" else "ab"
+    x, y = r.standard_normal((T, n)).astype(np.float32) * 0.5, r.standard_normal((T, 3)).astype(np.float32) * 0.3
+    init = {lab: r.standard_normal((n, n)) * 0.3 for lab in labs}
+    W_out, W_ab = r.standard_normal((3, n)) * 0.3, r.standard_normal((n, n)) * 0.2
+    res = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("RECTIPY_AMD_FUSED_SGD", env)
+        accum.clear()
+        net = Network(1e-2, **target)
+        for lab in labs:
+            net.add_diffeq_node(lab, TANH, weights=init[lab], source_var="tanh_op/r", target_var="li_op/r_in", input_var="li_op/I_ext",
+                                output_var="li_op/v", dtype=torch.float32, train_params=["weights", "li_op/k"])
+        net.add_func_node("out", 3, "identity")
+        edges = [net.add_edge(labs[-1], "out", weights=W_out, train="gd")]
+        if len(labs) == 2:
+            edges.append(net.add_edge("a", "b", weights=W_ab, train="gd"))
+        obs = net.fit_bptt(x, y, optimizer="sgd", lr=5.0, update_steps=win, sampling_steps=1, verbose=False)
+        assert accum == ["W"] * (len(labs) * (3 if env == "1" else 0))
+        params = [net.get_node(lab)[k_] for lab in labs for k_ in ("weights", "li_op/k")] + [e.weights for e in edges]
+        assert all(p.grad is not None for p in params)
+        res.append(([p.detach().cpu().numpy().copy() for p in params], [p.grad.detach().cpu().numpy().copy() for p in params],
+                    obs.to_numpy("out"), obs.to_numpy("loss")))
+    for (p1, p0, g1, g0) in zip(res[0][0], res[1][0], res[0][1], res[1][1]):
+        assert np.abs(p1 - p0).max() <= 1e-6 and np.abs(g1 - g0).max() <= 1e-4 * np.abs(g0).max()
+    assert np.abs(res[0][2] - res[1][2]).max() < 1e-5 and np.abs(res[0][3] - res[1][3]).max() < 1e-5
+    assert np.abs(res[0][0][0] - init["a"]).max() > 5e-5
