@@ -581,6 +581,154 @@ __global__ __launch_bounds__(kThreads) void step_merged_kernel(const MergedParam
     }
 }
 
+// ---- ... and ALL steps of a coupled circuit in ONE launch (r05: the resident form of the shared launch; machinery: rp_resident.h) ---
+// The shared launch above is bounded by the host's launch rate (5.6 us per step; a population alone runs resident at 2-3 us).
+// Here a wave keeps its rows of the member's own matrix AND of the member's in-edge matrices in registers (slots of NC chunks;
+// NSEG slots, NSEG x NC <= 4 chunks), every member hands its source vector -- and its state vector, when an edge reads that --
+// from wave to wave as tagged granules (one stream per member and vector, two parities), and every wave waits for the source
+// stream of EVERY member before it steps (the circuit moves in lockstep: a member whose output nobody in a cycle reads cannot
+// run ahead and overwrite granules its readers have not consumed).  A lagging edge (RP_EDGE_LAG) multiplies with the vector
+// the wave received one step earlier.  The row dots are each matrix's own contract, the edge sums are added in edge order, the
+// epilogue is the per-step kernels': bit-identical to the shared launch.
+constexpr int kRcCap = 512;       // granules per stream and parity (members of up to 512 neurons)
+constexpr int kRcSlots = 4;
+struct RcMember {
+    StepParams P0;                // the member's step-0 arguments (set_step(.., 0))
+    ResidentArgs A;               // (A.C unused: the launch's control block is a kernel argument)
+    int first_block, nslots, publish_v, model;
+    int slot_src[kRcSlots];       // slot 0: the member itself; slot k: the source member of edge k - 1
+    int slot_state[kRcSlots];     // the slot reads the source's state vector (its output variable), not its source vector
+    int slot_lag[kRcSlots];       // RP_EDGE_LAG: the vector of one step earlier
+    int slot_n[kRcSlots];         // columns of the slot's matrix
+    const float* slot_w[kRcSlots];
+    int64_t slot_ld[kRcSlots];
+    const float* slot_vec0[kRcSlots];   // the slot's vector at the call's first step, as it lies in memory
+    const float* slot_lag0[kRcSlots];   // ... and, for a lagging slot, the one before it
+    int all_rows[kMergeMax];            // neurons of every member of the circuit (the lockstep sweeps)
+};
+struct RcParams {
+    int count;
+    RcMember M[kMergeMax];
+};
+
+__device__ __forceinline__ unsigned long long* rc_stream(const rp_resident_ctl& C, int member, int state, int parity) {
+    return C.gran[0] + (size_t)((member * 2 + state) * 2 + parity) * kRcCap;
+}
+
+template <int MODEL, int NSEG, int NC, int RW>
+__device__ __forceinline__ void resident_coupled_member(const rp_resident_ctl& C, const RcMember& M, int m, int count, int block) {
+    typedef rp_layout_v4<NC, RW, false> L;   // (the vector's lane layout and the sweep; the dots go through rp_resident_dots_slot)
+    const int lane = threadIdx.x & (RP_WAVE - 1);
+    const ResidentArgs& A = M.A;
+    const int row_w0 = (block * kWavesPerBlock + (threadIdx.x >> 6)) * RW;
+    StepParams P = M.P0;
+    rp_f4 w[NSEG][RW][NC];
+#pragma unroll
+    for (int k = 0; k < NSEG; ++k) {
+        if (k < M.nslots)
+            rp_resident_load_rows_rect<NC, RW>(w[k], M.slot_w[k], M.slot_ld[k], row_w0, lane, P.rows, M.slot_n[k]);
+        else
+#pragma unroll
+            for (int j = 0; j < RW; ++j)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) w[k][j][c] = rp_f4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the members whose source stream no slot of this wave sweeps: their tags are waited for all the same (lockstep)
+    unsigned swept = 0u;
+#pragma unroll
+    for (int k = 0; k < NSEG; ++k)
+        if (k < M.nslots && !M.slot_state[k]) swept |= 1u << M.slot_src[k];
+    int acc_count = A.acc_count0, sample_idx = A.sample_idx0;
+    const int my_row = row_w0 + rp_rows_allreduce_row<RW>(lane);
+    const bool epi_lane = (lane & (64 / RW - 1)) == 0 && my_row < P.rows;
+    float v_reg = 0.f, s_reg = 0.f;
+    RateRegs R = {};
+    constexpr bool kRate = MODEL == RP_MODEL_LI_TANH || MODEL == RP_MODEL_LI_SIGMOID;
+    if (epi_lane) {
+        v_reg = M.P0.y[RP_Y_V][my_row];
+        s_reg = A.src[A.cur0][my_row];
+        if constexpr (kRate) R = rate_regs_load<MODEL>(M.P0, my_row);
+    }
+    typename L::Vec prev[NSEG];   // lagging slots: the vector of the step before
+#pragma unroll
+    for (int k = 1; k < NSEG; ++k)
+        if (k < M.nslots && M.slot_lag[k]) L::load_vec(prev[k], M.slot_lag0[k], lane, M.slot_n[k]);
+    rp_resident_ctl Cs = C;   // (the sweep and the publication take the stream's granules as "parity 0")
+    for (int t = 0; t < A.steps; ++t) {
+        resident_set_step(P, A, t, acc_count, sample_idx);
+        P.hist_t = nullptr;   // as in the shared launch: the ring is written one step ahead, nothing reads this step's entry late
+        P.hist_next = A.hist[0] ? A.hist[(A.step0 + t + 1) % 3] : nullptr;
+        P.spike_src = nullptr;
+        const float I_x = epi_lane ? input_current(P, my_row) : 0.f;
+        if constexpr (kRate) R.mv_tau = -v_reg / R.tau;
+        float wsum = 0.f, esum = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSEG; ++k) {
+            if (k >= M.nslots) continue;   // (wave-uniform)
+            typename L::Vec cur;
+            if (t == 0) {
+                L::load_vec(cur, M.slot_vec0[k], lane, M.slot_n[k]);
+            } else {
+                Cs.gran[0] = rc_stream(C, M.slot_src[k], M.slot_state[k], (t - 1) & 1);
+                if (!L::sweep(Cs, 0, (unsigned)t, cur, lane, M.slot_n[k])) return;
+            }
+            float total;
+            if (k > 0 && M.slot_lag[k]) {
+                total = rp_resident_dots_slot<NC, RW>(w[k], prev[k].c, M.slot_n[k], P.row0 + row_w0, lane);
+                prev[k] = cur;
+            } else {
+                total = rp_resident_dots_slot<NC, RW>(w[k], cur.c, M.slot_n[k], P.row0 + row_w0, lane);
+            }
+            if (k == 0)
+                wsum = total;
+            else
+                esum = k == 1 ? total : esum + total;
+        }
+        if (t > 0)
+            for (int q = 0; q < count; ++q) {   // the other members' progress
+                if ((swept >> q) & 1u) continue;
+                typename L::Vec seen;
+                Cs.gran[0] = rc_stream(C, q, 0, (t - 1) & 1);
+                if (!L::sweep(Cs, 0, (unsigned)t, seen, lane, M.all_rows[q])) return;
+            }
+        if (epi_lane) {
+            float v_new;
+            s_reg = epilogue_core<MODEL, true>(P, my_row, wsum, esum, I_x, v_reg, s_reg, &v_new, kRate ? &R : nullptr);
+            v_reg = v_new;
+            if (t + 1 < A.steps) {
+                if (M.publish_v) {
+                    Cs.gran[0] = rc_stream(C, m, 1, t & 1);
+                    rp_resident_publish(Cs, 0, my_row, (unsigned)(t + 1), v_new);
+                }
+                Cs.gran[0] = rc_stream(C, m, 0, t & 1);
+                rp_resident_publish(Cs, 0, my_row, (unsigned)(t + 1), s_reg);
+            }
+        }
+    }
+}
+
+template <int NSEG, int NC, int RW>
+__global__ __launch_bounds__(kThreads) void resident_coupled_kernel(const rp_resident_ctl C, const RcParams* __restrict__ params) {
+    static_assert(kWavesPerBlock == kResidentWaves, "rp_resident.h counts four waves per workgroup");
+    static_assert(NSEG * NC * RW <= 32 && NSEG <= kRcSlots, "a wave's rows: at most 128 registers");
+    const int work = rp_resident_join(C);
+    if (work < 0) return;
+    // the member this workgroup belongs to; its argument block is read in place (read-only, uniform addresses: scalar loads)
+    const int count = params->count;
+    int m = 0;
+    while (m + 1 < count && work >= params->M[m + 1].first_block) ++m;
+    const RcMember& M = params->M[m];
+    const int block = work - M.first_block;
+    switch (M.model) {
+        case RP_MODEL_LI_TANH: resident_coupled_member<RP_MODEL_LI_TANH, NSEG, NC, RW>(C, M, m, count, block); break;
+        case RP_MODEL_LI_SIGMOID: resident_coupled_member<RP_MODEL_LI_SIGMOID, NSEG, NC, RW>(C, M, m, count, block); break;
+        case RP_MODEL_QIF: resident_coupled_member<RP_MODEL_QIF, NSEG, NC, RW>(C, M, m, count, block); break;
+        case RP_MODEL_QIF_SFA: resident_coupled_member<RP_MODEL_QIF_SFA, NSEG, NC, RW>(C, M, m, count, block); break;
+        case RP_MODEL_LIF: resident_coupled_member<RP_MODEL_LIF, NSEG, NC, RW>(C, M, m, count, block); break;
+        default: resident_coupled_member<RP_MODEL_IK, NSEG, NC, RW>(C, M, m, count, block); break;
+    }
+}
+
 // The same code under its own name: the launches rp_tune_forward times on its scratch population, so that a kernel
 // trace keeps them apart from the steps of a run.
 template <int R, int U>
@@ -1392,8 +1540,38 @@ bool resident_ok(const rp_net* net, const rp_run* run) {
     return rp_resident_shape_any(net->n);
 }
 
+void resident_args_of(const rp_net* net, const rp_run* run, ResidentArgs& A);
+
 int forward_resident(rp_net* net, rp_run* run, StepParams& P, hipStream_t st) {
     ResidentArgs A = {};
+    resident_args_of(net, run, A);
+    void* ws = nullptr;
+    const bool v4 = use_vec4(net);
+    if (rp_resident_begin(net->n, st, &A.C, &ws, v4) != RP_OK) {   // (no stream-ordered allocator: one launch per step)
+        (void)hipGetLastError();
+        return kResidentUnavailable;
+    }
+    set_step(P, net, run, 0);   // (step 0's arguments -- the kernel forms every step's itself; the bookkeeping is advanced below)
+    switch (net->model) {
+        case RP_MODEL_LI_TANH: launch_resident_model<RP_MODEL_LI_TANH>(P, A, v4, st); break;
+        case RP_MODEL_LI_SIGMOID: launch_resident_model<RP_MODEL_LI_SIGMOID>(P, A, v4, st); break;
+        case RP_MODEL_QIF: launch_resident_model<RP_MODEL_QIF>(P, A, v4, st); break;
+        case RP_MODEL_QIF_SFA: launch_resident_model<RP_MODEL_QIF_SFA>(P, A, v4, st); break;
+        case RP_MODEL_LIF: launch_resident_model<RP_MODEL_LIF>(P, A, v4, st); break;
+        default: launch_resident_model<RP_MODEL_IK>(P, A, v4, st); break;
+    }
+    const int rc = rp_resident_end(A.C, ws, st, "the resident step kernel");
+    if (rc != RP_OK) return rc;
+    StepParams Q = P;
+    net->cur ^= 1;
+    for (int t = 1; t < run->steps; ++t) {   // the sampling bookkeeping and the buffer parity of the steps the kernel ran
+        set_step(Q, net, run, t);
+        net->cur ^= 1;
+    }
+    return RP_OK;
+}
+
+void resident_args_of(const rp_net* net, const rp_run* run, ResidentArgs& A) {
     A.steps = run->steps;
     A.cur0 = net->cur;
     A.src[0] = net->src[0];
@@ -1419,30 +1597,6 @@ int forward_resident(rp_net* net, rp_run* run, StepParams& P, hipStream_t st) {
     A.has_acc = run->acc ? 1 : 0;
     A.samples = run->samples;
     A.ldsamples = run->ldsamples;
-    void* ws = nullptr;
-    const bool v4 = use_vec4(net);
-    if (rp_resident_begin(net->n, st, &A.C, &ws, v4) != RP_OK) {   // (no stream-ordered allocator: one launch per step)
-        (void)hipGetLastError();
-        return kResidentUnavailable;
-    }
-    set_step(P, net, run, 0);   // (step 0's arguments -- the kernel forms every step's itself; the bookkeeping is advanced below)
-    switch (net->model) {
-        case RP_MODEL_LI_TANH: launch_resident_model<RP_MODEL_LI_TANH>(P, A, v4, st); break;
-        case RP_MODEL_LI_SIGMOID: launch_resident_model<RP_MODEL_LI_SIGMOID>(P, A, v4, st); break;
-        case RP_MODEL_QIF: launch_resident_model<RP_MODEL_QIF>(P, A, v4, st); break;
-        case RP_MODEL_QIF_SFA: launch_resident_model<RP_MODEL_QIF_SFA>(P, A, v4, st); break;
-        case RP_MODEL_LIF: launch_resident_model<RP_MODEL_LIF>(P, A, v4, st); break;
-        default: launch_resident_model<RP_MODEL_IK>(P, A, v4, st); break;
-    }
-    const int rc = rp_resident_end(A.C, ws, st, "the resident step kernel");
-    if (rc != RP_OK) return rc;
-    StepParams Q = P;
-    net->cur ^= 1;
-    for (int t = 1; t < run->steps; ++t) {   // the sampling bookkeeping and the buffer parity of the steps the kernel ran
-        set_step(Q, net, run, t);
-        net->cur ^= 1;
-    }
-    return RP_OK;
 }
 
 // rp_forward / rp_forward_sharded: `comm` != nullptr adds the per-step all-gather of the source slices.
@@ -1544,10 +1698,109 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
     return RP_OK;
 }
 
+// ---- the resident launch of a coupled circuit (resident_coupled_kernel): eligibility and the call --------------------------------
+// Circuits the shared launch takes (coupled_impl: `merged`) whose matrices are all on the 16-byte path with at most 512 columns,
+// (1 + in-edges) x chunks <= 4 per member.  kResidentUnavailable: nothing launched, the caller goes on with a launch per step.
+int coupled_resident(rp_member* mem, int count, StepParams* P, const bool* vec4, hipStream_t st) {
+    const int steps = mem[0].run->steps;
+    if (!rp_resident_enabled() || steps < kResidentMinSteps) return kResidentUnavailable;
+    int nseg = 2, widest = 0;
+    for (int m = 0; m < count; ++m) {
+        const rp_net* net = mem[m].net;
+        const rp_run* run = mem[m].run;
+        if (!vec4[m] || net->sp_vals || net->n > kRcCap || !rp_resident_shape(net->n, net->ldw) || !aligned16(net->W) ||
+            !aligned16(net->src[0]) || !aligned16(net->src[1]) || run->n_edges + 1 > kRcSlots)
+            return kResidentUnavailable;
+        widest = std::max(widest, net->n);
+        nseg = std::max(nseg, run->n_edges + 1);
+        for (int e = 0; e < run->n_edges; ++e)
+            if (!P[m].edge[e].vec4 || !aligned16(run->edge_w[e]) || run->edge_n[e] > kRcCap) return kResidentUnavailable;
+    }
+    const int nc = widest > 256 ? 2 : 1;
+    if (nseg * nc > 4) return kResidentUnavailable;
+    const int rw = nseg * nc <= 2 ? 16 : 8;
+
+    static_assert(sizeof(RcParams) <= 8192, "the members' argument blocks: a few KiB behind the granules");
+    RcParams H = {};
+    H.count = count;
+    int blocks = 0;
+    const int64_t a0 = mem[0].run->step0;
+    for (int m = 0; m < count; ++m) {
+        rp_net* net = mem[m].net;
+        rp_run* run = mem[m].run;
+        RcMember& M = H.M[m];
+        M.P0 = P[m];
+        resident_args_of(net, run, M.A);
+        M.first_block = blocks;
+        blocks += ((net->rows + rw - 1) / rw + kWavesPerBlock - 1) / kWavesPerBlock;
+        M.nslots = 1 + run->n_edges;
+        M.model = net->model;
+        M.slot_src[0] = m;
+        M.slot_n[0] = net->n;
+        M.slot_w[0] = net->W;
+        M.slot_ld[0] = net->ldw;
+        M.slot_vec0[0] = net->src[net->cur];
+        for (int e = 0; e < run->n_edges; ++e) {
+            const int k = e + 1, q = mem[m].edge_source[e];
+            const rp_net* qn = mem[q].net;
+            const rp_run* qr = mem[q].run;
+            const bool state_out = qr->out_var == RP_OUT_STATE0;
+            M.slot_src[k] = q;
+            M.slot_state[k] = state_out ? 1 : 0;
+            M.slot_lag[k] = mem[m].edge_mode[e] == RP_EDGE_LAG ? 1 : 0;
+            M.slot_n[k] = run->edge_n[e];
+            M.slot_w[k] = run->edge_w[e];
+            M.slot_ld[k] = run->edge_ld[e];
+            // (the state vector of this step from the ring -- seeded by the caller --, never from y: the step overwrites that)
+            M.slot_vec0[k] = state_out ? qr->hist[a0 % 3] : qn->src[qn->cur];
+            M.slot_lag0[k] = M.slot_lag[k] ? qr->hist[(a0 + 2) % 3] : nullptr;
+            if (state_out) H.M[q].publish_v = 1;
+        }
+        for (int q = 0; q < count; ++q) M.all_rows[q] = mem[q].net->rows;
+    }
+    rp_resident_ctl C = {};
+    void* ws = nullptr;
+    void* dev_params = nullptr;
+    if (rp_resident_begin_streams(2 * count, kRcCap, blocks, sizeof(RcParams), st, &C, &ws, &dev_params) != RP_OK) {
+        (void)hipGetLastError();
+        return kResidentUnavailable;
+    }
+    for (int m = 0; m < count; ++m) {   // step 0's arguments (the kernel forms every step's itself)
+        set_step(P[m], mem[m].net, mem[m].run, 0);
+        H.M[m].P0 = P[m];
+    }
+    if (hipMemcpyAsync(dev_params, &H, sizeof(RcParams), hipMemcpyHostToDevice, st) != hipSuccess) {
+        (void)hipFreeAsync(ws, st);
+        RP_FAIL(RP_ERR_HIP, "rp_forward_coupled: copying the members' argument blocks failed");
+    }
+    const dim3 grid(rp_resident_grid(C));
+    const RcParams* D = static_cast<const RcParams*>(dev_params);
+    if (nc == 2)
+        hipLaunchKernelGGL((resident_coupled_kernel<2, 2, 8>), grid, dim3(kThreads), 0, st, C, D);
+    else if (nseg == 2)
+        hipLaunchKernelGGL((resident_coupled_kernel<2, 1, 16>), grid, dim3(kThreads), 0, st, C, D);
+    else if (nseg == 3)
+        hipLaunchKernelGGL((resident_coupled_kernel<3, 1, 8>), grid, dim3(kThreads), 0, st, C, D);
+    else
+        hipLaunchKernelGGL((resident_coupled_kernel<4, 1, 8>), grid, dim3(kThreads), 0, st, C, D);
+    const int rc = rp_resident_end(C, ws, st, "the resident step kernel of a coupled circuit");
+    if (rc != RP_OK) return rc;
+    for (int m = 0; m < count; ++m) {   // the sampling bookkeeping and the buffer parity of the steps the kernel ran
+        StepParams Q = P[m];
+        mem[m].net->cur ^= 1;
+        for (int t = 1; t < steps; ++t) {
+            set_step(Q, mem[m].net, mem[m].run, t);
+            mem[m].net->cur ^= 1;
+        }
+    }
+    return RP_OK;
+}
+
 // rp_forward_coupled: the members' steps interleaved, one launch per member and Euler step
 int coupled_impl(rp_member* mem, int32_t count, void* stream) {
     constexpr int kMaxMembers = RP_MAX_MEMBERS;
     if (!mem || count < 1 || count > kMaxMembers) RP_FAIL(RP_ERR_ARG, "rp_forward_coupled: 1..%d members", kMaxMembers);
+    if (const int late = rp_resident_poll(); late != RP_OK) return late;
     for (int m = 0; m < count; ++m) {
         if (!mem[m].net || !mem[m].run) RP_FAIL(RP_ERR_ARG, "member %d: net / run is null", m);
         int rc = validate_net(mem[m].net);
@@ -1647,6 +1900,10 @@ int coupled_impl(rp_member* mem, int32_t count, void* stream) {
             const float* cur_out = run->out_var == RP_OUT_STATE0 ? net->y[RP_Y_V] : net->src[net->cur];
             RP_HIP_CHECK(hipMemcpyAsync(run->hist[a0 % 3], cur_out, sizeof(float) * (size_t)net->rows, hipMemcpyDeviceToDevice, st));
         }
+    }
+    if (merged) {   // launch-bound sizes: all steps in ONE launch (the resident form of the shared launch)
+        const int rc = coupled_resident(mem, count, P, vec4, st);
+        if (rc != kResidentUnavailable) return rc;
     }
     const int mR = max_rows <= 2048 ? 1 : 2;  // rows per wave (chunks in flight: 8, the whole row up to 2048 columns)
 

@@ -193,6 +193,32 @@ __device__ __forceinline__ float rp_resident_dots(const rp_f4 (&w)[RW][NC], cons
     return rp_rows_allreduce<RW>(rs, lane);
 }
 
+// ---- coupled circuits (rnn_forward.hip: resident_coupled_kernel): a wave keeps its rows of SEVERAL matrices -- the member's own
+// and its in-edges' --, each in a slot of NC chunks whatever the matrix's own width (<= 256 NC columns) -------------------------
+// rows past `rows` and columns past `cols` hold zeros
+template <int NC, int RW>
+__device__ __forceinline__ void rp_resident_load_rows_rect(rp_f4 (&w)[RW][NC], const float* W, int64_t ldw, int row_w0, int lane, int rows,
+                                                           int cols) {
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+        for (int m = 0; m < NC; ++m)
+            w[j][m] = (row_w0 + j < rows && 256 * m + 4 * lane < cols) ? rp_ld4(W + (int64_t)(row_w0 + j) * ldw + 256 * m + 4 * lane)
+                                                                       : rp_f4{0.f, 0.f, 0.f, 0.f};
+}
+// the row totals of a slot that holds a matrix of `cols` columns, in the order of THAT width's contract: a slot chunk past the
+// matrix's last one holds zeros and may come last (fma(0, 0, a) == a); the full chunks rotate among themselves
+template <int NC, int RW>
+__device__ __forceinline__ float rp_resident_dots_slot(const rp_f4 (&w)[RW][NC], const rp_f4 (&r)[NC], int cols, int global_row_w0, int lane) {
+    static_assert(NC == 1 || NC == 2, "slots of one or two chunks");
+    if constexpr (NC == 1) {
+        return rp_resident_dots<1, RW, false>(w, r, global_row_w0, lane);
+    } else {
+        if (cols == 512) return rp_resident_dots<2, RW, false>(w, r, global_row_w0, lane);   // two full chunks: the start chunk rotates
+        return rp_resident_dots<2, RW, true>(w, r, global_row_w0, lane);                      // chunk 0, then the partial (or empty) chunk 1
+    }
+}
+
 // ---- the two row-dot contracts as layouts of a wave's registers ------------------------------------------------------------------
 // 16-byte path (rp_dot_rows_v4: n % 4 == 0, ld % 4 == 0): lane l holds columns 256 m + 4 l .. + 3 of NC chunks
 template <int NC, int RW_, bool PARTIAL>
@@ -422,23 +448,25 @@ inline int* rp_resident_host_word(int** device_view) {
     if (device_view) *device_view = w.dev;
     return w.host;
 }
+// once per device: the default pool keeps the few KiB of scratch across synchronisations instead of returning them to the system
+inline void rp_resident_keep_pool() {
+    static unsigned char kept[RP_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < RP_MAX_DEVICES && !kept[dev]) {
+        hipMemPool_t pool = nullptr;
+        uint64_t keep = 1u << 20;
+        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool)
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        (void)hipGetLastError();
+        kept[dev] = 1;
+    }
+}
 // stream-ordered scratch (granules, failure word, roster), zeroed: a tag is never 0
 inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** ws, bool v4 = true) {
     const size_t bytes = (size_t)2 * n * sizeof(unsigned long long) + 64;
     *ws = nullptr;
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT_TEST_FAULT"); e && e[0] == '2') return RP_ERR_HIP;   // (test seam: no scratch)
-    {   // once per device: the default pool keeps the few KiB of scratch across synchronisations instead of returning them to the system
-        static unsigned char kept[RP_MAX_DEVICES];
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < RP_MAX_DEVICES && !kept[dev]) {
-            hipMemPool_t pool = nullptr;
-            uint64_t keep = 1u << 20;
-            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool)
-                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-            (void)hipGetLastError();
-            kept[dev] = 1;
-        }
-    }
+    rp_resident_keep_pool();
     if (hipMallocAsync(ws, bytes, st) != hipSuccess) return RP_ERR_HIP;
     if (hipMemsetAsync(*ws, 0, bytes, st) != hipSuccess) {
         (void)hipFreeAsync(*ws, st);
@@ -458,6 +486,38 @@ inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** w
     C->spin_cap = 1u << 22;   // polls of about a microsecond each: seconds
     C->test_fault = 0;
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT_TEST_FAULT"); e && e[0] == '1') {   // (test seam: a peer that never delivers)
+        C->test_fault = 1;
+        C->spin_cap = 4000;
+    }
+    return RP_OK;
+}
+// the same for a coupled circuit: `streams` granule vectors of `cap` granules in two parities each, `extra` bytes behind them
+// (the members' argument blocks); gran[0] = the first granule, gran[1] unused
+inline int rp_resident_begin_streams(int streams, int cap, int need_blocks, size_t extra, hipStream_t st, rp_resident_ctl* C, void** ws,
+                                     void** extra_ptr) {
+    const size_t gran_bytes = (size_t)2 * streams * cap * sizeof(unsigned long long);
+    const size_t bytes = gran_bytes + 64 + ((extra + 63) & ~(size_t)63);
+    *ws = nullptr;
+    if (const char* e = getenv("RECTIPY_AMD_RESIDENT_TEST_FAULT"); e && e[0] == '2') return RP_ERR_HIP;   // (test seam: no scratch)
+    rp_resident_keep_pool();
+    if (hipMallocAsync(ws, bytes, st) != hipSuccess) return RP_ERR_HIP;
+    if (hipMemsetAsync(*ws, 0, gran_bytes + 64, st) != hipSuccess) {
+        (void)hipFreeAsync(*ws, st);
+        return RP_ERR_HIP;
+    }
+    C->gran[0] = static_cast<unsigned long long*>(*ws);
+    C->gran[1] = nullptr;
+    C->fail = reinterpret_cast<int*>(static_cast<char*>(*ws) + gran_bytes);
+    C->ctl = reinterpret_cast<unsigned*>(C->fail) + 4;
+    *extra_ptr = static_cast<char*>(*ws) + gran_bytes + 64;
+    (void)rp_resident_host_word(&C->host_fail);
+    C->need_blocks = need_blocks;
+    C->one_xcd = need_blocks <= 8 ? 1 : 0;
+    if (const char* e = getenv("RECTIPY_AMD_RESIDENT_XCD"); e && e[0] == '0') C->one_xcd = 0;
+    else if (e && e[0] == '2' && C->one_xcd) C->one_xcd = 2;
+    C->spin_cap = 1u << 22;
+    C->test_fault = 0;
+    if (const char* e = getenv("RECTIPY_AMD_RESIDENT_TEST_FAULT"); e && e[0] == '1') {
         C->test_fault = 1;
         C->spin_cap = 4000;
     }

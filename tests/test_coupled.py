@@ -211,15 +211,24 @@ def test_argument_checks(oracle_backend):
 
 # ---- HIP vs oracle ---------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("launches", ["shared", "member"])
+@pytest.mark.parametrize("launches", ["resident", "shared", "member"])
 @pytest.mark.parametrize("sizes,models,out_vars", CASES + [((1024, 2052, 512), ("li_tanh", "qif", "li_tanh"), (0, 1, 1)),
-                                                           ((4100, 260), ("li_tanh", "li_tanh"), (0, 0))])
+                                                           ((4100, 260), ("li_tanh", "li_tanh"), (0, 0)),
+                                                           # the resident launch's shapes: two chunks per slot, four slots, ragged widths
+                                                           ((256, 512), ("li_tanh", "qif"), (0, 1)),
+                                                           ((512, 512), ("li_tanh", "li_tanh"), (1, 1)),
+                                                           ((500, 300), ("qif", "li_tanh"), (1, 0)),
+                                                           ((128, 132, 64, 32), ("li_tanh", "qif", "li_tanh", "qif"), (0, 0, 1, 1)),
+                                                           ((256, 8, 200), ("qif", "qif", "li_tanh"), (0, 1, 0))])
 def test_hip_coupled_bit_exact(oracle_backend, hip_device, monkeypatch, sizes, models, out_vars, launches):
-    """HIP == oracle, bit for bit, both ways the library issues a step: ONE launch for all members (every edge of these
-    circuits reads a value from before the step; members of at most 4096 neurons) and one launch per member
-    (RECTIPY_AMD_COUPLED_LAUNCHES=member; the 4100-neuron case takes it by size)."""
+    """HIP == oracle, bit for bit, all three ways the library issues the steps: ALL steps of the call in one launch (r05: circuits
+    of members of at most 512 neurons on the 16-byte path, (1 + in-edges) x chunks <= 4; the others fall through to ...) ONE
+    launch per step for all members (every edge of these circuits reads a value from before the step; members of at most 4096
+    neurons), and one launch per member and step (RECTIPY_AMD_COUPLED_LAUNCHES=member; the 4100-neuron case takes it by size)."""
     if launches == "member":
         monkeypatch.setenv("RECTIPY_AMD_COUPLED_LAUNCHES", "member")
+    if launches != "resident":
+        monkeypatch.setenv("RECTIPY_AMD_RESIDENT", "0")
     T = 40
     x = torch.randn(T, sizes[0], generator=torch.Generator().manual_seed(9)) * 0.5
     res = []

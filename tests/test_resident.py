@@ -278,3 +278,30 @@ def test_no_resident_launch_reported_a_timeout(hip_device):
     from rectipy_amd.engine import default_backend
     torch.cuda.synchronize()
     default_backend().async_status()
+
+
+def test_coupled_circuit_takes_the_resident_launch_and_reports_a_peer_that_never_delivers(hip_device, monkeypatch):
+    """A circuit of small members runs all steps of an rp_forward_coupled call in one launch (resident_coupled_kernel): with the test
+    seam that withholds element 0 of every stream the launch gives up after its bounded wait and the library reports it at the next
+    look (rp_async_status) -- so the path was taken --; without the seam the call equals the launches per step (bit for bit:
+    tests/test_coupled.py::test_hip_coupled_bit_exact)."""
+    from rectipy_amd.engine import default_backend
+    from test_coupled import circuit, run_circuit
+    sizes, models, out_vars = (64, 96), ("li_tanh", "li_tanh"), (0, 0)
+    x = torch.randn(20, sizes[0], generator=torch.Generator().manual_seed(1)).to(hip_device)
+    backend = default_backend()
+    torch.cuda.synchronize()
+    backend.async_status()   # (nothing pending from the tests before)
+    monkeypatch.setenv("RECTIPY_AMD_RESIDENT_TEST_FAULT", "1")
+    pops, edges = circuit(sizes, models, seed=5, dev=hip_device, backend=None)
+    run_circuit(pops, edges, models, out_vars, x, 20, 1, hip_device)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("RECTIPY_AMD_RESIDENT_TEST_FAULT")
+    with pytest.raises(RuntimeError, match="timed out waiting for a peer wave"):
+        backend.async_status()
+    backend.async_status()   # (reported once)
+    pops, edges = circuit(sizes, models, seed=5, dev=hip_device, backend=None)
+    res = run_circuit(pops, edges, models, out_vars, x, 20, 1, hip_device)
+    torch.cuda.synchronize()
+    backend.async_status()
+    assert all(bool(torch.isfinite(r[0]).all()) for r in res)
