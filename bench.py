@@ -611,9 +611,45 @@ def small_n_extra(dev, N=512, T=2000):
                    "the dependent-launch interval of the stream and fit_bptt by the host's launch rate; fit_bptt adds the per-window work "
                    "(W^T copy, dW GEMM, read-out, loss, optimiser); fit_rls with an update every step: the RLS sweep of a window is one "
                    "launch too (P and W in registers, one exchange per update; three launches per update before)")
+    # a small coupled circuit (two populations of N/2, a -> b with feedback b -> a): rp_forward_coupled runs all steps of a call in one
+    # launch too (resident_coupled_kernel: the members' and the edges' rows in registers, one granule stream per member)
+    from rectipy_amd import FeedbackNetwork
+    h = N // 2
+
+    def pair(train):
+        fb = FeedbackNetwork(dt=1e-2, device=str(dev))
+        kw = lambda Wm: dict(input_var="li_op/I_ext", output_var="li_op/v", weights=Wm, source_var="tanh_op/r", target_var="li_op/r_in",
+                             dtype=torch.float32, train_params=["weights"] if train else None)
+        fb.add_diffeq_node("a", tanh, **kw(gen_rows(h, 0, h, dev, g=0.8)))
+        fb.add_diffeq_node("b", tanh, **kw(gen_rows(h, 0, h, dev, g=0.8)))
+        fb.add_func_node("out", 3, "identity")
+        fb.add_edge("a", "b", weights=gen_rows(h, 0, h, dev, g=0.5), train=train)
+        fb.add_edge("b", "a", weights=gen_rows(h, 0, h, dev, g=0.5), feedback=True, train=train)
+        fb.add_edge("b", "out", weights=torch.randn(3, h, device=dev, generator=gen) / h ** 0.5, train="gd")
+        return fb
+
+    xh = x[:, :h].contiguous()
+
+    def pair_times():
+        out = {}
+        with contextlib.redirect_stdout(sys.stderr):
+            for key, train in (("FeedbackNetwork_run", None), ("FeedbackNetwork_fit_bptt_all_matrices", "gd")):
+                fb = pair(train)
+                call = (lambda: fb.run(xh, sampling_steps=1, verbose=False, enable_grad=False)) if train is None else \
+                    (lambda: fb.fit_bptt(xh, target, optimizer="sgd", lr=1e-3, update_steps=100, sampling_steps=100, verbose=False))
+                call()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                call()
+                torch.cuda.synchronize()
+                out[key] = (time.perf_counter() - t0) / T * 1e6
+                del fb
+        return out
+    res["two_populations_of_N_over_2"] = pair_times()
     # the same calls with one launch per step (the r04 path), for the record
     os.environ["RECTIPY_AMD_RESIDENT"] = "0"
     try:
+        res["two_populations_of_N_over_2_launch_per_step"] = pair_times()
         with contextlib.redirect_stdout(sys.stderr):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
