@@ -112,12 +112,8 @@ struct BwdParams {
 
 // partials[q][j] = sum_{i in chunk q, ascending} W[i][j] * u[i]
 // SW = 16-byte column groups per lane: a wave covers a strip of 256*SW columns (SW KiB contiguous per row).
-struct NoTail {
-    __device__ __forceinline__ void operator()(int) const {}
-};
-// TAIL: called by the wave after each item's partial sums are stored, with the item's strip (the coupled circuits' one-launch step)
-template <bool VEC4, int U, int SW, class TAIL = NoTail>
-__device__ __forceinline__ void wt_partial_body(const BwdParams& P, const TAIL& tail = TAIL()) {
+template <bool VEC4, int U, int SW>
+__device__ __forceinline__ void wt_partial_body(const BwdParams& P) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row indices and u[i] go scalar
     constexpr int CW = VEC4 ? 256 * SW : 64;  // columns per strip
@@ -189,7 +185,6 @@ __device__ __forceinline__ void wt_partial_body(const BwdParams& P, const TAIL& 
                 P.partials[(int64_t)chunk * P.n + col] = a;
             }
         }
-        tail(strip);
     }
 }
 
@@ -1309,97 +1304,6 @@ __global__ __launch_bounds__(256) void coupled_finalize_kernel(const CoupledFin 
         finalize_elem(P, j, z);
 }
 
-// ---- ... and ONE launch per backward step (r05): the wave that completes a column strip runs its element-wise part ------------
-// The two launches above are bounded by the host's launch rate at these sizes (5-6 us each on the box).  Every item (strip, chunk)
-// of every matrix counts itself arrived at the strip of the member its product ends in -- the member itself for W^T u, the
-// edge's SOURCE for W_e^T gx --: partial sums stored, fence, one atomic add; the wave that brings a strip's count to the step's
-// target (cumulative over the sweep: the counters are zeroed once per call) has every partial sum of those 256 columns behind
-// its own fence and does what coupled_finalize_kernel does for them: the edge sums into the output-gradient rows in member /
-// edge order, the chunk-ordered sum of W^T u, the member's adjoint step.  No wave waits for another.  Same partial sums, same
-// additions in the same order: bit-identical to the two launches (RECTIPY_AMD_COUPLED_ADJ_LAUNCHES=2 selects them).
-constexpr int kFusedStrips = kFusedMaxN / 256;
-struct TailArgs {
-    unsigned* counters;                            // [kFusedMembers][kFusedStrips], zeroed at the start of the sweep
-    unsigned target[kFusedMembers];                // arrivals per strip of member m up to and including this step
-    int dest[kFusedMembers + kFusedEdges];         // the member matrix i's product ends in
-};
-static_assert(sizeof(PartArgs) + sizeof(CoupledFin) + sizeof(TailArgs) <= 4000, "the argument blocks of coupled_step_kernel must fit the kernel-argument segment");
-
-struct CoupledTail {
-    int dest;
-    unsigned* counter;    // the destination member's strips
-    unsigned target;
-    size_t fin_offset;    // CoupledFin in the kernel-argument segment
-    __device__ __forceinline__ void operator()(int strip) const {
-        typedef const __attribute__((address_space(4))) char* karg_ptr;
-        const int lane = threadIdx.x & 63;
-        __threadfence();   // this wave's partial sums before its arrival
-        unsigned seen = 0u;
-        if (lane == 0) seen = __hip_atomic_fetch_add(counter + strip, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        seen = (unsigned)__builtin_amdgcn_readfirstlane((int)seen);
-        if (seen + 1u != target) return;
-        __threadfence();   // the last to arrive: everyone else's partial sums after their arrivals
-        const karg_ptr base = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + fin_offset;
-        const int m = dest;
-        BwdParams P;
-        SpkGrad G;
-        __builtin_memcpy(&P, base + offsetof(CoupledFin, mem) + sizeof(BwdParams) * m, sizeof(BwdParams));
-        __builtin_memcpy(&G, base + offsetof(CoupledFin, grad) + sizeof(SpkGrad) * m, sizeof(SpkGrad));
-        int n_in;
-        __builtin_memcpy(&n_in, base + offsetof(CoupledFin, n_in) + sizeof(int) * m, sizeof(int));
-        for (int k = 0; k < 4; ++k) {
-            const int j = 256 * strip + 64 * k + lane;
-            if (j >= P.rows) continue;
-            for (int e = 0; e < n_in; ++e) {
-                EdgeSum E;
-                __builtin_memcpy(&E, base + offsetof(CoupledFin, in) + sizeof(EdgeSum) * (m * kFusedEdges + e), sizeof(EdgeSum));
-                if (!E.dst) continue;
-                BwdParams Q = {};
-                Q.partials = const_cast<float*>(E.partials);
-                Q.n = E.n;
-                Q.q = E.q;
-                E.dst[j] = E.dst[j] + chunk_sum(Q, j);
-            }
-            const float z = chunk_sum(P, j);
-            if (P.model >= RP_MODEL_QIF)
-                spk_finalize_elem(P, G, j, z);
-            else
-                finalize_elem(P, j, z);
-        }
-    }
-};
-
-#define RP_COUPLED_STEP(NAME, U_)                                                                                              \
-    __global__ __launch_bounds__(kThreads) void NAME(const PartArgs A, const CoupledFin F, const TailArgs Tl) {               \
-        typedef const __attribute__((address_space(4))) char* karg_ptr;                                                       \
-        const karg_ptr kbase = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();                                              \
-        PartArg a;                                                                                                            \
-        __builtin_memcpy(&a, kbase + offsetof(PartArgs, a) + sizeof(PartArg) * blockIdx.y, sizeof(PartArg));                  \
-        int dest;                                                                                                             \
-        __builtin_memcpy(&dest, kbase + sizeof(PartArgs) + sizeof(CoupledFin) + offsetof(TailArgs, dest) + sizeof(int) * blockIdx.y, \
-                         sizeof(int));                                                                                        \
-        unsigned target;                                                                                                      \
-        __builtin_memcpy(&target, kbase + sizeof(PartArgs) + sizeof(CoupledFin) + offsetof(TailArgs, target) + sizeof(unsigned) * dest, \
-                         sizeof(unsigned));                                                                                   \
-        BwdParams P = {};                                                                                                     \
-        P.W = a.W;                                                                                                            \
-        P.ldw = a.ldw;                                                                                                        \
-        P.u = a.u;                                                                                                            \
-        P.partials = a.partials;                                                                                              \
-        P.n = a.n;                                                                                                            \
-        P.rows = a.rows;                                                                                                      \
-        P.rc = a.rc;                                                                                                          \
-        P.q = a.q;                                                                                                            \
-        const int strips = (P.n + 255) / 256;                                                                                 \
-        if ((int)blockIdx.x * (kThreads / 64) >= strips * P.q) return; /* (the grid is sized for the largest matrix) */       \
-        wt_partial_body<true, U_, 1>(P, CoupledTail{dest, Tl.counters + dest * kFusedStrips, target, sizeof(PartArgs)});      \
-    }
-RP_COUPLED_STEP(coupled_step_kernel_8, 8)
-RP_COUPLED_STEP(coupled_step_kernel_2, 2)
-#undef RP_COUPLED_STEP
-static_assert(offsetof(PartArgs, a) == 0 && sizeof(PartArgs) % 8 == 0 && sizeof(CoupledFin) % 8 == 0,
-              "coupled_step_kernel reads its three argument blocks at their offsets in the kernel-argument segment");
-
 int rp_sizeof_bwd_member(void) { return (int)sizeof(rp_bwd_member); }
 
 
@@ -1434,28 +1338,11 @@ static bool coupled_fused_ok(const rp_bwd_member* mem, int count, bool* small) {
 static int coupled_fused_sweep(const rp_bwd_member* mem, int count, int T, hipStream_t st, bool one_launch) {
     CoupledFin F = {};
     PartArgs A = {};
-    TailArgs Tl = {};
-    // one launch per step (coupled_step_kernel) when the products share a launch anyway and the arrival counters can be had
-    bool single = one_launch;
-    if (const char* e = getenv("RECTIPY_AMD_COUPLED_ADJ_LAUNCHES"); e && e[0] == '2') single = false;
-    if (single) {
-        const size_t bytes = sizeof(unsigned) * kFusedMembers * kFusedStrips;
-        void* ws = nullptr;
-        if (hipMallocAsync(&ws, bytes, st) != hipSuccess || hipMemsetAsync(ws, 0, bytes, st) != hipSuccess) {
-            if (ws) (void)hipFreeAsync(ws, st);
-            (void)hipGetLastError();
-            single = false;
-        }
-        Tl.counters = static_cast<unsigned*>(ws);
-    }
     bool vec4;
     for (int m = 0; m < count; ++m) {
         const int rc = is_spiking(mem[m].net) ? spk_setup(mem[m].net, mem[m].bwd, F.mem[m], F.grad[m], vec4)
                                               : sharded_params(mem[m].net, mem[m].bwd, F.mem[m], vec4);
-        if (rc != RP_OK) {
-            if (Tl.counters) (void)hipFreeAsync(Tl.counters, st);
-            return rc;
-        }
+        if (rc != RP_OK) return rc;
     }
     int max_rows = 0, max_blocks = 1;
     for (int t = T - 1; t >= 0; --t) {
@@ -1464,8 +1351,6 @@ static int coupled_fused_sweep(const rp_bwd_member* mem, int count, int T, hipSt
         for (int m = 0; m < count; ++m) {
             const rp_bwd* b = mem[m].bwd;
             BwdParams& P = F.mem[m];
-            Tl.dest[mats] = m;
-            Tl.target[m] += (unsigned)P.q;
             A.a[mats++] = PartArg{P.W, P.ldw, b->u_traj + (int64_t)t * b->ld, P.partials, P.n, P.rows, P.rc, P.q};
             int64_t off = 0;
             for (int e = 0; e < mem[m].n_edges; ++e) {
@@ -1476,8 +1361,6 @@ static int coupled_fused_sweep(const rp_bwd_member* mem, int count, int T, hipSt
                 off += (int64_t)chunks * nq;
                 const int tau = mem[m].edge_mode[e] == RP_EDGE_LAG ? t - 1 : t;
                 if (tau < 0) continue;
-                Tl.dest[mats] = q;
-                Tl.target[q] += (unsigned)chunks;
                 A.a[mats++] = PartArg{mem[m].edge_w[e], mem[m].edge_ld[e], b->grad_x + (int64_t)t * b->ldgx, work, nq, P.rows, rc, chunks};
                 F.in[q][F.n_in[q]++] = EdgeSum{work, const_cast<float*>(mem[q].bwd->grad_out) + (int64_t)tau * mem[q].bwd->ldg, nq, chunks};
             }
@@ -1521,19 +1404,12 @@ static int coupled_fused_sweep(const rp_bwd_member* mem, int count, int T, hipSt
                                 !(reinterpret_cast<uintptr_t>(Q.partials) & 15u);
                 launch_wt_partial(Q, v4, st);
             }
-        } else if (single) {
-            if (many)
-                hipLaunchKernelGGL(coupled_step_kernel_2, dim3(max_blocks, mats), dim3(kThreads), 0, st, A, F, Tl);
-            else
-                hipLaunchKernelGGL(coupled_step_kernel_8, dim3(max_blocks, mats), dim3(kThreads), 0, st, A, F, Tl);
-            continue;
         } else if (many)
             hipLaunchKernelGGL(coupled_partials_kernel_2, dim3(max_blocks, mats), dim3(kThreads), 0, st, A);
         else
             hipLaunchKernelGGL(coupled_partials_kernel_8, dim3(max_blocks, mats), dim3(kThreads), 0, st, A);
         hipLaunchKernelGGL(coupled_finalize_kernel, dim3((max_rows + 255) / 256, count), dim3(256), 0, st, F);
     }
-    if (Tl.counters) (void)hipFreeAsync(Tl.counters, st);
     RP_HIP_CHECK(hipGetLastError());
     return RP_OK;
 }
