@@ -915,7 +915,9 @@ def test_feedback_from_a_population_already_stepped_takes_the_fused_adjoint_too(
     ((24, 40, 16), (0, 0, 1), None), ((17, 30), (1, 0), None), ((260, 136, 72), (1, 1, 0), None),
     ((1024, 2052, 512), (0, 1, 1), None), ((4100, 520), (1, 0), None),
     ((32, 20), (1, 0), ("qif", "li_tanh")), ((17, 30, 12), (1, 1, 0), ("li_tanh", "qif", "qif")),
-    ((520, 1028), (1, 1), ("qif", "qif"))])
+    ((520, 1028), (1, 1), ("qif", "qif")),
+    # strips of 256 columns that do not fill, four members
+    ((256, 512, 300), (0, 1, 0), None), ((64, 128, 36, 260), (0, 1, 1, 0), ("li_tanh", "qif", "li_tanh", "qif"))])
 def test_hip_coupled_adjoint_bit_exact(oracle_backend, hip_device, sizes, out_vars, models, post):
     """rp_backward_coupled on the GPU against the C oracle: adjoint states, per-step u, input gradients, the output
     gradients the edges accumulate into and the per-neuron parameter gradients, bit for bit."""
