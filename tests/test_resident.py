@@ -305,3 +305,24 @@ def test_coupled_circuit_takes_the_resident_launch_and_reports_a_peer_that_never
     torch.cuda.synchronize()
     backend.async_status()
     assert all(bool(torch.isfinite(r[0]).all()) for r in res)
+
+
+@pytest.mark.parametrize("xcd", ["0", "2"])
+def test_coupled_resident_launch_on_any_placement(hip_device, monkeypatch, xcd):
+    """The roster of the coupled launch completes wherever its workgroups land: no one-XCD placement (RECTIPY_AMD_RESIDENT_XCD=0)
+    and a placement whose XCD "gets" too few workgroups (=2: the others take the leftover tickets) -- the bits of a launch per step."""
+    from rectipy_amd.engine import default_backend
+    from test_coupled import circuit, run_circuit
+    sizes, models, out_vars = (64, 96, 32), ("li_tanh", "qif", "li_tanh"), (0, 1, 1)
+    x = (torch.randn(30, sizes[0], generator=torch.Generator().manual_seed(2)) * 0.5).to(hip_device)
+    got = []
+    for resident in ("1", "0"):
+        monkeypatch.setenv("RECTIPY_AMD_RESIDENT", resident)
+        monkeypatch.setenv("RECTIPY_AMD_RESIDENT_XCD", xcd)
+        pops, edges = circuit(sizes, models, seed=11, dev=hip_device, backend=None)
+        got.append(run_circuit(pops, edges, models, out_vars, x, 30, 2, hip_device))
+    torch.cuda.synchronize()
+    default_backend().async_status()
+    for m in range(len(sizes)):
+        for a, b, name in zip(got[0][m], got[1][m], ("traj", "samples", "v", "source")):
+            same(a, b, f"member {m} {name}")
