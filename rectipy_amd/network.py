@@ -926,10 +926,13 @@ class Network:
         plan = self._chain_plan()
         rec_vars = list(obs.recorded_state_variables)
         steps = inp.shape[0]
+        # recorded variables of THE population of a chain come out of the window the autograd node stores anyway
+        slots = self._record_slots(self.get_node(plan[1]), rec_vars) \
+            if rec_vars and plan is not None and all(v[0] == plan[1] for v in rec_vars) else None
         windows = plan is None and not rec_vars and self._dag_plan([]) is not None  # several populations, no cycles
         # populations joined by dense edges, cycles included (FeedbackNetwork): forward and adjoint one call per window each
         coupled = self._coupled_grad_plan() if plan is None and not windows and not rec_vars else None
-        if (plan is None and not windows and coupled is None) or rec_vars:
+        if (plan is None and not windows and coupled is None) or (rec_vars and slots is None):
             if rec_vars:
                 self._why_not = dict(getattr(self, "_why_not", {}), rec="fit_bptt records state variables (record_vars)")
                 self._warn_stepwise("Network.fit_bptt", "rec")
@@ -939,7 +942,7 @@ class Network:
                                        optim_steps, verbose)
         try:
             return self._bptt_windows(inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps, optim_steps,
-                                      verbose, plan, windows, coupled)
+                                      verbose, plan, windows, coupled, slots or [])
         finally:
             self._set_fused_sgd(None)   # (an exception inside a window must not leave the plan to a later backward call)
 
@@ -952,7 +955,7 @@ class Network:
                 self.get_node(n)._fused_sgd = plan
 
     def _bptt_windows(self, inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps, optim_steps, verbose,
-                      plan, windows, coupled) -> Observer:
+                      plan, windows, coupled, slots=()) -> Observer:
         steps, error = inp.shape[0], 0.0
         if not windows and coupled is None:
             pre, label, post = plan
@@ -983,10 +986,20 @@ class Network:
                     # parameters or something trainable upstream.  (The reference also tracks the state after
                     # `detach(requires_grad=True)`, network.py:496; inside fit_bptt that leaf is unreachable for the
                     # caller, so a read-out-only fit skips the sweep: same parameter updates at the forward's speed.)
-                    into_rnn = X.requires_grad or any(p.requires_grad for p in rnn.parameters())
+                    into_rnn = X.requires_grad or any(p.requires_grad for p in rnn.parameters()) or bool(slots)
                     traj = rnn._grad_window(b - a, self._fit_width(X, N)) if into_rnn else \
                         self._nograd_traj(rnn, b - a, self._fit_width(X, N))
                     preds = self._apply_chain(post, traj, label, None) if post else traj
+                    rec_rows = []
+                    if slots:   # (as `run` with a gradient: the window the autograd node stored)
+                        window = tuple(rnn._last_window) + (None, None)  # (v, source, aux, aux2)
+                        for slot in slots:
+                            src = window[slot]
+                            if isinstance(rnn, SpikeResetNet):  # exposes the pre-update state (nodes.py:387-392)
+                                rec_rows.append(src)
+                            else:  # post-update values: row t + 1, last row = the state now
+                                last = rnn._pop.v if slot == 0 else rnn._pop.source_local
+                                rec_rows.append(torch.cat((src[1:], last.detach().reshape(1, -1))))
                 prev_error = error
                 if b - a == optim_steps:  # only complete windows trigger an update (network.py:1035)
                     error = self._bptt_step(preds, target[a:b], optimizer, loss, error_kwargs, step_kwargs,
@@ -999,7 +1012,8 @@ class Network:
                 losses = [error if (t == b - 1 and b - a == optim_steps) else prev_error for t in sample_at]
                 # (a strided view: indexing with a Python list builds an index tensor on the host and copies it to the device --
                 # a blocking copy that waits for the whole window's kernels, once per window)
-                obs.record_block(sample_at, preds.detach()[sample_at[0] - a::sampling_steps].clone(), losses, [])
+                obs.record_block(sample_at, preds.detach()[sample_at[0] - a::sampling_steps].clone(), losses,
+                                 [r.detach()[sample_at[0] - a::sampling_steps].clone() for r in rec_rows] if slots else [])
                 if verbose:
                     print(f"Progress: {sample_at[-1]}/{steps} training steps finished. Current loss: {error}.")
         return obs
