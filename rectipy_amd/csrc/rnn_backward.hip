@@ -669,7 +669,7 @@ int launch_resident_adj(const BwdParams& P, const rp_bwd* b, bool v4, hipStream_
     }
     const dim3 grid(rp_resident_grid(A.C));
 #define RP_LAUNCH_(L_) hipLaunchKernelGGL((resident_adj_kernel<RP_UNPAREN L_>), grid, dim3(kThreads), 0, st, P, A)
-    RP_RESIDENT_DISPATCH_LAYOUT(P.n, v4, RP_LAUNCH_)
+    RP_RESIDENT_DISPATCH_LAYOUT_WIDE(P.n, v4, RP_LAUNCH_)
 #undef RP_LAUNCH_
     return rp_resident_end(A.C, ws, st, "the resident adjoint sweep");
 }
@@ -764,7 +764,7 @@ int launch_resident_spk_adj(const BwdParams& P, const SpkGrad& G, const rp_bwd* 
     }
     const dim3 grid(rp_resident_grid(A.C));
 #define RP_LAUNCH_(L_) hipLaunchKernelGGL((resident_spk_adj_kernel<RP_UNPAREN L_>), grid, dim3(kThreads), 0, st, P, G, A)
-    RP_RESIDENT_DISPATCH_LAYOUT(P.n, v4, RP_LAUNCH_)
+    RP_RESIDENT_DISPATCH_LAYOUT_WIDE(P.n, v4, RP_LAUNCH_)
 #undef RP_LAUNCH_
     return rp_resident_end(A.C, ws, st, "the resident adjoint sweep");
 }
@@ -1043,7 +1043,7 @@ int rp_rate_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     set_prep(T - 1);
     hipLaunchKernelGGL(prep_kernel, dim3(eblocks), dim3(256), 0, st, P);
     if (use_wt && rp_resident_enabled() && T >= 4 &&
-        (vec4_t ? (rp_resident_shape(n, b->ldwt) && b->ld % 4 == 0 && !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u)) : rp_resident_shape_any(n)))
+        (vec4_t ? (rp_resident_shape_wide(n, b->ldwt) && b->ld % 4 == 0 && !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u)) : rp_resident_shape_any(n)))
     {
         const int rrc = launch_resident_adj(P, b, vec4_t, st);   // the whole sweep in one launch (the row-dot path the launches would take)
         if (rrc != kResidentUnavailable) return rrc;
@@ -1903,7 +1903,7 @@ int rp_qif_backward(const rp_net* net, const rp_bwd* b, void* stream) {
     if (mean_coupled) hipLaunchKernelGGL(adj_mean_kernel, dim3(1), dim3(1024), 0, st, P);
     hipLaunchKernelGGL(spk_prep_kernel, dim3(eblocks), dim3(256), 0, st, P, G);
     if (use_wt && !mean_coupled && rp_resident_enabled() && T >= 4 &&
-        (vec4_t ? (rp_resident_shape(P.n, b->ldwt) && b->ld % 4 == 0 && !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u))
+        (vec4_t ? (rp_resident_shape_wide(P.n, b->ldwt) && b->ld % 4 == 0 && !(reinterpret_cast<uintptr_t>(b->u_traj) & 15u))
                 : rp_resident_shape_any(P.n)))
     {
         const int rrc = launch_resident_spk_adj(P, G, b, vec4_t, st);   // the whole sweep in one launch

@@ -1523,7 +1523,7 @@ template <int MODEL>
 void launch_resident_model(const StepParams& P, const ResidentArgs& A, bool v4, hipStream_t st) {
     const dim3 grid(rp_resident_grid(A.C));
 #define RP_LAUNCH_(L_) hipLaunchKernelGGL((resident_kernel<MODEL, RP_UNPAREN L_>), grid, dim3(kThreads), 0, st, P, A)
-    RP_RESIDENT_DISPATCH_LAYOUT(P.n, v4, RP_LAUNCH_)
+    RP_RESIDENT_DISPATCH_LAYOUT_WIDE(P.n, v4, RP_LAUNCH_)
 #undef RP_LAUNCH_
 }
 
@@ -1536,7 +1536,7 @@ bool resident_ok(const rp_net* net, const rp_run* run) {
     if (net->sp_vals || run->n_edges > 0 || run->save_src_full || run->steps < kResidentMinSteps) return false;
     if (net->rows != net->n || net->row0 != 0) return false;
     if (use_vec4(net))   // the 16-byte path of the per-step kernels, or their 4-byte path: the same rule, the same bits
-        return rp_resident_shape(net->n, net->ldw) && aligned16(net->W) && aligned16(net->src[0]) && aligned16(net->src[1]);
+        return rp_resident_shape_wide(net->n, net->ldw) && aligned16(net->W) && aligned16(net->src[0]) && aligned16(net->src[1]);
     return rp_resident_shape_any(net->n);
 }
 

@@ -40,7 +40,7 @@ typedef __attribute__((address_space(1))) int rp_gi32;
 constexpr int kResidentWaves = 4;                     // waves per workgroup
 constexpr int kResidentUnavailable = 1;               // (internal: no stream-ordered scratch -- nothing launched, the caller launches per step)
 constexpr int rp_resident_chunks(int n) { return (n + 255) >> 8; }   // 256-column chunks, the last one possibly partial
-constexpr int rp_resident_rows_per_wave(int n) { return rp_resident_chunks(n) <= 2 ? 16 : 8; }
+constexpr int rp_resident_rows_per_wave(int n) { return rp_resident_chunks(n) <= 2 ? 16 : (rp_resident_chunks(n) <= 4 ? 8 : 4); }
 
 // the work index of this workgroup, or -1 (it leaves).  Ends with the workgroup's barrier.
 __device__ __forceinline__ int rp_resident_join(const rp_resident_ctl& C) {
@@ -142,10 +142,10 @@ __device__ __forceinline__ void rp_resident_publish(const rp_resident_ctl& C, in
 
 // eight rows (one stagger group: the same start chunk M0) against the chunks of the vector, in the contract's order (rp_dot.h:
 // the MF full chunks from M0 on, wrapping; then the partial last chunk -- its lanes past n hold zeros: fma(0, 0, a) == a)
-template <int NC, int MF, int M0>
+template <int NC, int MF, int M0, int ROWS = 8>
 __device__ __forceinline__ void rp_resident_dot8(const rp_f4 (*w)[NC], const rp_f4 (&r)[NC], float* rs) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < ROWS; ++j) {
         rp_f4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
@@ -173,20 +173,26 @@ __device__ __forceinline__ void rp_resident_load_rows(rp_f4 (&w)[RW][NC], const 
 // STAGGER = false: every row starts at chunk 0 (the RLS passes)
 template <int NC, int RW, bool PARTIAL, bool STAGGER = true>
 __device__ __forceinline__ float rp_resident_dots(const rp_f4 (&w)[RW][NC], const rp_f4 (&r)[NC], int global_row_w0, int lane) {
-    static_assert(RW == 8 || RW == 16, "one or two stagger groups of eight rows per wave");
+    static_assert(RW == 4 || RW == 8 || RW == 16, "half a stagger group of eight rows, one, or two per wave");
+    static_assert(NC <= 8, "start chunks 0 .. 7");
     constexpr int MF = PARTIAL ? NC - 1 : NC;   // full chunks
+    constexpr int G = RW < 8 ? RW : 8;          // rows that share a start chunk (a wave's rows never straddle a group of eight)
     float rs[RW];
 #pragma unroll
-    for (int h = 0; h < RW / 8; ++h) {
+    for (int h = 0; h < RW / G; ++h) {
         if constexpr (MF <= 1 || !STAGGER) {
-            rp_resident_dot8<NC, MF, 0>(w + 8 * h, r, rs + 8 * h);
+            rp_resident_dot8<NC, MF, 0, G>(w + G * h, r, rs + G * h);
         } else {
-            const int m0 = (int)(((unsigned)((global_row_w0 + 8 * h) >> 3) * kStagger) % (unsigned)MF);   // wave-uniform
-            switch (m0) {
-                case 0: rp_resident_dot8<NC, MF, 0>(w + 8 * h, r, rs + 8 * h); break;
-                case 1: rp_resident_dot8<NC, MF, 1>(w + 8 * h, r, rs + 8 * h); break;
-                case 2: rp_resident_dot8<NC, MF, 2 % MF>(w + 8 * h, r, rs + 8 * h); break;
-                default: rp_resident_dot8<NC, MF, 3 % MF>(w + 8 * h, r, rs + 8 * h); break;
+            const int m0 = (int)(((unsigned)((global_row_w0 + G * h) >> 3) * kStagger) % (unsigned)MF);   // wave-uniform
+            switch (m0) {   // (m0 < MF: the cases past MF - 1 are never taken)
+                case 0: rp_resident_dot8<NC, MF, 0, G>(w + G * h, r, rs + G * h); break;
+                case 1: rp_resident_dot8<NC, MF, 1, G>(w + G * h, r, rs + G * h); break;
+                case 2: rp_resident_dot8<NC, MF, 2 % MF, G>(w + G * h, r, rs + G * h); break;
+                case 3: rp_resident_dot8<NC, MF, 3 % MF, G>(w + G * h, r, rs + G * h); break;
+                case 4: rp_resident_dot8<NC, MF, 4 % MF, G>(w + G * h, r, rs + G * h); break;
+                case 5: rp_resident_dot8<NC, MF, 5 % MF, G>(w + G * h, r, rs + G * h); break;
+                case 6: rp_resident_dot8<NC, MF, 6 % MF, G>(w + G * h, r, rs + G * h); break;
+                default: rp_resident_dot8<NC, MF, 7 % MF, G>(w + G * h, r, rs + G * h); break;
             }
         }
     }
@@ -428,6 +434,24 @@ constexpr int rp_resident_rows_per_wave_s1(int n) { return rp_resident_strides_s
         }                                                                                  \
     }
 
+// ... the same with the wide layouts of the forward step and the adjoint sweeps (1024 < n <= 2048: 5 .. 8 chunks, four rows per wave;
+// the RLS sweep keeps P AND the weights in registers and stays at n <= 1024)
+#define RP_RESIDENT_DISPATCH_LAYOUT_WIDE(n_, v4_, LAUNCH)                                  \
+    if ((v4_) && rp_resident_chunks(n_) > 4) {                                             \
+        switch (rp_resident_chunks(n_) * 2 + ((n_) % 256 != 0 ? 1 : 0)) {                 \
+            case 10: LAUNCH((rp_layout_v4<5, 4, false>)); break;                           \
+            case 11: LAUNCH((rp_layout_v4<5, 4, true>)); break;                            \
+            case 12: LAUNCH((rp_layout_v4<6, 4, false>)); break;                           \
+            case 13: LAUNCH((rp_layout_v4<6, 4, true>)); break;                            \
+            case 14: LAUNCH((rp_layout_v4<7, 4, false>)); break;                           \
+            case 15: LAUNCH((rp_layout_v4<7, 4, true>)); break;                            \
+            case 16: LAUNCH((rp_layout_v4<8, 4, false>)); break;                           \
+            default: LAUNCH((rp_layout_v4<8, 4, true>)); break;                            \
+        }                                                                                  \
+    } else {                                                                               \
+        RP_RESIDENT_DISPATCH_LAYOUT(n_, v4_, LAUNCH)                                       \
+    }
+
 // ---- host side ------------------------------------------------------------------------------------------------------------
 // The sticky failure word: pinned host memory the device can write (one int per process), looked at by the library's next calls
 // (rp_resident_poll) and by rp_async_status -- no copy, no synchronisation.
@@ -546,6 +570,8 @@ inline int rp_resident_end(const rp_resident_ctl& C, void* ws, hipStream_t st, c
 
 // n <= 1024 on the 16-byte path
 inline bool rp_resident_shape(int n, int64_t ld) { return n >= 4 && n <= 1024 && n % 4 == 0 && ld % 4 == 0; }
+// ... the forward step and the adjoint sweeps on the 16-byte path: up to 2048 (four rows of up to eight chunks per wave: 128 registers)
+inline bool rp_resident_shape_wide(int n, int64_t ld) { return n >= 4 && n <= 2048 && n % 4 == 0 && ld % 4 == 0; }
 // ... or on the 4-byte path (any n, any leading dimension)
 inline bool rp_resident_shape_any(int n) { return n >= 1 && n <= 1024; }
 
