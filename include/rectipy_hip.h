@@ -416,7 +416,7 @@ typedef struct rp_bwd {
 int rp_abi_version(void);
 const char* rp_last_error(void);
 
-/* (v19) At launch-bound sizes (dense W, no edges, rows == n, n <= 1024, 4 steps or more) rp_forward and -- on the
+/* (v19) At launch-bound sizes (dense W, no edges, rows == n, n <= 1024 -- n <= 1536 when n % 4 == 0 --, 4 steps or more) rp_forward and -- on the
    transposed-copy sweep -- rp_rate_backward / rp_qif_backward run ALL their steps in ONE launch (rectipy_amd/csrc/rp_resident.h; bit-identical
    to a launch per step; RECTIPY_AMD_RESIDENT=0 in the environment selects the launches).  Such a launch is as asynchronous as the
    launches it replaces; the one thing it can report only afterwards is a wave that timed out waiting for its peers (seconds: the

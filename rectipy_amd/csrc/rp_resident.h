@@ -434,7 +434,7 @@ constexpr int rp_resident_rows_per_wave_s1(int n) { return rp_resident_strides_s
         }                                                                                  \
     }
 
-// ... the same with the wide layouts of the forward step and the adjoint sweeps (1024 < n <= 2048: 5 .. 8 chunks, four rows per wave;
+// ... the same with the wide layouts of the forward step and the adjoint sweeps (1024 < n <= 1536: 5 or 6 chunks, four rows per wave;
 // the RLS sweep keeps P AND the weights in registers and stays at n <= 1024)
 #define RP_RESIDENT_DISPATCH_LAYOUT_WIDE(n_, v4_, LAUNCH)                                  \
     if ((v4_) && rp_resident_chunks(n_) > 4) {                                             \
@@ -442,11 +442,7 @@ constexpr int rp_resident_rows_per_wave_s1(int n) { return rp_resident_strides_s
             case 10: LAUNCH((rp_layout_v4<5, 4, false>)); break;                           \
             case 11: LAUNCH((rp_layout_v4<5, 4, true>)); break;                            \
             case 12: LAUNCH((rp_layout_v4<6, 4, false>)); break;                           \
-            case 13: LAUNCH((rp_layout_v4<6, 4, true>)); break;                            \
-            case 14: LAUNCH((rp_layout_v4<7, 4, false>)); break;                           \
-            case 15: LAUNCH((rp_layout_v4<7, 4, true>)); break;                            \
-            case 16: LAUNCH((rp_layout_v4<8, 4, false>)); break;                           \
-            default: LAUNCH((rp_layout_v4<8, 4, true>)); break;                            \
+            default: LAUNCH((rp_layout_v4<6, 4, true>)); break;                            \
         }                                                                                  \
     } else {                                                                               \
         RP_RESIDENT_DISPATCH_LAYOUT(n_, v4_, LAUNCH)                                       \
@@ -570,8 +566,10 @@ inline int rp_resident_end(const rp_resident_ctl& C, void* ws, hipStream_t st, c
 
 // n <= 1024 on the 16-byte path
 inline bool rp_resident_shape(int n, int64_t ld) { return n >= 4 && n <= 1024 && n % 4 == 0 && ld % 4 == 0; }
-// ... the forward step and the adjoint sweeps on the 16-byte path: up to 2048 (four rows of up to eight chunks per wave: 128 registers)
-inline bool rp_resident_shape_wide(int n, int64_t ld) { return n >= 4 && n <= 2048 && n % 4 == 0 && ld % 4 == 0; }
+// ... the forward step and the adjoint sweeps on the 16-byte path: up to 1536 (four rows of up to six chunks per wave).  Every wave
+// reads the whole vector every step, so the hand-off grows with n while the launch it replaces does not: measured break-even at
+// n = 1800 for the forward (5.3 against 5.5 us per step at 1792; 4.7 / 5.5 at 1536), n = 2048 loses in fit_bptt (12.4 / 11.5)
+inline bool rp_resident_shape_wide(int n, int64_t ld) { return n >= 4 && n <= 1536 && n % 4 == 0 && ld % 4 == 0; }
 // ... or on the 4-byte path (any n, any leading dimension)
 inline bool rp_resident_shape_any(int n) { return n >= 1 && n <= 1024; }
 

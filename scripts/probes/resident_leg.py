@@ -14,7 +14,7 @@ from rectipy_amd import Network  # noqa: E402
 dev = torch.device("cuda:0")
 tanh = "neuron_model_templates.rate_neurons.leaky_integrator.tanh"
 out = {}
-for N in (100, 250, 512, 1000, 1024):
+for N in [int(a) for a in sys.argv[1:]] or (100, 250, 512, 1000, 1024):
     T = 4000
     gen = torch.Generator(device=dev).manual_seed(0)
     W = torch.randn(N, N, device=dev, generator=gen) * 1.5 / N ** 0.5

@@ -1,4 +1,4 @@
-"""Soak of the resident launches: random sizes (up to 1024; both row-dot paths), models, step counts and windows for a fixed wall time; every
+"""Soak of the resident launches: random sizes (up to 1536 on the 16-byte path, 1024 on the 4-byte path), models, step counts and windows for a fixed wall time; every
 call is repeated with one launch per step from the same state and compared bit for bit; rp_async_status at the end.
 
     python scripts/probes/resident_soak.py [seconds] [seed]
@@ -34,7 +34,7 @@ def make(model, n, seed):
 t_end = time.time() + budget
 calls = steps_total = 0
 while time.time() < t_end:
-    n = int(rng.integers(1, 257)) * 4 if rng.integers(0, 3) else int(rng.integers(1, 1025))   # (a third: any n -- the 4-byte path)
+    n = int(rng.integers(1, 385)) * 4 if rng.integers(0, 3) else int(rng.integers(1, 1025))   # (a third: any n -- the 4-byte path)
     model = ["li_tanh", "qif"][int(rng.integers(0, 2))]
     seed = int(rng.integers(0, 1 << 30))
     pops = []
