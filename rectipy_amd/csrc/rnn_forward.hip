@@ -590,7 +590,7 @@ __global__ __launch_bounds__(kThreads) void step_merged_kernel(const MergedParam
 // run ahead and overwrite granules its readers have not consumed).  A lagging edge (RP_EDGE_LAG) multiplies with the vector
 // the wave received one step earlier.  The row dots are each matrix's own contract, the edge sums are added in edge order, the
 // epilogue is the per-step kernels': bit-identical to the shared launch.
-constexpr int kRcCap = 512;       // granules per stream and parity (members of up to 512 neurons)
+constexpr int kRcCap = 1024;      // granules per stream and parity (members of up to 1024 neurons)
 constexpr int kRcSlots = 4;
 struct RcMember {
     StepParams P0;                // the member's step-0 arguments (set_step(.., 0))
@@ -710,7 +710,7 @@ __device__ __forceinline__ void resident_coupled_member(const rp_resident_ctl& C
 template <int NSEG, int NC, int RW>
 __global__ __launch_bounds__(kThreads) void resident_coupled_kernel(const rp_resident_ctl C, const RcParams* __restrict__ params) {
     static_assert(kWavesPerBlock == kResidentWaves, "rp_resident.h counts four waves per workgroup");
-    static_assert(NSEG * NC * RW <= 32 && NSEG <= kRcSlots, "a wave's rows: at most 128 registers");
+    static_assert(NSEG * NC * RW <= 32 && NSEG <= kRcSlots && NC <= 4, "a wave's rows: at most 128 registers");
     const int work = rp_resident_join(C);
     if (work < 0) return;
     // the member this workgroup belongs to; its argument block is read in place (read-only, uniform addresses: scalar loads)
@@ -1699,8 +1699,8 @@ int forward_impl(rp_net* net, rp_run* run, const rp_comm* comm, void* stream) {
 }
 
 // ---- the resident launch of a coupled circuit (resident_coupled_kernel): eligibility and the call --------------------------------
-// Circuits the shared launch takes (coupled_impl: `merged`) whose matrices are all on the 16-byte path with at most 512 columns,
-// (1 + in-edges) x chunks <= 4 per member.  kResidentUnavailable: nothing launched, the caller goes on with a launch per step.
+// Circuits the shared launch takes (coupled_impl: `merged`) whose matrices are all on the 16-byte path with at most 1024 columns,
+// (1 + in-edges) x chunks <= 8 per member (chunks: of the circuit's widest matrix).  kResidentUnavailable: nothing launched, the caller goes on with a launch per step.
 int coupled_resident(rp_member* mem, int count, StepParams* P, const bool* vec4, hipStream_t st) {
     const int steps = mem[0].run->steps;
     if (!rp_resident_enabled() || steps < kResidentMinSteps) return kResidentUnavailable;
@@ -1716,9 +1716,9 @@ int coupled_resident(rp_member* mem, int count, StepParams* P, const bool* vec4,
         for (int e = 0; e < run->n_edges; ++e)
             if (!P[m].edge[e].vec4 || !aligned16(run->edge_w[e]) || run->edge_n[e] > kRcCap) return kResidentUnavailable;
     }
-    const int nc = widest > 256 ? 2 : 1;
-    if (nseg * nc > 4) return kResidentUnavailable;
-    const int rw = nseg * nc <= 2 ? 16 : 8;
+    const int nc = (widest + 255) / 256;   // chunks per slot, by the widest matrix of the circuit
+    if (nseg * nc > 8 || nc > 4) return kResidentUnavailable;
+    const int rw = nseg * nc <= 2 ? 16 : (nseg * nc <= 4 ? 8 : 4);
 
     static_assert(sizeof(RcParams) <= 8192, "the members' argument blocks: a few KiB behind the granules");
     RcParams H = {};
@@ -1775,14 +1775,18 @@ int coupled_resident(rp_member* mem, int count, StepParams* P, const bool* vec4,
     }
     const dim3 grid(rp_resident_grid(C));
     const RcParams* D = static_cast<const RcParams*>(dev_params);
-    if (nc == 2)
-        hipLaunchKernelGGL((resident_coupled_kernel<2, 2, 8>), grid, dim3(kThreads), 0, st, C, D);
-    else if (nseg == 2)
-        hipLaunchKernelGGL((resident_coupled_kernel<2, 1, 16>), grid, dim3(kThreads), 0, st, C, D);
-    else if (nseg == 3)
-        hipLaunchKernelGGL((resident_coupled_kernel<3, 1, 8>), grid, dim3(kThreads), 0, st, C, D);
-    else
-        hipLaunchKernelGGL((resident_coupled_kernel<4, 1, 8>), grid, dim3(kThreads), 0, st, C, D);
+#define RP_RC_(S_, C_, R_) hipLaunchKernelGGL((resident_coupled_kernel<S_, C_, R_>), grid, dim3(kThreads), 0, st, C, D)
+    switch (nseg * 10 + nc) {   // (slots, chunks per slot) -> rows per wave: at most 128 registers of matrix rows
+        case 21: RP_RC_(2, 1, 16); break;
+        case 31: RP_RC_(3, 1, 8); break;
+        case 41: RP_RC_(4, 1, 8); break;
+        case 22: RP_RC_(2, 2, 8); break;
+        case 32: RP_RC_(3, 2, 4); break;
+        case 42: RP_RC_(4, 2, 4); break;
+        case 23: RP_RC_(2, 3, 4); break;
+        default: RP_RC_(2, 4, 4); break;   // (24)
+    }
+#undef RP_RC_
     const int rc = rp_resident_end(C, ws, st, "the resident step kernel of a coupled circuit");
     if (rc != RP_OK) return rc;
     for (int m = 0; m < count; ++m) {   // the sampling bookkeeping and the buffer parity of the steps the kernel ran

@@ -214,14 +214,72 @@ __device__ __forceinline__ void rp_resident_load_rows_rect(rp_f4 (&w)[RW][NC], c
 }
 // the row totals of a slot that holds a matrix of `cols` columns, in the order of THAT width's contract: a slot chunk past the
 // matrix's last one holds zeros and may come last (fma(0, 0, a) == a); the full chunks rotate among themselves
+// (slots of three or four chunks: exactly the chunks the matrix has -- MF full ones from the row group's start chunk on, wrapping,
+// then the partial one at index MF; the slot's empty chunks are not visited)
+template <int NC, int MF, int M0, int ROWS, bool HASP>
+__device__ __forceinline__ void rp_resident_slot_rows(const rp_f4 (*w)[NC], const rp_f4 (&r)[NC], float* rs) {
+    static_assert(MF + (HASP ? 1 : 0) <= NC, "the matrix fits the slot");
+#pragma unroll
+    for (int j = 0; j < ROWS; ++j) {
+        rp_f4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+            const int m = (M0 + i) % (MF > 0 ? MF : 1);
+            a = rp_fma4(w[j][m], r[m], a);
+        }
+        if constexpr (HASP) a = rp_fma4(w[j][MF], r[MF], a);
+        rs[j] = rp_lane_sum4(a);
+    }
+}
+template <int NC, int RW, int MF, bool HASP>
+__device__ __forceinline__ float rp_resident_slot_dots(const rp_f4 (&w)[RW][NC], const rp_f4 (&r)[NC], int global_row_w0, int lane) {
+    static_assert(RW == 4 || RW == 8, "half a stagger group of eight rows or one per wave");
+    float rs[RW];
+    if constexpr (MF <= 1) {
+        rp_resident_slot_rows<NC, MF, 0, RW, HASP>(w, r, rs);
+    } else {
+        const int m0 = (int)(((unsigned)(global_row_w0 >> 3) * kStagger) % (unsigned)MF);   // wave-uniform
+        switch (m0) {   // (m0 < MF)
+            case 0: rp_resident_slot_rows<NC, MF, 0, RW, HASP>(w, r, rs); break;
+            case 1: rp_resident_slot_rows<NC, MF, 1, RW, HASP>(w, r, rs); break;
+            case 2: rp_resident_slot_rows<NC, MF, 2 % MF, RW, HASP>(w, r, rs); break;
+            default: rp_resident_slot_rows<NC, MF, 3 % MF, RW, HASP>(w, r, rs); break;
+        }
+    }
+    return rp_rows_allreduce<RW>(rs, lane);
+}
 template <int NC, int RW>
 __device__ __forceinline__ float rp_resident_dots_slot(const rp_f4 (&w)[RW][NC], const rp_f4 (&r)[NC], int cols, int global_row_w0, int lane) {
-    static_assert(NC == 1 || NC == 2, "slots of one or two chunks");
+    static_assert(NC >= 1 && NC <= 4, "slots of one to four chunks");
     if constexpr (NC == 1) {
         return rp_resident_dots<1, RW, false>(w, r, global_row_w0, lane);
-    } else {
+    } else if constexpr (NC == 2) {
         if (cols == 512) return rp_resident_dots<2, RW, false>(w, r, global_row_w0, lane);   // two full chunks: the start chunk rotates
         return rp_resident_dots<2, RW, true>(w, r, global_row_w0, lane);                      // chunk 0, then the partial (or empty) chunk 1
+    } else {
+        const int mf = cols >> 8;
+        const bool hasp = (cols & 255) != 0;   // (wave-uniform, as mf)
+#define RP_SLOT_(MF_, P_) return rp_resident_slot_dots<NC, RW, MF_, P_>(w, r, global_row_w0, lane)
+        if (hasp) {
+            switch (mf) {
+                case 0: RP_SLOT_(0, true);
+                case 1: RP_SLOT_(1, true);
+                case 2: RP_SLOT_(2, true);
+                default:
+                    if constexpr (NC == 4) RP_SLOT_(3, true);
+                    else RP_SLOT_(2, true);   // (NC == 3: never reached -- three full chunks have no partial one behind them)
+            }
+        } else {
+            switch (mf) {
+                case 1: RP_SLOT_(1, false);
+                case 2: RP_SLOT_(2, false);
+                case 3: RP_SLOT_(3, false);
+                default:
+                    if constexpr (NC == 4) RP_SLOT_(4, false);
+                    else RP_SLOT_(3, false);
+            }
+        }
+#undef RP_SLOT_
     }
 }
 

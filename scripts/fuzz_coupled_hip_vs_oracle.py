@@ -156,7 +156,7 @@ def small4(sizes):
     """FUZZ_SMALL4=1: every population on the 16-byte path with at most 512 neurons -- the shapes whose rp_forward_coupled calls run
     all their steps in ONE resident launch (r05)."""
     if os.environ.get("FUZZ_SMALL4"):
-        return [min(512, max(8, n - n % 4)) for n in sizes]
+        return [min(1024 if len(sizes) == 2 else 512, max(8, n - n % 4)) for n in sizes]
     return sizes
 
 

@@ -26,7 +26,7 @@ t_end = time.time() + budget
 calls = steps_total = 0
 while time.time() < t_end:
     count = int(rng.integers(2, 5))
-    cap = 512 if count == 2 else 256
+    cap = (1024 if count == 2 else 512) if rng.integers(0, 3) == 0 else (512 if count == 2 else 256)   # (a third: four rows per wave)
     sizes = tuple(int(rng.integers(1, cap // 4 + 1)) * 4 for _ in range(count))
     models = tuple(["li_tanh", "qif"][int(rng.integers(0, 2))] for _ in range(count))
     out_vars = tuple(int(rng.integers(0, 2)) for _ in range(count))

@@ -219,10 +219,16 @@ def test_argument_checks(oracle_backend):
                                                            ((512, 512), ("li_tanh", "li_tanh"), (1, 1)),
                                                            ((500, 300), ("qif", "li_tanh"), (1, 0)),
                                                            ((128, 132, 64, 32), ("li_tanh", "qif", "li_tanh", "qif"), (0, 0, 1, 1)),
-                                                           ((256, 8, 200), ("qif", "qif", "li_tanh"), (0, 1, 0))])
+                                                           ((256, 8, 200), ("qif", "qif", "li_tanh"), (0, 1, 0)),
+                                                           # ... four rows per wave: slots of three / four chunks, three and four slots of two
+                                                           ((1024, 1024), ("li_tanh", "li_tanh"), (0, 1)),
+                                                           ((768, 520), ("qif", "li_tanh"), (1, 0)),
+                                                           ((1000, 600), ("li_tanh", "qif"), (0, 0)),
+                                                           ((512, 260, 384), ("li_tanh", "li_tanh", "qif"), (1, 0, 1)),
+                                                           ((300, 512, 256, 128), ("qif", "li_tanh", "li_tanh", "li_tanh"), (0, 1, 0, 1))])
 def test_hip_coupled_bit_exact(oracle_backend, hip_device, monkeypatch, sizes, models, out_vars, launches):
     """HIP == oracle, bit for bit, all three ways the library issues the steps: ALL steps of the call in one launch (r05: circuits
-    of members of at most 512 neurons on the 16-byte path, (1 + in-edges) x chunks <= 4; the others fall through to ...) ONE
+    of members of at most 1024 neurons on the 16-byte path, (1 + in-edges) x chunks <= 8; the others fall through to ...) ONE
     launch per step for all members (every edge of these circuits reads a value from before the step; members of at most 4096
     neurons), and one launch per member and step (RECTIPY_AMD_COUPLED_LAUNCHES=member; the 4100-neuron case takes it by size)."""
     if launches == "member":
