@@ -461,8 +461,8 @@ int rp_forward(rp_net* net, rp_run* run, void* stream);
  * bits as the launch per member (N = 2 x 2048: 13 instead of 21 us per step).
  *
  * ALL steps of the call in ONE launch (r05) for such circuits when, in addition, every member's W and every edge matrix is on
- * the 16-byte path with at most 512 columns, no W is packed, (1 + edges into a member) x (1 or 2 chunks of 256 columns, by the
- * widest matrix of the circuit) <= 4 for every member, and steps >= 4: the rows of a member's own and in-edge matrices stay in
+ * the 16-byte path with at most 1024 columns, no W is packed, (1 + edges into a member) x (1 .. 4 chunks of 256 columns, by the
+ * widest matrix of the circuit) <= 8 for every member, and steps >= 4: the rows of a member's own and in-edge matrices stay in
  * registers, the members' vectors go from wave to wave as tagged granules (the resident launches described at rp_async_status,
  * which also reports their one failure mode).  Same bits (2 x 256 neurons: 3.2 instead of 6.5 us per step);
  * RECTIPY_AMD_RESIDENT=0 selects the launch per step.
