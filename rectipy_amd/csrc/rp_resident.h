@@ -19,6 +19,9 @@
 #pragma once
 
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "rp_common.h"
 #include "rp_dot.h"
@@ -526,30 +529,48 @@ inline int* rp_resident_host_word(int** device_view) {
     if (device_view) *device_view = w.dev;
     return w.host;
 }
-// once per device: the default pool keeps the few KiB of scratch across synchronisations instead of returning them to the system
-inline void rp_resident_keep_pool() {
-    static unsigned char kept[RP_MAX_DEVICES];
+// The scratch of a resident launch (granules, failure word, roster; for a coupled circuit the members' argument blocks): ONE block
+// per (device, stream), allocated on the stream's first resident launch and kept.  Launches on a stream follow each other, and each
+// starts with a stream-ordered memset, so they can share it.  (r05, measured -- scripts/probes/async_alloc_probe.hip: with
+// hipMallocAsync / hipFreeAsync around every launch the host waited for the PREVIOUS launch of the stream in every call, 208 us
+// per iteration for a 200 us kernel; memsetAsync + launch on a kept block: 5 us.  The library's calls were not asynchronous.)
+constexpr size_t kResidentScratchBytes = 192u << 10;
+inline int rp_resident_scratch(hipStream_t st, size_t bytes, void** out, unsigned* serial = nullptr) {
+    struct Block {
+        void* p;
+        unsigned calls;
+    };
+    struct Table {
+        std::mutex mu;
+        std::map<std::pair<int, hipStream_t>, Block> blocks;
+    };
+    static Table t;
+    *out = nullptr;
+    if (bytes > kResidentScratchBytes) return RP_ERR_HIP;
     int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < RP_MAX_DEVICES && !kept[dev]) {
-        hipMemPool_t pool = nullptr;
-        uint64_t keep = 1u << 20;
-        if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool)
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-        (void)hipGetLastError();
-        kept[dev] = 1;
+    if (hipGetDevice(&dev) != hipSuccess) return RP_ERR_HIP;
+    std::lock_guard<std::mutex> lock(t.mu);
+    auto it = t.blocks.find({dev, st});
+    if (it == t.blocks.end()) {
+        if (t.blocks.size() >= 256) return RP_ERR_HIP;   // (a process that keeps making streams: launches per step from here on)
+        void* p = nullptr;
+        if (hipMalloc(&p, kResidentScratchBytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return RP_ERR_HIP;
+        }
+        it = t.blocks.emplace(std::make_pair(dev, st), Block{p, 0u}).first;
     }
+    *out = it->second.p;
+    if (serial) *serial = it->second.calls++;   // (the stream's n-th launch with a copied argument block: rotating slots)
+    return RP_OK;
 }
-// stream-ordered scratch (granules, failure word, roster), zeroed: a tag is never 0
+// the stream's scratch (granules, failure word, roster), zeroed in stream order: a tag is never 0
 inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** ws, bool v4 = true) {
     const size_t bytes = (size_t)2 * n * sizeof(unsigned long long) + 64;
     *ws = nullptr;
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT_TEST_FAULT"); e && e[0] == '2') return RP_ERR_HIP;   // (test seam: no scratch)
-    rp_resident_keep_pool();
-    if (hipMallocAsync(ws, bytes, st) != hipSuccess) return RP_ERR_HIP;
-    if (hipMemsetAsync(*ws, 0, bytes, st) != hipSuccess) {
-        (void)hipFreeAsync(*ws, st);
-        return RP_ERR_HIP;
-    }
+    if (rp_resident_scratch(st, bytes, ws) != RP_OK) return RP_ERR_HIP;
+    if (hipMemsetAsync(*ws, 0, bytes, st) != hipSuccess) return RP_ERR_HIP;
     C->gran[0] = static_cast<unsigned long long*>(*ws);
     C->gran[1] = C->gran[0] + n;
     C->fail = reinterpret_cast<int*>(C->gran[1] + n);
@@ -573,21 +594,21 @@ inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** w
 // (the members' argument blocks); gran[0] = the first granule, gran[1] unused
 inline int rp_resident_begin_streams(int streams, int cap, int need_blocks, size_t extra, hipStream_t st, rp_resident_ctl* C, void** ws,
                                      void** extra_ptr) {
+    // the argument blocks are copied from host memory in stream order; consecutive launches still use different slots
+    constexpr unsigned kSlots = 8;
     const size_t gran_bytes = (size_t)2 * streams * cap * sizeof(unsigned long long);
-    const size_t bytes = gran_bytes + 64 + ((extra + 63) & ~(size_t)63);
+    const size_t slot_bytes = (extra + 63) & ~(size_t)63;
+    const size_t bytes = gran_bytes + 64 + kSlots * slot_bytes;
+    unsigned serial = 0;
     *ws = nullptr;
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT_TEST_FAULT"); e && e[0] == '2') return RP_ERR_HIP;   // (test seam: no scratch)
-    rp_resident_keep_pool();
-    if (hipMallocAsync(ws, bytes, st) != hipSuccess) return RP_ERR_HIP;
-    if (hipMemsetAsync(*ws, 0, gran_bytes + 64, st) != hipSuccess) {
-        (void)hipFreeAsync(*ws, st);
-        return RP_ERR_HIP;
-    }
+    if (rp_resident_scratch(st, bytes, ws, &serial) != RP_OK) return RP_ERR_HIP;
+    if (hipMemsetAsync(*ws, 0, gran_bytes + 64, st) != hipSuccess) return RP_ERR_HIP;
     C->gran[0] = static_cast<unsigned long long*>(*ws);
     C->gran[1] = nullptr;
     C->fail = reinterpret_cast<int*>(static_cast<char*>(*ws) + gran_bytes);
     C->ctl = reinterpret_cast<unsigned*>(C->fail) + 4;
-    *extra_ptr = static_cast<char*>(*ws) + gran_bytes + 64;
+    *extra_ptr = static_cast<char*>(*ws) + gran_bytes + 64 + (serial % kSlots) * slot_bytes;
     (void)rp_resident_host_word(&C->host_fail);
     C->need_blocks = need_blocks;
     C->one_xcd = need_blocks <= 8 ? 1 : 0;
@@ -613,11 +634,12 @@ inline int rp_resident_poll() {   // a resident launch that timed out since the 
     return RP_OK;
 }
 
-// after the launch: the scratch back to the pool -- no synchronisation
+// after the launch -- no synchronisation (the scratch stays with the stream)
 inline int rp_resident_end(const rp_resident_ctl& C, void* ws, hipStream_t st, const char* what) {
     (void)C;
+    (void)ws;
+    (void)st;
     const hipError_t launched = hipGetLastError();
-    (void)hipFreeAsync(ws, st);
     if (launched != hipSuccess) RP_FAIL(RP_ERR_HIP, "%s: %s", what, hipGetErrorString(launched));
     return RP_OK;
 }
