@@ -897,14 +897,21 @@ class Network:
         differently from a zero gradient; the fused window's adjoint returns zeros, so the step sets them back to None.
         Edges with memory delay further and are left alone (zeros), as are windows whose start state carries a graph."""
         from .edge_variants import LinearMasked, _Stateful
-        if any(isinstance(self.get_edge(s, t), _Stateful) and not isinstance(self.get_edge(s, t), LinearMasked)
-               for s, t in self.graph.edges):
-            return []
-        for n in self.graph.nodes:
-            node = self.get_node(n)
+        # (once per fit call and window length: the graph and the trainable flags do not change inside fit_bptt's window loop --
+        # only whether a start state carries a graph does, which is looked at every time)
+        memo = getattr(self, "_unreached_memo", None)
+        for n in (memo["nodes"] if memo is not None else self.graph.nodes):
+            node = n if memo is not None else self.get_node(n)
             handle = getattr(node, "_y_grad", None)
             if handle is not None and handle.grad_fn is not None:
                 return []
+        if memo is not None and steps in memo["by_steps"]:
+            return memo["by_steps"][steps]
+        if any(isinstance(self.get_edge(s, t), _Stateful) and not isinstance(self.get_edge(s, t), LinearMasked)
+               for s, t in self.graph.edges):
+            if memo is not None:
+                memo["by_steps"][steps] = []
+            return []
         count = {}
         for n in reversed(self._order):
             nxt = [count[m] for m in self.graph.successors(n) if m in count]
@@ -919,6 +926,8 @@ class Network:
                 out.extend(p for p in self.get_node(n).parameters() if p.requires_grad)
             for m in self.graph.predecessors(n):
                 out.extend(p for p in self.get_edge(m, n).parameters() if p.requires_grad)
+        if memo is not None:
+            memo["by_steps"][steps] = out
         return out
 
     def _bptt(self, inp, target, loss, optimizer, obs: Observer, error_kwargs, step_kwargs, sampling_steps,
@@ -940,19 +949,23 @@ class Network:
                 self._warn_stepwise("Network.fit_bptt", "dag", "coupled_grad")
             return self._bptt_stepwise(inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps,
                                        optim_steps, verbose)
+        self._unreached_memo = dict(nodes=[self.get_node(n) for n in self.graph.nodes],
+                                    diffeq=[self.get_node(n) for n in self.graph.nodes if self[n]["node_type"] == "diff_eq"], by_steps={})
         try:
             return self._bptt_windows(inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps, optim_steps,
                                       verbose, plan, windows, coupled, slots or [])
         finally:
+            self._unreached_memo = None
             self._set_fused_sgd(None)   # (an exception inside a window must not leave the plan to a later backward call)
 
     def _set_fused_sgd(self, plan: Optional[dict]) -> None:
         """Hand the plain-SGD plan (or None) to the window nodes that apply it: the coupled window reads it from the network, a
         rate population's own window from the node."""
         self._fused_sgd = plan
-        for n in self.graph.nodes:
-            if self[n]["node_type"] == "diff_eq":
-                self.get_node(n)._fused_sgd = plan
+        memo = getattr(self, "_unreached_memo", None)   # (inside fit_bptt's window loop: the population nodes, looked up once)
+        for node in (memo["diffeq"] if memo is not None else
+                     [self.get_node(n) for n in self.graph.nodes if self[n]["node_type"] == "diff_eq"]):
+            node._fused_sgd = plan
 
     def _bptt_windows(self, inp, target, loss, optimizer, obs, error_kwargs, step_kwargs, sampling_steps, optim_steps, verbose,
                       plan, windows, coupled, slots=()) -> Observer:
