@@ -605,7 +605,8 @@ def small_n_extra(dev, N=512, T=2000):
     e1.record()
     torch.cuda.synchronize()
     res["launch_floor_us"] = e0.elapsed_time(e1) / 2000 * 1e3
-    res["note"] = ("r05: up to n = 1024 ALL steps of a call run in ONE launch, forward and (rate models) adjoint -- W / W^T in registers, "
+    res["note"] = ("r05: up to n = 1024 (1536 when n % 4 == 0; coupled circuits: members up to 1024) ALL steps of a call run in ONE launch, "
+                   "forward and adjoint -- W / W^T in registers, "
                    "the vector handed from wave to wave as tagged 8-byte granules, bit-identical to a launch per step "
                    "(rectipy_amd/csrc/rp_resident.h); with one launch per step (RECTIPY_AMD_RESIDENT=0: `launch_per_step`) a step is bounded by "
                    "the dependent-launch interval of the stream and fit_bptt by the host's launch rate; fit_bptt adds the per-window work "
