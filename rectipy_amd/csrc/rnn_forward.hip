@@ -1770,6 +1770,7 @@ int coupled_resident(rp_member* mem, int count, StepParams* P, const bool* vec4,
         H.M[m].P0 = P[m];
     }
     if (hipMemcpyAsync(dev_params, &H, sizeof(RcParams), hipMemcpyHostToDevice, st) != hipSuccess) {
+        rp_resident_release(st);
         RP_FAIL(RP_ERR_HIP, "rp_forward_coupled: copying the members' argument blocks failed");
     }
     const dim3 grid(rp_resident_grid(C));

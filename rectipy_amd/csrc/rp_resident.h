@@ -535,33 +535,59 @@ inline int* rp_resident_host_word(int** device_view) {
 // hipMallocAsync / hipFreeAsync around every launch the host waited for the PREVIOUS launch of the stream in every call, 208 us
 // per iteration for a 200 us kernel; memsetAsync + launch on a kept block: 5 us.  The library's calls were not asynchronous.)
 constexpr size_t kResidentScratchBytes = 192u << 10;
+// Two host threads may launch on the SAME stream (the default stream is every thread's): the zeroing and the launch that uses the
+// block must reach the stream as a pair, so a block is held (`hold`: its mutex taken) from rp_resident_begin* to rp_resident_end --
+// or rp_resident_release on a path that ends without a launch.
+struct rp_resident_block {
+    void* p = nullptr;
+    unsigned calls = 0;
+    std::mutex seq;
+};
+struct rp_resident_table {
+    std::mutex mu;
+    std::map<std::pair<int, hipStream_t>, rp_resident_block> blocks;
+};
+inline rp_resident_table& rp_resident_blocks() {
+    static rp_resident_table t;
+    return t;
+}
+inline void rp_resident_release(hipStream_t st) {
+    rp_resident_table& t = rp_resident_blocks();
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    rp_resident_block* b = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(t.mu);
+        auto it = t.blocks.find({dev, st});
+        if (it != t.blocks.end()) b = &it->second;
+    }
+    if (b) b->seq.unlock();
+}
 inline int rp_resident_scratch(hipStream_t st, size_t bytes, void** out, unsigned* serial = nullptr) {
-    struct Block {
-        void* p;
-        unsigned calls;
-    };
-    struct Table {
-        std::mutex mu;
-        std::map<std::pair<int, hipStream_t>, Block> blocks;
-    };
-    static Table t;
+    rp_resident_table& t = rp_resident_blocks();
     *out = nullptr;
     if (bytes > kResidentScratchBytes) return RP_ERR_HIP;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return RP_ERR_HIP;
-    std::lock_guard<std::mutex> lock(t.mu);
-    auto it = t.blocks.find({dev, st});
-    if (it == t.blocks.end()) {
-        if (t.blocks.size() >= 256) return RP_ERR_HIP;   // (a process that keeps making streams: launches per step from here on)
-        void* p = nullptr;
-        if (hipMalloc(&p, kResidentScratchBytes) != hipSuccess) {
-            (void)hipGetLastError();
-            return RP_ERR_HIP;
+    rp_resident_block* b = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(t.mu);
+        auto it = t.blocks.find({dev, st});
+        if (it == t.blocks.end()) {
+            if (t.blocks.size() >= 256) return RP_ERR_HIP;   // (a process that keeps making streams: launches per step from here on)
+            void* p = nullptr;
+            if (hipMalloc(&p, kResidentScratchBytes) != hipSuccess) {
+                (void)hipGetLastError();
+                return RP_ERR_HIP;
+            }
+            it = t.blocks.try_emplace(std::make_pair(dev, st)).first;   // (map nodes do not move: the mutex stays where it is)
+            it->second.p = p;
         }
-        it = t.blocks.emplace(std::make_pair(dev, st), Block{p, 0u}).first;
+        b = &it->second;
     }
-    *out = it->second.p;
-    if (serial) *serial = it->second.calls++;   // (the stream's n-th launch with a copied argument block: rotating slots)
+    b->seq.lock();   // held until rp_resident_end / rp_resident_release
+    *out = b->p;
+    if (serial) *serial = b->calls++;   // (the stream's n-th launch with a copied argument block: rotating slots)
     return RP_OK;
 }
 // the stream's scratch (granules, failure word, roster), zeroed in stream order: a tag is never 0
@@ -570,7 +596,10 @@ inline int rp_resident_begin(int n, hipStream_t st, rp_resident_ctl* C, void** w
     *ws = nullptr;
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT_TEST_FAULT"); e && e[0] == '2') return RP_ERR_HIP;   // (test seam: no scratch)
     if (rp_resident_scratch(st, bytes, ws) != RP_OK) return RP_ERR_HIP;
-    if (hipMemsetAsync(*ws, 0, bytes, st) != hipSuccess) return RP_ERR_HIP;
+    if (hipMemsetAsync(*ws, 0, bytes, st) != hipSuccess) {
+        rp_resident_release(st);
+        return RP_ERR_HIP;
+    }
     C->gran[0] = static_cast<unsigned long long*>(*ws);
     C->gran[1] = C->gran[0] + n;
     C->fail = reinterpret_cast<int*>(C->gran[1] + n);
@@ -603,7 +632,10 @@ inline int rp_resident_begin_streams(int streams, int cap, int need_blocks, size
     *ws = nullptr;
     if (const char* e = getenv("RECTIPY_AMD_RESIDENT_TEST_FAULT"); e && e[0] == '2') return RP_ERR_HIP;   // (test seam: no scratch)
     if (rp_resident_scratch(st, bytes, ws, &serial) != RP_OK) return RP_ERR_HIP;
-    if (hipMemsetAsync(*ws, 0, gran_bytes + 64, st) != hipSuccess) return RP_ERR_HIP;
+    if (hipMemsetAsync(*ws, 0, gran_bytes + 64, st) != hipSuccess) {
+        rp_resident_release(st);
+        return RP_ERR_HIP;
+    }
     C->gran[0] = static_cast<unsigned long long*>(*ws);
     C->gran[1] = nullptr;
     C->fail = reinterpret_cast<int*>(static_cast<char*>(*ws) + gran_bytes);
@@ -638,8 +670,8 @@ inline int rp_resident_poll() {   // a resident launch that timed out since the 
 inline int rp_resident_end(const rp_resident_ctl& C, void* ws, hipStream_t st, const char* what) {
     (void)C;
     (void)ws;
-    (void)st;
     const hipError_t launched = hipGetLastError();
+    rp_resident_release(st);
     if (launched != hipSuccess) RP_FAIL(RP_ERR_HIP, "%s: %s", what, hipGetErrorString(launched));
     return RP_OK;
 }

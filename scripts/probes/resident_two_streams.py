@@ -1,5 +1,9 @@
-"""Two host threads, each on its own stream, issuing resident launches at the same time (different populations): results against a
-launch per step, and no timeout."""
+"""Two host threads, each on its own stream -- or, with `same` as the second argument, both on ONE stream (the default stream is
+every thread's unless it chooses another) --, issuing resident launches at the same time (different populations): results against a
+launch per step, and no timeout.
+
+    python scripts/probes/resident_two_streams.py [seconds] [same]
+"""
 import os
 import sys
 import threading
@@ -13,6 +17,7 @@ from rectipy_amd.engine import Population, default_backend  # noqa: E402
 
 dev = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+shared = torch.cuda.Stream(device=dev) if len(sys.argv) > 2 and sys.argv[2] == "same" else None
 errors = []
 
 
@@ -34,7 +39,7 @@ def reference(n, seed, T, calls, x):
 
 
 def worker(n, seed, T, calls, x, want, t_end):
-    stream = torch.cuda.Stream(device=dev)
+    stream = shared if shared is not None else torch.cuda.Stream(device=dev)
     rounds = 0
     with torch.cuda.stream(stream):
         while time.time() < t_end and not errors:
@@ -62,5 +67,5 @@ for th in threads:
     th.join()
 torch.cuda.synchronize()
 default_backend().async_status()
-print("two streams:", "FAILED " + "; ".join(errors) if errors else "ok, no timeout reported", flush=True)
+print("one stream, two threads:" if shared is not None else "two streams:", "FAILED " + "; ".join(errors) if errors else "ok, no timeout reported", flush=True)
 sys.exit(1 if errors else 0)
